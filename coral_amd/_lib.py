@@ -1,0 +1,158 @@
+"""ctypes binding of libcoral_amd.so (the C ABI declared in include/coral_amd.h).
+
+There is no CPU fallback: importing this module without the built library raises, and
+every wrapper raises `CoralAmdError` when a kernel call reports a failure.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "libcoral_amd.so"
+
+
+class CoralAmdError(RuntimeError):
+    """Raised when the HIP library is missing or a call into it fails."""
+
+
+class CaGemmDesc(C.Structure):
+    """Mirror of `CaGemmDesc` in include/coral_amd.h."""
+
+    _fields_ = [
+        ("A", C.c_void_p),
+        ("B", C.c_void_p),
+        ("C", C.c_void_p),
+        ("C2", C.c_void_p),
+        ("R", C.c_void_p),
+        ("bias", C.c_void_p),
+        ("M", C.c_int32),
+        ("N", C.c_int32),
+        ("K", C.c_int32),
+        ("a_layout", C.c_int32),
+        ("b_layout", C.c_int32),
+        ("lda", C.c_int64),
+        ("ldb", C.c_int64),
+        ("ldc", C.c_int64),
+        ("ldr", C.c_int64),
+        ("a_kseg", C.c_int32),
+        ("b_kseg", C.c_int32),
+        ("a_kseg_stride", C.c_int64),
+        ("b_kseg_stride", C.c_int64),
+        ("batch1", C.c_int32),
+        ("batch2", C.c_int32),
+        ("sA1", C.c_int64),
+        ("sA2", C.c_int64),
+        ("sB1", C.c_int64),
+        ("sB2", C.c_int64),
+        ("sC1", C.c_int64),
+        ("sC2", C.c_int64),
+        ("sR1", C.c_int64),
+        ("sR2", C.c_int64),
+        ("epilogue", C.c_int32),
+        ("out_f32", C.c_int32),
+        ("accumulate", C.c_int32),
+        ("alpha", C.c_float),
+        ("dropout_p", C.c_float),
+        ("dropout_seed", C.c_uint64),
+    ]
+
+
+KMAJOR, MNMAJOR = 0, 1
+EPI_NONE, EPI_GELU, EPI_RESIDUAL, EPI_DGELU = 0, 1, 2, 3
+
+_vp, _i32, _i64, _f32, _u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint64
+
+# name -> (restype, argtypes); must list every symbol include/coral_amd.h declares.
+SIGNATURES = {
+    "ca_version": (C.c_int, []),
+    "ca_last_error": (C.c_char_p, []),
+    "ca_device_count": (C.c_int, []),
+    "ca_gemm_bf16": (C.c_int, [C.POINTER(CaGemmDesc), _vp]),
+    "ca_layernorm_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _i32, _vp]),
+    "ca_layernorm_bwd_partial_floats": (_i64, [_i64, _i32]),
+    "ca_layernorm_bwd": (
+        C.c_int,
+        [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp],
+    ),
+    "ca_colsum_partial_floats": (_i64, [_i64, _i32]),
+    "ca_colsum_bf16": (C.c_int, [_vp, _i64, _i64, _i32, _vp, _i32, _vp, _vp]),
+    "ca_wave_normalize": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _f32, _vp]),
+    "ca_conv0_ln_gelu_fwd": (
+        C.c_int,
+        [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _i32, _f32, _vp],
+    ),
+    "ca_conv0_bwd_partial_floats": (_i64, [_i32, _i64, _i32, _i32, _i32]),
+    "ca_conv0_ln_gelu_bwd": (
+        C.c_int,
+        [_vp] * 11 + [_i32, _i64, _i32, _i32, _i32, _f32, _vp],
+    ),
+    "ca_col2im_1d": (C.c_int, [_vp, _vp, _i32, _i64, _i64, _i32, _i32, _i32, _vp]),
+    "ca_softmax_fwd": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i64, _i32, _vp]),
+    "ca_softmax_bwd": (C.c_int, [_vp, _vp, _vp, _f32, _i32, _i32, _i32, _i64, _vp]),
+    "ca_ctc_workspace_bytes": (_i64, [_i32, _i32, _i32]),
+    "ca_ctc_loss_fwd_bwd": (
+        C.c_int,
+        [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _i32, _i32, _i32, _vp],
+    ),
+    "ca_ctc_greedy_decode": (
+        C.c_int,
+        [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _i32, _vp],
+    ),
+    "ca_mask_frames": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "ca_regroup_pad": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "ca_posconv_weight": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "ca_posconv_weight_bwd": (
+        C.c_int,
+        [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp],
+    ),
+    "ca_cast_f32_bf16": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "ca_cast_bf16_f32": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "ca_transpose_f32_bf16": (C.c_int, [_vp, _vp, _i32, _i32, _vp]),
+    "ca_conv_weight_reorder": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
+    "ca_conv_weight_grad_reorder": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
+    "ca_sumsq_f32": (C.c_int, [_vp, _i64, _vp, _i32, _vp, _vp]),
+    "ca_adamw_step": (
+        C.c_int,
+        [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i32, _f32, _f32, _vp, _vp],
+    ),
+    "ca_logmel_workspace_bytes": (_i64, [_i32]),
+    "ca_logmel": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i64, _i32, _vp]),
+    "ca_cross_entropy_fwd_bwd": (
+        C.c_int,
+        [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i64, _i32, _vp],
+    ),
+    "ca_argmax_masked": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i64, _vp]),
+    "ca_embed_tokens": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libcoral_amd.so (once) and attach prototypes. Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = Path(os.environ.get("CORAL_AMD_LIB", LIB_PATH))
+    if not path.exists():
+        raise CoralAmdError(
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (or `make -C coral_amd/csrc`). There is no CPU fallback."
+        )
+    lib = C.CDLL(str(path))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing: loud by design
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    """Raise CoralAmdError with the library's message if `rc` is not CA_OK."""
+    if rc != 0:
+        msg = load().ca_last_error()
+        raise CoralAmdError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")

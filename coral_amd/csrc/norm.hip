@@ -1,0 +1,325 @@
+// LayerNorm (+ optional exact GELU) forward/backward and column sums.  HBM-bound kernels:
+// one 64-lane wave per row, 16-byte bf16 vector loads, fp32 statistics via wave shuffles.
+// Reference: nn.LayerNorm call sites in $TF/models/wav2vec2/modeling_wav2vec2.py:291-298
+// (conv block LN + GELU), :429-434, :611-654, :791.
+#include "common.h"
+
+#define LN_MAXCH 8  // up to 8 chunks of 8 elements per lane -> C <= 4096
+
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const unsigned short* __restrict__ x,
+                                                     const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta,
+                                                     unsigned short* __restrict__ y,
+                                                     float* __restrict__ stats, int64_t rows,
+                                                     int C, float eps, int act) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int nchunk = C >> 3;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+    const unsigned short* xr = x + row * C;
+    float v[NCH][8];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int ch = lane + c * 64;
+      if (ch < nchunk) {
+        const u16x8_t u = *(const u16x8_t*)(xr + ch * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          v[c][e] = bf2f(u[e]);
+          s += v[c][e];
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[c][e] = 0.f;
+      }
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int ch = lane + c * 64;
+      if (ch < nchunk) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float dlt = v[c][e] - mean;
+          s2 += dlt * dlt;
+        }
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(s2) / (float)C + eps);
+    if (lane == 0 && stats) {
+      stats[row * 2] = mean;
+      stats[row * 2 + 1] = rstd;
+    }
+    unsigned short* yr = y + row * C;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int ch = lane + c * 64;
+      if (ch < nchunk) {
+        const f32x4_t g0 = *(const f32x4_t*)(gamma + ch * 8);
+        const f32x4_t g1 = *(const f32x4_t*)(gamma + ch * 8 + 4);
+        const f32x4_t b0 = *(const f32x4_t*)(beta + ch * 8);
+        const f32x4_t b1 = *(const f32x4_t*)(beta + ch * 8 + 4);
+        u16x8_t o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float gm = e < 4 ? g0[e] : g1[e - 4];
+          const float bt = e < 4 ? b0[e] : b1[e - 4];
+          float u = (v[c][e] - mean) * rstd * gm + bt;
+          if (act) u = gelu_erf(u);
+          o[e] = f2bf(u);
+        }
+        *(u16x8_t*)(yr + ch * 8) = o;
+      }
+    }
+  }
+}
+
+static int ln_grid(int64_t rows) {
+  int64_t g = (rows + 3) / 4;
+  if (g > 4096) g = 4096;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+extern "C" int ca_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y,
+                                float* stats, int64_t rows, int32_t C, float eps, int32_t act,
+                                void* stream) {
+  CA_CHECK_ARG(x && gamma && beta && y, "ca_layernorm_fwd: null pointer");
+  CA_CHECK_ARG(rows > 0 && C > 0 && (C % 8) == 0 && C <= LN_MAXCH * 512,
+               "ca_layernorm_fwd: C=%d must be a multiple of 8 and <= %d", C, LN_MAXCH * 512);
+  const int nch = (C / 8 + 63) / 64;
+  dim3 grid(ln_grid(rows)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+#define LN_FWD(N)                                                                            \
+  hipLaunchKernelGGL((ln_fwd_kernel<N>), grid, block, 0, s, (const unsigned short*)x, gamma, \
+                     beta, (unsigned short*)y, stats, rows, C, eps, act)
+  switch (nch) {
+    case 1: LN_FWD(1); break;
+    case 2: LN_FWD(2); break;
+    case 3: LN_FWD(3); break;
+    case 4: LN_FWD(4); break;
+    default: LN_FWD(8); break;
+  }
+#undef LN_FWD
+  CA_CHECK_LAUNCH("ca_layernorm_fwd");
+  return CA_OK;
+}
+
+// ---- backward ------------------------------------------------------------------------------
+// partial layout: [grid][2][C] (dgamma partials then dbeta partials per block).
+#define LN_BWD_GRID_MAX 1024
+static int ln_bwd_grid(int64_t rows) {
+  int64_t g = (rows + 3) / 4;
+  if (g > LN_BWD_GRID_MAX) g = LN_BWD_GRID_MAX;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(
+    const unsigned short* __restrict__ dy, const unsigned short* __restrict__ x,
+    const float* __restrict__ gamma, const float* __restrict__ beta,
+    const float* __restrict__ stats, unsigned short* __restrict__ dx,
+    float* __restrict__ partial, int64_t rows, int C, int act) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* red = (float*)smem_raw;  // [4 waves][2][C]
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int nchunk = C >> 3;
+  float dg[NCH][8], db[NCH][8];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dg[c][e] = db[c][e] = 0.f;
+
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+    const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
+    const unsigned short* xr = x + row * C;
+    const unsigned short* dyr = dy + row * C;
+    float xh[NCH][8], dxh[NCH][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int ch = lane + c * 64;
+      if (ch < nchunk) {
+        const u16x8_t ux = *(const u16x8_t*)(xr + ch * 8);
+        const u16x8_t ud = *(const u16x8_t*)(dyr + ch * 8);
+        const f32x4_t g0 = *(const f32x4_t*)(gamma + ch * 8);
+        const f32x4_t g1 = *(const f32x4_t*)(gamma + ch * 8 + 4);
+        f32x4_t b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
+        if (act) {
+          b0 = *(const f32x4_t*)(beta + ch * 8);
+          b1 = *(const f32x4_t*)(beta + ch * 8 + 4);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float gm = e < 4 ? g0[e] : g1[e - 4];
+          const float h = (bf2f(ux[e]) - mean) * rstd;
+          float du = bf2f(ud[e]);
+          if (act) {
+            const float bt = e < 4 ? b0[e] : b1[e - 4];
+            du *= dgelu_erf(h * gm + bt);
+          }
+          dg[c][e] += du * h;
+          db[c][e] += du;
+          const float d = du * gm;
+          xh[c][e] = h;
+          dxh[c][e] = d;
+          s1 += d;
+          s2 += d * h;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xh[c][e] = dxh[c][e] = 0.f;
+      }
+    }
+    const float m1 = wave_sum(s1) / (float)C;
+    const float m2 = wave_sum(s2) / (float)C;
+    unsigned short* dxr = dx + row * C;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int ch = lane + c * 64;
+      if (ch < nchunk) {
+        u16x8_t o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = f2bf(rstd * (dxh[c][e] - m1 - xh[c][e] * m2));
+        *(u16x8_t*)(dxr + ch * 8) = o;
+      }
+    }
+  }
+  // block reduction of the parameter gradients over the 4 waves
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int ch = lane + c * 64;
+    if (ch < nchunk) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        red[(wave * 2 + 0) * C + ch * 8 + e] = dg[c][e];
+        red[(wave * 2 + 1) * C + ch * 8 + e] = db[c][e];
+      }
+    }
+  }
+  __syncthreads();
+  float* pout = partial + (int64_t)blockIdx.x * 2 * C;
+  for (int i = threadIdx.x; i < 2 * C; i += 256) {
+    const int which = i / C, ch = i % C;
+    float a = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) a += red[(w * 2 + which) * C + ch];
+    pout[i] = a;
+  }
+}
+
+// out[i] (+)= sum_p partial[p*stride + i], i < n
+__global__ void reduce_partials_kernel(const float* __restrict__ partial, int nparts,
+                                       int64_t stride, int n, float* __restrict__ out,
+                                       int accumulate) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float a = 0.f;
+  for (int p = 0; p < nparts; ++p) a += partial[(int64_t)p * stride + i];
+  out[i] = accumulate ? out[i] + a : a;
+}
+
+extern "C" int64_t ca_layernorm_bwd_partial_floats(int64_t rows, int32_t C) {
+  return (int64_t)ln_bwd_grid(rows) * 2 * C;
+}
+
+extern "C" int ca_layernorm_bwd(const void* dy, const void* x, const float* gamma,
+                                const float* beta, const float* stats, void* dx, float* dgamma,
+                                float* dbeta, float* partial, int64_t rows, int32_t C,
+                                int32_t act, void* stream) {
+  CA_CHECK_ARG(dy && x && gamma && stats && dx && partial, "ca_layernorm_bwd: null pointer");
+  CA_CHECK_ARG(!act || beta, "ca_layernorm_bwd: act needs beta");
+  CA_CHECK_ARG(rows > 0 && C > 0 && (C % 8) == 0 && C <= LN_MAXCH * 512,
+               "ca_layernorm_bwd: bad C=%d", C);
+  const int nch = (C / 8 + 63) / 64;
+  const int g = ln_bwd_grid(rows);
+  dim3 grid(g), block(256);
+  const size_t lds = (size_t)4 * 2 * C * sizeof(float);
+  hipStream_t s = (hipStream_t)stream;
+#define LN_BWD(N)                                                                         \
+  hipLaunchKernelGGL((ln_bwd_kernel<N>), grid, block, lds, s, (const unsigned short*)dy,  \
+                     (const unsigned short*)x, gamma, beta, stats, (unsigned short*)dx,   \
+                     partial, rows, C, act)
+  switch (nch) {
+    case 1: LN_BWD(1); break;
+    case 2: LN_BWD(2); break;
+    case 3: LN_BWD(3); break;
+    case 4: LN_BWD(4); break;
+    default: LN_BWD(8); break;
+  }
+#undef LN_BWD
+  CA_CHECK_LAUNCH("ca_layernorm_bwd");
+  if (dgamma)
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((C + 255) / 256), dim3(256), 0, s, partial, g,
+                       (int64_t)2 * C, C, dgamma, 1);
+  if (dbeta)
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((C + 255) / 256), dim3(256), 0, s,
+                       partial + C, g, (int64_t)2 * C, C, dbeta, 1);
+  CA_CHECK_LAUNCH("ca_layernorm_bwd(reduce)");
+  return CA_OK;
+}
+
+// ---- column sums (bias gradients) ---------------------------------------------------------
+// block = 32 column-chunks (256 columns) x 8 row lanes; grid.y slabs of rows.
+#define CS_SLAB_MAX 256
+static int cs_slabs(int64_t rows) {
+  int64_t s = (rows + 63) / 64;
+  if (s > CS_SLAB_MAX) s = CS_SLAB_MAX;
+  if (s < 1) s = 1;
+  return (int)s;
+}
+__global__ __launch_bounds__(256) void colsum_kernel(const unsigned short* __restrict__ x,
+                                                     int64_t ld, int64_t rows, int N,
+                                                     float* __restrict__ partial) {
+  __shared__ float red[8][256 + 8];
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int col = (blockIdx.x * 32 + cl) * 8;
+  const int nslab = gridDim.y;
+  const int64_t per = (rows + nslab - 1) / nslab;
+  const int64_t r0 = (int64_t)blockIdx.y * per;
+  int64_t r1 = r0 + per;
+  if (r1 > rows) r1 = rows;
+  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (col < N) {
+    for (int64_t r = r0 + rl; r < r1; r += 8) {
+      const u16x8_t u = *(const u16x8_t*)(x + r * ld + col);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[e] += bf2f(u[e]);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[rl][cl * 8 + e] = a[e];
+  __syncthreads();
+  const int c = threadIdx.x;
+  const int gc = blockIdx.x * 256 + c;
+  if (gc < N) {
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) t += red[r][c];
+    partial[(int64_t)blockIdx.y * N + gc] = t;
+  }
+}
+
+extern "C" int64_t ca_colsum_partial_floats(int64_t rows, int32_t N) {
+  return (int64_t)cs_slabs(rows) * N;
+}
+
+extern "C" int ca_colsum_bf16(const void* x, int64_t ld, int64_t rows, int32_t N, float* out,
+                              int32_t accumulate, float* partial, void* stream) {
+  CA_CHECK_ARG(x && out && partial, "ca_colsum_bf16: null pointer");
+  CA_CHECK_ARG(rows > 0 && N > 0 && (N % 8) == 0 && (ld % 8) == 0,
+               "ca_colsum_bf16: N and ld must be multiples of 8");
+  const int ns = cs_slabs(rows);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(colsum_kernel, dim3((N + 255) / 256, ns), dim3(256), 0, s,
+                     (const unsigned short*)x, ld, rows, N, partial);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((N + 255) / 256), dim3(256), 0, s, partial, ns,
+                     (int64_t)N, N, out, accumulate);
+  CA_CHECK_LAUNCH("ca_colsum_bf16");
+  return CA_OK;
+}

@@ -1,0 +1,260 @@
+/*
+ * coral_amd.h — C ABI of libcoral_amd.so, the MI355X (gfx950) hot path behind CoRal's
+ * ModelSetup boundary.
+ *
+ * The reference (alexandrainst/coral) has no FFI of its own: everything below the
+ * ModelSetup ABC (R/src/coral/data_models.py:44-82) runs inside HuggingFace Transformers
+ * + torch ATen.  Each entry point here therefore cites the *library* call it replaces
+ * ($TF = transformers/, line numbers for v5.15.0) and the CoRal line that causes the call.
+ *
+ * Conventions (all entry points):
+ *   - plain pointers are DEVICE pointers unless the name ends in _h;
+ *   - `stream` is a hipStream_t passed as void*; kernels are enqueued, never synchronised;
+ *   - no allocation, no ownership transfer: the caller allocates outputs and workspaces;
+ *   - return 0 on success, negative CA_ERR_* on failure; ca_last_error() gives the text;
+ *   - activations are row-major "channels-last" [rows, channels] bf16 unless stated;
+ *   - no CPU fallback exists in this library.
+ */
+#ifndef CORAL_AMD_H
+#define CORAL_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CA_OK 0
+#define CA_ERR_ARG (-1)
+#define CA_ERR_LAUNCH (-2)
+#define CA_ERR_UNSUPPORTED (-3)
+
+/* library / diagnostics */
+int ca_version(void);
+const char* ca_last_error(void);
+/* number of HIP devices visible (does not initialise a context beyond the count) */
+int ca_device_count(void);
+
+/* ------------------------------------------------------------------------------------
+ * GEMM family (MFMA bf16, fp32 accumulate).  Replaces every nn.Linear / Conv1d-as-GEMM /
+ * attention matmul on the path:
+ *   $TF/models/wav2vec2/modeling_wav2vec2.py:495-498,546 (q,k,v,o)  :565-572 (FFN)
+ *   :429-434 (feature projection) :282-299 (conv layers 1..6, as implicit GEMM)
+ *   :326-368 (positional conv, grouped implicit GEMM) :1700 (lm_head)
+ *   $TF/models/whisper/modeling_whisper.py:284-356,379-413,448-505 (encoder/decoder)
+ *
+ *   C[m,n] = epilogue( alpha * sum_k opA(m,k) * opB(n,k) )
+ *
+ * Operand layouts (bf16):
+ *   CA_KMAJOR  : element (m,k) at  A[m*lda + k]   (reduction index contiguous)
+ *   CA_MNMAJOR : element (m,k) at  A[row(k) + m]  (output index contiguous);
+ *                row(k) = k*lda, or with kseg>0: (k / kseg)*kseg_stride + (k % kseg)*lda,
+ *                which lets a reduction run over (batch, time) of a strided/overlapping
+ *                window view (conv weight-gradients) without materialising im2col.
+ * Overlapping rows are legal (lda smaller than the row length): a channels-last Conv1d
+ * with stride s is exactly a KMAJOR GEMM with lda = s*C_in and K = k*C_in.
+ * Constraints: all leading dimensions and offsets multiples of 8 elements (16 bytes);
+ * KMAJOR operands must be readable (and zero) up to K rounded up to 8.
+ * Batch: blockIdx.z = z1*batch2 + z2, pointer offsets z1*s?1 + z2*s?2 (elements).
+ * ---------------------------------------------------------------------------------- */
+#define CA_KMAJOR 0
+#define CA_MNMAJOR 1
+
+#define CA_EPI_NONE 0      /* C = v                         (v = alpha*acc + bias)      */
+#define CA_EPI_GELU 1      /* C = v (pre-activation, may be NULL), C2 = gelu_erf(v)     */
+#define CA_EPI_RESIDUAL 2  /* C = v + R                                                 */
+#define CA_EPI_DGELU 3     /* C = v * gelu_erf'(R)          (R = saved pre-activation)  */
+
+typedef struct CaGemmDesc {
+  const void* A;
+  const void* B;
+  void* C;
+  void* C2;          /* second output for CA_EPI_GELU (bf16), else NULL */
+  const void* R;     /* bf16 side input for RESIDUAL / DGELU, else NULL */
+  const float* bias; /* [N] fp32 or NULL */
+  int32_t M, N, K;
+  int32_t a_layout, b_layout;
+  int64_t lda, ldb, ldc, ldr;
+  int32_t a_kseg, b_kseg;
+  int64_t a_kseg_stride, b_kseg_stride;
+  int32_t batch1, batch2;
+  int64_t sA1, sA2, sB1, sB2, sC1, sC2, sR1, sR2;
+  int32_t epilogue;
+  int32_t out_f32;    /* 0: C is bf16; 1: C is fp32 */
+  int32_t accumulate; /* 1: C += result (read-modify-write) */
+  float alpha;
+  /* activation dropout fused into CA_EPI_GELU / CA_EPI_DGELU
+   * ($TF/models/wav2vec2/modeling_wav2vec2.py:556,567; R/config/model/wav2vec2-large.yaml:12):
+   * keep-mask = hash(seed, m*N+n) >= p; kept values scaled by 1/(1-p). p = 0 disables. */
+  float dropout_p;
+  uint64_t dropout_seed;
+} CaGemmDesc;
+
+int ca_gemm_bf16(const CaGemmDesc* desc, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * LayerNorm over the channel axis.  $TF/models/wav2vec2/modeling_wav2vec2.py:429-434,
+ * :611-654,:791 (nn.LayerNorm, eps 1e-5); whisper :379-413.
+ * x,y bf16 [rows, C]; gamma,beta fp32 [C]; stats fp32 [rows,2] = (mean, rstd) saved for bwd.
+ * act: 0 none, 1 exact-erf GELU applied after the affine (conv-block form, :291-298).
+ * ---------------------------------------------------------------------------------- */
+int ca_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y,
+                     float* stats, int64_t rows, int32_t C, float eps, int32_t act,
+                     void* stream);
+/* dx bf16 [rows,C]; dgamma/dbeta fp32 [C] are ACCUMULATED into (+=) through the fp32
+ * partial buffer `partial` of ca_layernorm_bwd_partial_floats(rows, C) floats. */
+int64_t ca_layernorm_bwd_partial_floats(int64_t rows, int32_t C);
+int ca_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* beta,
+                     const float* stats, void* dx, float* dgamma, float* dbeta,
+                     float* partial, int64_t rows, int32_t C, int32_t act, void* stream);
+
+/* column sums: out[n] (+)= sum_m x[m*ld + n]  (bias gradients). x bf16, out fp32.
+ * partial: fp32 workspace of ca_colsum_partial_floats(rows, N) floats. */
+int64_t ca_colsum_partial_floats(int64_t rows, int32_t N);
+int ca_colsum_bf16(const void* x, int64_t ld, int64_t rows, int32_t N, float* out,
+                   int32_t accumulate, float* partial, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Waveform front end.
+ * ca_wave_normalize: zero-mean / unit-variance over the valid samples of each utterance,
+ *   padding -> 0.  $TF/models/wav2vec2/feature_extraction_wav2vec2.py:77-97 (called from
+ *   R/src/coral/data.py:747).  x,y fp32 [B,N]; lengths int32 [B].
+ * ca_conv0_*: feature-encoder layer 0 — Conv1d(1,C,k,stride,bias) + LayerNorm(C) + GELU
+ *   fused ($TF/models/wav2vec2/modeling_wav2vec2.py:275-299 with layer_id 0).
+ *   x fp32 [B,N] -> y bf16 [B,T0,C], T0 = (N-k)/stride+1.  w fp32 [C,k].
+ *   The backward recomputes the conv from x (10 MACs/channel) instead of saving it.
+ * ---------------------------------------------------------------------------------- */
+int ca_wave_normalize(const float* x, const int32_t* lengths, float* y, int32_t B,
+                      int64_t N, float eps, void* stream);
+int ca_conv0_ln_gelu_fwd(const float* x, const float* w, const float* bias,
+                         const float* gamma, const float* beta, void* y, int32_t B,
+                         int64_t N, int32_t C, int32_t k, int32_t stride, float eps,
+                         void* stream);
+int64_t ca_conv0_bwd_partial_floats(int32_t B, int64_t N, int32_t C, int32_t k,
+                                    int32_t stride);
+int ca_conv0_ln_gelu_bwd(const float* x, const float* w, const float* bias,
+                         const float* gamma, const float* beta, const void* dy, float* dw,
+                         float* dbias, float* dgamma, float* dbeta, float* partial,
+                         int32_t B, int64_t N, int32_t C, int32_t k, int32_t stride,
+                         float eps, void* stream);
+
+/* col2im for a strided channels-last Conv1d data-gradient:
+ * dx[b,p,c] = sum_{j, t*stride+j==p} dcol[b,t,j*C+c].  dcol bf16 [B,T,k*C] (output of the
+ * dgrad GEMM), dx bf16 [B,L,C]. */
+int ca_col2im_1d(const void* dcol, void* dx, int32_t B, int64_t T, int64_t L, int32_t C,
+                 int32_t k, int32_t stride, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Attention softmax (the middle of SDPA, $TF/models/wav2vec2/modeling_wav2vec2.py:438-463,
+ * $TF/models/whisper/modeling_whisper.py:215-238).  scores fp32 [BH, Tq, ld] (alpha already
+ * applied by the GEMM), key padding by klen[b] (b = bh / H), optional causal mask;
+ * probs bf16 [BH, Tq, ld] with columns >= Tk written as zero (so it can feed a KMAJOR GEMM).
+ * bwd: ds = p * (dp - sum_j dp_j p_j) * scale, bf16, zero padded.
+ * ---------------------------------------------------------------------------------- */
+int ca_softmax_fwd(const float* scores, void* probs, const int32_t* klen, int32_t BH,
+                   int32_t H, int32_t Tq, int32_t Tk, int64_t ld, int32_t causal,
+                   void* stream);
+int ca_softmax_bwd(const float* dprobs, const void* probs, void* dscores, float scale,
+                   int32_t BH, int32_t Tq, int32_t Tk, int64_t ld, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * CTC head: log_softmax(fp32) + CTC loss (+ gradient wrt logits) + greedy decode.
+ *   $TF/models/wav2vec2/modeling_wav2vec2.py:1705-1728 (F.ctc_loss, blank = pad id,
+ *   zero_infinity) ← R/src/coral/wav2vec2.py:120,125; greedy: R/src/coral/compute_metrics.py:68-69
+ *   + $TF/models/wav2vec2/tokenization_wav2vec2.py:311-323 (collapse repeats, drop blank).
+ * logits fp32 [B,T,ldv] (first V columns valid); labels int32 [B,Lmax] (-100 padded);
+ * in_len int32 [B] frames; nll fp32 [B] per-utterance loss (0 where infeasible and
+ * zero_infinity); grad fp32 [B,T,ldv] = d(sum_b nll_b * gscale[b])/dlogits
+ * (gscale NULL = 1).  ws: ca_ctc_workspace_bytes(B,T,Lmax) bytes.
+ * ---------------------------------------------------------------------------------- */
+int64_t ca_ctc_workspace_bytes(int32_t B, int32_t T, int32_t Lmax);
+int ca_ctc_loss_fwd_bwd(const float* logits, const int32_t* labels, const int32_t* in_len,
+                        float* nll, float* grad, const float* gscale, void* ws, int32_t B,
+                        int32_t T, int32_t V, int64_t ldv, int32_t Lmax, int32_t blank,
+                        int32_t zero_infinity, void* stream);
+/* ids int32 [B,T] (collapsed ids, -1 padded), out_len int32 [B]; raw int32 [B,T] argmax. */
+int ca_ctc_greedy_decode(const float* logits, const int32_t* in_len, int32_t* raw,
+                         int32_t* ids, int32_t* out_len, int32_t B, int32_t T, int32_t V,
+                         int64_t ldv, int32_t blank, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Small elementwise pieces of the wav2vec2 encoder.
+ * ca_mask_frames: SpecAugment + padding ($TF/.../modeling_wav2vec2.py:1272-1316, 752-755):
+ *   h[b,t,:] = embed where tmask[b,t]; h[b,t,c] = 0 where fmask[b,c]; h[b,t,:] = 0 for
+ *   t >= flen[b].  tmask/fmask uint8 (NULL = none), embed bf16 [C].
+ * ca_regroup_pad: x [B,T,G*Cg] -> xg [B,G,T+2*pad,Cg] with zero time padding (layout for
+ *   the grouped positional conv as an overlapping-row GEMM, :326-368).
+ * ca_posconv_weight: weight-norm (dim=2) + reorder for the implicit GEMMs:
+ *   w = g * v / ||v||_(0,1);  wf[g][co][j][ci] = w[g*Cg+co, ci, j]  (forward)
+ *   wb[g][ci][j][co] = w[g*Cg+co, ci, K-1-j]                        (data gradient)
+ *   v fp32 [d, Cg, K], g fp32 [K]; norm fp32 [K] saved.
+ * ca_posconv_weight_bwd: dwf fp32 [G][Cg][K][Cg] -> dv, dg (+=).
+ * ---------------------------------------------------------------------------------- */
+int ca_mask_frames(void* h, const uint8_t* tmask, const uint8_t* fmask, const void* embed,
+                   const int32_t* flen, int32_t B, int32_t T, int32_t C, void* stream);
+int ca_regroup_pad(const void* x, void* xg, int32_t B, int32_t T, int32_t G, int32_t Cg,
+                   int32_t pad, void* stream);
+int ca_posconv_weight(const float* v, const float* g, void* wf, void* wb, float* norm,
+                      int32_t d, int32_t Cg, int32_t K, void* stream);
+int ca_posconv_weight_bwd(const float* dwf, const float* v, const float* g,
+                          const float* norm, float* dv, float* dg, int32_t d, int32_t Cg,
+                          int32_t K, void* stream);
+
+/* casts / transposes used when refreshing bf16 compute copies from fp32 masters */
+int ca_cast_f32_bf16(const float* x, void* y, int64_t n, void* stream);
+int ca_cast_bf16_f32(const void* x, float* y, int64_t n, void* stream);
+/* y[c*rows + r] = x[r*cols + c] with cast; x fp32 [rows, cols] -> y bf16 [cols, rows] */
+int ca_transpose_f32_bf16(const float* x, void* y, int32_t rows, int32_t cols, void* stream);
+/* conv weight reorder: w fp32 [Co,Ci,k] -> wr bf16 [Co][k][Ci] */
+int ca_conv_weight_reorder(const float* w, void* wr, int32_t Co, int32_t Ci, int32_t k,
+                           void* stream);
+/* inverse for the gradient: dwr fp32 [Co][k][Ci] -> dw fp32 [Co,Ci,k] (+=) */
+int ca_conv_weight_grad_reorder(const float* dwr, float* dw, int32_t Co, int32_t Ci,
+                                int32_t k, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Optimiser step.  $TF/trainer.py:1778-1796 (clip_grad_norm_ 1.0, AdamW β=(0.9,0.98))
+ * ← R/src/coral/wav2vec2.py:216-240, R/config/asr_finetuning.yaml:64-75.
+ * Flat fp32 buffers.  ca_sumsq: out[0] (+)= sum g^2 (partial: >= 4096 floats).
+ * ca_adamw_step: reads *gnorm_sq (device), clip = min(1, max_norm/(sqrt+1e-6)); updates
+ * p,m,v in place and writes the bf16 compute copy p16 (may be NULL). grad_scale multiplies
+ * the gradient first (1/world for DDP-mean semantics).
+ * ---------------------------------------------------------------------------------- */
+int ca_sumsq_f32(const float* g, int64_t n, float* out, int32_t accumulate, float* partial,
+                 void* stream);
+int ca_adamw_step(float* p, float* m, float* v, const float* g, void* p16, int64_t n,
+                  float lr, float beta1, float beta2, float eps, float weight_decay,
+                  int32_t step, float grad_scale, float max_norm, const float* gnorm_sq,
+                  void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Whisper log-mel front end.  $TF/models/whisper/feature_extraction_whisper.py:135-168
+ * (torch.stft n_fft 400 hop 160 hann, reflect pad, |.|^2 of frames[:-1], mel, log10 clamp
+ * 1e-10, max-8 floor, (x+4)/4) ← R/src/coral/whisper.py:51-55, R/src/coral/data.py:747.
+ * wave fp32 [B,N] (already padded/truncated to N = 480000), mel_filters fp32 [201,n_mels],
+ * out fp32 [B,n_mels,frames], frames = N/160.  ws: ca_logmel_workspace_bytes(B).
+ * ---------------------------------------------------------------------------------- */
+int64_t ca_logmel_workspace_bytes(int32_t B);
+int ca_logmel(const float* wave, const float* mel_filters, float* out, void* ws, int32_t B,
+              int64_t N, int32_t n_mels, void* stream);
+
+/* cross-entropy over the vocabulary with ignore_index (-100), fp32 logits [rows, ldv]:
+ * $TF/models/whisper/modeling_whisper.py:1084-1087.  loss_sum fp32[1] += sum nll,
+ * count int32[1] += #valid; grad fp32 [rows, ldv] = (softmax - onehot) (unscaled). */
+int ca_cross_entropy_fwd_bwd(const float* logits, const int32_t* labels, float* loss_sum,
+                             int32_t* count, float* grad, int64_t rows, int32_t V,
+                             int64_t ldv, int32_t ignore_index, void* stream);
+/* masked argmax over the vocabulary for greedy generation
+ * ($TF/models/whisper/generation_whisper.py:1774-1812 suppress processors + argmax):
+ * out[r] = argmax_v (logits[r,v] if !suppress[v]); suppress uint8 [V] or NULL. */
+int ca_argmax_masked(const float* logits, const uint8_t* suppress, int32_t* out,
+                     int64_t rows, int32_t V, int64_t ldv, void* stream);
+/* embedding gather: y[r,:] = table[ids[r],:] + pos[pos_ids[r],:]  (bf16 tables)
+ * $TF/models/whisper/modeling_whisper.py:204-212,676. */
+int ca_embed_tokens(const void* table, const void* pos, const int32_t* ids,
+                    const int32_t* pos_ids, void* y, int64_t rows, int32_t C, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CORAL_AMD_H */
