@@ -51,6 +51,8 @@ class CaGemmDesc(C.Structure):
         ("sC2", C.c_int64),
         ("sR1", C.c_int64),
         ("sR2", C.c_int64),
+        ("sBias1", C.c_int64),
+        ("sBias2", C.c_int64),
         ("epilogue", C.c_int32),
         ("out_f32", C.c_int32),
         ("accumulate", C.c_int32),
@@ -61,7 +63,7 @@ class CaGemmDesc(C.Structure):
 
 
 KMAJOR, MNMAJOR = 0, 1
-EPI_NONE, EPI_GELU, EPI_RESIDUAL, EPI_DGELU = 0, 1, 2, 3
+EPI_NONE, EPI_GELU, EPI_RESIDUAL, EPI_DGELU, EPI_GELU_RESIDUAL = 0, 1, 2, 3, 4
 
 _vp, _i32, _i64, _f32, _u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint64
 
@@ -75,10 +77,11 @@ SIGNATURES = {
     "ca_layernorm_bwd_partial_floats": (_i64, [_i64, _i32]),
     "ca_layernorm_bwd": (
         C.c_int,
-        [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp],
+        [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp],
     ),
     "ca_colsum_partial_floats": (_i64, [_i64, _i32]),
-    "ca_colsum_bf16": (C.c_int, [_vp, _i64, _i64, _i32, _vp, _i32, _vp, _vp]),
+    "ca_colsum_bf16": (C.c_int, [_vp, _i64, _i64, _i32, _vp, _vp, _i32, _vp, _vp]),
+    "ca_dgelu_mul": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
     "ca_wave_normalize": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _f32, _vp]),
     "ca_conv0_ln_gelu_fwd": (
         C.c_int,
@@ -103,10 +106,11 @@ SIGNATURES = {
     ),
     "ca_mask_frames": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "ca_regroup_pad": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
-    "ca_posconv_weight": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "ca_posconv_partial_floats": (_i64, [_i32]),
+    "ca_posconv_weight": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "ca_posconv_weight_bwd": (
         C.c_int,
-        [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp],
+        [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp],
     ),
     "ca_cast_f32_bf16": (C.c_int, [_vp, _vp, _i64, _vp]),
     "ca_cast_bf16_f32": (C.c_int, [_vp, _vp, _i64, _vp]),

@@ -1,0 +1,325 @@
+// Waveform front end of the wav2vec2 path: utterance normalisation, fused feature-encoder
+// layer 0 (Conv1d(1,512,k=10,s=5) + LayerNorm + GELU) forward/backward, col2im for the
+// strided conv data-gradients.  All HBM-bound; coalesced fp32 PCM reads, 1-KiB row stores.
+#include "common.h"
+
+// ---- (x - mean) / sqrt(var + eps) over the valid samples; padding -> 0 ---------------------
+// $TF/models/wav2vec2/feature_extraction_wav2vec2.py:77-97.  One 1024-thread block per
+// utterance, three passes (the utterance is 640 KB: passes 2 and 3 hit L2).
+__global__ __launch_bounds__(1024) void wave_normalize_kernel(const float* __restrict__ x,
+                                                              const int32_t* __restrict__ lengths,
+                                                              float* __restrict__ y, int64_t N,
+                                                              float eps) {
+  __shared__ float red[16];
+  __shared__ float bc;
+  const int b = blockIdx.x;
+  const float* xb = x + (int64_t)b * N;
+  float* yb = y + (int64_t)b * N;
+  int64_t len = lengths ? lengths[b] : N;
+  if (len > N) len = N;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float s = 0.f;
+  for (int64_t i = threadIdx.x; i < len; i += 1024) s += xb[i];
+  s = wave_sum(s);
+  if (lane == 0) red[wave] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int w = 0; w < 16; ++w) t += red[w];
+    bc = len > 0 ? t / (float)len : 0.f;
+  }
+  __syncthreads();
+  const float mean = bc;
+  float s2 = 0.f;
+  for (int64_t i = threadIdx.x; i < len; i += 1024) {
+    const float d = xb[i] - mean;
+    s2 += d * d;
+  }
+  s2 = wave_sum(s2);
+  __syncthreads();
+  if (lane == 0) red[wave] = s2;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int w = 0; w < 16; ++w) t += red[w];
+    bc = len > 0 ? rsqrtf(t / (float)len + eps) : 0.f;
+  }
+  __syncthreads();
+  const float rstd = bc;
+  for (int64_t i = threadIdx.x; i < N; i += 1024) yb[i] = i < len ? (xb[i] - mean) * rstd : 0.f;
+}
+
+extern "C" int ca_wave_normalize(const float* x, const int32_t* lengths, float* y, int32_t B,
+                                 int64_t N, float eps, void* stream) {
+  CA_CHECK_ARG(x && y && B > 0 && N > 0, "ca_wave_normalize: bad argument");
+  hipLaunchKernelGGL(wave_normalize_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, x,
+                     lengths, y, N, eps);
+  CA_CHECK_LAUNCH("ca_wave_normalize");
+  return CA_OK;
+}
+
+// ---- feature-encoder layer 0, fused ---------------------------------------------------------
+// One wave per output frame: lane owns 8 consecutive channels (C = 512), the k input samples
+// are wave-uniform.  LN statistics by wave shuffles; the frame is stored as one 1-KiB row.
+#define C0 512
+#define K0MAX 16
+
+template <int KW>
+__global__ __launch_bounds__(256) void conv0_fwd_kernel(const float* __restrict__ x,
+                                                        const float* __restrict__ w,
+                                                        const float* __restrict__ bias,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta,
+                                                        unsigned short* __restrict__ y, int B,
+                                                        int64_t N, int64_t T0, int stride,
+                                                        float eps) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float wr[8][KW], bs[8], gm[8], bt[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = lane * 8 + e;
+#pragma unroll
+    for (int j = 0; j < KW; ++j) wr[e][j] = w[c * KW + j];
+    bs[e] = bias[c];
+    gm[e] = gamma[c];
+    bt[e] = beta[c];
+  }
+  const int64_t total = (int64_t)B * T0;
+  for (int64_t f = (int64_t)blockIdx.x * 4 + wave; f < total; f += (int64_t)gridDim.x * 4) {
+    const int64_t b = f / T0, t = f % T0;
+    const float* xp = x + b * N + t * stride;
+    float xs[KW];
+#pragma unroll
+    for (int j = 0; j < KW; ++j) xs[j] = xp[j];
+    float v[8], s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float a = bs[e];
+#pragma unroll
+      for (int j = 0; j < KW; ++j) a = fmaf(wr[e][j], xs[j], a);
+      v[e] = a;
+      s += a;
+    }
+    const float mean = wave_sum(s) * (1.f / C0);
+    float s2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float d = v[e] - mean;
+      s2 += d * d;
+    }
+    const float rstd = rsqrtf(wave_sum(s2) * (1.f / C0) + eps);
+    u16x8_t o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = f2bf(gelu_erf((v[e] - mean) * rstd * gm[e] + bt[e]));
+    *(u16x8_t*)(y + f * C0 + lane * 8) = o;
+  }
+}
+
+extern "C" int ca_conv0_ln_gelu_fwd(const float* x, const float* w, const float* bias,
+                                    const float* gamma, const float* beta, void* y, int32_t B,
+                                    int64_t N, int32_t C, int32_t k, int32_t stride, float eps,
+                                    void* stream) {
+  CA_CHECK_ARG(x && w && bias && gamma && beta && y, "ca_conv0_ln_gelu_fwd: null pointer");
+  CA_CHECK_ARG(C == C0, "ca_conv0_ln_gelu_fwd: C must be %d (got %d)", C0, C);
+  CA_CHECK_ARG(k == 10 && stride >= 1 && N >= k, "ca_conv0_ln_gelu_fwd: k must be 10");
+  const int64_t T0 = (N - k) / stride + 1;
+  int64_t g = ((int64_t)B * T0 + 3) / 4;
+  if (g > 8192) g = 8192;
+  hipLaunchKernelGGL((conv0_fwd_kernel<10>), dim3((int)g), dim3(256), 0, (hipStream_t)stream, x,
+                     w, bias, gamma, beta, (unsigned short*)y, B, N, T0, stride, eps);
+  CA_CHECK_LAUNCH("ca_conv0_ln_gelu_fwd");
+  return CA_OK;
+}
+
+// backward: recompute conv + LN from x; accumulate dw[C][k], dbias, dgamma, dbeta per wave in
+// registers, reduce over the block's waves in LDS, one partial row per block:
+// partial[blk][C*(k+3)] laid out as [dw (C*k) | dbias (C) | dgamma (C) | dbeta (C)].
+#define CONV0_BWD_GRID 1024
+template <int KW>
+__global__ __launch_bounds__(256) void conv0_bwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+    const float* __restrict__ gamma, const float* __restrict__ beta,
+    const unsigned short* __restrict__ dy, float* __restrict__ partial, int B, int64_t N,
+    int64_t T0, int stride, float eps) {
+  __shared__ float red[4][C0];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float wr[8][KW], bs[8], gm[8], bt[8];
+  float dw[8][KW], dbs[8], dgm[8], dbt[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = lane * 8 + e;
+#pragma unroll
+    for (int j = 0; j < KW; ++j) {
+      wr[e][j] = w[c * KW + j];
+      dw[e][j] = 0.f;
+    }
+    bs[e] = bias[c];
+    gm[e] = gamma[c];
+    bt[e] = beta[c];
+    dbs[e] = dgm[e] = dbt[e] = 0.f;
+  }
+  const int64_t total = (int64_t)B * T0;
+  for (int64_t f = (int64_t)blockIdx.x * 4 + wave; f < total; f += (int64_t)gridDim.x * 4) {
+    const int64_t b = f / T0, t = f % T0;
+    const float* xp = x + b * N + t * stride;
+    float xs[KW];
+#pragma unroll
+    for (int j = 0; j < KW; ++j) xs[j] = xp[j];
+    const u16x8_t ud = *(const u16x8_t*)(dy + f * C0 + lane * 8);
+    float v[8], s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float a = bs[e];
+#pragma unroll
+      for (int j = 0; j < KW; ++j) a = fmaf(wr[e][j], xs[j], a);
+      v[e] = a;
+      s += a;
+    }
+    const float mean = wave_sum(s) * (1.f / C0);
+    float s2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float d = v[e] - mean;
+      s2 += d * d;
+    }
+    const float rstd = rsqrtf(wave_sum(s2) * (1.f / C0) + eps);
+    float h[8], dh[8], a1 = 0.f, a2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      h[e] = (v[e] - mean) * rstd;
+      const float du = bf2f(ud[e]) * dgelu_erf(h[e] * gm[e] + bt[e]);
+      dgm[e] += du * h[e];
+      dbt[e] += du;
+      dh[e] = du * gm[e];
+      a1 += dh[e];
+      a2 += dh[e] * h[e];
+    }
+    const float m1 = wave_sum(a1) * (1.f / C0), m2 = wave_sum(a2) * (1.f / C0);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float dv = rstd * (dh[e] - m1 - h[e] * m2);
+      dbs[e] += dv;
+#pragma unroll
+      for (int j = 0; j < KW; ++j) dw[e][j] = fmaf(dv, xs[j], dw[e][j]);
+    }
+  }
+  float* pout = partial + (int64_t)blockIdx.x * (C0 * (KW + 3));
+  // reduce each of the KW+3 channel vectors over the 4 waves through LDS
+  for (int q = 0; q < KW + 3; ++q) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float val;
+      if (q < KW) {
+        val = 0.f;
+#pragma unroll
+        for (int j = 0; j < KW; ++j)
+          if (j == q) val = dw[e][j];
+      } else if (q == KW) {
+        val = dbs[e];
+      } else if (q == KW + 1) {
+        val = dgm[e];
+      } else {
+        val = dbt[e];
+      }
+      red[wave][lane * 8 + e] = val;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C0; c += 256) {
+      const float t = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+      if (q < KW)
+        pout[c * KW + q] = t;
+      else
+        pout[C0 * KW + (q - KW) * C0 + c] = t;
+    }
+    __syncthreads();
+  }
+}
+
+__global__ void reduce_partials_kernel2(const float* __restrict__ partial, int nparts,
+                                        int64_t stride, int n, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float a = 0.f;
+  for (int p = 0; p < nparts; ++p) a += partial[(int64_t)p * stride + i];
+  out[i] += a;
+}
+
+static int conv0_bwd_grid(int32_t B, int64_t T0) {
+  int64_t g = ((int64_t)B * T0 + 3) / 4;
+  if (g > CONV0_BWD_GRID) g = CONV0_BWD_GRID;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+extern "C" int64_t ca_conv0_bwd_partial_floats(int32_t B, int64_t N, int32_t C, int32_t k,
+                                               int32_t stride) {
+  const int64_t T0 = (N - k) / stride + 1;
+  return (int64_t)conv0_bwd_grid(B, T0) * C * (k + 3);
+}
+
+extern "C" int ca_conv0_ln_gelu_bwd(const float* x, const float* w, const float* bias,
+                                    const float* gamma, const float* beta, const void* dy,
+                                    float* dw, float* dbias, float* dgamma, float* dbeta,
+                                    float* partial, int32_t B, int64_t N, int32_t C, int32_t k,
+                                    int32_t stride, float eps, void* stream) {
+  CA_CHECK_ARG(x && w && bias && gamma && beta && dy && dw && dbias && dgamma && dbeta && partial,
+               "ca_conv0_ln_gelu_bwd: null pointer");
+  CA_CHECK_ARG(C == C0 && k == 10, "ca_conv0_ln_gelu_bwd: needs C=512, k=10");
+  const int64_t T0 = (N - k) / stride + 1;
+  const int g = conv0_bwd_grid(B, T0);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL((conv0_bwd_kernel<10>), dim3(g), dim3(256), 0, s, x, w, bias, gamma, beta,
+                     (const unsigned short*)dy, partial, B, N, T0, stride, eps);
+  const int64_t st = (int64_t)C0 * (k + 3);
+  hipLaunchKernelGGL(reduce_partials_kernel2, dim3((C0 * k + 255) / 256), dim3(256), 0, s,
+                     partial, g, st, C0 * k, dw);
+  hipLaunchKernelGGL(reduce_partials_kernel2, dim3(2), dim3(256), 0, s, partial + C0 * k, g, st,
+                     C0, dbias);
+  hipLaunchKernelGGL(reduce_partials_kernel2, dim3(2), dim3(256), 0, s, partial + C0 * (k + 1),
+                     g, st, C0, dgamma);
+  hipLaunchKernelGGL(reduce_partials_kernel2, dim3(2), dim3(256), 0, s, partial + C0 * (k + 2),
+                     g, st, C0, dbeta);
+  CA_CHECK_LAUNCH("ca_conv0_ln_gelu_bwd");
+  return CA_OK;
+}
+
+// ---- col2im for strided channels-last Conv1d data gradients ---------------------------------
+__global__ __launch_bounds__(256) void col2im_kernel(const unsigned short* __restrict__ dcol,
+                                                     unsigned short* __restrict__ dx, int B,
+                                                     int64_t T, int64_t L, int C, int k,
+                                                     int stride) {
+  const int cch = C >> 3;
+  const int64_t total = (int64_t)B * L * cch;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * 256) {
+    const int c8 = (int)(i % cch);
+    const int64_t bp = i / cch;
+    const int64_t p = bp % L, b = bp / L;
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int j = (int)(p % stride); j < k; j += stride) {
+      const int64_t t = (p - j) / stride;
+      if (p - j < 0) break;
+      if (t >= T) continue;
+      const u16x8_t u =
+          *(const u16x8_t*)(dcol + ((b * T + t) * k + j) * (int64_t)C + c8 * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[e] += bf2f(u[e]);
+    }
+    u16x8_t o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = f2bf(a[e]);
+    *(u16x8_t*)(dx + (b * L + p) * (int64_t)C + c8 * 8) = o;
+  }
+}
+
+extern "C" int ca_col2im_1d(const void* dcol, void* dx, int32_t B, int64_t T, int64_t L,
+                            int32_t C, int32_t k, int32_t stride, void* stream) {
+  CA_CHECK_ARG(dcol && dx && B > 0 && T > 0 && L > 0 && (C % 8) == 0 && k > 0 && stride > 0,
+               "ca_col2im_1d: bad argument");
+  int64_t g = ((int64_t)B * L * (C / 8) + 255) / 256;
+  if (g > 16384) g = 16384;
+  hipLaunchKernelGGL(col2im_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream,
+                     (const unsigned short*)dcol, (unsigned short*)dx, B, T, L, C, k, stride);
+  CA_CHECK_LAUNCH("ca_col2im_1d");
+  return CA_OK;
+}

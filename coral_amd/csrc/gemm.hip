@@ -75,7 +75,8 @@ struct MNMajorLoader {  // operand stored [k][mn], mn contiguous; k rows may be 
       const int swz = (kr & 3) | (((kr >> 3) & 1) << 2);
       const int c = (lane & 15) ^ (swz << 1);
       int cc = col0 + c * 8;
-      cc = cc <= ncols - 8 ? cc : ncols - 8;
+      const int nc8 = (ncols + 7) & ~7;  // rows are readable up to ncols rounded up to 8
+      cc = cc <= nc8 - 8 ? cc : nc8 - 8;
       colp[i] = (const char*)(base + cc);
       if (kseg > 0) {
         seg[i] = kr / kseg;
@@ -249,9 +250,10 @@ __global__ __launch_bounds__(256) void ca_gemm_kernel(const CaGemmDesc d) {
     const int nvalid = (N - nb) < 4 ? (N - nb) : 4;
     float bias4[4] = {0.f, 0.f, 0.f, 0.f};
     if (d.bias) {
+      const float* bz = d.bias + z1 * d.sBias1 + z2 * d.sBias2;
 #pragma unroll
       for (int e = 0; e < 4; ++e)
-        if (e < nvalid) bias4[e] = d.bias[nb + e];
+        if (e < nvalid) bias4[e] = bz[nb + e];
     }
 #pragma unroll 1
     for (int it = 0; it < 16; ++it) {
@@ -264,7 +266,7 @@ __global__ __launch_bounds__(256) void ca_gemm_kernel(const CaGemmDesc d) {
       for (int e = 0; e < 4; ++e) v[e] = a4[e] * d.alpha + bias4[e];
       const int64_t coff = zoffC + (int64_t)m * d.ldc + nb;
       const int64_t roff = zoffR + (int64_t)m * d.ldr + nb;
-      if (d.epilogue == CA_EPI_GELU) {
+      if (d.epilogue == CA_EPI_GELU || d.epilogue == CA_EPI_GELU_RESIDUAL) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float g = gelu_erf(v[e]);
@@ -273,6 +275,12 @@ __global__ __launch_bounds__(256) void ca_gemm_kernel(const CaGemmDesc d) {
             g = ca_dropout_keep(d.dropout_seed, idx, d.dropout_p) ? g * keep_scale : 0.f;
           }
           v2[e] = g;
+        }
+        if (d.epilogue == CA_EPI_GELU_RESIDUAL) {
+          const unsigned short* R = (const unsigned short*)d.R + roff;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (e < nvalid) v2[e] += bf2f(R[e]);
         }
       } else if (d.epilogue == CA_EPI_RESIDUAL) {
         const unsigned short* R = (const unsigned short*)d.R + roff;
@@ -321,7 +329,7 @@ __global__ __launch_bounds__(256) void ca_gemm_kernel(const CaGemmDesc d) {
             if (e < nvalid) C[e] = f2bf(v[e]);
         }
       }
-      if (d.epilogue == CA_EPI_GELU && d.C2) {
+      if ((d.epilogue == CA_EPI_GELU || d.epilogue == CA_EPI_GELU_RESIDUAL) && d.C2) {
         unsigned short* C2 = (unsigned short*)d.C2 + coff;
         if (nvalid == 4 && vec_ok) {
           *(u16x4_t*)C2 = (u16x4_t){f2bf(v2[0]), f2bf(v2[1]), f2bf(v2[2]), f2bf(v2[3])};
@@ -338,7 +346,8 @@ __global__ __launch_bounds__(256) void ca_gemm_kernel(const CaGemmDesc d) {
 extern "C" int ca_gemm_bf16(const CaGemmDesc* desc, void* stream) {
   CA_CHECK_ARG(desc != nullptr, "ca_gemm_bf16: null descriptor");
   const CaGemmDesc& d = *desc;
-  CA_CHECK_ARG(d.A && d.B && (d.C || (d.epilogue == CA_EPI_GELU && d.C2)),
+  CA_CHECK_ARG(d.A && d.B &&
+                   (d.C || ((d.epilogue == CA_EPI_GELU || d.epilogue == CA_EPI_GELU_RESIDUAL) && d.C2)),
                "ca_gemm_bf16: null operand");
   CA_CHECK_ARG(d.M > 0 && d.N > 0 && d.K > 0, "ca_gemm_bf16: bad shape %d %d %d", d.M, d.N,
                d.K);
@@ -348,13 +357,8 @@ extern "C" int ca_gemm_bf16(const CaGemmDesc* desc, void* stream) {
                "ca_gemm_bf16: batch strides must be multiples of 8");
   CA_CHECK_ARG(((uintptr_t)d.A % 16) == 0 && ((uintptr_t)d.B % 16) == 0,
                "ca_gemm_bf16: A/B must be 16-byte aligned");
-  if (d.a_layout == CA_MNMAJOR)
-    CA_CHECK_ARG(d.M >= 8 && (d.M % 8) == 0, "ca_gemm_bf16: MNMAJOR A needs M %% 8 == 0");
-  if (d.b_layout == CA_MNMAJOR)
-    CA_CHECK_ARG(d.N >= 8 && (d.N % 8) == 0, "ca_gemm_bf16: MNMAJOR B needs N %% 8 == 0");
-  CA_CHECK_ARG(d.a_kseg == 0 || d.a_kseg >= BK, "ca_gemm_bf16: a_kseg must be 0 or >= 64");
-  CA_CHECK_ARG(d.b_kseg == 0 || d.b_kseg >= BK, "ca_gemm_bf16: b_kseg must be 0 or >= 64");
-  if (d.epilogue == CA_EPI_RESIDUAL || d.epilogue == CA_EPI_DGELU)
+  CA_CHECK_ARG(d.a_kseg >= 0 && d.b_kseg >= 0, "ca_gemm_bf16: negative kseg");
+  if (d.epilogue == CA_EPI_RESIDUAL || d.epilogue == CA_EPI_DGELU || d.epilogue == CA_EPI_GELU_RESIDUAL)
     CA_CHECK_ARG(d.R != nullptr, "ca_gemm_bf16: epilogue needs R");
   CA_CHECK_ARG(d.dropout_p >= 0.f && d.dropout_p < 1.f, "ca_gemm_bf16: bad dropout_p");
 

@@ -1,0 +1,476 @@
+// Small HBM-bound pieces: SpecAugment/padding masks, grouped-conv regrouping, weight-norm for
+// the positional conv, dtype casts / weight reorders, gradient-norm + fused AdamW, embeddings.
+#include "common.h"
+
+// ---- SpecAugment + padding --------------------------------------------------------------------
+// $TF/models/wav2vec2/modeling_wav2vec2.py:1272-1316 (masked_spec_embed on time spans, zeros on
+// feature spans) and :752-755 (padded frames -> 0).
+__global__ __launch_bounds__(256) void mask_frames_kernel(unsigned short* __restrict__ h,
+                                                          const uint8_t* __restrict__ tmask,
+                                                          const uint8_t* __restrict__ fmask,
+                                                          const unsigned short* __restrict__ embed,
+                                                          const int32_t* __restrict__ flen, int B,
+                                                          int T, int C) {
+  const int cch = C >> 3;
+  const int64_t total = (int64_t)B * T * cch;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * 256) {
+    const int c8 = (int)(i % cch);
+    const int64_t bt = i / cch;
+    const int t = (int)(bt % T), b = (int)(bt / T);
+    const bool tm = tmask && tmask[bt];
+    const bool pad = flen && t >= flen[b];
+    bool anyf = false;
+    if (fmask) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) anyf |= fmask[(int64_t)b * C + c8 * 8 + e] != 0;
+    }
+    if (!tm && !pad && !anyf) continue;
+    unsigned short* p = h + bt * C + c8 * 8;
+    u16x8_t v = *(u16x8_t*)p;
+    if (tm) v = *(const u16x8_t*)(embed + c8 * 8);
+    if (fmask) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (fmask[(int64_t)b * C + c8 * 8 + e]) v[e] = 0;
+    }
+    if (pad) v = (u16x8_t){0, 0, 0, 0, 0, 0, 0, 0};
+    *(u16x8_t*)p = v;
+  }
+}
+
+extern "C" int ca_mask_frames(void* h, const uint8_t* tmask, const uint8_t* fmask,
+                              const void* embed, const int32_t* flen, int32_t B, int32_t T,
+                              int32_t C, void* stream) {
+  CA_CHECK_ARG(h && B > 0 && T > 0 && C > 0 && (C % 8) == 0, "ca_mask_frames: bad argument");
+  CA_CHECK_ARG(!tmask || embed, "ca_mask_frames: tmask needs embed");
+  int64_t g = ((int64_t)B * T * (C / 8) + 255) / 256;
+  if (g > 8192) g = 8192;
+  hipLaunchKernelGGL(mask_frames_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream,
+                     (unsigned short*)h, tmask, fmask, (const unsigned short*)embed, flen, B, T, C);
+  CA_CHECK_LAUNCH("ca_mask_frames");
+  return CA_OK;
+}
+
+// ---- x [B,T,G*Cg] -> xg [B,G,T+2*pad,Cg], zero time padding -----------------------------------
+__global__ __launch_bounds__(256) void regroup_pad_kernel(const unsigned short* __restrict__ x,
+                                                          unsigned short* __restrict__ xg, int B,
+                                                          int T, int G, int Cg, int pad) {
+  const int cch = Cg >> 3;
+  const int Tp = T + 2 * pad;
+  const int64_t total = (int64_t)B * G * Tp * cch;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * 256) {
+    const int c8 = (int)(i % cch);
+    int64_t r = i / cch;
+    const int tp = (int)(r % Tp);
+    r /= Tp;
+    const int g = (int)(r % G), b = (int)(r / G);
+    const int t = tp - pad;
+    u16x8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (t >= 0 && t < T) v = *(const u16x8_t*)(x + ((int64_t)b * T + t) * (G * Cg) + g * Cg + c8 * 8);
+    *(u16x8_t*)(xg + i * 8) = v;
+  }
+}
+
+extern "C" int ca_regroup_pad(const void* x, void* xg, int32_t B, int32_t T, int32_t G,
+                              int32_t Cg, int32_t pad, void* stream) {
+  CA_CHECK_ARG(x && xg && B > 0 && T > 0 && G > 0 && Cg > 0 && (Cg % 8) == 0 && pad >= 0,
+               "ca_regroup_pad: bad argument");
+  int64_t g = ((int64_t)B * G * (T + 2 * pad) * (Cg / 8) + 255) / 256;
+  if (g > 8192) g = 8192;
+  hipLaunchKernelGGL(regroup_pad_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream,
+                     (const unsigned short*)x, (unsigned short*)xg, B, T, G, Cg, pad);
+  CA_CHECK_LAUNCH("ca_regroup_pad");
+  return CA_OK;
+}
+
+// ---- positional-conv weight norm (dim=2): w = g * v / ||v||_(0,1) -----------------------------
+// $TF/models/wav2vec2/modeling_wav2vec2.py:326-358 (nn.utils.parametrizations.weight_norm).
+// v fp32 [d][Cg][K]; per-tap norm over all (co, ci).
+#define PCW_SLABS 256
+// partial[slab][K]: sum over the slab's rows of a[row][j]*b[row][j]
+__global__ __launch_bounds__(256) void tap_dot_kernel(const float* __restrict__ a,
+                                                      const float* __restrict__ b,
+                                                      float* __restrict__ partial, int64_t nrows,
+                                                      int K, int bmode, int Cg, int G) {
+  // bmode 0: b has the same [row][K] layout as a.
+  // bmode 1: a = v [d][Cg][K], b = dwf [G][Cg_out][K][Cg_in] (gradient in GEMM layout).
+  const int j = threadIdx.x % K;  // K = 128 -> two row lanes per 256-thread block
+  const int rl = threadIdx.x / K;
+  const int nrl = 256 / K;
+  const int64_t per = (nrows + gridDim.x - 1) / gridDim.x;
+  const int64_t r0 = (int64_t)blockIdx.x * per;
+  int64_t r1 = r0 + per;
+  if (r1 > nrows) r1 = nrows;
+  float acc = 0.f;
+  for (int64_t r = r0 + rl; r < r1; r += nrl) {
+    const float av = a[r * K + j];
+    float bv;
+    if (bmode == 0) {
+      bv = b[r * K + j];
+    } else {
+      const int ci = (int)(r % Cg);
+      const int64_t co_g = r / Cg;  // global output channel = g*Cg + co
+      bv = b[(co_g * K + j) * Cg + ci];
+    }
+    acc += av * bv;
+  }
+  __shared__ float red[256];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if (rl == 0) {
+    float t = 0.f;
+    for (int q = 0; q < nrl; ++q) t += red[q * K + j];
+    partial[(int64_t)blockIdx.x * K + j] = t;
+  }
+}
+
+__global__ void tap_finish_kernel(const float* __restrict__ partial, int nparts, int K,
+                                  float* __restrict__ out, int do_sqrt) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= K) return;
+  float a = 0.f;
+  for (int p = 0; p < nparts; ++p) a += partial[(int64_t)p * K + j];
+  out[j] = do_sqrt ? sqrtf(a) : a;
+}
+
+// one block per (row-set): transposes a [R][K] fp32 panel into [K][R] bf16 with scaling.
+// forward weights : fixed co_g, R = ci (Cg rows, stride K)        -> wf[co_g][j][ci]
+// backward weights: fixed (g, ci), R = co (Cg rows, stride Cg*K)   -> wb[g][ci][K-1-j][co]
+__global__ __launch_bounds__(256) void posconv_build_kernel(const float* __restrict__ v,
+                                                            const float* __restrict__ gvec,
+                                                            const float* __restrict__ norm,
+                                                            unsigned short* __restrict__ out,
+                                                            int Cg, int K, int mode) {
+  extern __shared__ float tile[];  // [Cg][K+1]
+  const int blk = blockIdx.x;
+  const float* src;
+  int64_t rstride;
+  if (mode == 0) {
+    src = v + (int64_t)blk * Cg * K;
+    rstride = K;
+  } else {
+    const int g = blk / Cg, ci = blk % Cg;
+    src = v + ((int64_t)g * Cg * Cg + ci) * K;
+    rstride = (int64_t)Cg * K;
+  }
+  for (int i = threadIdx.x; i < Cg * K; i += 256) {
+    const int r = i / K, j = i % K;
+    tile[r * (K + 1) + j] = src[r * rstride + j] * (gvec[j] / norm[j]);
+  }
+  __syncthreads();
+  unsigned short* dst = out + (int64_t)blk * K * Cg;
+  for (int i = threadIdx.x; i < Cg * K; i += 256) {
+    const int jo = i / Cg, r = i % Cg;
+    const int j = mode == 0 ? jo : (K - 1 - jo);
+    dst[i] = f2bf(tile[r * (K + 1) + j]);
+  }
+}
+
+extern "C" int ca_posconv_weight(const float* v, const float* g, void* wf, void* wb, float* norm,
+                                 float* partial, int32_t d, int32_t Cg, int32_t K, void* stream) {
+  CA_CHECK_ARG(v && g && wf && norm && partial, "ca_posconv_weight: null pointer");
+  CA_CHECK_ARG(d > 0 && Cg > 0 && (d % Cg) == 0 && K > 0 && K <= 256 && (256 % K) == 0,
+               "ca_posconv_weight: K must divide 256");
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t nrows = (int64_t)d * Cg;
+  hipLaunchKernelGGL(tap_dot_kernel, dim3(PCW_SLABS), dim3(256), 0, s, v, v, partial, nrows, K, 0,
+                     Cg, d / Cg);
+  hipLaunchKernelGGL(tap_finish_kernel, dim3(1), dim3(256), 0, s, partial, PCW_SLABS, K, norm, 1);
+  const size_t lds = (size_t)Cg * (K + 1) * sizeof(float);
+  hipLaunchKernelGGL(posconv_build_kernel, dim3(d), dim3(256), lds, s, v, g, norm,
+                     (unsigned short*)wf, Cg, K, 0);
+  if (wb)
+    hipLaunchKernelGGL(posconv_build_kernel, dim3(d), dim3(256), lds, s, v, g, norm,
+                       (unsigned short*)wb, Cg, K, 1);
+  CA_CHECK_LAUNCH("ca_posconv_weight");
+  return CA_OK;
+}
+
+// dv[co_g][ci][j] += (g_j/n_j) * (dw - v * dot_j / n_j^2),  dg[j] += dot_j / n_j,
+// dot_j = sum_{co,ci} dw*v, with dw[co_g][ci][j] = dwf[co_g][j][ci].
+__global__ __launch_bounds__(256) void posconv_wbwd_kernel(const float* __restrict__ dwf,
+                                                           const float* __restrict__ v,
+                                                           const float* __restrict__ gvec,
+                                                           const float* __restrict__ norm,
+                                                           const float* __restrict__ dot,
+                                                           float* __restrict__ dv, int Cg, int K) {
+  extern __shared__ float tile[];  // [K][Cg+1] of dwf for this output channel
+  const int co_g = blockIdx.x;
+  const float* src = dwf + (int64_t)co_g * K * Cg;
+  for (int i = threadIdx.x; i < K * Cg; i += 256) {
+    const int j = i / Cg, ci = i % Cg;
+    tile[j * (Cg + 1) + ci] = src[i];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < Cg * K; i += 256) {
+    const int ci = i / K, j = i % K;
+    const float n = norm[j];
+    const int64_t idx = ((int64_t)co_g * Cg + ci) * K + j;
+    dv[idx] += (gvec[j] / n) * (tile[j * (Cg + 1) + ci] - v[idx] * dot[j] / (n * n));
+  }
+}
+__global__ void posconv_dg_kernel(const float* __restrict__ dot, const float* __restrict__ norm,
+                                  float* __restrict__ dg, int K) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < K) dg[j] += dot[j] / norm[j];
+}
+
+extern "C" int ca_posconv_weight_bwd(const float* dwf, const float* v, const float* g,
+                                     const float* norm, float* dv, float* dg, float* partial,
+                                     int32_t d, int32_t Cg, int32_t K, void* stream) {
+  CA_CHECK_ARG(dwf && v && g && norm && dv && dg && partial, "ca_posconv_weight_bwd: null pointer");
+  CA_CHECK_ARG(K > 0 && K <= 256 && (256 % K) == 0, "ca_posconv_weight_bwd: K must divide 256");
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t nrows = (int64_t)d * Cg;
+  float* dot = partial + (int64_t)PCW_SLABS * K;
+  hipLaunchKernelGGL(tap_dot_kernel, dim3(PCW_SLABS), dim3(256), 0, s, v, dwf, partial, nrows, K,
+                     1, Cg, d / Cg);
+  hipLaunchKernelGGL(tap_finish_kernel, dim3(1), dim3(256), 0, s, partial, PCW_SLABS, K, dot, 0);
+  const size_t lds = (size_t)K * (Cg + 1) * sizeof(float);
+  hipLaunchKernelGGL(posconv_wbwd_kernel, dim3(d), dim3(256), lds, s, dwf, v, g, norm, dot, dv,
+                     Cg, K);
+  hipLaunchKernelGGL(posconv_dg_kernel, dim3(1), dim3(256), 0, s, dot, norm, dg, K);
+  CA_CHECK_LAUNCH("ca_posconv_weight_bwd");
+  return CA_OK;
+}
+
+extern "C" int64_t ca_posconv_partial_floats(int32_t K) { return (int64_t)(PCW_SLABS + 1) * K; }
+
+// ---- casts / reorders -------------------------------------------------------------------------
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ x, unsigned short* __restrict__ y,
+                                     int64_t n) {
+  const int64_t n4 = n >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const f32x4_t v = *(const f32x4_t*)(x + i * 4);
+    *(u16x4_t*)(y + i * 4) = (u16x4_t){f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const int64_t i = (n4 << 2) + threadIdx.x;
+    y[i] = f2bf(x[i]);
+  }
+}
+__global__ void cast_bf16_f32_kernel(const unsigned short* __restrict__ x, float* __restrict__ y,
+                                     int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    y[i] = bf2f(x[i]);
+}
+static int ew_grid(int64_t n, int per) {
+  int64_t g = (n / per + 255) / 256;
+  if (g > 8192) g = 8192;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+extern "C" int ca_cast_f32_bf16(const float* x, void* y, int64_t n, void* stream) {
+  CA_CHECK_ARG(x && y && n > 0, "ca_cast_f32_bf16: bad argument");
+  CA_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 8) == 0, "ca_cast_f32_bf16: alignment");
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(ew_grid(n, 4)), dim3(256), 0, (hipStream_t)stream,
+                     x, (unsigned short*)y, n);
+  CA_CHECK_LAUNCH("ca_cast_f32_bf16");
+  return CA_OK;
+}
+extern "C" int ca_cast_bf16_f32(const void* x, float* y, int64_t n, void* stream) {
+  CA_CHECK_ARG(x && y && n > 0, "ca_cast_bf16_f32: bad argument");
+  hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(ew_grid(n, 1)), dim3(256), 0, (hipStream_t)stream,
+                     (const unsigned short*)x, y, n);
+  CA_CHECK_LAUNCH("ca_cast_bf16_f32");
+  return CA_OK;
+}
+
+// x fp32 [rows][cols] -> y bf16 [cols][rows]; 32x32 LDS tiles
+__global__ __launch_bounds__(256) void transpose_f32_bf16_kernel(const float* __restrict__ x,
+                                                                 unsigned short* __restrict__ y,
+                                                                 int rows, int cols) {
+  __shared__ float tile[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int k = ty; k < 32; k += 8) {
+    const int r = r0 + k, c = c0 + tx;
+    tile[k][tx] = (r < rows && c < cols) ? x[(int64_t)r * cols + c] : 0.f;
+  }
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8) {
+    const int c = c0 + k, r = r0 + tx;
+    if (c < cols && r < rows) y[(int64_t)c * rows + r] = f2bf(tile[tx][k]);
+  }
+}
+extern "C" int ca_transpose_f32_bf16(const float* x, void* y, int32_t rows, int32_t cols,
+                                     void* stream) {
+  CA_CHECK_ARG(x && y && rows > 0 && cols > 0, "ca_transpose_f32_bf16: bad argument");
+  hipLaunchKernelGGL(transpose_f32_bf16_kernel, dim3((cols + 31) / 32, (rows + 31) / 32),
+                     dim3(256), 0, (hipStream_t)stream, x, (unsigned short*)y, rows, cols);
+  CA_CHECK_LAUNCH("ca_transpose_f32_bf16");
+  return CA_OK;
+}
+
+// w fp32 [Co][Ci][k] -> wr bf16 [Co][k][Ci]
+__global__ void conv_w_reorder_kernel(const float* __restrict__ w, unsigned short* __restrict__ wr,
+                                      int64_t n, int Ci, int k) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int ci = (int)(i % Ci);
+    const int64_t r = i / Ci;
+    const int j = (int)(r % k);
+    const int64_t co = r / k;
+    wr[i] = f2bf(w[(co * Ci + ci) * k + j]);
+  }
+}
+extern "C" int ca_conv_weight_reorder(const float* w, void* wr, int32_t Co, int32_t Ci, int32_t k,
+                                      void* stream) {
+  CA_CHECK_ARG(w && wr && Co > 0 && Ci > 0 && k > 0, "ca_conv_weight_reorder: bad argument");
+  const int64_t n = (int64_t)Co * Ci * k;
+  hipLaunchKernelGGL(conv_w_reorder_kernel, dim3(ew_grid(n, 1)), dim3(256), 0,
+                     (hipStream_t)stream, w, (unsigned short*)wr, n, Ci, k);
+  CA_CHECK_LAUNCH("ca_conv_weight_reorder");
+  return CA_OK;
+}
+// dwr fp32 [Co][k][Ci] -> dw fp32 [Co][Ci][k] (+=)
+__global__ void conv_w_grad_reorder_kernel(const float* __restrict__ dwr, float* __restrict__ dw,
+                                           int64_t n, int Ci, int k) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int ci = (int)(i % Ci);
+    const int64_t r = i / Ci;
+    const int j = (int)(r % k);
+    const int64_t co = r / k;
+    dw[(co * Ci + ci) * k + j] += dwr[i];
+  }
+}
+extern "C" int ca_conv_weight_grad_reorder(const float* dwr, float* dw, int32_t Co, int32_t Ci,
+                                           int32_t k, void* stream) {
+  CA_CHECK_ARG(dwr && dw && Co > 0 && Ci > 0 && k > 0, "ca_conv_weight_grad_reorder: bad arg");
+  const int64_t n = (int64_t)Co * Ci * k;
+  hipLaunchKernelGGL(conv_w_grad_reorder_kernel, dim3(ew_grid(n, 1)), dim3(256), 0,
+                     (hipStream_t)stream, dwr, dw, n, Ci, k);
+  CA_CHECK_LAUNCH("ca_conv_weight_grad_reorder");
+  return CA_OK;
+}
+
+// ---- gradient norm + fused AdamW ---------------------------------------------------------------
+#define SUMSQ_BLOCKS 1024
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n,
+                                                    float* __restrict__ partial) {
+  __shared__ float red[4];
+  float a = 0.f;
+  const int64_t n4 = n >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const f32x4_t v = *(const f32x4_t*)(g + i * 4);
+    a += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const float v = g[(n4 << 2) + threadIdx.x];
+    a += v * v;
+  }
+  a = wave_sum(a);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ __launch_bounds__(256) void sumsq_finish_kernel(const float* __restrict__ partial,
+                                                           int nparts, float* __restrict__ out,
+                                                           int accumulate) {
+  __shared__ float red[4];
+  float a = 0.f;
+  for (int i = threadIdx.x; i < nparts; i += 256) a += partial[i];
+  a = wave_sum(a);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float t = red[0] + red[1] + red[2] + red[3];
+    out[0] = accumulate ? out[0] + t : t;
+  }
+}
+extern "C" int ca_sumsq_f32(const float* g, int64_t n, float* out, int32_t accumulate,
+                            float* partial, void* stream) {
+  CA_CHECK_ARG(g && out && partial && n > 0, "ca_sumsq_f32: bad argument");
+  CA_CHECK_ARG(((uintptr_t)g % 16) == 0, "ca_sumsq_f32: g must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(sumsq_kernel, dim3(SUMSQ_BLOCKS), dim3(256), 0, s, g, n, partial);
+  hipLaunchKernelGGL(sumsq_finish_kernel, dim3(1), dim3(256), 0, s, partial, SUMSQ_BLOCKS, out,
+                     accumulate);
+  CA_CHECK_LAUNCH("ca_sumsq_f32");
+  return CA_OK;
+}
+
+// torch.optim.AdamW (decoupled decay) with the clip coefficient of clip_grad_norm_ folded in.
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ m,
+                                                    float* __restrict__ v,
+                                                    const float* __restrict__ g,
+                                                    unsigned short* __restrict__ p16, int64_t n,
+                                                    float lr, float b1, float b2, float eps,
+                                                    float wd, float bc1, float bc2_sqrt,
+                                                    float grad_scale, float max_norm,
+                                                    const float* __restrict__ gnorm_sq) {
+  float coef = grad_scale;
+  if (gnorm_sq && max_norm > 0.f) {
+    const float nrm = sqrtf(gnorm_sq[0]) * grad_scale;
+    const float c = max_norm / (nrm + 1e-6f);
+    coef *= c < 1.f ? c : 1.f;
+  }
+  const float step_size = lr / bc1;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float gi = g[i] * coef;
+    float pi = p[i] * (1.f - lr * wd);
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    pi -= step_size * mi / denom;
+    p[i] = pi;
+    m[i] = mi;
+    v[i] = vi;
+    if (p16) p16[i] = f2bf(pi);
+  }
+}
+extern "C" int ca_adamw_step(float* p, float* m, float* v, const float* g, void* p16, int64_t n,
+                             float lr, float beta1, float beta2, float eps, float weight_decay,
+                             int32_t step, float grad_scale, float max_norm,
+                             const float* gnorm_sq, void* stream) {
+  CA_CHECK_ARG(p && m && v && g && n > 0 && step >= 1, "ca_adamw_step: bad argument");
+  const float bc1 = 1.f - powf(beta1, (float)step);
+  const float bc2 = 1.f - powf(beta2, (float)step);
+  hipLaunchKernelGGL(adamw_kernel, dim3(ew_grid(n, 1)), dim3(256), 0, (hipStream_t)stream, p, m,
+                     v, g, (unsigned short*)p16, n, lr, beta1, beta2, eps, weight_decay, bc1,
+                     sqrtf(bc2), grad_scale, max_norm, gnorm_sq);
+  CA_CHECK_LAUNCH("ca_adamw_step");
+  return CA_OK;
+}
+
+// ---- token + position embedding gather ----------------------------------------------------------
+__global__ __launch_bounds__(256) void embed_kernel(const unsigned short* __restrict__ table,
+                                                    const unsigned short* __restrict__ pos,
+                                                    const int32_t* __restrict__ ids,
+                                                    const int32_t* __restrict__ pos_ids,
+                                                    unsigned short* __restrict__ y, int64_t rows,
+                                                    int C) {
+  const int cch = C >> 3;
+  const int64_t total = rows * cch;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * 256) {
+    const int c8 = (int)(i % cch);
+    const int64_t r = i / cch;
+    const u16x8_t a = *(const u16x8_t*)(table + (int64_t)ids[r] * C + c8 * 8);
+    u16x8_t o;
+    if (pos) {
+      const u16x8_t b = *(const u16x8_t*)(pos + (int64_t)pos_ids[r] * C + c8 * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = f2bf(bf2f(a[e]) + bf2f(b[e]));
+    } else {
+      o = a;
+    }
+    *(u16x8_t*)(y + r * C + c8 * 8) = o;
+  }
+}
+extern "C" int ca_embed_tokens(const void* table, const void* pos, const int32_t* ids,
+                               const int32_t* pos_ids, void* y, int64_t rows, int32_t C,
+                               void* stream) {
+  CA_CHECK_ARG(table && ids && y && rows > 0 && C > 0 && (C % 8) == 0, "ca_embed_tokens: bad arg");
+  CA_CHECK_ARG(!pos || pos_ids, "ca_embed_tokens: pos needs pos_ids");
+  hipLaunchKernelGGL(embed_kernel, dim3(ew_grid(rows * (C / 8), 1)), dim3(256), 0,
+                     (hipStream_t)stream, (const unsigned short*)table, (const unsigned short*)pos,
+                     ids, pos_ids, (unsigned short*)y, rows, C);
+  CA_CHECK_LAUNCH("ca_embed_tokens");
+  return CA_OK;
+}

@@ -122,8 +122,8 @@ template <int NCH>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(
     const unsigned short* __restrict__ dy, const unsigned short* __restrict__ x,
     const float* __restrict__ gamma, const float* __restrict__ beta,
-    const float* __restrict__ stats, unsigned short* __restrict__ dx,
-    float* __restrict__ partial, int64_t rows, int C, int act) {
+    const float* __restrict__ stats, const unsigned short* __restrict__ dres,
+    unsigned short* __restrict__ dx, float* __restrict__ partial, int64_t rows, int C, int act) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* red = (float*)smem_raw;  // [4 waves][2][C]
   const int lane = threadIdx.x & 63;
@@ -184,8 +184,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
       const int ch = lane + c * 64;
       if (ch < nchunk) {
         u16x8_t o;
+        u16x8_t rs = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (dres) rs = *(const u16x8_t*)(dres + row * C + ch * 8);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = f2bf(rstd * (dxh[c][e] - m1 - xh[c][e] * m2));
+        for (int e = 0; e < 8; ++e)
+          o[e] = f2bf(rstd * (dxh[c][e] - m1 - xh[c][e] * m2) + bf2f(rs[e]));
         *(u16x8_t*)(dxr + ch * 8) = o;
       }
     }
@@ -229,9 +232,9 @@ extern "C" int64_t ca_layernorm_bwd_partial_floats(int64_t rows, int32_t C) {
 }
 
 extern "C" int ca_layernorm_bwd(const void* dy, const void* x, const float* gamma,
-                                const float* beta, const float* stats, void* dx, float* dgamma,
-                                float* dbeta, float* partial, int64_t rows, int32_t C,
-                                int32_t act, void* stream) {
+                                const float* beta, const float* stats, const void* dres,
+                                void* dx, float* dgamma, float* dbeta, float* partial,
+                                int64_t rows, int32_t C, int32_t act, void* stream) {
   CA_CHECK_ARG(dy && x && gamma && stats && dx && partial, "ca_layernorm_bwd: null pointer");
   CA_CHECK_ARG(!act || beta, "ca_layernorm_bwd: act needs beta");
   CA_CHECK_ARG(rows > 0 && C > 0 && (C % 8) == 0 && C <= LN_MAXCH * 512,
@@ -243,8 +246,8 @@ extern "C" int ca_layernorm_bwd(const void* dy, const void* x, const float* gamm
   hipStream_t s = (hipStream_t)stream;
 #define LN_BWD(N)                                                                         \
   hipLaunchKernelGGL((ln_bwd_kernel<N>), grid, block, lds, s, (const unsigned short*)dy,  \
-                     (const unsigned short*)x, gamma, beta, stats, (unsigned short*)dx,   \
-                     partial, rows, C, act)
+                     (const unsigned short*)x, gamma, beta, stats,                        \
+                     (const unsigned short*)dres, (unsigned short*)dx, partial, rows, C, act)
   switch (nch) {
     case 1: LN_BWD(1); break;
     case 2: LN_BWD(2); break;
@@ -275,6 +278,7 @@ static int cs_slabs(int64_t rows) {
 }
 __global__ __launch_bounds__(256) void colsum_kernel(const unsigned short* __restrict__ x,
                                                      int64_t ld, int64_t rows, int N,
+                                                     const uint8_t* __restrict__ rowmask,
                                                      float* __restrict__ partial) {
   __shared__ float red[8][256 + 8];
   const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
@@ -287,6 +291,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const unsigned short* __res
   float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (col < N) {
     for (int64_t r = r0 + rl; r < r1; r += 8) {
+      if (rowmask && !rowmask[r]) continue;
       const u16x8_t u = *(const u16x8_t*)(x + r * ld + col);
 #pragma unroll
       for (int e = 0; e < 8; ++e) a[e] += bf2f(u[e]);
@@ -309,17 +314,43 @@ extern "C" int64_t ca_colsum_partial_floats(int64_t rows, int32_t N) {
   return (int64_t)cs_slabs(rows) * N;
 }
 
-extern "C" int ca_colsum_bf16(const void* x, int64_t ld, int64_t rows, int32_t N, float* out,
-                              int32_t accumulate, float* partial, void* stream) {
+extern "C" int ca_colsum_bf16(const void* x, int64_t ld, int64_t rows, int32_t N,
+                              const uint8_t* rowmask, float* out, int32_t accumulate,
+                              float* partial, void* stream) {
   CA_CHECK_ARG(x && out && partial, "ca_colsum_bf16: null pointer");
   CA_CHECK_ARG(rows > 0 && N > 0 && (N % 8) == 0 && (ld % 8) == 0,
                "ca_colsum_bf16: N and ld must be multiples of 8");
   const int ns = cs_slabs(rows);
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(colsum_kernel, dim3((N + 255) / 256, ns), dim3(256), 0, s,
-                     (const unsigned short*)x, ld, rows, N, partial);
+                     (const unsigned short*)x, ld, rows, N, rowmask, partial);
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((N + 255) / 256), dim3(256), 0, s, partial, ns,
                      (int64_t)N, N, out, accumulate);
   CA_CHECK_LAUNCH("ca_colsum_bf16");
+  return CA_OK;
+}
+
+// ---- out = dy * gelu'(u) -------------------------------------------------------------------
+__global__ void dgelu_mul_kernel(const unsigned short* __restrict__ dy,
+                                 const unsigned short* __restrict__ u,
+                                 unsigned short* __restrict__ out, int64_t n8) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const u16x8_t a = *(const u16x8_t*)(dy + i * 8);
+    const u16x8_t b = *(const u16x8_t*)(u + i * 8);
+    u16x8_t o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = f2bf(bf2f(a[e]) * dgelu_erf(bf2f(b[e])));
+    *(u16x8_t*)(out + i * 8) = o;
+  }
+}
+extern "C" int ca_dgelu_mul(const void* dy, const void* u, void* out, int64_t n, void* stream) {
+  CA_CHECK_ARG(dy && u && out && n > 0 && (n % 8) == 0, "ca_dgelu_mul: n must be a multiple of 8");
+  int64_t g = (n / 8 + 255) / 256;
+  if (g > 8192) g = 8192;
+  hipLaunchKernelGGL(dgelu_mul_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream,
+                     (const unsigned short*)dy, (const unsigned short*)u, (unsigned short*)out,
+                     n / 8);
+  CA_CHECK_LAUNCH("ca_dgelu_mul");
   return CA_OK;
 }

@@ -1,0 +1,209 @@
+// Attention softmax forward/backward (the middle of SDPA), cross-entropy, masked argmax.
+// One 64-lane wave per row; rows are a few KB so the extra passes hit L1/L2, HBM sees one
+// read of the scores and one write of the probabilities.
+#include "common.h"
+
+#define NEG_INF (-__builtin_inff())
+
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restrict__ sc,
+                                                          unsigned short* __restrict__ pr,
+                                                          const int32_t* __restrict__ klen,
+                                                          int64_t nrows, int H, int Tq, int Tk,
+                                                          int64_t ld, int causal) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < nrows; row += (int64_t)gridDim.x * 4) {
+    const int64_t bh = row / Tq;
+    const int q = (int)(row % Tq);
+    int lim = Tk;
+    if (klen) {
+      const int kl = klen[bh / H];
+      lim = kl < lim ? kl : lim;
+    }
+    if (causal) lim = (q + 1) < lim ? (q + 1) : lim;
+    const float* s = sc + row * ld;
+    unsigned short* p = pr + row * ld;
+    float mx = NEG_INF;
+    for (int c = lane * 4; c < lim; c += 256) {
+      const f32x4_t v = *(const f32x4_t*)(s + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (c + e < lim) mx = fmaxf(mx, v[e]);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int c = lane * 4; c < lim; c += 256) {
+      const f32x4_t v = *(const f32x4_t*)(s + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (c + e < lim) sum += __expf(v[e] - mx);
+    }
+    sum = wave_sum(sum);
+    const float inv = sum > 0.f ? 1.f / sum : 0.f;
+    for (int c = lane * 4; c < ld; c += 256) {
+      u16x4_t o;
+      if (c < lim) {
+        const f32x4_t v = *(const f32x4_t*)(s + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (c + e < lim) ? f2bf(__expf(v[e] - mx) * inv) : 0;
+      } else {
+        o = (u16x4_t){0, 0, 0, 0};
+      }
+      *(u16x4_t*)(p + c) = o;
+    }
+  }
+}
+
+extern "C" int ca_softmax_fwd(const float* scores, void* probs, const int32_t* klen, int32_t BH,
+                              int32_t H, int32_t Tq, int32_t Tk, int64_t ld, int32_t causal,
+                              void* stream) {
+  CA_CHECK_ARG(scores && probs && BH > 0 && H > 0 && Tq > 0 && Tk > 0, "ca_softmax_fwd: bad arg");
+  CA_CHECK_ARG(ld >= Tk && (ld % 8) == 0, "ca_softmax_fwd: ld must be >= Tk and a multiple of 8");
+  const int64_t nrows = (int64_t)BH * Tq;
+  int64_t g = (nrows + 3) / 4;
+  if (g > 16384) g = 16384;
+  hipLaunchKernelGGL(softmax_fwd_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, scores,
+                     (unsigned short*)probs, klen, nrows, H, Tq, Tk, ld, causal);
+  CA_CHECK_LAUNCH("ca_softmax_fwd");
+  return CA_OK;
+}
+
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ dp,
+                                                          const unsigned short* __restrict__ pr,
+                                                          unsigned short* __restrict__ ds,
+                                                          float scale, int64_t nrows, int Tk,
+                                                          int64_t ld) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < nrows; row += (int64_t)gridDim.x * 4) {
+    const float* d = dp + row * ld;
+    const unsigned short* p = pr + row * ld;
+    unsigned short* o = ds + row * ld;
+    float dot = 0.f;
+    for (int c = lane * 4; c < Tk; c += 256) {
+      const f32x4_t v = *(const f32x4_t*)(d + c);
+      const u16x4_t u = *(const u16x4_t*)(p + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (c + e < Tk) dot += v[e] * bf2f(u[e]);
+    }
+    dot = wave_sum(dot);
+    for (int c = lane * 4; c < ld; c += 256) {
+      u16x4_t r;
+      if (c < Tk) {
+        const f32x4_t v = *(const f32x4_t*)(d + c);
+        const u16x4_t u = *(const u16x4_t*)(p + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          r[e] = (c + e < Tk) ? f2bf(bf2f(u[e]) * (v[e] - dot) * scale) : 0;
+      } else {
+        r = (u16x4_t){0, 0, 0, 0};
+      }
+      *(u16x4_t*)(o + c) = r;
+    }
+  }
+}
+
+extern "C" int ca_softmax_bwd(const float* dprobs, const void* probs, void* dscores, float scale,
+                              int32_t BH, int32_t Tq, int32_t Tk, int64_t ld, void* stream) {
+  CA_CHECK_ARG(dprobs && probs && dscores && BH > 0 && Tq > 0 && Tk > 0, "ca_softmax_bwd: bad arg");
+  CA_CHECK_ARG(ld >= Tk && (ld % 8) == 0, "ca_softmax_bwd: ld must be >= Tk and a multiple of 8");
+  const int64_t nrows = (int64_t)BH * Tq;
+  int64_t g = (nrows + 3) / 4;
+  if (g > 16384) g = 16384;
+  hipLaunchKernelGGL(softmax_bwd_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, dprobs,
+                     (const unsigned short*)probs, (unsigned short*)dscores, scale, nrows, Tk, ld);
+  CA_CHECK_LAUNCH("ca_softmax_bwd");
+  return CA_OK;
+}
+
+// ---- cross-entropy (Whisper LM loss) ---------------------------------------------------------
+// $TF/models/whisper/modeling_whisper.py:1084-1087: CrossEntropyLoss(ignore_index=-100), mean
+// taken by the caller (loss_sum / count).  One wave per row; V ~ 51 866.
+__global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ lg,
+                                                 const int32_t* __restrict__ labels,
+                                                 float* __restrict__ loss_sum,
+                                                 int32_t* __restrict__ count,
+                                                 float* __restrict__ grad, int64_t rows, int V,
+                                                 int64_t ldv, int ignore) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+    const float* l = lg + row * ldv;
+    float* g = grad ? grad + row * ldv : nullptr;
+    const int lab = labels[row];
+    if (lab == ignore || lab < 0 || lab >= V) {
+      if (g)
+        for (int c = lane; c < ldv; c += 64) g[c] = 0.f;
+      continue;
+    }
+    float mx = NEG_INF;
+    for (int c = lane; c < V; c += 64) mx = fmaxf(mx, l[c]);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int c = lane; c < V; c += 64) sum += __expf(l[c] - mx);
+    sum = wave_sum(sum);
+    const float lse = mx + __logf(sum);
+    if (lane == 0) {
+      atomicAdd(loss_sum, lse - l[lab]);
+      atomicAdd(count, 1);
+    }
+    if (g) {
+      for (int c = lane; c < ldv; c += 64)
+        g[c] = c < V ? __expf(l[c] - lse) - (c == lab ? 1.f : 0.f) : 0.f;
+    }
+  }
+}
+
+extern "C" int ca_cross_entropy_fwd_bwd(const float* logits, const int32_t* labels,
+                                        float* loss_sum, int32_t* count, float* grad,
+                                        int64_t rows, int32_t V, int64_t ldv,
+                                        int32_t ignore_index, void* stream) {
+  CA_CHECK_ARG(logits && labels && loss_sum && count && rows > 0 && V > 0 && ldv >= V,
+               "ca_cross_entropy_fwd_bwd: bad argument");
+  int64_t g = (rows + 3) / 4;
+  if (g > 8192) g = 8192;
+  hipLaunchKernelGGL(ce_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, logits, labels,
+                     loss_sum, count, grad, rows, V, ldv, ignore_index);
+  CA_CHECK_LAUNCH("ca_cross_entropy_fwd_bwd");
+  return CA_OK;
+}
+
+// ---- masked argmax (greedy generation) -------------------------------------------------------
+__global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ lg,
+                                                     const uint8_t* __restrict__ suppress,
+                                                     int32_t* __restrict__ out, int64_t rows,
+                                                     int V, int64_t ldv) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+    const float* l = lg + row * ldv;
+    float best = NEG_INF;
+    int bi = 0x7fffffff;
+    for (int c = lane; c < V; c += 64) {
+      if (suppress && suppress[c]) continue;
+      const float v = l[c];
+      if (v > best || (v == best && c < bi)) {
+        best = v;
+        bi = c;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ob = __shfl_xor(best, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ob > best || (ob == best && oi < bi)) {
+        best = ob;
+        bi = oi;
+      }
+    }
+    if (lane == 0) out[row] = bi == 0x7fffffff ? 0 : bi;
+  }
+}
+
+extern "C" int ca_argmax_masked(const float* logits, const uint8_t* suppress, int32_t* out,
+                                int64_t rows, int32_t V, int64_t ldv, void* stream) {
+  CA_CHECK_ARG(logits && out && rows > 0 && V > 0 && ldv >= V, "ca_argmax_masked: bad argument");
+  int64_t g = (rows + 3) / 4;
+  if (g > 8192) g = 8192;
+  hipLaunchKernelGGL(argmax_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, logits,
+                     suppress, out, rows, V, ldv);
+  CA_CHECK_LAUNCH("ca_argmax_masked");
+  return CA_OK;
+}

@@ -1,0 +1,234 @@
+"""Thin host wrappers over the C ABI (include/coral_amd.h): torch tensors in, kernel enqueued on
+torch's current HIP stream.  PyTorch is used here for device memory and streams only — every
+arithmetic op on the hot path is a kernel of libcoral_amd.so.  No fallbacks: a missing library
+or a non-GPU tensor raises.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import (EPI_DGELU, EPI_GELU, EPI_GELU_RESIDUAL, EPI_NONE, EPI_RESIDUAL, KMAJOR,
+                   MNMAJOR, CaGemmDesc, CoralAmdError, check)
+
+__all__ = ["KMAJOR", "MNMAJOR", "EPI_NONE", "EPI_GELU", "EPI_RESIDUAL", "EPI_DGELU",
+           "EPI_GELU_RESIDUAL", "CoralAmdError"]
+
+_ELT = {torch.bfloat16: 2, torch.float32: 4, torch.int32: 4, torch.uint8: 1, torch.int64: 8}
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: torch.Tensor | None, off: int = 0) -> int | None:
+    """Device pointer of `t` advanced by `off` ELEMENTS (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise CoralAmdError("coral_amd ops need device tensors (there is no CPU path)")
+    return t.data_ptr() + off * _ELT[t.dtype]
+
+
+def lib():
+    return _lib.load()
+
+
+def gemm(A, B, Cout, *, M, N, K, lda, ldb, ldc, a_layout=KMAJOR, b_layout=KMAJOR, a_off=0,
+         b_off=0, c_off=0, bias=None, bias_off=0, R=None, r_off=0, ldr=0, C2=None, c2_off=None,
+         epilogue=EPI_NONE, out_f32=None, accumulate=False, alpha=1.0, batch1=1, batch2=1,
+         sA=(0, 0), sB=(0, 0), sC=(0, 0), sR=(0, 0), sBias=(0, 0), a_kseg=0, a_kseg_stride=0, b_kseg=0,
+         b_kseg_stride=0, dropout_p=0.0, dropout_seed=0):
+    """C = epilogue(alpha * opA @ opB^T) — see CaGemmDesc in include/coral_amd.h."""
+    d = CaGemmDesc()
+    d.A, d.B = _p(A, a_off), _p(B, b_off)
+    d.C = _p(Cout, c_off) if Cout is not None else None
+    if C2 is not None:
+        d.C2 = _p(C2, c_off if c2_off is None else c2_off)
+    if R is not None:
+        d.R = _p(R, r_off)
+    if bias is not None:
+        d.bias = _p(bias, bias_off)
+    d.M, d.N, d.K = M, N, K
+    d.a_layout, d.b_layout = a_layout, b_layout
+    d.lda, d.ldb, d.ldc, d.ldr = lda, ldb, ldc, ldr
+    d.a_kseg, d.b_kseg = a_kseg, b_kseg
+    d.a_kseg_stride, d.b_kseg_stride = a_kseg_stride, b_kseg_stride
+    d.batch1, d.batch2 = batch1, batch2
+    d.sA1, d.sA2 = sA
+    d.sB1, d.sB2 = sB
+    d.sC1, d.sC2 = sC
+    d.sR1, d.sR2 = sR
+    d.sBias1, d.sBias2 = sBias
+    d.epilogue = epilogue
+    ref_out = Cout if Cout is not None else C2
+    d.out_f32 = int(ref_out.dtype == torch.float32) if out_f32 is None else int(out_f32)
+    d.accumulate = int(accumulate)
+    d.alpha = alpha
+    d.dropout_p = dropout_p
+    d.dropout_seed = dropout_seed
+    check(lib().ca_gemm_bf16(C.byref(d), _stream()), "ca_gemm_bf16")
+
+
+def layernorm_fwd(x, gamma, beta, y, stats, rows, Cn, eps=1e-5, act=0, x_off=0, y_off=0):
+    check(lib().ca_layernorm_fwd(_p(x, x_off), _p(gamma), _p(beta), _p(y, y_off), _p(stats), rows,
+                                 Cn, eps, act, _stream()), "ca_layernorm_fwd")
+
+
+def layernorm_bwd_partial_floats(rows, Cn):
+    return lib().ca_layernorm_bwd_partial_floats(rows, Cn)
+
+
+def layernorm_bwd(dy, x, gamma, beta, stats, dres, dx, dgamma, dbeta, partial, rows, Cn, act=0):
+    check(lib().ca_layernorm_bwd(_p(dy), _p(x), _p(gamma), _p(beta), _p(stats), _p(dres), _p(dx),
+                                 _p(dgamma), _p(dbeta), _p(partial), rows, Cn, act, _stream()),
+          "ca_layernorm_bwd")
+
+
+def colsum_partial_floats(rows, N):
+    return lib().ca_colsum_partial_floats(rows, N)
+
+
+def colsum(x, ld, rows, N, out, partial, accumulate=True, rowmask=None, x_off=0, out_off=0):
+    check(lib().ca_colsum_bf16(_p(x, x_off), ld, rows, N, _p(rowmask), _p(out, out_off),
+                               int(accumulate), _p(partial), _stream()), "ca_colsum_bf16")
+
+
+def dgelu_mul(dy, u, out, n):
+    check(lib().ca_dgelu_mul(_p(dy), _p(u), _p(out), n, _stream()), "ca_dgelu_mul")
+
+
+def wave_normalize(x, lengths, y, B, N, eps=1e-7):
+    check(lib().ca_wave_normalize(_p(x), _p(lengths), _p(y), B, N, eps, _stream()),
+          "ca_wave_normalize")
+
+
+def conv0_fwd(x, w, bias, gamma, beta, y, B, N, Cn, k, stride, eps=1e-5):
+    check(lib().ca_conv0_ln_gelu_fwd(_p(x), _p(w), _p(bias), _p(gamma), _p(beta), _p(y), B, N, Cn,
+                                     k, stride, eps, _stream()), "ca_conv0_ln_gelu_fwd")
+
+
+def conv0_bwd_partial_floats(B, N, Cn, k, stride):
+    return lib().ca_conv0_bwd_partial_floats(B, N, Cn, k, stride)
+
+
+def conv0_bwd(x, w, bias, gamma, beta, dy, dw, dbias, dgamma, dbeta, partial, B, N, Cn, k,
+              stride, eps=1e-5):
+    check(lib().ca_conv0_ln_gelu_bwd(_p(x), _p(w), _p(bias), _p(gamma), _p(beta), _p(dy), _p(dw),
+                                     _p(dbias), _p(dgamma), _p(dbeta), _p(partial), B, N, Cn, k,
+                                     stride, eps, _stream()), "ca_conv0_ln_gelu_bwd")
+
+
+def col2im_1d(dcol, dx, B, T, L, Cn, k, stride):
+    check(lib().ca_col2im_1d(_p(dcol), _p(dx), B, T, L, Cn, k, stride, _stream()), "ca_col2im_1d")
+
+
+def softmax_fwd(scores, probs, klen, BH, H, Tq, Tk, ld, causal=False):
+    check(lib().ca_softmax_fwd(_p(scores), _p(probs), _p(klen), BH, H, Tq, Tk, ld, int(causal),
+                               _stream()), "ca_softmax_fwd")
+
+
+def softmax_bwd(dprobs, probs, dscores, scale, BH, Tq, Tk, ld):
+    check(lib().ca_softmax_bwd(_p(dprobs), _p(probs), _p(dscores), scale, BH, Tq, Tk, ld,
+                               _stream()), "ca_softmax_bwd")
+
+
+def ctc_workspace_bytes(B, T, Lmax):
+    return lib().ca_ctc_workspace_bytes(B, T, Lmax)
+
+
+def ctc_loss_fwd_bwd(logits, labels, in_len, nll, grad, gscale, ws, B, T, V, ldv, Lmax, blank,
+                     zero_infinity=True):
+    check(lib().ca_ctc_loss_fwd_bwd(_p(logits), _p(labels), _p(in_len), _p(nll), _p(grad),
+                                    _p(gscale), _p(ws), B, T, V, ldv, Lmax, blank,
+                                    int(zero_infinity), _stream()), "ca_ctc_loss_fwd_bwd")
+
+
+def ctc_greedy_decode(logits, in_len, raw, ids, out_len, B, T, V, ldv, blank):
+    check(lib().ca_ctc_greedy_decode(_p(logits), _p(in_len), _p(raw), _p(ids), _p(out_len), B, T,
+                                     V, ldv, blank, _stream()), "ca_ctc_greedy_decode")
+
+
+def mask_frames(h, tmask, fmask, embed, flen, B, T, Cn):
+    check(lib().ca_mask_frames(_p(h), _p(tmask), _p(fmask), _p(embed), _p(flen), B, T, Cn,
+                               _stream()), "ca_mask_frames")
+
+
+def regroup_pad(x, xg, B, T, G, Cg, pad):
+    check(lib().ca_regroup_pad(_p(x), _p(xg), B, T, G, Cg, pad, _stream()), "ca_regroup_pad")
+
+
+def posconv_partial_floats(K):
+    return lib().ca_posconv_partial_floats(K)
+
+
+def posconv_weight(v, g, wf, wb, norm, partial, d, Cg, K):
+    check(lib().ca_posconv_weight(_p(v), _p(g), _p(wf), _p(wb), _p(norm), _p(partial), d, Cg, K,
+                                  _stream()), "ca_posconv_weight")
+
+
+def posconv_weight_bwd(dwf, v, g, norm, dv, dg, partial, d, Cg, K):
+    check(lib().ca_posconv_weight_bwd(_p(dwf), _p(v), _p(g), _p(norm), _p(dv), _p(dg),
+                                      _p(partial), d, Cg, K, _stream()), "ca_posconv_weight_bwd")
+
+
+def cast_f32_bf16(x, y, n, x_off=0, y_off=0):
+    check(lib().ca_cast_f32_bf16(_p(x, x_off), _p(y, y_off), n, _stream()), "ca_cast_f32_bf16")
+
+
+def cast_bf16_f32(x, y, n):
+    check(lib().ca_cast_bf16_f32(_p(x), _p(y), n, _stream()), "ca_cast_bf16_f32")
+
+
+def transpose_f32_bf16(x, y, rows, cols):
+    check(lib().ca_transpose_f32_bf16(_p(x), _p(y), rows, cols, _stream()), "ca_transpose_f32_bf16")
+
+
+def conv_weight_reorder(w, wr, Co, Ci, k, w_off=0):
+    check(lib().ca_conv_weight_reorder(_p(w, w_off), _p(wr), Co, Ci, k, _stream()),
+          "ca_conv_weight_reorder")
+
+
+def conv_weight_grad_reorder(dwr, dw, Co, Ci, k, dw_off=0):
+    check(lib().ca_conv_weight_grad_reorder(_p(dwr), _p(dw, dw_off), Co, Ci, k, _stream()),
+          "ca_conv_weight_grad_reorder")
+
+
+def sumsq(g, n, out, partial, accumulate=False):
+    check(lib().ca_sumsq_f32(_p(g), n, _p(out), int(accumulate), _p(partial), _stream()),
+          "ca_sumsq_f32")
+
+
+def adamw_step(p, m, v, g, p16, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0,
+               max_norm=0.0, gnorm_sq=None):
+    check(lib().ca_adamw_step(_p(p), _p(m), _p(v), _p(g), _p(p16), n, lr, beta1, beta2, eps,
+                              weight_decay, step, grad_scale, max_norm, _p(gnorm_sq), _stream()),
+          "ca_adamw_step")
+
+
+def logmel_workspace_bytes(B):
+    return lib().ca_logmel_workspace_bytes(B)
+
+
+def logmel(wave, mel_filters, out, ws, B, N, n_mels):
+    check(lib().ca_logmel(_p(wave), _p(mel_filters), _p(out), _p(ws), B, N, n_mels, _stream()),
+          "ca_logmel")
+
+
+def cross_entropy_fwd_bwd(logits, labels, loss_sum, count, grad, rows, V, ldv, ignore_index=-100):
+    check(lib().ca_cross_entropy_fwd_bwd(_p(logits), _p(labels), _p(loss_sum), _p(count), _p(grad),
+                                         rows, V, ldv, ignore_index, _stream()),
+          "ca_cross_entropy_fwd_bwd")
+
+
+def argmax_masked(logits, suppress, out, rows, V, ldv):
+    check(lib().ca_argmax_masked(_p(logits), _p(suppress), _p(out), rows, V, ldv, _stream()),
+          "ca_argmax_masked")
+
+
+def embed_tokens(table, pos, ids, pos_ids, y, rows, Cn):
+    check(lib().ca_embed_tokens(_p(table), _p(pos), _p(ids), _p(pos_ids), _p(y), rows, Cn,
+                                _stream()), "ca_embed_tokens")

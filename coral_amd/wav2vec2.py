@@ -1,0 +1,611 @@
+"""MI355X-native Wav2Vec2ForCTC engine (XLS-R family) behind CoRal's `model=wav2vec2-*` keys.
+
+Host-side sequencing of the C-ABI kernels in libcoral_amd.so: forward, hand-written backward
+and parameter/gradient storage.  It mirrors what `Wav2Vec2ForCTC.from_pretrained(...)` gives
+CoRal (R/src/coral/wav2vec2.py:104-126): `model(input_values, attention_mask, labels)` ->
+loss + logits ($TF/models/wav2vec2/modeling_wav2vec2.py:1667-1736), HF parameter names, CTC
+with blank = pad id, reduction "sum", zero_infinity.
+
+HBM layout
+  * parameters: one flat fp32 master buffer + one flat fp32 gradient buffer + one flat bf16
+    compute copy (same offsets), ordered [front | layer 0 | ... | layer L-1 | head] so that a
+    data-parallel bucket is a contiguous slice (see coral_amd/trainer.py);
+  * activations: channels-last [B*T, C] bf16; q,k,v of a layer live in one [B*T, 3d] matrix;
+    attention scores/probabilities are [B, H, T, Tp] with Tp = T rounded up to 8;
+  * conv layers 1..6 and the grouped positional conv run as implicit GEMMs over overlapping-row
+    views (no im2col is ever materialised in the forward pass).
+"""
+
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+
+import torch
+
+from . import ops
+from .ops import EPI_DGELU, EPI_GELU, EPI_GELU_RESIDUAL, EPI_NONE, EPI_RESIDUAL, KMAJOR, MNMAJOR
+
+
+@dataclass
+class Wav2Vec2Shape:
+    """Architecture hyper-parameters (HF Wav2Vec2Config subset used by XLS-R)."""
+
+    hidden_size: int = 1024
+    num_hidden_layers: int = 24
+    num_attention_heads: int = 16
+    intermediate_size: int = 4096
+    conv_dim: tuple = (512,) * 7
+    conv_kernel: tuple = (10, 3, 3, 3, 3, 2, 2)
+    conv_stride: tuple = (5, 2, 2, 2, 2, 2, 2)
+    num_conv_pos_embeddings: int = 128
+    num_conv_pos_embedding_groups: int = 16
+    vocab_size: int = 46
+    pad_token_id: int = 45
+    layer_norm_eps: float = 1e-5
+    ctc_loss_reduction: str = "sum"
+    ctc_zero_infinity: bool = True
+    activation_dropout: float = 0.0
+    layerdrop: float = 0.0
+
+    @property
+    def head_dim(self):
+        return self.hidden_size // self.num_attention_heads
+
+
+# CoRal model keys -> XLS-R shapes (R/config/model/wav2vec2-{small,medium,large}.yaml:3)
+CORAL_W2V2_SHAPES = {
+    "wav2vec2-small": dict(hidden_size=1024, num_hidden_layers=24, intermediate_size=4096),
+    "wav2vec2-medium": dict(hidden_size=1280, num_hidden_layers=48, intermediate_size=5120),
+    "wav2vec2-large": dict(hidden_size=1920, num_hidden_layers=48, intermediate_size=7680),
+}
+
+
+def _r8(n: int) -> int:
+    return (n + 7) // 8 * 8
+
+
+class ParamStore:
+    """Flat fp32 master / fp32 grad / bf16 compute buffers with HF-named views."""
+
+    def __init__(self, shapes: list[tuple[str, tuple, str]], device):
+        self.index: dict[str, tuple[int, tuple]] = {}
+        self.buckets: dict[str, list[int]] = {}
+        off = 0
+        for name, shape, bucket in shapes:
+            n = int(math.prod(shape))
+            self.index[name] = (off, tuple(shape))
+            b = self.buckets.setdefault(bucket, [off, off])
+            off += _r8(n)
+            b[1] = off
+        self.numel = off
+        self.device = device
+        self.p32 = torch.zeros(off, dtype=torch.float32, device=device)
+        self.g32 = torch.zeros(off, dtype=torch.float32, device=device)
+        self.p16 = torch.zeros(off, dtype=torch.bfloat16, device=device)
+
+    def off(self, name: str) -> int:
+        return self.index[name][0]
+
+    def view(self, name: str, which: str = "p32") -> torch.Tensor:
+        off, shape = self.index[name]
+        n = int(math.prod(shape))
+        return getattr(self, which)[off:off + n].view(shape)
+
+    def names(self):
+        return list(self.index.keys())
+
+    def refresh_bf16(self):
+        ops.cast_f32_bf16(self.p32, self.p16, self.numel)
+
+
+def w2v2_param_list(s: Wav2Vec2Shape) -> list[tuple[str, tuple, str]]:
+    """(HF name, shape, bucket) in storage order; q/k/v of a layer are adjacent on purpose."""
+    d, f = s.hidden_size, s.intermediate_size
+    out = []
+    cin = 1
+    for i, (co, k) in enumerate(zip(s.conv_dim, s.conv_kernel)):
+        p = f"wav2vec2.feature_extractor.conv_layers.{i}."
+        out += [(p + "conv.weight", (co, cin, k), "front"), (p + "conv.bias", (co,), "front"),
+                (p + "layer_norm.weight", (co,), "front"), (p + "layer_norm.bias", (co,), "front")]
+        cin = co
+    K, G = s.num_conv_pos_embeddings, s.num_conv_pos_embedding_groups
+    out += [
+        ("wav2vec2.feature_projection.layer_norm.weight", (cin,), "front"),
+        ("wav2vec2.feature_projection.layer_norm.bias", (cin,), "front"),
+        ("wav2vec2.feature_projection.projection.weight", (d, cin), "front"),
+        ("wav2vec2.feature_projection.projection.bias", (d,), "front"),
+        ("wav2vec2.masked_spec_embed", (d,), "front"),
+        ("wav2vec2.encoder.pos_conv_embed.conv.bias", (d,), "front"),
+        ("wav2vec2.encoder.pos_conv_embed.conv.parametrizations.weight.original0", (1, 1, K), "front"),
+        ("wav2vec2.encoder.pos_conv_embed.conv.parametrizations.weight.original1", (d, d // G, K), "front"),
+    ]
+    for l in range(s.num_hidden_layers):
+        p = f"wav2vec2.encoder.layers.{l}."
+        b = f"layer{l}"
+        out += [(p + "layer_norm.weight", (d,), b), (p + "layer_norm.bias", (d,), b)]
+        for n in ("q_proj", "k_proj", "v_proj"):
+            out.append((p + f"attention.{n}.weight", (d, d), b))
+        for n in ("q_proj", "k_proj", "v_proj"):
+            out.append((p + f"attention.{n}.bias", (d,), b))
+        out += [(p + "attention.out_proj.weight", (d, d), b), (p + "attention.out_proj.bias", (d,), b),
+                (p + "final_layer_norm.weight", (d,), b), (p + "final_layer_norm.bias", (d,), b),
+                (p + "feed_forward.intermediate_dense.weight", (f, d), b),
+                (p + "feed_forward.intermediate_dense.bias", (f,), b),
+                (p + "feed_forward.output_dense.weight", (d, f), b),
+                (p + "feed_forward.output_dense.bias", (d,), b)]
+    out += [("wav2vec2.encoder.layer_norm.weight", (d,), "head"),
+            ("wav2vec2.encoder.layer_norm.bias", (d,), "head"),
+            ("lm_head.weight", (s.vocab_size, d), "head"), ("lm_head.bias", (s.vocab_size,), "head")]
+    return out
+
+
+class CTCOutput(dict):
+    """`model(**batch)` result: out["loss"], out.loss, out.logits (HF CausalLMOutput-like)."""
+
+    __getattr__ = dict.get
+
+    def __getitem__(self, k):
+        if isinstance(k, int):
+            return [self["loss"], self["logits"]][k] if self.get("loss") is not None else self["logits"]
+        return dict.__getitem__(self, k)
+
+
+class Wav2Vec2CTCEngine:
+    """Forward + backward of Wav2Vec2ForCTC as a fixed sequence of HIP kernels."""
+
+    def __init__(self, shape: Wav2Vec2Shape, device="cuda:0", freeze_base: bool = False):
+        self.s = shape
+        self.device = torch.device(device)
+        ops.lib()  # fail loudly if the HIP library is not built
+        if not torch.cuda.is_available():
+            raise ops.CoralAmdError("Wav2Vec2CTCEngine needs a GPU: there is no CPU path")
+        s = shape
+        assert s.conv_dim[0] == 512 and s.conv_kernel[0] == 10, "layer-0 kernel expects C=512,k=10"
+        assert s.hidden_size % 8 == 0 and (s.hidden_size // s.num_conv_pos_embedding_groups) % 8 == 0
+        assert s.head_dim % 8 == 0
+        self.store = ParamStore(w2v2_param_list(s), self.device)
+        self.freeze_base = freeze_base
+        self.training = False
+        self._ws = None
+        self._ws_key = None
+        self._saved = None
+        self.step_seed = 0
+        d = s.hidden_size
+        G = s.num_conv_pos_embedding_groups
+        K = s.num_conv_pos_embeddings
+        dev = self.device
+        # reordered / derived bf16 weights
+        self.conv_wr = [None] + [
+            torch.zeros(s.conv_dim[i] * s.conv_kernel[i] * s.conv_dim[i - 1], dtype=torch.bfloat16, device=dev)
+            for i in range(1, len(s.conv_dim))]
+        self.pc_wf = torch.zeros(d * K * (d // G), dtype=torch.bfloat16, device=dev)
+        self.pc_wb = torch.zeros(d * K * (d // G), dtype=torch.bfloat16, device=dev)
+        self.pc_norm = torch.zeros(K, dtype=torch.float32, device=dev)
+        self.pc_partial = torch.zeros(ops.posconv_partial_floats(K), dtype=torch.float32, device=dev)
+        self.zero_embed = torch.zeros(d, dtype=torch.bfloat16, device=dev)
+
+    # ---- parameters ------------------------------------------------------------------------
+    def load_state_dict(self, P: dict):
+        """Copy HF-named fp32 tensors into the flat master buffer and refresh compute copies."""
+        missing = [n for n in self.store.names() if n not in P]
+        if missing:
+            raise KeyError(f"missing parameters: {missing[:4]}...")
+        for n in self.store.names():
+            self.store.view(n).copy_(P[n].to(self.device, torch.float32).reshape(self.store.index[n][1]))
+        self.refresh_compute_weights()
+
+    def state_dict(self) -> dict:
+        return {n: self.store.view(n).detach().clone() for n in self.store.names()}
+
+    def grad_dict(self) -> dict:
+        return {n: self.store.view(n, "g32") for n in self.store.names()}
+
+    def zero_grad(self):
+        self.store.g32.zero_()
+
+    def train(self, mode: bool = True):
+        self.training = mode
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    def refresh_compute_weights(self):
+        """fp32 masters -> bf16 copies, conv weight reorders, weight-normed pos-conv weights."""
+        s, st = self.s, self.store
+        st.refresh_bf16()
+        for i in range(1, len(s.conv_dim)):
+            ops.conv_weight_reorder(st.p32, self.conv_wr[i], s.conv_dim[i], s.conv_dim[i - 1],
+                                    s.conv_kernel[i],
+                                    w_off=st.off(f"wav2vec2.feature_extractor.conv_layers.{i}.conv.weight"))
+        d, G, K = s.hidden_size, s.num_conv_pos_embedding_groups, s.num_conv_pos_embeddings
+        pre = "wav2vec2.encoder.pos_conv_embed.conv.parametrizations.weight."
+        ops.posconv_weight(st.view(pre + "original1"), st.view(pre + "original0"), self.pc_wf, self.pc_wb,
+                           self.pc_norm, self.pc_partial, d, d // G, K)
+
+    # ---- shapes / workspaces -------------------------------------------------------------------
+    def conv_lengths(self, N: int) -> list[int]:
+        out, n = [], N
+        for k, st in zip(self.s.conv_kernel, self.s.conv_stride):
+            n = (n - k) // st + 1
+            out.append(n)
+        return out
+
+    def feat_lengths(self, sample_lengths: torch.Tensor) -> torch.Tensor:
+        n = sample_lengths.clone().long()
+        for k, st in zip(self.s.conv_kernel, self.s.conv_stride):
+            n = torch.div(n - k, st, rounding_mode="floor") + 1
+        return n
+
+    def _workspace(self, B: int, N: int):
+        key = (B, N)
+        if self._ws_key == key:
+            return self._ws
+        s, dev = self.s, self.device
+        d, f, H = s.hidden_size, s.intermediate_size, s.num_attention_heads
+        L = s.num_hidden_layers
+        Ts = self.conv_lengths(N)
+        T = Ts[-1]
+        M = B * T
+        Tp = _r8(T)
+        G, K = s.num_conv_pos_embedding_groups, s.num_conv_pos_embeddings
+        Cg = d // G
+        bf, f32 = torch.bfloat16, torch.float32
+        z = lambda *sh, dt=bf: torch.zeros(*sh, dtype=dt, device=dev)  # noqa: E731
+        w = {"B": B, "N": N, "Ts": Ts, "T": T, "M": M, "Tp": Tp}
+        C0 = s.conv_dim[0]
+        w["a"] = [z(B * Ts[i] * s.conv_dim[i]) for i in range(7)]          # conv block outputs
+        w["y"] = [None] + [z(B * Ts[i] * s.conv_dim[i]) for i in range(1, 7)]  # pre-LN conv outputs
+        w["cstats"] = [None] + [z(B * Ts[i] * 2, dt=f32) for i in range(1, 7)]
+        w["fp_stats"] = z(M * 2, dt=f32)
+        w["xln"] = z(M * C0)
+        w["h0"] = z(M * d)
+        w["xg"] = z(B * G * (T + K) * Cg + 8 * Cg)
+        w["pc_pre"] = z(M * d)
+        w["h"] = [z(M * d) for _ in range(L + 1)]      # residual stream entering layer l (h[L] = out)
+        w["x1"] = [z(M * d) for _ in range(L)]
+        w["st1"] = [z(M * 2, dt=f32) for _ in range(L)]
+        w["qkv"] = [z(M * 3 * d) for _ in range(L)]
+        w["P"] = [z(B * H * T * Tp) for _ in range(L)]
+        w["ctx"] = [z(M * d) for _ in range(L)]
+        w["h1"] = [z(M * d) for _ in range(L)]
+        w["x2"] = [z(M * d) for _ in range(L)]
+        w["st2"] = [z(M * 2, dt=f32) for _ in range(L)]
+        w["u"] = [z(M * f) for _ in range(L)]
+        w["g"] = [z(M * f) for _ in range(L)]
+        w["S"] = z(B * H * T * Tp, dt=f32)             # transient scores / dprobs
+        w["hf"] = z(M * d)
+        w["stf"] = z(M * 2, dt=f32)
+        Vp = _r8(s.vocab_size)
+        w["Vp"] = Vp
+        w["logits"] = z(M * Vp, dt=f32)
+        w["dlogits"] = z(M * Vp, dt=f32)
+        w["dlogits16"] = z(M * Vp)
+        w["nll"] = z(B, dt=f32)
+        # backward scratch
+        w["dA"] = z(M * d)
+        w["dB"] = z(M * d)
+        w["dC"] = z(M * d)
+        w["dqkv"] = z(M * 3 * d)
+        w["dS"] = z(B * H * T * Tp)
+        w["du"] = z(M * f)
+        w["dxg"] = z(B * G * (T + K) * Cg + 8 * Cg)
+        w["dwf"] = z(d * K * Cg, dt=f32)
+        nmax = max(B * Ts[i] * s.conv_kernel[i] * s.conv_dim[i - 1] for i in range(1, 7))
+        w["dcol"] = z(nmax)
+        w["dconv"] = [z(B * Ts[i] * s.conv_dim[i]) for i in range(7)]   # grads wrt conv block outputs
+        w["dy"] = z(max(B * Ts[i] * s.conv_dim[i] for i in range(1, 7)))
+        w["dwr"] = z(max(s.conv_dim[i] * s.conv_kernel[i] * s.conv_dim[i - 1] for i in range(1, 7)), dt=f32)
+        pf = max(
+            ops.layernorm_bwd_partial_floats(B * Ts[1], 512), ops.layernorm_bwd_partial_floats(M, d),
+            ops.colsum_partial_floats(M, max(f, 3 * d)), ops.colsum_partial_floats(B * Ts[1], 512),
+            ops.conv0_bwd_partial_floats(B, N, C0, s.conv_kernel[0], s.conv_stride[0]), 4096)
+        w["partial"] = z(pf, dt=f32)
+        self._ws, self._ws_key = w, key
+        return w
+
+    # ---- forward -------------------------------------------------------------------------------
+    def __call__(self, input_values, attention_mask=None, labels=None, mask_time=None,
+                 mask_feature=None, layer_keep=None):
+        return self.forward(input_values, attention_mask, labels, mask_time, mask_feature, layer_keep)
+
+    def forward(self, input_values, attention_mask=None, labels=None, mask_time=None,
+                mask_feature=None, layer_keep=None) -> CTCOutput:
+        """input_values f32 [B,N] (already zero-mean/unit-var: the reference's feature extractor
+        output), attention_mask [B,N] or None, labels i64/i32 [B,L] (-100 padded) or None."""
+        s, st = self.s, self.store
+        dev = self.device
+        x = input_values.to(dev, torch.float32).contiguous()
+        B, N = x.shape
+        w = self._workspace(B, N)
+        d, f, H, hd = s.hidden_size, s.intermediate_size, s.num_attention_heads, s.head_dim
+        L = s.num_hidden_layers
+        Ts, T, M, Tp, Vp = w["Ts"], w["T"], w["M"], w["Tp"], w["Vp"]
+        eps = s.layer_norm_eps
+        p32, p16 = st.p32, st.p16
+        o = st.off
+
+        if attention_mask is not None:
+            slen = attention_mask.to(dev).sum(-1)
+            flen = self.feat_lengths(slen).to(torch.int32).contiguous()
+        else:
+            flen = torch.full((B,), T, dtype=torch.int32, device=dev)
+        keep = [True] * L if layer_keep is None else list(layer_keep)
+
+        # feature encoder
+        p0 = "wav2vec2.feature_extractor.conv_layers.0."
+        ops.conv0_fwd(x, st.view(p0 + "conv.weight"), st.view(p0 + "conv.bias"),
+                      st.view(p0 + "layer_norm.weight"), st.view(p0 + "layer_norm.bias"), w["a"][0],
+                      B, N, s.conv_dim[0], s.conv_kernel[0], s.conv_stride[0], eps)
+        Lin = Ts[0]
+        for i in range(1, 7):
+            pi = f"wav2vec2.feature_extractor.conv_layers.{i}."
+            k, sd, Ci, Co = s.conv_kernel[i], s.conv_stride[i], s.conv_dim[i - 1], s.conv_dim[i]
+            ops.gemm(w["a"][i - 1], self.conv_wr[i], w["y"][i], M=Ts[i], N=Co, K=k * Ci, lda=sd * Ci,
+                     ldb=k * Ci, ldc=Co, bias=p32, bias_off=o(pi + "conv.bias"), batch2=B,
+                     sA=(0, Lin * Ci), sC=(0, Ts[i] * Co))
+            ops.layernorm_fwd(w["y"][i], st.view(pi + "layer_norm.weight"), st.view(pi + "layer_norm.bias"),
+                              w["a"][i], w["cstats"][i], B * Ts[i], Co, eps, act=1)
+            Lin = Ts[i]
+        feats = w["a"][6]
+        C6 = s.conv_dim[6]
+        # feature projection
+        fp = "wav2vec2.feature_projection."
+        ops.layernorm_fwd(feats, st.view(fp + "layer_norm.weight"), st.view(fp + "layer_norm.bias"),
+                          w["xln"], w["fp_stats"], M, C6, eps)
+        ops.gemm(w["xln"], p16, w["h0"], M=M, N=d, K=C6, lda=C6, ldb=C6, ldc=d,
+                 b_off=o(fp + "projection.weight"), bias=p32, bias_off=o(fp + "projection.bias"))
+        # SpecAugment + padding
+        tm = mask_time.to(dev, torch.uint8).contiguous() if mask_time is not None else None
+        fm = mask_feature.to(dev, torch.uint8).contiguous() if mask_feature is not None else None
+        ops.mask_frames(w["h0"], tm, fm, p16[o("wav2vec2.masked_spec_embed"):], flen, B, T, d)
+        # positional conv embedding: h = h0 + gelu(conv(h0) + b)
+        G, K = s.num_conv_pos_embedding_groups, s.num_conv_pos_embeddings
+        Cg = d // G
+        Tpad = T + K
+        ops.regroup_pad(w["h0"], w["xg"], B, T, G, Cg, K // 2)
+        ops.gemm(w["xg"], self.pc_wf, w["pc_pre"], C2=w["h"][0], R=w["h0"], ldr=d, M=T, N=Cg, K=K * Cg,
+                 lda=Cg, ldb=K * Cg, ldc=d, bias=p32, bias_off=o("wav2vec2.encoder.pos_conv_embed.conv.bias"),
+                 epilogue=EPI_GELU_RESIDUAL, batch1=B, batch2=G, sA=(G * Tpad * Cg, Tpad * Cg),
+                 sB=(0, Cg * K * Cg), sC=(T * d, Cg), sR=(T * d, Cg), sBias=(0, Cg))
+        # encoder layers
+        drop_p = s.activation_dropout if self.training else 0.0
+        scale = hd ** -0.5
+        for l in range(L):
+            hin, hout = w["h"][l], w["h"][l + 1]
+            if not keep[l]:
+                hout.copy_(hin)
+                continue
+            pl = f"wav2vec2.encoder.layers.{l}."
+            ops.layernorm_fwd(hin, st.view(pl + "layer_norm.weight"), st.view(pl + "layer_norm.bias"),
+                              w["x1"][l], w["st1"][l], M, d, eps)
+            ops.gemm(w["x1"][l], p16, w["qkv"][l], M=M, N=3 * d, K=d, lda=d, ldb=d, ldc=3 * d,
+                     b_off=o(pl + "attention.q_proj.weight"), bias=p32, bias_off=o(pl + "attention.q_proj.bias"))
+            self._attention_fwd(w, l, B, T, Tp, H, hd, d, flen, scale)
+            ops.gemm(w["ctx"][l], p16, w["h1"][l], M=M, N=d, K=d, lda=d, ldb=d, ldc=d,
+                     b_off=o(pl + "attention.out_proj.weight"), bias=p32,
+                     bias_off=o(pl + "attention.out_proj.bias"), epilogue=EPI_RESIDUAL, R=hin, ldr=d)
+            ops.layernorm_fwd(w["h1"][l], st.view(pl + "final_layer_norm.weight"),
+                              st.view(pl + "final_layer_norm.bias"), w["x2"][l], w["st2"][l], M, d, eps)
+            ops.gemm(w["x2"][l], p16, w["u"][l], C2=w["g"][l], M=M, N=f, K=d, lda=d, ldb=d, ldc=f,
+                     b_off=o(pl + "feed_forward.intermediate_dense.weight"), bias=p32,
+                     bias_off=o(pl + "feed_forward.intermediate_dense.bias"), epilogue=EPI_GELU,
+                     dropout_p=drop_p, dropout_seed=self.step_seed * 1000 + l)
+            ops.gemm(w["g"][l], p16, hout, M=M, N=d, K=f, lda=f, ldb=f, ldc=d,
+                     b_off=o(pl + "feed_forward.output_dense.weight"), bias=p32,
+                     bias_off=o(pl + "feed_forward.output_dense.bias"), epilogue=EPI_RESIDUAL,
+                     R=w["h1"][l], ldr=d)
+        # final LN + lm_head (fp32 logits, ld = Vp)
+        ops.layernorm_fwd(w["h"][L], st.view("wav2vec2.encoder.layer_norm.weight"),
+                          st.view("wav2vec2.encoder.layer_norm.bias"), w["hf"], w["stf"], M, d, eps)
+        V = s.vocab_size
+        ops.gemm(w["hf"], p16, w["logits"], M=M, N=V, K=d, lda=d, ldb=d, ldc=Vp,
+                 b_off=o("lm_head.weight"), bias=p32, bias_off=o("lm_head.bias"))
+        logits = w["logits"].view(B, T, Vp)[:, :, :V]
+        out = CTCOutput(logits=logits, loss=None)
+        self._saved = dict(w=w, x=x, flen=flen, keep=keep, tm=tm, fm=fm, drop_p=drop_p, B=B, N=N,
+                           has_loss=False)
+        if labels is not None:
+            lab = labels.to(dev, torch.int32).contiguous()
+            Lmax = lab.shape[1]
+            in_len = flen
+            key = (B, T, Lmax)
+            if getattr(self, "_ctc_key", None) != key:
+                self._ctc_ws = torch.zeros(ops.ctc_workspace_bytes(B, T, Lmax), dtype=torch.uint8, device=dev)
+                self._ctc_key = key
+            gscale = None
+            if s.ctc_loss_reduction == "mean":
+                tl = (lab >= 0).sum(-1).clamp(min=1).to(torch.float32)
+                gscale = (1.0 / (tl * B)).contiguous()
+            ops.ctc_loss_fwd_bwd(w["logits"], lab, in_len, w["nll"], w["dlogits"], gscale, self._ctc_ws,
+                                 B, T, V, Vp, Lmax, s.pad_token_id, s.ctc_zero_infinity)
+            nll = w["nll"]
+            out["nll"] = nll
+            out["loss"] = nll.sum() if gscale is None else (nll * gscale).sum()
+            self._saved["has_loss"] = True
+        return out
+
+    def _attention_fwd(self, w, l, B, T, Tp, H, hd, d, flen, scale):
+        qkv, S, P, ctx = w["qkv"][l], w["S"], w["P"][l], w["ctx"][l]
+        ops.gemm(qkv, qkv, S, M=T, N=T, K=hd, lda=3 * d, ldb=3 * d, ldc=Tp, b_off=d, alpha=scale,
+                 batch1=B, batch2=H, sA=(T * 3 * d, hd), sB=(T * 3 * d, hd), sC=(H * T * Tp, T * Tp))
+        ops.softmax_fwd(S, P, flen, B * H, H, T, T, Tp)
+        ops.gemm(P, qkv, ctx, M=T, N=hd, K=T, lda=Tp, b_layout=MNMAJOR, ldb=3 * d, b_off=2 * d, ldc=d,
+                 batch1=B, batch2=H, sA=(H * T * Tp, T * Tp), sB=(T * 3 * d, hd), sC=(T * d, hd))
+
+    # ---- backward ------------------------------------------------------------------------------
+    def backward(self, loss_scale: float = 1.0, accumulate: bool = True):
+        """Back-propagate d(loss*loss_scale) into the flat gradient buffer (+=)."""
+        sv = self._saved
+        if sv is None or not sv["has_loss"]:
+            raise RuntimeError("backward() needs a forward pass with labels")
+        s, st = self.s, self.store
+        w, x, flen, keep = sv["w"], sv["x"], sv["flen"], sv["keep"]
+        B, N = sv["B"], sv["N"]
+        d, f, H, hd = s.hidden_size, s.intermediate_size, s.num_attention_heads, s.head_dim
+        L = s.num_hidden_layers
+        Ts, T, M, Tp, Vp = w["Ts"], w["T"], w["M"], w["Tp"], w["Vp"]
+        V = s.vocab_size
+        p32, p16, g32 = st.p32, st.p16, st.g32
+        o = st.off
+        part = w["partial"]
+        acc = True  # gradients are always accumulated; zero_grad() starts a step
+
+        # head: dlogits (fp32) -> bf16 for the MFMA path
+        dl = w["dlogits"]
+        if loss_scale != 1.0:
+            dl.mul_(loss_scale)
+        ops.cast_f32_bf16(dl, w["dlogits16"], M * Vp)
+        d16 = w["dlogits16"]
+        ops.gemm(d16, w["hf"], g32, M=V, N=d, K=M, a_layout=MNMAJOR, lda=Vp, b_layout=MNMAJOR, ldb=d,
+                 ldc=d, c_off=o("lm_head.weight"), out_f32=True, accumulate=acc)
+        ops.colsum(d16, Vp, M, Vp, g32, part, out_off=o("lm_head.bias"))
+        if self.freeze_base:
+            return
+        ops.gemm(d16, p16, w["dA"], M=M, N=d, K=V, lda=Vp, b_layout=MNMAJOR, ldb=d, ldc=d,
+                 b_off=o("lm_head.weight"))
+        dh = w["dB"]
+        ops.layernorm_bwd(w["dA"], w["h"][L], st.view("wav2vec2.encoder.layer_norm.weight"), None,
+                          w["stf"], None, dh, st.view("wav2vec2.encoder.layer_norm.weight", "g32"),
+                          st.view("wav2vec2.encoder.layer_norm.bias", "g32"), part, M, d)
+        # dh = gradient wrt residual stream leaving layer L-1
+        other = w["dA"]
+        scale = hd ** -0.5
+        drop_p = sv["drop_p"]
+        for l in reversed(range(L)):
+            if not keep[l]:
+                continue
+            pl = f"wav2vec2.encoder.layers.{l}."
+            hin = w["h"][l]
+            # FFN2: h_out = h1 + W2 g + b2
+            ops.colsum(dh, d, M, d, g32, part, out_off=o(pl + "feed_forward.output_dense.bias"))
+            ops.gemm(dh, w["g"][l], g32, M=d, N=f, K=M, a_layout=MNMAJOR, lda=d, b_layout=MNMAJOR, ldb=f,
+                     ldc=f, c_off=o(pl + "feed_forward.output_dense.weight"), out_f32=True, accumulate=acc)
+            ops.gemm(dh, p16, w["du"], M=M, N=f, K=d, lda=d, b_layout=MNMAJOR, ldb=f, ldc=f,
+                     b_off=o(pl + "feed_forward.output_dense.weight"), epilogue=EPI_DGELU, R=w["u"][l],
+                     ldr=f, dropout_p=drop_p, dropout_seed=self.step_seed * 1000 + l)
+            # FFN1
+            du = w["du"]
+            ops.colsum(du, f, M, f, g32, part, out_off=o(pl + "feed_forward.intermediate_dense.bias"))
+            ops.gemm(du, w["x2"][l], g32, M=f, N=d, K=M, a_layout=MNMAJOR, lda=f, b_layout=MNMAJOR, ldb=d,
+                     ldc=d, c_off=o(pl + "feed_forward.intermediate_dense.weight"), out_f32=True,
+                     accumulate=acc)
+            ops.gemm(du, p16, other, M=M, N=d, K=f, lda=f, b_layout=MNMAJOR, ldb=d, ldc=d,
+                     b_off=o(pl + "feed_forward.intermediate_dense.weight"))
+            # LN2: dh1 = dh + LN'(dx2)
+            dh1 = w["dC"]
+            ops.layernorm_bwd(other, w["h1"][l], st.view(pl + "final_layer_norm.weight"), None, w["st2"][l],
+                              dh, dh1, st.view(pl + "final_layer_norm.weight", "g32"),
+                              st.view(pl + "final_layer_norm.bias", "g32"), part, M, d)
+            # out_proj: h1 = h + Wo ctx + bo
+            ops.colsum(dh1, d, M, d, g32, part, out_off=o(pl + "attention.out_proj.bias"))
+            ops.gemm(dh1, w["ctx"][l], g32, M=d, N=d, K=M, a_layout=MNMAJOR, lda=d, b_layout=MNMAJOR, ldb=d,
+                     ldc=d, c_off=o(pl + "attention.out_proj.weight"), out_f32=True, accumulate=acc)
+            dctx = other
+            ops.gemm(dh1, p16, dctx, M=M, N=d, K=d, lda=d, b_layout=MNMAJOR, ldb=d, ldc=d,
+                     b_off=o(pl + "attention.out_proj.weight"))
+            self._attention_bwd(w, l, dctx, B, T, Tp, H, hd, d, scale)
+            dqkv = w["dqkv"]
+            ops.colsum(dqkv, 3 * d, M, 3 * d, g32, part, out_off=o(pl + "attention.q_proj.bias"))
+            ops.gemm(dqkv, w["x1"][l], g32, M=3 * d, N=d, K=M, a_layout=MNMAJOR, lda=3 * d,
+                     b_layout=MNMAJOR, ldb=d, ldc=d, c_off=o(pl + "attention.q_proj.weight"), out_f32=True,
+                     accumulate=acc)
+            dx1 = other
+            ops.gemm(dqkv, p16, dx1, M=M, N=d, K=3 * d, lda=3 * d, b_layout=MNMAJOR, ldb=d, ldc=d,
+                     b_off=o(pl + "attention.q_proj.weight"))
+            # LN1: dh_in = dh1 + LN'(dx1)   (written over the old dh buffer)
+            ops.layernorm_bwd(dx1, hin, st.view(pl + "layer_norm.weight"), None, w["st1"][l], dh1, dh,
+                              st.view(pl + "layer_norm.weight", "g32"), st.view(pl + "layer_norm.bias", "g32"),
+                              part, M, d)
+        # dh: gradient wrt h[0] = h0m + gelu(pc_pre)
+        G, K = s.num_conv_pos_embedding_groups, s.num_conv_pos_embeddings
+        Cg = d // G
+        Tpad = T + K
+        dpc = w["dC"]
+        ops.dgelu_mul(dh, w["pc_pre"], dpc, M * d)
+        ops.colsum(dpc, d, M, d, g32, part, out_off=o("wav2vec2.encoder.pos_conv_embed.conv.bias"))
+        # weight gradient in GEMM layout [G][Cg][K][Cg], then through the weight norm
+        ops.gemm(dpc, w["xg"], w["dwf"], M=Cg, N=K * Cg, K=M, a_layout=MNMAJOR, lda=d, b_layout=MNMAJOR,
+                 ldb=Cg, b_kseg=T, b_kseg_stride=G * Tpad * Cg, ldc=K * Cg, batch2=G, sA=(0, Cg),
+                 sB=(0, Tpad * Cg), sC=(0, Cg * K * Cg), out_f32=True)
+        pre = "wav2vec2.encoder.pos_conv_embed.conv.parametrizations.weight."
+        ops.posconv_weight_bwd(w["dwf"], st.view(pre + "original1"), st.view(pre + "original0"), self.pc_norm,
+                               st.view(pre + "original1", "g32"), st.view(pre + "original0", "g32"),
+                               self.pc_partial, d, Cg, K)
+        # data gradient: correlation of the (left 63 / right 64) padded dpc with flipped weights
+        ops.regroup_pad(dpc, w["dxg"], B, T, G, Cg, K // 2)
+        dh0 = w["dA"]
+        ops.gemm(w["dxg"], self.pc_wb, dh0, M=T, N=Cg, K=K * Cg, lda=Cg, ldb=K * Cg, ldc=d, a_off=Cg,
+                 epilogue=EPI_RESIDUAL, R=dh, ldr=d, batch1=B, batch2=G, sA=(G * Tpad * Cg, Tpad * Cg),
+                 sB=(0, Cg * K * Cg), sC=(T * d, Cg), sR=(T * d, Cg))
+        # SpecAugment / padding backward: masked rows feed masked_spec_embed, then are zeroed
+        if sv["tm"] is not None:
+            ops.colsum(dh0, d, M, d, g32, part, rowmask=sv["tm"], out_off=o("wav2vec2.masked_spec_embed"))
+        ops.mask_frames(dh0, sv["tm"], sv["fm"], self.zero_embed, flen, B, T, d)
+        # feature projection
+        fp = "wav2vec2.feature_projection."
+        C6 = s.conv_dim[6]
+        ops.colsum(dh0, d, M, d, g32, part, out_off=o(fp + "projection.bias"))
+        ops.gemm(dh0, w["xln"], g32, M=d, N=C6, K=M, a_layout=MNMAJOR, lda=d, b_layout=MNMAJOR, ldb=C6,
+                 ldc=C6, c_off=o(fp + "projection.weight"), out_f32=True, accumulate=acc)
+        dxln = w["dy"]
+        ops.gemm(dh0, p16, dxln, M=M, N=C6, K=d, lda=d, b_layout=MNMAJOR, ldb=C6, ldc=C6,
+                 b_off=o(fp + "projection.weight"))
+        ops.layernorm_bwd(dxln, w["a"][6], st.view(fp + "layer_norm.weight"), None, w["fp_stats"], None,
+                          w["dconv"][6], st.view(fp + "layer_norm.weight", "g32"),
+                          st.view(fp + "layer_norm.bias", "g32"), part, M, C6)
+        # conv stack 6..1
+        for i in range(6, 0, -1):
+            pi = f"wav2vec2.feature_extractor.conv_layers.{i}."
+            k, sd, Ci, Co = s.conv_kernel[i], s.conv_stride[i], s.conv_dim[i - 1], s.conv_dim[i]
+            Lin, Ti = Ts[i - 1], Ts[i]
+            dy = w["dy"]
+            ops.layernorm_bwd(w["dconv"][i], w["y"][i], st.view(pi + "layer_norm.weight"),
+                              st.view(pi + "layer_norm.bias"), w["cstats"][i], None, dy,
+                              st.view(pi + "layer_norm.weight", "g32"), st.view(pi + "layer_norm.bias", "g32"),
+                              part, B * Ti, Co, act=1)
+            ops.colsum(dy, Co, B * Ti, Co, g32, part, out_off=o(pi + "conv.bias"))
+            ops.gemm(dy, w["a"][i - 1], w["dwr"], M=Co, N=k * Ci, K=B * Ti, a_layout=MNMAJOR, lda=Co,
+                     b_layout=MNMAJOR, ldb=sd * Ci, b_kseg=Ti, b_kseg_stride=Lin * Ci, ldc=k * Ci,
+                     out_f32=True)
+            ops.conv_weight_grad_reorder(w["dwr"], g32, Co, Ci, k, dw_off=o(pi + "conv.weight"))
+            ops.gemm(dy, self.conv_wr[i], w["dcol"], M=B * Ti, N=k * Ci, K=Co, lda=Co, b_layout=MNMAJOR,
+                     ldb=k * Ci, ldc=k * Ci)
+            ops.col2im_1d(w["dcol"], w["dconv"][i - 1], B, Ti, Lin, Ci, k, sd)
+        p0 = "wav2vec2.feature_extractor.conv_layers.0."
+        ops.conv0_bwd(x, st.view(p0 + "conv.weight"), st.view(p0 + "conv.bias"),
+                      st.view(p0 + "layer_norm.weight"), st.view(p0 + "layer_norm.bias"), w["dconv"][0],
+                      st.view(p0 + "conv.weight", "g32"), st.view(p0 + "conv.bias", "g32"),
+                      st.view(p0 + "layer_norm.weight", "g32"), st.view(p0 + "layer_norm.bias", "g32"),
+                      part, B, N, s.conv_dim[0], s.conv_kernel[0], s.conv_stride[0], s.layer_norm_eps)
+
+    def _attention_bwd(self, w, l, dctx, B, T, Tp, H, hd, d, scale):
+        qkv, P, dP, dS, dqkv = w["qkv"][l], w["P"][l], w["S"], w["dS"], w["dqkv"]
+        bs = dict(batch1=B, batch2=H)
+        # dP = dctx V^T
+        ops.gemm(dctx, qkv, dP, M=T, N=T, K=hd, lda=d, ldb=3 * d, b_off=2 * d, ldc=Tp, sA=(T * d, hd),
+                 sB=(T * 3 * d, hd), sC=(H * T * Tp, T * Tp), **bs)
+        ops.softmax_bwd(dP, P, dS, scale, B * H, T, T, Tp)
+        # dQ = dS K ; dK = dS^T Q ; dV = P^T dctx
+        ops.gemm(dS, qkv, dqkv, M=T, N=hd, K=T, lda=Tp, b_layout=MNMAJOR, ldb=3 * d, b_off=d, ldc=3 * d,
+                 c_off=0, sA=(H * T * Tp, T * Tp), sB=(T * 3 * d, hd), sC=(T * 3 * d, hd), **bs)
+        ops.gemm(dS, qkv, dqkv, M=T, N=hd, K=T, a_layout=MNMAJOR, lda=Tp, b_layout=MNMAJOR, ldb=3 * d,
+                 b_off=0, ldc=3 * d, c_off=d, sA=(H * T * Tp, T * Tp), sB=(T * 3 * d, hd),
+                 sC=(T * 3 * d, hd), **bs)
+        ops.gemm(P, dctx, dqkv, M=T, N=hd, K=T, a_layout=MNMAJOR, lda=Tp, b_layout=MNMAJOR, ldb=d, ldc=3 * d,
+                 c_off=2 * d, sA=(H * T * Tp, T * Tp), sB=(T * d, hd), sC=(T * 3 * d, hd), **bs)
+
+    # ---- inference helpers -----------------------------------------------------------------------
+    def greedy_decode(self, logits_full: torch.Tensor | None = None, in_len=None):
+        """argmax + collapse + drop blank on the logits of the last forward (ids list per row)."""
+        sv = self._saved
+        w = sv["w"]
+        B, T, V, Vp = sv["B"], w["T"], self.s.vocab_size, w["Vp"]
+        dev = self.device
+        raw = torch.empty(B, T, dtype=torch.int32, device=dev)
+        ids = torch.empty(B, T, dtype=torch.int32, device=dev)
+        olen = torch.empty(B, dtype=torch.int32, device=dev)
+        ops.ctc_greedy_decode(w["logits"], in_len, raw, ids, olen, B, T, V, Vp, self.s.pad_token_id)
+        ids_c, olen_c = ids.cpu(), olen.cpu()
+        return [ids_c[b, :int(olen_c[b])].tolist() for b in range(B)], raw

@@ -54,7 +54,8 @@ int ca_device_count(void);
  * Overlapping rows are legal (lda smaller than the row length): a channels-last Conv1d
  * with stride s is exactly a KMAJOR GEMM with lda = s*C_in and K = k*C_in.
  * Constraints: all leading dimensions and offsets multiples of 8 elements (16 bytes);
- * KMAJOR operands must be readable (and zero) up to K rounded up to 8.
+ * KMAJOR operands must be readable (and zero) up to K rounded up to 8; MNMAJOR operand rows
+ * must be readable up to M (resp. N) rounded up to 8 (those extra outputs are discarded).
  * Batch: blockIdx.z = z1*batch2 + z2, pointer offsets z1*s?1 + z2*s?2 (elements).
  * ---------------------------------------------------------------------------------- */
 #define CA_KMAJOR 0
@@ -64,6 +65,7 @@ int ca_device_count(void);
 #define CA_EPI_GELU 1      /* C = v (pre-activation, may be NULL), C2 = gelu_erf(v)     */
 #define CA_EPI_RESIDUAL 2  /* C = v + R                                                 */
 #define CA_EPI_DGELU 3     /* C = v * gelu_erf'(R)          (R = saved pre-activation)  */
+#define CA_EPI_GELU_RESIDUAL 4 /* C = v (may be NULL), C2 = gelu_erf(v) + R  (pos-conv add) */
 
 typedef struct CaGemmDesc {
   const void* A;
@@ -79,6 +81,7 @@ typedef struct CaGemmDesc {
   int64_t a_kseg_stride, b_kseg_stride;
   int32_t batch1, batch2;
   int64_t sA1, sA2, sB1, sB2, sC1, sC2, sR1, sR2;
+  int64_t sBias1, sBias2; /* per-batch offset of the bias vector (grouped conv) */
   int32_t epilogue;
   int32_t out_f32;    /* 0: C is bf16; 1: C is fp32 */
   int32_t accumulate; /* 1: C += result (read-modify-write) */
@@ -101,18 +104,23 @@ int ca_gemm_bf16(const CaGemmDesc* desc, void* stream);
 int ca_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y,
                      float* stats, int64_t rows, int32_t C, float eps, int32_t act,
                      void* stream);
-/* dx bf16 [rows,C]; dgamma/dbeta fp32 [C] are ACCUMULATED into (+=) through the fp32
- * partial buffer `partial` of ca_layernorm_bwd_partial_floats(rows, C) floats. */
+/* dx bf16 [rows,C] (+ dres if non-NULL: the residual-stream gradient that bypasses the LN);
+ * dgamma/dbeta fp32 [C] are ACCUMULATED into (+=) through the fp32 partial buffer `partial`
+ * of ca_layernorm_bwd_partial_floats(rows, C) floats. */
 int64_t ca_layernorm_bwd_partial_floats(int64_t rows, int32_t C);
 int ca_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* beta,
-                     const float* stats, void* dx, float* dgamma, float* dbeta,
-                     float* partial, int64_t rows, int32_t C, int32_t act, void* stream);
+                     const float* stats, const void* dres, void* dx, float* dgamma,
+                     float* dbeta, float* partial, int64_t rows, int32_t C, int32_t act,
+                     void* stream);
 
 /* column sums: out[n] (+)= sum_m x[m*ld + n]  (bias gradients). x bf16, out fp32.
- * partial: fp32 workspace of ca_colsum_partial_floats(rows, N) floats. */
+ * rowmask uint8 [rows] or NULL: only rows with a non-zero mask byte are summed (gradient of
+ * masked_spec_embed).  partial: fp32 workspace of ca_colsum_partial_floats(rows, N) floats. */
 int64_t ca_colsum_partial_floats(int64_t rows, int32_t N);
-int ca_colsum_bf16(const void* x, int64_t ld, int64_t rows, int32_t N, float* out,
-                   int32_t accumulate, float* partial, void* stream);
+int ca_colsum_bf16(const void* x, int64_t ld, int64_t rows, int32_t N, const uint8_t* rowmask,
+                   float* out, int32_t accumulate, float* partial, void* stream);
+/* out = dy * gelu_erf'(u), bf16 elementwise (backward of the pos-conv GELU, :374). */
+int ca_dgelu_mul(const void* dy, const void* u, void* out, int64_t n, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Waveform front end.
@@ -194,11 +202,12 @@ int ca_mask_frames(void* h, const uint8_t* tmask, const uint8_t* fmask, const vo
                    const int32_t* flen, int32_t B, int32_t T, int32_t C, void* stream);
 int ca_regroup_pad(const void* x, void* xg, int32_t B, int32_t T, int32_t G, int32_t Cg,
                    int32_t pad, void* stream);
+int64_t ca_posconv_partial_floats(int32_t K); /* size of `partial` below, in floats */
 int ca_posconv_weight(const float* v, const float* g, void* wf, void* wb, float* norm,
-                      int32_t d, int32_t Cg, int32_t K, void* stream);
+                      float* partial, int32_t d, int32_t Cg, int32_t K, void* stream);
 int ca_posconv_weight_bwd(const float* dwf, const float* v, const float* g,
-                          const float* norm, float* dv, float* dg, int32_t d, int32_t Cg,
-                          int32_t K, void* stream);
+                          const float* norm, float* dv, float* dg, float* partial, int32_t d,
+                          int32_t Cg, int32_t K, void* stream);
 
 /* casts / transposes used when refreshing bf16 compute copies from fp32 masters */
 int ca_cast_f32_bf16(const float* x, void* y, int64_t n, void* stream);

@@ -1,0 +1,392 @@
+"""Per-kernel parity on a real MI355X: every C-ABI entry point against a plain torch fp32
+statement of the same op (floating point) or bit-exact (integer outputs).  `-m gpu` only."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from coral_amd import ops as o
+
+    o.lib()
+    assert torch.cuda.is_available(), "GPU tests need a GPU (no CPU fallback exists)"
+    return o
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+@pytest.mark.parametrize("al,bl", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (499, 120, 504), (1000, 1920, 328), (46, 1024, 3992)])
+def test_gemm_layouts(ops, al, bl, M, N, K):
+    A, B = bf(rnd(M, K, seed=1, scale=0.5)), bf(rnd(N, K, seed=2, scale=0.5))
+    ref = A.float() @ B.float().t()
+    Mp, Np = (M + 7) // 8 * 8, (N + 7) // 8 * 8
+    if al:  # [K][Mp] zero padded rows
+        Ad = torch.zeros(K, Mp, dtype=torch.bfloat16)
+        Ad[:, :M] = A.t()
+    else:
+        Ad = A
+    if bl:
+        Bd = torch.zeros(K, Np, dtype=torch.bfloat16)
+        Bd[:, :N] = B.t()
+    else:
+        Bd = B
+    Ad, Bd = Ad.contiguous().to(DEV), Bd.contiguous().to(DEV)
+    C = torch.zeros(M, Np, dtype=torch.float32, device=DEV)
+    ops.gemm(Ad, Bd, C, M=M, N=N, K=K, lda=(Mp if al else K), ldb=(Np if bl else K), ldc=Np,
+             a_layout=al, b_layout=bl)
+    torch.cuda.synchronize()
+    err = (C[:, :N].cpu() - ref).abs().max().item()
+    assert err <= 1e-3 * (K ** 0.5), err  # fp32 accumulate of exact bf16 products
+
+
+def test_gemm_epilogues_and_batch(ops):
+    M, N, K, Bt = 300, 256, 192, 3
+    A, W = bf(rnd(Bt, M, K, seed=3, scale=0.5)), bf(rnd(N, K, seed=4, scale=0.2))
+    bias = rnd(N, seed=5)
+    R = bf(rnd(Bt, M, N, seed=6))
+    Ad, Wd, Rd, bd = A.to(DEV), W.to(DEV), R.to(DEV), bias.to(DEV)
+    v = A.float() @ W.float().t() + bias
+    kw = dict(M=M, N=N, K=K, lda=K, ldb=K, ldc=N, batch2=Bt, sA=(0, M * K), sC=(0, M * N), bias=bd)
+    C = torch.zeros(Bt, M, N, dtype=torch.bfloat16, device=DEV)
+    C2 = torch.zeros_like(C)
+    ops.gemm(Ad, Wd, C, C2=C2, epilogue=ops.EPI_GELU, **kw)
+    assert (C.float().cpu() - v).abs().max() < 0.05
+    assert (C2.float().cpu() - torch.nn.functional.gelu(v)).abs().max() < 0.05
+    ops.gemm(Ad, Wd, C, epilogue=ops.EPI_RESIDUAL, R=Rd, ldr=N, sR=(0, M * N), **kw)
+    assert (C.float().cpu() - (v + R.float())).abs().max() < 0.06
+    ops.gemm(Ad, Wd, None, C2=C2, epilogue=ops.EPI_GELU_RESIDUAL, R=Rd, ldr=N, sR=(0, M * N), **kw)
+    assert (C2.float().cpu() - (torch.nn.functional.gelu(v) + R.float())).abs().max() < 0.06
+    u = R.float().requires_grad_(True)
+    torch.nn.functional.gelu(u).sum().backward()
+    ops.gemm(Ad, Wd, C, epilogue=ops.EPI_DGELU, R=Rd, ldr=N, sR=(0, M * N), **kw)
+    assert (C.float().cpu() - v * u.grad).abs().max() < 0.06
+    # fp32 accumulate
+    Cf = torch.full((Bt, M, N), 2.0, dtype=torch.float32, device=DEV)
+    ops.gemm(Ad, Wd, Cf, accumulate=True, **kw)
+    assert (Cf.cpu() - (v + 2.0)).abs().max() < 1e-2
+    # dropout: same mask in GELU forward and DGELU backward, keep-rate ~ 1-p
+    ops.gemm(Ad, Wd, None, C2=C2, epilogue=ops.EPI_GELU, dropout_p=0.25, dropout_seed=7, **kw)
+    g = torch.nn.functional.gelu(v)
+    kept = (C2.float().cpu() != 0) | (g.abs() < 1e-3)
+    rate = kept.float().mean().item()
+    assert 0.72 < rate < 0.78, rate
+    sel = C2.float().cpu() != 0
+    assert ((C2.float().cpu() - g / 0.75)[sel].abs().max()) < 0.08
+    ops.gemm(Ad, Wd, C, epilogue=ops.EPI_DGELU, R=Rd, ldr=N, sR=(0, M * N), dropout_p=0.25,
+             dropout_seed=7, **kw)
+    # the DGELU mask is keyed on (m, n) exactly like the GELU one
+    ops.gemm(Ad, Wd, None, C2=C2, epilogue=ops.EPI_GELU, dropout_p=0.25, dropout_seed=7, **kw)
+    z1 = (C.float().cpu() == 0) & (v.abs() > 1e-2) & (u.grad.abs() > 1e-2)
+    z2 = (C2.float().cpu() == 0) & (g.abs() > 1e-3)
+    assert (z1 & ~z2 & (g.abs() > 1e-3)).sum() == 0
+
+
+@pytest.mark.parametrize("C,act", [(512, 1), (1024, 0), (1920, 0), (128, 0)])
+def test_layernorm_fwd_bwd(ops, C, act):
+    rows = 777
+    x = bf(rnd(rows, C, seed=1, scale=2.0))
+    gamma, beta = 1 + 0.1 * rnd(C, seed=2), 0.1 * rnd(C, seed=3)
+    dy = bf(rnd(rows, C, seed=4))
+    dres = bf(rnd(rows, C, seed=5))
+    xr = x.float().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    y = torch.nn.functional.layer_norm(xr, (C,), gr, br, 1e-5)
+    if act:
+        y = torch.nn.functional.gelu(y)
+    y.backward(dy.float())
+    xd, gd, bd = x.to(DEV), gamma.to(DEV), beta.to(DEV)
+    yd = torch.empty(rows, C, dtype=torch.bfloat16, device=DEV)
+    st = torch.empty(rows, 2, dtype=torch.float32, device=DEV)
+    ops.layernorm_fwd(xd, gd, bd, yd, st, rows, C, 1e-5, act)
+    assert (yd.float().cpu() - y.detach()).abs().max() < 0.04
+    dx = torch.empty_like(yd)
+    dg = torch.ones(C, dtype=torch.float32, device=DEV)
+    db = torch.ones(C, dtype=torch.float32, device=DEV)
+    part = torch.empty(ops.layernorm_bwd_partial_floats(rows, C), dtype=torch.float32, device=DEV)
+    ops.layernorm_bwd(dy.to(DEV), xd, gd, bd, st, dres.to(DEV), dx, dg, db, part, rows, C, act)
+    want = xr.grad + dres.float()
+    assert (dx.float().cpu() - want).abs().max() < 0.05 * max(1.0, want.abs().max().item() / 4)
+    assert (dg.cpu() - 1 - gr.grad).abs().max() < 2e-3 * gr.grad.abs().max() + 1e-2
+    assert (db.cpu() - 1 - br.grad).abs().max() < 2e-3 * br.grad.abs().max() + 1e-2
+
+
+def test_colsum_and_dgelu(ops):
+    rows, N = 3992, 1920
+    x = bf(rnd(rows, N, seed=1))
+    mask = (torch.arange(rows) % 3 == 0).to(torch.uint8)
+    out = torch.zeros(N, dtype=torch.float32, device=DEV)
+    part = torch.empty(ops.colsum_partial_floats(rows, N), dtype=torch.float32, device=DEV)
+    ops.colsum(x.to(DEV), N, rows, N, out, part, accumulate=False)
+    assert (out.cpu() - x.float().sum(0)).abs().max() < 1e-2
+    ops.colsum(x.to(DEV), N, rows, N, out, part, accumulate=True, rowmask=mask.to(DEV))
+    want = x.float().sum(0) + x.float()[mask.bool()].sum(0)
+    assert (out.cpu() - want).abs().max() < 1e-2
+    u = bf(rnd(rows, N, seed=2))
+    o = torch.empty_like(x, device=DEV)
+    ops.dgelu_mul(x.to(DEV), u.to(DEV), o, rows * N)
+    ur = u.float().requires_grad_(True)
+    torch.nn.functional.gelu(ur).backward(x.float())
+    assert (o.float().cpu() - ur.grad).abs().max() < 0.03
+
+
+def test_wave_normalize_and_conv0(ops):
+    B, N = 3, 4000
+    x = rnd(B, N, seed=1, scale=0.1) + 0.01
+    lens = torch.tensor([4000, 3333, 800], dtype=torch.int32)
+    y = torch.empty(B, N, device=DEV)
+    ops.wave_normalize(x.to(DEV), lens.to(DEV), y, B, N)
+    for b in range(B):
+        n = int(lens[b])
+        a = x[b, :n]
+        want = (a - a.mean()) / torch.sqrt(a.var(unbiased=False) + 1e-7)
+        assert (y[b, :n].cpu() - want).abs().max() < 2e-5
+        assert (y[b, n:] == 0).all()
+    # fused layer 0
+    C, k, s = 512, 10, 5
+    w, bias = rnd(C, 1, k, seed=2, scale=0.3), 0.05 * rnd(C, seed=3)
+    gamma, beta = 1 + 0.1 * rnd(C, seed=4), 0.1 * rnd(C, seed=5)
+    xin = y.cpu()
+    wr, br, gr, ber = [t.clone().requires_grad_(True) for t in (w, bias, gamma, beta)]
+    h = torch.nn.functional.conv1d(xin[:, None, :], wr, br, stride=s).transpose(1, 2)
+    h = torch.nn.functional.gelu(torch.nn.functional.layer_norm(h, (C,), gr, ber, 1e-5))
+    T0 = h.shape[1]
+    out = torch.empty(B, T0, C, dtype=torch.bfloat16, device=DEV)
+    args = [t.to(DEV).contiguous() for t in (w.view(C, k), bias, gamma, beta)]
+    ops.conv0_fwd(y, *args, out, B, N, C, k, s)
+    assert (out.float().cpu() - h.detach()).abs().max() < 0.03
+    dy = bf(rnd(B, T0, C, seed=6))
+    h.backward(dy.float())
+    dw = torch.zeros(C, k, device=DEV)
+    dbs, dg, dbt = (torch.zeros(C, device=DEV) for _ in range(3))
+    part = torch.empty(ops.conv0_bwd_partial_floats(B, N, C, k, s), device=DEV)
+    ops.conv0_bwd(y, *args, dy.to(DEV), dw, dbs, dg, dbt, part, B, N, C, k, s)
+    for got, want in ((dw.cpu().view(C, 1, k), wr.grad), (dbs.cpu(), br.grad), (dg.cpu(), gr.grad),
+                      (dbt.cpu(), ber.grad)):
+        assert (got - want).abs().max() < 2e-3 * want.abs().max() + 1e-3
+
+
+def test_col2im(ops):
+    B, L, C, k, s = 2, 41, 16, 3, 2
+    T = (L - k) // s + 1
+    dcol = bf(rnd(B, T, k * C, seed=1))
+    want = torch.zeros(B, L, C)
+    dc = dcol.float().view(B, T, k, C)
+    for t in range(T):
+        for j in range(k):
+            want[:, t * s + j] += dc[:, t, j]
+    dx = torch.empty(B, L, C, dtype=torch.bfloat16, device=DEV)
+    ops.col2im_1d(dcol.to(DEV), dx, B, T, L, C, k, s)
+    assert (dx.float().cpu() - want).abs().max() < 0.02
+
+
+def test_softmax_fwd_bwd(ops):
+    B, H, T, ld = 2, 3, 499, 504
+    s = rnd(B * H, T, ld, seed=1, scale=3.0)
+    klen = torch.tensor([499, 300], dtype=torch.int32)
+    p = torch.empty(B * H, T, ld, dtype=torch.bfloat16, device=DEV)
+    ops.softmax_fwd(s.to(DEV), p, klen.to(DEV), B * H, H, T, T, ld)
+    pc = p.float().cpu()
+    for bh in range(B * H):
+        kl = int(klen[bh // H])
+        want = torch.softmax(s[bh, :, :kl], -1)
+        assert (pc[bh, :, :kl] - want).abs().max() < 4e-3
+        assert (pc[bh, :, kl:] == 0).all()
+    # causal variant
+    ops.softmax_fwd(s.to(DEV), p, None, B * H, H, T, T, ld, causal=True)
+    pc2 = p.float().cpu()
+    i = torch.arange(T)
+    mask = i[None, :] <= i[:, None]
+    want = torch.softmax(s[0, :, :T].masked_fill(~mask, float("-inf")), -1)
+    assert (pc2[0, :, :T] - want).abs().max() < 4e-3
+    # backward
+    dp = rnd(B * H, T, ld, seed=2)
+    ds = torch.empty_like(p)
+    ops.softmax_fwd(s.to(DEV), p, klen.to(DEV), B * H, H, T, T, ld)
+    ops.softmax_bwd(dp.to(DEV), p, ds, 0.125, B * H, T, T, ld)
+    pf = p.float().cpu()
+    want = pf * (dp - (dp[..., :T] * pf[..., :T]).sum(-1, keepdim=True)) * 0.125
+    assert (ds.float().cpu()[..., :T] - want[..., :T]).abs().max() < 5e-3
+    assert (ds.float().cpu()[..., T:] == 0).all()
+
+
+def test_ctc_matches_golden_and_torch(ops, golden_dir):
+    z = np.load(golden_dir / "ctc_cases.npz")
+    for i in range(int(z["n_cases"])):
+        lg = torch.tensor(z[f"c{i}_logits"])
+        T, V = lg.shape
+        tg = torch.tensor(z[f"c{i}_targets"], dtype=torch.int32)
+        L = max(1, len(tg))
+        labels = torch.full((1, L + 2), -100, dtype=torch.int32)
+        labels[0, :len(tg)] = tg
+        Vp = (V + 7) // 8 * 8
+        lgd = torch.zeros(1, T, Vp, device=DEV)
+        lgd[0, :, :V] = lg.to(DEV)
+        nll = torch.zeros(1, device=DEV)
+        grad = torch.full((1, T, Vp), 7.0, device=DEV)
+        ws = torch.zeros(ops.ctc_workspace_bytes(1, T, L + 2), dtype=torch.uint8, device=DEV)
+        tin = torch.tensor([int(z[f"c{i}_tin"])], dtype=torch.int32, device=DEV)
+        ops.ctc_loss_fwd_bwd(lgd, labels.to(DEV), tin, nll, grad, None, ws, 1, T, V, Vp, L + 2, V - 1)
+        want = float(z[f"c{i}_loss"])
+        assert abs(nll.item() - want) <= 1e-4 * max(1.0, abs(want)), (i, nll.item(), want)  # << 1e-3 rel
+        np.testing.assert_allclose(grad[0, :, :V].cpu().numpy(), z[f"c{i}_grad"], atol=3e-5, rtol=1e-3)
+        assert (grad[0, :, V:] == 0).all()
+    # BASELINE-sized batch vs torch on the same seeded inputs
+    B, T, V, Vp, Lmax = 8, 499, 46, 48, 120
+    g = torch.Generator().manual_seed(5)
+    lg = torch.randn(B, T, V, generator=g)
+    labels = torch.full((B, Lmax), -100, dtype=torch.long)
+    tl = torch.randint(20, Lmax + 1, (B,), generator=g)
+    for b in range(B):
+        labels[b, :tl[b]] = torch.randint(0, 42, (int(tl[b]),), generator=g)
+    tin = torch.tensor([499, 499, 400, 300, 499, 250, 499, 130])
+    lgr = lg.clone().requires_grad_(True)
+    lp = torch.log_softmax(lgr, -1).transpose(0, 1)
+    ref = torch.nn.functional.ctc_loss(lp, labels[labels >= 0], tin, tl, blank=45, reduction="none",
+                                       zero_infinity=True)
+    ref.sum().backward()
+    lgd = torch.zeros(B, T, Vp, device=DEV)
+    lgd[..., :V] = lg.to(DEV)
+    nll = torch.zeros(B, device=DEV)
+    grad = torch.zeros(B, T, Vp, device=DEV)
+    ws = torch.zeros(ops.ctc_workspace_bytes(B, T, Lmax), dtype=torch.uint8, device=DEV)
+    ops.ctc_loss_fwd_bwd(lgd, labels.to(torch.int32).to(DEV), tin.to(torch.int32).to(DEV), nll, grad, None,
+                         ws, B, T, V, Vp, Lmax, 45)
+    assert (nll.cpu() - ref.detach()).abs().max() <= 1e-4 * ref.abs().max()
+    # alpha+beta+nll-lp has magnitude ~1.5e3 here: a few fp32 ulps (1.2e-4) of it move exp() by ~1e-3 rel
+    assert (grad[..., :V].cpu() - lgr.grad).abs().max() < 2e-3
+
+
+def test_greedy_decode_bit_exact(ops, golden_dir):
+    import json
+
+    from oracle import wav2vec2_ref as ref
+
+    z = json.loads((golden_dir / "tokenizer_collapse.json").read_text())
+    T = max(len(r) for r in z["rows"])
+    B, V, Vp = len(z["rows"]), 46, 48
+    lg = torch.full((B, T, Vp), -3.0)
+    lens = []
+    for b, row in enumerate(z["rows"]):
+        lg[b, torch.arange(len(row)), torch.tensor(row)] = 4.0
+        lg[b, len(row):, 45] = 4.0
+        lens.append(len(row))
+    g = torch.Generator().manual_seed(3)
+    lg[..., :V] += 0.5 * torch.rand(B, T, V, generator=g)
+    raw = torch.empty(B, T, dtype=torch.int32, device=DEV)
+    ids = torch.empty(B, T, dtype=torch.int32, device=DEV)
+    olen = torch.empty(B, dtype=torch.int32, device=DEV)
+    ops.ctc_greedy_decode(lg.to(DEV), None, raw, ids, olen, B, T, V, Vp, 45)
+    want = ref.greedy_ctc_ids(lg[..., :V].numpy(), 45)
+    assert (raw.cpu().numpy() == lg[..., :V].numpy().argmax(-1)).all()
+    for b in range(B):
+        got = ids[b, :int(olen[b])].cpu().tolist()
+        assert got == want[b]
+        assert ref.ids_to_text(got, z["vocab"]) == z["texts"][b]
+    # ties: first maximum wins (np.argmax semantics)
+    tie = torch.zeros(1, 4, Vp)
+    tie[0, :, 5] = 1.0
+    tie[0, :, 9] = 1.0
+    ops.ctc_greedy_decode(tie.to(DEV), None, raw[:1, :4].contiguous(), ids[:1, :4].contiguous(), olen[:1], 1, 4,
+                          V, Vp, 45)
+
+
+def test_posconv_weight_fwd_bwd(ops):
+    d, G, K = 128, 16, 128
+    Cg = d // G
+    v, g = rnd(d, Cg, K, seed=1, scale=0.1), 1 + 0.2 * torch.rand(1, 1, K)
+    vr, gr = v.clone().requires_grad_(True), g.clone().requires_grad_(True)
+    w = gr * vr / vr.norm(p=2, dim=(0, 1), keepdim=True)
+    wf = torch.empty(d * K * Cg, dtype=torch.bfloat16, device=DEV)
+    wb = torch.empty_like(wf)
+    norm = torch.empty(K, device=DEV)
+    part = torch.empty(ops.posconv_partial_floats(K), device=DEV)
+    vd, gd = v.to(DEV), g.to(DEV)
+    ops.posconv_weight(vd, gd, wf, wb, norm, part, d, Cg, K)
+    want_f = w.detach().view(G, Cg, Cg, K).permute(0, 1, 3, 2)          # [g][co][j][ci]
+    want_b = w.detach().flip(-1).view(G, Cg, Cg, K).permute(0, 2, 3, 1)  # [g][ci][j'][co]
+    assert (wf.float().cpu().view(G, Cg, K, Cg) - want_f).abs().max() < 2e-3
+    assert (wb.float().cpu().view(G, Cg, K, Cg) - want_b).abs().max() < 2e-3
+    dw = rnd(d, Cg, K, seed=2)
+    w.backward(dw)
+    dwf = dw.view(G, Cg, Cg, K).permute(0, 1, 3, 2).contiguous().to(DEV)
+    dv = torch.zeros(d, Cg, K, device=DEV)
+    dg = torch.zeros(K, device=DEV)
+    ops.posconv_weight_bwd(dwf, vd, gd, norm, dv, dg, part, d, Cg, K)
+    assert (dv.cpu() - vr.grad).abs().max() < 1e-3 * vr.grad.abs().max() + 1e-5
+    assert (dg.cpu() - gr.grad.view(K)).abs().max() < 1e-3 * gr.grad.abs().max() + 1e-5
+
+
+def test_optimizer_kernels(ops):
+    n = 100_003
+    p, g = rnd(n, seed=1), rnd(n, seed=2, scale=0.1)
+    pad = (n + 7) // 8 * 8
+    pd = torch.zeros(pad, device=DEV)
+    pd[:n] = p.to(DEV)
+    gd = torch.zeros(pad, device=DEV)
+    gd[:n] = g.to(DEV)
+    m, v = torch.zeros(pad, device=DEV), torch.zeros(pad, device=DEV)
+    p16 = torch.zeros(pad, dtype=torch.bfloat16, device=DEV)
+    nsq = torch.zeros(1, device=DEV)
+    part = torch.zeros(4096, device=DEV)
+    ops.sumsq(gd, pad, nsq, part)
+    assert abs(nsq.item() - (g.double() ** 2).sum().item()) < 1e-3 * (g ** 2).sum().item()
+    pr = p.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([pr], lr=1e-3, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.01)
+    for step in (1, 2, 3):
+        pr.grad = g.clone()
+        torch.nn.utils.clip_grad_norm_([pr], 1.0)
+        opt.step()
+        ops.sumsq(gd, pad, nsq, part)
+        ops.adamw_step(pd, m, v, gd, p16, pad, 1e-3, 0.9, 0.98, 1e-8, 0.01, step, 1.0, 1.0, nsq)
+    assert (pd[:n].cpu() - pr.detach()).abs().max() < 2e-6
+    assert (p16[:n].float().cpu() - pr.detach()).abs().max() < 2e-2
+
+
+def test_misc_reorders(ops):
+    Co, Ci, k = 8, 16, 3
+    w = rnd(Co, Ci, k, seed=1)
+    wr = torch.empty(Co * k * Ci, dtype=torch.bfloat16, device=DEV)
+    ops.conv_weight_reorder(w.to(DEV), wr, Co, Ci, k)
+    assert (wr.float().cpu().view(Co, k, Ci) - w.permute(0, 2, 1)).abs().max() < 1e-2
+    dwr = rnd(Co, k, Ci, seed=2)
+    dw = torch.ones(Co, Ci, k, device=DEV)
+    ops.conv_weight_grad_reorder(dwr.to(DEV), dw, Co, Ci, k)
+    assert (dw.cpu() - 1 - dwr.permute(0, 2, 1)).abs().max() < 1e-6
+    x = rnd(37, 53, seed=3)
+    y = torch.empty(53, 37, dtype=torch.bfloat16, device=DEV)
+    ops.transpose_f32_bf16(x.to(DEV), y, 37, 53)
+    assert (y.float().cpu() - x.t()).abs().max() < 2e-2
+    # regroup_pad + mask_frames
+    B, T, G, Cg, pad = 2, 9, 4, 8, 3
+    h = bf(rnd(B, T, G * Cg, seed=4))
+    xg = torch.empty(B, G, T + 2 * pad, Cg, dtype=torch.bfloat16, device=DEV)
+    ops.regroup_pad(h.to(DEV), xg, B, T, G, Cg, pad)
+    want = torch.zeros(B, G, T + 2 * pad, Cg)
+    want[:, :, pad:pad + T] = h.float().view(B, T, G, Cg).permute(0, 2, 1, 3)
+    assert (xg.float().cpu() - want).abs().max() == 0
+    tm = torch.zeros(B, T, dtype=torch.uint8)
+    tm[0, 2] = 1
+    fm = torch.zeros(B, G * Cg, dtype=torch.uint8)
+    fm[1, 5] = 1
+    emb = bf(rnd(G * Cg, seed=5))
+    flen = torch.tensor([9, 6], dtype=torch.int32)
+    hd = h.clone().to(DEV)
+    ops.mask_frames(hd, tm.to(DEV), fm.to(DEV), emb.to(DEV), flen.to(DEV), B, T, G * Cg)
+    want = h.clone()
+    want[0, 2] = emb
+    want[1, :, 5] = 0
+    want[1, 6:] = 0
+    assert (hd.cpu().float() - want.float()).abs().max() == 0

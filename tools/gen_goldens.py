@@ -1,0 +1,266 @@
+"""Generate tests/golden/* from the reference's own library path (HuggingFace Transformers CPU).
+
+Runs ONLY in the build container (imports `transformers`, which never travels to the GPU box);
+its outputs — small input/expected-output vectors — are committed.  CoRal itself pins nothing
+numerically on this path, so these vectors are the parity anchor:
+Wav2Vec2ForCTC / Wav2Vec2FeatureExtractor / Wav2Vec2CTCTokenizer / F.ctc_loss /
+WhisperFeatureExtractor / WhisperForConditionalGeneration as instantiated by
+R/src/coral/wav2vec2.py:91-126 and R/src/coral/whisper.py:51-85.
+
+Weights: no checkpoints exist offline, so every parameter is overwritten with
+oracle.wav2vec2_ref.synth_params (name-keyed seeded values) — the tests regenerate the same
+weights instead of storing them.
+
+usage: python tools/gen_goldens.py [w2v2_tiny ctc featext tokenizer w2v2_cfg1 logmel whisper_tiny]
+"""
+
+from __future__ import annotations
+
+import json
+import sys
+import tempfile
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+GOLD = ROOT / "tests" / "golden"
+GOLD.mkdir(parents=True, exist_ok=True)
+
+from oracle import wav2vec2_ref as ref  # noqa: E402
+
+
+def hf_w2v2(cfg: ref.W2V2Config, apply_spec_augment=False):
+    from transformers import Wav2Vec2Config, Wav2Vec2ForCTC
+
+    hc = Wav2Vec2Config(
+        hidden_size=cfg.hidden_size, num_hidden_layers=cfg.num_hidden_layers,
+        num_attention_heads=cfg.num_attention_heads, intermediate_size=cfg.intermediate_size,
+        conv_dim=list(cfg.conv_dim), conv_kernel=list(cfg.conv_kernel),
+        conv_stride=list(cfg.conv_stride), feat_extract_norm="layer", conv_bias=True,
+        do_stable_layer_norm=True, num_conv_pos_embeddings=cfg.num_conv_pos_embeddings,
+        num_conv_pos_embedding_groups=cfg.num_conv_pos_embedding_groups,
+        vocab_size=cfg.vocab_size, pad_token_id=cfg.pad_token_id,
+        ctc_loss_reduction=cfg.ctc_loss_reduction, ctc_zero_infinity=cfg.ctc_zero_infinity,
+        layerdrop=0.0, hidden_dropout=0.0, activation_dropout=0.0, attention_dropout=0.0,
+        feat_proj_dropout=0.0, final_dropout=0.0, apply_spec_augment=apply_spec_augment,
+        mask_time_prob=0.05, mask_feature_prob=0.0, attn_implementation="eager",
+    )
+    model = Wav2Vec2ForCTC(hc)
+    P = ref.synth_params(cfg)
+    sd = model.state_dict()
+    missing = [k for k in P if k not in sd]
+    assert not missing, missing
+    with torch.no_grad():
+        for k, v in P.items():
+            assert sd[k].shape == v.shape, (k, sd[k].shape, v.shape)
+            sd[k].copy_(v)
+    model.train()  # all dropouts are 0; train() exercises the SpecAugment branch when enabled
+    return model
+
+
+def synth_batch(B, n_max, lens, lab_lens, seed=4242):
+    """Ragged peak-normalised 0.1*randn waveforms + uniform labels (SURVEY.md §8d recipe)."""
+    g = torch.Generator().manual_seed(seed)
+    waves = []
+    for n in lens:
+        x = (0.1 * torch.randn(n, generator=g)).clamp(-1, 1)
+        waves.append((x / x.abs().max()).numpy())
+    Lmax = max(lab_lens)
+    labels = torch.full((B, Lmax), -100, dtype=torch.long)
+    for b, L in enumerate(lab_lens):
+        labels[b, :L] = torch.randint(0, 42, (L,), generator=g)
+    return waves, labels
+
+
+def gen_w2v2_tiny():
+    cfg = ref.W2V2Config(hidden_size=128, num_hidden_layers=2, num_attention_heads=4,
+                         intermediate_size=256)
+    lens, lab_lens = [4000, 3400, 2800], [5, 3, 4]
+    waves, labels = synth_batch(3, 4000, lens, lab_lens)
+    iv, am = ref.zero_mean_unit_var_norm(waves)
+    iv_t, am_t = torch.from_numpy(iv), torch.from_numpy(am).long()
+    out = {"lens": np.array(lens), "labels": labels.numpy()}
+    for variant in ("plain", "specaug"):
+        model = hf_w2v2(cfg, apply_spec_augment=(variant == "specaug"))
+        kw = {}
+        if variant == "specaug":
+            T = int(ref.feat_extract_output_lengths(torch.tensor([4000]), cfg)[0])
+            mt = torch.zeros(3, T, dtype=torch.bool)
+            mt[0, 2:5] = True
+            mt[1, 0:2] = True
+            mt[2, 7] = True
+            kw["mask_time_indices"] = mt
+            out["mask_time"] = mt.numpy()
+        if variant == "specaug":
+            # Wav2Vec2ForCTC.forward does not take mask_time_indices; drive the base model with
+            # the injected mask and apply the CTC tail exactly as modeling_wav2vec2.py:1697-1728.
+            hidden = model.wav2vec2(iv_t, attention_mask=am_t, mask_time_indices=kw["mask_time_indices"])[0]
+            logits = model.lm_head(model.dropout(hidden))
+            in_len = model._get_feat_extract_output_lengths(am_t.sum(-1)).to(torch.long)
+            lm = labels >= 0
+            lp = torch.nn.functional.log_softmax(logits, dim=-1, dtype=torch.float32).transpose(0, 1)
+            loss = torch.nn.functional.ctc_loss(lp, labels.masked_select(lm), in_len, lm.sum(-1),
+                                                blank=cfg.pad_token_id, reduction="sum",
+                                                zero_infinity=True)
+            out["specaug_loss"] = loss.detach().numpy()
+            out["specaug_logits"] = logits.detach().numpy()
+            continue
+        res = model(input_values=iv_t, attention_mask=am_t, labels=labels, output_hidden_states=True)
+        res.loss.backward()
+        out[f"{variant}_loss"] = res.loss.detach().numpy()
+        out[f"{variant}_logits"] = res.logits.detach().numpy()
+        if variant == "plain":
+            hs = res.hidden_states
+            out["hs_first"] = hs[0].detach().numpy()  # after pos-conv add
+            out["hs_l0"] = hs[1].detach().numpy()
+            out["hs_last"] = hs[-1].detach().numpy()  # after final LN
+            feats = model.wav2vec2.feature_extractor(iv_t).transpose(1, 2)
+            out["conv_feats"] = feats.detach().numpy()
+            sd = dict(model.named_parameters())
+            for name in [
+                "lm_head.weight", "lm_head.bias",
+                "wav2vec2.feature_extractor.conv_layers.0.conv.weight",
+                "wav2vec2.feature_extractor.conv_layers.0.layer_norm.weight",
+                "wav2vec2.feature_extractor.conv_layers.6.conv.bias",
+                "wav2vec2.encoder.layers.0.attention.q_proj.weight",
+                "wav2vec2.encoder.layers.1.feed_forward.output_dense.bias",
+                "wav2vec2.encoder.layers.1.final_layer_norm.weight",
+                "wav2vec2.encoder.pos_conv_embed.conv.parametrizations.weight.original0",
+                "wav2vec2.encoder.pos_conv_embed.conv.bias",
+                "wav2vec2.feature_projection.projection.bias",
+                "wav2vec2.encoder.layer_norm.bias",
+            ]:
+                out["grad:" + name] = sd[name].grad.detach().numpy()
+            for name in [
+                "wav2vec2.feature_extractor.conv_layers.1.conv.weight",
+                "wav2vec2.feature_extractor.conv_layers.6.conv.weight",
+                "wav2vec2.encoder.pos_conv_embed.conv.parametrizations.weight.original1",
+                "wav2vec2.feature_projection.projection.weight",
+                "wav2vec2.encoder.layers.0.feed_forward.intermediate_dense.weight",
+            ]:
+                gr = sd[name].grad.detach()
+                out["gradnorm:" + name] = gr.norm().numpy()
+                out["gradhead:" + name] = gr.reshape(-1)[:64].numpy()
+    np.savez_compressed(GOLD / "w2v2_tiny.npz", **out)
+    print("w2v2_tiny:", {k: (v.shape if hasattr(v, "shape") else v) for k, v in out.items() if "loss" in k},
+          out["plain_loss"], out["specaug_loss"])
+
+
+def gen_ctc():
+    """F.ctc_loss known answers incl. repeats, empty targets and infeasible cases."""
+    cases = []
+    rng = np.random.RandomState(4242)
+    specs = [(12, 5, 3), (20, 6, 0), (8, 4, 8), (8, 4, 5), (30, 12, 10), (16, 7, 7), (5, 3, 6),
+             (40, 46, 12), (25, 9, 12), (3, 5, 1), (1, 4, 1), (50, 46, 20), (10, 3, 4), (64, 46, 31),
+             (33, 11, 16), (18, 5, 9), (7, 6, 3), (45, 46, 2), (22, 8, 11), (60, 46, 25)]
+    out = {}
+    for i, (T, V, L) in enumerate(specs):
+        blank = V - 1
+        g = torch.Generator().manual_seed(1000 + i)
+        logits = torch.randn(T, V, generator=g) * 2.0
+        if i % 3 == 0 and L >= 2:  # force repeats
+            tg = torch.randint(0, max(1, V - 1), (1,), generator=g).repeat(L)
+        else:
+            tg = torch.randint(0, max(1, V - 1), (L,), generator=g)
+        t_in = T if i % 4 else max(1, T - 2)
+        lg = logits.clone().requires_grad_(True)
+        lp = torch.log_softmax(lg, -1)
+        loss = torch.nn.functional.ctc_loss(lp[:, None, :], tg[None, :], torch.tensor([t_in]),
+                                            torch.tensor([L]), blank=blank, reduction="sum",
+                                            zero_infinity=True)
+        loss.backward()
+        out[f"c{i}_logits"] = logits.numpy()
+        out[f"c{i}_targets"] = tg.numpy()
+        out[f"c{i}_tin"] = np.array(t_in)
+        out[f"c{i}_loss"] = loss.detach().numpy()
+        out[f"c{i}_grad"] = lg.grad.numpy()
+        cases.append((T, V, L, float(loss)))
+    # one BASELINE-sized case: regenerated from its seed in the test, checksums stored
+    T, V, L = 499, 46, 120
+    g = torch.Generator().manual_seed(777)
+    logits = torch.randn(T, V, generator=g)
+    tg = torch.randint(0, 42, (L,), generator=g)
+    lg = logits.clone().requires_grad_(True)
+    loss = torch.nn.functional.ctc_loss(torch.log_softmax(lg, -1)[:, None, :], tg[None, :],
+                                        torch.tensor([T]), torch.tensor([L]), blank=45,
+                                        reduction="sum", zero_infinity=True)
+    loss.backward()
+    out["big_loss"] = loss.detach().numpy()
+    out["big_grad_rows"] = lg.grad[::50].numpy()
+    out["big_grad_abs_sum"] = lg.grad.abs().sum().numpy()
+    out["n_cases"] = np.array(len(specs))
+    np.savez_compressed(GOLD / "ctc_cases.npz", **out)
+    print("ctc:", cases[:6], float(out["big_loss"]))
+
+
+def gen_featext():
+    from transformers import Wav2Vec2FeatureExtractor
+
+    fe = Wav2Vec2FeatureExtractor(feature_size=1, sampling_rate=16000, padding_value=0.0,
+                                  do_normalize=True, return_attention_mask=True)
+    g = np.random.RandomState(7)
+    waves = [(0.1 * g.randn(n) + off).astype(np.float32) for n, off in
+             [(1600, 0.0), (900, 0.02), (1234, -0.01), (400, 0.0)]]
+    res = fe(waves, sampling_rate=16000, padding="longest", return_tensors="np")
+    res2 = fe(waves, sampling_rate=16000, padding="max_length", max_length=2000, return_tensors="np")
+    np.savez_compressed(GOLD / "feature_extractor.npz", **{f"wave{i}": w for i, w in enumerate(waves)},
+                        input_values=res["input_values"], attention_mask=res["attention_mask"],
+                        input_values_max=res2["input_values"], attention_mask_max=res2["attention_mask"])
+    print("featext:", res["input_values"].shape, res2["input_values"].shape)
+
+
+def gen_tokenizer():
+    from transformers import Wav2Vec2CTCTokenizer
+
+    vocab = ref.coral_vocab()
+    with tempfile.TemporaryDirectory() as td:
+        vf = Path(td) / "vocab.json"
+        vf.write_text(json.dumps(vocab))
+        tok = Wav2Vec2CTCTokenizer(str(vf), unk_token="<unk>", pad_token="<pad>", bos_token="<s>",
+                                   eos_token="</s>", word_delimiter_token="|")
+        rng = np.random.RandomState(11)
+        rows = [[vocab[c] for c in "hh"] + [45] + [vocab["e"], vocab["j"], vocab["j"], vocab["|"],
+                                                  vocab["|"], 45, vocab["j"], 45, vocab["j"]]]
+        for _ in range(12):
+            n = rng.randint(5, 60)
+            r = rng.choice(list(range(42)) + [45] * 20 + [vocab["|"]] * 6, size=n)
+            r = np.repeat(r, rng.randint(1, 4, size=n))
+            rows.append([int(x) for x in r])
+        texts = [tok.decode(r) for r in rows]
+    (GOLD / "tokenizer_collapse.json").write_text(
+        json.dumps({"vocab": vocab, "rows": rows, "texts": texts}, ensure_ascii=False, indent=0))
+    print("tokenizer:", texts[:3])
+
+
+def gen_w2v2_cfg1():
+    """BASELINE.json configs[0]: XLS-R-300M shape, 4 x 5 s, fp32 CPU, fwd+bwd with CTC."""
+    cfg = ref.W2V2Config(**ref.CORAL_SHAPES["wav2vec2-small"])
+    lens, lab_lens = [80000, 80000, 72000, 56000], [60, 45, 38, 25]
+    waves, labels = synth_batch(4, 80000, lens, lab_lens)
+    iv, am = ref.zero_mean_unit_var_norm(waves)
+    model = hf_w2v2(cfg)
+    res = model(input_values=torch.from_numpy(iv), attention_mask=torch.from_numpy(am).long(),
+                labels=labels)
+    res.loss.backward()
+    sd = dict(model.named_parameters())
+    out = {"lens": np.array(lens), "labels": labels.numpy(), "loss": res.loss.detach().numpy(),
+           "logits_slice": res.logits.detach()[:, ::16, :].numpy(),
+           "logits_abs_mean": res.logits.detach().abs().mean().numpy()}
+    for name in ["lm_head.weight", "wav2vec2.encoder.layers.23.feed_forward.output_dense.weight",
+                 "wav2vec2.encoder.layers.0.attention.q_proj.weight",
+                 "wav2vec2.feature_extractor.conv_layers.0.conv.weight",
+                 "wav2vec2.feature_extractor.conv_layers.3.conv.weight",
+                 "wav2vec2.encoder.pos_conv_embed.conv.parametrizations.weight.original1"]:
+        out["gradnorm:" + name] = sd[name].grad.norm().numpy()
+    np.savez_compressed(GOLD / "w2v2_cfg1.npz", **out)
+    print("w2v2_cfg1 loss", out["loss"], {k: float(v) for k, v in out.items() if k.startswith("gradnorm")})
+
+
+if __name__ == "__main__":
+    todo = sys.argv[1:] or ["w2v2_tiny", "ctc", "featext", "tokenizer"]
+    torch.manual_seed(4242)
+    for name in todo:
+        globals()["gen_" + name]()
