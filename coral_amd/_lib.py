@@ -73,6 +73,9 @@ SIGNATURES = {
     "ca_last_error": (C.c_char_p, []),
     "ca_device_count": (C.c_int, []),
     "ca_gemm_bf16": (C.c_int, [C.POINTER(CaGemmDesc), _vp]),
+    "ca_gemm_force_kernel": (C.c_int, [C.c_int]),
+    "ca_prof_begin": (C.c_int, []),
+    "ca_prof_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "ca_layernorm_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _i32, _vp]),
     "ca_layernorm_bwd_partial_floats": (_i64, [_i64, _i32]),
     "ca_layernorm_bwd": (

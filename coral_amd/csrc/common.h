@@ -77,3 +77,7 @@ __device__ __forceinline__ bool ca_dropout_keep(uint64_t seed, uint64_t idx, flo
   const float u = (float)(ca_hash32(seed, idx) >> 8) * (1.0f / 16777216.0f);
   return u >= p;
 }
+
+// out[i] (+)= sum_p partial[p*stride + i]  (defined in norm.hip)
+void ca_reduce_partials_launch(const float* partial, int nparts, int64_t stride, int n, float* out,
+                               int accumulate, hipStream_t s);

@@ -134,7 +134,7 @@ extern "C" int ca_conv0_ln_gelu_fwd(const float* x, const float* w, const float*
 // backward: recompute conv + LN from x; accumulate dw[C][k], dbias, dgamma, dbeta per wave in
 // registers, reduce over the block's waves in LDS, one partial row per block:
 // partial[blk][C*(k+3)] laid out as [dw (C*k) | dbias (C) | dgamma (C) | dbeta (C)].
-#define CONV0_BWD_GRID 1024
+#define CONV0_BWD_GRID 512
 template <int KW>
 __global__ __launch_bounds__(256) void conv0_bwd_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
@@ -235,15 +235,6 @@ __global__ __launch_bounds__(256) void conv0_bwd_kernel(
   }
 }
 
-__global__ void reduce_partials_kernel2(const float* __restrict__ partial, int nparts,
-                                        int64_t stride, int n, float* __restrict__ out) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float a = 0.f;
-  for (int p = 0; p < nparts; ++p) a += partial[(int64_t)p * stride + i];
-  out[i] += a;
-}
-
 static int conv0_bwd_grid(int32_t B, int64_t T0) {
   int64_t g = ((int64_t)B * T0 + 3) / 4;
   if (g > CONV0_BWD_GRID) g = CONV0_BWD_GRID;
@@ -271,14 +262,10 @@ extern "C" int ca_conv0_ln_gelu_bwd(const float* x, const float* w, const float*
   hipLaunchKernelGGL((conv0_bwd_kernel<10>), dim3(g), dim3(256), 0, s, x, w, bias, gamma, beta,
                      (const unsigned short*)dy, partial, B, N, T0, stride, eps);
   const int64_t st = (int64_t)C0 * (k + 3);
-  hipLaunchKernelGGL(reduce_partials_kernel2, dim3((C0 * k + 255) / 256), dim3(256), 0, s,
-                     partial, g, st, C0 * k, dw);
-  hipLaunchKernelGGL(reduce_partials_kernel2, dim3(2), dim3(256), 0, s, partial + C0 * k, g, st,
-                     C0, dbias);
-  hipLaunchKernelGGL(reduce_partials_kernel2, dim3(2), dim3(256), 0, s, partial + C0 * (k + 1),
-                     g, st, C0, dgamma);
-  hipLaunchKernelGGL(reduce_partials_kernel2, dim3(2), dim3(256), 0, s, partial + C0 * (k + 2),
-                     g, st, C0, dbeta);
+  ca_reduce_partials_launch(partial, g, st, C0 * k, dw, 1, s);
+  ca_reduce_partials_launch(partial + C0 * k, g, st, C0, dbias, 1, s);
+  ca_reduce_partials_launch(partial + C0 * (k + 1), g, st, C0, dgamma, 1, s);
+  ca_reduce_partials_launch(partial + C0 * (k + 2), g, st, C0, dbeta, 1, s);
   CA_CHECK_LAUNCH("ca_conv0_ln_gelu_bwd");
   return CA_OK;
 }

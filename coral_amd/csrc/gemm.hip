@@ -32,14 +32,16 @@ __device__ __forceinline__ void glds16(const void* g, char* lds_wave_base) {
 }
 
 // ---- per-lane loader state -------------------------------------------------------------
-struct KMajorLoader {  // operand stored [row][k], k contiguous
-  const char* p[4];    // current source (advanced BK elements per step)
-  int kc[4];           // element offset of this lane's chunk inside the k-step
+// NI = LDS-DMA instructions per wave per tile (each moves 1 KiB = 64 lanes x 16 B).
+template <int NI>
+struct KMajorLoader {  // operand stored [row][k], k contiguous; LDS image [rows][64 k], 128-B rows
+  const char* p[NI];   // current source (advanced BK elements per step)
+  int kc[NI];          // element offset of this lane's chunk inside the k-step
   __device__ __forceinline__ void init(const __bf16* base, int64_t ld, int row0, int nrows,
                                        int wave, int lane) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int r = (wave * 4 + i) * 8 + (lane >> 3);
+    for (int i = 0; i < NI; ++i) {
+      const int r = (wave * NI + i) * 8 + (lane >> 3);
       const int c = (lane & 7) ^ ((r >> 1) & 7);
       int rr = row0 + r;
       rr = rr < nrows ? rr : nrows - 1;
@@ -49,57 +51,59 @@ struct KMajorLoader {  // operand stored [row][k], k contiguous
   }
   __device__ __forceinline__ void issue(char* tile, int wave, int k0, int K) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NI; ++i) {
       const void* src = (k0 + kc[i] < K) ? (const void*)p[i] : (const void*)g_ca_zero_page;
-      glds16(src, tile + (wave * 4 + i) * 1024);
+      glds16(src, tile + (wave * NI + i) * 1024);
       p[i] += BK * 2;
     }
   }
 };
 
-struct MNMajorLoader {  // operand stored [k][mn], mn contiguous; k rows may be segmented
-  const char* colp[4];
-  int t[4];
-  int seg[4];
-  int64_t ld, segstride;
+// operand stored [k][mn], mn contiguous; LDS image [64 k][PC*8 mn]; PC = 16-B chunks per row.
+// The source pointer of each lane walks down the k rows by plain 64-bit adds (BK rows per step);
+// with segmented rows (kseg > 0) it hops by (segstride - kseg*ld) whenever it crosses a segment.
+template <int NI, int PC>
+struct MNMajorLoader {
+  const char* p[NI];  // current source address of this lane's chunk
+  int t[NI];          // row index inside the current segment
+  int64_t step, hop;  // bytes per BK rows; extra bytes when crossing a segment boundary
   int kseg;
-  __device__ __forceinline__ void init(const __bf16* base, int64_t ld_, int kseg_,
-                                       int64_t segstride_, int col0, int ncols, int wave,
+  static constexpr int RPI = 64 / PC;  // k-rows per LDS-DMA instruction
+  __device__ __forceinline__ void init(const __bf16* base, int64_t ld, int kseg_,
+                                       int64_t segstride, int col0, int ncols, int wave,
                                        int lane) {
-    ld = ld_;
     kseg = kseg_;
-    segstride = segstride_;
+    step = (int64_t)BK * ld * 2;
+    hop = kseg > 0 ? (segstride - (int64_t)kseg * ld) * 2 : 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int kr = (wave * 4 + i) * 4 + (lane >> 4);
+    for (int i = 0; i < NI; ++i) {
+      const int kr = (wave * NI + i) * RPI + lane / PC;
       const int swz = (kr & 3) | (((kr >> 3) & 1) << 2);
-      const int c = (lane & 15) ^ (swz << 1);
+      const int c = (lane % PC) ^ (swz << 1);
       int cc = col0 + c * 8;
       const int nc8 = (ncols + 7) & ~7;  // rows are readable up to ncols rounded up to 8
       cc = cc <= nc8 - 8 ? cc : nc8 - 8;
-      colp[i] = (const char*)(base + cc);
+      int seg = 0, tt = kr;
       if (kseg > 0) {
-        seg[i] = kr / kseg;
-        t[i] = kr % kseg;
-      } else {
-        seg[i] = 0;
-        t[i] = kr;
+        seg = kr / kseg;
+        tt = kr % kseg;
       }
+      t[i] = tt;
+      p[i] = (const char*)(base + cc) + ((int64_t)seg * segstride + (int64_t)tt * ld) * 2;
     }
   }
   __device__ __forceinline__ void issue(char* tile, int wave, int lane, int k0, int K) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int kr = (wave * 4 + i) * 4 + (lane >> 4);
-      const int64_t off = (int64_t)seg[i] * segstride + (int64_t)t[i] * ld;
-      const void* src =
-          (k0 + kr < K) ? (const void*)(colp[i] + off * 2) : (const void*)g_ca_zero_page;
-      glds16(src, tile + (wave * 4 + i) * 1024);
-      t[i] += BK;
+    for (int i = 0; i < NI; ++i) {
+      const int kr = (wave * NI + i) * RPI + lane / PC;
+      const void* src = (k0 + kr < K) ? (const void*)p[i] : (const void*)g_ca_zero_page;
+      glds16(src, tile + (wave * NI + i) * 1024);
+      p[i] += step;
       if (kseg > 0) {
+        t[i] += BK;
         while (t[i] >= kseg) {
           t[i] -= kseg;
-          seg[i] += 1;
+          p[i] += hop;
         }
       }
     }
@@ -114,7 +118,9 @@ __device__ __forceinline__ bf16x8_t frag_kmajor(const char* tile, int rb, int s,
   const int c = (4 * s + (lane >> 4)) ^ ((r >> 1) & 7);
   return *(const bf16x8_t*)(tile + r * 128 + c * 16);
 }
-// MNMAJOR tile: 16 columns starting at cb (multiple of 16), k-step s: two transposed reads.
+// MNMAJOR tile (row pitch PITCH bytes): 16 columns starting at cb (multiple of 16), k-step s:
+// two transposed reads (k = 8g..8g+3 and 8g+4..8g+7 of the 32-k step).
+template <int PITCH>
 __device__ __forceinline__ bf16x8_t frag_mnmajor(const char* tile, int cb, int s, int lane) {
   const int g = lane >> 4;
   const int q = (lane & 15) >> 2;
@@ -122,16 +128,177 @@ __device__ __forceinline__ bf16x8_t frag_mnmajor(const char* tile, int cb, int s
   const int kr = 32 * s + 8 * g + q;
   const int swz = q | ((g & 1) << 2);
   const int c = ((cb >> 3) + (p >> 1)) ^ (swz << 1);
-  const char* a0 = tile + kr * 256 + c * 16 + (p & 1) * 8;
+  const char* a0 = tile + kr * PITCH + c * 16 + (p & 1) * 8;
   s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
       (__attribute__((address_space(3))) s16x4_t*)(lptr_t)a0);
   s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-      (__attribute__((address_space(3))) s16x4_t*)(lptr_t)(a0 + 4 * 256));
+      (__attribute__((address_space(3))) s16x4_t*)(lptr_t)(a0 + 4 * PITCH));
   typedef __attribute__((ext_vector_type(8))) short s16x8_t;
   s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   return __builtin_bit_cast(bf16x8_t, v);
 }
 
+// XCD-aware tile rasterisation.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and
+// b+8 share an L2), and the tiles that are resident together on one XCD should share operand
+// panels: they stream the same K-slices at about the same time, so each slice is pulled across
+// the fabric once per XCD and served to the other tiles from that XCD's 4-MiB L2.  The grid is
+// cut into super-blocks of SBM x SBN tiles (= the number of tiles one XCD holds at once); the
+// i-th workgroup of XCD x works on tile (i % (SBM*SBN)) of super-block (i / (SBM*SBN))*8 + x.
+// Placement only affects speed: any dispatch order gives the same result.
+template <int SBM, int SBN>
+__device__ __forceinline__ bool tile_of_block(int bid, int ntm, int ntn, int& tm, int& tn) {
+  const int x = bid & 7, i = bid >> 3;
+  const int per = SBM * SBN;
+  const int sb = (i / per) * 8 + x, t = i % per;
+  const int nsbn = (ntn + SBN - 1) / SBN;
+  const int sbm = sb / nsbn, sbn = sb % nsbn;
+  tm = sbm * SBM + (t % SBM);
+  tn = sbn * SBN + (t / SBM);
+  return tm < ntm && tn < ntn;
+}
+template <int SBM, int SBN>
+static inline unsigned tile_grid(int ntm, int ntn) {
+  const int nsb = ((ntm + SBM - 1) / SBM) * ((ntn + SBN - 1) / SBN);
+  return (unsigned)(((nsb + 7) / 8) * 8 * SBM * SBN);
+}
+
+// ---- epilogue --------------------------------------------------------------------------------
+// Each wave parks its 64x64 fp32 tile in LDS (row pitch 68 floats: conflict-free b128 writes),
+// then walks it 4 rows x 64 columns at a time in a rolled loop so the generic (runtime-selected)
+// epilogue is emitted once and every row is stored as one contiguous 128-B (bf16) / 256-B (fp32)
+// segment.  mw/nw: global row/column of the wave's tile origin.
+__device__ __forceinline__ void gemm_epilogue(const CaGemmDesc& d, f32x4_t (&acc)[4][4], char* smem,
+                                              int wave, int lane, int mw, int nw, int z, int z1,
+                                              int z2) {
+  float* wt = (float*)smem + wave * (64 * EPI_PITCH);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      *(f32x4_t*)(wt + (i * 16 + (lane & 15)) * EPI_PITCH + j * 16 + 4 * (lane >> 4)) = acc[i][j];
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private region: no barrier
+
+  // lane -> 8 consecutive columns of one row; 8 rows per pass, 8 passes; 16-byte bf16 stores
+  const int M = d.M, N = d.N;
+  const int64_t zoffC = z1 * d.sC1 + z2 * d.sC2;
+  const int64_t zoffR = z1 * d.sR1 + z2 * d.sR2;
+  const bool vec_ok = ((d.ldc & 7) == 0) && ((zoffC & 7) == 0) && ((d.ldr & 7) == 0) && ((zoffR & 7) == 0);
+  const float keep_scale = d.dropout_p > 0.f ? 1.f / (1.f - d.dropout_p) : 1.f;
+  const int nb = nw + 8 * (lane & 7);
+  const int nvalid = (N - nb) < 8 ? (N - nb) : 8;
+  if (nvalid <= 0) return;
+  const bool full = nvalid == 8 && vec_ok;
+  float bias8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (d.bias) {
+    const float* bz = d.bias + z1 * d.sBias1 + z2 * d.sBias2;
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (e < nvalid) bias8[e] = bz[nb + e];
+  }
+  const int epi = d.epilogue;
+  const bool has_gelu = epi == CA_EPI_GELU || epi == CA_EPI_GELU_RESIDUAL;
+  const bool needs_r = epi == CA_EPI_RESIDUAL || epi == CA_EPI_DGELU || epi == CA_EPI_GELU_RESIDUAL;
+#pragma unroll 1
+  for (int it = 0; it < 8; ++it) {
+    const int ml = it * 8 + (lane >> 3);
+    const int m = mw + ml;
+    if (m >= M) continue;
+    const f32x4_t a4 = *(const f32x4_t*)(wt + ml * EPI_PITCH + 8 * (lane & 7));
+    const f32x4_t b4 = *(const f32x4_t*)(wt + ml * EPI_PITCH + 8 * (lane & 7) + 4);
+    float v[8], v2[8], r[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      v[e] = (e < 4 ? a4[e] : b4[e - 4]) * d.alpha + bias8[e];
+      v2[e] = 0.f;
+      r[e] = 0.f;
+    }
+    const int64_t coff = zoffC + (int64_t)m * d.ldc + nb;
+    if (needs_r) {
+      const unsigned short* R = (const unsigned short*)d.R + zoffR + (int64_t)m * d.ldr + nb;
+      if (full) {
+        const u16x8_t u = *(const u16x8_t*)R;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r[e] = bf2f(u[e]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (e < nvalid) r[e] = bf2f(R[e]);
+      }
+    }
+    if (has_gelu) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float g = gelu_erf(v[e]);
+        if (d.dropout_p > 0.f) {
+          const uint64_t idx = ((uint64_t)z * M + m) * (uint64_t)N + (nb + e);
+          g = ca_dropout_keep(d.dropout_seed, idx, d.dropout_p) ? g * keep_scale : 0.f;
+        }
+        v2[e] = g + r[e];  // r is zero unless GELU_RESIDUAL
+      }
+    } else if (epi == CA_EPI_RESIDUAL) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += r[e];
+    } else if (epi == CA_EPI_DGELU) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float dg = dgelu_erf(r[e]);
+        if (d.dropout_p > 0.f) {
+          const uint64_t idx = ((uint64_t)z * M + m) * (uint64_t)N + (nb + e);
+          dg = ca_dropout_keep(d.dropout_seed, idx, d.dropout_p) ? dg * keep_scale : 0.f;
+        }
+        v[e] *= dg;
+      }
+    }
+    if (d.out_f32) {
+      float* C = (float*)d.C + coff;
+      if (full) {
+        if (d.accumulate) {
+          const f32x4_t c0 = *(const f32x4_t*)C, c1 = *(const f32x4_t*)(C + 4);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += e < 4 ? c0[e] : c1[e - 4];
+        }
+        *(f32x4_t*)C = (f32x4_t){v[0], v[1], v[2], v[3]};
+        *(f32x4_t*)(C + 4) = (f32x4_t){v[4], v[5], v[6], v[7]};
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (e < nvalid) C[e] = d.accumulate ? C[e] + v[e] : v[e];
+      }
+    } else if (d.C) {
+      unsigned short* C = (unsigned short*)d.C + coff;
+      if (full) {
+        if (d.accumulate) {
+          const u16x8_t c = *(const u16x8_t*)C;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += bf2f(c[e]);
+        }
+        u16x8_t o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e]);
+        *(u16x8_t*)C = o;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (e < nvalid) C[e] = f2bf(d.accumulate ? bf2f(C[e]) + v[e] : v[e]);
+      }
+    }
+    if (has_gelu && d.C2) {
+      unsigned short* C2 = (unsigned short*)d.C2 + coff;
+      if (full) {
+        u16x8_t o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = f2bf(v2[e]);
+        *(u16x8_t*)C2 = o;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (e < nvalid) C2[e] = f2bf(v2[e]);
+      }
+    }
+  }
+}
+
+// ---- kernel S: 128x128 tile, 4 waves, 2 LDS stages, 2 blocks/CU (small / batched problems) ----
 template <int AL, int BL>
 __global__ __launch_bounds__(256) void ca_gemm_kernel(const CaGemmDesc d) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -139,18 +306,8 @@ __global__ __launch_bounds__(256) void ca_gemm_kernel(const CaGemmDesc d) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-
-  // XCD-aware tile order: consecutive logical tiles (sharing an A row-panel) are dealt to
-  // the same XCD (blocks b and b+8 share an L2).  Bijective for any grid size.
-  int bid = blockIdx.x;
-  {
-    const int nwg = gridDim.x;
-    const int q = nwg >> 3, r = nwg & 7;
-    const int xcd = bid & 7, idx = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int ntn = (d.N + BN - 1) / BN;
-  const int tm = bid / ntn, tn = bid % ntn;
+  int tm, tn;
+  if (!tile_of_block<8, 8>(blockIdx.x, (d.M + BM - 1) / BM, (d.N + BN - 1) / BN, tm, tn)) return;
   const int m0 = tm * BM, n0 = tn * BN;
   const int z = blockIdx.z;
   const int z1 = z / d.batch2, z2 = z % d.batch2;
@@ -158,8 +315,8 @@ __global__ __launch_bounds__(256) void ca_gemm_kernel(const CaGemmDesc d) {
   const __bf16* A = (const __bf16*)d.A + z1 * d.sA1 + z2 * d.sA2;
   const __bf16* B = (const __bf16*)d.B + z1 * d.sB1 + z2 * d.sB2;
 
-  KMajorLoader la_k, lb_k;
-  MNMajorLoader la_m, lb_m;
+  KMajorLoader<4> la_k, lb_k;
+  MNMajorLoader<4, 16> la_m, lb_m;
   if (AL == CA_KMAJOR)
     la_k.init(A, d.lda, m0, d.M, wave, lane);
   else
@@ -209,11 +366,11 @@ __global__ __launch_bounds__(256) void ca_gemm_kernel(const CaGemmDesc d) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
         af[i] = (AL == CA_KMAJOR) ? frag_kmajor(ta, wm * 64 + i * 16, s, lane)
-                                  : frag_mnmajor(ta, wm * 64 + i * 16, s, lane);
+                                  : frag_mnmajor<256>(ta, wm * 64 + i * 16, s, lane);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         bfr[j] = (BL == CA_KMAJOR) ? frag_kmajor(tb, wn * 64 + j * 16, s, lane)
-                                   : frag_mnmajor(tb, wn * 64 + j * 16, s, lane);
+                                   : frag_mnmajor<256>(tb, wn * 64 + j * 16, s, lane);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -225,125 +382,270 @@ __global__ __launch_bounds__(256) void ca_gemm_kernel(const CaGemmDesc d) {
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   }
+  gemm_epilogue(d, acc, smem, wave, lane, m0 + wm * 64, n0 + wn * 64, z, z1, z2);
+}
 
-  // ---- epilogue --------------------------------------------------------------------------
-  // Each wave parks its 64x64 fp32 tile in LDS (row pitch 68 floats: conflict-free b128
-  // writes), then walks it 4 rows x 64 columns at a time in a rolled loop so the generic
-  // (runtime-selected) epilogue is emitted once and every row is stored as one contiguous
-  // 128-B (bf16) / 256-B (fp32) segment.
-  {
-    float* wt = (float*)smem + wave * (64 * EPI_PITCH);
+// ---- kernel L: 256x128 tile, 8 waves (4x2), 3-stage LDS ring, ONE barrier per K-step --------
+// Software pipeline: LDS-DMA runs two K-tiles ahead behind a counted vmcnt (never drained in the
+// loop); the second half (k = 32..63) of each tile's fragments is held in registers across the
+// barrier so the MFMA pipe always has 16 independent MFMAs to issue while the next tile's first
+// fragments are being read.  One workgroup per CU (144 KiB LDS).
+#define LBM 256
+#define LBN 128
+#define LA_BYTES (LBM * BK * 2)
+#define LB_BYTES (LBN * BK * 2)
+#define LSTAGE (LA_BYTES + LB_BYTES)
+#define L_NSTAGE 3
+#define L_LDS_BYTES (L_NSTAGE * LSTAGE)  // 147456 >= 8 waves * 64*68*4 (139264) epilogue staging
+
+template <int AL, int BL>
+__global__ __launch_bounds__(512) void ca_gemm_kernel_l(const CaGemmDesc d) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;  // 4 x 2 waves, 64x64 each
+  int tm, tn;
+  if (!tile_of_block<4, 8>(blockIdx.x, (d.M + LBM - 1) / LBM, (d.N + LBN - 1) / LBN, tm, tn)) return;
+  const int m0 = tm * LBM, n0 = tn * LBN;
+  const int z = blockIdx.z;
+  const int z1 = z / d.batch2, z2 = z % d.batch2;
+
+  const __bf16* A = (const __bf16*)d.A + z1 * d.sA1 + z2 * d.sA2;
+  const __bf16* B = (const __bf16*)d.B + z1 * d.sB1 + z2 * d.sB2;
+
+  const int K = d.K;
+  const int nk = (K + BK - 1) / BK;
+
+  KMajorLoader<4> la_k;
+  KMajorLoader<2> lb_k;
+  MNMajorLoader<4, 32> la_m;
+  MNMajorLoader<2, 16> lb_m;
+  if (AL == CA_KMAJOR)
+    la_k.init(A, d.lda, m0, d.M, wave, lane);
+  else
+    la_m.init(A, d.lda, d.a_kseg, d.a_kseg_stride, m0, d.M, wave, lane);
+  if (BL == CA_KMAJOR)
+    lb_k.init(B, d.ldb, n0, d.N, wave, lane);
+  else
+    lb_m.init(B, d.ldb, d.b_kseg, d.b_kseg_stride, n0, d.N, wave, lane);
+
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  auto issue_stage = [&](int kt, int stage) {
+    char* st = smem + stage * LSTAGE;
+    if (AL == CA_KMAJOR)
+      la_k.issue(st, wave, kt * BK, K);
+    else
+      la_m.issue(st, wave, lane, kt * BK, K);
+    if (BL == CA_KMAJOR)
+      lb_k.issue(st + LA_BYTES, wave, kt * BK, K);
+    else
+      lb_m.issue(st + LA_BYTES, wave, lane, kt * BK, K);
+  };
+  // Fragment reads are inline asm so that hipcc's own (conservative, lgkmcnt(0)) waits do not
+  // serialise the register pipeline; completion is tracked by the explicit s_waitcnt below.
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
+  uint32_t a_addr[2], b_addr[2];  // per-lane LDS byte address of fragment (i or j = 0) for s = 0, 1
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    if (AL == CA_KMAJOR) {
+      const int r = wm * 64 + (lane & 15);
+      a_addr[s] = lds0 + r * 128 + (((4 * s + (lane >> 4)) ^ ((r >> 1) & 7)) * 16);
+    } else {
+      const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+      const int c = (((wm * 64) >> 3) + (p >> 1)) ^ ((q | ((g & 1) << 2)) << 1);
+      a_addr[s] = lds0 + (32 * s + 8 * g + q) * 512 + c * 16 + (p & 1) * 8;
+    }
+    if (BL == CA_KMAJOR) {
+      const int r = wn * 64 + (lane & 15);
+      b_addr[s] = lds0 + LA_BYTES + r * 128 + (((4 * s + (lane >> 4)) ^ ((r >> 1) & 7)) * 16);
+    } else {
+      const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+      const int c = (((wn * 64) >> 3) + (p >> 1)) ^ ((q | ((g & 1) << 2)) << 1);
+      b_addr[s] = lds0 + LA_BYTES + (32 * s + 8 * g + q) * 256 + c * 16 + (p & 1) * 8;
+    }
+  }
+  typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+#define LDS_B128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
+#define LDS_TR(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
+  auto read_frags = [&](int stage, int s, bf16x8_t (&af)[4], bf16x8_t (&bfr)[4]) {
+    const uint32_t so = (uint32_t)stage * LSTAGE;
+    const uint32_t aa = a_addr[s] + so, ba = b_addr[s] + so;
+    if (AL == CA_KMAJOR) {
+      LDS_B128(af[0], aa, 0);
+      LDS_B128(af[1], aa, 2048);
+      LDS_B128(af[2], aa, 4096);
+      LDS_B128(af[3], aa, 6144);
+    } else {
+      // 16 columns further = 2 chunks of 16 B: the swizzle XOR only touches chunk bits 1..3, and
+      // (cb>>3) advances by 2 per fragment, so fragment i sits at +32*i bytes before the XOR; the
+      // XOR is folded into the base only when it commutes, so compute each address explicitly.
+      s16x4_t lo[4], hi[4];
+      const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+      const int sw = (q | ((g & 1) << 2)) << 1;
+      const uint32_t rowb = lds0 + so + (32 * s + 8 * g + q) * 512 + (p & 1) * 8;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const uint32_t ad = rowb + ((((wm * 64 + i * 16) >> 3) + (p >> 1)) ^ sw) * 16;
+        LDS_TR(lo[i], ad, 0);
+        LDS_TR(hi[i], ad, 2048);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        s16x8_t v = {lo[i][0], lo[i][1], lo[i][2], lo[i][3], hi[i][0], hi[i][1], hi[i][2], hi[i][3]};
+        af[i] = __builtin_bit_cast(bf16x8_t, v);
+      }
+    }
+    if (BL == CA_KMAJOR) {
+      LDS_B128(bfr[0], ba, 0);
+      LDS_B128(bfr[1], ba, 2048);
+      LDS_B128(bfr[2], ba, 4096);
+      LDS_B128(bfr[3], ba, 6144);
+    } else {
+      s16x4_t lo[4], hi[4];
+      const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+      const int sw = (q | ((g & 1) << 2)) << 1;
+      const uint32_t rowb = lds0 + so + LA_BYTES + (32 * s + 8 * g + q) * 256 + (p & 1) * 8;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t ad = rowb + ((((wn * 64 + j * 16) >> 3) + (p >> 1)) ^ sw) * 16;
+        LDS_TR(lo[j], ad, 0);
+        LDS_TR(hi[j], ad, 1024);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        s16x8_t v = {lo[j][0], lo[j][1], lo[j][2], lo[j][3], hi[j][0], hi[j][1], hi[j][2], hi[j][3]};
+        bfr[j] = __builtin_bit_cast(bf16x8_t, v);
+      }
+    }
+  };
+  auto mma = [&](bf16x8_t (&af)[4], bf16x8_t (&bfr)[4]) {
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        *(f32x4_t*)(wt + (i * 16 + (lane & 15)) * EPI_PITCH + j * 16 + 4 * (lane >> 4)) =
-            acc[i][j];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private region: no barrier
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
 
-    const int M = d.M, N = d.N;
-    const int64_t zoffC = z1 * d.sC1 + z2 * d.sC2;
-    const int64_t zoffR = z1 * d.sR1 + z2 * d.sR2;
-    const bool vec_ok = ((d.ldc & 3) == 0) && ((zoffC & 3) == 0);
-    const float keep_scale = d.dropout_p > 0.f ? 1.f / (1.f - d.dropout_p) : 1.f;
-    const int nb = n0 + wn * 64 + 4 * (lane & 15);
-    const int nvalid = (N - nb) < 4 ? (N - nb) : 4;
-    float bias4[4] = {0.f, 0.f, 0.f, 0.f};
-    if (d.bias) {
-      const float* bz = d.bias + z1 * d.sBias1 + z2 * d.sBias2;
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (e < nvalid) bias4[e] = bz[nb + e];
-    }
-#pragma unroll 1
-    for (int it = 0; it < 16; ++it) {
-      const int ml = it * 4 + (lane >> 4);
-      const int m = m0 + wm * 64 + ml;
-      if (m >= M || nvalid <= 0) continue;
-      const f32x4_t a4 = *(const f32x4_t*)(wt + ml * EPI_PITCH + 4 * (lane & 15));
-      float v[4], v2[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = a4[e] * d.alpha + bias4[e];
-      const int64_t coff = zoffC + (int64_t)m * d.ldc + nb;
-      const int64_t roff = zoffR + (int64_t)m * d.ldr + nb;
-      if (d.epilogue == CA_EPI_GELU || d.epilogue == CA_EPI_GELU_RESIDUAL) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float g = gelu_erf(v[e]);
-          if (d.dropout_p > 0.f) {
-            const uint64_t idx = ((uint64_t)z * M + m) * (uint64_t)N + (nb + e);
-            g = ca_dropout_keep(d.dropout_seed, idx, d.dropout_p) ? g * keep_scale : 0.f;
-          }
-          v2[e] = g;
-        }
-        if (d.epilogue == CA_EPI_GELU_RESIDUAL) {
-          const unsigned short* R = (const unsigned short*)d.R + roff;
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (e < nvalid) v2[e] += bf2f(R[e]);
-        }
-      } else if (d.epilogue == CA_EPI_RESIDUAL) {
-        const unsigned short* R = (const unsigned short*)d.R + roff;
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (e < nvalid) v[e] += bf2f(R[e]);
-      } else if (d.epilogue == CA_EPI_DGELU) {
-        const unsigned short* R = (const unsigned short*)d.R + roff;
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (e < nvalid) {
-            float dg = dgelu_erf(bf2f(R[e]));
-            if (d.dropout_p > 0.f) {
-              const uint64_t idx = ((uint64_t)z * M + m) * (uint64_t)N + (nb + e);
-              dg = ca_dropout_keep(d.dropout_seed, idx, d.dropout_p) ? dg * keep_scale : 0.f;
-            }
-            v[e] *= dg;
-          }
-      }
-      if (d.out_f32) {
-        float* C = (float*)d.C + coff;
-        if (d.accumulate) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (e < nvalid) v[e] += C[e];
-        }
-        if (nvalid == 4 && vec_ok) {
-          *(f32x4_t*)C = (f32x4_t){v[0], v[1], v[2], v[3]};
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (e < nvalid) C[e] = v[e];
-        }
-      } else if (d.C) {
-        unsigned short* C = (unsigned short*)d.C + coff;
-        if (d.accumulate) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (e < nvalid) v[e] += bf2f(C[e]);
-        }
-        if (nvalid == 4 && vec_ok) {
-          *(u16x4_t*)C = (u16x4_t){f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (e < nvalid) C[e] = f2bf(v[e]);
-        }
-      }
-      if ((d.epilogue == CA_EPI_GELU || d.epilogue == CA_EPI_GELU_RESIDUAL) && d.C2) {
-        unsigned short* C2 = (unsigned short*)d.C2 + coff;
-        if (nvalid == 4 && vec_ok) {
-          *(u16x4_t*)C2 = (u16x4_t){f2bf(v2[0]), f2bf(v2[1]), f2bf(v2[2]), f2bf(v2[3])};
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (e < nvalid) C2[e] = f2bf(v2[e]);
-        }
-      }
-    }
+  bf16x8_t a0[4], b0[4], a1[4], b1[4];
+  // prologue: two tiles in flight (6 LDS-DMA per wave per tile)
+  issue_stage(0, 0);
+  if (nk > 1) {
+    issue_stage(1, 1);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  if (nk > 2) issue_stage(2, 2);
+  read_frags(0, 0, a0, b0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  read_frags(0, 1, a1, b1);
+  __builtin_amdgcn_sched_barrier(0);
+  mma(a0, b0);
+  int stage = 1;  // stage holding tile kt
+  for (int kt = 1; kt < nk; ++kt) {
+    // frag1(kt-1) has landed in registers; tile kt has landed in LDS (tile kt+1 may be in flight)
+    if (kt + 1 < nk)
+      asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    // the stage that held tile kt-1 is free now: every wave finished reading it before arriving
+    if (kt + 2 < nk) issue_stage(kt + 2, stage == 0 ? 2 : stage - 1);
+    read_frags(stage, 0, a0, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(a1, b1);  // second half of tile kt-1, from registers: covers the LDS read latency
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // a0/b0 (issued a whole MFMA block ago)
+    __builtin_amdgcn_sched_barrier(0);
+    read_frags(stage, 1, a1, b1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(a0, b0);
+    stage = stage == 2 ? 0 : stage + 1;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  mma(a1, b1);
+  // all waves are done with the staging ring before it is reused for the epilogue
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  gemm_epilogue(d, acc, smem, wave, lane, m0 + wm * 64, n0 + wn * 64, z, z1, z2);
 }
 
+// ---- optional per-launch timing (bench.py's live roofline measurement) -----------------------
+// When enabled, every ca_gemm_bf16 launch is bracketed by two hipEvents on the launch stream and
+// its algorithmic FLOPs (2*M*N*K*batch) are recorded per template variant (index a_layout*2 +
+// b_layout).  ca_prof_end synchronises the events and returns the totals.
+#include <vector>
+struct ProfRec {
+  hipEvent_t e0, e1;
+  double flops;
+  int variant;
+};
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+
+extern "C" int ca_prof_begin(void) {
+  g_prof.clear();
+  g_prof_on = true;
+  return CA_OK;
+}
+extern "C" int ca_prof_end(double* ms, int64_t* count, double* flops) {
+  g_prof_on = false;
+  for (int v = 0; v < 4; ++v) {
+    ms[v] = 0.0;
+    count[v] = 0;
+    flops[v] = 0.0;
+  }
+  for (auto& r : g_prof) {
+    float t = 0.f;
+    if (hipEventSynchronize(r.e1) != hipSuccess || hipEventElapsedTime(&t, r.e0, r.e1) != hipSuccess) {
+      ca_set_error("ca_prof_end: event query failed");
+      return CA_ERR_LAUNCH;
+    }
+    ms[r.variant] += t;
+    count[r.variant] += 1;
+    flops[r.variant] += r.flops;
+    hipEventDestroy(r.e0);
+    hipEventDestroy(r.e1);
+  }
+  g_prof.clear();
+  return CA_OK;
+}
+
+static int g_force_kernel = 0;  // 0 auto, 1 force 128x128, 2 force 256x128 (tests / tuning)
+extern "C" int ca_gemm_force_kernel(int which) {
+  g_force_kernel = which;
+  return CA_OK;
+}
+static int ca_gemm_launch(const CaGemmDesc* desc, void* stream);
+
 extern "C" int ca_gemm_bf16(const CaGemmDesc* desc, void* stream) {
+  if (!g_prof_on || desc == nullptr) return ca_gemm_launch(desc, stream);
+  ProfRec r;
+  hipEventCreate(&r.e0);
+  hipEventCreate(&r.e1);
+  r.variant = (desc->a_layout ? 2 : 0) + (desc->b_layout ? 1 : 0);
+  r.flops = 2.0 * desc->M * (double)desc->N * desc->K * desc->batch1 * desc->batch2;
+  hipEventRecord(r.e0, (hipStream_t)stream);
+  const int rc = ca_gemm_launch(desc, stream);
+  hipEventRecord(r.e1, (hipStream_t)stream);
+  g_prof.push_back(r);
+  return rc;
+}
+
+static int ca_gemm_launch(const CaGemmDesc* desc, void* stream) {
   CA_CHECK_ARG(desc != nullptr, "ca_gemm_bf16: null descriptor");
   const CaGemmDesc& d = *desc;
   CA_CHECK_ARG(d.A && d.B &&
@@ -362,22 +664,47 @@ extern "C" int ca_gemm_bf16(const CaGemmDesc* desc, void* stream) {
     CA_CHECK_ARG(d.R != nullptr, "ca_gemm_bf16: epilogue needs R");
   CA_CHECK_ARG(d.dropout_p >= 0.f && d.dropout_p < 1.f, "ca_gemm_bf16: bad dropout_p");
 
-  const int ntm = (d.M + BM - 1) / BM, ntn = (d.N + BN - 1) / BN;
-  dim3 grid(ntm * ntn, 1, d.batch1 * d.batch2);
-  dim3 block(256);
-  const size_t lds = LDS_BYTES;
   hipStream_t s = (hipStream_t)stream;
-  if (d.a_layout == CA_KMAJOR && d.b_layout == CA_KMAJOR)
-    hipLaunchKernelGGL((ca_gemm_kernel<CA_KMAJOR, CA_KMAJOR>), grid, block, lds, s, d);
-  else if (d.a_layout == CA_KMAJOR && d.b_layout == CA_MNMAJOR)
-    hipLaunchKernelGGL((ca_gemm_kernel<CA_KMAJOR, CA_MNMAJOR>), grid, block, lds, s, d);
-  else if (d.a_layout == CA_MNMAJOR && d.b_layout == CA_KMAJOR)
-    hipLaunchKernelGGL((ca_gemm_kernel<CA_MNMAJOR, CA_KMAJOR>), grid, block, lds, s, d);
-  else if (d.a_layout == CA_MNMAJOR && d.b_layout == CA_MNMAJOR)
-    hipLaunchKernelGGL((ca_gemm_kernel<CA_MNMAJOR, CA_MNMAJOR>), grid, block, lds, s, d);
-  else {
-    ca_set_error("ca_gemm_bf16: bad layout");
-    return CA_ERR_ARG;
+  const int lay = (d.a_layout ? 2 : 0) + (d.b_layout ? 1 : 0);
+  CA_CHECK_ARG(d.a_layout == CA_KMAJOR || d.a_layout == CA_MNMAJOR, "ca_gemm_bf16: bad a_layout");
+  CA_CHECK_ARG(d.b_layout == CA_KMAJOR || d.b_layout == CA_MNMAJOR, "ca_gemm_bf16: bad b_layout");
+  // Kernel choice: the 256x128 pipelined kernel runs one workgroup per CU, so it needs enough
+  // tiles to fill the chip; small or heavily batched problems use the 128x128 kernel.
+  const int64_t nb = (int64_t)d.batch1 * d.batch2;
+  const int64_t tiles_l = (int64_t)((d.M + LBM - 1) / LBM) * ((d.N + LBN - 1) / LBN) * nb;
+  // Measured on MI355X (profiles/r01_gemm_shapes.txt): at the path's shapes (K = 1920..7680, M = 3992)
+  // the 128x128 kernel with two workgroups per CU equals or beats the 256x128 one-per-CU kernel,
+  // because its second workgroup hides the epilogue; the L kernel is kept selectable for tuning.
+  (void)tiles_l;
+  int use_l = g_force_kernel == 2 ? 1 : 0;
+  if (use_l) {
+    static bool attr_done = false;
+    if (!attr_done) {
+      hipFuncSetAttribute((const void*)ca_gemm_kernel_l<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, L_LDS_BYTES);
+      hipFuncSetAttribute((const void*)ca_gemm_kernel_l<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, L_LDS_BYTES);
+      hipFuncSetAttribute((const void*)ca_gemm_kernel_l<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, L_LDS_BYTES);
+      hipFuncSetAttribute((const void*)ca_gemm_kernel_l<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, L_LDS_BYTES);
+      attr_done = true;
+    }
+    dim3 grid(tile_grid<4, 8>((d.M + LBM - 1) / LBM, (d.N + LBN - 1) / LBN), 1, (unsigned)nb);
+    dim3 block(512);
+    switch (lay) {
+      case 0: hipLaunchKernelGGL((ca_gemm_kernel_l<0, 0>), grid, block, L_LDS_BYTES, s, d); break;
+      case 1: hipLaunchKernelGGL((ca_gemm_kernel_l<0, 1>), grid, block, L_LDS_BYTES, s, d); break;
+      case 2: hipLaunchKernelGGL((ca_gemm_kernel_l<1, 0>), grid, block, L_LDS_BYTES, s, d); break;
+      default: hipLaunchKernelGGL((ca_gemm_kernel_l<1, 1>), grid, block, L_LDS_BYTES, s, d); break;
+    }
+  } else {
+    const int ntm = (d.M + BM - 1) / BM, ntn = (d.N + BN - 1) / BN;
+    dim3 grid(tile_grid<8, 8>(ntm, ntn), 1, (unsigned)nb);
+    dim3 block(256);
+    const size_t lds = LDS_BYTES;
+    switch (lay) {
+      case 0: hipLaunchKernelGGL((ca_gemm_kernel<0, 0>), grid, block, lds, s, d); break;
+      case 1: hipLaunchKernelGGL((ca_gemm_kernel<0, 1>), grid, block, lds, s, d); break;
+      case 2: hipLaunchKernelGGL((ca_gemm_kernel<1, 0>), grid, block, lds, s, d); break;
+      default: hipLaunchKernelGGL((ca_gemm_kernel<1, 1>), grid, block, lds, s, d); break;
+    }
   }
   CA_CHECK_LAUNCH("ca_gemm_bf16");
   return CA_OK;

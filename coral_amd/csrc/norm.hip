@@ -110,7 +110,7 @@ extern "C" int ca_layernorm_fwd(const void* x, const float* gamma, const float* 
 
 // ---- backward ------------------------------------------------------------------------------
 // partial layout: [grid][2][C] (dgamma partials then dbeta partials per block).
-#define LN_BWD_GRID_MAX 1024
+#define LN_BWD_GRID_MAX 512
 static int ln_bwd_grid(int64_t rows) {
   int64_t g = (rows + 3) / 4;
   if (g > LN_BWD_GRID_MAX) g = LN_BWD_GRID_MAX;
@@ -216,15 +216,30 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
   }
 }
 
-// out[i] (+)= sum_p partial[p*stride + i], i < n
-__global__ void reduce_partials_kernel(const float* __restrict__ partial, int nparts,
-                                       int64_t stride, int n, float* __restrict__ out,
-                                       int accumulate) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+// out[i] (+)= sum_p partial[p*stride + i], i < n.  64 columns x 4 partial-lanes per block so the
+// (few hundred) partial rows are summed by coalesced, parallel loads instead of one serial chain.
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial,
+                                                              int nparts, int64_t stride, int n,
+                                                              float* __restrict__ out,
+                                                              int accumulate) {
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + cl;
   float a = 0.f;
-  for (int p = 0; p < nparts; ++p) a += partial[(int64_t)p * stride + i];
-  out[i] = accumulate ? out[i] + a : a;
+  if (i < n)
+    for (int p = pl; p < nparts; p += 4) a += partial[(int64_t)p * stride + i];
+  red[pl][cl] = a;
+  __syncthreads();
+  if (pl == 0 && i < n) {
+    const float t = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
+    out[i] = accumulate ? out[i] + t : t;
+  }
+}
+
+void ca_reduce_partials_launch(const float* partial, int nparts, int64_t stride, int n, float* out,
+                               int accumulate, hipStream_t s) {
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((n + 63) / 64), dim3(256), 0, s, partial, nparts,
+                     stride, n, out, accumulate);
 }
 
 extern "C" int64_t ca_layernorm_bwd_partial_floats(int64_t rows, int32_t C) {
@@ -257,12 +272,8 @@ extern "C" int ca_layernorm_bwd(const void* dy, const void* x, const float* gamm
   }
 #undef LN_BWD
   CA_CHECK_LAUNCH("ca_layernorm_bwd");
-  if (dgamma)
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((C + 255) / 256), dim3(256), 0, s, partial, g,
-                       (int64_t)2 * C, C, dgamma, 1);
-  if (dbeta)
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((C + 255) / 256), dim3(256), 0, s,
-                       partial + C, g, (int64_t)2 * C, C, dbeta, 1);
+  if (dgamma) ca_reduce_partials_launch(partial, g, (int64_t)2 * C, C, dgamma, 1, s);
+  if (dbeta) ca_reduce_partials_launch(partial + C, g, (int64_t)2 * C, C, dbeta, 1, s);
   CA_CHECK_LAUNCH("ca_layernorm_bwd(reduce)");
   return CA_OK;
 }
@@ -324,8 +335,7 @@ extern "C" int ca_colsum_bf16(const void* x, int64_t ld, int64_t rows, int32_t N
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(colsum_kernel, dim3((N + 255) / 256, ns), dim3(256), 0, s,
                      (const unsigned short*)x, ld, rows, N, rowmask, partial);
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((N + 255) / 256), dim3(256), 0, s, partial, ns,
-                     (int64_t)N, N, out, accumulate);
+  ca_reduce_partials_launch(partial, ns, (int64_t)N, N, out, accumulate, s);
   CA_CHECK_LAUNCH("ca_colsum_bf16");
   return CA_OK;
 }

@@ -232,3 +232,16 @@ def argmax_masked(logits, suppress, out, rows, V, ldv):
 def embed_tokens(table, pos, ids, pos_ids, y, rows, Cn):
     check(lib().ca_embed_tokens(_p(table), _p(pos), _p(ids), _p(pos_ids), _p(y), rows, Cn,
                                 _stream()), "ca_embed_tokens")
+
+
+def prof_begin():
+    check(lib().ca_prof_begin(), "ca_prof_begin")
+
+
+def prof_end():
+    """-> list of 4 dicts (variant NT, NN, TN, TT): ms, count, flops of the GEMM launches."""
+    ms, cnt, fl = (C.c_double * 4)(), (C.c_int64 * 4)(), (C.c_double * 4)()
+    check(lib().ca_prof_end(ms, cnt, fl), "ca_prof_end")
+    names = ["ca_gemm_kernel<KMAJOR,KMAJOR>", "ca_gemm_kernel<KMAJOR,MNMAJOR>",
+             "ca_gemm_kernel<MNMAJOR,KMAJOR>", "ca_gemm_kernel<MNMAJOR,MNMAJOR>"]
+    return [dict(kernel=names[i], ms=ms[i], count=cnt[i], flops=fl[i]) for i in range(4)]

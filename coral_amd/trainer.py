@@ -1,0 +1,123 @@
+"""Data-parallel CTC finetuning step: the MI355X replacement for the inner loop CoRal gets from
+`transformers.Trainer` + accelerate/DDP ($TF/trainer.py:1678-1800 `_run_epoch`, :1892-1963
+`training_step`, :1778-1796 clip + optimizer step; launched by R/src/coral/finetune.py:60-79).
+
+One process per GPU (`torch.distributed`, backend "nccl" = RCCL over xGMI).  Utterances are
+sharded across ranks; the only exchange is the gradient all-reduce, issued per parameter bucket
+(head, layer L-1 ... layer 0, front — contiguous slices of the flat fp32 gradient buffer) on a
+dedicated HIP stream from the engine's backward hooks, so communication of layer l overlaps the
+backward of layers < l.  DDP semantics are kept: gradients are averaged over ranks
+(sum all-reduce, then 1/world folded into the fused AdamW kernel), the global-norm clip and the
+AdamW update (beta=(0.9, 0.98), cosine schedule with warm-up; R/src/coral/wav2vec2.py:216-240,
+R/config/asr_finetuning.yaml:64-75) run replicated on every rank.
+"""
+
+from __future__ import annotations
+
+import math
+import os
+
+import torch
+
+from . import ops
+
+
+def cosine_lr(step: int, base_lr: float, warmup_steps: int, max_steps: int) -> float:
+    """transformers.get_cosine_schedule_with_warmup (SchedulerType.COSINE,
+    R/src/coral/wav2vec2.py:217): `step` = number of optimiser steps already taken."""
+    if step < warmup_steps:
+        return base_lr * step / max(1, warmup_steps)
+    progress = (step - warmup_steps) / max(1, max_steps - warmup_steps)
+    return base_lr * max(0.0, 0.5 * (1.0 + math.cos(math.pi * progress)))
+
+
+def grad_accumulation_steps(total_batch_size: int, num_devices: int, per_device_batch_size: int) -> int:
+    """R/src/coral/wav2vec2.py:159-181: total // devices // per-device, at least 1."""
+    return max(1, total_batch_size // max(1, num_devices) // per_device_batch_size)
+
+
+class DataParallelTrainer:
+    """Owns optimiser state (flat fp32 m, v) and the communication stream for one engine."""
+
+    def __init__(self, engine, learning_rate=1e-4, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.0,
+                 max_grad_norm=1.0, warmup_steps=1000, max_steps=100_000, grad_accum=1,
+                 process_group=None, overlap=True):
+        self.engine = engine
+        self.lr, self.betas, self.eps, self.wd = learning_rate, betas, eps, weight_decay
+        self.max_grad_norm = max_grad_norm
+        self.warmup_steps, self.max_steps = warmup_steps, max_steps
+        self.grad_accum = grad_accum
+        self.opt_step = 0
+        st = engine.store
+        self.m = torch.zeros_like(st.p32)
+        self.v = torch.zeros_like(st.p32)
+        self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=st.device)
+        self.partial = torch.zeros(4096, dtype=torch.float32, device=st.device)
+        self.pg = process_group
+        self.world = 1
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            self.world = torch.distributed.get_world_size(process_group)
+        self.overlap = overlap and self.world > 1
+        self.comm_stream = torch.cuda.Stream(device=st.device) if self.world > 1 else None
+        self._pending = []
+        lo, hi = st.buckets["head"] if engine.freeze_base else (0, st.numel)
+        self.train_range = (lo, hi)
+
+    # ---- gradient exchange ---------------------------------------------------------------------
+    def _allreduce_bucket(self, name: str):
+        st = self.engine.store
+        lo, hi = st.buckets[name]
+        cur = torch.cuda.current_stream()
+        self.comm_stream.wait_stream(cur)  # grads of this bucket are enqueued on `cur`
+        with torch.cuda.stream(self.comm_stream):
+            h = torch.distributed.all_reduce(st.g32[lo:hi], op=torch.distributed.ReduceOp.SUM,
+                                             group=self.pg, async_op=True)
+        self._pending.append(h)
+
+    def _finish_comm(self):
+        for h in self._pending:
+            h.wait()
+        self._pending.clear()
+        if self.comm_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+
+    # ---- one optimiser step ----------------------------------------------------------------------
+    def train_step(self, micro_batches) -> float | torch.Tensor:
+        """micro_batches: list (len = grad_accum) of dicts with input_values / attention_mask /
+        labels (+ optional mask_time / mask_feature / layer_keep).  Returns the summed loss
+        tensor (device) of this rank, scaled as Trainer does (1/grad_accum)."""
+        eng = self.engine
+        eng.train()
+        eng.zero_grad(matrices=eng.freeze_base)
+        eng.step_seed = self.opt_step * 64 + (int(os.environ.get("RANK", "0")) % 64)
+        total = None
+        n = len(micro_batches)
+        for i, mb in enumerate(micro_batches):
+            out = eng(**mb)
+            last = i == n - 1
+            hook = self._allreduce_bucket if (self.world > 1 and last and self.overlap) else None
+            eng.backward(loss_scale=1.0 / n, overwrite_matrices=(i == 0), bucket_done=hook)
+            total = out.loss / n if total is None else total + out.loss / n
+        if self.world > 1 and not self.overlap:
+            for name in self.engine.store.buckets:
+                self._allreduce_bucket(name)
+        self._finish_comm()
+        self.optimizer_step()
+        return total
+
+    def optimizer_step(self):
+        eng, st = self.engine, self.engine.store
+        lo, hi = self.train_range
+        n = hi - lo
+        lr = cosine_lr(self.opt_step, self.lr, self.warmup_steps, self.max_steps)
+        self.opt_step += 1
+        ops.sumsq(st.g32[lo:hi], n, self.gnorm_sq, self.partial)
+        ops.adamw_step(st.p32[lo:hi], self.m[lo:hi], self.v[lo:hi], st.g32[lo:hi], st.p16[lo:hi], n, lr,
+                       self.betas[0], self.betas[1], self.eps, self.wd, self.opt_step,
+                       grad_scale=1.0 / self.world, max_norm=self.max_grad_norm, gnorm_sq=self.gnorm_sq)
+        if not eng.freeze_base:
+            eng.refresh_derived()
+
+    def grad_norm(self) -> float:
+        """Global gradient norm of the last step (after the DDP mean), host scalar."""
+        return float(self.gnorm_sq.sqrt().item()) / self.world

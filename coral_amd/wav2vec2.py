@@ -123,17 +123,20 @@ def w2v2_param_list(s: Wav2Vec2Shape) -> list[tuple[str, tuple, str]]:
     for l in range(s.num_hidden_layers):
         p = f"wav2vec2.encoder.layers.{l}."
         b = f"layer{l}"
+        # small tensors first (one contiguous slice to clear per step), then the matrices whose
+        # gradients are written -- not accumulated -- by the first micro-batch's wgrad GEMMs
         out += [(p + "layer_norm.weight", (d,), b), (p + "layer_norm.bias", (d,), b)]
         for n in ("q_proj", "k_proj", "v_proj"):
-            out.append((p + f"attention.{n}.weight", (d, d), b))
-        for n in ("q_proj", "k_proj", "v_proj"):
             out.append((p + f"attention.{n}.bias", (d,), b))
-        out += [(p + "attention.out_proj.weight", (d, d), b), (p + "attention.out_proj.bias", (d,), b),
+        out += [(p + "attention.out_proj.bias", (d,), b),
                 (p + "final_layer_norm.weight", (d,), b), (p + "final_layer_norm.bias", (d,), b),
-                (p + "feed_forward.intermediate_dense.weight", (f, d), b),
                 (p + "feed_forward.intermediate_dense.bias", (f,), b),
-                (p + "feed_forward.output_dense.weight", (d, f), b),
                 (p + "feed_forward.output_dense.bias", (d,), b)]
+        for n in ("q_proj", "k_proj", "v_proj"):
+            out.append((p + f"attention.{n}.weight", (d, d), b))
+        out += [(p + "attention.out_proj.weight", (d, d), b),
+                (p + "feed_forward.intermediate_dense.weight", (f, d), b),
+                (p + "feed_forward.output_dense.weight", (d, f), b)]
     out += [("wav2vec2.encoder.layer_norm.weight", (d,), "head"),
             ("wav2vec2.encoder.layer_norm.bias", (d,), "head"),
             ("lm_head.weight", (s.vocab_size, d), "head"), ("lm_head.bias", (s.vocab_size,), "head")]
@@ -201,8 +204,21 @@ class Wav2Vec2CTCEngine:
     def grad_dict(self) -> dict:
         return {n: self.store.view(n, "g32") for n in self.store.names()}
 
-    def zero_grad(self):
-        self.store.g32.zero_()
+    def zero_grad(self, matrices: bool = True):
+        """Clear gradients.  matrices=False clears everything except the transformer layers' weight
+        matrices (>99 % of the bytes): the next backward(overwrite_matrices=True) writes those
+        instead of accumulating, which saves a full read + write of the gradient buffer."""
+        st = self.store
+        if matrices:
+            st.g32.zero_()
+            return
+        for name in ("front", "head"):
+            lo, hi = st.buckets[name]
+            st.g32[lo:hi].zero_()
+        for l in range(self.s.num_hidden_layers):
+            lo = st.off(f"wav2vec2.encoder.layers.{l}.layer_norm.weight")
+            hi = st.off(f"wav2vec2.encoder.layers.{l}.attention.q_proj.weight")
+            st.g32[lo:hi].zero_()
 
     def train(self, mode: bool = True):
         self.training = mode
@@ -213,8 +229,13 @@ class Wav2Vec2CTCEngine:
 
     def refresh_compute_weights(self):
         """fp32 masters -> bf16 copies, conv weight reorders, weight-normed pos-conv weights."""
+        self.store.refresh_bf16()
+        self.refresh_derived()
+
+    def refresh_derived(self):
+        """Weights whose compute copy is not a plain cast (after an optimiser step the flat bf16
+        copy is already written by ca_adamw_step)."""
         s, st = self.s, self.store
-        st.refresh_bf16()
         for i in range(1, len(s.conv_dim)):
             ops.conv_weight_reorder(st.p32, self.conv_wr[i], s.conv_dim[i], s.conv_dim[i - 1],
                                     s.conv_kernel[i],
@@ -435,8 +456,13 @@ class Wav2Vec2CTCEngine:
                  batch1=B, batch2=H, sA=(H * T * Tp, T * Tp), sB=(T * 3 * d, hd), sC=(T * d, hd))
 
     # ---- backward ------------------------------------------------------------------------------
-    def backward(self, loss_scale: float = 1.0, accumulate: bool = True):
-        """Back-propagate d(loss*loss_scale) into the flat gradient buffer (+=)."""
+    def backward(self, loss_scale: float = 1.0, overwrite_matrices: bool = False, bucket_done=None):
+        """Back-propagate d(loss*loss_scale) into the flat gradient buffer (+=).
+
+        bucket_done(name): called as soon as every gradient of a parameter bucket ("head",
+        "layer{l}" in reverse order, "front") has been enqueued — the data-parallel trainer
+        starts that bucket's all-reduce on its communication stream from this hook."""
+        done = bucket_done if bucket_done is not None else (lambda name: None)
         sv = self._saved
         if sv is None or not sv["has_loss"]:
             raise RuntimeError("backward() needs a forward pass with labels")
@@ -450,7 +476,8 @@ class Wav2Vec2CTCEngine:
         p32, p16, g32 = st.p32, st.p16, st.g32
         o = st.off
         part = w["partial"]
-        acc = True  # gradients are always accumulated; zero_grad() starts a step
+        acc = True  # small tensors, front and head always accumulate (zero_grad clears them)
+        lacc = not overwrite_matrices  # layer weight matrices: accumulate or overwrite
 
         # head: dlogits (fp32) -> bf16 for the MFMA path
         dl = w["dlogits"]
@@ -462,6 +489,7 @@ class Wav2Vec2CTCEngine:
                  ldc=d, c_off=o("lm_head.weight"), out_f32=True, accumulate=acc)
         ops.colsum(d16, Vp, M, Vp, g32, part, out_off=o("lm_head.bias"))
         if self.freeze_base:
+            done("head")
             return
         ops.gemm(d16, p16, w["dA"], M=M, N=d, K=V, lda=Vp, b_layout=MNMAJOR, ldb=d, ldc=d,
                  b_off=o("lm_head.weight"))
@@ -469,19 +497,24 @@ class Wav2Vec2CTCEngine:
         ops.layernorm_bwd(w["dA"], w["h"][L], st.view("wav2vec2.encoder.layer_norm.weight"), None,
                           w["stf"], None, dh, st.view("wav2vec2.encoder.layer_norm.weight", "g32"),
                           st.view("wav2vec2.encoder.layer_norm.bias", "g32"), part, M, d)
+        done("head")
         # dh = gradient wrt residual stream leaving layer L-1
         other = w["dA"]
         scale = hd ** -0.5
         drop_p = sv["drop_p"]
         for l in reversed(range(L)):
             if not keep[l]:
+                if overwrite_matrices:  # dropped layer: its matrices get no gradient this step
+                    lo = o(f"wav2vec2.encoder.layers.{l}.attention.q_proj.weight")
+                    g32[lo:st.buckets[f"layer{l}"][1]].zero_()
+                done(f"layer{l}")
                 continue
             pl = f"wav2vec2.encoder.layers.{l}."
             hin = w["h"][l]
             # FFN2: h_out = h1 + W2 g + b2
             ops.colsum(dh, d, M, d, g32, part, out_off=o(pl + "feed_forward.output_dense.bias"))
             ops.gemm(dh, w["g"][l], g32, M=d, N=f, K=M, a_layout=MNMAJOR, lda=d, b_layout=MNMAJOR, ldb=f,
-                     ldc=f, c_off=o(pl + "feed_forward.output_dense.weight"), out_f32=True, accumulate=acc)
+                     ldc=f, c_off=o(pl + "feed_forward.output_dense.weight"), out_f32=True, accumulate=lacc)
             ops.gemm(dh, p16, w["du"], M=M, N=f, K=d, lda=d, b_layout=MNMAJOR, ldb=f, ldc=f,
                      b_off=o(pl + "feed_forward.output_dense.weight"), epilogue=EPI_DGELU, R=w["u"][l],
                      ldr=f, dropout_p=drop_p, dropout_seed=self.step_seed * 1000 + l)
@@ -490,7 +523,7 @@ class Wav2Vec2CTCEngine:
             ops.colsum(du, f, M, f, g32, part, out_off=o(pl + "feed_forward.intermediate_dense.bias"))
             ops.gemm(du, w["x2"][l], g32, M=f, N=d, K=M, a_layout=MNMAJOR, lda=f, b_layout=MNMAJOR, ldb=d,
                      ldc=d, c_off=o(pl + "feed_forward.intermediate_dense.weight"), out_f32=True,
-                     accumulate=acc)
+                     accumulate=lacc)
             ops.gemm(du, p16, other, M=M, N=d, K=f, lda=f, b_layout=MNMAJOR, ldb=d, ldc=d,
                      b_off=o(pl + "feed_forward.intermediate_dense.weight"))
             # LN2: dh1 = dh + LN'(dx2)
@@ -501,7 +534,7 @@ class Wav2Vec2CTCEngine:
             # out_proj: h1 = h + Wo ctx + bo
             ops.colsum(dh1, d, M, d, g32, part, out_off=o(pl + "attention.out_proj.bias"))
             ops.gemm(dh1, w["ctx"][l], g32, M=d, N=d, K=M, a_layout=MNMAJOR, lda=d, b_layout=MNMAJOR, ldb=d,
-                     ldc=d, c_off=o(pl + "attention.out_proj.weight"), out_f32=True, accumulate=acc)
+                     ldc=d, c_off=o(pl + "attention.out_proj.weight"), out_f32=True, accumulate=lacc)
             dctx = other
             ops.gemm(dh1, p16, dctx, M=M, N=d, K=d, lda=d, b_layout=MNMAJOR, ldb=d, ldc=d,
                      b_off=o(pl + "attention.out_proj.weight"))
@@ -510,7 +543,7 @@ class Wav2Vec2CTCEngine:
             ops.colsum(dqkv, 3 * d, M, 3 * d, g32, part, out_off=o(pl + "attention.q_proj.bias"))
             ops.gemm(dqkv, w["x1"][l], g32, M=3 * d, N=d, K=M, a_layout=MNMAJOR, lda=3 * d,
                      b_layout=MNMAJOR, ldb=d, ldc=d, c_off=o(pl + "attention.q_proj.weight"), out_f32=True,
-                     accumulate=acc)
+                     accumulate=lacc)
             dx1 = other
             ops.gemm(dqkv, p16, dx1, M=M, N=d, K=3 * d, lda=3 * d, b_layout=MNMAJOR, ldb=d, ldc=d,
                      b_off=o(pl + "attention.q_proj.weight"))
@@ -518,6 +551,7 @@ class Wav2Vec2CTCEngine:
             ops.layernorm_bwd(dx1, hin, st.view(pl + "layer_norm.weight"), None, w["st1"][l], dh1, dh,
                               st.view(pl + "layer_norm.weight", "g32"), st.view(pl + "layer_norm.bias", "g32"),
                               part, M, d)
+            done(f"layer{l}")
         # dh: gradient wrt h[0] = h0m + gelu(pc_pre)
         G, K = s.num_conv_pos_embedding_groups, s.num_conv_pos_embeddings
         Cg = d // G
@@ -579,6 +613,7 @@ class Wav2Vec2CTCEngine:
                       st.view(p0 + "conv.weight", "g32"), st.view(p0 + "conv.bias", "g32"),
                       st.view(p0 + "layer_norm.weight", "g32"), st.view(p0 + "layer_norm.bias", "g32"),
                       part, B, N, s.conv_dim[0], s.conv_kernel[0], s.conv_stride[0], s.layer_norm_eps)
+        done("front")
 
     def _attention_bwd(self, w, l, dctx, B, T, Tp, H, hd, d, scale):
         qkv, P, dP, dS, dqkv = w["qkv"][l], w["P"][l], w["S"], w["dS"], w["dqkv"]

@@ -95,6 +95,16 @@ typedef struct CaGemmDesc {
 
 int ca_gemm_bf16(const CaGemmDesc* desc, void* stream);
 
+/* Live kernel timing for bench.py's roofline line: between ca_prof_begin() and ca_prof_end()
+ * every ca_gemm_bf16 launch is bracketed by hipEvents on its own stream.  ca_prof_end fills
+ * three arrays of 4 entries indexed by (a_layout*2 + b_layout): summed kernel milliseconds,
+ * launch count, summed algorithmic FLOPs (2*M*N*K*batch).  Not for use inside graph capture. */
+/* Tuning/test hook: 0 = automatic kernel choice, 1 = force the 128x128 kernel, 2 = force the
+ * 256x128 pipelined kernel. */
+int ca_gemm_force_kernel(int which);
+int ca_prof_begin(void);
+int ca_prof_end(double* ms, int64_t* count, double* flops);
+
 /* ------------------------------------------------------------------------------------
  * LayerNorm over the channel axis.  $TF/models/wav2vec2/modeling_wav2vec2.py:429-434,
  * :611-654,:791 (nn.LayerNorm, eps 1e-5); whisper :379-413.

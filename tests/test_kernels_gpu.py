@@ -52,6 +52,18 @@ def test_gemm_layouts(ops, al, bl, M, N, K):
     assert err <= 1e-3 * (K ** 0.5), err  # fp32 accumulate of exact bf16 products
 
 
+@pytest.mark.parametrize("al,bl", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [(1000, 520, 328), (3992, 1920, 704), (300, 136, 64)])
+def test_gemm_pipelined_256x128_kernel(ops, al, bl, M, N, K):
+    """Same parity check with the 256x128 3-stage kernel forced (it is normally picked only for
+    large problems), including ragged M/N tails, odd K-step counts and a single K-step."""
+    ops.lib().ca_gemm_force_kernel(2)
+    try:
+        test_gemm_layouts(ops, al, bl, M, N, K)
+    finally:
+        ops.lib().ca_gemm_force_kernel(0)
+
+
 def test_gemm_epilogues_and_batch(ops):
     M, N, K, Bt = 300, 256, 192, 3
     A, W = bf(rnd(Bt, M, K, seed=3, scale=0.5)), bf(rnd(N, K, seed=4, scale=0.2))
