@@ -147,6 +147,11 @@ __device__ __forceinline__ bf16x8_t frag_mnmajor(const char* tile, int cb, int s
 // Placement only affects speed: any dispatch order gives the same result.
 template <int SBM, int SBN>
 __device__ __forceinline__ bool tile_of_block(int bid, int ntm, int ntn, int& tm, int& tn) {
+  if ((int)gridDim.x == ntm * ntn) {  // small problem: plain row-major tiles, no padding blocks
+    tm = bid / ntn;
+    tn = bid % ntn;
+    return true;
+  }
   const int x = bid & 7, i = bid >> 3;
   const int per = SBM * SBN;
   const int sb = (i / per) * 8 + x, t = i % per;
@@ -158,6 +163,7 @@ __device__ __forceinline__ bool tile_of_block(int bid, int ntm, int ntn, int& tm
 }
 template <int SBM, int SBN>
 static inline unsigned tile_grid(int ntm, int ntn) {
+  if (ntm * ntn < 4 * 8 * SBM * SBN) return (unsigned)(ntm * ntn);  // fewer than 4 super-blocks per XCD
   const int nsb = ((ntm + SBM - 1) / SBM) * ((ntn + SBN - 1) / SBN);
   return (unsigned)(((nsb + 7) / 8) * 8 * SBM * SBN);
 }
