@@ -110,7 +110,7 @@ extern "C" int ca_layernorm_fwd(const void* x, const float* gamma, const float* 
 
 // ---- backward ------------------------------------------------------------------------------
 // partial layout: [grid][2][C] (dgamma partials then dbeta partials per block).
-#define LN_BWD_GRID_MAX 512
+#define LN_BWD_GRID_MAX 256
 static int ln_bwd_grid(int64_t rows) {
   int64_t g = (rows + 3) / 4;
   if (g > LN_BWD_GRID_MAX) g = LN_BWD_GRID_MAX;
@@ -216,29 +216,40 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
   }
 }
 
-// out[i] (+)= sum_p partial[p*stride + i], i < n.  64 columns x 4 partial-lanes per block so the
-// (few hundred) partial rows are summed by coalesced, parallel loads instead of one serial chain.
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial,
-                                                              int nparts, int64_t stride, int n,
-                                                              float* __restrict__ out,
-                                                              int accumulate) {
-  __shared__ float red[4][64];
+// out[i] (+)= sum_p partial[p*stride + i], i < n.  64 columns x 16 partial-lanes per block, four
+// independent accumulators per thread: the few hundred partial rows are summed by coalesced,
+// parallel loads instead of one serial dependent chain.
+__global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __restrict__ partial,
+                                                               int nparts, int64_t stride, int n,
+                                                               float* __restrict__ out,
+                                                               int accumulate) {
+  __shared__ float red[16][64];
   const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + cl;
-  float a = 0.f;
-  if (i < n)
-    for (int p = pl; p < nparts; p += 4) a += partial[(int64_t)p * stride + i];
-  red[pl][cl] = a;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (i < n) {
+    int p = pl;
+    for (; p + 48 < nparts; p += 64) {
+      a0 += partial[(int64_t)p * stride + i];
+      a1 += partial[(int64_t)(p + 16) * stride + i];
+      a2 += partial[(int64_t)(p + 32) * stride + i];
+      a3 += partial[(int64_t)(p + 48) * stride + i];
+    }
+    for (; p < nparts; p += 16) a0 += partial[(int64_t)p * stride + i];
+  }
+  red[pl][cl] = (a0 + a1) + (a2 + a3);
   __syncthreads();
   if (pl == 0 && i < n) {
-    const float t = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += red[q][cl];
     out[i] = accumulate ? out[i] + t : t;
   }
 }
 
 void ca_reduce_partials_launch(const float* partial, int nparts, int64_t stride, int n, float* out,
                                int accumulate, hipStream_t s) {
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((n + 63) / 64), dim3(256), 0, s, partial, nparts,
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((n + 63) / 64), dim3(1024), 0, s, partial, nparts,
                      stride, n, out, accumulate);
 }
 
@@ -280,7 +291,7 @@ extern "C" int ca_layernorm_bwd(const void* dy, const void* x, const float* gamm
 
 // ---- column sums (bias gradients) ---------------------------------------------------------
 // block = 32 column-chunks (256 columns) x 8 row lanes; grid.y slabs of rows.
-#define CS_SLAB_MAX 256
+#define CS_SLAB_MAX 128
 static int cs_slabs(int64_t rows) {
   int64_t s = (rows + 63) / 64;
   if (s > CS_SLAB_MAX) s = CS_SLAB_MAX;

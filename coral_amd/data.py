@@ -1,0 +1,72 @@
+"""Data plane stub of the hot path.  The reference's `coral.data` (HF `datasets` streaming, text
+normalisation, augmentation; R/src/coral/data.py) is host-side I/O that needs the network and is out
+of scope; what the hot path needs from it is a stream of examples
+`{"input_values": f32[n], "labels": [ids], "input_length": n}` — exactly what `process_example`
+emits (R/src/coral/data.py:747-757).  This module provides that stream for the `synthetic` dataset
+key and for local `.npz` shards, so the entry points run end-to-end offline."""
+
+from __future__ import annotations
+
+from pathlib import Path
+
+import numpy as np
+
+
+def synthetic_examples(processor, n: int, seed: int, min_seconds=1.0, max_seconds=10.0, sampling_rate=16_000,
+                       fixed_length: bool = False):
+    """Seeded 0.1*randn utterances, peak-normalised like `ta.PeakNormalization`
+    (R/src/coral/data.py:710), with random transcriptions over the tokenizer's characters."""
+    rng = np.random.RandomState(seed)
+    chars = [c for c in processor.tokenizer.get_vocab() if len(c) == 1 and c != "|"]
+    for _ in range(n):
+        secs = max_seconds if fixed_length else rng.uniform(min_seconds, max_seconds)
+        wave = np.clip(0.1 * rng.randn(int(secs * sampling_rate)), -1, 1).astype(np.float32)
+        wave /= np.abs(wave).max()
+        n_chars = int(rng.randint(5, max(6, int(secs * 12))))
+        text = "".join(rng.choice(chars + [" "] * 6, size=n_chars)).strip() or "a"
+        ex = processor(wave, sampling_rate=sampling_rate)
+        ex["labels"] = processor(text=text, truncation=True)["input_ids"]
+        ex["input_length"] = len(ex["input_values"])
+        ex["text"] = text
+        yield ex
+
+
+def load_data_for_finetuning(config, processor, n_examples: int | None = None):
+    """-> {"train": iterable, "val": list}.  Only `datasets=synthetic` and local `.npz` directories
+    (arrays `audio`, `text`) are supported offline."""
+    rank = 0
+    try:
+        import os
+
+        rank = int(os.environ.get("RANK", "0"))
+    except ValueError:
+        pass
+    out_train = []
+    for key, ds in config.datasets.items():
+        if ds["id"] == "synthetic":
+            n = n_examples or config.per_device_batch_size * config.max_steps
+            fixed = config.padding == "max_length"
+            out_train.append(synthetic_examples(processor, n, config.seed + 1000 * rank,
+                                                config.min_seconds_per_example, config.max_seconds_per_example,
+                                                config.model.sampling_rate, fixed_length=fixed))
+        elif Path(ds["id"]).is_dir():
+            out_train.append(_npz_examples(Path(ds["id"]), processor, ds["text_column"], config.model.sampling_rate))
+        else:
+            raise RuntimeError(f"dataset {key!r} ({ds['id']}) needs the HuggingFace hub; this environment is "
+                               "offline — use datasets=synthetic or a local directory of .npz shards")
+
+    def chain():
+        for it in out_train:
+            yield from it
+
+    val = list(synthetic_examples(processor, 8, config.seed + 7, 1.0, 3.0, config.model.sampling_rate))
+    return {"train": chain(), "val": val}
+
+
+def _npz_examples(root: Path, processor, text_column: str, sampling_rate: int):
+    for f in sorted(root.glob("*.npz")):
+        z = np.load(f, allow_pickle=True)
+        ex = processor(z["audio"].astype(np.float32), sampling_rate=sampling_rate)
+        ex["labels"] = processor(text=str(z[text_column]), truncation=True)["input_ids"]
+        ex["input_length"] = len(ex["input_values"])
+        yield ex

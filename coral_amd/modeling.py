@@ -1,0 +1,167 @@
+"""HF-shaped model objects over the engines: `Wav2Vec2ForCTC.from_pretrained / save_pretrained`,
+`model(input_values, attention_mask, labels)` -> output with `.loss` / `.logits`
+(the contract `Trainer` and the ASR pipeline rely on)."""
+
+from __future__ import annotations
+
+import json
+import logging
+from pathlib import Path
+
+import numpy as np
+import torch
+
+from . import specaugment
+from .wav2vec2 import CORAL_W2V2_SHAPES, Wav2Vec2CTCEngine, Wav2Vec2Shape
+
+logger = logging.getLogger(__package__)
+
+# hub ids CoRal configures (R/config/model/wav2vec2-*.yaml:3) -> architecture
+HUB_SHAPES = {
+    "facebook/wav2vec2-xls-r-300m": CORAL_W2V2_SHAPES["wav2vec2-small"],
+    "facebook/wav2vec2-xls-r-1b": CORAL_W2V2_SHAPES["wav2vec2-medium"],
+    "facebook/wav2vec2-xls-r-2b": CORAL_W2V2_SHAPES["wav2vec2-large"],
+}
+
+
+def _save_safetensors(tensors: dict, path: Path):
+    from safetensors.torch import save_file
+
+    save_file({k: v.detach().cpu().contiguous() for k, v in tensors.items()}, str(path), metadata={"format": "pt"})
+
+
+def _load_safetensors(path: Path) -> dict:
+    from safetensors.torch import load_file
+
+    return load_file(str(path))
+
+
+class Wav2Vec2ForCTC:
+    """`Wav2Vec2ForCTC` look-alike backed by `Wav2Vec2CTCEngine` (HIP kernels only)."""
+
+    def __init__(self, shape: Wav2Vec2Shape, device=None, freeze_base=False, spec=None):
+        device = device or f"cuda:{torch.cuda.current_device() if torch.cuda.is_available() else 0}"
+        self.engine = Wav2Vec2CTCEngine(shape, device, freeze_base=freeze_base)
+        self.shape = shape
+        self.spec = spec or dict(apply_spec_augment=False, mask_time_prob=0.0, mask_time_length=10,
+                                 mask_feature_prob=0.0, mask_feature_length=64)
+        self.training = False
+        self._rng = np.random.RandomState(4242)
+
+    # ---- construction -----------------------------------------------------------------------
+    @classmethod
+    def from_pretrained(cls, name_or_path: str, device=None, freeze_base: bool = False, seed: int = 4242,
+                        **overrides):
+        path = Path(name_or_path)
+        spec = {k: overrides.pop(k) for k in ("apply_spec_augment", "mask_time_prob", "mask_time_length",
+                                              "mask_feature_prob", "mask_feature_length") if k in overrides}
+        if path.is_dir() and (path / "config.json").exists():
+            cfg = json.loads((path / "config.json").read_text())
+            shape = Wav2Vec2Shape(
+                hidden_size=cfg["hidden_size"], num_hidden_layers=cfg["num_hidden_layers"],
+                num_attention_heads=cfg["num_attention_heads"], intermediate_size=cfg["intermediate_size"],
+                conv_dim=tuple(cfg["conv_dim"]), conv_kernel=tuple(cfg["conv_kernel"]),
+                conv_stride=tuple(cfg["conv_stride"]),
+                num_conv_pos_embeddings=cfg["num_conv_pos_embeddings"],
+                num_conv_pos_embedding_groups=cfg["num_conv_pos_embedding_groups"],
+                vocab_size=overrides.get("vocab_size", cfg["vocab_size"]),
+                pad_token_id=overrides.get("pad_token_id", cfg["pad_token_id"]),
+                ctc_loss_reduction=overrides.get("ctc_loss_reduction", cfg.get("ctc_loss_reduction", "sum")),
+                ctc_zero_infinity=overrides.get("ctc_zero_infinity", cfg.get("ctc_zero_infinity", True)),
+                activation_dropout=overrides.get("activation_dropout", cfg.get("activation_dropout", 0.0)),
+                layerdrop=overrides.get("layerdrop", cfg.get("layerdrop", 0.0)))
+            model = cls(shape, device, freeze_base, spec)
+            sd = _load_safetensors(path / "model.safetensors")
+            model.engine.load_state_dict(sd)
+            return model
+        if name_or_path not in HUB_SHAPES:
+            raise ValueError(f"unknown model {name_or_path!r}: not a local directory and not one of {list(HUB_SHAPES)}")
+        shape = Wav2Vec2Shape(**HUB_SHAPES[name_or_path],
+                              vocab_size=overrides.get("vocab_size", 46), pad_token_id=overrides.get("pad_token_id", 45),
+                              ctc_loss_reduction=overrides.get("ctc_loss_reduction", "sum"),
+                              ctc_zero_infinity=overrides.get("ctc_zero_infinity", True),
+                              activation_dropout=overrides.get("activation_dropout", 0.0),
+                              layerdrop=overrides.get("layerdrop", 0.0))
+        logger.warning("no network / hub cache here: %s is instantiated with seeded random weights "
+                       "(pass a local directory holding model.safetensors for real weights)", name_or_path)
+        model = cls(shape, device, freeze_base, spec)
+        model.init_weights(seed)
+        return model
+
+    def init_weights(self, seed: int = 4242):
+        """Seeded random init generated on the device (HF-like scales)."""
+        eng = self.engine
+        g = torch.Generator(device=eng.device).manual_seed(seed)
+        for name, (_, shp) in eng.store.index.items():
+            v = eng.store.view(name)
+            if name.endswith("layer_norm.weight") or name.endswith("original0"):
+                v.fill_(1.0)
+            elif name.endswith(".bias"):
+                v.zero_()
+            elif name.endswith("masked_spec_embed"):
+                v.uniform_(0.0, 1.0, generator=g)
+            else:
+                fan_in = int(np.prod(shp[1:])) if len(shp) > 1 else shp[0]
+                v.normal_(0.0, fan_in ** -0.5, generator=g)
+        eng.refresh_compute_weights()
+
+    def save_pretrained(self, model_dir):
+        """HF layout: config.json + model.safetensors with HF parameter names."""
+        model_dir = Path(model_dir)
+        model_dir.mkdir(parents=True, exist_ok=True)
+        s = self.shape
+        cfg = dict(architectures=["Wav2Vec2ForCTC"], model_type="wav2vec2", hidden_size=s.hidden_size,
+                   num_hidden_layers=s.num_hidden_layers, num_attention_heads=s.num_attention_heads,
+                   intermediate_size=s.intermediate_size, conv_dim=list(s.conv_dim), conv_kernel=list(s.conv_kernel),
+                   conv_stride=list(s.conv_stride), num_conv_pos_embeddings=s.num_conv_pos_embeddings,
+                   num_conv_pos_embedding_groups=s.num_conv_pos_embedding_groups, vocab_size=s.vocab_size,
+                   pad_token_id=s.pad_token_id, ctc_loss_reduction=s.ctc_loss_reduction,
+                   ctc_zero_infinity=s.ctc_zero_infinity, feat_extract_norm="layer", conv_bias=True,
+                   do_stable_layer_norm=True, hidden_act="gelu", feat_extract_activation="gelu",
+                   activation_dropout=s.activation_dropout, layerdrop=s.layerdrop, layer_norm_eps=s.layer_norm_eps,
+                   **{k: v for k, v in self.spec.items()})
+        (model_dir / "config.json").write_text(json.dumps(cfg, indent=2))
+        _save_safetensors(self.engine.state_dict(), model_dir / "model.safetensors")
+
+    # ---- nn.Module-like surface --------------------------------------------------------------
+    def train(self, mode=True):
+        self.training = mode
+        self.engine.train(mode)
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    def parameters(self):
+        return [self.engine.store.view(n) for n in self.engine.store.names()]
+
+    def num_parameters(self):
+        return sum(int(np.prod(shp)) for _, shp in self.engine.store.index.values())
+
+    def sample_spec_masks(self, B: int, T: int, frame_lengths):
+        sp = self.spec
+        if not (self.training and sp.get("apply_spec_augment", False)):
+            return None, None
+        mt, mf = specaugment.sample_masks(B, T, self.shape.hidden_size, frame_lengths, sp["mask_time_prob"],
+                                          sp["mask_time_length"], sp["mask_feature_prob"],
+                                          sp["mask_feature_length"], rng=self._rng)
+        return (None if mt is None else torch.from_numpy(mt)), (None if mf is None else torch.from_numpy(mf))
+
+    def sample_layer_keep(self):
+        if not self.training or self.shape.layerdrop <= 0:
+            return None
+        return [bool(self._rng.rand() >= self.shape.layerdrop) for _ in range(self.shape.num_hidden_layers)]
+
+    def __call__(self, input_values, attention_mask=None, labels=None, mask_time=None, mask_feature=None,
+                 layer_keep=None):
+        B, N = input_values.shape
+        if mask_time is None and mask_feature is None and self.training:
+            T = self.engine.conv_lengths(N)[-1]
+            flen = [T] * B if attention_mask is None else self.engine.feat_lengths(attention_mask.sum(-1)).tolist()
+            mask_time, mask_feature = self.sample_spec_masks(B, T, flen)
+        if layer_keep is None:
+            layer_keep = self.sample_layer_keep()
+        return self.engine(input_values, attention_mask, labels, mask_time, mask_feature, layer_keep)
+
+    def backward(self, **kw):
+        return self.engine.backward(**kw)

@@ -36,12 +36,75 @@ def grad_accumulation_steps(total_batch_size: int, num_devices: int, per_device_
     return max(1, total_batch_size // max(1, num_devices) // per_device_batch_size)
 
 
+class GradSync:
+    """Bucketed gradient all-reduce over a flat buffer (device-agnostic, so the N>1 logic is
+    testable with gloo on CPU).  `start(name)` launches the asynchronous SUM all-reduce of one
+    contiguous bucket — on a side HIP stream when the buffer lives on a GPU — and `finish()`
+    waits for all of them.  The 1/world averaging is NOT applied here (it is folded into the
+    fused AdamW kernel / `scale_` below), so the wire carries plain sums like DDP's buckets."""
+
+    def __init__(self, flat_grad: torch.Tensor, buckets: dict, process_group=None):
+        self.g = flat_grad
+        self.buckets = buckets
+        self.pg = process_group
+        self.world = 1
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            self.world = torch.distributed.get_world_size(process_group)
+        self.on_gpu = flat_grad.is_cuda
+        self.comm_stream = torch.cuda.Stream(device=flat_grad.device) if (self.on_gpu and self.world > 1) else None
+        self._pending = []
+        self.launched: list[str] = []
+
+    def start(self, name: str):
+        if self.world == 1:
+            return
+        lo, hi = self.buckets[name]
+        self.launched.append(name)
+        if self.comm_stream is not None:
+            self.comm_stream.wait_stream(torch.cuda.current_stream())  # bucket's grads are enqueued
+            with torch.cuda.stream(self.comm_stream):
+                h = torch.distributed.all_reduce(self.g[lo:hi], op=torch.distributed.ReduceOp.SUM,
+                                                 group=self.pg, async_op=True)
+        else:
+            h = torch.distributed.all_reduce(self.g[lo:hi], op=torch.distributed.ReduceOp.SUM,
+                                             group=self.pg, async_op=True)
+        self._pending.append(h)
+
+    def start_all(self):
+        for name in self.buckets:
+            self.start(name)
+
+    def finish(self):
+        for h in self._pending:
+            h.wait()
+        self._pending.clear()
+        self.launched.clear()
+        if self.comm_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+
+    def scale_(self):
+        """DDP-mean semantics for host-side consumers: g /= world."""
+        if self.world > 1:
+            self.g.mul_(1.0 / self.world)
+
+
+def shard_indices(n_items: int, rank: int, world: int) -> list[int]:
+    """Utterance indices of `rank` for one global batch: contiguous equal shards (the per-device
+    batches accelerate hands each DDP rank); n_items must be divisible by world."""
+    if n_items % world:
+        raise ValueError(f"global batch {n_items} is not divisible by world size {world}")
+    per = n_items // world
+    return list(range(rank * per, (rank + 1) * per))
+
+
 class DataParallelTrainer:
     """Owns optimiser state (flat fp32 m, v) and the communication stream for one engine."""
 
     def __init__(self, engine, learning_rate=1e-4, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.0,
                  max_grad_norm=1.0, warmup_steps=1000, max_steps=100_000, grad_accum=1,
                  process_group=None, overlap=True):
+        self.model = engine                          # HF-shaped wrapper or the bare engine
+        engine = getattr(engine, "engine", engine)  # the kernel-sequencing engine underneath
         self.engine = engine
         self.lr, self.betas, self.eps, self.wd = learning_rate, betas, eps, weight_decay
         self.max_grad_norm = max_grad_norm
@@ -53,33 +116,11 @@ class DataParallelTrainer:
         self.v = torch.zeros_like(st.p32)
         self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=st.device)
         self.partial = torch.zeros(4096, dtype=torch.float32, device=st.device)
-        self.pg = process_group
-        self.world = 1
-        if torch.distributed.is_available() and torch.distributed.is_initialized():
-            self.world = torch.distributed.get_world_size(process_group)
+        self.sync = GradSync(st.g32, st.buckets, process_group)
+        self.world = self.sync.world
         self.overlap = overlap and self.world > 1
-        self.comm_stream = torch.cuda.Stream(device=st.device) if self.world > 1 else None
-        self._pending = []
         lo, hi = st.buckets["head"] if engine.freeze_base else (0, st.numel)
         self.train_range = (lo, hi)
-
-    # ---- gradient exchange ---------------------------------------------------------------------
-    def _allreduce_bucket(self, name: str):
-        st = self.engine.store
-        lo, hi = st.buckets[name]
-        cur = torch.cuda.current_stream()
-        self.comm_stream.wait_stream(cur)  # grads of this bucket are enqueued on `cur`
-        with torch.cuda.stream(self.comm_stream):
-            h = torch.distributed.all_reduce(st.g32[lo:hi], op=torch.distributed.ReduceOp.SUM,
-                                             group=self.pg, async_op=True)
-        self._pending.append(h)
-
-    def _finish_comm(self):
-        for h in self._pending:
-            h.wait()
-        self._pending.clear()
-        if self.comm_stream is not None:
-            torch.cuda.current_stream().wait_stream(self.comm_stream)
 
     # ---- one optimiser step ----------------------------------------------------------------------
     def train_step(self, micro_batches) -> float | torch.Tensor:
@@ -87,21 +128,20 @@ class DataParallelTrainer:
         labels (+ optional mask_time / mask_feature / layer_keep).  Returns the summed loss
         tensor (device) of this rank, scaled as Trainer does (1/grad_accum)."""
         eng = self.engine
-        eng.train()
+        self.model.train()
         eng.zero_grad(matrices=eng.freeze_base)
         eng.step_seed = self.opt_step * 64 + (int(os.environ.get("RANK", "0")) % 64)
         total = None
         n = len(micro_batches)
         for i, mb in enumerate(micro_batches):
-            out = eng(**mb)
+            out = self.model(**mb)
             last = i == n - 1
-            hook = self._allreduce_bucket if (self.world > 1 and last and self.overlap) else None
+            hook = self.sync.start if (self.world > 1 and last and self.overlap) else None
             eng.backward(loss_scale=1.0 / n, overwrite_matrices=(i == 0), bucket_done=hook)
             total = out.loss / n if total is None else total + out.loss / n
         if self.world > 1 and not self.overlap:
-            for name in self.engine.store.buckets:
-                self._allreduce_bucket(name)
-        self._finish_comm()
+            self.sync.start_all()
+        self.sync.finish()
         self.optimizer_step()
         return total
 

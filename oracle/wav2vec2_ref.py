@@ -291,7 +291,7 @@ def ctc_nll(log_probs: torch.Tensor, targets: list[int], t_in: int, blank: int) 
         alpha = torch.clamp(alpha, min=NEG)
     tail = alpha[-1:] if S == 1 else alpha[-2:]
     ll = torch.logsumexp(tail, dim=0)
-    if float(ll) < -1e29:
+    if float(ll.detach()) < -1e29:
         return torch.tensor(float("inf"), dtype=log_probs.dtype)
     return -ll
 

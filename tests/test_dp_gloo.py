@@ -1,0 +1,78 @@
+"""Multi-process (world_size 2, gloo, CPU) coverage of the N>1 path: bucketed gradient all-reduce
+in backward order, DDP-mean semantics, utterance sharding, LR schedule and accumulation formula."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    from coral_amd.trainer import GradSync, shard_indices
+
+    buckets = {"front": [0, 40], "layer0": [40, 104], "layer1": [104, 168], "head": [168, 200]}
+    g = torch.arange(200, dtype=torch.float32) * (rank + 1)
+    sync = GradSync(g, buckets)
+    order = []
+    for name in ("head", "layer1", "layer0", "front"):  # the order backward() reports buckets
+        sync.start(name)
+        order.append(name)
+    launched = list(sync.launched)
+    sync.finish()
+    want_sum = torch.arange(200, dtype=torch.float32) * sum(r + 1 for r in range(world))
+    ok_sum = torch.equal(g, want_sum)
+    sync.scale_()
+    ok_mean = torch.allclose(g, want_sum / world)
+    # a partial launch (frozen base: only the head bucket) leaves the rest untouched
+    g2 = torch.ones(200) * (rank + 1)
+    s2 = GradSync(g2, buckets)
+    s2.start("head")
+    s2.finish()
+    ok_partial = bool((g2[168:] == 3).all() and (g2[:168] == rank + 1).all())
+    q.put((rank, ok_sum, ok_mean, ok_partial, launched == order, shard_indices(8, rank, world)))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_bucketed_allreduce_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[1:5] for r in res] == [(True, True, True, True)] * 2
+    assert res[0][5] == [0, 1, 2, 3] and res[1][5] == [4, 5, 6, 7]  # disjoint, covering shards
+
+
+def test_schedule_and_accumulation():
+    from coral_amd.trainer import cosine_lr, grad_accumulation_steps, shard_indices
+
+    # transformers.get_cosine_schedule_with_warmup values (warm-up 1000, 100k steps, lr 1e-4)
+    assert cosine_lr(0, 1e-4, 1000, 100_000) == 0.0
+    assert abs(cosine_lr(500, 1e-4, 1000, 100_000) - 5e-5) < 1e-12
+    assert abs(cosine_lr(1000, 1e-4, 1000, 100_000) - 1e-4) < 1e-12
+    assert abs(cosine_lr(50_500, 1e-4, 1000, 100_000) - 5e-5) < 1e-9
+    assert cosine_lr(100_000, 1e-4, 1000, 100_000) < 1e-12
+    # R/src/coral/wav2vec2.py:159-181 with the CoRal defaults 256 / n / 8
+    assert grad_accumulation_steps(256, 1, 8) == 32
+    assert grad_accumulation_steps(256, 8, 8) == 4
+    assert grad_accumulation_steps(64, 8, 8) == 1
+    assert grad_accumulation_steps(8, 8, 8) == 1  # never below one
+    with pytest.raises(ValueError):
+        shard_indices(10, 0, 4)

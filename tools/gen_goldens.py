@@ -259,8 +259,67 @@ def gen_w2v2_cfg1():
     print("w2v2_cfg1 loss", out["loss"], {k: float(v) for k, v in out.items() if k.startswith("gradnorm")})
 
 
+def gen_collator():
+    """DataCollatorCTCWithPadding semantics (R/src/coral/data_collators.py:62-95) from the HF
+    building blocks it calls: Wav2Vec2Processor.pad(audio) + pad(labels) + -100 fill."""
+    from transformers import Wav2Vec2CTCTokenizer, Wav2Vec2FeatureExtractor, Wav2Vec2Processor
+
+    vocab = {k: v for k, v in ref.coral_vocab().items() if not k.startswith("<")}
+    with tempfile.TemporaryDirectory() as td:
+        (Path(td) / "vocab.json").write_text(json.dumps(vocab))
+        tok = Wav2Vec2CTCTokenizer(str(Path(td) / "vocab.json"), unk_token="<unk>", pad_token="<pad>",
+                                   bos_token="<s>", eos_token="</s>", word_delimiter_token="|")
+        fe = Wav2Vec2FeatureExtractor(feature_size=1, sampling_rate=16000, padding_value=0.0,
+                                      do_normalize=True, return_attention_mask=True)
+        proc = Wav2Vec2Processor(feature_extractor=fe, tokenizer=tok)
+        g = np.random.RandomState(3)
+        texts = ["hej med dig", "æøå 123", "a", "det er en længere sætning end de andre"]
+        feats = []
+        for i, n in enumerate([800, 1200, 500, 1600]):
+            wave = (0.1 * g.randn(n)).astype(np.float32)
+            iv = proc(wave, sampling_rate=16000).input_values[0]
+            ids = proc(text=texts[i], truncation=True).input_ids
+            feats.append(dict(input_values=iv, labels=ids))
+        out = {f"iv{i}": f["input_values"] for i, f in enumerate(feats)}
+        for i, f in enumerate(feats):
+            out[f"lab{i}"] = np.array(f["labels"])
+        for padding, key in (("longest", "longest"), ("max_length", "max")):
+            batch = proc.pad([dict(input_values=f["input_values"]) for f in feats], padding=padding,
+                             return_tensors="np", max_length=2000)
+            lb = proc.pad(labels=[dict(input_ids=f["labels"]) for f in feats], padding=padding,
+                          return_tensors="np", max_length=min(tok.model_max_length, 512))
+            labels = np.where(lb["attention_mask"] == 1, lb["input_ids"], -100)
+            out[f"{key}_input_values"] = batch["input_values"]
+            out[f"{key}_attention_mask"] = batch["attention_mask"]
+            out[f"{key}_labels"] = labels
+        (GOLD / "collator_texts.json").write_text(json.dumps(texts, ensure_ascii=False))
+        np.savez_compressed(GOLD / "collator.npz", **out)
+    print("collator:", out["longest_labels"].shape, out["max_labels"].shape)
+
+
+def gen_specaug():
+    """_compute_mask_indices under fixed np.random seeds (host RNG stream parity)."""
+    from transformers.models.wav2vec2.modeling_wav2vec2 import _compute_mask_indices
+
+    cases = [(1, (8, 499), 0.5, 10, None, 2), (2, (4, 249), 0.5, 10, [249, 200, 120, 30], 2),
+             (3, (8, 1920), 0.5, 64, None, 0), (4, (3, 12), 0.05, 10, [12, 10, 8], 2), (5, (2, 20), 0.9, 5, [20, 3], 2),
+             (6, (8, 1024), 0.5, 64, None, 0)]
+    out = {"n": np.array(len(cases))}
+    for i, (seed, shape, p, ml, lens, mm) in enumerate(cases):
+        np.random.seed(seed)
+        am = None
+        if lens is not None:
+            am = torch.zeros(shape, dtype=torch.long)
+            for r, n in enumerate(lens):
+                am[r, :n] = 1
+        out[f"m{i}"] = np.packbits(_compute_mask_indices(shape, p, ml, attention_mask=am, min_masks=mm))
+        out[f"spec{i}"] = np.array([seed, shape[0], shape[1], int(p * 1000), ml, mm] + (lens or []))
+    np.savez_compressed(GOLD / "specaugment.npz", **out)
+    print("specaug ok")
+
+
 if __name__ == "__main__":
-    todo = sys.argv[1:] or ["w2v2_tiny", "ctc", "featext", "tokenizer"]
+    todo = sys.argv[1:] or ["w2v2_tiny", "ctc", "featext", "tokenizer", "collator", "specaug"]
     torch.manual_seed(4242)
     for name in todo:
         globals()["gen_" + name]()
