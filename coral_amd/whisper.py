@@ -1,0 +1,394 @@
+"""MI355X-native Whisper engine behind CoRal's `model=whisper-*` keys: log-mel front end on the
+GPU, encoder, teacher-forced decoder with the tied LM head + cross-entropy, and greedy generation.
+
+Mirrors what `WhisperModelSetup` gives CoRal (R/src/coral/whisper.py:49-109) and what the ASR
+pipeline calls (R/src/coral/evaluate.py:56-60 -> `model.generate`):
+  WhisperFeatureExtractor            $TF/models/whisper/feature_extraction_whisper.py:135-168  -> ca_logmel
+  WhisperEncoder.forward             $TF/models/whisper/modeling_whisper.py:592-646
+  WhisperDecoder(.Layer).forward     :448-505, 690-795
+  WhisperForConditionalGeneration    :994-1099 (shift_tokens_right, tied proj_out, CE ignore -100)
+  greedy generate                    $TF/models/whisper/generation_whisper.py:383,1455,1774-1812
+
+Round-1 scope: forward paths (inference, evaluation loss, greedy decode).  The conv stem runs as
+overlapping-row GEMMs over a time-padded channels-last buffer (Conv1d k=3, p=1, stride 1 / 2), the
+sinusoidal positions are added in the second conv's epilogue, layers reuse the wav2vec2 kernels
+(the encoder layer is the same pre-LN block), the decoder adds causal and cross attention.
+Greedy decoding re-runs the decoder over the growing prefix with the cross-attention K/V computed
+once per clip (a KV-cached single-token step and the Whisper backward are the next items).
+"""
+
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import ops
+from .ops import EPI_GELU, EPI_GELU_RESIDUAL, EPI_NONE, EPI_RESIDUAL, KMAJOR, MNMAJOR
+from .wav2vec2 import ParamStore, _r8
+
+
+@dataclass
+class WhisperShape:
+    d_model: int = 384
+    encoder_layers: int = 4
+    decoder_layers: int = 4
+    encoder_attention_heads: int = 6
+    decoder_attention_heads: int = 6
+    encoder_ffn_dim: int = 1536
+    decoder_ffn_dim: int = 1536
+    num_mel_bins: int = 80
+    vocab_size: int = 51865
+    max_source_positions: int = 1500
+    max_target_positions: int = 448
+    pad_token_id: int = 50257
+    decoder_start_token_id: int = 50258
+    eos_token_id: int = 50257
+    layer_norm_eps: float = 1e-5
+
+
+# CoRal model keys -> architectures (R/config/model/whisper-*.yaml:3-5; public config.json values)
+CORAL_WHISPER_SHAPES = {
+    "whisper-xxsmall": dict(d_model=384, encoder_layers=4, decoder_layers=4, encoder_attention_heads=6,
+                            decoder_attention_heads=6, encoder_ffn_dim=1536, decoder_ffn_dim=1536),
+    "whisper-xsmall": dict(d_model=512, encoder_layers=6, decoder_layers=6, encoder_attention_heads=8,
+                           decoder_attention_heads=8, encoder_ffn_dim=2048, decoder_ffn_dim=2048),
+    "whisper-small": dict(d_model=768, encoder_layers=12, decoder_layers=12, encoder_attention_heads=12,
+                          decoder_attention_heads=12, encoder_ffn_dim=3072, decoder_ffn_dim=3072),
+    "whisper-medium": dict(d_model=1024, encoder_layers=24, decoder_layers=24, encoder_attention_heads=16,
+                           decoder_attention_heads=16, encoder_ffn_dim=4096, decoder_ffn_dim=4096),
+    "whisper-large": dict(d_model=1280, encoder_layers=32, decoder_layers=32, encoder_attention_heads=20,
+                          decoder_attention_heads=20, encoder_ffn_dim=5120, decoder_ffn_dim=5120,
+                          num_mel_bins=128, vocab_size=51866),
+    "whisper-large-turbo": dict(d_model=1280, encoder_layers=32, decoder_layers=4, encoder_attention_heads=20,
+                                decoder_attention_heads=20, encoder_ffn_dim=5120, decoder_ffn_dim=5120,
+                                num_mel_bins=128, vocab_size=51866),
+}
+
+N_FFT, HOP, N_SAMPLES = 400, 160, 480_000
+
+
+def mel_filter_bank(n_mels: int, n_freq: int = 201, sr: int = 16_000, fmin=0.0, fmax=8000.0) -> np.ndarray:
+    """Slaney-scale, Slaney-normalised triangular filters [n_freq, n_mels]
+    (`mel_filter_bank(201, n_mels, 0, 8000, 16000, "slaney", "slaney")`, $TF/audio_utils.py:638-731)."""
+    def hz2mel(f):
+        f = np.asarray(f, dtype=np.float64)
+        return np.where(f >= 1000.0, 15.0 + np.log(np.maximum(f, 1e-10) / 1000.0) * (27.0 / np.log(6.4)), 3.0 * f / 200.0)
+
+    def mel2hz(m):
+        m = np.asarray(m, dtype=np.float64)
+        return np.where(m >= 15.0, 1000.0 * np.exp((np.log(6.4) / 27.0) * (m - 15.0)), 200.0 * m / 3.0)
+
+    hz = mel2hz(np.linspace(hz2mel(fmin), hz2mel(fmax), n_mels + 2))
+    freqs = np.linspace(0, sr // 2, n_freq)
+    slopes = hz[None, :] - freqs[:, None]
+    d = np.diff(hz)
+    fb = np.maximum(0.0, np.minimum(-slopes[:, :-2] / d[:-1], slopes[:, 2:] / d[1:]))
+    return (fb * (2.0 / (hz[2:n_mels + 2] - hz[:n_mels]))[None, :]).astype(np.float32)
+
+
+def whisper_param_list(s: WhisperShape):
+    """(HF name, shape, bucket); q,k,v weights adjacent, and a zero `k_proj.bias` slot (HF has none)
+    so the fused [3d] bias vector exists.  Names ending in `__zero` are internal and never exported."""
+    d = s.d_model
+    out = [("model.encoder.conv1.weight", (d, s.num_mel_bins, 3), "front"), ("model.encoder.conv1.bias", (d,), "front"),
+           ("model.encoder.conv2.weight", (d, d, 3), "front"), ("model.encoder.conv2.bias", (d,), "front"),
+           ("model.encoder.embed_positions.weight", (s.max_source_positions, d), "front")]
+
+    def attn(p, b):
+        o = []
+        for n in ("q_proj", "k_proj", "v_proj"):
+            o.append((p + n + ".weight", (d, d), b))
+        o += [(p + "q_proj.bias", (d,), b), (p + "k_proj.bias__zero", (d,), b), (p + "v_proj.bias", (d,), b),
+              (p + "out_proj.weight", (d, d), b), (p + "out_proj.bias", (d,), b)]
+        return o
+
+    for l in range(s.encoder_layers):
+        p, b = f"model.encoder.layers.{l}.", f"enc{l}"
+        out += attn(p + "self_attn.", b)
+        out += [(p + "self_attn_layer_norm.weight", (d,), b), (p + "self_attn_layer_norm.bias", (d,), b),
+                (p + "final_layer_norm.weight", (d,), b), (p + "final_layer_norm.bias", (d,), b),
+                (p + "fc1.weight", (s.encoder_ffn_dim, d), b), (p + "fc1.bias", (s.encoder_ffn_dim,), b),
+                (p + "fc2.weight", (d, s.encoder_ffn_dim), b), (p + "fc2.bias", (d,), b)]
+    out += [("model.encoder.layer_norm.weight", (d,), "encf"), ("model.encoder.layer_norm.bias", (d,), "encf"),
+            ("model.decoder.embed_tokens.weight", (s.vocab_size, d), "emb"),
+            ("model.decoder.embed_positions.weight", (s.max_target_positions, d), "emb")]
+    for l in range(s.decoder_layers):
+        p, b = f"model.decoder.layers.{l}.", f"dec{l}"
+        out += attn(p + "self_attn.", b) + attn(p + "encoder_attn.", b)
+        for n in ("self_attn_layer_norm", "encoder_attn_layer_norm", "final_layer_norm"):
+            out += [(p + n + ".weight", (d,), b), (p + n + ".bias", (d,), b)]
+        out += [(p + "fc1.weight", (s.decoder_ffn_dim, d), b), (p + "fc1.bias", (s.decoder_ffn_dim,), b),
+                (p + "fc2.weight", (d, s.decoder_ffn_dim), b), (p + "fc2.bias", (d,), b)]
+    out += [("model.decoder.layer_norm.weight", (d,), "decf"), ("model.decoder.layer_norm.bias", (d,), "decf")]
+    return out
+
+
+class WhisperEngine:
+    """Forward paths of WhisperForConditionalGeneration as sequences of HIP kernels."""
+
+    def __init__(self, shape: WhisperShape, device="cuda:0"):
+        ops.lib()
+        if not torch.cuda.is_available():
+            raise ops.CoralAmdError("WhisperEngine needs a GPU: there is no CPU path")
+        self.s = shape
+        self.device = torch.device(device)
+        assert shape.d_model % 8 == 0 and shape.num_mel_bins % 8 == 0
+        self.store = ParamStore(whisper_param_list(shape), self.device)
+        d = shape.d_model
+        self.conv1_wr = torch.zeros(d * 3 * shape.num_mel_bins, dtype=torch.bfloat16, device=self.device)
+        self.conv2_wr = torch.zeros(d * 3 * d, dtype=torch.bfloat16, device=self.device)
+        self.mel_filters = torch.from_numpy(mel_filter_bank(shape.num_mel_bins)).to(self.device)
+        self._enc_ws = {}
+        self._dec_ws = {}
+
+    # ---- parameters ------------------------------------------------------------------------
+    def exported_names(self):
+        return [n for n in self.store.names() if not n.endswith("__zero")]
+
+    def load_state_dict(self, P: dict):
+        missing = [n for n in self.exported_names() if n not in P]
+        if missing:
+            raise KeyError(f"missing parameters: {missing[:4]}...")
+        for n in self.exported_names():
+            self.store.view(n).copy_(P[n].to(self.device, torch.float32).reshape(self.store.index[n][1]))
+        self.refresh_compute_weights()
+
+    def state_dict(self):
+        return {n: self.store.view(n).detach().clone() for n in self.exported_names()}
+
+    def refresh_compute_weights(self):
+        s, st = self.s, self.store
+        st.refresh_bf16()
+        ops.conv_weight_reorder(st.p32, self.conv1_wr, s.d_model, s.num_mel_bins, 3, w_off=st.off("model.encoder.conv1.weight"))
+        ops.conv_weight_reorder(st.p32, self.conv2_wr, s.d_model, s.d_model, 3, w_off=st.off("model.encoder.conv2.weight"))
+
+    # ---- front end ---------------------------------------------------------------------------
+    def log_mel(self, waves: torch.Tensor) -> torch.Tensor:
+        """waves f32 [B, 480000] (padded/truncated PCM) -> input_features f32 [B, mels, 3000] on the GPU."""
+        B, N = waves.shape
+        x = waves.to(self.device, torch.float32).contiguous()
+        out = torch.empty(B, self.s.num_mel_bins, N // HOP, dtype=torch.float32, device=self.device)
+        ws = torch.empty(ops.logmel_workspace_bytes(B), dtype=torch.uint8, device=self.device)
+        ops.logmel(x, self.mel_filters, out, ws, B, N, self.s.num_mel_bins)
+        return out
+
+    # ---- shared blocks -----------------------------------------------------------------------
+    def _self_attention(self, x, qkv, S, P, ctx, B, T, H, hd, d, causal):
+        Tp = _r8(T)
+        ops.gemm(qkv, qkv, S, M=T, N=T, K=hd, lda=3 * d, ldb=3 * d, ldc=Tp, b_off=d, alpha=hd ** -0.5,
+                 batch1=B, batch2=H, sA=(T * 3 * d, hd), sB=(T * 3 * d, hd), sC=(H * T * Tp, T * Tp))
+        ops.softmax_fwd(S, P, None, B * H, H, T, T, Tp, causal=causal)
+        ops.gemm(P, qkv, ctx, M=T, N=hd, K=T, lda=Tp, b_layout=MNMAJOR, ldb=3 * d, b_off=2 * d, ldc=d,
+                 batch1=B, batch2=H, sA=(H * T * Tp, T * Tp), sB=(T * 3 * d, hd), sC=(T * d, hd))
+
+    def _ffn(self, w, h_in, h_out, p, M, d, f):
+        st, p32, p16 = self.store, self.store.p32, self.store.p16
+        o = st.off
+        ops.layernorm_fwd(h_in, st.view(p + "final_layer_norm.weight"), st.view(p + "final_layer_norm.bias"),
+                          w["x"], None, M, d, self.s.layer_norm_eps)
+        ops.gemm(w["x"], p16, None, C2=w["g"], M=M, N=f, K=d, lda=d, ldb=d, ldc=f, b_off=o(p + "fc1.weight"),
+                 bias=p32, bias_off=o(p + "fc1.bias"), epilogue=EPI_GELU)
+        ops.gemm(w["g"], p16, h_out, M=M, N=d, K=f, lda=f, ldb=f, ldc=d, b_off=o(p + "fc2.weight"), bias=p32,
+                 bias_off=o(p + "fc2.bias"), epilogue=EPI_RESIDUAL, R=h_in, ldr=d)
+
+    # ---- encoder -----------------------------------------------------------------------------
+    def _encoder_ws(self, B):
+        if B in self._enc_ws:
+            return self._enc_ws[B]
+        s, dev = self.s, self.device
+        d, f, H, T = s.d_model, s.encoder_ffn_dim, s.encoder_attention_heads, s.max_source_positions
+        Tin = 2 * T
+        Tp = _r8(T)
+        z = lambda n, dt=torch.bfloat16: torch.zeros(n, dtype=dt, device=dev)  # noqa: E731
+        w = dict(xin=z(B * (Tin + 2) * s.num_mel_bins + 64), c1=z(B * (Tin + 2) * d + 64), h=[z(B * T * d), z(B * T * d)],
+                 x=z(B * T * d), qkv=z(B * T * 3 * d), S=z(B * H * T * Tp, torch.float32), P=z(B * H * T * Tp),
+                 ctx=z(B * T * d), g=z(B * T * f), out=z(B * T * d),
+                 pos16=self.store.p16[self.store.off("model.encoder.embed_positions.weight"):])
+        self._enc_ws[B] = w
+        return w
+
+    def encode(self, input_features: torch.Tensor) -> torch.Tensor:
+        """input_features f32 [B, mels, 3000] -> encoder states bf16 [B, 1500, d]."""
+        s, st = self.s, self.store
+        p32, p16, o = st.p32, st.p16, st.off
+        x = input_features.to(self.device, torch.float32).contiguous()
+        B, mels, Tin = x.shape
+        T = s.max_source_positions
+        if mels != s.num_mel_bins or Tin != 2 * T:
+            raise ValueError(f"Whisper expects the mel input features to be of shape [B, {s.num_mel_bins}, {2 * T}], "
+                             f"but found {tuple(x.shape)}")
+        d, f, H = s.d_model, s.encoder_ffn_dim, s.encoder_attention_heads
+        hd = d // H
+        w = self._encoder_ws(B)
+        M = B * T
+        # channels-last, time-padded input: rows 1..3000 of each clip hold the frames
+        for b in range(B):
+            ops.transpose_f32_bf16(x[b], w["xin"][(b * (Tin + 2) + 1) * mels:], mels, Tin)
+        # conv1 (k=3, p=1) + GELU -> padded [B, 3002, d]
+        ops.gemm(w["xin"], self.conv1_wr, None, C2=w["c1"], c2_off=d, M=Tin, N=d, K=3 * mels, lda=mels, ldb=3 * mels,
+                 ldc=d, bias=p32, bias_off=o("model.encoder.conv1.bias"), epilogue=EPI_GELU, batch2=B,
+                 sA=(0, (Tin + 2) * mels), sC=(0, (Tin + 2) * d))
+        # conv2 (k=3, s=2, p=1) + GELU + sinusoidal positions
+        h = w["h"][0]
+        ops.gemm(w["c1"], self.conv2_wr, None, C2=h, M=T, N=d, K=3 * d, lda=2 * d, ldb=3 * d, ldc=d, bias=p32,
+                 bias_off=o("model.encoder.conv2.bias"), epilogue=EPI_GELU_RESIDUAL, R=w["pos16"], ldr=d, batch2=B,
+                 sA=(0, (Tin + 2) * d), sC=(0, T * d), sR=(0, 0))
+        cur = 0
+        for l in range(s.encoder_layers):
+            p = f"model.encoder.layers.{l}."
+            hin, hmid = w["h"][cur], w["h"][1 - cur]
+            ops.layernorm_fwd(hin, st.view(p + "self_attn_layer_norm.weight"), st.view(p + "self_attn_layer_norm.bias"),
+                              w["x"], None, M, d, s.layer_norm_eps)
+            ops.gemm(w["x"], p16, w["qkv"], M=M, N=3 * d, K=d, lda=d, ldb=d, ldc=3 * d,
+                     b_off=o(p + "self_attn.q_proj.weight"), bias=p32, bias_off=o(p + "self_attn.q_proj.bias"))
+            self._self_attention(w["x"], w["qkv"], w["S"], w["P"], w["ctx"], B, T, H, hd, d, causal=False)
+            ops.gemm(w["ctx"], p16, hmid, M=M, N=d, K=d, lda=d, ldb=d, ldc=d, b_off=o(p + "self_attn.out_proj.weight"),
+                     bias=p32, bias_off=o(p + "self_attn.out_proj.bias"), epilogue=EPI_RESIDUAL, R=hin, ldr=d)
+            self._ffn(w, hmid, hin, p, M, d, f)  # result back in `hin`
+        ops.layernorm_fwd(w["h"][cur], st.view("model.encoder.layer_norm.weight"), st.view("model.encoder.layer_norm.bias"),
+                          w["out"], None, M, d, s.layer_norm_eps)
+        return w["out"].view(B, T, d)
+
+    # ---- decoder -----------------------------------------------------------------------------
+    def cross_kv(self, enc: torch.Tensor) -> list[torch.Tensor]:
+        """Per decoder layer: K|V projections of the encoder states, bf16 [B*1500, 2d] (computed once
+        per clip, like the cross-attention cache at $TF/models/whisper/modeling_whisper.py:312-335)."""
+        s, st = self.s, self.store
+        d = s.d_model
+        B, T, _ = enc.shape
+        out = []
+        for l in range(s.decoder_layers):
+            p = f"model.decoder.layers.{l}.encoder_attn."
+            kv = torch.empty(B * T * 2 * d, dtype=torch.bfloat16, device=self.device)
+            ops.gemm(enc, st.p16, kv, M=B * T, N=2 * d, K=d, lda=d, ldb=d, ldc=2 * d, b_off=st.off(p + "k_proj.weight"),
+                     bias=st.p32, bias_off=st.off(p + "k_proj.bias__zero"))
+            out.append(kv)
+        return out
+
+    def _decoder_ws(self, B, L):
+        key = (B, L)
+        if key in self._dec_ws:
+            return self._dec_ws[key]
+        s, dev = self.s, self.device
+        d, f, H, Te = s.d_model, s.decoder_ffn_dim, s.decoder_attention_heads, s.max_source_positions
+        Lp, Tep = _r8(L), _r8(Te)
+        z = lambda n, dt=torch.bfloat16: torch.zeros(n, dtype=dt, device=dev)  # noqa: E731
+        w = dict(h=[z(B * L * d), z(B * L * d)], x=z(B * L * d), qkv=z(B * L * 3 * d), q=z(B * L * d),
+                 S=z(B * H * L * max(Lp, Tep), torch.float32), P=z(B * H * L * max(Lp, Tep)), ctx=z(B * L * d),
+                 g=z(B * L * f), hf=z(B * L * d))
+        self._dec_ws[key] = w
+        return w
+
+    def decode(self, input_ids: torch.Tensor, enc: torch.Tensor, kv: list | None = None, last_only: bool = False):
+        """Teacher-forced decoder: input_ids [B, L] -> fp32 logits [B, L, V] (or [B, 1, V] for the
+        last position only)."""
+        s, st = self.s, self.store
+        p32, p16, o = st.p32, st.p16, st.off
+        dev = self.device
+        B, L = input_ids.shape
+        if L > s.max_target_positions:
+            raise ValueError(f"sequence length {L} cannot exceed the maximum allowed length of {s.max_target_positions} tokens")
+        d, f, H, Te = s.d_model, s.decoder_ffn_dim, s.decoder_attention_heads, s.max_source_positions
+        hd = d // H
+        M = B * L
+        Tep = _r8(Te)
+        w = self._decoder_ws(B, L)
+        kv = kv if kv is not None else self.cross_kv(enc)
+        ids = input_ids.to(dev, torch.int32).contiguous().view(-1)
+        pos = torch.arange(L, dtype=torch.int32, device=dev).repeat(B)
+        ops.embed_tokens(p16[o("model.decoder.embed_tokens.weight"):], p16[o("model.decoder.embed_positions.weight"):],
+                         ids, pos, w["h"][0], M, d)
+        for l in range(s.decoder_layers):
+            p = f"model.decoder.layers.{l}."
+            h0, h1 = w["h"][0], w["h"][1]
+            # causal self-attention
+            ops.layernorm_fwd(h0, st.view(p + "self_attn_layer_norm.weight"), st.view(p + "self_attn_layer_norm.bias"),
+                              w["x"], None, M, d, s.layer_norm_eps)
+            ops.gemm(w["x"], p16, w["qkv"], M=M, N=3 * d, K=d, lda=d, ldb=d, ldc=3 * d,
+                     b_off=o(p + "self_attn.q_proj.weight"), bias=p32, bias_off=o(p + "self_attn.q_proj.bias"))
+            self._self_attention(w["x"], w["qkv"], w["S"], w["P"], w["ctx"], B, L, H, hd, d, causal=True)
+            ops.gemm(w["ctx"], p16, h1, M=M, N=d, K=d, lda=d, ldb=d, ldc=d, b_off=o(p + "self_attn.out_proj.weight"),
+                     bias=p32, bias_off=o(p + "self_attn.out_proj.bias"), epilogue=EPI_RESIDUAL, R=h0, ldr=d)
+            # cross-attention over the encoder states
+            ops.layernorm_fwd(h1, st.view(p + "encoder_attn_layer_norm.weight"), st.view(p + "encoder_attn_layer_norm.bias"),
+                              w["x"], None, M, d, s.layer_norm_eps)
+            ops.gemm(w["x"], p16, w["q"], M=M, N=d, K=d, lda=d, ldb=d, ldc=d, b_off=o(p + "encoder_attn.q_proj.weight"),
+                     bias=p32, bias_off=o(p + "encoder_attn.q_proj.bias"))
+            ops.gemm(w["q"], kv[l], w["S"], M=L, N=Te, K=hd, lda=d, ldb=2 * d, ldc=Tep, alpha=hd ** -0.5, batch1=B,
+                     batch2=H, sA=(L * d, hd), sB=(Te * 2 * d, hd), sC=(H * L * Tep, L * Tep))
+            ops.softmax_fwd(w["S"], w["P"], None, B * H, H, L, Te, Tep)
+            ops.gemm(w["P"], kv[l], w["ctx"], M=L, N=hd, K=Te, lda=Tep, b_layout=MNMAJOR, ldb=2 * d, b_off=d, ldc=d,
+                     batch1=B, batch2=H, sA=(H * L * Tep, L * Tep), sB=(Te * 2 * d, hd), sC=(L * d, hd))
+            ops.gemm(w["ctx"], p16, h0, M=M, N=d, K=d, lda=d, ldb=d, ldc=d, b_off=o(p + "encoder_attn.out_proj.weight"),
+                     bias=p32, bias_off=o(p + "encoder_attn.out_proj.bias"), epilogue=EPI_RESIDUAL, R=h1, ldr=d)
+            # feed-forward (result back in h1, then swap roles by copying the pointer order)
+            self._ffn(w, h0, h1, p, M, d, f)
+            w["h"][0], w["h"][1] = h1, h0
+        ops.layernorm_fwd(w["h"][0], st.view("model.decoder.layer_norm.weight"), st.view("model.decoder.layer_norm.bias"),
+                          w["hf"], None, M, d, s.layer_norm_eps)
+        V = s.vocab_size
+        Vp = _r8(V)
+        if last_only:
+            rows = w["hf"].view(B, L, d)[:, -1, :].contiguous()
+            logits = torch.zeros(B, Vp, dtype=torch.float32, device=dev)
+            ops.gemm(rows, p16, logits, M=B, N=V, K=d, lda=d, ldb=d, ldc=Vp, b_off=o("model.decoder.embed_tokens.weight"))
+            return logits.view(B, 1, Vp)[:, :, :V]
+        logits = torch.zeros(M, Vp, dtype=torch.float32, device=dev)
+        ops.gemm(w["hf"], p16, logits, M=M, N=V, K=d, lda=d, ldb=d, ldc=Vp, b_off=o("model.decoder.embed_tokens.weight"))
+        self._last_logits = logits
+        return logits.view(B, L, Vp)[:, :, :V]
+
+    # ---- model-level API -------------------------------------------------------------------------
+    def forward(self, input_features, labels=None, decoder_input_ids=None):
+        """-> dict(loss, logits): `WhisperForConditionalGeneration.forward(input_features, labels)`."""
+        s = self.s
+        enc = self.encode(input_features)
+        if decoder_input_ids is None:
+            if labels is None:
+                raise ValueError("either labels or decoder_input_ids is required")
+            lab = labels.to(torch.int64)
+            dec = lab.new_zeros(lab.shape)
+            dec[:, 1:] = lab[:, :-1]
+            dec[:, 0] = s.decoder_start_token_id
+            decoder_input_ids = dec.masked_fill(dec == -100, s.pad_token_id)
+        logits = self.decode(decoder_input_ids, enc)
+        out = dict(logits=logits, loss=None, encoder_last_hidden_state=enc)
+        if labels is not None:
+            B, L = labels.shape
+            lab = labels.to(self.device, torch.int32).contiguous().view(-1)
+            loss_sum = torch.zeros(1, dtype=torch.float32, device=self.device)
+            count = torch.zeros(1, dtype=torch.int32, device=self.device)
+            ops.cross_entropy_fwd_bwd(self._last_logits, lab, loss_sum, count, None, B * L, s.vocab_size,
+                                      _r8(s.vocab_size), -100)
+            out["loss"] = (loss_sum / count.clamp(min=1).to(torch.float32))[0]
+        return out
+
+    def generate(self, input_features, prefix: list[int], max_length: int, suppress_tokens=None,
+                 begin_suppress_tokens=None) -> list[list[int]]:
+        """Greedy decoding with a forced prefix (<|sot|><|da|><|transcribe|><|notimestamps|> in CoRal's
+        evaluation): masked argmax on the GPU (ca_argmax_masked), stop at EOS / max_length."""
+        s, dev = self.s, self.device
+        enc = self.encode(input_features)
+        kv = self.cross_kv(enc)
+        B = enc.shape[0]
+        V = s.vocab_size
+        sup = torch.zeros(V, dtype=torch.uint8, device=dev)
+        if suppress_tokens:
+            sup[torch.tensor(list(suppress_tokens), device=dev)] = 1
+        sup_begin = sup.clone()
+        if begin_suppress_tokens:
+            sup_begin[torch.tensor(list(begin_suppress_tokens), device=dev)] = 1
+        ids = torch.tensor([prefix] * B, dtype=torch.int64, device=dev)
+        done = torch.zeros(B, dtype=torch.bool, device=dev)
+        nxt = torch.empty(B, dtype=torch.int32, device=dev)
+        while ids.shape[1] < max_length and not bool(done.all()):
+            base = self.decode(ids, enc, kv, last_only=True)[:, 0, :].contiguous()  # fp32 [B, V]
+            mask = sup_begin if ids.shape[1] == len(prefix) else sup
+            ops.argmax_masked(base, mask, nxt, B, V, V)
+            step = torch.where(done, torch.full_like(nxt, s.pad_token_id), nxt).to(torch.int64)
+            ids = torch.cat([ids, step[:, None]], 1)
+            done |= step == s.eos_token_id
+        return ids.tolist()

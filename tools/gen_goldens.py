@@ -318,6 +318,83 @@ def gen_specaug():
     print("specaug ok")
 
 
+def gen_logmel():
+    """WhisperFeatureExtractor (torch STFT path, the one used when torch is installed) on seeded clips."""
+    from transformers import WhisperFeatureExtractor
+
+    rng = np.random.RandomState(5)
+    t = np.arange(59_200) / 16000.0
+    clips = [(0.3 * np.sin(2 * np.pi * 440 * t) + 0.05 * rng.randn(len(t))).astype(np.float32),
+             (0.1 * rng.randn(480_000)).astype(np.float32)]
+    out = {"clip0_len": np.array(len(clips[0]))}
+    for mels in (80, 128):
+        fe = WhisperFeatureExtractor(feature_size=mels)
+        out[f"filters{mels}"] = fe.mel_filters.astype(np.float32)
+        feats = fe(clips, sampling_rate=16000, return_tensors="np")["input_features"]
+        assert feats.shape == (2, mels, 3000)
+        out[f"feat{mels}_sub"] = feats[:, :, ::25].astype(np.float32)       # every 25th frame
+        out[f"feat{mels}_head"] = feats[:, :, :40].astype(np.float32)       # first frames (reflect pad)
+        out[f"feat{mels}_stats"] = np.array([[f.mean(), f.std(), f.min(), f.max()] for f in feats], dtype=np.float64)
+    np.savez_compressed(GOLD / "logmel.npz", **out)
+    print("logmel:", out["feat80_sub"].shape, out["feat80_stats"])
+
+
+def gen_whisper_tiny():
+    """WhisperForConditionalGeneration with a small architecture: encoder states, teacher-forced
+    logits, CE loss and a manual greedy loop over the HF forward."""
+    from transformers import WhisperConfig, WhisperForConditionalGeneration
+
+    from oracle import whisper_ref as wref
+
+    c = wref.WhisperConfig(d_model=64, encoder_layers=2, decoder_layers=2, encoder_attention_heads=4,
+                           decoder_attention_heads=4, encoder_ffn_dim=128, decoder_ffn_dim=128, num_mel_bins=80,
+                           vocab_size=200, max_target_positions=64, pad_token_id=150, decoder_start_token_id=151,
+                           eos_token_id=150)
+    hc = WhisperConfig(d_model=c.d_model, encoder_layers=2, decoder_layers=2, encoder_attention_heads=4,
+                       decoder_attention_heads=4, encoder_ffn_dim=128, decoder_ffn_dim=128, num_mel_bins=80,
+                       vocab_size=200, max_source_positions=1500, max_target_positions=64, pad_token_id=150,
+                       bos_token_id=150, eos_token_id=150, decoder_start_token_id=151, dropout=0.0,
+                       attention_dropout=0.0, activation_dropout=0.0, encoder_layerdrop=0.0, decoder_layerdrop=0.0,
+                       apply_spec_augment=False, attn_implementation="eager", suppress_tokens=[],
+                       begin_suppress_tokens=[])
+    model = WhisperForConditionalGeneration(hc)
+    P = wref.synth_params(c)
+    sd = model.state_dict()
+    with torch.no_grad():
+        for k, v in P.items():
+            assert sd[k].shape == v.shape, (k, sd[k].shape, v.shape)
+            sd[k].copy_(v)
+    model.eval()
+    g = torch.Generator().manual_seed(9)
+    feats = torch.randn(2, 80, 3000, generator=g) * 0.5
+    labels = torch.randint(0, 150, (2, 9), generator=g)
+    labels[1, 6:] = -100
+    res = model(input_features=feats, labels=labels)
+    res.loss.backward()
+    enc = model.model.encoder(feats).last_hidden_state
+    out = {"labels": labels.numpy(), "loss": res.loss.detach().numpy(), "logits": res.logits.detach().numpy(),
+           "enc_slice": enc.detach()[:, ::100, :].numpy(),
+           "grad_fc1": dict(model.named_parameters())["model.decoder.layers.1.fc1.weight"].grad.detach().numpy(),
+           "gradnorm_embed": dict(model.named_parameters())["model.decoder.embed_tokens.weight"].grad.norm().detach().numpy(),
+           "gradnorm_conv1": dict(model.named_parameters())["model.encoder.conv1.weight"].grad.norm().detach().numpy()}
+    prefix = [151, 160, 161, 162]
+    ids = torch.tensor([prefix, prefix])
+    done = torch.zeros(2, dtype=torch.bool)
+    with torch.no_grad():
+        while ids.shape[1] < 24 and not bool(done.all()):
+            lg = model(input_features=feats, decoder_input_ids=ids).logits[:, -1].clone()
+            lg[:, [170, 171]] = float("-inf")
+            if ids.shape[1] == len(prefix):
+                lg[:, [20, 150]] = float("-inf")
+            nxt = lg.argmax(-1)
+            nxt = torch.where(done, torch.full_like(nxt, 150), nxt)
+            ids = torch.cat([ids, nxt[:, None]], 1)
+            done |= nxt == 150
+    out["greedy_ids"] = ids.numpy()
+    np.savez_compressed(GOLD / "whisper_tiny.npz", **out)
+    print("whisper_tiny: loss", out["loss"], "greedy", ids.tolist())
+
+
 if __name__ == "__main__":
     todo = sys.argv[1:] or ["w2v2_tiny", "ctc", "featext", "tokenizer", "collator", "specaug"]
     torch.manual_seed(4242)
