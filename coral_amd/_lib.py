@@ -62,6 +62,16 @@ class CaGemmDesc(C.Structure):
     ]
 
 
+class CaAttnDesc(C.Structure):
+    """Mirror of `CaAttnDesc` in include/coral_amd.h."""
+
+    _fields_ = ([(n, C.c_void_p) for n in ("Q", "K", "V", "O", "dO", "dQ", "dK", "dV", "lse", "Dq", "klen")]
+                + [(n, C.c_int64) for n in ("ldq", "ldk", "ldv", "ldo", "lddo", "lddq", "lddk", "lddv",
+                                             "sqb", "skb", "svb", "sob", "sdob", "sdqb", "sdkb", "sdvb")]
+                + [(n, C.c_int32) for n in ("B", "H", "Tq", "Tk", "hd", "Tqp", "causal")]
+                + [("scale", C.c_float)])
+
+
 KMAJOR, MNMAJOR = 0, 1
 EPI_NONE, EPI_GELU, EPI_RESIDUAL, EPI_DGELU, EPI_GELU_RESIDUAL = 0, 1, 2, 3, 4
 
@@ -76,6 +86,8 @@ SIGNATURES = {
     "ca_gemm_force_kernel": (C.c_int, [C.c_int]),
     "ca_prof_begin": (C.c_int, []),
     "ca_prof_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+    "ca_attn_fwd": (C.c_int, [C.POINTER(CaAttnDesc), _vp]),
+    "ca_attn_bwd": (C.c_int, [C.POINTER(CaAttnDesc), _vp]),
     "ca_layernorm_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _i32, _vp]),
     "ca_layernorm_bwd_partial_floats": (_i64, [_i64, _i32]),
     "ca_layernorm_bwd": (
@@ -85,6 +97,7 @@ SIGNATURES = {
     "ca_colsum_partial_floats": (_i64, [_i64, _i32]),
     "ca_colsum_bf16": (C.c_int, [_vp, _i64, _i64, _i32, _vp, _vp, _i32, _vp, _vp]),
     "ca_dgelu_mul": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
+    "ca_reduce_rows_f32": (C.c_int, [_vp, _i32, _i64, _i32, _vp, _i32, _vp]),
     "ca_wave_normalize": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _f32, _vp]),
     "ca_conv0_ln_gelu_fwd": (
         C.c_int,

@@ -1,0 +1,519 @@
+// Fused (flash-style) multi-head attention for gfx950: forward and backward without ever writing the
+// [T, T] score / probability matrices to HBM.  Replaces SDPA at
+// $TF/models/wav2vec2/modeling_wav2vec2.py:438-463,529-543 and $TF/models/whisper/modeling_whisper.py:215-238.
+//
+// Shapes: Q [B, Tq, *] / K, V [B, Tk, *] bf16 with row strides ldq / ldk / ldv and head h at column
+// offset h*hd (so q, k, v can live in one fused [B*T, 3d] projection output); head_dim hd is any
+// multiple of 8 up to 128 (64, 80 and 120 on this path).
+//
+// Structure (all three kernels): one 256-thread workgroup = 4 waves x 16 rows (queries or keys); the
+// rows of the *other* side stream through LDS in tiles staged by global_load_lds (two images per tile
+// where needed: a K-major one read with ds_read_b128 for the Q.K^T / dO.V^T products and an MN-major one
+// read with ds_read_b64_tr_b16 for the products that contract over the tile's rows).  Score tiles are
+// computed in the orientation whose accumulator registers ARE the next MFMA's A operand (the rows of a
+// 32-row step are permuted so that a lane group ends up with 8 consecutive contraction indices), so
+// probabilities never leave registers.  Softmax statistics use a first pass (row max and sum, merged
+// across the four lane groups with two shuffles); the second pass recomputes the scores and multiplies
+// by V with already-normalised probabilities (no running rescale of the output accumulators).
+#include "common.h"
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+
+__device__ __attribute__((aligned(16))) uint32_t g_attn_zero_page[4];
+
+__device__ __forceinline__ void glds16a(const void* g, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)lds_wave_base, 16, 0, 0);
+}
+
+// ---- LDS images -----------------------------------------------------------------------------------
+// K-major image: [HDPV/64 chunks][ROWS][64 dims], 128-B rows, 16-B chunk index XOR ((row>>1)&7).
+template <int ROWS, int HDPV>
+__device__ __forceinline__ void load_kmajor_image(char* lds, const unsigned short* base, int64_t ld,
+                                                  int row0, int nrows, int hd, int wave, int lane) {
+  constexpr int NCH = HDPV / 64;
+  constexpr int IPW = ROWS / 32;  // instructions per wave per chunk (ROWS*128 B / 1 KiB / 4 waves)
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int i = 0; i < IPW; ++i) {
+      const int inst = wave * IPW + i;
+      const int r = inst * 8 + (lane >> 3);
+      const int cc = (lane & 7) ^ ((r >> 1) & 7);
+      const int dim = c * 64 + cc * 8;
+      int row = row0 + r;
+      row = row < nrows ? row : nrows - 1;
+      const void* src = dim < hd ? (const void*)(base + (int64_t)row * ld + dim) : (const void*)g_attn_zero_page;
+      glds16a(src, lds + c * ROWS * 128 + inst * 1024);
+    }
+}
+// MN-major image: [ROWS][HDPV dims], chunk index XOR ((swz(row) << 1) & (PC-1)); rows >= nrows are zero.
+template <int ROWS, int HDPV>
+__device__ __forceinline__ void load_mnmajor_image(char* lds, const unsigned short* base, int64_t ld,
+                                                   int row0, int nrows, int hd, int wave, int lane) {
+  constexpr int PC = HDPV / 8;
+  constexpr int RPI = 64 / PC;
+  constexpr int IPW = ROWS * HDPV * 2 / 1024 / 4;
+#pragma unroll
+  for (int i = 0; i < IPW; ++i) {
+    const int inst = wave * IPW + i;
+    const int kr = inst * RPI + lane / PC;
+    const int swz = (kr & 3) | (((kr >> 3) & 1) << 2);
+    const int c = (lane % PC) ^ ((swz << 1) & (PC - 1));
+    const int dim = c * 8;
+    const int row = row0 + kr;
+    const void* src = (row < nrows && dim < hd) ? (const void*)(base + (int64_t)row * ld + dim)
+                                                : (const void*)g_attn_zero_page;
+    glds16a(src, lds + inst * 1024);
+  }
+}
+template <int ROWS>
+__device__ __forceinline__ bf16x8_t kimg_frag(const char* img, int row, int ks, int lane) {
+  const int cc = (4 * (ks & 1) + (lane >> 4)) ^ ((row >> 1) & 7);
+  return *(const bf16x8_t*)(img + (ks >> 1) * ROWS * 128 + row * 128 + cc * 16);
+}
+// rows 32*s + 8g + {0..7} of the image x 16 columns starting at 16*nb, transposed into a B operand
+template <int HDPV>
+__device__ __forceinline__ bf16x8_t timg_frag(const char* img, int s, int nb, int lane) {
+  constexpr int PC = HDPV / 8;
+  constexpr int PITCH = HDPV * 2;
+  const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+  const int kr = 32 * s + 8 * g + q;
+  const int swz = q | ((g & 1) << 2);
+  const int c = ((2 * nb) + (p >> 1)) ^ ((swz << 1) & (PC - 1));
+  const char* a0 = img + kr * PITCH + c * 16 + (p & 1) * 8;
+  s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(lptr_t)a0);
+  s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s16x4_t*)(lptr_t)(a0 + 4 * PITCH));
+  s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+// row of a 32-row step that lane-row r of block bb must read so that lane group g ends up holding the
+// contraction indices 8g .. 8g+7 (bb = 0: +0..3, bb = 1: +4..7)
+__device__ __forceinline__ int rowperm(int bb, int r) { return 8 * (r >> 2) + 4 * bb + (r & 3); }
+
+__device__ __forceinline__ bf16x8_t pack8(const float (&v)[8]) {
+  s16x8_t o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (short)f2bf(v[e]);
+  return __builtin_bit_cast(bf16x8_t, o);
+}
+__device__ __forceinline__ bf16x8_t load_rowfrag(const unsigned short* base, int64_t ld, int row, int ks,
+                                                 int lane, int hd) {
+  const int dim = 32 * ks + 8 * (lane >> 4);
+  if (dim < hd) return *(const bf16x8_t*)(base + (int64_t)row * ld + dim);
+  s16x8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+  return __builtin_bit_cast(bf16x8_t, z);
+}
+
+struct AttnArgs {
+  const unsigned short *Q, *K, *V;
+  int64_t ldq, ldk, ldv, sqb, skb, svb;  // row strides and per-batch strides (elements)
+  unsigned short* O;                     // forward output / backward: saved O is not needed (Dq given)
+  int64_t ldo, sob;
+  float* lse;                            // [B, H, Tqp]
+  const int32_t* klen;                   // [B] or null
+  int H, Tq, Tk, hd, Tqp, causal;
+  float scale;
+  // backward
+  const unsigned short* dO;
+  int64_t lddo, sdob;
+  const float* Dq;                       // [B, H, Tqp] rowsum(dO * O)
+  unsigned short *dQ, *dK, *dV;
+  int64_t lddq, lddk, lddv, sdqb, sdkb, sdvb;
+};
+
+#define NEG_INF (-__builtin_inff())
+
+// ---- forward ----------------------------------------------------------------------------------------
+template <int HDPV>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NKS = HDPV / 32, NNB = HDPV / 16;
+  char* Kimg = smem;                  // K-major image of the key tile
+  char* Vimg = smem + 64 * HDPV * 2;  // MN-major image of the value tile
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, r = lane & 15;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int hd = a.hd;
+  const unsigned short* Q = a.Q + b * a.sqb + h * hd;
+  const unsigned short* K = a.K + b * a.skb + h * hd;
+  const unsigned short* V = a.V + b * a.svb + h * hd;
+  const int q0 = blockIdx.x * 64 + wave * 16;
+  const int qi = q0 + r;  // this lane's query (column of the transposed score tile)
+  const int qrow = qi < a.Tq ? qi : a.Tq - 1;
+  int kl = a.Tk;
+  if (a.klen) kl = a.klen[b] < kl ? a.klen[b] : kl;
+  const int nks = (hd + 31) / 32, nnb = (hd + 15) / 16;
+  bf16x8_t qf[NKS];
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) qf[ks] = load_rowfrag(Q, a.ldq, qrow, ks, lane, hd);
+  const int ntile = (kl + 63) / 64;
+  const float scale = a.scale;
+
+  // scores of one 16-key block (bb) of 32-key step s for this wave's 16 queries, transposed:
+  // lane holds keys kbase + 8g + 4bb + {0..3} of query qi
+  auto score_block = [&](int s, int bb) {
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    const int row = 32 * s + rowperm(bb, r);
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks)
+      if (ks < nks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kimg_frag<64>(Kimg, row, ks, lane), qf[ks], acc, 0, 0, 0);
+    return acc;
+  };
+
+  // pass A: softmax statistics
+  float m = NEG_INF, l = 0.f;
+  for (int kt = 0; kt < ntile; ++kt) {
+    load_kmajor_image<64, HDPV>(Kimg, K, a.ldk, kt * 64, a.Tk, hd, wave, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int bb = 0; bb < 2; ++bb) {
+        const f32x4_t acc = score_block(s, bb);
+        float mx = m;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int key = kt * 64 + 32 * s + 8 * g + 4 * bb + e;
+          const bool ok = key < kl && (!a.causal || key <= qi);
+          v[e] = ok ? acc[e] * scale : NEG_INF;
+          mx = fmaxf(mx, v[e]);
+        }
+        if (mx > NEG_INF) {
+          float sum = l * __expf(m - mx);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) sum += __expf(v[e] - mx);
+          l = sum;
+          m = mx;
+        }
+      }
+    __syncthreads();
+  }
+  // merge the four lane groups that share a query
+#pragma unroll
+  for (int o = 16; o < 64; o <<= 1) {
+    const float m2 = __shfl_xor(m, o, 64), l2 = __shfl_xor(l, o, 64);
+    const float mn = fmaxf(m, m2);
+    if (mn > NEG_INF) l = l * __expf(m - mn) + l2 * __expf(m2 - mn);
+    m = mn;
+  }
+  const float lse = l > 0.f ? m + __logf(l) : __builtin_inff();  // +inf: nothing attended -> p = 0
+  if (g == 0 && qi < a.Tq && a.lse) a.lse[((int64_t)b * a.H + h) * a.Tqp + qi] = lse;
+
+  // pass B: O = P V with normalised probabilities
+  f32x4_t o[NNB];
+#pragma unroll
+  for (int nb = 0; nb < NNB; ++nb) o[nb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  for (int kt = 0; kt < ntile; ++kt) {
+    load_kmajor_image<64, HDPV>(Kimg, K, a.ldk, kt * 64, a.Tk, hd, wave, lane);
+    load_mnmajor_image<64, HDPV>(Vimg, V, a.ldv, kt * 64, a.Tk, hd, wave, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      float p[8];
+#pragma unroll
+      for (int bb = 0; bb < 2; ++bb) {
+        const f32x4_t acc = score_block(s, bb);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int key = kt * 64 + 32 * s + 8 * g + 4 * bb + e;
+          const bool ok = key < kl && (!a.causal || key <= qi);
+          p[4 * bb + e] = ok ? __expf(acc[e] * scale - lse) : 0.f;
+        }
+      }
+      const bf16x8_t pf = pack8(p);
+#pragma unroll
+      for (int nb = 0; nb < NNB; ++nb)
+        if (nb < nnb) o[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, timg_frag<HDPV>(Vimg, s, nb, lane), o[nb], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  unsigned short* O = a.O + b * a.sob + h * hd;
+#pragma unroll
+  for (int nb = 0; nb < NNB; ++nb) {
+    const int n = 16 * nb + r;
+    if (nb < nnb && n < hd) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int q = q0 + 4 * g + e;
+        if (q < a.Tq) O[(int64_t)q * a.ldo + n] = f2bf(o[nb][e]);
+      }
+    }
+  }
+}
+
+// ---- backward: D = rowsum(dO * O) ---------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const unsigned short* __restrict__ dO, int64_t lddo,
+                                                            int64_t sdob, const unsigned short* __restrict__ O,
+                                                            int64_t ldo, int64_t sob, float* __restrict__ Dq, int H,
+                                                            int Tq, int Tqp, int hd, int B) {
+  // one 16-lane group per (b, h, q)
+  const int64_t gid = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
+  const int sub = threadIdx.x & 15;
+  const int64_t total = (int64_t)B * H * Tq;
+  if (gid >= total) return;
+  const int q = (int)(gid % Tq);
+  const int h = (int)((gid / Tq) % H);
+  const int b = (int)(gid / ((int64_t)Tq * H));
+  const unsigned short* x = dO + b * sdob + (int64_t)q * lddo + h * hd;
+  const unsigned short* y = O + b * sob + (int64_t)q * ldo + h * hd;
+  float s = 0.f;
+  for (int c = sub * 8; c < hd; c += 128) {
+    const u16x8_t u = *(const u16x8_t*)(x + c), v = *(const u16x8_t*)(y + c);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += bf2f(u[e]) * bf2f(v[e]);
+  }
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (sub == 0) Dq[((int64_t)b * H + h) * Tqp + q] = s;
+}
+
+// ---- backward: dK, dV (workgroup = 64 keys, loops over the queries) ------------------------------------
+template <int HDPV>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NKS = HDPV / 32, NNB = HDPV / 16;
+  constexpr int IMG = 32 * HDPV * 2;
+  char* Qk = smem;            // K-major image of the 32-query tile   (for S = Q K^T)
+  char* dOk = smem + IMG;     // K-major image of dO                   (for dP = dO V^T)
+  char* Qt = smem + 2 * IMG;  // MN-major image of Q                   (for dK += dS^T Q)
+  char* dOt = smem + 3 * IMG; // MN-major image of dO                  (for dV += P^T dO)
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, r = lane & 15;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int hd = a.hd;
+  const unsigned short* Q = a.Q + b * a.sqb + h * hd;
+  const unsigned short* K = a.K + b * a.skb + h * hd;
+  const unsigned short* V = a.V + b * a.svb + h * hd;
+  const unsigned short* dO = a.dO + b * a.sdob + h * hd;
+  const float* lse = a.lse + ((int64_t)b * a.H + h) * a.Tqp;
+  const float* Dq = a.Dq + ((int64_t)b * a.H + h) * a.Tqp;
+  const int k0 = blockIdx.x * 64 + wave * 16;
+  const int key = k0 + r;  // this lane's key (column of the score tile)
+  const int krow = key < a.Tk ? key : a.Tk - 1;
+  int kl = a.Tk;
+  if (a.klen) kl = a.klen[b] < kl ? a.klen[b] : kl;
+  const int nks = (hd + 31) / 32, nnb = (hd + 15) / 16;
+  bf16x8_t kf[NKS], vf[NKS];
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {
+    kf[ks] = load_rowfrag(K, a.ldk, krow, ks, lane, hd);
+    vf[ks] = load_rowfrag(V, a.ldv, krow, ks, lane, hd);
+  }
+  f32x4_t dk[NNB], dv[NNB];
+#pragma unroll
+  for (int nb = 0; nb < NNB; ++nb) dk[nb] = dv[nb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const float scale = a.scale;
+  const int nstep = (a.Tq + 31) / 32;
+  const int s0 = a.causal ? (blockIdx.x * 64) / 32 : 0;  // queries before the tile's first key see none of it
+  for (int qs = s0; qs < nstep; ++qs) {
+    load_kmajor_image<32, HDPV>(Qk, Q, a.ldq, qs * 32, a.Tq, hd, wave, lane);
+    load_kmajor_image<32, HDPV>(dOk, dO, a.lddo, qs * 32, a.Tq, hd, wave, lane);
+    load_mnmajor_image<32, HDPV>(Qt, Q, a.ldq, qs * 32, a.Tq, hd, wave, lane);
+    load_mnmajor_image<32, HDPV>(dOt, dO, a.lddo, qs * 32, a.Tq, hd, wave, lane);
+    // per-query statistics of this step: indices 8g .. 8g+7 are contiguous
+    const f32x4_t l0 = *(const f32x4_t*)(lse + qs * 32 + 8 * g), l1 = *(const f32x4_t*)(lse + qs * 32 + 8 * g + 4);
+    const f32x4_t d0 = *(const f32x4_t*)(Dq + qs * 32 + 8 * g), d1 = *(const f32x4_t*)(Dq + qs * 32 + 8 * g + 4);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    float p[8], ds[8];
+#pragma unroll
+    for (int bb = 0; bb < 2; ++bb) {
+      f32x4_t sacc = {0.f, 0.f, 0.f, 0.f}, pacc = {0.f, 0.f, 0.f, 0.f};
+      const int row = rowperm(bb, r);
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks)
+        if (ks < nks) {
+          sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kimg_frag<32>(Qk, row, ks, lane), kf[ks], sacc, 0, 0, 0);
+          pacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kimg_frag<32>(dOk, row, ks, lane), vf[ks], pacc, 0, 0, 0);
+        }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int qi = qs * 32 + 8 * g + 4 * bb + e;
+        const float ls = bb == 0 ? l0[e] : l1[e];
+        const float dq = bb == 0 ? d0[e] : d1[e];
+        const bool ok = qi < a.Tq && key < kl && (!a.causal || key <= qi);
+        const float pv = ok ? __expf(sacc[e] * scale - ls) : 0.f;
+        p[4 * bb + e] = pv;
+        ds[4 * bb + e] = ok ? pv * (pacc[e] - dq) * scale : 0.f;  // statistics of padded queries are not initialised
+      }
+    }
+    const bf16x8_t pf = pack8(p), dsf = pack8(ds);
+#pragma unroll
+    for (int nb = 0; nb < NNB; ++nb)
+      if (nb < nnb) {
+        dv[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, timg_frag<HDPV>(dOt, 0, nb, lane), dv[nb], 0, 0, 0);
+        dk[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsf, timg_frag<HDPV>(Qt, 0, nb, lane), dk[nb], 0, 0, 0);
+      }
+    __syncthreads();
+  }
+  unsigned short* dK = a.dK + b * a.sdkb + h * hd;
+  unsigned short* dV = a.dV + b * a.sdvb + h * hd;
+#pragma unroll
+  for (int nb = 0; nb < NNB; ++nb) {
+    const int n = 16 * nb + r;
+    if (nb < nnb && n < hd) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int kk = k0 + 4 * g + e;
+        if (kk < a.Tk) {
+          dK[(int64_t)kk * a.lddk + n] = f2bf(dk[nb][e]);
+          dV[(int64_t)kk * a.lddv + n] = f2bf(dv[nb][e]);
+        }
+      }
+    }
+  }
+}
+
+// ---- backward: dQ (workgroup = 64 queries, loops over the keys) ------------------------------------------
+template <int HDPV>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NKS = HDPV / 32, NNB = HDPV / 16;
+  constexpr int IMG = 64 * HDPV * 2;
+  char* Kk = smem;            // K-major image of the key tile   (S^T = K Q^T)
+  char* Vk = smem + IMG;      // K-major image of V              (dP^T = V dO^T)
+  char* Kt = smem + 2 * IMG;  // MN-major image of K             (dQ += dS K)
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, r = lane & 15;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int hd = a.hd;
+  const unsigned short* Q = a.Q + b * a.sqb + h * hd;
+  const unsigned short* K = a.K + b * a.skb + h * hd;
+  const unsigned short* V = a.V + b * a.svb + h * hd;
+  const unsigned short* dO = a.dO + b * a.sdob + h * hd;
+  const int q0 = blockIdx.x * 64 + wave * 16;
+  const int qi = q0 + r;
+  const int qrow = qi < a.Tq ? qi : a.Tq - 1;
+  int kl = a.Tk;
+  if (a.klen) kl = a.klen[b] < kl ? a.klen[b] : kl;
+  const int nks = (hd + 31) / 32, nnb = (hd + 15) / 16;
+  bf16x8_t qf[NKS], dof[NKS];
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {
+    qf[ks] = load_rowfrag(Q, a.ldq, qrow, ks, lane, hd);
+    dof[ks] = load_rowfrag(dO, a.lddo, qrow, ks, lane, hd);
+  }
+  const float lse = a.lse[((int64_t)b * a.H + h) * a.Tqp + qrow];
+  const float dq_row = a.Dq[((int64_t)b * a.H + h) * a.Tqp + qrow];
+  f32x4_t acc[NNB];
+#pragma unroll
+  for (int nb = 0; nb < NNB; ++nb) acc[nb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const float scale = a.scale;
+  int ntile = (kl + 63) / 64;
+  if (a.causal) {
+    const int last = (blockIdx.x * 64 + 63) / 64 + 1;  // keys beyond the tile's last query are masked
+    ntile = ntile < last ? ntile : last;
+  }
+  for (int kt = 0; kt < ntile; ++kt) {
+    load_kmajor_image<64, HDPV>(Kk, K, a.ldk, kt * 64, a.Tk, hd, wave, lane);
+    load_kmajor_image<64, HDPV>(Vk, V, a.ldv, kt * 64, a.Tk, hd, wave, lane);
+    load_mnmajor_image<64, HDPV>(Kt, K, a.ldk, kt * 64, a.Tk, hd, wave, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      float ds[8];
+#pragma unroll
+      for (int bb = 0; bb < 2; ++bb) {
+        f32x4_t sacc = {0.f, 0.f, 0.f, 0.f}, pacc = {0.f, 0.f, 0.f, 0.f};
+        const int row = 32 * s + rowperm(bb, r);
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks)
+          if (ks < nks) {
+            sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kimg_frag<64>(Kk, row, ks, lane), qf[ks], sacc, 0, 0, 0);
+            pacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kimg_frag<64>(Vk, row, ks, lane), dof[ks], pacc, 0, 0, 0);
+          }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int key = kt * 64 + 32 * s + 8 * g + 4 * bb + e;
+          const bool ok = key < kl && (!a.causal || key <= qi);
+          ds[4 * bb + e] = ok ? __expf(sacc[e] * scale - lse) * (pacc[e] - dq_row) * scale : 0.f;
+        }
+      }
+      const bf16x8_t dsf = pack8(ds);
+#pragma unroll
+      for (int nb = 0; nb < NNB; ++nb)
+        if (nb < nnb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsf, timg_frag<HDPV>(Kt, s, nb, lane), acc[nb], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  unsigned short* dQ = a.dQ + b * a.sdqb + h * hd;
+#pragma unroll
+  for (int nb = 0; nb < NNB; ++nb) {
+    const int n = 16 * nb + r;
+    if (nb < nnb && n < hd) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int q = q0 + 4 * g + e;
+        if (q < a.Tq) dQ[(int64_t)q * a.lddq + n] = f2bf(acc[nb][e]);
+      }
+    }
+  }
+}
+
+// ---- C ABI ------------------------------------------------------------------------------------------------
+static int attn_check(const CaAttnDesc* d, const char* who) {
+  CA_CHECK_ARG(d && d->Q && d->K && d->V, "%s: null pointer", who);
+  CA_CHECK_ARG(d->B > 0 && d->H > 0 && d->Tq > 0 && d->Tk > 0, "%s: bad shape", who);
+  CA_CHECK_ARG(d->hd >= 8 && d->hd <= 128 && (d->hd % 8) == 0, "%s: head_dim must be a multiple of 8 in [8,128]", who);
+  CA_CHECK_ARG((d->ldq % 8) == 0 && (d->ldk % 8) == 0 && (d->ldv % 8) == 0, "%s: strides must be multiples of 8", who);
+  CA_CHECK_ARG(d->lse != nullptr && d->Tqp >= d->Tq && (d->Tqp % 32) == 0, "%s: lse needs Tqp %% 32 == 0 rows", who);
+  return CA_OK;
+}
+static AttnArgs to_args(const CaAttnDesc& d) {
+  AttnArgs a;
+  a.Q = (const unsigned short*)d.Q; a.K = (const unsigned short*)d.K; a.V = (const unsigned short*)d.V;
+  a.ldq = d.ldq; a.ldk = d.ldk; a.ldv = d.ldv; a.sqb = d.sqb; a.skb = d.skb; a.svb = d.svb;
+  a.O = (unsigned short*)d.O; a.ldo = d.ldo; a.sob = d.sob;
+  a.lse = d.lse; a.klen = d.klen; a.H = d.H; a.Tq = d.Tq; a.Tk = d.Tk; a.hd = d.hd; a.Tqp = d.Tqp;
+  a.causal = d.causal; a.scale = d.scale;
+  a.dO = (const unsigned short*)d.dO; a.lddo = d.lddo; a.sdob = d.sdob; a.Dq = d.Dq;
+  a.dQ = (unsigned short*)d.dQ; a.dK = (unsigned short*)d.dK; a.dV = (unsigned short*)d.dV;
+  a.lddq = d.lddq; a.lddk = d.lddk; a.lddv = d.lddv; a.sdqb = d.sdqb; a.sdkb = d.sdkb; a.sdvb = d.sdvb;
+  return a;
+}
+
+extern "C" int ca_attn_fwd(const CaAttnDesc* desc, void* stream) {
+  if (int rc = attn_check(desc, "ca_attn_fwd")) return rc;
+  CA_CHECK_ARG(desc->O != nullptr, "ca_attn_fwd: null output");
+  const AttnArgs a = to_args(*desc);
+  dim3 grid((desc->Tq + 63) / 64, desc->H, desc->B), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (desc->hd <= 64)
+    hipLaunchKernelGGL((attn_fwd_kernel<64>), grid, block, 2 * 64 * 64 * 2, s, a);
+  else
+    hipLaunchKernelGGL((attn_fwd_kernel<128>), grid, block, 2 * 64 * 128 * 2, s, a);
+  CA_CHECK_LAUNCH("ca_attn_fwd");
+  return CA_OK;
+}
+
+extern "C" int ca_attn_bwd(const CaAttnDesc* desc, void* stream) {
+  if (int rc = attn_check(desc, "ca_attn_bwd")) return rc;
+  CA_CHECK_ARG(desc->dO && desc->O && desc->Dq && desc->dQ && desc->dK && desc->dV, "ca_attn_bwd: null pointer");
+  CA_CHECK_ARG((desc->lddo % 8) == 0, "ca_attn_bwd: lddo must be a multiple of 8");
+  const AttnArgs a = to_args(*desc);
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t groups = (int64_t)desc->B * desc->H * desc->Tq;
+  hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((unsigned)((groups * 16 + 255) / 256)), dim3(256), 0, s,
+                     (const unsigned short*)desc->dO, desc->lddo, desc->sdob, (const unsigned short*)desc->O,
+                     desc->ldo, desc->sob, (float*)desc->Dq, desc->H, desc->Tq, desc->Tqp, desc->hd, desc->B);
+  dim3 gk((desc->Tk + 63) / 64, desc->H, desc->B), gq((desc->Tq + 63) / 64, desc->H, desc->B), block(256);
+  if (desc->hd <= 64) {
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<64>), gk, block, 4 * 32 * 64 * 2, s, a);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<64>), gq, block, 3 * 64 * 64 * 2, s, a);
+  } else {
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<128>), gk, block, 4 * 32 * 128 * 2, s, a);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<128>), gq, block, 3 * 64 * 128 * 2, s, a);
+  }
+  CA_CHECK_LAUNCH("ca_attn_bwd");
+  return CA_OK;
+}

@@ -72,10 +72,28 @@ __device__ __forceinline__ uint32_t ca_hash32(uint64_t seed, uint64_t idx) {
   z = z ^ (z >> 31);
   return (uint32_t)(z >> 32);
 }
+__device__ __forceinline__ uint64_t ca_hash64(uint64_t seed, uint64_t idx) {
+  uint64_t z = idx + seed * 0x9E3779B97F4A7C15ull + 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+// Keep decision for element `idx` (a flat index): one 64-bit hash serves the 4 elements of an
+// aligned group (16 bits each), so the mask depends only on (seed, idx) -- identical in the forward
+// GELU epilogue and the backward GELU' epilogue -- at a quarter of the hashing cost.
 __device__ __forceinline__ bool ca_dropout_keep(uint64_t seed, uint64_t idx, float p) {
-  // uniform in [0,1): top 24 bits
-  const float u = (float)(ca_hash32(seed, idx) >> 8) * (1.0f / 16777216.0f);
-  return u >= p;
+  const uint64_t h = ca_hash64(seed, idx >> 2);
+  const unsigned int bits = (unsigned int)(h >> (16 * (idx & 3))) & 0xFFFFu;
+  return (float)bits * (1.0f / 65536.0f) >= p;
+}
+// the same decision for 4 consecutive elements starting at a multiple of 4 (one hash)
+__device__ __forceinline__ unsigned int ca_dropout_keep4(uint64_t seed, uint64_t idx4, float p) {
+  const uint64_t h = ca_hash64(seed, idx4 >> 2);
+  unsigned int m = 0;
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    m |= ((float)((unsigned int)(h >> (16 * e)) & 0xFFFFu) * (1.0f / 65536.0f) >= p ? 1u : 0u) << e;
+  return m;
 }
 
 // out[i] (+)= sum_p partial[p*stride + i]  (defined in norm.hip)

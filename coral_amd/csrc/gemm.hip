@@ -231,14 +231,23 @@ __device__ __forceinline__ void gemm_epilogue(const CaGemmDesc& d, f32x4_t (&acc
           if (e < nvalid) r[e] = bf2f(R[e]);
       }
     }
+    unsigned int keep = 0xFFu;
+    if (d.dropout_p > 0.f && (has_gelu || epi == CA_EPI_DGELU)) {
+      const uint64_t idx = ((uint64_t)z * M + m) * (uint64_t)N + nb;
+      if ((idx & 3) == 0) {  // aligned group: two hashes for the 8 elements
+        keep = ca_dropout_keep4(d.dropout_seed, idx, d.dropout_p) |
+               (ca_dropout_keep4(d.dropout_seed, idx + 4, d.dropout_p) << 4);
+      } else {
+        keep = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) keep |= (ca_dropout_keep(d.dropout_seed, idx + e, d.dropout_p) ? 1u : 0u) << e;
+      }
+    }
     if (has_gelu) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         float g = gelu_erf(v[e]);
-        if (d.dropout_p > 0.f) {
-          const uint64_t idx = ((uint64_t)z * M + m) * (uint64_t)N + (nb + e);
-          g = ca_dropout_keep(d.dropout_seed, idx, d.dropout_p) ? g * keep_scale : 0.f;
-        }
+        if (d.dropout_p > 0.f) g = ((keep >> e) & 1u) ? g * keep_scale : 0.f;
         v2[e] = g + r[e];  // r is zero unless GELU_RESIDUAL
       }
     } else if (epi == CA_EPI_RESIDUAL) {
@@ -248,10 +257,7 @@ __device__ __forceinline__ void gemm_epilogue(const CaGemmDesc& d, f32x4_t (&acc
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         float dg = dgelu_erf(r[e]);
-        if (d.dropout_p > 0.f) {
-          const uint64_t idx = ((uint64_t)z * M + m) * (uint64_t)N + (nb + e);
-          dg = ca_dropout_keep(d.dropout_seed, idx, d.dropout_p) ? dg * keep_scale : 0.f;
-        }
+        if (d.dropout_p > 0.f) dg = ((keep >> e) & 1u) ? dg * keep_scale : 0.f;
         v[e] *= dg;
       }
     }

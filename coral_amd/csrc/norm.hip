@@ -375,3 +375,12 @@ extern "C" int ca_dgelu_mul(const void* dy, const void* u, void* out, int64_t n,
   CA_CHECK_LAUNCH("ca_dgelu_mul");
   return CA_OK;
 }
+
+// out[i] (+)= sum_p partial[p*stride + i]: public form of the partial-sum reduction
+extern "C" int ca_reduce_rows_f32(const float* partial, int32_t nparts, int64_t stride, int32_t n, float* out,
+                                  int32_t accumulate, void* stream) {
+  CA_CHECK_ARG(partial && out && nparts > 0 && n > 0 && stride >= n, "ca_reduce_rows_f32: bad argument");
+  ca_reduce_partials_launch(partial, nparts, stride, n, out, accumulate, (hipStream_t)stream);
+  CA_CHECK_LAUNCH("ca_reduce_rows_f32");
+  return CA_OK;
+}

@@ -11,7 +11,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import (EPI_DGELU, EPI_GELU, EPI_GELU_RESIDUAL, EPI_NONE, EPI_RESIDUAL, KMAJOR,
+from ._lib import (CaAttnDesc, EPI_DGELU, EPI_GELU, EPI_GELU_RESIDUAL, EPI_NONE, EPI_RESIDUAL, KMAJOR,
                    MNMAJOR, CaGemmDesc, CoralAmdError, check)
 
 __all__ = ["KMAJOR", "MNMAJOR", "EPI_NONE", "EPI_GELU", "EPI_RESIDUAL", "EPI_DGELU",
@@ -95,6 +95,11 @@ def colsum_partial_floats(rows, N):
 def colsum(x, ld, rows, N, out, partial, accumulate=True, rowmask=None, x_off=0, out_off=0):
     check(lib().ca_colsum_bf16(_p(x, x_off), ld, rows, N, _p(rowmask), _p(out, out_off),
                                int(accumulate), _p(partial), _stream()), "ca_colsum_bf16")
+
+
+def reduce_rows(partial, nparts, stride, n, out, accumulate=False):
+    check(lib().ca_reduce_rows_f32(_p(partial), nparts, stride, n, _p(out), int(accumulate), _stream()),
+          "ca_reduce_rows_f32")
 
 
 def dgelu_mul(dy, u, out, n):
@@ -245,3 +250,30 @@ def prof_end():
     names = ["ca_gemm_kernel<KMAJOR,KMAJOR>", "ca_gemm_kernel<KMAJOR,MNMAJOR>",
              "ca_gemm_kernel<MNMAJOR,KMAJOR>", "ca_gemm_kernel<MNMAJOR,MNMAJOR>"]
     return [dict(kernel=names[i], ms=ms[i], count=cnt[i], flops=fl[i]) for i in range(4)]
+
+
+def _attn_desc(Q, K, V, O, lse, *, B, H, Tq, Tk, hd, Tqp, scale, ldq, ldk, ldv, ldo, sqb, skb, svb, sob,
+               q_off=0, k_off=0, v_off=0, o_off=0, klen=None, causal=False):
+    d = CaAttnDesc()
+    d.Q, d.K, d.V, d.O = _p(Q, q_off), _p(K, k_off), _p(V, v_off), _p(O, o_off)
+    d.lse, d.klen = _p(lse), _p(klen)
+    d.ldq, d.ldk, d.ldv, d.ldo = ldq, ldk, ldv, ldo
+    d.sqb, d.skb, d.svb, d.sob = sqb, skb, svb, sob
+    d.B, d.H, d.Tq, d.Tk, d.hd, d.Tqp, d.causal, d.scale = B, H, Tq, Tk, hd, Tqp, int(causal), scale
+    return d
+
+
+def attn_fwd(Q, K, V, O, lse, **kw):
+    """Fused attention forward: O = softmax(scale Q K^T + masks) V, lse saved for the backward."""
+    d = _attn_desc(Q, K, V, O, lse, **kw)
+    check(lib().ca_attn_fwd(C.byref(d), _stream()), "ca_attn_fwd")
+
+
+def attn_bwd(Q, K, V, O, lse, dO, Dq, dQ, dK, dV, *, lddo, sdob, lddq, lddk, lddv, sdqb, sdkb, sdvb, do_off=0,
+             dq_off=0, dk_off=0, dv_off=0, **kw):
+    d = _attn_desc(Q, K, V, O, lse, **kw)
+    d.dO, d.Dq = _p(dO, do_off), _p(Dq)
+    d.dQ, d.dK, d.dV = _p(dQ, dq_off), _p(dK, dk_off), _p(dV, dv_off)
+    d.lddo, d.sdob = lddo, sdob
+    d.lddq, d.lddk, d.lddv, d.sdqb, d.sdkb, d.sdvb = lddq, lddk, lddv, sdqb, sdkb, sdvb
+    check(lib().ca_attn_bwd(C.byref(d), _stream()), "ca_attn_bwd")

@@ -157,8 +157,10 @@ class CTCOutput(dict):
 class Wav2Vec2CTCEngine:
     """Forward + backward of Wav2Vec2ForCTC as a fixed sequence of HIP kernels."""
 
-    def __init__(self, shape: Wav2Vec2Shape, device="cuda:0", freeze_base: bool = False):
+    def __init__(self, shape: Wav2Vec2Shape, device="cuda:0", freeze_base: bool = False,
+                 fused_attention: bool = True):
         self.s = shape
+        self.fused_attention = fused_attention  # False: batched-GEMM + softmax kernels (A/B reference)
         self.device = torch.device(device)
         ops.lib()  # fail loudly if the HIP library is not built
         if not torch.cuda.is_available():
@@ -288,14 +290,21 @@ class Wav2Vec2CTCEngine:
         w["x1"] = [z(M * d) for _ in range(L)]
         w["st1"] = [z(M * 2, dt=f32) for _ in range(L)]
         w["qkv"] = [z(M * 3 * d) for _ in range(L)]
-        w["P"] = [z(B * H * T * Tp) for _ in range(L)]
+        Tqp = (T + 31) // 32 * 32
+        w["Tqp"] = Tqp
+        if self.fused_attention:
+            w["lse"] = [z(B * H * Tqp, dt=f32) for _ in range(L)]
+            w["Dq"] = z(B * H * Tqp, dt=f32)
+        else:
+            w["P"] = [z(B * H * T * Tp) for _ in range(L)]
         w["ctx"] = [z(M * d) for _ in range(L)]
         w["h1"] = [z(M * d) for _ in range(L)]
         w["x2"] = [z(M * d) for _ in range(L)]
         w["st2"] = [z(M * 2, dt=f32) for _ in range(L)]
         w["u"] = [z(M * f) for _ in range(L)]
         w["g"] = [z(M * f) for _ in range(L)]
-        w["S"] = z(B * H * T * Tp, dt=f32)             # transient scores / dprobs
+        if not self.fused_attention:
+            w["S"] = z(B * H * T * Tp, dt=f32)         # transient scores / dprobs
         w["hf"] = z(M * d)
         w["stf"] = z(M * 2, dt=f32)
         Vp = _r8(s.vocab_size)
@@ -309,7 +318,8 @@ class Wav2Vec2CTCEngine:
         w["dB"] = z(M * d)
         w["dC"] = z(M * d)
         w["dqkv"] = z(M * 3 * d)
-        w["dS"] = z(B * H * T * Tp)
+        if not self.fused_attention:
+            w["dS"] = z(B * H * T * Tp)
         w["du"] = z(M * f)
         w["dxg"] = z(B * G * (T + K) * Cg + 8 * Cg)
         w["dwf"] = z(d * K * Cg, dt=f32)
@@ -318,6 +328,7 @@ class Wav2Vec2CTCEngine:
         w["dconv"] = [z(B * Ts[i] * s.conv_dim[i]) for i in range(7)]   # grads wrt conv block outputs
         w["dy"] = z(max(B * Ts[i] * s.conv_dim[i] for i in range(1, 7)))
         w["dwr"] = z(max(s.conv_dim[i] * s.conv_kernel[i] * s.conv_dim[i - 1] for i in range(1, 7)), dt=f32)
+        w["dwr_part"] = z(B * max(s.conv_dim[i] * s.conv_kernel[i] * s.conv_dim[i - 1] for i in range(1, 7)), dt=f32)
         pf = max(
             ops.layernorm_bwd_partial_floats(B * Ts[1], 512), ops.layernorm_bwd_partial_floats(M, d),
             ops.colsum_partial_floats(M, max(f, 3 * d)), ops.colsum_partial_floats(B * Ts[1], 512),
@@ -353,6 +364,7 @@ class Wav2Vec2CTCEngine:
         else:
             flen = torch.full((B,), T, dtype=torch.int32, device=dev)
         keep = [True] * L if layer_keep is None else list(layer_keep)
+        w["flen"] = flen
 
         # feature encoder
         p0 = "wav2vec2.feature_extractor.conv_layers.0."
@@ -448,6 +460,12 @@ class Wav2Vec2CTCEngine:
         return out
 
     def _attention_fwd(self, w, l, B, T, Tp, H, hd, d, flen, scale):
+        if self.fused_attention:
+            qkv = w["qkv"][l]
+            ops.attn_fwd(qkv, qkv, qkv, w["ctx"][l], w["lse"][l], B=B, H=H, Tq=T, Tk=T, hd=hd, Tqp=w["Tqp"],
+                         scale=scale, ldq=3 * d, ldk=3 * d, ldv=3 * d, ldo=d, sqb=T * 3 * d, skb=T * 3 * d,
+                         svb=T * 3 * d, sob=T * d, q_off=0, k_off=d, v_off=2 * d, klen=flen)
+            return
         qkv, S, P, ctx = w["qkv"][l], w["S"], w["P"][l], w["ctx"][l]
         ops.gemm(qkv, qkv, S, M=T, N=T, K=hd, lda=3 * d, ldb=3 * d, ldc=Tp, b_off=d, alpha=scale,
                  batch1=B, batch2=H, sA=(T * 3 * d, hd), sB=(T * 3 * d, hd), sC=(H * T * Tp, T * Tp))
@@ -600,9 +618,12 @@ class Wav2Vec2CTCEngine:
                               st.view(pi + "layer_norm.weight", "g32"), st.view(pi + "layer_norm.bias", "g32"),
                               part, B * Ti, Co, act=1)
             ops.colsum(dy, Co, B * Ti, Co, g32, part, out_off=o(pi + "conv.bias"))
-            ops.gemm(dy, w["a"][i - 1], w["dwr"], M=Co, N=k * Ci, K=B * Ti, a_layout=MNMAJOR, lda=Co,
-                     b_layout=MNMAJOR, ldb=sd * Ci, b_kseg=Ti, b_kseg_stride=Lin * Ci, ldc=k * Ci,
-                     out_f32=True)
+            # weight gradient: one TN GEMM per utterance (batch dimension) into fp32 partials, summed
+            # afterwards -- the single long-K GEMM has only Co/128 x k*Ci/128 = 48 tiles
+            ops.gemm(dy, w["a"][i - 1], w["dwr_part"], M=Co, N=k * Ci, K=Ti, a_layout=MNMAJOR, lda=Co,
+                     b_layout=MNMAJOR, ldb=sd * Ci, ldc=k * Ci, out_f32=True, batch2=B, sA=(0, Ti * Co),
+                     sB=(0, Lin * Ci), sC=(0, Co * k * Ci))
+            ops.reduce_rows(w["dwr_part"], B, Co * k * Ci, Co * k * Ci, w["dwr"])
             ops.conv_weight_grad_reorder(w["dwr"], g32, Co, Ci, k, dw_off=o(pi + "conv.weight"))
             ops.gemm(dy, self.conv_wr[i], w["dcol"], M=B * Ti, N=k * Ci, K=Co, lda=Co, b_layout=MNMAJOR,
                      ldb=k * Ci, ldc=k * Ci)
@@ -616,6 +637,14 @@ class Wav2Vec2CTCEngine:
         done("front")
 
     def _attention_bwd(self, w, l, dctx, B, T, Tp, H, hd, d, scale):
+        if self.fused_attention:
+            qkv, dqkv = w["qkv"][l], w["dqkv"]
+            ops.attn_bwd(qkv, qkv, qkv, w["ctx"][l], w["lse"][l], dctx, w["Dq"], dqkv, dqkv, dqkv, lddo=d,
+                         sdob=T * d, lddq=3 * d, lddk=3 * d, lddv=3 * d, sdqb=T * 3 * d, sdkb=T * 3 * d,
+                         sdvb=T * 3 * d, dq_off=0, dk_off=d, dv_off=2 * d, B=B, H=H, Tq=T, Tk=T, hd=hd,
+                         Tqp=w["Tqp"], scale=scale, ldq=3 * d, ldk=3 * d, ldv=3 * d, ldo=d, sqb=T * 3 * d,
+                         skb=T * 3 * d, svb=T * 3 * d, sob=T * d, q_off=0, k_off=d, v_off=2 * d, klen=w["flen"])
+            return
         qkv, P, dP, dS, dqkv = w["qkv"][l], w["P"][l], w["S"], w["dS"], w["dqkv"]
         bs = dict(batch1=B, batch2=H)
         # dP = dctx V^T

@@ -176,13 +176,16 @@ class WhisperEngine:
         return out
 
     # ---- shared blocks -----------------------------------------------------------------------
-    def _self_attention(self, x, qkv, S, P, ctx, B, T, H, hd, d, causal):
-        Tp = _r8(T)
-        ops.gemm(qkv, qkv, S, M=T, N=T, K=hd, lda=3 * d, ldb=3 * d, ldc=Tp, b_off=d, alpha=hd ** -0.5,
-                 batch1=B, batch2=H, sA=(T * 3 * d, hd), sB=(T * 3 * d, hd), sC=(H * T * Tp, T * Tp))
-        ops.softmax_fwd(S, P, None, B * H, H, T, T, Tp, causal=causal)
-        ops.gemm(P, qkv, ctx, M=T, N=hd, K=T, lda=Tp, b_layout=MNMAJOR, ldb=3 * d, b_off=2 * d, ldc=d,
-                 batch1=B, batch2=H, sA=(H * T * Tp, T * Tp), sB=(T * 3 * d, hd), sC=(T * d, hd))
+    def _lse(self, n):
+        if getattr(self, "_lse_buf", None) is None or self._lse_buf.numel() < n:
+            self._lse_buf = torch.zeros(n, dtype=torch.float32, device=self.device)
+        return self._lse_buf
+
+    def _self_attention(self, qkv, ctx, B, T, H, hd, d, causal):
+        Tqp = (T + 31) // 32 * 32
+        ops.attn_fwd(qkv, qkv, qkv, ctx, self._lse(B * H * Tqp), B=B, H=H, Tq=T, Tk=T, hd=hd, Tqp=Tqp,
+                     scale=hd ** -0.5, ldq=3 * d, ldk=3 * d, ldv=3 * d, ldo=d, sqb=T * 3 * d, skb=T * 3 * d,
+                     svb=T * 3 * d, sob=T * d, q_off=0, k_off=d, v_off=2 * d, causal=causal)
 
     def _ffn(self, w, h_in, h_out, p, M, d, f):
         st, p32, p16 = self.store, self.store.p32, self.store.p16
@@ -204,8 +207,7 @@ class WhisperEngine:
         Tp = _r8(T)
         z = lambda n, dt=torch.bfloat16: torch.zeros(n, dtype=dt, device=dev)  # noqa: E731
         w = dict(xin=z(B * (Tin + 2) * s.num_mel_bins + 64), c1=z(B * (Tin + 2) * d + 64), h=[z(B * T * d), z(B * T * d)],
-                 x=z(B * T * d), qkv=z(B * T * 3 * d), S=z(B * H * T * Tp, torch.float32), P=z(B * H * T * Tp),
-                 ctx=z(B * T * d), g=z(B * T * f), out=z(B * T * d),
+                 x=z(B * T * d), qkv=z(B * T * 3 * d), ctx=z(B * T * d), g=z(B * T * f), out=z(B * T * d),
                  pos16=self.store.p16[self.store.off("model.encoder.embed_positions.weight"):])
         self._enc_ws[B] = w
         return w
@@ -244,7 +246,7 @@ class WhisperEngine:
                               w["x"], None, M, d, s.layer_norm_eps)
             ops.gemm(w["x"], p16, w["qkv"], M=M, N=3 * d, K=d, lda=d, ldb=d, ldc=3 * d,
                      b_off=o(p + "self_attn.q_proj.weight"), bias=p32, bias_off=o(p + "self_attn.q_proj.bias"))
-            self._self_attention(w["x"], w["qkv"], w["S"], w["P"], w["ctx"], B, T, H, hd, d, causal=False)
+            self._self_attention(w["qkv"], w["ctx"], B, T, H, hd, d, causal=False)
             ops.gemm(w["ctx"], p16, hmid, M=M, N=d, K=d, lda=d, ldb=d, ldc=d, b_off=o(p + "self_attn.out_proj.weight"),
                      bias=p32, bias_off=o(p + "self_attn.out_proj.bias"), epilogue=EPI_RESIDUAL, R=hin, ldr=d)
             self._ffn(w, hmid, hin, p, M, d, f)  # result back in `hin`
@@ -276,8 +278,7 @@ class WhisperEngine:
         d, f, H, Te = s.d_model, s.decoder_ffn_dim, s.decoder_attention_heads, s.max_source_positions
         Lp, Tep = _r8(L), _r8(Te)
         z = lambda n, dt=torch.bfloat16: torch.zeros(n, dtype=dt, device=dev)  # noqa: E731
-        w = dict(h=[z(B * L * d), z(B * L * d)], x=z(B * L * d), qkv=z(B * L * 3 * d), q=z(B * L * d),
-                 S=z(B * H * L * max(Lp, Tep), torch.float32), P=z(B * H * L * max(Lp, Tep)), ctx=z(B * L * d),
+        w = dict(h=[z(B * L * d), z(B * L * d)], x=z(B * L * d), qkv=z(B * L * 3 * d), q=z(B * L * d), ctx=z(B * L * d),
                  g=z(B * L * f), hf=z(B * L * d))
         self._dec_ws[key] = w
         return w
@@ -309,7 +310,7 @@ class WhisperEngine:
                               w["x"], None, M, d, s.layer_norm_eps)
             ops.gemm(w["x"], p16, w["qkv"], M=M, N=3 * d, K=d, lda=d, ldb=d, ldc=3 * d,
                      b_off=o(p + "self_attn.q_proj.weight"), bias=p32, bias_off=o(p + "self_attn.q_proj.bias"))
-            self._self_attention(w["x"], w["qkv"], w["S"], w["P"], w["ctx"], B, L, H, hd, d, causal=True)
+            self._self_attention(w["qkv"], w["ctx"], B, L, H, hd, d, causal=True)
             ops.gemm(w["ctx"], p16, h1, M=M, N=d, K=d, lda=d, ldb=d, ldc=d, b_off=o(p + "self_attn.out_proj.weight"),
                      bias=p32, bias_off=o(p + "self_attn.out_proj.bias"), epilogue=EPI_RESIDUAL, R=h0, ldr=d)
             # cross-attention over the encoder states
@@ -317,11 +318,10 @@ class WhisperEngine:
                               w["x"], None, M, d, s.layer_norm_eps)
             ops.gemm(w["x"], p16, w["q"], M=M, N=d, K=d, lda=d, ldb=d, ldc=d, b_off=o(p + "encoder_attn.q_proj.weight"),
                      bias=p32, bias_off=o(p + "encoder_attn.q_proj.bias"))
-            ops.gemm(w["q"], kv[l], w["S"], M=L, N=Te, K=hd, lda=d, ldb=2 * d, ldc=Tep, alpha=hd ** -0.5, batch1=B,
-                     batch2=H, sA=(L * d, hd), sB=(Te * 2 * d, hd), sC=(H * L * Tep, L * Tep))
-            ops.softmax_fwd(w["S"], w["P"], None, B * H, H, L, Te, Tep)
-            ops.gemm(w["P"], kv[l], w["ctx"], M=L, N=hd, K=Te, lda=Tep, b_layout=MNMAJOR, ldb=2 * d, b_off=d, ldc=d,
-                     batch1=B, batch2=H, sA=(H * L * Tep, L * Tep), sB=(Te * 2 * d, hd), sC=(L * d, hd))
+            Lqp = (L + 31) // 32 * 32
+            ops.attn_fwd(w["q"], kv[l], kv[l], w["ctx"], self._lse(B * H * Lqp), B=B, H=H, Tq=L, Tk=Te, hd=hd, Tqp=Lqp,
+                         scale=hd ** -0.5, ldq=d, ldk=2 * d, ldv=2 * d, ldo=d, sqb=L * d, skb=Te * 2 * d,
+                         svb=Te * 2 * d, sob=L * d, k_off=0, v_off=d)
             ops.gemm(w["ctx"], p16, h0, M=M, N=d, K=d, lda=d, ldb=d, ldc=d, b_off=o(p + "encoder_attn.out_proj.weight"),
                      bias=p32, bias_off=o(p + "encoder_attn.out_proj.bias"), epilogue=EPI_RESIDUAL, R=h1, ldr=d)
             # feed-forward (result back in h1, then swap roles by copying the pointer order)

@@ -129,6 +129,9 @@ int ca_layernorm_bwd(const void* dy, const void* x, const float* gamma, const fl
 int64_t ca_colsum_partial_floats(int64_t rows, int32_t N);
 int ca_colsum_bf16(const void* x, int64_t ld, int64_t rows, int32_t N, const uint8_t* rowmask,
                    float* out, int32_t accumulate, float* partial, void* stream);
+/* out[i] (+)= sum_{p<nparts} partial[p*stride + i], i < n  (fp32; split-batch weight gradients) */
+int ca_reduce_rows_f32(const float* partial, int32_t nparts, int64_t stride, int32_t n, float* out,
+                       int32_t accumulate, void* stream);
 /* out = dy * gelu_erf'(u), bf16 elementwise (backward of the pos-conv GELU, :374). */
 int ca_dgelu_mul(const void* dy, const void* u, void* out, int64_t n, void* stream);
 
@@ -174,6 +177,32 @@ int ca_softmax_fwd(const float* scores, void* probs, const int32_t* klen, int32_
                    void* stream);
 int ca_softmax_bwd(const float* dprobs, const void* probs, void* dscores, float scale,
                    int32_t BH, int32_t Tq, int32_t Tk, int64_t ld, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Fused multi-head attention (flash-style, no [T,T] matrix in HBM): forward and backward.
+ *   $TF/models/wav2vec2/modeling_wav2vec2.py:438-463,529-543 (SDPA) and
+ *   $TF/models/whisper/modeling_whisper.py:215-238,284-356.
+ * Q [B,Tq,*], K,V [B,Tk,*] bf16 with row strides ldq/ldk/ldv, batch strides s?b (elements) and head h
+ * at column offset h*hd; O/dO/dQ/dK/dV likewise.  softmax(scale * Q K^T + masks) V with key padding
+ * klen[b] (NULL = none) and an optional causal mask.  lse fp32 [B,H,Tqp] (row log-sum-exp, written
+ * by the forward, read by the backward), Dq fp32 [B,H,Tqp] scratch for rowsum(dO*O); Tqp % 32 == 0.
+ * head_dim: any multiple of 8 up to 128.
+ * ---------------------------------------------------------------------------------- */
+typedef struct CaAttnDesc {
+  const void *Q, *K, *V;
+  void* O;          /* forward: output; backward: the saved forward output */
+  const void* dO;   /* backward only */
+  void *dQ, *dK, *dV;
+  float* lse;
+  float* Dq;
+  const int32_t* klen;
+  int64_t ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
+  int64_t sqb, skb, svb, sob, sdob, sdqb, sdkb, sdvb;
+  int32_t B, H, Tq, Tk, hd, Tqp, causal;
+  float scale;
+} CaAttnDesc;
+int ca_attn_fwd(const CaAttnDesc* desc, void* stream);
+int ca_attn_bwd(const CaAttnDesc* desc, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * CTC head: log_softmax(fp32) + CTC loss (+ gradient wrt logits) + greedy decode.

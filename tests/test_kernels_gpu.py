@@ -402,3 +402,84 @@ def test_misc_reorders(ops):
     want[1, :, 5] = 0
     want[1, 6:] = 0
     assert (hd.cpu().float() - want.float()).abs().max() == 0
+
+
+@pytest.mark.parametrize("hd,H,Tq,Tk,causal,pad", [(64, 2, 499, 499, False, True), (120, 2, 499, 499, False, True),
+                                                    (80, 3, 130, 130, False, False), (32, 4, 12, 12, False, True),
+                                                    (64, 2, 77, 77, True, False), (64, 2, 40, 300, False, False),
+                                                    (128, 1, 200, 200, True, True)])
+def test_fused_attention_fwd_bwd(ops, hd, H, Tq, Tk, causal, pad):
+    """ca_attn_fwd / ca_attn_bwd against an fp32 torch statement of softmax(scale QK^T + masks) V and
+    its autograd gradients; q,k,v live in one fused [B*T, 3d] buffer like the engine's (self-attention)
+    or in separate buffers (cross-attention shapes)."""
+    B, d = 2, H * hd
+    g = torch.Generator().manual_seed(hd + Tq + Tk)
+    scale = hd ** -0.5
+    fused = Tq == Tk
+    if fused:
+        qkv = bf(torch.randn(B, Tq, 3 * d, generator=g))
+        q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
+    else:
+        q, k, v = bf(torch.randn(B, Tq, d, generator=g)), bf(torch.randn(B, Tk, d, generator=g)), bf(torch.randn(B, Tk, d, generator=g))
+    klen = torch.tensor([Tk, max(1, Tk * 3 // 5)], dtype=torch.int32) if pad else None
+    dO = bf(torch.randn(B, Tq, d, generator=g))
+
+    def heads(x, T):
+        return x.float().view(B, T, H, hd).transpose(1, 2)
+
+    qr, kr, vr = [heads(t, T).clone().requires_grad_(True) for t, T in ((q, Tq), (k, Tk), (v, Tk))]
+    s = qr @ kr.transpose(-1, -2) * scale
+    mask = torch.ones(B, 1, Tq, Tk, dtype=torch.bool)
+    if klen is not None:
+        mask = mask & (torch.arange(Tk)[None, None, None, :] < klen[:, None, None, None])
+    if causal:
+        mask = mask & (torch.arange(Tk)[None, None, None, :] <= torch.arange(Tq)[None, None, :, None])
+    s = s.masked_fill(~mask, float("-inf"))
+    o_ref = torch.softmax(s, -1) @ vr
+    o_ref.backward(heads(dO, Tq))
+    o_ref = o_ref.detach().transpose(1, 2).reshape(B, Tq, d)
+
+    Tqp = (Tq + 31) // 32 * 32
+    lse = torch.zeros(B, H, Tqp, device=DEV)
+    Dq = torch.zeros(B, H, Tqp, device=DEV)
+    O = torch.zeros(B, Tq, d, dtype=torch.bfloat16, device=DEV)
+    kd = klen.to(DEV) if klen is not None else None
+    if fused:
+        buf = qkv.to(DEV).contiguous()
+        Qd = Kd = Vd = buf
+        offs = dict(q_off=0, k_off=d, v_off=2 * d)
+        lds = dict(ldq=3 * d, ldk=3 * d, ldv=3 * d, sqb=Tq * 3 * d, skb=Tk * 3 * d, svb=Tk * 3 * d)
+        dbuf = torch.zeros(B, Tq, 3 * d, dtype=torch.bfloat16, device=DEV)
+        dQd = dKd = dVd = dbuf
+        doffs = dict(dq_off=0, dk_off=d, dv_off=2 * d)
+        dlds = dict(lddq=3 * d, lddk=3 * d, lddv=3 * d, sdqb=Tq * 3 * d, sdkb=Tk * 3 * d, sdvb=Tk * 3 * d)
+    else:
+        Qd, Kd, Vd = q.to(DEV).contiguous(), k.to(DEV).contiguous(), v.to(DEV).contiguous()
+        offs = {}
+        lds = dict(ldq=d, ldk=d, ldv=d, sqb=Tq * d, skb=Tk * d, svb=Tk * d)
+        dQd = torch.zeros(B, Tq, d, dtype=torch.bfloat16, device=DEV)
+        dKd, dVd = torch.zeros(B, Tk, d, dtype=torch.bfloat16, device=DEV), torch.zeros(B, Tk, d, dtype=torch.bfloat16, device=DEV)
+        doffs = {}
+        dlds = dict(lddq=d, lddk=d, lddv=d, sdqb=Tq * d, sdkb=Tk * d, sdvb=Tk * d)
+    common = dict(B=B, H=H, Tq=Tq, Tk=Tk, hd=hd, Tqp=Tqp, scale=scale, ldo=d, sob=Tq * d, klen=kd, causal=causal,
+                  **lds, **offs)
+    ops.attn_fwd(Qd, Kd, Vd, O, lse, **common)
+    torch.cuda.synchronize()
+    assert (O.float().cpu() - o_ref).abs().max() < 2e-2
+    lse_ref = torch.logsumexp(s.detach(), -1)
+    assert (lse[:, :, :Tq].cpu() - lse_ref).abs().max() < 2e-2
+    ops.attn_bwd(Qd, Kd, Vd, O, lse, dO.to(DEV).contiguous(), Dq, dQd, dKd, dVd, lddo=d, sdob=Tq * d, **dlds, **doffs,
+                 **common)
+    torch.cuda.synchronize()
+
+    def unheads(x, T):
+        return x.transpose(1, 2).reshape(B, T, d)
+
+    if fused:
+        dq, dk, dv = dbuf[..., :d], dbuf[..., d:2 * d], dbuf[..., 2 * d:]
+    else:
+        dq, dk, dv = dQd, dKd, dVd
+    for got, want, T in ((dq, qr.grad, Tq), (dk, kr.grad, Tk), (dv, vr.grad, Tk)):
+        want = unheads(want, T)
+        err = (got.float().cpu() - want).abs().max().item()
+        assert err < 3e-2 * max(1.0, want.abs().max().item()), (err, want.abs().max().item())
