@@ -359,16 +359,14 @@ __global__ __launch_bounds__(256) void ca_gemm_kernel(const CaGemmDesc d) {
       lb_m.issue(st + TILE_BYTES, wave, lane, kt * BK, K);
   };
 
+  // One barrier per K-step: a wave arrives at barrier(kt) only after it consumed every fragment of
+  // tile kt-1 (lgkmcnt(0) below), so the stage of tile kt-1 may be re-staged right after the barrier.
   issue_stage(0);
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) {
-      issue_stage(kt + 1);
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // 8 LDS-DMA per stage per wave
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // tile kt landed; my reads of kt-1 done
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    if (kt + 1 < nk) issue_stage(kt + 1);
 
     const char* ta = smem + (kt & 1) * STAGE_BYTES;
     const char* tb = ta + TILE_BYTES;
@@ -389,12 +387,115 @@ __global__ __launch_bounds__(256) void ca_gemm_kernel(const CaGemmDesc d) {
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
     }
-    // every wave's fragment reads of this stage have returned before it is re-staged
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();  // all waves are done with the stages before the epilogue reuses the LDS
+  asm volatile("" ::: "memory");
+  gemm_epilogue(d, acc, smem, wave, lane, m0 + wm * 64, n0 + wn * 64, z, z1, z2);
+}
+
+// ---- kernel X: 256x256 tile, 8 waves (2x4, 128x64 each), 2 LDS stages, one workgroup per CU ----------
+// Half the LDS-fill bytes per FLOP of kernel S (the fill stream is what bounds S);
+// used when both output dimensions are large enough to give every CU a tile.
+#define XBM 256
+#define XBN 256
+#define XTILE (XBM * BK * 2)  // 32 KiB per operand tile
+#define XSTAGE (2 * XTILE)
+#define X_LDS_BYTES (8 * 64 * EPI_PITCH * 4)  // 139264 >= 2 stages * 64 KiB
+
+template <int AL, int BL>
+__global__ __launch_bounds__(512) void ca_gemm_kernel_x(const CaGemmDesc d) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;  // 2 x 4 waves, 128 (M) x 64 (N) each
+  int tm, tn;
+  if (!tile_of_block<4, 8>(blockIdx.x, (d.M + XBM - 1) / XBM, (d.N + XBN - 1) / XBN, tm, tn)) return;
+  const int m0 = tm * XBM, n0 = tn * XBN;
+  const int z = blockIdx.z;
+  const int z1 = z / d.batch2, z2 = z % d.batch2;
+  const __bf16* A = (const __bf16*)d.A + z1 * d.sA1 + z2 * d.sA2;
+  const __bf16* B = (const __bf16*)d.B + z1 * d.sB1 + z2 * d.sB2;
+
+  KMajorLoader<4> la_k, lb_k;
+  MNMajorLoader<4, 32> la_m, lb_m;
+  if (AL == CA_KMAJOR)
+    la_k.init(A, d.lda, m0, d.M, wave, lane);
+  else
+    la_m.init(A, d.lda, d.a_kseg, d.a_kseg_stride, m0, d.M, wave, lane);
+  if (BL == CA_KMAJOR)
+    lb_k.init(B, d.ldb, n0, d.N, wave, lane);
+  else
+    lb_m.init(B, d.ldb, d.b_kseg, d.b_kseg_stride, n0, d.N, wave, lane);
+
+  f32x4_t acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  const int K = d.K;
+  const int nk = (K + BK - 1) / BK;
+  auto issue_stage = [&](int kt) {
+    char* st = smem + (kt & 1) * XSTAGE;
+    if (AL == CA_KMAJOR)
+      la_k.issue(st, wave, kt * BK, K);
+    else
+      la_m.issue(st, wave, lane, kt * BK, K);
+    if (BL == CA_KMAJOR)
+      lb_k.issue(st + XTILE, wave, kt * BK, K);
+    else
+      lb_m.issue(st + XTILE, wave, lane, kt * BK, K);
+  };
+
+  issue_stage(0);
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    if (kt + 1 < nk) issue_stage(kt + 1);
+    const char* ta = smem + (kt & 1) * XSTAGE;
+    const char* tb = ta + XTILE;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8_t bfr[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        bfr[j] = (BL == CA_KMAJOR) ? frag_kmajor(tb, wn * 64 + j * 16, s, lane)
+                                   : frag_mnmajor<512>(tb, wn * 64 + j * 16, s, lane);
+#pragma unroll
+      for (int ih = 0; ih < 2; ++ih) {  // two halves of the wave's 8 m-tiles: 16 A registers live at a time
+        bf16x8_t af[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          af[i] = (AL == CA_KMAJOR) ? frag_kmajor(ta, wm * 128 + (ih * 4 + i) * 16, s, lane)
+                                    : frag_mnmajor<512>(ta, wm * 128 + (ih * 4 + i) * 16, s, lane);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[ih * 4 + i][j] =
+                __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[ih * 4 + i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+      }
+    }
   }
-  gemm_epilogue(d, acc, smem, wave, lane, m0 + wm * 64, n0 + wn * 64, z, z1, z2);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  // two 64-row halves through the shared epilogue (each wave re-uses its own staging region)
+#pragma unroll
+  for (int ih = 0; ih < 2; ++ih) {
+    f32x4_t half[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) half[i][j] = acc[ih * 4 + i][j];
+    gemm_epilogue(d, half, smem, wave, lane, m0 + wm * 128 + ih * 64, n0 + wn * 64, z, z1, z2);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // staging reads done before it is overwritten
+  }
 }
 
 // ---- kernel L: 256x128 tile, 8 waves (4x2), 3-stage LDS ring, ONE barrier per K-step --------
@@ -689,6 +790,34 @@ static int ca_gemm_launch(const CaGemmDesc* desc, void* stream) {
   // because its second workgroup hides the epilogue; the L kernel is kept selectable for tuning.
   (void)tiles_l;
   int use_l = g_force_kernel == 2 ? 1 : 0;
+  // Kernel X (256x256): only where it fills the chip -- at least ~0.9 tiles per CU and little tail waste.
+  const int xtm = (d.M + XBM - 1) / XBM, xtn = (d.N + XBN - 1) / XBN;
+  const int64_t xt = (int64_t)xtm * xtn * nb;
+  const double xwaves = (double)xt / 256.0;
+  const double xeff = xwaves / (double)((xt + 255) / 256);                       // last-wave occupancy
+  const double xfill = ((double)d.M * d.N) / ((double)xtm * XBM * (double)xtn * XBN);  // tile padding waste
+  int use_x = (g_force_kernel == 0 && d.K >= 512 && xt >= 224 && xeff * xfill >= 0.80) ? 1 : 0;
+  if (g_force_kernel == 3) use_x = 1;
+  if (use_x) {
+    static bool xattr = false;
+    if (!xattr) {
+      hipFuncSetAttribute((const void*)ca_gemm_kernel_x<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, X_LDS_BYTES);
+      hipFuncSetAttribute((const void*)ca_gemm_kernel_x<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, X_LDS_BYTES);
+      hipFuncSetAttribute((const void*)ca_gemm_kernel_x<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, X_LDS_BYTES);
+      hipFuncSetAttribute((const void*)ca_gemm_kernel_x<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, X_LDS_BYTES);
+      xattr = true;
+    }
+    dim3 grid(tile_grid<4, 8>(xtm, xtn), 1, (unsigned)nb);
+    dim3 block(512);
+    switch (lay) {
+      case 0: hipLaunchKernelGGL((ca_gemm_kernel_x<0, 0>), grid, block, X_LDS_BYTES, s, d); break;
+      case 1: hipLaunchKernelGGL((ca_gemm_kernel_x<0, 1>), grid, block, X_LDS_BYTES, s, d); break;
+      case 2: hipLaunchKernelGGL((ca_gemm_kernel_x<1, 0>), grid, block, X_LDS_BYTES, s, d); break;
+      default: hipLaunchKernelGGL((ca_gemm_kernel_x<1, 1>), grid, block, X_LDS_BYTES, s, d); break;
+    }
+    CA_CHECK_LAUNCH("ca_gemm_bf16");
+    return CA_OK;
+  }
   if (use_l) {
     static bool attr_done = false;
     if (!attr_done) {

@@ -64,6 +64,17 @@ def test_gemm_pipelined_256x128_kernel(ops, al, bl, M, N, K):
         ops.lib().ca_gemm_force_kernel(0)
 
 
+@pytest.mark.parametrize("al,bl", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [(1000, 520, 328), (3992, 768, 704), (300, 264, 64)])
+def test_gemm_256x256_kernel(ops, al, bl, M, N, K):
+    """Parity of the 256x256 kernel (forced), ragged tails in both dimensions."""
+    ops.lib().ca_gemm_force_kernel(3)
+    try:
+        test_gemm_layouts(ops, al, bl, M, N, K)
+    finally:
+        ops.lib().ca_gemm_force_kernel(0)
+
+
 def test_gemm_epilogues_and_batch(ops):
     M, N, K, Bt = 300, 256, 192, 3
     A, W = bf(rnd(Bt, M, K, seed=3, scale=0.5)), bf(rnd(N, K, seed=4, scale=0.2))
