@@ -699,7 +699,7 @@ __global__ __launch_bounds__(512) void ca_gemm_kernel_l(const CaGemmDesc d) {
 // ---- optional per-launch timing (bench.py's live roofline measurement) -----------------------
 // When enabled, every ca_gemm_bf16 launch is bracketed by two hipEvents on the launch stream and
 // its algorithmic FLOPs (2*M*N*K*batch) are recorded per template variant (index a_layout*2 +
-// b_layout).  ca_prof_end synchronises the events and returns the totals.
+// b_layout) and kernel (S, L, X).  ca_prof_end synchronises the events and returns the totals.
 #include <vector>
 struct ProfRec {
   hipEvent_t e0, e1;
@@ -716,7 +716,7 @@ extern "C" int ca_prof_begin(void) {
 }
 extern "C" int ca_prof_end(double* ms, int64_t* count, double* flops) {
   g_prof_on = false;
-  for (int v = 0; v < 4; ++v) {
+  for (int v = 0; v < 12; ++v) {
     ms[v] = 0.0;
     count[v] = 0;
     flops[v] = 0.0;
@@ -743,17 +743,18 @@ extern "C" int ca_gemm_force_kernel(int which) {
   return CA_OK;
 }
 static int ca_gemm_launch(const CaGemmDesc* desc, void* stream);
+static int g_last_kind = 0;  // kernel chosen by the last launch: 0 = S, 1 = L, 2 = X
 
 extern "C" int ca_gemm_bf16(const CaGemmDesc* desc, void* stream) {
   if (!g_prof_on || desc == nullptr) return ca_gemm_launch(desc, stream);
   ProfRec r;
   hipEventCreate(&r.e0);
   hipEventCreate(&r.e1);
-  r.variant = (desc->a_layout ? 2 : 0) + (desc->b_layout ? 1 : 0);
   r.flops = 2.0 * desc->M * (double)desc->N * desc->K * desc->batch1 * desc->batch2;
   hipEventRecord(r.e0, (hipStream_t)stream);
   const int rc = ca_gemm_launch(desc, stream);
   hipEventRecord(r.e1, (hipStream_t)stream);
+  r.variant = g_last_kind * 4 + (desc->a_layout ? 2 : 0) + (desc->b_layout ? 1 : 0);
   g_prof.push_back(r);
   return rc;
 }
@@ -798,6 +799,7 @@ static int ca_gemm_launch(const CaGemmDesc* desc, void* stream) {
   const double xfill = ((double)d.M * d.N) / ((double)xtm * XBM * (double)xtn * XBN);  // tile padding waste
   int use_x = (g_force_kernel == 0 && d.K >= 512 && xt >= 224 && xeff * xfill >= 0.80) ? 1 : 0;
   if (g_force_kernel == 3) use_x = 1;
+  g_last_kind = use_x ? 2 : (use_l ? 1 : 0);
   if (use_x) {
     static bool xattr = false;
     if (!xattr) {

@@ -244,12 +244,16 @@ def prof_begin():
 
 
 def prof_end():
-    """-> list of 4 dicts (variant NT, NN, TN, TT): ms, count, flops of the GEMM launches."""
-    ms, cnt, fl = (C.c_double * 4)(), (C.c_int64 * 4)(), (C.c_double * 4)()
+    """-> list of 12 dicts (kernel S/L/X x layout NT, NN, TN, TT): ms, count, flops of the GEMM launches.
+    `kernel` is the symbol rocprofv3 reports for the same launches."""
+    ms, cnt, fl = (C.c_double * 12)(), (C.c_int64 * 12)(), (C.c_double * 12)()
     check(lib().ca_prof_end(ms, cnt, fl), "ca_prof_end")
-    names = ["ca_gemm_kernel<KMAJOR,KMAJOR>", "ca_gemm_kernel<KMAJOR,MNMAJOR>",
-             "ca_gemm_kernel<MNMAJOR,KMAJOR>", "ca_gemm_kernel<MNMAJOR,MNMAJOR>"]
-    return [dict(kernel=names[i], ms=ms[i], count=cnt[i], flops=fl[i]) for i in range(4)]
+    out = []
+    for k, sym in enumerate(("ca_gemm_kernel", "ca_gemm_kernel_l", "ca_gemm_kernel_x")):
+        for v in range(4):
+            i = k * 4 + v
+            out.append(dict(kernel=f"void {sym}<{v >> 1}, {v & 1}>(CaGemmDesc)", ms=ms[i], count=cnt[i], flops=fl[i]))
+    return out
 
 
 def _attn_desc(Q, K, V, O, lse, *, B, H, Tq, Tk, hd, Tqp, scale, ldq, ldk, ldv, ldo, sqb, skb, svb, sob,
