@@ -132,7 +132,8 @@ def main():
     ap.add_argument("--seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-specaugment", action="store_true")
-    ap.add_argument("--graph", action="store_true", help="replay fwd+bwd from a captured HIP graph")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for 1-GPU debugging of the N>1 logic)")
+    ap.add_argument("--check-replicas", action="store_true", help="after the run, verify every rank holds identical parameters")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -140,11 +141,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    ndev = torch.cuda.device_count()
+    local_rank = local_rank % max(1, ndev)  # (gloo debugging may put several ranks on one GPU)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.distributed.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=device)
+        else:
+            torch.distributed.init_process_group(args.backend)
 
     from coral_amd import ops, specaugment
     from coral_amd.trainer import DataParallelTrainer
@@ -241,6 +247,16 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.model)
         print(json.dumps(out), flush=True)
     if world > 1:
+        if args.check_replicas:
+            # DDP invariant: identical parameters on every rank after identical (averaged) updates
+            p = eng.store.p32
+            lo, hi = p.clone(), p.clone()
+            torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
+            torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
+            spread = float((hi - lo).abs().max())
+            if rank == 0:
+                print(json.dumps({"replica_param_spread": spread, "loss_rank0": loss_val}), flush=True)
+            assert spread == 0.0, f"replicas diverged: {spread}"
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

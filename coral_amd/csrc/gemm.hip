@@ -51,11 +51,12 @@ struct KMajorLoader {  // operand stored [row][k], k contiguous; LDS image [rows
   }
   __device__ __forceinline__ void issue(char* tile, int wave, int k0, int K) {
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const void* src = (k0 + kc[i] < K) ? (const void*)p[i] : (const void*)g_ca_zero_page;
-      glds16(src, tile + (wave * NI + i) * 1024);
-      p[i] += BK * 2;
-    }
+    for (int i = 0; i < NI; ++i) issue_one(tile, wave, k0, K, i);
+  }
+  __device__ __forceinline__ void issue_one(char* tile, int wave, int k0, int K, int i) {
+    const void* src = (k0 + kc[i] < K) ? (const void*)p[i] : (const void*)g_ca_zero_page;
+    glds16(src, tile + (wave * NI + i) * 1024);
+    p[i] += BK * 2;
   }
 };
 
@@ -94,17 +95,18 @@ struct MNMajorLoader {
   }
   __device__ __forceinline__ void issue(char* tile, int wave, int lane, int k0, int K) {
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const int kr = (wave * NI + i) * RPI + lane / PC;
-      const void* src = (k0 + kr < K) ? (const void*)p[i] : (const void*)g_ca_zero_page;
-      glds16(src, tile + (wave * NI + i) * 1024);
-      p[i] += step;
-      if (kseg > 0) {
-        t[i] += BK;
-        while (t[i] >= kseg) {
-          t[i] -= kseg;
-          p[i] += hop;
-        }
+    for (int i = 0; i < NI; ++i) issue_one(tile, wave, lane, k0, K, i);
+  }
+  __device__ __forceinline__ void issue_one(char* tile, int wave, int lane, int k0, int K, int i) {
+    const int kr = (wave * NI + i) * RPI + lane / PC;
+    const void* src = (k0 + kr < K) ? (const void*)p[i] : (const void*)g_ca_zero_page;
+    glds16(src, tile + (wave * NI + i) * 1024);
+    p[i] += step;
+    if (kseg > 0) {
+      t[i] += BK;
+      while (t[i] >= kseg) {
+        t[i] -= kseg;
+        p[i] += hop;
       }
     }
   }
@@ -366,7 +368,7 @@ __global__ __launch_bounds__(256) void ca_gemm_kernel(const CaGemmDesc d) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // tile kt landed; my reads of kt-1 done
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (kt + 1 < nk) issue_stage(kt + 1);
+    if (kt + 1 < nk) issue_stage(kt + 1);  // (splitting this burst across the MFMA blocks was measured slower here)
 
     const char* ta = smem + (kt & 1) * STAGE_BYTES;
     const char* tb = ta + TILE_BYTES;
@@ -454,7 +456,20 @@ __global__ __launch_bounds__(512) void ca_gemm_kernel_x(const CaGemmDesc d) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (kt + 1 < nk) issue_stage(kt + 1);
+    const bool more = kt + 1 < nk;
+    char* nst = smem + ((kt + 1) & 1) * XSTAGE;
+    // the next tile's 8 LDS-DMA are issued two at a time in front of the four MFMA blocks
+    auto issue_part = [&](int part) {
+      if (!more) return;
+      if (AL == CA_KMAJOR)
+        la_k.issue_one(nst, wave, (kt + 1) * BK, K, part);
+      else
+        la_m.issue_one(nst, wave, lane, (kt + 1) * BK, K, part);
+      if (BL == CA_KMAJOR)
+        lb_k.issue_one(nst + XTILE, wave, (kt + 1) * BK, K, part);
+      else
+        lb_m.issue_one(nst + XTILE, wave, lane, (kt + 1) * BK, K, part);
+    };
     const char* ta = smem + (kt & 1) * XSTAGE;
     const char* tb = ta + XTILE;
 #pragma unroll
@@ -466,6 +481,7 @@ __global__ __launch_bounds__(512) void ca_gemm_kernel_x(const CaGemmDesc d) {
                                    : frag_mnmajor<512>(tb, wn * 64 + j * 16, s, lane);
 #pragma unroll
       for (int ih = 0; ih < 2; ++ih) {  // two halves of the wave's 8 m-tiles: 16 A registers live at a time
+        issue_part(s * 2 + ih);
         bf16x8_t af[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
