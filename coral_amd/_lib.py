@@ -146,6 +146,7 @@ SIGNATURES = {
     ),
     "ca_argmax_masked": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i64, _vp]),
     "ca_embed_tokens": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
+    "ca_embed_tokens_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
 }
 
 _lib = None

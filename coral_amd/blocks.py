@@ -1,0 +1,184 @@
+"""Pre-LN transformer sub-blocks (forward with saved activations + hand-written backward) as sequences
+of libcoral_amd kernels.  Used by the Whisper training path; the three block kinds are exactly the
+ones of `WhisperEncoderLayer` / `WhisperDecoderLayer` ($TF/models/whisper/modeling_whisper.py:379-413,
+448-505): residual self-attention, residual cross-attention, residual GELU feed-forward.
+
+Every block works on flat row-major bf16 activations [B*T, d] and a `ParamStore` (fp32 masters `p32`,
+bf16 compute copies `p16`, fp32 gradients `g32`); weight gradients are accumulated in fp32.
+"""
+
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from .ops import EPI_DGELU, EPI_GELU, EPI_RESIDUAL, MNMAJOR
+
+
+def _z(n, dev, dt=torch.bfloat16):
+    return torch.zeros(n, dtype=dt, device=dev)
+
+
+class Scratch:
+    """Shared backward scratch for one (rows, d, f) problem size."""
+
+    def __init__(self, M, d, f, dev, Mkv=0):
+        self.dx = _z(M * d, dev)
+        self.dctx = _z(M * d, dev)
+        self.dqkv = _z(M * 3 * d, dev)
+        self.du = _z(M * f, dev)
+        self.dkv = _z(Mkv * 2 * d, dev) if Mkv else None
+        npart = max(ops.layernorm_bwd_partial_floats(M, d), ops.colsum_partial_floats(max(M, Mkv), max(f, 3 * d)), 4096)
+        self.part = _z(npart, dev, torch.float32)
+
+
+class SelfAttnBlock:
+    """h_out = h_in + out_proj(attn(q, k, v)),  q|k|v = LN(h_in) Wqkv^T + bqkv."""
+
+    def __init__(self, store, ln: str, attn: str, H: int, d: int, eps: float, causal: bool, qbias: str):
+        self.st, self.ln, self.attn, self.H, self.d, self.eps, self.causal = store, ln, attn, H, d, eps, causal
+        self.qbias = qbias  # name of the first of the three adjacent bias vectors (q, k, v)
+
+    def alloc(self, B, T, dev):
+        d, H = self.d, self.H
+        Tqp = (T + 31) // 32 * 32
+        return dict(x=_z(B * T * d, dev), st=_z(B * T * 2, dev, torch.float32), qkv=_z(B * T * 3 * d, dev),
+                    ctx=_z(B * T * d, dev), lse=_z(B * H * Tqp, dev, torch.float32), Dq=_z(B * H * Tqp, dev, torch.float32),
+                    Tqp=Tqp)
+
+    def _akw(self, B, T, sv, klen):
+        d, H = self.d, self.H
+        hd = d // H
+        return dict(B=B, H=H, Tq=T, Tk=T, hd=hd, Tqp=sv["Tqp"], scale=hd ** -0.5, ldq=3 * d, ldk=3 * d, ldv=3 * d, ldo=d,
+                    sqb=T * 3 * d, skb=T * 3 * d, svb=T * 3 * d, sob=T * d, q_off=0, k_off=d, v_off=2 * d, klen=klen,
+                    causal=self.causal)
+
+    def forward(self, hin, hout, sv, B, T, klen=None):
+        st, d = self.st, self.d
+        M = B * T
+        ops.layernorm_fwd(hin, st.view(self.ln + ".weight"), st.view(self.ln + ".bias"), sv["x"], sv["st"], M, d, self.eps)
+        ops.gemm(sv["x"], st.p16, sv["qkv"], M=M, N=3 * d, K=d, lda=d, ldb=d, ldc=3 * d, b_off=st.off(self.attn + "q_proj.weight"),
+                 bias=st.p32, bias_off=st.off(self.qbias))
+        ops.attn_fwd(sv["qkv"], sv["qkv"], sv["qkv"], sv["ctx"], sv["lse"], **self._akw(B, T, sv, klen))
+        ops.gemm(sv["ctx"], st.p16, hout, M=M, N=d, K=d, lda=d, ldb=d, ldc=d, b_off=st.off(self.attn + "out_proj.weight"),
+                 bias=st.p32, bias_off=st.off(self.attn + "out_proj.bias"), epilogue=EPI_RESIDUAL, R=hin, ldr=d)
+        sv["hin"], sv["klen"] = hin, klen
+
+    def backward(self, dh, dhin, sv, sc: Scratch, B, T):
+        """dh: grad wrt h_out (kept intact); dhin: output buffer for grad wrt h_in (may alias nothing of sv)."""
+        st, d = self.st, self.d
+        M = B * T
+        o, g32, p16 = st.off, st.g32, st.p16
+        ops.colsum(dh, d, M, d, g32, sc.part, out_off=o(self.attn + "out_proj.bias"))
+        ops.gemm(dh, sv["ctx"], g32, M=d, N=d, K=M, a_layout=MNMAJOR, lda=d, b_layout=MNMAJOR, ldb=d, ldc=d,
+                 c_off=o(self.attn + "out_proj.weight"), out_f32=True, accumulate=True)
+        ops.gemm(dh, p16, sc.dctx, M=M, N=d, K=d, lda=d, b_layout=MNMAJOR, ldb=d, ldc=d, b_off=o(self.attn + "out_proj.weight"))
+        qkv, dqkv = sv["qkv"], sc.dqkv
+        ops.attn_bwd(qkv, qkv, qkv, sv["ctx"], sv["lse"], sc.dctx, sv["Dq"], dqkv, dqkv, dqkv, lddo=d, sdob=T * d, lddq=3 * d,
+                     lddk=3 * d, lddv=3 * d, sdqb=T * 3 * d, sdkb=T * 3 * d, sdvb=T * 3 * d, dq_off=0, dk_off=d, dv_off=2 * d,
+                     **self._akw(B, T, sv, sv["klen"]))
+        ops.colsum(dqkv, 3 * d, M, 3 * d, g32, sc.part, out_off=o(self.qbias))
+        ops.gemm(dqkv, sv["x"], g32, M=3 * d, N=d, K=M, a_layout=MNMAJOR, lda=3 * d, b_layout=MNMAJOR, ldb=d, ldc=d,
+                 c_off=o(self.attn + "q_proj.weight"), out_f32=True, accumulate=True)
+        ops.gemm(dqkv, p16, sc.dx, M=M, N=d, K=3 * d, lda=3 * d, b_layout=MNMAJOR, ldb=d, ldc=d, b_off=o(self.attn + "q_proj.weight"))
+        ops.layernorm_bwd(sc.dx, sv["hin"], st.view(self.ln + ".weight"), None, sv["st"], dh, dhin,
+                          st.view(self.ln + ".weight", "g32"), st.view(self.ln + ".bias", "g32"), sc.part, M, d)
+
+
+class CrossAttnBlock:
+    """h_out = h_in + out_proj(attn(q, K, V)) with q from LN(h_in) and K|V = enc Wkv^T + [0|bv] [B*Te, 2d]."""
+
+    def __init__(self, store, ln: str, attn: str, H: int, d: int, eps: float):
+        self.st, self.ln, self.attn, self.H, self.d, self.eps = store, ln, attn, H, d, eps
+
+    def alloc(self, B, L, Te, dev):
+        d, H = self.d, self.H
+        Lqp = (L + 31) // 32 * 32
+        return dict(x=_z(B * L * d, dev), st=_z(B * L * 2, dev, torch.float32), q=_z(B * L * d, dev), ctx=_z(B * L * d, dev),
+                    kv=_z(B * Te * 2 * d, dev), lse=_z(B * H * Lqp, dev, torch.float32), Dq=_z(B * H * Lqp, dev, torch.float32),
+                    Tqp=Lqp)
+
+    def _akw(self, B, L, Te, sv):
+        d, H = self.d, self.H
+        hd = d // H
+        return dict(B=B, H=H, Tq=L, Tk=Te, hd=hd, Tqp=sv["Tqp"], scale=hd ** -0.5, ldq=d, ldk=2 * d, ldv=2 * d, ldo=d,
+                    sqb=L * d, skb=Te * 2 * d, svb=Te * 2 * d, sob=L * d, k_off=0, v_off=d)
+
+    def project_kv(self, enc, sv, B, Te):
+        st, d = self.st, self.d
+        ops.gemm(enc, st.p16, sv["kv"], M=B * Te, N=2 * d, K=d, lda=d, ldb=d, ldc=2 * d, b_off=st.off(self.attn + "k_proj.weight"),
+                 bias=st.p32, bias_off=st.off(self.attn + "k_proj.bias__zero"))
+        sv["enc"] = enc
+
+    def forward(self, hin, hout, sv, B, L, Te):
+        st, d = self.st, self.d
+        M = B * L
+        ops.layernorm_fwd(hin, st.view(self.ln + ".weight"), st.view(self.ln + ".bias"), sv["x"], sv["st"], M, d, self.eps)
+        ops.gemm(sv["x"], st.p16, sv["q"], M=M, N=d, K=d, lda=d, ldb=d, ldc=d, b_off=st.off(self.attn + "q_proj.weight"),
+                 bias=st.p32, bias_off=st.off(self.attn + "q_proj.bias"))
+        ops.attn_fwd(sv["q"], sv["kv"], sv["kv"], sv["ctx"], sv["lse"], **self._akw(B, L, Te, sv))
+        ops.gemm(sv["ctx"], st.p16, hout, M=M, N=d, K=d, lda=d, ldb=d, ldc=d, b_off=st.off(self.attn + "out_proj.weight"),
+                 bias=st.p32, bias_off=st.off(self.attn + "out_proj.bias"), epilogue=EPI_RESIDUAL, R=hin, ldr=d)
+        sv["hin"] = hin
+
+    def backward(self, dh, dhin, sv, sc: Scratch, denc32, B, L, Te):
+        """denc32: fp32 [B*Te, d] accumulator of the gradient wrt the encoder states (+=)."""
+        st, d = self.st, self.d
+        M, Mk = B * L, B * Te
+        o, g32, p16 = st.off, st.g32, st.p16
+        ops.colsum(dh, d, M, d, g32, sc.part, out_off=o(self.attn + "out_proj.bias"))
+        ops.gemm(dh, sv["ctx"], g32, M=d, N=d, K=M, a_layout=MNMAJOR, lda=d, b_layout=MNMAJOR, ldb=d, ldc=d,
+                 c_off=o(self.attn + "out_proj.weight"), out_f32=True, accumulate=True)
+        ops.gemm(dh, p16, sc.dctx, M=M, N=d, K=d, lda=d, b_layout=MNMAJOR, ldb=d, ldc=d, b_off=o(self.attn + "out_proj.weight"))
+        dq, dkv = sc.dx, sc.dkv
+        ops.attn_bwd(sv["q"], sv["kv"], sv["kv"], sv["ctx"], sv["lse"], sc.dctx, sv["Dq"], dq, dkv, dkv, lddo=d, sdob=L * d,
+                     lddq=d, lddk=2 * d, lddv=2 * d, sdqb=L * d, sdkb=Te * 2 * d, sdvb=Te * 2 * d, dk_off=0, dv_off=d,
+                     **self._akw(B, L, Te, sv))
+        # q projection
+        ops.colsum(dq, d, M, d, g32, sc.part, out_off=o(self.attn + "q_proj.bias"))
+        ops.gemm(dq, sv["x"], g32, M=d, N=d, K=M, a_layout=MNMAJOR, lda=d, b_layout=MNMAJOR, ldb=d, ldc=d,
+                 c_off=o(self.attn + "q_proj.weight"), out_f32=True, accumulate=True)
+        ops.gemm(dq, p16, sc.dctx, M=M, N=d, K=d, lda=d, b_layout=MNMAJOR, ldb=d, ldc=d, b_off=o(self.attn + "q_proj.weight"))
+        ops.layernorm_bwd(sc.dctx, sv["hin"], st.view(self.ln + ".weight"), None, sv["st"], dh, dhin,
+                          st.view(self.ln + ".weight", "g32"), st.view(self.ln + ".bias", "g32"), sc.part, M, d)
+        # k|v projection of the encoder states
+        ops.colsum(dkv, 2 * d, Mk, 2 * d, g32, sc.part, out_off=o(self.attn + "k_proj.bias__zero"))
+        ops.gemm(dkv, sv["enc"], g32, M=2 * d, N=d, K=Mk, a_layout=MNMAJOR, lda=2 * d, b_layout=MNMAJOR, ldb=d, ldc=d,
+                 c_off=o(self.attn + "k_proj.weight"), out_f32=True, accumulate=True)
+        ops.gemm(dkv, p16, denc32, M=Mk, N=d, K=2 * d, lda=2 * d, b_layout=MNMAJOR, ldb=d, ldc=d,
+                 b_off=o(self.attn + "k_proj.weight"), out_f32=True, accumulate=True)
+
+
+class FFNBlock:
+    """h_out = h_in + fc2(dropout(gelu(fc1(LN(h_in)))))."""
+
+    def __init__(self, store, ln: str, fc1: str, fc2: str, d: int, f: int, eps: float):
+        self.st, self.ln, self.fc1, self.fc2, self.d, self.f, self.eps = store, ln, fc1, fc2, d, f, eps
+
+    def alloc(self, M, dev):
+        return dict(x=_z(M * self.d, dev), st=_z(M * 2, dev, torch.float32), u=_z(M * self.f, dev), g=_z(M * self.f, dev))
+
+    def forward(self, hin, hout, sv, M, dropout_p=0.0, seed=0):
+        st, d, f = self.st, self.d, self.f
+        ops.layernorm_fwd(hin, st.view(self.ln + ".weight"), st.view(self.ln + ".bias"), sv["x"], sv["st"], M, d, self.eps)
+        ops.gemm(sv["x"], st.p16, sv["u"], C2=sv["g"], M=M, N=f, K=d, lda=d, ldb=d, ldc=f, b_off=st.off(self.fc1 + ".weight"),
+                 bias=st.p32, bias_off=st.off(self.fc1 + ".bias"), epilogue=EPI_GELU, dropout_p=dropout_p, dropout_seed=seed)
+        ops.gemm(sv["g"], st.p16, hout, M=M, N=d, K=f, lda=f, ldb=f, ldc=d, b_off=st.off(self.fc2 + ".weight"), bias=st.p32,
+                 bias_off=st.off(self.fc2 + ".bias"), epilogue=EPI_RESIDUAL, R=hin, ldr=d)
+        sv["hin"], sv["drop"] = hin, (dropout_p, seed)
+
+    def backward(self, dh, dhin, sv, sc: Scratch, M):
+        st, d, f = self.st, self.d, self.f
+        o, g32, p16 = st.off, st.g32, st.p16
+        p, seed = sv["drop"]
+        ops.colsum(dh, d, M, d, g32, sc.part, out_off=o(self.fc2 + ".bias"))
+        ops.gemm(dh, sv["g"], g32, M=d, N=f, K=M, a_layout=MNMAJOR, lda=d, b_layout=MNMAJOR, ldb=f, ldc=f,
+                 c_off=o(self.fc2 + ".weight"), out_f32=True, accumulate=True)
+        ops.gemm(dh, p16, sc.du, M=M, N=f, K=d, lda=d, b_layout=MNMAJOR, ldb=f, ldc=f, b_off=o(self.fc2 + ".weight"),
+                 epilogue=EPI_DGELU, R=sv["u"], ldr=f, dropout_p=p, dropout_seed=seed)
+        ops.colsum(sc.du, f, M, f, g32, sc.part, out_off=o(self.fc1 + ".bias"))
+        ops.gemm(sc.du, sv["x"], g32, M=f, N=d, K=M, a_layout=MNMAJOR, lda=f, b_layout=MNMAJOR, ldb=d, ldc=d,
+                 c_off=o(self.fc1 + ".weight"), out_f32=True, accumulate=True)
+        ops.gemm(sc.du, p16, sc.dx, M=M, N=d, K=f, lda=f, b_layout=MNMAJOR, ldb=d, ldc=d, b_off=o(self.fc1 + ".weight"))
+        ops.layernorm_bwd(sc.dx, sv["hin"], st.view(self.ln + ".weight"), None, sv["st"], dh, dhin,
+                          st.view(self.ln + ".weight", "g32"), st.view(self.ln + ".bias", "g32"), sc.part, M, d)

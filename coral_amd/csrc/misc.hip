@@ -474,3 +474,36 @@ extern "C" int ca_embed_tokens(const void* table, const void* pos, const int32_t
   CA_CHECK_LAUNCH("ca_embed_tokens");
   return CA_OK;
 }
+
+// backward of the embedding gather: dtable[ids[r], :] += dy[r, :], dpos[pos_ids[r], :] += dy[r, :]
+// (fp32 atomics: a handful of rows hit the same token; $TF/models/whisper/modeling_whisper.py:676 backward)
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const unsigned short* __restrict__ dy,
+                                                        const int32_t* __restrict__ ids,
+                                                        const int32_t* __restrict__ pos_ids,
+                                                        float* __restrict__ dtable, float* __restrict__ dpos,
+                                                        int64_t rows, int C) {
+  const int cch = C >> 3;
+  const int64_t total = rows * cch;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c8 = (int)(i % cch);
+    const int64_t r = i / cch;
+    const u16x8_t u = *(const u16x8_t*)(dy + r * C + c8 * 8);
+    float* t = dtable ? dtable + (int64_t)ids[r] * C + c8 * 8 : nullptr;
+    float* p = dpos ? dpos + (int64_t)pos_ids[r] * C + c8 * 8 : nullptr;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float v = bf2f(u[e]);
+      if (t) atomicAdd(t + e, v);
+      if (p) atomicAdd(p + e, v);
+    }
+  }
+}
+extern "C" int ca_embed_tokens_bwd(const void* dy, const int32_t* ids, const int32_t* pos_ids, float* dtable,
+                                   float* dpos, int64_t rows, int32_t C, void* stream) {
+  CA_CHECK_ARG(dy && ids && rows > 0 && C > 0 && (C % 8) == 0, "ca_embed_tokens_bwd: bad argument");
+  CA_CHECK_ARG(!dpos || pos_ids, "ca_embed_tokens_bwd: dpos needs pos_ids");
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3(ew_grid(rows * (C / 8), 1)), dim3(256), 0, (hipStream_t)stream,
+                     (const unsigned short*)dy, ids, pos_ids, dtable, dpos, rows, C);
+  CA_CHECK_LAUNCH("ca_embed_tokens_bwd");
+  return CA_OK;
+}

@@ -239,6 +239,11 @@ def embed_tokens(table, pos, ids, pos_ids, y, rows, Cn):
                                 _stream()), "ca_embed_tokens")
 
 
+def embed_tokens_bwd(dy, ids, pos_ids, dtable, dpos, rows, Cn, dtable_off=0, dpos_off=0):
+    check(lib().ca_embed_tokens_bwd(_p(dy), _p(ids), _p(pos_ids), _p(dtable, dtable_off), _p(dpos, dpos_off), rows, Cn,
+                                    _stream()), "ca_embed_tokens_bwd")
+
+
 def prof_begin():
     check(lib().ca_prof_begin(), "ca_prof_begin")
 

@@ -1,0 +1,271 @@
+"""Whisper finetuning step on the MI355X engine: forward with saved activations and the hand-written
+backward of `WhisperForConditionalGeneration.forward(input_features, labels)`
+($TF/models/whisper/modeling_whisper.py:994-1099: shift_tokens_right -> encoder -> decoder -> tied
+proj_out -> CrossEntropyLoss(ignore_index=-100)), as driven by `Seq2SeqTrainer` in
+R/src/coral/whisper.py:124-232.
+
+Gradient flow: CE -> tied LM head (gradient joins the token-embedding gradient) -> decoder layers
+(FFN, cross-attention, causal self-attention; the cross-attention K|V projections accumulate the
+gradient wrt the encoder states in fp32) -> embeddings (atomic scatter-add) ; encoder states ->
+encoder layers -> conv2 (+GELU, stride 2) -> conv1 (+GELU).  The sinusoidal encoder positions are
+constants (requires_grad False in the reference, :570).  SpecAugment on the input features
+(:821-862) takes host-drawn masks like the wav2vec2 path.
+"""
+
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from .blocks import CrossAttnBlock, FFNBlock, Scratch, SelfAttnBlock, _z
+from .ops import EPI_GELU, EPI_GELU_RESIDUAL, MNMAJOR
+from .wav2vec2 import _r8
+from .whisper import WhisperEngine, WhisperShape
+
+
+class WhisperTrainEngine(WhisperEngine):
+    """Adds forward_train()/backward() to the inference engine; gradients land in `store.g32`."""
+
+    def __init__(self, shape: WhisperShape, device="cuda:0", activation_dropout: float = 0.0):
+        super().__init__(shape, device)
+        s, st = shape, self.store
+        d, eps = s.d_model, s.layer_norm_eps
+        self.activation_dropout = activation_dropout
+        self.training = True
+        self.step_seed = 0
+        self.enc_blocks, self.dec_blocks = [], []
+        for l in range(s.encoder_layers):
+            p = f"model.encoder.layers.{l}."
+            self.enc_blocks.append((
+                SelfAttnBlock(st, p + "self_attn_layer_norm", p + "self_attn.", s.encoder_attention_heads, d, eps, False,
+                              p + "self_attn.q_proj.bias"),
+                FFNBlock(st, p + "final_layer_norm", p + "fc1", p + "fc2", d, s.encoder_ffn_dim, eps)))
+        for l in range(s.decoder_layers):
+            p = f"model.decoder.layers.{l}."
+            self.dec_blocks.append((
+                SelfAttnBlock(st, p + "self_attn_layer_norm", p + "self_attn.", s.decoder_attention_heads, d, eps, True,
+                              p + "self_attn.q_proj.bias"),
+                CrossAttnBlock(st, p + "encoder_attn_layer_norm", p + "encoder_attn.", s.decoder_attention_heads, d, eps),
+                FFNBlock(st, p + "final_layer_norm", p + "fc1", p + "fc2", d, s.decoder_ffn_dim, eps)))
+        self._tw = None
+        self._tw_key = None
+        self.zero_mel = torch.zeros(s.num_mel_bins, dtype=torch.bfloat16, device=self.device)
+
+    freeze_base = False
+
+    def zero_grad(self, matrices: bool = True):
+        self.store.g32.zero_()
+
+    def train(self, mode: bool = True):
+        self.training = mode
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    def refresh_derived(self):
+        """conv stem weights are consumed in the reordered [Co][k][Ci] layout."""
+        s, st = self.s, self.store
+        ops.conv_weight_reorder(st.p32, self.conv1_wr, s.d_model, s.num_mel_bins, 3, w_off=st.off("model.encoder.conv1.weight"))
+        ops.conv_weight_reorder(st.p32, self.conv2_wr, s.d_model, s.d_model, 3, w_off=st.off("model.encoder.conv2.weight"))
+
+    def __call__(self, input_features, labels, mask_time=None, mask_feature=None):
+        """Trainer-facing call: returns an object with `.loss` (device scalar) and `.logits`."""
+        from .wav2vec2 import CTCOutput
+
+        out = self.forward_train(input_features, labels, mask_time, mask_feature)
+        return CTCOutput(loss=out["loss"], logits=out["logits"])
+
+    def clear_internal_grads(self):
+        """The `k_proj.bias__zero` slots exist only so q|k|v biases form one vector: keep them (and their
+        gradients) at zero so the optimiser never moves them."""
+        for n in self.store.names():
+            if n.endswith("__zero"):
+                self.store.view(n, "g32").zero_()
+
+    # ---- workspace ---------------------------------------------------------------------------
+    def _train_ws(self, B, L):
+        key = (B, L)
+        if self._tw_key == key:
+            return self._tw
+        s, dev = self.s, self.device
+        d, T = s.d_model, s.max_source_positions
+        Tin = 2 * T
+        Me, Md = B * T, B * L
+        f32 = torch.float32
+        w = dict(
+            xin=_z(B * (Tin + 2) * s.num_mel_bins + 64, dev), pre1=_z(B * (Tin + 2) * d + 64, dev),
+            c1=_z(B * (Tin + 2) * d + 64, dev), pre2=_z(Me * d, dev),
+            eh=[_z(Me * d, dev) for _ in range(2 * s.encoder_layers + 1)], enc_out=_z(Me * d, dev),
+            enc_st=_z(Me * 2, dev, f32),
+            enc_sv=[(sa.alloc(B, T, dev), ff.alloc(Me, dev)) for sa, ff in self.enc_blocks],
+            dh=[_z(Md * d, dev) for _ in range(3 * s.decoder_layers + 1)], dec_out=_z(Md * d, dev),
+            dec_st=_z(Md * 2, dev, f32),
+            dec_sv=[(sa.alloc(B, L, dev), ca.alloc(B, L, T, dev), ff.alloc(Md, dev)) for sa, ca, ff in self.dec_blocks],
+            logits=_z(Md * _r8(s.vocab_size), dev, f32), dlogits=_z(Md * _r8(s.vocab_size), dev, f32),
+            dlogits16=_z(Md * _r8(s.vocab_size), dev),
+            loss_sum=_z(1, dev, f32), count=torch.zeros(1, dtype=torch.int32, device=dev),
+            sc_e=Scratch(Me, d, s.encoder_ffn_dim, dev), sc_d=Scratch(Md, d, s.decoder_ffn_dim, dev, Mkv=Me),
+            g_e=[_z(Me * d, dev), _z(Me * d, dev)], g_d=[_z(Md * d, dev), _z(Md * d, dev)],
+            denc32=_z(Me * d, dev, f32), dpre=_z(B * (Tin + 2) * d + 64, dev),
+            dcol=_z(Me * 3 * d, dev), dwr_part=_z(B * d * 3 * max(d, s.num_mel_bins), dev, f32),
+            dwr=_z(d * 3 * max(d, s.num_mel_bins), dev, f32))
+        self._tw, self._tw_key = w, key
+        return w
+
+    # ---- forward -----------------------------------------------------------------------------
+    def forward_train(self, input_features, labels, mask_time=None, mask_feature=None):
+        """-> dict(loss, logits).  labels i64 [B, L] with -100 padding."""
+        s, st = self.s, self.store
+        p32, p16, o = st.p32, st.p16, st.off
+        dev = self.device
+        x = input_features.to(dev, torch.float32).contiguous()
+        B, mels, Tin = x.shape
+        T, d = s.max_source_positions, s.d_model
+        if mels != s.num_mel_bins or Tin != 2 * T:
+            raise ValueError(f"Whisper expects mel input features of shape [B, {s.num_mel_bins}, {2 * T}]")
+        lab = labels.to(torch.int64)
+        L = lab.shape[1]
+        if L > s.max_target_positions:
+            raise ValueError(f"Labels' sequence length {L} cannot exceed the maximum allowed length of {s.max_target_positions} tokens.")
+        dec_in = lab.new_zeros(lab.shape)
+        dec_in[:, 1:] = lab[:, :-1]
+        dec_in[:, 0] = s.decoder_start_token_id
+        dec_in = dec_in.masked_fill(dec_in == -100, s.pad_token_id)
+        w = self._train_ws(B, L)
+        Me, Md = B * T, B * L
+        drop = self.activation_dropout if self.training else 0.0
+        # encoder stem
+        for b in range(B):
+            ops.transpose_f32_bf16(x[b], w["xin"][(b * (Tin + 2) + 1) * mels:], mels, Tin)
+            if mask_time is not None or mask_feature is not None:  # SpecAugment on the input features
+                tm = mask_time[b:b + 1].to(dev, torch.uint8).contiguous() if mask_time is not None else None
+                fm = mask_feature[b:b + 1].to(dev, torch.uint8).contiguous() if mask_feature is not None else None
+                ops.mask_frames(w["xin"][(b * (Tin + 2) + 1) * mels:], tm, fm, self.zero_mel, None, 1, Tin, mels)
+        ops.gemm(w["xin"], self.conv1_wr, w["pre1"], C2=w["c1"], c_off=d, c2_off=d, M=Tin, N=d, K=3 * mels, lda=mels,
+                 ldb=3 * mels, ldc=d, bias=p32, bias_off=o("model.encoder.conv1.bias"), epilogue=EPI_GELU, batch2=B,
+                 sA=(0, (Tin + 2) * mels), sC=(0, (Tin + 2) * d))
+        ops.gemm(w["c1"], self.conv2_wr, w["pre2"], C2=w["eh"][0], M=T, N=d, K=3 * d, lda=2 * d, ldb=3 * d, ldc=d, bias=p32,
+                 bias_off=o("model.encoder.conv2.bias"), epilogue=EPI_GELU_RESIDUAL, R=p16, r_off=o("model.encoder.embed_positions.weight"),
+                 ldr=d, batch2=B, sA=(0, (Tin + 2) * d), sC=(0, T * d), sR=(0, 0))
+        for l, (sa, ff) in enumerate(self.enc_blocks):
+            sv_a, sv_f = w["enc_sv"][l]
+            sa.forward(w["eh"][2 * l], w["eh"][2 * l + 1], sv_a, B, T)
+            ff.forward(w["eh"][2 * l + 1], w["eh"][2 * l + 2], sv_f, Me, drop, self.step_seed * 4096 + l)
+        ops.layernorm_fwd(w["eh"][-1], st.view("model.encoder.layer_norm.weight"), st.view("model.encoder.layer_norm.bias"),
+                          w["enc_out"], w["enc_st"], Me, d, s.layer_norm_eps)
+        # decoder
+        ids = dec_in.to(dev, torch.int32).contiguous().view(-1)
+        pos = torch.arange(L, dtype=torch.int32, device=dev).repeat(B)
+        ops.embed_tokens(p16[o("model.decoder.embed_tokens.weight"):], p16[o("model.decoder.embed_positions.weight"):],
+                         ids, pos, w["dh"][0], Md, d)
+        for l, (sa, ca, ff) in enumerate(self.dec_blocks):
+            sv_a, sv_c, sv_f = w["dec_sv"][l]
+            ca.project_kv(w["enc_out"], sv_c, B, T)
+            sa.forward(w["dh"][3 * l], w["dh"][3 * l + 1], sv_a, B, L)
+            ca.forward(w["dh"][3 * l + 1], w["dh"][3 * l + 2], sv_c, B, L, T)
+            ff.forward(w["dh"][3 * l + 2], w["dh"][3 * l + 3], sv_f, Md, drop, self.step_seed * 4096 + 2048 + l)
+        ops.layernorm_fwd(w["dh"][-1], st.view("model.decoder.layer_norm.weight"), st.view("model.decoder.layer_norm.bias"),
+                          w["dec_out"], w["dec_st"], Md, d, s.layer_norm_eps)
+        V, Vp = s.vocab_size, _r8(s.vocab_size)
+        ops.gemm(w["dec_out"], p16, w["logits"], M=Md, N=V, K=d, lda=d, ldb=d, ldc=Vp, b_off=o("model.decoder.embed_tokens.weight"))
+        w["loss_sum"].zero_()
+        w["count"].zero_()
+        lab32 = lab.to(dev, torch.int32).contiguous().view(-1)
+        ops.cross_entropy_fwd_bwd(w["logits"], lab32, w["loss_sum"], w["count"], w["dlogits"], Md, V, Vp, -100)
+        cnt = w["count"].clamp(min=1).to(torch.float32)
+        loss = (w["loss_sum"] / cnt)[0]
+        self._saved = dict(w=w, B=B, L=L, ids=ids, pos=pos, inv_count=(1.0 / cnt), x=x)
+        return dict(loss=loss, logits=w["logits"].view(B, L, Vp)[:, :, :V])
+
+    # ---- backward ----------------------------------------------------------------------------
+    def backward(self, loss_scale: float = 1.0, overwrite_matrices: bool = False, bucket_done=None):
+        """Gradients are accumulated into store.g32; `bucket_done(name)` is called per parameter bucket
+        once its gradients are enqueued (decoder buckets first, then the embeddings, then the encoder)."""
+        done = bucket_done if bucket_done is not None else (lambda name: None)
+        sv = self._saved
+        s, st = self.s, self.store
+        w, B, L = sv["w"], sv["B"], sv["L"]
+        p16, g32, o = st.p16, st.g32, st.off
+        T, d = s.max_source_positions, s.d_model
+        Tin = 2 * T
+        Me, Md = B * T, B * L
+        V, Vp = s.vocab_size, _r8(s.vocab_size)
+        mels = s.num_mel_bins
+        sc_e, sc_d = w["sc_e"], w["sc_d"]
+        # mean over the non-ignored tokens, then bf16 for the MFMA path
+        w["dlogits"].mul_(sv["inv_count"] * loss_scale)
+        ops.cast_f32_bf16(w["dlogits"], w["dlogits16"], Md * Vp)
+        dl = w["dlogits16"]
+        # tied LM head: dE += dlogits^T hf ; dhf = dlogits E
+        ops.gemm(dl, w["dec_out"], g32, M=V, N=d, K=Md, a_layout=MNMAJOR, lda=Vp, b_layout=MNMAJOR, ldb=d, ldc=d,
+                 c_off=o("model.decoder.embed_tokens.weight"), out_f32=True, accumulate=True)
+        ga, gb = w["g_d"]
+        ops.gemm(dl, p16, ga, M=Md, N=d, K=V, lda=Vp, b_layout=MNMAJOR, ldb=d, ldc=d, b_off=o("model.decoder.embed_tokens.weight"))
+        ops.layernorm_bwd(ga, w["dh"][-1], st.view("model.decoder.layer_norm.weight"), None, w["dec_st"], None, gb,
+                          st.view("model.decoder.layer_norm.weight", "g32"), st.view("model.decoder.layer_norm.bias", "g32"),
+                          sc_d.part, Md, d)
+        cur, other = gb, ga  # cur: gradient wrt the residual stream
+        w["denc32"].zero_()
+        for l in reversed(range(s.decoder_layers)):
+            sa, ca, ff = self.dec_blocks[l]
+            sv_a, sv_c, sv_f = w["dec_sv"][l]
+            ff.backward(cur, other, sv_f, sc_d, Md)
+            cur, other = other, cur
+            ca.backward(cur, other, sv_c, sc_d, w["denc32"], B, L, T)
+            cur, other = other, cur
+            sa.backward(cur, other, sv_a, sc_d, B, L)
+            cur, other = other, cur
+            self.clear_internal_grads_of(f"model.decoder.layers.{l}.")
+            done(f"dec{l}")
+        done("decf")
+        ops.embed_tokens_bwd(cur, sv["ids"], sv["pos"], g32, g32, Md, d, dtable_off=o("model.decoder.embed_tokens.weight"),
+                             dpos_off=o("model.decoder.embed_positions.weight"))
+        done("emb")
+        # encoder
+        ea, eb = w["g_e"]
+        ops.cast_f32_bf16(w["denc32"], ea, Me * d)
+        ops.layernorm_bwd(ea, w["eh"][-1], st.view("model.encoder.layer_norm.weight"), None, w["enc_st"], None, eb,
+                          st.view("model.encoder.layer_norm.weight", "g32"), st.view("model.encoder.layer_norm.bias", "g32"),
+                          sc_e.part, Me, d)
+        cur, other = eb, ea
+        for l in reversed(range(s.encoder_layers)):
+            sa, ff = self.enc_blocks[l]
+            sv_a, sv_f = w["enc_sv"][l]
+            ff.backward(cur, other, sv_f, sc_e, Me)
+            cur, other = other, cur
+            sa.backward(cur, other, sv_a, sc_e, B, T)
+            cur, other = other, cur
+            self.clear_internal_grads_of(f"model.encoder.layers.{l}.")
+            done(f"enc{l}")
+        done("encf")
+        # conv2: h0 = gelu(pre2) + pos
+        dpre2 = other
+        ops.dgelu_mul(cur, w["pre2"], dpre2, Me * d)
+        ops.colsum(dpre2, d, Me, d, g32, sc_e.part, out_off=o("model.encoder.conv2.bias"))
+        ops.gemm(dpre2, w["c1"], w["dwr_part"], M=d, N=3 * d, K=T, a_layout=MNMAJOR, lda=d, b_layout=MNMAJOR, ldb=2 * d,
+                 ldc=3 * d, out_f32=True, batch2=B, sA=(0, T * d), sB=(0, (Tin + 2) * d), sC=(0, d * 3 * d))
+        ops.reduce_rows(w["dwr_part"], B, d * 3 * d, d * 3 * d, w["dwr"])
+        ops.conv_weight_grad_reorder(w["dwr"], g32, d, d, 3, dw_off=o("model.encoder.conv2.weight"))
+        ops.gemm(dpre2, self.conv2_wr, w["dcol"], M=Me, N=3 * d, K=d, lda=d, b_layout=MNMAJOR, ldb=3 * d, ldc=3 * d)
+        ops.col2im_1d(w["dcol"], w["dpre"], B, T, Tin + 2, d, 3, 2)  # gradient wrt the padded gelu(pre1)
+        # conv1: rows 1..3000 of every clip (the padding rows carry no parameter gradient)
+        ops.dgelu_mul(w["dpre"], w["pre1"], w["dpre"], B * (Tin + 2) * d)
+        part_n = ops.colsum_partial_floats(Tin, d)
+        for b in range(B):
+            ops.colsum(w["dpre"], d, Tin, d, g32, sc_e.part[:part_n], x_off=(b * (Tin + 2) + 1) * d,
+                       out_off=o("model.encoder.conv1.bias"))
+        ops.gemm(w["dpre"], w["xin"], w["dwr_part"], M=d, N=3 * mels, K=Tin, a_layout=MNMAJOR, lda=d, a_off=d,
+                 b_layout=MNMAJOR, ldb=mels, ldc=3 * mels, out_f32=True, batch2=B, sA=(0, (Tin + 2) * d),
+                 sB=(0, (Tin + 2) * mels), sC=(0, d * 3 * mels))
+        ops.reduce_rows(w["dwr_part"], B, d * 3 * mels, d * 3 * mels, w["dwr"])
+        ops.conv_weight_grad_reorder(w["dwr"], g32, d, mels, 3, dw_off=o("model.encoder.conv1.weight"))
+        done("front")
+
+    def clear_internal_grads_of(self, prefix: str):
+        for n in self.store.names():
+            if n.startswith(prefix) and n.endswith("__zero"):
+                self.store.view(n, "g32").zero_()
+
+    def grad_dict(self):
+        return {n: self.store.view(n, "g32") for n in self.exported_names()}

@@ -302,6 +302,9 @@ int ca_argmax_masked(const float* logits, const uint8_t* suppress, int32_t* out,
  * $TF/models/whisper/modeling_whisper.py:204-212,676. */
 int ca_embed_tokens(const void* table, const void* pos, const int32_t* ids,
                     const int32_t* pos_ids, void* y, int64_t rows, int32_t C, void* stream);
+/* its backward: dtable[ids[r],:] += dy[r,:], dpos[pos_ids[r],:] += dy[r,:]  (fp32 tables, bf16 dy) */
+int ca_embed_tokens_bwd(const void* dy, const int32_t* ids, const int32_t* pos_ids, float* dtable,
+                        float* dpos, int64_t rows, int32_t C, void* stream);
 
 #ifdef __cplusplus
 }
