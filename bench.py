@@ -122,6 +122,83 @@ def cpu_baseline(model_key: str, seconds: float = 2.0, max_threads: int = 32):
                       f"(oracle/wav2vec2_ref.py, torch {torch.__version__} CPU, {cores} threads)"}
 
 
+def whisper_bench(args, world, rank, device):
+    """Secondary workload (BASELINE.json configs[3]/[4] shapes, bf16): Whisper teacher-forced finetune
+    step on 30 s clips (log-mel on the GPU inside the step) or greedy decoding (--decode)."""
+    import numpy as np
+
+    from coral_amd import ops
+    from coral_amd.trainer import DataParallelTrainer
+    from coral_amd.whisper import CORAL_WHISPER_SHAPES, N_SAMPLES, WhisperShape
+    from coral_amd.whisper_train import WhisperTrainEngine
+
+    shape = WhisperShape(**CORAL_WHISPER_SHAPES[args.model])
+    eng = WhisperTrainEngine(shape, device, activation_dropout=0.1)
+    g = torch.Generator(device=device).manual_seed(4242)
+    for n in eng.exported_names():
+        v = eng.store.view(n)
+        if n.endswith("layer_norm.weight"):
+            v.fill_(1.0)
+        elif n.endswith(".bias"):
+            v.zero_()
+        elif n == "model.encoder.embed_positions.weight":
+            from coral_amd.whisper_setup import WhisperForConditionalGeneration  # noqa: F401
+            T, d = shape.max_source_positions, shape.d_model
+            inc = np.log(10000.0) / (d // 2 - 1)
+            inv = torch.exp(-inc * torch.arange(d // 2, device=device))
+            t = torch.arange(T, device=device)[:, None] * inv[None, :]
+            v.copy_(torch.cat([t.sin(), t.cos()], 1))
+        else:
+            v.normal_(0.0, 0.02, generator=g)
+    eng.refresh_compute_weights()
+    B = args.batch
+    gen = torch.Generator().manual_seed(4242 + rank)
+    waves = torch.zeros(B, N_SAMPLES)
+    for b in range(B):
+        n = int(torch.randint(112_000, N_SAMPLES + 1, (1,), generator=gen))
+        waves[b, :n] = 0.1 * torch.randn(n, generator=gen)
+    waves = waves.to(device)
+    tl = torch.randint(20, 121, (B,), generator=gen)
+    labels = torch.full((B, int(tl.max())), -100, dtype=torch.int64)
+    for b in range(B):
+        labels[b, :tl[b]] = torch.randint(0, 50257, (int(tl[b]),), generator=gen)
+    trainer = DataParallelTrainer(eng, learning_rate=6e-6, betas=(0.9, 0.98), warmup_steps=1000, max_steps=100_000,
+                                  compress_grads=(args.grad_wire == "bf16"))
+
+    def step():
+        feats = eng.log_mel(waves)  # front end on the GPU, inside the step
+        if args.decode:
+            return eng.generate(feats, [50258, 50285, 50359, 50363], 4 + args.decode_tokens)
+        return trainer.train_step([dict(input_features=feats, labels=labels)])
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    sync()
+    dt = time.perf_counter() - t0
+    if rank == 0:
+        audio_s = world * B * 30.0 * args.steps
+        mode = f"greedy decode, {args.decode_tokens} new tokens" if args.decode else "finetune step fwd+bwd+clip+AdamW, teacher-forced"
+        print(json.dumps({
+            "metric": f"audio-seconds/sec ({mode}), {args.model}, 30 s clips", "value": round(audio_s / dt, 2),
+            "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"{args.model} {mode}, {B} x 30 s per GPU, log-mel on GPU", "global_batch": world * B,
+                       "label_len": int(labels.shape[1]), "parallelism": f"dp{world}"}}), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -132,6 +209,10 @@ def main():
     ap.add_argument("--seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-specaugment", action="store_true")
+    ap.add_argument("--decode", action="store_true", help="whisper models: time greedy decoding instead of training")
+    ap.add_argument("--decode-tokens", type=int, default=32)
+    ap.add_argument("--grad-wire", default="bf16", choices=["bf16", "fp32"],
+                    help="dtype of the gradient all-reduce at N>1 (bf16 = DDP bf16_compress_hook equivalent)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for 1-GPU debugging of the N>1 logic)")
     ap.add_argument("--check-replicas", action="store_true", help="after the run, verify every rank holds identical parameters")
     args = ap.parse_args()
@@ -156,6 +237,9 @@ def main():
     from coral_amd.trainer import DataParallelTrainer
     from coral_amd.wav2vec2 import CORAL_W2V2_SHAPES, Wav2Vec2CTCEngine, Wav2Vec2Shape
 
+    if args.model.startswith("whisper"):
+        return whisper_bench(args, world, rank, device)
+
     # CoRal model YAML values (R/config/model/wav2vec2-large.yaml:12-22); layerdrop is forced to 0
     # in the multi-GPU regime (R/src/scripts/finetune_asr_model.py:48-54) and kept 0 at N=1 so the
     # per-GPU work is identical at every N (weak scaling).
@@ -163,7 +247,7 @@ def main():
     eng = Wav2Vec2CTCEngine(shape, device)
     init_random_(eng, 4242)
     trainer = DataParallelTrainer(eng, learning_rate=1e-4, betas=(0.9, 0.98), max_grad_norm=1.0,
-                                  warmup_steps=1000, max_steps=100_000)
+                                  warmup_steps=1000, max_steps=100_000, compress_grads=(args.grad_wire == "bf16"))
     batch, lens = synth_batch(args.batch, args.seconds, rank, device)
     B, N = batch["input_values"].shape
     Ts = eng.conv_lengths(N)
@@ -231,7 +315,8 @@ def main():
             "config": {"workload": f"{args.model} (XLS-R shape d={shape.hidden_size} L={shape.num_hidden_layers} "
                                    f"ffn={shape.intermediate_size}) CTC finetune, {B} x {args.seconds:g} s per GPU, "
                                    f"SpecAugment {'off' if args.no_specaugment else 'on'}, activation_dropout 0.1, "
-                                   "layerdrop 0 (multi-GPU rule), fp32 master + AdamW + clip 1.0",
+                                   "layerdrop 0 (multi-GPU rule), fp32 master + AdamW + clip 1.0"
+                                   + (f", gradient all-reduce on {args.grad_wire} wire, per-layer buckets overlapped with backward" if world > 1 else ""),
                        "global_batch": world * B, "frames_per_utt": T, "parallelism": f"dp{world}",
                        "loss": round(loss_val, 3)},
             "roofline": {"bound": "mfma", "kernel": dom["kernel"], "achieved": round(ach, 1),

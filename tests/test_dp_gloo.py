@@ -40,7 +40,14 @@ def _worker(rank, world, port, q):
     s2.start("head")
     s2.finish()
     ok_partial = bool((g2[168:] == 3).all() and (g2[:168] == rank + 1).all())
-    q.put((rank, ok_sum, ok_mean, ok_partial, launched == order, shard_indices(8, rank, world)))
+    # bf16 wire format: sums of bf16-rounded gradients, written back to the fp32 buffer
+    g3 = (torch.arange(200, dtype=torch.float32) * 0.37 + rank).clone()
+    want3 = sum(((torch.arange(200, dtype=torch.float32) * 0.37 + r).to(torch.bfloat16)).float() for r in range(world))
+    s3 = GradSync(g3, buckets, compress=True)
+    s3.start_all()
+    s3.finish()
+    ok_bf16 = bool((g3 - want3.to(torch.bfloat16).float()).abs().max() <= 1e-6 + 0.008 * want3.abs().max())
+    q.put((rank, ok_sum, ok_mean, ok_partial, launched == order and ok_bf16, shard_indices(8, rank, world)))
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 
