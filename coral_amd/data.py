@@ -31,7 +31,23 @@ def synthetic_examples(processor, n: int, seed: int, min_seconds=1.0, max_second
         yield ex
 
 
-def load_data_for_finetuning(config, processor, n_examples: int | None = None):
+def synthetic_whisper_examples(processor, n: int, seed: int, prefix, eos: int, min_seconds=1.0, max_seconds=10.0,
+                               sampling_rate=16_000, max_tokens: int = 64):
+    """Whisper flavour of `process_example` (R/src/coral/data.py:747-757): `input_features` is the log-mel
+    of the 30 s padded clip (computed on the GPU by the processor's feature extractor), `labels` the
+    token ids `<|sot|><|da|><|transcribe|><|notimestamps|> … <|endoftext|>`.  The byte-level BPE files
+    are not available offline, so the transcription ids are drawn directly (text tokens < 50257)."""
+    rng = np.random.RandomState(seed)
+    for _ in range(n):
+        secs = rng.uniform(min_seconds, max_seconds)
+        wave = np.clip(0.1 * rng.randn(int(secs * sampling_rate)), -1, 1).astype(np.float32)
+        wave /= np.abs(wave).max()
+        feats = processor.feature_extractor(wave, sampling_rate=sampling_rate)[0]
+        ids = rng.randint(0, 50257, size=int(rng.randint(4, max_tokens))).tolist()
+        yield dict(input_features=feats, labels=list(prefix) + ids + [eos], input_length=len(wave))
+
+
+def load_data_for_finetuning(config, processor, n_examples: int | None = None, model=None):
     """-> {"train": iterable, "val": list}.  Only `datasets=synthetic` and local `.npz` directories
     (arrays `audio`, `text`) are supported offline."""
     rank = 0
@@ -42,6 +58,20 @@ def load_data_for_finetuning(config, processor, n_examples: int | None = None):
     except ValueError:
         pass
     out_train = []
+    if config.model.type == "whisper":
+        from .whisper_setup import prefix_ids
+
+        shape = model.shape
+        for key, ds in config.datasets.items():
+            if ds["id"] != "synthetic":
+                raise RuntimeError(f"dataset {key!r} ({ds['id']}) needs the HuggingFace hub and the Whisper tokenizer "
+                                   "files; this environment is offline — use datasets=synthetic")
+        n = n_examples or config.per_device_batch_size * config.max_steps
+        mk = lambda k, sd, hi: synthetic_whisper_examples(  # noqa: E731
+            processor, k, sd, prefix_ids(shape), shape.eos_token_id, config.min_seconds_per_example, hi,
+            config.model.sampling_rate)
+        return {"train": mk(n, config.seed + 1000 * rank, config.max_seconds_per_example),
+                "val": list(mk(4, config.seed + 7, 3.0))}
     for key, ds in config.datasets.items():
         if ds["id"] == "synthetic":
             n = n_examples or config.per_device_batch_size * config.max_steps

@@ -19,11 +19,15 @@ logger = logging.getLogger(__package__)
 def finetune(config, n_examples: int | None = None) -> dict:
     is_main = os.getenv("RANK", "0") == "0"
     setup = load_model_setup(config)
-    processor = setup.load_processor()
+    if config.model.type == "whisper":  # the GPU log-mel front end lives on the model's engine
+        model = setup.load_model()
+        processor = setup.load_processor()
+    else:
+        processor = setup.load_processor()
+        model = setup.load_model()
     if is_main:
         processor.save_pretrained(config.model_dir)
-    model = setup.load_model()
-    dataset = load_data_for_finetuning(config, processor, n_examples)
+    dataset = load_data_for_finetuning(config, processor, n_examples, model=model)
     collator = setup.load_data_collator()
     args = setup.load_training_arguments()
     compute_metrics = setup.load_compute_metrics()
@@ -55,11 +59,37 @@ def finetune(config, n_examples: int | None = None) -> dict:
             if is_main:
                 logger.info("step %d loss %.4f", step + 1, float(loss))
         if (step + 1) % args.eval_steps == 0 or step + 1 == args.max_steps:
-            metrics = evaluate_split(model, dataset["val"], collator, compute_metrics, B)
+            if config.model.type == "whisper":
+                metrics = evaluate_split_seq2seq(model, dataset["val"], collator, compute_metrics, B,
+                                                 args.generation_max_length)
+            else:
+                metrics = evaluate_split(model, dataset["val"], collator, compute_metrics, B)
             history.append(dict(step=step + 1, **{f"val_{k}": v for k, v in metrics.items()}))
     if is_main:
         model.save_pretrained(config.model_dir)
     return dict(history=history, model=model, processor=processor)
+
+
+def evaluate_split_seq2seq(model, examples, collator, compute_metrics, batch_size, max_length) -> dict:
+    """`predict_with_generate` evaluation (R/src/coral/whisper.py:221-222): greedy generation on the GPU,
+    CER/WER of the decoded strings on the host."""
+    model.eval()
+    preds, labels = [], []
+    for i in range(0, len(examples), batch_size):
+        batch = collator(examples[i:i + batch_size])
+        ids = model.generate(batch["input_features"], language="danish", task="transcribe", max_length=max_length)
+        preds.extend(ids.tolist() if hasattr(ids, "tolist") else ids)
+        labels.extend(batch["labels"].tolist())
+    import numpy as np
+
+    pad = model.shape.pad_token_id
+    P = np.full((len(preds), max(len(p) for p in preds)), pad, dtype=np.int64)
+    for i, p in enumerate(preds):
+        P[i, :len(p)] = p
+    Lb = np.full((len(labels), max(len(x) for x in labels)), -100, dtype=np.int64)
+    for i, x in enumerate(labels):
+        Lb[i, :len(x)] = x
+    return compute_metrics(P, Lb)
 
 
 def evaluate_split(model, examples, collator, compute_metrics, batch_size) -> dict:

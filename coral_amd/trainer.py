@@ -150,7 +150,10 @@ class DataParallelTrainer:
         self.sync = GradSync(st.g32, st.buckets, process_group, compress=compress_grads)
         self.world = self.sync.world
         self.overlap = overlap and self.world > 1
-        lo, hi = st.buckets["head"] if engine.freeze_base else (0, st.numel)
+        if hasattr(engine, "trainable_range"):
+            lo, hi = engine.trainable_range()
+        else:
+            lo, hi = st.buckets["head"] if engine.freeze_base else (0, st.numel)
         self.train_range = (lo, hi)
 
     # ---- one optimiser step ----------------------------------------------------------------------

@@ -126,6 +126,17 @@ def whisper_param_list(s: WhisperShape):
     return out
 
 
+def sinusoid_positions(length: int, channels: int, max_timescale: float = 10000.0) -> torch.Tensor:
+    """The encoder's fixed position table ($TF/models/whisper/modeling_whisper.py:55-64): [sin | cos] of
+    position x geometric timescales."""
+    import math
+
+    inc = math.log(max_timescale) / (channels // 2 - 1)
+    inv = torch.exp(-inc * torch.arange(channels // 2, dtype=torch.float32))
+    t = torch.arange(length, dtype=torch.float32).view(-1, 1) * inv.view(1, -1)
+    return torch.cat([t.sin(), t.cos()], dim=1)
+
+
 class WhisperEngine:
     """Forward paths of WhisperForConditionalGeneration as sequences of HIP kernels."""
 

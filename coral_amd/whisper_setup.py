@@ -17,7 +17,9 @@ import torch
 
 from .model_setup import ModelSetup, PreTrainedModelData, _training_args
 from .trainer import DataParallelTrainer
-from .whisper import CORAL_WHISPER_SHAPES, N_SAMPLES, WhisperEngine, WhisperShape
+from . import specaugment
+from .whisper import CORAL_WHISPER_SHAPES, N_SAMPLES, WhisperEngine, WhisperShape, sinusoid_positions
+from .whisper_train import WhisperTrainEngine
 
 logger = logging.getLogger(__package__)
 
@@ -29,6 +31,10 @@ HUB_SHAPES = {"openai/whisper-tiny": "whisper-xxsmall", "openai/whisper-base": "
 # (language="danish", task="transcribe": R/src/coral/evaluate.py:59, R/src/coral/whisper.py:51-55)
 DANISH_TRANSCRIBE_PREFIX = [50258, 50285, 50359, 50363]
 DANISH_TRANSCRIBE_PREFIX_V3 = [50258, 50285, 50360, 50364]  # large-v3 vocabulary (51866 entries)
+
+
+def prefix_ids(shape: WhisperShape):
+    return DANISH_TRANSCRIBE_PREFIX_V3 if shape.vocab_size == 51866 else DANISH_TRANSCRIBE_PREFIX
 
 
 class WhisperFeatureExtractorGPU:
@@ -57,34 +63,75 @@ class WhisperProcessor:
 
     def batch_decode(self, ids, skip_special_tokens=True):
         if self.tokenizer is None:
-            raise RuntimeError("no Whisper tokenizer files available offline (need tokenizer.json in model_dir)")
+            # no byte-level BPE files offline: render every text token as the word "t<id>", so WER on
+            # the rendered strings is the token error rate (special tokens >= 50257 are skipped)
+            return [" ".join(f"t{int(i)}" for i in r if not (skip_special_tokens and int(i) >= 50257)) for r in ids]
         return self.tokenizer.decode_batch([list(map(int, r)) for r in ids], skip_special_tokens=skip_special_tokens)
+
+    def save_pretrained(self, model_dir):
+        model_dir = Path(model_dir)
+        model_dir.mkdir(parents=True, exist_ok=True)
+        s = self.feature_extractor.engine.s
+        (model_dir / "preprocessor_config.json").write_text(json.dumps(dict(
+            feature_extractor_type="WhisperFeatureExtractor", feature_size=s.num_mel_bins, sampling_rate=self.feature_extractor.sampling_rate,
+            hop_length=160, chunk_length=30, n_fft=400, padding_value=0.0, return_attention_mask=False), indent=2))
+        if self.tokenizer is not None:
+            self.tokenizer.save(str(model_dir / "tokenizer.json"))
 
 
 class WhisperForConditionalGeneration:
-    """HF-shaped wrapper: `model(input_features, labels)` and `model.generate(...)`."""
+    """HF-shaped wrapper: `model(input_features, labels)` and `model.generate(...)`.
 
-    def __init__(self, shape: WhisperShape, device=None):
+    In training mode the call draws SpecAugment masks on the input features
+    ($TF/models/whisper/modeling_whisper.py:821-862: time spans over the 3000 frames, then feature
+    spans over the mel bins, zero fill) and LayerDrop decisions (:626-634, :771-779) on the host, in
+    the reference's order, and runs the training forward (activations saved for `backward`)."""
+
+    def __init__(self, shape: WhisperShape, device=None, activation_dropout: float = 0.0, freeze_base: bool = False,
+                 spec=None, layerdrop: float = 0.0):
         device = device or f"cuda:{torch.cuda.current_device() if torch.cuda.is_available() else 0}"
-        self.engine = WhisperEngine(shape, device)
+        self.engine = WhisperTrainEngine(shape, device, activation_dropout=activation_dropout, freeze_base=freeze_base)
         self.shape = shape
+        self.spec = spec or dict(apply_spec_augment=False, mask_time_prob=0.0, mask_time_length=10,
+                                 mask_feature_prob=0.0, mask_feature_length=64)
+        self.layerdrop = layerdrop
+        self.training = False
+        self.engine.training = False
+        self._rng = np.random
+
+    def train(self, mode: bool = True):
+        self.training = mode
+        self.engine.training = mode
+        return self
+
+    def eval(self):
+        return self.train(False)
 
     @classmethod
-    def from_pretrained(cls, name_or_path: str, device=None, seed: int = 4242, **_):
+    def from_pretrained(cls, name_or_path: str, device=None, seed: int = 4242, **overrides):
+        spec = {k: overrides.pop(k) for k in ("apply_spec_augment", "mask_time_prob", "mask_time_length",
+                                              "mask_feature_prob", "mask_feature_length") if k in overrides}
+        kw = dict(activation_dropout=float(overrides.pop("activation_dropout", 0.0)),
+                  freeze_base=bool(overrides.pop("freeze_base", False)), spec=spec or None,
+                  layerdrop=float(overrides.pop("encoder_layerdrop", overrides.pop("layerdrop", 0.0))))
+        for k in ("dropout", "attention_dropout"):  # CoRal configures both as 0 (R/config/model/whisper-*.yaml)
+            if float(overrides.pop(k, 0.0)) != 0.0:
+                raise NotImplementedError(f"{k} > 0 is not implemented (every CoRal Whisper config sets it to 0)")
         path = Path(name_or_path)
         if path.is_dir() and (path / "config.json").exists():
             cfg = json.loads((path / "config.json").read_text())
             fields = WhisperShape.__dataclass_fields__
-            model = cls(WhisperShape(**{k: cfg[k] for k in fields if k in cfg}), device)
+            model = cls(WhisperShape(**{k: cfg[k] for k in fields if k in cfg}), device, **kw)
             from safetensors.torch import load_file
 
             sd = load_file(str(path / "model.safetensors"))
             sd = {(k if k.startswith("model.") else "model." + k): v for k, v in sd.items() if k != "proj_out.weight"}
             model.engine.load_state_dict(sd)
+            model.engine.refresh_derived()
             return model
         if name_or_path not in HUB_SHAPES:
             raise ValueError(f"unknown model {name_or_path!r}")
-        model = cls(WhisperShape(**CORAL_WHISPER_SHAPES[HUB_SHAPES[name_or_path]]), device)
+        model = cls(WhisperShape(**CORAL_WHISPER_SHAPES[HUB_SHAPES[name_or_path]]), device, **kw)
         logger.warning("no network / hub cache here: %s is instantiated with seeded random weights", name_or_path)
         g = torch.Generator(device=model.engine.device).manual_seed(seed)
         for n in model.engine.exported_names():
@@ -93,9 +140,12 @@ class WhisperForConditionalGeneration:
                 v.fill_(1.0)
             elif n.endswith(".bias"):
                 v.zero_()
+            elif n.endswith("encoder.embed_positions.weight"):  # fixed sinusoid table (:55-64, requires_grad False)
+                v.copy_(sinusoid_positions(*v.shape).to(v.device))
             else:
                 v.normal_(0.0, 0.02, generator=g)
         model.engine.refresh_compute_weights()
+        model.engine.refresh_derived()
         return model
 
     def save_pretrained(self, model_dir):
@@ -108,13 +158,38 @@ class WhisperForConditionalGeneration:
         save_file({k: v.cpu().contiguous() for k, v in self.engine.state_dict().items()},
                   str(model_dir / "model.safetensors"), metadata={"format": "pt"})
 
-    def __call__(self, input_features, labels=None, decoder_input_ids=None):
+    def sample_spec_masks(self, B: int):
+        sp = self.spec
+        if not (self.training and sp.get("apply_spec_augment", False)):
+            return None, None
+        mt, mf = specaugment.sample_masks(B, 2 * self.shape.max_source_positions, self.shape.num_mel_bins, None,
+                                          sp["mask_time_prob"], sp["mask_time_length"], sp["mask_feature_prob"],
+                                          sp["mask_feature_length"], rng=self._rng)
+        return (None if mt is None else torch.from_numpy(mt)), (None if mf is None else torch.from_numpy(mf))
+
+    def sample_layer_keep(self):
+        if not self.training or self.layerdrop <= 0:
+            return None, None
+        draw = lambda n: [bool(float(torch.rand([])) >= self.layerdrop) for _ in range(n)]  # noqa: E731
+        return draw(self.shape.encoder_layers), draw(self.shape.decoder_layers)
+
+    def __call__(self, input_features, labels=None, decoder_input_ids=None, mask_time=None, mask_feature=None,
+                 enc_keep=None, dec_keep=None):
+        if self.training and labels is not None:
+            if mask_time is None and mask_feature is None:
+                mask_time, mask_feature = self.sample_spec_masks(input_features.shape[0])
+            if enc_keep is None and dec_keep is None:
+                enc_keep, dec_keep = self.sample_layer_keep()
+            return self.engine(input_features, labels, mask_time, mask_feature, enc_keep, dec_keep)
         return self.engine.forward(input_features, labels, decoder_input_ids)
+
+    def backward(self, **kw):
+        return self.engine.backward(**kw)
 
     def generate(self, input_features, language="danish", task="transcribe", max_length: int = 225, **_):
         if language not in ("danish", "da") or task != "transcribe":
             raise ValueError("only language='danish', task='transcribe' (CoRal's evaluation call) is wired up")
-        prefix = DANISH_TRANSCRIBE_PREFIX_V3 if self.shape.vocab_size == 51866 else DANISH_TRANSCRIBE_PREFIX
+        prefix = prefix_ids(self.shape)
         # CoRal clears `suppress_tokens`; the default begin-suppress set (blank ' ' = 220, eos) stays
         return self.engine.generate(input_features, prefix, max_length, suppress_tokens=None,
                                     begin_suppress_tokens=[220, self.shape.eos_token_id])
@@ -128,8 +203,13 @@ class WhisperModelSetup(ModelSetup):
         self.is_main_process = os.getenv("RANK", "0") == "0"
 
     def load_model(self):
-        self.model = WhisperForConditionalGeneration.from_pretrained(self.config.model.pretrained_model_id,
-                                                                     seed=self.config.seed)
+        m = self.config.model
+        self.model = WhisperForConditionalGeneration.from_pretrained(
+            m.pretrained_model_id, seed=self.config.seed, dropout=m.dropout, activation_dropout=m.activation_dropout,
+            attention_dropout=m.attention_dropout, apply_spec_augment=True, mask_time_prob=m.mask_time_prob,
+            mask_time_length=m.mask_time_length, mask_feature_prob=m.mask_feature_prob,
+            mask_feature_length=m.mask_feature_length, encoder_layerdrop=m.layerdrop, decoder_layerdrop=m.layerdrop,
+            freeze_base=bool(m.freeze_feature_encoder))
         return self.model
 
     def load_processor(self):

@@ -26,8 +26,10 @@ from .whisper import WhisperEngine, WhisperShape
 class WhisperTrainEngine(WhisperEngine):
     """Adds forward_train()/backward() to the inference engine; gradients land in `store.g32`."""
 
-    def __init__(self, shape: WhisperShape, device="cuda:0", activation_dropout: float = 0.0):
+    def __init__(self, shape: WhisperShape, device="cuda:0", activation_dropout: float = 0.0,
+                 freeze_base: bool = False):
         super().__init__(shape, device)
+        self.freeze_base = freeze_base
         s, st = shape, self.store
         d, eps = s.d_model, s.layer_norm_eps
         self.activation_dropout = activation_dropout
@@ -51,7 +53,13 @@ class WhisperTrainEngine(WhisperEngine):
         self._tw_key = None
         self.zero_mel = torch.zeros(s.num_mel_bins, dtype=torch.bfloat16, device=self.device)
 
-    freeze_base = False
+    def trainable_range(self):
+        """`freeze_feature_encoder` (R/src/coral/whisper.py:88-92) leaves only `proj_out` trainable, and
+        proj_out is tied to the token embedding: the one matrix keeps both of its gradients."""
+        if not self.freeze_base:
+            return 0, self.store.numel
+        lo = self.store.off("model.decoder.embed_tokens.weight")
+        return lo, lo + self.s.vocab_size * self.s.d_model
 
     def zero_grad(self, matrices: bool = True):
         self.store.g32.zero_()
@@ -69,11 +77,11 @@ class WhisperTrainEngine(WhisperEngine):
         ops.conv_weight_reorder(st.p32, self.conv1_wr, s.d_model, s.num_mel_bins, 3, w_off=st.off("model.encoder.conv1.weight"))
         ops.conv_weight_reorder(st.p32, self.conv2_wr, s.d_model, s.d_model, 3, w_off=st.off("model.encoder.conv2.weight"))
 
-    def __call__(self, input_features, labels, mask_time=None, mask_feature=None):
+    def __call__(self, input_features, labels, mask_time=None, mask_feature=None, enc_keep=None, dec_keep=None):
         """Trainer-facing call: returns an object with `.loss` (device scalar) and `.logits`."""
         from .wav2vec2 import CTCOutput
 
-        out = self.forward_train(input_features, labels, mask_time, mask_feature)
+        out = self.forward_train(input_features, labels, mask_time, mask_feature, enc_keep, dec_keep)
         return CTCOutput(loss=out["loss"], logits=out["logits"])
 
     def clear_internal_grads(self):
@@ -114,8 +122,10 @@ class WhisperTrainEngine(WhisperEngine):
         return w
 
     # ---- forward -----------------------------------------------------------------------------
-    def forward_train(self, input_features, labels, mask_time=None, mask_feature=None):
-        """-> dict(loss, logits).  labels i64 [B, L] with -100 padding."""
+    def forward_train(self, input_features, labels, mask_time=None, mask_feature=None, enc_keep=None, dec_keep=None):
+        """-> dict(loss, logits).  labels i64 [B, L] with -100 padding.  enc_keep / dec_keep: host-drawn
+        LayerDrop decisions (one bool per layer, $TF/models/whisper/modeling_whisper.py:626-634,771-779);
+        a dropped layer is the identity in forward and backward."""
         s, st = self.s, self.store
         p32, p16, o = st.p32, st.p16, st.off
         dev = self.device
@@ -148,7 +158,12 @@ class WhisperTrainEngine(WhisperEngine):
         ops.gemm(w["c1"], self.conv2_wr, w["pre2"], C2=w["eh"][0], M=T, N=d, K=3 * d, lda=2 * d, ldb=3 * d, ldc=d, bias=p32,
                  bias_off=o("model.encoder.conv2.bias"), epilogue=EPI_GELU_RESIDUAL, R=p16, r_off=o("model.encoder.embed_positions.weight"),
                  ldr=d, batch2=B, sA=(0, (Tin + 2) * d), sC=(0, T * d), sR=(0, 0))
+        ek = [True] * s.encoder_layers if enc_keep is None else [bool(k) for k in enc_keep]
+        dk = [True] * s.decoder_layers if dec_keep is None else [bool(k) for k in dec_keep]
         for l, (sa, ff) in enumerate(self.enc_blocks):
+            if not ek[l]:
+                w["eh"][2 * l + 2].copy_(w["eh"][2 * l])
+                continue
             sv_a, sv_f = w["enc_sv"][l]
             sa.forward(w["eh"][2 * l], w["eh"][2 * l + 1], sv_a, B, T)
             ff.forward(w["eh"][2 * l + 1], w["eh"][2 * l + 2], sv_f, Me, drop, self.step_seed * 4096 + l)
@@ -160,6 +175,9 @@ class WhisperTrainEngine(WhisperEngine):
         ops.embed_tokens(p16[o("model.decoder.embed_tokens.weight"):], p16[o("model.decoder.embed_positions.weight"):],
                          ids, pos, w["dh"][0], Md, d)
         for l, (sa, ca, ff) in enumerate(self.dec_blocks):
+            if not dk[l]:
+                w["dh"][3 * l + 3].copy_(w["dh"][3 * l])
+                continue
             sv_a, sv_c, sv_f = w["dec_sv"][l]
             ca.project_kv(w["enc_out"], sv_c, B, T)
             sa.forward(w["dh"][3 * l], w["dh"][3 * l + 1], sv_a, B, L)
@@ -175,7 +193,7 @@ class WhisperTrainEngine(WhisperEngine):
         ops.cross_entropy_fwd_bwd(w["logits"], lab32, w["loss_sum"], w["count"], w["dlogits"], Md, V, Vp, -100)
         cnt = w["count"].clamp(min=1).to(torch.float32)
         loss = (w["loss_sum"] / cnt)[0]
-        self._saved = dict(w=w, B=B, L=L, ids=ids, pos=pos, inv_count=(1.0 / cnt), x=x)
+        self._saved = dict(w=w, B=B, L=L, ids=ids, pos=pos, inv_count=(1.0 / cnt), x=x, ek=ek, dk=dk)
         return dict(loss=loss, logits=w["logits"].view(B, L, Vp)[:, :, :V])
 
     # ---- backward ----------------------------------------------------------------------------
@@ -208,6 +226,9 @@ class WhisperTrainEngine(WhisperEngine):
         cur, other = gb, ga  # cur: gradient wrt the residual stream
         w["denc32"].zero_()
         for l in reversed(range(s.decoder_layers)):
+            if not sv["dk"][l]:
+                done(f"dec{l}")
+                continue
             sa, ca, ff = self.dec_blocks[l]
             sv_a, sv_c, sv_f = w["dec_sv"][l]
             ff.backward(cur, other, sv_f, sc_d, Md)
@@ -230,6 +251,9 @@ class WhisperTrainEngine(WhisperEngine):
                           sc_e.part, Me, d)
         cur, other = eb, ea
         for l in reversed(range(s.encoder_layers)):
+            if not sv["ek"][l]:
+                done(f"enc{l}")
+                continue
             sa, ff = self.enc_blocks[l]
             sv_a, sv_f = w["enc_sv"][l]
             ff.backward(cur, other, sv_f, sc_e, Me)

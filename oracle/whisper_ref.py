@@ -205,12 +205,15 @@ def _ln(x, P, p, eps):
     return F.layer_norm(x, (x.shape[-1],), P[p + ".weight"], P[p + ".bias"], eps)
 
 
-def encoder(input_features: torch.Tensor, P: dict, c: WhisperConfig) -> torch.Tensor:
-    """input_features f32 [B, mels, 3000] -> [B, 1500, d]."""
+def encoder(input_features: torch.Tensor, P: dict, c: WhisperConfig, keep=None) -> torch.Tensor:
+    """input_features f32 [B, mels, 3000] -> [B, 1500, d].  keep[l] False = the layer is skipped
+    (training-time LayerDrop, $TF/models/whisper/modeling_whisper.py:626-634)."""
     x = F.gelu(F.conv1d(input_features, P["model.encoder.conv1.weight"], P["model.encoder.conv1.bias"], padding=1))
     x = F.gelu(F.conv1d(x, P["model.encoder.conv2.weight"], P["model.encoder.conv2.bias"], stride=2, padding=1))
     h = x.permute(0, 2, 1) + P["model.encoder.embed_positions.weight"]
     for l in range(c.encoder_layers):
+        if keep is not None and not keep[l]:
+            continue
         p = f"model.encoder.layers.{l}."
         x = _ln(h, P, p + "self_attn_layer_norm", c.layer_norm_eps)
         h = h + _attn(x, x, P, p + "self_attn.", c.encoder_attention_heads)
@@ -220,11 +223,14 @@ def encoder(input_features: torch.Tensor, P: dict, c: WhisperConfig) -> torch.Te
     return _ln(h, P, "model.encoder.layer_norm", c.layer_norm_eps)
 
 
-def decoder(input_ids: torch.Tensor, enc: torch.Tensor, P: dict, c: WhisperConfig) -> torch.Tensor:
-    """input_ids i64 [B, L], enc [B, 1500, d] -> logits [B, L, V] (tied projection)."""
+def decoder(input_ids: torch.Tensor, enc: torch.Tensor, P: dict, c: WhisperConfig, keep=None) -> torch.Tensor:
+    """input_ids i64 [B, L], enc [B, 1500, d] -> logits [B, L, V] (tied projection); keep as in
+    `encoder` (:771-779)."""
     L = input_ids.shape[1]
     h = P["model.decoder.embed_tokens.weight"][input_ids] + P["model.decoder.embed_positions.weight"][:L]
     for l in range(c.decoder_layers):
+        if keep is not None and not keep[l]:
+            continue
         p = f"model.decoder.layers.{l}."
         x = _ln(h, P, p + "self_attn_layer_norm", c.layer_norm_eps)
         h = h + _attn(x, x, P, p + "self_attn.", c.decoder_attention_heads, causal=True)
@@ -244,10 +250,10 @@ def shift_tokens_right(labels: torch.Tensor, pad_id: int, start_id: int) -> torc
     return out.masked_fill(out == -100, pad_id)
 
 
-def forward_loss(input_features, labels, P, c: WhisperConfig):
+def forward_loss(input_features, labels, P, c: WhisperConfig, enc_keep=None, dec_keep=None):
     """WhisperForConditionalGeneration.forward(input_features, labels) -> (loss, logits)."""
     dec_in = shift_tokens_right(labels, c.pad_token_id, c.decoder_start_token_id)
-    logits = decoder(dec_in, encoder(input_features, P, c), P, c)
+    logits = decoder(dec_in, encoder(input_features, P, c, enc_keep), P, c, dec_keep)
     loss = F.cross_entropy(logits.reshape(-1, c.vocab_size), labels.reshape(-1), ignore_index=-100)
     return loss, logits
 

@@ -185,3 +185,68 @@ def test_whisper_trainer_reduces_loss():
     for n in eng.store.names():
         if n.endswith("__zero"):
             assert float(eng.store.view(n).abs().sum()) == 0.0
+
+
+def test_whisper_layerdrop_matches_oracle():
+    """LayerDrop decisions are host-drawn; a dropped layer is the identity in forward and backward and
+    its parameters get no gradient."""
+    from coral_amd.whisper import WhisperShape
+    from coral_amd.whisper_train import WhisperTrainEngine
+    from oracle import whisper_ref as w
+
+    kw, c = _tiny()
+    P = w.synth_params(c)
+    g = torch.Generator().manual_seed(5)
+    feats = torch.randn(2, 80, 3000, generator=g) * 0.5
+    labels = torch.randint(0, 150, (2, 9), generator=g)
+    ek = [l != 0 for l in range(c.encoder_layers)]
+    dk = [l != c.decoder_layers - 1 for l in range(c.decoder_layers)]
+    Pr = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    loss_ref, logits_ref = w.forward_loss(feats, labels, Pr, c, ek, dk)
+    loss_ref.backward()
+    eng = WhisperTrainEngine(WhisperShape(**kw), DEV)
+    eng.load_state_dict(P)
+    eng.zero_grad()
+    out = eng.forward_train(feats, labels, enc_keep=ek, dec_keep=dk)
+    eng.backward()
+    torch.cuda.synchronize()
+    assert abs(float(out["loss"]) - float(loss_ref)) <= 1e-2 * float(loss_ref)
+    assert (out["logits"].float().cpu() - logits_ref.detach()).abs().max() <= 5e-2
+    gd = eng.grad_dict()
+    for name, gq in gd.items():
+        dropped = name.startswith("model.encoder.layers.0.") or name.startswith(f"model.decoder.layers.{c.decoder_layers - 1}.")
+        if dropped:
+            assert float(gq.abs().sum()) == 0.0, name
+    for name in ["model.encoder.conv1.weight", "model.decoder.embed_tokens.weight", "model.decoder.layers.0.fc1.weight",
+                 f"model.encoder.layers.{c.encoder_layers - 1}.self_attn.v_proj.weight"]:
+        a, b = gd[name].double().cpu().flatten(), Pr[name].grad.double().flatten()
+        assert float(a @ b / (a.norm() * b.norm())) >= 0.99, name
+
+
+def test_whisper_finetune_entry_point(tmp_path):
+    """`finetune(config)` with `model=test-whisper` (R/tests/test_finetune.py:8-10 runs exactly this key):
+    SpecAugment + LayerDrop drawn on the host, frozen base = only the tied proj_out/embed_tokens matrix
+    moves (R/src/coral/whisper.py:88-92), predict-with-generate evaluation, HF-layout save and reload."""
+    import sys
+    from pathlib import Path
+
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1] / "scripts"))
+    import finetune_asr_model
+
+    from coral_amd.whisper_setup import WhisperForConditionalGeneration
+
+    res = finetune_asr_model.main(["model=test-whisper", "datasets=synthetic", f"models_dir={tmp_path}", "model_id=wsmoke",
+                                   "max_steps=2", "total_batch_size=2", "per_device_batch_size=2",
+                                   "max_seconds_per_example=2.0", "min_seconds_per_example=1.0", "logging_steps=1",
+                                   "eval_steps=2", "model.max_length=12"])
+    hist = res["history"]
+    assert any("loss" in h for h in hist) and any("val_wer" in h for h in hist)
+    mdir = tmp_path / "wsmoke"
+    assert (mdir / "model.safetensors").exists() and (mdir / "config.json").exists()
+    assert (mdir / "preprocessor_config.json").exists()
+    trained = res["model"].engine.state_dict()
+    fresh = WhisperForConditionalGeneration.from_pretrained("openai/whisper-tiny", seed=4242).engine.state_dict()
+    moved = [n for n in trained if not torch.equal(trained[n], fresh[n])]
+    assert moved == ["model.decoder.embed_tokens.weight"], moved
+    again = WhisperForConditionalGeneration.from_pretrained(str(mdir)).engine.state_dict()
+    assert all(torch.equal(again[n], trained[n]) for n in trained)
