@@ -63,7 +63,7 @@ struct KMajorLoader {  // operand stored [row][k], k contiguous; LDS image [rows
 // operand stored [k][mn], mn contiguous; LDS image [64 k][PC*8 mn]; PC = 16-B chunks per row.
 // The source pointer of each lane walks down the k rows by plain 64-bit adds (BK rows per step);
 // with segmented rows (kseg > 0) it hops by (segstride - kseg*ld) whenever it crosses a segment.
-template <int NI, int PC>
+template <int NI, int PC, bool KS = true>
 struct MNMajorLoader {
   const char* p[NI];  // current source address of this lane's chunk
   int t[NI];          // row index inside the current segment
@@ -102,7 +102,7 @@ struct MNMajorLoader {
     const void* src = (k0 + kr < K) ? (const void*)p[i] : (const void*)g_ca_zero_page;
     glds16(src, tile + (wave * NI + i) * 1024);
     p[i] += step;
-    if (kseg > 0) {
+    if (KS && kseg > 0) {
       t[i] += BK;
       while (t[i] >= kseg) {
         t[i] -= kseg;
@@ -122,6 +122,11 @@ __device__ __forceinline__ bf16x8_t frag_kmajor(const char* tile, int rb, int s,
 }
 // MNMAJOR tile (row pitch PITCH bytes): 16 columns starting at cb (multiple of 16), k-step s:
 // two transposed reads (k = 8g..8g+3 and 8g+4..8g+7 of the 32-k step).
+// The reads are inline asm on purpose: hipcc treats the ds_read_tr builtin as a memory operation
+// that may alias the LDS-DMA of the NEXT tile and puts `s_waitcnt vmcnt(0)` in front of it, which
+// serialises the whole prefetch behind every fragment read (seen in the ISA of every MN-major
+// variant).  The price: the compiler does not know when the data arrives, so every consumer must
+// pass the fragments through lds_wait() first.
 template <int PITCH>
 __device__ __forceinline__ bf16x8_t frag_mnmajor(const char* tile, int cb, int s, int lane) {
   const int g = lane >> 4;
@@ -130,14 +135,17 @@ __device__ __forceinline__ bf16x8_t frag_mnmajor(const char* tile, int cb, int s
   const int kr = 32 * s + 8 * g + q;
   const int swz = q | ((g & 1) << 2);
   const int c = ((cb >> 3) + (p >> 1)) ^ (swz << 1);
-  const char* a0 = tile + kr * PITCH + c * 16 + (p & 1) * 8;
-  s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-      (__attribute__((address_space(3))) s16x4_t*)(lptr_t)a0);
-  s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-      (__attribute__((address_space(3))) s16x4_t*)(lptr_t)(a0 + 4 * PITCH));
+  const uint32_t a0 = (uint32_t)(uintptr_t)(lptr_t)(tile + kr * PITCH + c * 16 + (p & 1) * 8);
+  s16x4_t lo, hi;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a0));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(a0), "n"(4 * PITCH));
   typedef __attribute__((ext_vector_type(8))) short s16x8_t;
   s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   return __builtin_bit_cast(bf16x8_t, v);
+}
+// all outstanding LDS reads have returned; the "+v" ties make every later use of f wait for it
+__device__ __forceinline__ void lds_wait(bf16x8_t (&f)[4]) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]));
 }
 
 // XCD-aware tile rasterisation.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and
@@ -313,7 +321,7 @@ __device__ __forceinline__ void gemm_epilogue(const CaGemmDesc& d, f32x4_t (&acc
 }
 
 // ---- kernel S: 128x128 tile, 4 waves, 2 LDS stages, 2 blocks/CU (small / batched problems) ----
-template <int AL, int BL>
+template <int AL, int BL, bool KS>
 __global__ __launch_bounds__(256) void ca_gemm_kernel(const CaGemmDesc d) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -330,7 +338,7 @@ __global__ __launch_bounds__(256) void ca_gemm_kernel(const CaGemmDesc d) {
   const __bf16* B = (const __bf16*)d.B + z1 * d.sB1 + z2 * d.sB2;
 
   KMajorLoader<4> la_k, lb_k;
-  MNMajorLoader<4, 16> la_m, lb_m;
+  MNMajorLoader<4, 16, KS> la_m, lb_m;
   if (AL == CA_KMAJOR)
     la_k.init(A, d.lda, m0, d.M, wave, lane);
   else
@@ -383,6 +391,8 @@ __global__ __launch_bounds__(256) void ca_gemm_kernel(const CaGemmDesc d) {
       for (int j = 0; j < 4; ++j)
         bfr[j] = (BL == CA_KMAJOR) ? frag_kmajor(tb, wn * 64 + j * 16, s, lane)
                                    : frag_mnmajor<256>(tb, wn * 64 + j * 16, s, lane);
+      if (AL != CA_KMAJOR) lds_wait(af);
+      if (BL != CA_KMAJOR) lds_wait(bfr);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -405,7 +415,7 @@ __global__ __launch_bounds__(256) void ca_gemm_kernel(const CaGemmDesc d) {
 #define XSTAGE (2 * XTILE)
 #define X_LDS_BYTES (8 * 64 * EPI_PITCH * 4)  // 139264 >= 2 stages * 64 KiB
 
-template <int AL, int BL>
+template <int AL, int BL, bool KS>
 __global__ __launch_bounds__(512) void ca_gemm_kernel_x(const CaGemmDesc d) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -421,7 +431,7 @@ __global__ __launch_bounds__(512) void ca_gemm_kernel_x(const CaGemmDesc d) {
   const __bf16* B = (const __bf16*)d.B + z1 * d.sB1 + z2 * d.sB2;
 
   KMajorLoader<4> la_k, lb_k;
-  MNMajorLoader<4, 32> la_m, lb_m;
+  MNMajorLoader<4, 32, KS> la_m, lb_m;
   if (AL == CA_KMAJOR)
     la_k.init(A, d.lda, m0, d.M, wave, lane);
   else
@@ -458,7 +468,6 @@ __global__ __launch_bounds__(512) void ca_gemm_kernel_x(const CaGemmDesc d) {
     asm volatile("" ::: "memory");
     const bool more = kt + 1 < nk;
     char* nst = smem + ((kt + 1) & 1) * XSTAGE;
-    // the next tile's 8 LDS-DMA are issued two at a time in front of the four MFMA blocks
     auto issue_part = [&](int part) {
       if (!more) return;
       if (AL == CA_KMAJOR)
@@ -481,12 +490,23 @@ __global__ __launch_bounds__(512) void ca_gemm_kernel_x(const CaGemmDesc d) {
                                    : frag_mnmajor<512>(tb, wn * 64 + j * 16, s, lane);
 #pragma unroll
       for (int ih = 0; ih < 2; ++ih) {  // two halves of the wave's 8 m-tiles: 16 A registers live at a time
-        issue_part(s * 2 + ih);
+        // The next tile's 8 LDS-DMA go out as one burst per wave, the two halves of the workgroup half a
+        // K-step apart (waves 0-3 in front of MFMA block 0, waves 4-7 in front of block 2): the SIMD
+        // partners then alternate between issuing DMA and feeding the matrix pipe instead of doing
+        // both in lockstep (TN +20 %, NT/NN unchanged; profiles/r01_gemm_ablation.txt).
+        if (s * 2 + ih == (wave < 4 ? 0 : 2)) {
+          issue_part(0);
+          issue_part(1);
+          issue_part(2);
+          issue_part(3);
+        }
         bf16x8_t af[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
           af[i] = (AL == CA_KMAJOR) ? frag_kmajor(ta, wm * 128 + (ih * 4 + i) * 16, s, lane)
                                     : frag_mnmajor<512>(ta, wm * 128 + (ih * 4 + i) * 16, s, lane);
+        if (AL != CA_KMAJOR) lds_wait(af);
+        if (BL != CA_KMAJOR && ih == 0) lds_wait(bfr);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -714,8 +734,8 @@ __global__ __launch_bounds__(512) void ca_gemm_kernel_l(const CaGemmDesc d) {
 
 // ---- optional per-launch timing (bench.py's live roofline measurement) -----------------------
 // When enabled, every ca_gemm_bf16 launch is bracketed by two hipEvents on the launch stream and
-// its algorithmic FLOPs (2*M*N*K*batch) are recorded per template variant (index a_layout*2 +
-// b_layout) and kernel (S, L, X).  ca_prof_end synchronises the events and returns the totals.
+// its algorithmic FLOPs (2*M*N*K*batch) are recorded per template variant (index kernel*8 +
+// segmented-K*4 + a_layout*2 + b_layout; kernel 0 = S, 1 = L, 2 = X).  ca_prof_end synchronises the events and returns the totals.
 #include <vector>
 struct ProfRec {
   hipEvent_t e0, e1;
@@ -732,7 +752,7 @@ extern "C" int ca_prof_begin(void) {
 }
 extern "C" int ca_prof_end(double* ms, int64_t* count, double* flops) {
   g_prof_on = false;
-  for (int v = 0; v < 12; ++v) {
+  for (int v = 0; v < 24; ++v) {
     ms[v] = 0.0;
     count[v] = 0;
     flops[v] = 0.0;
@@ -770,7 +790,8 @@ extern "C" int ca_gemm_bf16(const CaGemmDesc* desc, void* stream) {
   hipEventRecord(r.e0, (hipStream_t)stream);
   const int rc = ca_gemm_launch(desc, stream);
   hipEventRecord(r.e1, (hipStream_t)stream);
-  r.variant = g_last_kind * 4 + (desc->a_layout ? 2 : 0) + (desc->b_layout ? 1 : 0);
+  r.variant = g_last_kind * 8 + ((desc->a_kseg > 0 || desc->b_kseg > 0) ? 4 : 0) + (desc->a_layout ? 2 : 0) +
+              (desc->b_layout ? 1 : 0);
   g_prof.push_back(r);
   return rc;
 }
@@ -818,21 +839,28 @@ static int ca_gemm_launch(const CaGemmDesc* desc, void* stream) {
   g_last_kind = use_x ? 2 : (use_l ? 1 : 0);
   if (use_x) {
     static bool xattr = false;
+    const bool ks = d.a_kseg > 0 || d.b_kseg > 0;
+#define XK(a, b, k) ca_gemm_kernel_x<a, b, k>
     if (!xattr) {
-      hipFuncSetAttribute((const void*)ca_gemm_kernel_x<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, X_LDS_BYTES);
-      hipFuncSetAttribute((const void*)ca_gemm_kernel_x<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, X_LDS_BYTES);
-      hipFuncSetAttribute((const void*)ca_gemm_kernel_x<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, X_LDS_BYTES);
-      hipFuncSetAttribute((const void*)ca_gemm_kernel_x<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, X_LDS_BYTES);
+      const void* fs[8] = {(const void*)XK(0, 0, false), (const void*)XK(0, 1, false), (const void*)XK(1, 0, false),
+                           (const void*)XK(1, 1, false), (const void*)XK(0, 0, true),  (const void*)XK(0, 1, true),
+                           (const void*)XK(1, 0, true),  (const void*)XK(1, 1, true)};
+      for (int i = 0; i < 8; ++i) hipFuncSetAttribute(fs[i], hipFuncAttributeMaxDynamicSharedMemorySize, X_LDS_BYTES);
       xattr = true;
     }
     dim3 grid(tile_grid<4, 8>(xtm, xtn), 1, (unsigned)nb);
     dim3 block(512);
-    switch (lay) {
-      case 0: hipLaunchKernelGGL((ca_gemm_kernel_x<0, 0>), grid, block, X_LDS_BYTES, s, d); break;
-      case 1: hipLaunchKernelGGL((ca_gemm_kernel_x<0, 1>), grid, block, X_LDS_BYTES, s, d); break;
-      case 2: hipLaunchKernelGGL((ca_gemm_kernel_x<1, 0>), grid, block, X_LDS_BYTES, s, d); break;
-      default: hipLaunchKernelGGL((ca_gemm_kernel_x<1, 1>), grid, block, X_LDS_BYTES, s, d); break;
+    switch (lay + (ks ? 4 : 0)) {
+      case 0: hipLaunchKernelGGL((XK(0, 0, false)), grid, block, X_LDS_BYTES, s, d); break;
+      case 1: hipLaunchKernelGGL((XK(0, 1, false)), grid, block, X_LDS_BYTES, s, d); break;
+      case 2: hipLaunchKernelGGL((XK(1, 0, false)), grid, block, X_LDS_BYTES, s, d); break;
+      case 3: hipLaunchKernelGGL((XK(1, 1, false)), grid, block, X_LDS_BYTES, s, d); break;
+      case 4: hipLaunchKernelGGL((XK(0, 0, true)), grid, block, X_LDS_BYTES, s, d); break;
+      case 5: hipLaunchKernelGGL((XK(0, 1, true)), grid, block, X_LDS_BYTES, s, d); break;
+      case 6: hipLaunchKernelGGL((XK(1, 0, true)), grid, block, X_LDS_BYTES, s, d); break;
+      default: hipLaunchKernelGGL((XK(1, 1, true)), grid, block, X_LDS_BYTES, s, d); break;
     }
+#undef XK
     CA_CHECK_LAUNCH("ca_gemm_bf16");
     return CA_OK;
   }
@@ -858,11 +886,16 @@ static int ca_gemm_launch(const CaGemmDesc* desc, void* stream) {
     dim3 grid(tile_grid<8, 8>(ntm, ntn), 1, (unsigned)nb);
     dim3 block(256);
     const size_t lds = LDS_BYTES;
-    switch (lay) {
-      case 0: hipLaunchKernelGGL((ca_gemm_kernel<0, 0>), grid, block, lds, s, d); break;
-      case 1: hipLaunchKernelGGL((ca_gemm_kernel<0, 1>), grid, block, lds, s, d); break;
-      case 2: hipLaunchKernelGGL((ca_gemm_kernel<1, 0>), grid, block, lds, s, d); break;
-      default: hipLaunchKernelGGL((ca_gemm_kernel<1, 1>), grid, block, lds, s, d); break;
+    const bool ks = d.a_kseg > 0 || d.b_kseg > 0;
+    switch (lay + (ks ? 4 : 0)) {
+      case 0: hipLaunchKernelGGL((ca_gemm_kernel<0, 0, false>), grid, block, lds, s, d); break;
+      case 1: hipLaunchKernelGGL((ca_gemm_kernel<0, 1, false>), grid, block, lds, s, d); break;
+      case 2: hipLaunchKernelGGL((ca_gemm_kernel<1, 0, false>), grid, block, lds, s, d); break;
+      case 3: hipLaunchKernelGGL((ca_gemm_kernel<1, 1, false>), grid, block, lds, s, d); break;
+      case 4: hipLaunchKernelGGL((ca_gemm_kernel<0, 0, true>), grid, block, lds, s, d); break;
+      case 5: hipLaunchKernelGGL((ca_gemm_kernel<0, 1, true>), grid, block, lds, s, d); break;
+      case 6: hipLaunchKernelGGL((ca_gemm_kernel<1, 0, true>), grid, block, lds, s, d); break;
+      default: hipLaunchKernelGGL((ca_gemm_kernel<1, 1, true>), grid, block, lds, s, d); break;
     }
   }
   CA_CHECK_LAUNCH("ca_gemm_bf16");

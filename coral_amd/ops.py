@@ -249,15 +249,17 @@ def prof_begin():
 
 
 def prof_end():
-    """-> list of 12 dicts (kernel S/L/X x layout NT, NN, TN, TT): ms, count, flops of the GEMM launches.
-    `kernel` is the symbol rocprofv3 reports for the same launches."""
-    ms, cnt, fl = (C.c_double * 12)(), (C.c_int64 * 12)(), (C.c_double * 12)()
+    """-> list of 24 dicts (kernel S/L/X x segmented-K x layout NT, NN, TN, TT): ms, count, flops of the
+    GEMM launches.  `kernel` is the symbol rocprofv3 reports for the same launches."""
+    ms, cnt, fl = (C.c_double * 24)(), (C.c_int64 * 24)(), (C.c_double * 24)()
     check(lib().ca_prof_end(ms, cnt, fl), "ca_prof_end")
     out = []
     for k, sym in enumerate(("ca_gemm_kernel", "ca_gemm_kernel_l", "ca_gemm_kernel_x")):
-        for v in range(4):
-            i = k * 4 + v
-            out.append(dict(kernel=f"void {sym}<{v >> 1}, {v & 1}>(CaGemmDesc)", ms=ms[i], count=cnt[i], flops=fl[i]))
+        for ks in range(2):
+            for v in range(4):
+                i = k * 8 + ks * 4 + v
+                targs = f"{v >> 1}, {v & 1}" if k == 1 else f"{v >> 1}, {v & 1}, {'true' if ks else 'false'}"
+                out.append(dict(kernel=f"void {sym}<{targs}>(CaGemmDesc)", ms=ms[i], count=cnt[i], flops=fl[i]))
     return out
 
 

@@ -97,11 +97,12 @@ int ca_gemm_bf16(const CaGemmDesc* desc, void* stream);
 
 /* Live kernel timing for bench.py's roofline line: between ca_prof_begin() and ca_prof_end()
  * every ca_gemm_bf16 launch is bracketed by hipEvents on its own stream.  ca_prof_end fills
- * three arrays of 12 entries indexed by kernel*4 + a_layout*2 + b_layout (kernel 0 = ca_gemm_kernel,
- * 1 = ca_gemm_kernel_l, 2 = ca_gemm_kernel_x): summed kernel milliseconds, launch count, summed
- * algorithmic FLOPs (2*M*N*K*batch).  Not for use inside graph capture. */
+ * three arrays of 24 entries indexed by kernel*8 + segmented*4 + a_layout*2 + b_layout (kernel 0 =
+ * ca_gemm_kernel, 1 = ca_gemm_kernel_l, 2 = ca_gemm_kernel_x; segmented = a_kseg or b_kseg set):
+ * summed kernel milliseconds, launch count, summed algorithmic FLOPs (2*M*N*K*batch).  Not for use
+ * inside graph capture. */
 /* Tuning/test hook: 0 = automatic kernel choice, 1 = force the 128x128 kernel, 2 = force the
- * 256x128 pipelined kernel. */
+ * 256x128 pipelined kernel, 3 = force the 256x256 kernel. */
 int ca_gemm_force_kernel(int which);
 int ca_prof_begin(void);
 int ca_prof_end(double* ms, int64_t* count, double* flops);
