@@ -209,6 +209,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-specaugment", action="store_true")
+    ap.add_argument("--gemm-breakdown", action="store_true", help="print the per-kernel GEMM timing table to stderr")
     ap.add_argument("--decode", action="store_true", help="whisper models: time greedy decoding instead of training")
     ap.add_argument("--decode-tokens", type=int, default=32)
     ap.add_argument("--grad-wire", default="bf16", choices=["bf16", "fp32"],
@@ -293,6 +294,11 @@ def main():
     tot_ms = sum(r["ms"] for r in prof)
     tot_fl = sum(r["flops"] for r in prof)
 
+    if rank == 0 and args.gemm_breakdown:
+        for r in sorted(prof, key=lambda r: -r["ms"]):
+            if r["count"]:
+                print(f"{r['kernel']:55s} {r['count'] // 2:5d} launches/step {r['ms'] / 2:8.2f} ms/step "
+                      f"{r['flops'] / (r['ms'] * 1e-3) / 1e12:7.1f} TFLOP/s", file=sys.stderr)
     if rank == 0:
         audio_s = world * B * args.seconds * args.steps
         step_ms = dt / args.steps * 1e3

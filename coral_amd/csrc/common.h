@@ -43,13 +43,32 @@ __device__ __forceinline__ unsigned short f2bf(float f) {
 }
 
 // exact (erf) GELU and its derivative, fp32
+// Exact-erf GELU ($TF activations "gelu" = F.gelu(approximate="none")) evaluated without libm's
+// branchy erff: erfc(u) = t (a1 + t (a2 + t (a3 + t (a4 + t a5)))) exp(-u^2), t = 1/(1 + p u), u = |x|/sqrt(2)
+// (Abramowitz & Stegun 7.1.26, |error| <= 1.5e-7 on erf).  Phi(x) is taken from the complementary
+// form on the negative side, so there is no 1 + erf cancellation: against the float64 value this
+// rounds to the same bf16 more often than torch's own fp32 GELU does (tools/dev notes in DESIGN.md §4.4).
+// ~14 VALU ops instead of ~50; the exp(-x^2/2) is shared with the derivative's pdf term.
+__device__ __forceinline__ void ca_gauss_cdf_pdf(float x, float& cdf, float& e) {
+  const float u = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, u, 1.0f));
+  float poly = fmaf(t, 1.061405429f, -1.453152027f);
+  poly = fmaf(t, poly, 1.421413741f);
+  poly = fmaf(t, poly, -0.284496736f);
+  poly = fmaf(t, poly, 0.254829592f);
+  e = __expf(-u * u);  // exp(-x^2/2)
+  const float half_erfc = 0.5f * t * poly * e;
+  cdf = x >= 0.f ? 1.0f - half_erfc : half_erfc;
+}
 __device__ __forceinline__ float gelu_erf(float x) {
-  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+  float cdf, e;
+  ca_gauss_cdf_pdf(x, cdf, e);
+  return x * cdf;
 }
 __device__ __forceinline__ float dgelu_erf(float x) {
-  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
-  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
-  return cdf + x * pdf;
+  float cdf, e;
+  ca_gauss_cdf_pdf(x, cdf, e);
+  return fmaf(x * 0.39894228040143267794f, e, cdf);
 }
 
 // ---- 64-lane wavefront reductions ----
@@ -78,22 +97,38 @@ __device__ __forceinline__ uint64_t ca_hash64(uint64_t seed, uint64_t idx) {
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
   return z ^ (z >> 31);
 }
-// Keep decision for element `idx` (a flat index): one 64-bit hash serves the 4 elements of an
-// aligned group (16 bits each), so the mask depends only on (seed, idx) -- identical in the forward
-// GELU epilogue and the backward GELU' epilogue -- at a quarter of the hashing cost.
+// Dropout keep decisions.  The mask of element `idx` (a flat index) depends only on (seed, idx), so the
+// forward GELU epilogue and the backward GELU' epilogue regenerate the same mask instead of storing
+// it.  One 32-bit integer hash (two multiply-xorshift rounds) plus one cheap second word serve the 4
+// elements of an aligned group, 16 bits each, compared against an integer threshold.
+__device__ __forceinline__ unsigned int ca_mix32(unsigned int x) {
+  x ^= x >> 16;
+  x *= 0x7FEB352Du;
+  x ^= x >> 15;
+  x *= 0x846CA68Bu;
+  x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ unsigned int ca_dropout_threshold(float p) { return (unsigned int)(p * 65536.0f); }
+__device__ __forceinline__ void ca_dropout_words(uint64_t seed, uint64_t group, unsigned int& w0, unsigned int& w1) {
+  const unsigned int s = (unsigned int)seed * 0x9E3779B9u + (unsigned int)(seed >> 32);
+  w0 = ca_mix32((unsigned int)group ^ s ^ ((unsigned int)(group >> 32) * 0x85EBCA6Bu));
+  w1 = w0 * 0xC2B2AE35u;
+  w1 ^= w1 >> 15;
+}
 __device__ __forceinline__ bool ca_dropout_keep(uint64_t seed, uint64_t idx, float p) {
-  const uint64_t h = ca_hash64(seed, idx >> 2);
-  const unsigned int bits = (unsigned int)(h >> (16 * (idx & 3))) & 0xFFFFu;
-  return (float)bits * (1.0f / 65536.0f) >= p;
+  unsigned int w0, w1;
+  ca_dropout_words(seed, idx >> 2, w0, w1);
+  const unsigned int w = (idx & 2) ? w1 : w0;
+  return ((w >> (16 * (idx & 1))) & 0xFFFFu) >= ca_dropout_threshold(p);
 }
 // the same decision for 4 consecutive elements starting at a multiple of 4 (one hash)
 __device__ __forceinline__ unsigned int ca_dropout_keep4(uint64_t seed, uint64_t idx4, float p) {
-  const uint64_t h = ca_hash64(seed, idx4 >> 2);
-  unsigned int m = 0;
-#pragma unroll
-  for (int e = 0; e < 4; ++e)
-    m |= ((float)((unsigned int)(h >> (16 * e)) & 0xFFFFu) * (1.0f / 65536.0f) >= p ? 1u : 0u) << e;
-  return m;
+  unsigned int w0, w1;
+  ca_dropout_words(seed, idx4 >> 2, w0, w1);
+  const unsigned int thr = ca_dropout_threshold(p);
+  return ((w0 & 0xFFFFu) >= thr ? 1u : 0u) | ((w0 >> 16) >= thr ? 2u : 0u) | ((w1 & 0xFFFFu) >= thr ? 4u : 0u) |
+         ((w1 >> 16) >= thr ? 8u : 0u);
 }
 
 // out[i] (+)= sum_p partial[p*stride + i]  (defined in norm.hip)

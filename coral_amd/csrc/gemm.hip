@@ -120,6 +120,16 @@ __device__ __forceinline__ bf16x8_t frag_kmajor(const char* tile, int rb, int s,
   const int c = (4 * s + (lane >> 4)) ^ ((r >> 1) & 7);
   return *(const bf16x8_t*)(tile + r * 128 + c * 16);
 }
+// same fragment, issued as inline asm (completion through lds_wait): lets a kernel order its reads
+// against its MFMA blocks by hand
+__device__ __forceinline__ bf16x8_t frag_kmajor_async(const char* tile, int rb, int s, int lane) {
+  const int r = rb + (lane & 15);
+  const int c = (4 * s + (lane >> 4)) ^ ((r >> 1) & 7);
+  const uint32_t a = (uint32_t)(uintptr_t)(lptr_t)(tile + r * 128 + c * 16);
+  bf16x8_t v;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(a));
+  return v;
+}
 // MNMAJOR tile (row pitch PITCH bytes): 16 columns starting at cb (multiple of 16), k-step s:
 // two transposed reads (k = 8g..8g+3 and 8g+4..8g+7 of the 32-k step).
 // The reads are inline asm on purpose: hipcc treats the ds_read_tr builtin as a memory operation
@@ -481,42 +491,64 @@ __global__ __launch_bounds__(512) void ca_gemm_kernel_x(const CaGemmDesc d) {
     };
     const char* ta = smem + (kt & 1) * XSTAGE;
     const char* tb = ta + XTILE;
+    // Four MFMA blocks per K-step (k-half s x m-half ih, 16 MFMAs each).  Fragments are double-buffered
+    // in registers: the reads of block b+1 are issued before the MFMAs of block b, so only the first
+    // block of a K-step waits on LDS latency.  The next tile's 8 LDS-DMA go out as one burst per wave,
+    // the two halves of the workgroup half a K-step apart (waves 0-3 in front of block 0, waves 4-7 in
+    // front of block 2): SIMD partners alternate between issuing DMA and feeding the matrix pipe
+    // instead of doing both in lockstep (TN +20 %; profiles/r01_gemm_ablation.txt).
+    auto burst = [&]() {
+      issue_part(0);
+      issue_part(1);
+      issue_part(2);
+      issue_part(3);
+    };
+    auto read_a = [&](int s, int ih, bf16x8_t (&af)[4]) {
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      bf16x8_t bfr[4];
+      for (int i = 0; i < 4; ++i)
+        af[i] = (AL == CA_KMAJOR) ? frag_kmajor_async(ta, wm * 128 + (ih * 4 + i) * 16, s, lane)
+                                  : frag_mnmajor<512>(ta, wm * 128 + (ih * 4 + i) * 16, s, lane);
+    };
+    auto read_b = [&](int s, bf16x8_t (&bf)[4]) {
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        bfr[j] = (BL == CA_KMAJOR) ? frag_kmajor(tb, wn * 64 + j * 16, s, lane)
-                                   : frag_mnmajor<512>(tb, wn * 64 + j * 16, s, lane);
+        bf[j] = (BL == CA_KMAJOR) ? frag_kmajor_async(tb, wn * 64 + j * 16, s, lane)
+                                  : frag_mnmajor<512>(tb, wn * 64 + j * 16, s, lane);
+    };
+    auto mma = [&](int ih, bf16x8_t (&af)[4], bf16x8_t (&bf)[4]) {
+      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int ih = 0; ih < 2; ++ih) {  // two halves of the wave's 8 m-tiles: 16 A registers live at a time
-        // The next tile's 8 LDS-DMA go out as one burst per wave, the two halves of the workgroup half a
-        // K-step apart (waves 0-3 in front of MFMA block 0, waves 4-7 in front of block 2): the SIMD
-        // partners then alternate between issuing DMA and feeding the matrix pipe instead of doing
-        // both in lockstep (TN +20 %, NT/NN unchanged; profiles/r01_gemm_ablation.txt).
-        if (s * 2 + ih == (wave < 4 ? 0 : 2)) {
-          issue_part(0);
-          issue_part(1);
-          issue_part(2);
-          issue_part(3);
-        }
-        bf16x8_t af[4];
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-          af[i] = (AL == CA_KMAJOR) ? frag_kmajor(ta, wm * 128 + (ih * 4 + i) * 16, s, lane)
-                                    : frag_mnmajor<512>(ta, wm * 128 + (ih * 4 + i) * 16, s, lane);
-        if (AL != CA_KMAJOR) lds_wait(af);
-        if (BL != CA_KMAJOR && ih == 0) lds_wait(bfr);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            acc[ih * 4 + i][j] =
-                __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[ih * 4 + i][j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-      }
-    }
+        for (int j = 0; j < 4; ++j)
+          acc[ih * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], acc[ih * 4 + i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    };
+    bf16x8_t A0[4], A1[4], B0[4], B1[4];
+    read_b(0, B0);
+    read_a(0, 0, A0);
+    if (wave < 4) burst();
+    lds_wait(B0);
+    lds_wait(A0);
+    read_a(0, 1, A1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(0, A0, B0);
+    __builtin_amdgcn_sched_barrier(0);
+    lds_wait(A1);
+    read_b(1, B1);
+    read_a(1, 0, A0);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(1, A1, B0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (wave >= 4) burst();
+    lds_wait(B1);
+    lds_wait(A0);
+    read_a(1, 1, A1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(0, A0, B1);
+    __builtin_amdgcn_sched_barrier(0);
+    lds_wait(A1);
+    mma(1, A1, B1);
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
