@@ -12,9 +12,8 @@
 // read with ds_read_b64_tr_b16 for the products that contract over the tile's rows).  Score tiles are
 // computed in the orientation whose accumulator registers ARE the next MFMA's A operand (the rows of a
 // 32-row step are permuted so that a lane group ends up with 8 consecutive contraction indices), so
-// probabilities never leave registers.  Softmax statistics use a first pass (row max and sum, merged
-// across the four lane groups with two shuffles); the second pass recomputes the scores and multiplies
-// by V with already-normalised probabilities (no running rescale of the output accumulators).
+// probabilities never leave registers.  The forward is one pass with a running maximum (online softmax);
+// the backward kernels recompute probabilities from the saved log-sum-exp.
 #include "common.h"
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -114,7 +113,7 @@ struct AttnArgs {
   int64_t ldo, sob;
   float* lse;                            // [B, H, Tqp]
   const int32_t* klen;                   // [B] or null
-  int H, Tq, Tk, hd, Tqp, causal;
+  int B, H, Tq, Tk, hd, Tqp, causal;
   float scale;
   // backward
   const unsigned short* dO;
@@ -126,7 +125,31 @@ struct AttnArgs {
 
 #define NEG_INF (-__builtin_inff())
 
+// XCD-aware placement.  Workgroups are dealt round-robin over the 8 XCDs by linear id, and each XCD has
+// its own L2.  All tiles of one (batch, head) stream the same K/V (or Q/dO) panels, so they are placed
+// on ONE XCD: the i-th workgroup of XCD x works on tile (i % ntile) of pair (i / ntile) * 8 + x.  With the
+// plain (tile, head, batch) grid every XCD fetched every panel from HBM (6.5x the algorithmic bytes in
+// the PMC counters); placement only affects speed.
+__device__ __forceinline__ bool attn_tile_of_block(int ntile, int H, int B, int& tile, int& h, int& b) {
+  const int L = blockIdx.x;
+  const int x = L & 7, i = L >> 3;
+  const int pair = (i / ntile) * 8 + x;
+  tile = i % ntile;
+  if (pair >= H * B) return false;
+  h = pair % H;
+  b = pair / H;
+  return true;
+}
+static inline unsigned attn_grid(int ntile, int H, int B) { return (unsigned)(((H * B + 7) / 8) * 8 * ntile); }
+
 // ---- forward ----------------------------------------------------------------------------------------
+// One pass over the key tiles with a running maximum (online softmax).  Scores are kept in log2 units
+// (s * scale * log2 e), so a probability costs one FMA and one v_exp_f32.  The running maximum of a
+// query is shared by the four lane groups that hold its keys (two xor-shuffles per tile); the output
+// accumulators, whose rows are queries 4g+e, pick up their rescale factor from the lane that owns the
+// query (one shuffle per row) and are only touched when some maximum in the wave moved.  Tiles that lie
+// fully inside the valid key range take a path without any per-element masking.
+#define NEG_BIG (-1.0e30f)
 template <int HDPV>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -136,113 +159,117 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, r = lane & 15;
-  const int h = blockIdx.y, b = blockIdx.z;
+  int tile, h, b;
+  if (!attn_tile_of_block((a.Tq + 63) / 64, a.H, a.B, tile, h, b)) return;
   const int hd = a.hd;
   const unsigned short* Q = a.Q + b * a.sqb + h * hd;
   const unsigned short* K = a.K + b * a.skb + h * hd;
   const unsigned short* V = a.V + b * a.svb + h * hd;
-  const int q0 = blockIdx.x * 64 + wave * 16;
+  const int q0 = tile * 64 + wave * 16;
   const int qi = q0 + r;  // this lane's query (column of the transposed score tile)
   const int qrow = qi < a.Tq ? qi : a.Tq - 1;
   int kl = a.Tk;
   if (a.klen) kl = a.klen[b] < kl ? a.klen[b] : kl;
-  const int nks = (hd + 31) / 32, nnb = (hd + 15) / 16;
+  // all HDPV/32 k-steps and HDPV/16 column blocks are computed: dims >= hd are zero in every LDS image
   bf16x8_t qf[NKS];
 #pragma unroll
   for (int ks = 0; ks < NKS; ++ks) qf[ks] = load_rowfrag(Q, a.ldq, qrow, ks, lane, hd);
-  const int ntile = (kl + 63) / 64;
-  const float scale = a.scale;
+  int ntile = (kl + 63) / 64;
+  if (a.causal && ntile > tile + 1) ntile = tile + 1;  // keys beyond the tile's last query are masked
+  const float c2 = a.scale * 1.44269504088896340736f;
 
-  // scores of one 16-key block (bb) of 32-key step s for this wave's 16 queries, transposed:
-  // lane holds keys kbase + 8g + 4bb + {0..3} of query qi
-  auto score_block = [&](int s, int bb) {
-    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-    const int row = 32 * s + rowperm(bb, r);
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks)
-      if (ks < nks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kimg_frag<64>(Kimg, row, ks, lane), qf[ks], acc, 0, 0, 0);
-    return acc;
-  };
-
-  // pass A: softmax statistics
-  float m = NEG_INF, l = 0.f;
-  for (int kt = 0; kt < ntile; ++kt) {
-    load_kmajor_image<64, HDPV>(Kimg, K, a.ldk, kt * 64, a.Tk, hd, wave, lane);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-      for (int bb = 0; bb < 2; ++bb) {
-        const f32x4_t acc = score_block(s, bb);
-        float mx = m;
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int key = kt * 64 + 32 * s + 8 * g + 4 * bb + e;
-          const bool ok = key < kl && (!a.causal || key <= qi);
-          v[e] = ok ? acc[e] * scale : NEG_INF;
-          mx = fmaxf(mx, v[e]);
-        }
-        if (mx > NEG_INF) {
-          float sum = l * __expf(m - mx);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) sum += __expf(v[e] - mx);
-          l = sum;
-          m = mx;
-        }
-      }
-    __syncthreads();
-  }
-  // merge the four lane groups that share a query
-#pragma unroll
-  for (int o = 16; o < 64; o <<= 1) {
-    const float m2 = __shfl_xor(m, o, 64), l2 = __shfl_xor(l, o, 64);
-    const float mn = fmaxf(m, m2);
-    if (mn > NEG_INF) l = l * __expf(m - mn) + l2 * __expf(m2 - mn);
-    m = mn;
-  }
-  const float lse = l > 0.f ? m + __logf(l) : __builtin_inff();  // +inf: nothing attended -> p = 0
-  if (g == 0 && qi < a.Tq && a.lse) a.lse[((int64_t)b * a.H + h) * a.Tqp + qi] = lse;
-
-  // pass B: O = P V with normalised probabilities
+  float m = NEG_BIG, l = 0.f;  // running max (log2 units, same in the 4 lanes of a query) / this lane's partial sum
   f32x4_t o[NNB];
 #pragma unroll
   for (int nb = 0; nb < NNB; ++nb) o[nb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
   for (int kt = 0; kt < ntile; ++kt) {
     load_kmajor_image<64, HDPV>(Kimg, K, a.ldk, kt * 64, a.Tk, hd, wave, lane);
     load_mnmajor_image<64, HDPV>(Vimg, V, a.ldv, kt * 64, a.Tk, hd, wave, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    // transposed scores of the 64 keys: block (s, bb) holds keys 32 s + 8 g + 4 bb + {0..3} of query qi
+    f32x4_t sc[4];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      float p[8];
+    for (int blk = 0; blk < 4; ++blk) {
+      f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+      const int row = 32 * (blk >> 1) + rowperm(blk & 1, r);
 #pragma unroll
-      for (int bb = 0; bb < 2; ++bb) {
-        const f32x4_t acc = score_block(s, bb);
+      for (int ks = 0; ks < NKS; ++ks)
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kimg_frag<64>(Kimg, row, ks, lane), qf[ks], acc, 0, 0, 0);
+      sc[blk] = acc;
+    }
+    const bool full = (kt * 64 + 64 <= kl) && !a.causal;  // uniform: no element of this tile is masked
+    if (!full) {
+#pragma unroll
+      for (int blk = 0; blk < 4; ++blk)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const int key = kt * 64 + 32 * s + 8 * g + 4 * bb + e;
+          const int key = kt * 64 + 32 * (blk >> 1) + 8 * g + 4 * (blk & 1) + e;
           const bool ok = key < kl && (!a.causal || key <= qi);
-          p[4 * bb + e] = ok ? __expf(acc[e] * scale - lse) : 0.f;
+          sc[blk][e] = ok ? sc[blk][e] : NEG_BIG;
         }
+    }
+    float tmax = fmaxf(fmaxf(sc[0][0], sc[0][1]), fmaxf(sc[0][2], sc[0][3]));
+#pragma unroll
+    for (int blk = 1; blk < 4; ++blk)
+      tmax = fmaxf(tmax, fmaxf(fmaxf(sc[blk][0], sc[blk][1]), fmaxf(sc[blk][2], sc[blk][3])));
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float m_new = fmaxf(m, tmax * c2);
+    const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+    float p[16];
+    float sum = 0.f;
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float pv = __builtin_amdgcn_exp2f(fmaf(sc[blk][e], c2, -m_new));
+        if (!full) pv = sc[blk][e] > 0.5f * NEG_BIG ? pv : 0.f;
+        p[4 * blk + e] = pv;
+        sum += pv;
       }
-      const bf16x8_t pf = pack8(p);
+    l = fmaf(l, alpha, sum);
+    if (__builtin_amdgcn_ballot_w64(m_new > m) != 0) {  // some query of this wave moved its maximum
+      float ar[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ar[e] = __shfl(alpha, 4 * g + e, 64);
 #pragma unroll
       for (int nb = 0; nb < NNB; ++nb)
-        if (nb < nnb) o[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, timg_frag<HDPV>(Vimg, s, nb, lane), o[nb], 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[nb][e] *= ar[e];
+    }
+    m = m_new;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      float ps[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ps[e] = p[8 * s + e];
+      const bf16x8_t pf = pack8(ps);
+#pragma unroll
+      for (int nb = 0; nb < NNB; ++nb)
+        o[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, timg_frag<HDPV>(Vimg, s, nb, lane), o[nb], 0, 0, 0);
     }
     __syncthreads();
   }
+  // total of the four lane groups that share a query; lse in natural-log units for the backward
+  l += __shfl_xor(l, 16, 64);
+  l += __shfl_xor(l, 32, 64);
+  const float lse = l > 0.f ? (m + __builtin_amdgcn_logf(l)) * 0.69314718055994530942f : __builtin_inff();
+  if (g == 0 && qi < a.Tq && a.lse) a.lse[((int64_t)b * a.H + h) * a.Tqp + qi] = lse;
+  const float inv = l > 0.f ? 1.0f / l : 0.f;  // nothing attended -> zero output
+  float ir[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) ir[e] = __shfl(inv, 4 * g + e, 64);
   unsigned short* O = a.O + b * a.sob + h * hd;
 #pragma unroll
   for (int nb = 0; nb < NNB; ++nb) {
     const int n = 16 * nb + r;
-    if (nb < nnb && n < hd) {
+    if (n < hd) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int q = q0 + 4 * g + e;
-        if (q < a.Tq) O[(int64_t)q * a.ldo + n] = f2bf(o[nb][e]);
+        if (q < a.Tq) O[(int64_t)q * a.ldo + n] = f2bf(o[nb][e] * ir[e]);
       }
     }
   }
@@ -287,7 +314,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, r = lane & 15;
-  const int h = blockIdx.y, b = blockIdx.z;
+  int tile, h, b;
+  if (!attn_tile_of_block((a.Tk + 63) / 64, a.H, a.B, tile, h, b)) return;
   const int hd = a.hd;
   const unsigned short* Q = a.Q + b * a.sqb + h * hd;
   const unsigned short* K = a.K + b * a.skb + h * hd;
@@ -295,12 +323,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a) {
   const unsigned short* dO = a.dO + b * a.sdob + h * hd;
   const float* lse = a.lse + ((int64_t)b * a.H + h) * a.Tqp;
   const float* Dq = a.Dq + ((int64_t)b * a.H + h) * a.Tqp;
-  const int k0 = blockIdx.x * 64 + wave * 16;
+  const int k0 = tile * 64 + wave * 16;
   const int key = k0 + r;  // this lane's key (column of the score tile)
   const int krow = key < a.Tk ? key : a.Tk - 1;
   int kl = a.Tk;
   if (a.klen) kl = a.klen[b] < kl ? a.klen[b] : kl;
-  const int nks = (hd + 31) / 32, nnb = (hd + 15) / 16;
+  // all HDPV/32 k-steps and HDPV/16 column blocks are computed: dims >= hd are zero in every LDS image
   bf16x8_t kf[NKS], vf[NKS];
 #pragma unroll
   for (int ks = 0; ks < NKS; ++ks) {
@@ -312,7 +340,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a) {
   for (int nb = 0; nb < NNB; ++nb) dk[nb] = dv[nb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   const float scale = a.scale;
   const int nstep = (a.Tq + 31) / 32;
-  const int s0 = a.causal ? (blockIdx.x * 64) / 32 : 0;  // queries before the tile's first key see none of it
+  const int s0 = a.causal ? (tile * 64) / 32 : 0;  // queries before the tile's first key see none of it
   for (int qs = s0; qs < nstep; ++qs) {
     load_kmajor_image<32, HDPV>(Qk, Q, a.ldq, qs * 32, a.Tq, hd, wave, lane);
     load_kmajor_image<32, HDPV>(dOk, dO, a.lddo, qs * 32, a.Tq, hd, wave, lane);
@@ -330,7 +358,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a) {
       const int row = rowperm(bb, r);
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks)
-        if (ks < nks) {
+        {
           sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kimg_frag<32>(Qk, row, ks, lane), kf[ks], sacc, 0, 0, 0);
           pacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kimg_frag<32>(dOk, row, ks, lane), vf[ks], pacc, 0, 0, 0);
         }
@@ -348,7 +376,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a) {
     const bf16x8_t pf = pack8(p), dsf = pack8(ds);
 #pragma unroll
     for (int nb = 0; nb < NNB; ++nb)
-      if (nb < nnb) {
+      {
         dv[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, timg_frag<HDPV>(dOt, 0, nb, lane), dv[nb], 0, 0, 0);
         dk[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsf, timg_frag<HDPV>(Qt, 0, nb, lane), dk[nb], 0, 0, 0);
       }
@@ -359,7 +387,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a) {
 #pragma unroll
   for (int nb = 0; nb < NNB; ++nb) {
     const int n = 16 * nb + r;
-    if (nb < nnb && n < hd) {
+    if (n < hd) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int kk = k0 + 4 * g + e;
@@ -384,18 +412,19 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, r = lane & 15;
-  const int h = blockIdx.y, b = blockIdx.z;
+  int tile, h, b;
+  if (!attn_tile_of_block((a.Tq + 63) / 64, a.H, a.B, tile, h, b)) return;
   const int hd = a.hd;
   const unsigned short* Q = a.Q + b * a.sqb + h * hd;
   const unsigned short* K = a.K + b * a.skb + h * hd;
   const unsigned short* V = a.V + b * a.svb + h * hd;
   const unsigned short* dO = a.dO + b * a.sdob + h * hd;
-  const int q0 = blockIdx.x * 64 + wave * 16;
+  const int q0 = tile * 64 + wave * 16;
   const int qi = q0 + r;
   const int qrow = qi < a.Tq ? qi : a.Tq - 1;
   int kl = a.Tk;
   if (a.klen) kl = a.klen[b] < kl ? a.klen[b] : kl;
-  const int nks = (hd + 31) / 32, nnb = (hd + 15) / 16;
+  // all HDPV/32 k-steps and HDPV/16 column blocks are computed: dims >= hd are zero in every LDS image
   bf16x8_t qf[NKS], dof[NKS];
 #pragma unroll
   for (int ks = 0; ks < NKS; ++ks) {
@@ -410,7 +439,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a) {
   const float scale = a.scale;
   int ntile = (kl + 63) / 64;
   if (a.causal) {
-    const int last = (blockIdx.x * 64 + 63) / 64 + 1;  // keys beyond the tile's last query are masked
+    const int last = (tile * 64 + 63) / 64 + 1;  // keys beyond the tile's last query are masked
     ntile = ntile < last ? ntile : last;
   }
   for (int kt = 0; kt < ntile; ++kt) {
@@ -428,7 +457,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a) {
         const int row = 32 * s + rowperm(bb, r);
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks)
-          if (ks < nks) {
+          {
             sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kimg_frag<64>(Kk, row, ks, lane), qf[ks], sacc, 0, 0, 0);
             pacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kimg_frag<64>(Vk, row, ks, lane), dof[ks], pacc, 0, 0, 0);
           }
@@ -442,7 +471,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a) {
       const bf16x8_t dsf = pack8(ds);
 #pragma unroll
       for (int nb = 0; nb < NNB; ++nb)
-        if (nb < nnb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsf, timg_frag<HDPV>(Kt, s, nb, lane), acc[nb], 0, 0, 0);
+        acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsf, timg_frag<HDPV>(Kt, s, nb, lane), acc[nb], 0, 0, 0);
     }
     __syncthreads();
   }
@@ -450,7 +479,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a) {
 #pragma unroll
   for (int nb = 0; nb < NNB; ++nb) {
     const int n = 16 * nb + r;
-    if (nb < nnb && n < hd) {
+    if (n < hd) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int q = q0 + 4 * g + e;
@@ -474,7 +503,7 @@ static AttnArgs to_args(const CaAttnDesc& d) {
   a.Q = (const unsigned short*)d.Q; a.K = (const unsigned short*)d.K; a.V = (const unsigned short*)d.V;
   a.ldq = d.ldq; a.ldk = d.ldk; a.ldv = d.ldv; a.sqb = d.sqb; a.skb = d.skb; a.svb = d.svb;
   a.O = (unsigned short*)d.O; a.ldo = d.ldo; a.sob = d.sob;
-  a.lse = d.lse; a.klen = d.klen; a.H = d.H; a.Tq = d.Tq; a.Tk = d.Tk; a.hd = d.hd; a.Tqp = d.Tqp;
+  a.lse = d.lse; a.klen = d.klen; a.B = d.B; a.H = d.H; a.Tq = d.Tq; a.Tk = d.Tk; a.hd = d.hd; a.Tqp = d.Tqp;
   a.causal = d.causal; a.scale = d.scale;
   a.dO = (const unsigned short*)d.dO; a.lddo = d.lddo; a.sdob = d.sdob; a.Dq = d.Dq;
   a.dQ = (unsigned short*)d.dQ; a.dK = (unsigned short*)d.dK; a.dV = (unsigned short*)d.dV;
@@ -486,7 +515,7 @@ extern "C" int ca_attn_fwd(const CaAttnDesc* desc, void* stream) {
   if (int rc = attn_check(desc, "ca_attn_fwd")) return rc;
   CA_CHECK_ARG(desc->O != nullptr, "ca_attn_fwd: null output");
   const AttnArgs a = to_args(*desc);
-  dim3 grid((desc->Tq + 63) / 64, desc->H, desc->B), block(256);
+  dim3 grid(attn_grid((desc->Tq + 63) / 64, desc->H, desc->B)), block(256);
   hipStream_t s = (hipStream_t)stream;
   if (desc->hd <= 64)
     hipLaunchKernelGGL((attn_fwd_kernel<64>), grid, block, 2 * 64 * 64 * 2, s, a);
@@ -506,7 +535,7 @@ extern "C" int ca_attn_bwd(const CaAttnDesc* desc, void* stream) {
   hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((unsigned)((groups * 16 + 255) / 256)), dim3(256), 0, s,
                      (const unsigned short*)desc->dO, desc->lddo, desc->sdob, (const unsigned short*)desc->O,
                      desc->ldo, desc->sob, (float*)desc->Dq, desc->H, desc->Tq, desc->Tqp, desc->hd, desc->B);
-  dim3 gk((desc->Tk + 63) / 64, desc->H, desc->B), gq((desc->Tq + 63) / 64, desc->H, desc->B), block(256);
+  dim3 gk(attn_grid((desc->Tk + 63) / 64, desc->H, desc->B)), gq(attn_grid((desc->Tq + 63) / 64, desc->H, desc->B)), block(256);
   if (desc->hd <= 64) {
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<64>), gk, block, 4 * 32 * 64 * 2, s, a);
     hipLaunchKernelGGL((attn_bwd_dq_kernel<64>), gq, block, 3 * 64 * 64 * 2, s, a);

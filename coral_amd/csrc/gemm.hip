@@ -390,25 +390,35 @@ __global__ __launch_bounds__(256) void ca_gemm_kernel(const CaGemmDesc d) {
 
     const char* ta = smem + (kt & 1) * STAGE_BYTES;
     const char* tb = ta + TILE_BYTES;
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      bf16x8_t af[4], bfr[4];
+    // two k-halves per K-step; the fragments of the second half are read before the MFMAs of the first
+    auto read_frags = [&](int s, bf16x8_t (&af)[4], bf16x8_t (&bf)[4]) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        af[i] = (AL == CA_KMAJOR) ? frag_kmajor(ta, wm * 64 + i * 16, s, lane)
+        af[i] = (AL == CA_KMAJOR) ? frag_kmajor_async(ta, wm * 64 + i * 16, s, lane)
                                   : frag_mnmajor<256>(ta, wm * 64 + i * 16, s, lane);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        bfr[j] = (BL == CA_KMAJOR) ? frag_kmajor(tb, wn * 64 + j * 16, s, lane)
-                                   : frag_mnmajor<256>(tb, wn * 64 + j * 16, s, lane);
-      if (AL != CA_KMAJOR) lds_wait(af);
-      if (BL != CA_KMAJOR) lds_wait(bfr);
+        bf[j] = (BL == CA_KMAJOR) ? frag_kmajor_async(tb, wn * 64 + j * 16, s, lane)
+                                  : frag_mnmajor<256>(tb, wn * 64 + j * 16, s, lane);
+    };
+    auto mma = [&](bf16x8_t (&af)[4], bf16x8_t (&bf)[4]) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-    }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
+    };
+    bf16x8_t a0[4], b0[4], a1[4], b1[4];
+    read_frags(0, a0, b0);
+    lds_wait(a0);
+    lds_wait(b0);
+    read_frags(1, a1, b1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(a0, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    lds_wait(a1);
+    lds_wait(b1);
+    mma(a1, b1);
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();  // all waves are done with the stages before the epilogue reuses the LDS
@@ -866,7 +876,10 @@ static int ca_gemm_launch(const CaGemmDesc* desc, void* stream) {
   const double xwaves = (double)xt / 256.0;
   const double xeff = xwaves / (double)((xt + 255) / 256);                       // last-wave occupancy
   const double xfill = ((double)d.M * d.N) / ((double)xtm * XBM * (double)xtn * XBN);  // tile padding waste
-  int use_x = (g_force_kernel == 0 && d.K >= 512 && xt >= 224 && xeff * xfill >= 0.80) ? 1 : 0;
+  // The MN-major x MN-major (weight-gradient) form gains most from the 256x256 tile (1.0 PFLOP/s against 0.63
+  // for S inside the training step), so it switches at a lower fill than the other forms.
+  const bool tn = d.a_layout == CA_MNMAJOR && d.b_layout == CA_MNMAJOR;
+  int use_x = (g_force_kernel == 0 && d.K >= 512 && xt >= (tn ? 160 : 224) && xeff * xfill >= (tn ? 0.60 : 0.80)) ? 1 : 0;
   if (g_force_kernel == 3) use_x = 1;
   g_last_kind = use_x ? 2 : (use_l ? 1 : 0);
   if (use_x) {
