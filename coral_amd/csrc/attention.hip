@@ -88,6 +88,55 @@ __device__ __forceinline__ bf16x8_t timg_frag(const char* img, int s, int nb, in
   s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   return __builtin_bit_cast(bf16x8_t, v);
 }
+// The same B operand (rows 32*s + 8g + {0..7} x 16 columns starting at 16*nb, transposed) read out of a K-MAJOR
+// image, so a tile that is needed in both orientations is staged once.  The K-major swizzle leaves a 2-way bank
+// conflict on these reads (rows r and r+2 of a lane group share banks), which costs less than a second image:
+// half the LDS-DMA instructions and half the LDS bytes per step.
+template <int ROWS>
+__device__ __forceinline__ bf16x8_t timg_frag_k(const char* img, int s, int nb, int lane) {
+  const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+  const int r0 = 32 * s + 8 * g + q, r1 = r0 + 4;
+  const int c = 2 * (nb & 3) + (p >> 1);
+  const char* base = img + (nb >> 2) * ROWS * 128 + (p & 1) * 8;
+  const char* a0 = base + r0 * 128 + ((c ^ ((r0 >> 1) & 7)) * 16);
+  const char* a1 = base + r1 * 128 + ((c ^ ((r1 >> 1) & 7)) * 16);
+  s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(lptr_t)a0);
+  s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(lptr_t)a1);
+  s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+// inline-asm variants: hipcc orders the ds_read_tr builtin behind every outstanding LDS-DMA (s_waitcnt vmcnt(0)),
+// which would serialise a prefetch of the next tile behind these reads.  The caller must run lds_wait_all() and
+// tie() the fragments before using them.
+__device__ __forceinline__ bf16x8_t tr_pair_async(const char* a0, const char* a1) {
+  s16x4_t lo, hi;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"((uint32_t)(uintptr_t)(lptr_t)a0));
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"((uint32_t)(uintptr_t)(lptr_t)a1));
+  s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+template <int ROWS>
+__device__ __forceinline__ bf16x8_t timg_frag_k_async(const char* img, int s, int nb, int lane) {
+  const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+  const int r0 = 32 * s + 8 * g + q, r1 = r0 + 4;
+  const int c = 2 * (nb & 3) + (p >> 1);
+  const char* base = img + (nb >> 2) * ROWS * 128 + (p & 1) * 8;
+  return tr_pair_async(base + r0 * 128 + ((c ^ ((r0 >> 1) & 7)) * 16), base + r1 * 128 + ((c ^ ((r1 >> 1) & 7)) * 16));
+}
+template <int HDPV>
+__device__ __forceinline__ bf16x8_t timg_frag_async(const char* img, int s, int nb, int lane) {
+  constexpr int PC = HDPV / 8;
+  constexpr int PITCH = HDPV * 2;
+  const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+  const int kr = 32 * s + 8 * g + q;
+  const int swz = q | ((g & 1) << 2);
+  const int c = ((2 * nb) + (p >> 1)) ^ ((swz << 1) & (PC - 1));
+  const char* a0 = img + kr * PITCH + c * 16 + (p & 1) * 8;
+  return tr_pair_async(a0, a0 + 4 * PITCH);
+}
+__device__ __forceinline__ void lds_wait_all() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void tie(bf16x8_t& f) { asm volatile("" : "+v"(f)); }
+
 // row of a 32-row step that lane-row r of block bb must read so that lane group g ends up holding the
 // contraction indices 8g .. 8g+7 (bb = 0: +0..3, bb = 1: +4..7)
 __device__ __forceinline__ int rowperm(int bb, int r) { return 8 * (r >> 2) + 4 * bb + (r & 3); }
@@ -124,6 +173,7 @@ struct AttnArgs {
 };
 
 #define NEG_INF (-__builtin_inff())
+#define LOG2E 1.44269504088896340736f
 
 // XCD-aware placement.  Workgroups are dealt round-robin over the 8 XCDs by linear id, and each XCD has
 // its own L2.  All tiles of one (batch, head) stream the same K/V (or Q/dO) panels, so they are placed
@@ -176,7 +226,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
   for (int ks = 0; ks < NKS; ++ks) qf[ks] = load_rowfrag(Q, a.ldq, qrow, ks, lane, hd);
   int ntile = (kl + 63) / 64;
   if (a.causal && ntile > tile + 1) ntile = tile + 1;  // keys beyond the tile's last query are masked
-  const float c2 = a.scale * 1.44269504088896340736f;
+  const float c2 = a.scale * LOG2E;
 
   float m = NEG_BIG, l = 0.f;  // running max (log2 units, same in the 4 lanes of a query) / this lane's partial sum
   f32x4_t o[NNB];
@@ -307,10 +357,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NKS = HDPV / 32, NNB = HDPV / 16;
   constexpr int IMG = 32 * HDPV * 2;
-  char* Qk = smem;            // K-major image of the 32-query tile   (for S = Q K^T)
-  char* dOk = smem + IMG;     // K-major image of dO                   (for dP = dO V^T)
-  char* Qt = smem + 2 * IMG;  // MN-major image of Q                   (for dK += dS^T Q)
-  char* dOt = smem + 3 * IMG; // MN-major image of dO                  (for dV += P^T dO)
+  char* Qk = smem;         // K-major image of the 32-query tile: S = Q K^T, and (read transposed) dK += dS^T Q
+  char* dOk = smem + IMG;  // K-major image of dO:                dP = dO V^T, and (read transposed) dV += P^T dO
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, r = lane & 15;
@@ -339,48 +387,109 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a) {
 #pragma unroll
   for (int nb = 0; nb < NNB; ++nb) dk[nb] = dv[nb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   const float scale = a.scale;
+  const float c2 = scale * LOG2E;
+  const bool full_keys = (tile * 64 + 64 <= kl) && !a.causal;
   const int nstep = (a.Tq + 31) / 32;
   const int s0 = a.causal ? (tile * 64) / 32 : 0;  // queries before the tile's first key see none of it
+  // Double-buffered: the images and the per-query statistics of step qs+1 are requested right after the barrier
+  // of step qs (one barrier per step: every wave has finished reading the other buffer when it arrives).
+  auto issue = [&](int qs, int buf) {
+    load_kmajor_image<32, HDPV>(Qk + buf * 2 * IMG, Q, a.ldq, qs * 32, a.Tq, hd, wave, lane);
+    load_kmajor_image<32, HDPV>(dOk + buf * 2 * IMG, dO, a.lddo, qs * 32, a.Tq, hd, wave, lane);
+  };
+  f32x4_t l0, l1, d0, d1;  // statistics of the current step: indices 8g .. 8g+7 are contiguous
+  if (s0 < nstep) {
+    issue(s0, 0);
+    l0 = *(const f32x4_t*)(lse + s0 * 32 + 8 * g);
+    l1 = *(const f32x4_t*)(lse + s0 * 32 + 8 * g + 4);
+    d0 = *(const f32x4_t*)(Dq + s0 * 32 + 8 * g);
+    d1 = *(const f32x4_t*)(Dq + s0 * 32 + 8 * g + 4);
+  }
   for (int qs = s0; qs < nstep; ++qs) {
-    load_kmajor_image<32, HDPV>(Qk, Q, a.ldq, qs * 32, a.Tq, hd, wave, lane);
-    load_kmajor_image<32, HDPV>(dOk, dO, a.lddo, qs * 32, a.Tq, hd, wave, lane);
-    load_mnmajor_image<32, HDPV>(Qt, Q, a.ldq, qs * 32, a.Tq, hd, wave, lane);
-    load_mnmajor_image<32, HDPV>(dOt, dO, a.lddo, qs * 32, a.Tq, hd, wave, lane);
-    // per-query statistics of this step: indices 8g .. 8g+7 are contiguous
-    const f32x4_t l0 = *(const f32x4_t*)(lse + qs * 32 + 8 * g), l1 = *(const f32x4_t*)(lse + qs * 32 + 8 * g + 4);
-    const f32x4_t d0 = *(const f32x4_t*)(Dq + qs * 32 + 8 * g), d1 = *(const f32x4_t*)(Dq + qs * 32 + 8 * g + 4);
+    const int buf = (qs - s0) & 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    float p[8], ds[8];
+    f32x4_t nl0 = l0, nl1 = l1, nd0 = d0, nd1 = d1;
+    if (qs + 1 < nstep) {
+      issue(qs + 1, buf ^ 1);
+      nl0 = *(const f32x4_t*)(lse + (qs + 1) * 32 + 8 * g);
+      nl1 = *(const f32x4_t*)(lse + (qs + 1) * 32 + 8 * g + 4);
+      nd0 = *(const f32x4_t*)(Dq + (qs + 1) * 32 + 8 * g);
+      nd1 = *(const f32x4_t*)(Dq + (qs + 1) * 32 + 8 * g + 4);
+    }
+    const char* Qi = Qk + buf * 2 * IMG;
+    const char* dOi = dOk + buf * 2 * IMG;
+    const bool full = full_keys && (qs * 32 + 32 <= a.Tq);  // uniform: nothing in this step is masked
+    f32x4_t sacc[2], pacc[2];
 #pragma unroll
     for (int bb = 0; bb < 2; ++bb) {
-      f32x4_t sacc = {0.f, 0.f, 0.f, 0.f}, pacc = {0.f, 0.f, 0.f, 0.f};
+      sacc[bb] = pacc[bb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
       const int row = rowperm(bb, r);
 #pragma unroll
-      for (int ks = 0; ks < NKS; ++ks)
-        {
-          sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kimg_frag<32>(Qk, row, ks, lane), kf[ks], sacc, 0, 0, 0);
-          pacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kimg_frag<32>(dOk, row, ks, lane), vf[ks], pacc, 0, 0, 0);
-        }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int qi = qs * 32 + 8 * g + 4 * bb + e;
-        const float ls = bb == 0 ? l0[e] : l1[e];
-        const float dq = bb == 0 ? d0[e] : d1[e];
-        const bool ok = qi < a.Tq && key < kl && (!a.causal || key <= qi);
-        const float pv = ok ? __expf(sacc[e] * scale - ls) : 0.f;
-        p[4 * bb + e] = pv;
-        ds[4 * bb + e] = ok ? pv * (pacc[e] - dq) * scale : 0.f;  // statistics of padded queries are not initialised
+      for (int ks = 0; ks < NKS; ++ks) {
+        sacc[bb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kimg_frag<32>(Qi, row, ks, lane), kf[ks], sacc[bb], 0, 0, 0);
+        pacc[bb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kimg_frag<32>(dOi, row, ks, lane), vf[ks], pacc[bb], 0, 0, 0);
       }
     }
-    const bf16x8_t pf = pack8(p), dsf = pack8(ds);
+    // transposed fragments of the first half of the columns fly while the softmax arithmetic runs
+    constexpr int HB = NNB / 2;
+    bf16x8_t fo[HB], fq[HB];
 #pragma unroll
-    for (int nb = 0; nb < NNB; ++nb)
-      {
-        dv[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, timg_frag<HDPV>(dOt, 0, nb, lane), dv[nb], 0, 0, 0);
-        dk[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsf, timg_frag<HDPV>(Qt, 0, nb, lane), dk[nb], 0, 0, 0);
+    for (int i = 0; i < HB; ++i) {
+      fo[i] = timg_frag_k_async<32>(dOi, 0, i, lane);
+      fq[i] = timg_frag_k_async<32>(Qi, 0, i, lane);
+    }
+    float p[8], ds[8];
+#pragma unroll
+    for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float ls2 = (bb == 0 ? l0[e] : l1[e]) * LOG2E;
+        const float dq = bb == 0 ? d0[e] : d1[e];
+        float pv = __builtin_amdgcn_exp2f(fmaf(sacc[bb][e], c2, -ls2));
+        float dsv = pv * (pacc[bb][e] - dq) * scale;
+        if (!full) {  // statistics of padded queries are not initialised: select, never multiply by a mask
+          const int qi = qs * 32 + 8 * g + 4 * bb + e;
+          const bool ok = qi < a.Tq && key < kl && (!a.causal || key <= qi);
+          pv = ok ? pv : 0.f;
+          dsv = ok ? dsv : 0.f;
+        }
+        p[4 * bb + e] = pv;
+        ds[4 * bb + e] = dsv;
       }
-    __syncthreads();
+    const bf16x8_t pf = pack8(p), dsf = pack8(ds);
+    lds_wait_all();
+#pragma unroll
+    for (int i = 0; i < HB; ++i) {
+      tie(fo[i]);
+      tie(fq[i]);
+    }
+    bf16x8_t go[HB], gq[HB];
+#pragma unroll
+    for (int i = 0; i < HB; ++i) {
+      go[i] = timg_frag_k_async<32>(dOi, 0, HB + i, lane);
+      gq[i] = timg_frag_k_async<32>(Qi, 0, HB + i, lane);
+    }
+#pragma unroll
+    for (int i = 0; i < HB; ++i) {
+      dv[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, fo[i], dv[i], 0, 0, 0);
+      dk[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsf, fq[i], dk[i], 0, 0, 0);
+    }
+    lds_wait_all();
+#pragma unroll
+    for (int i = 0; i < HB; ++i) {
+      tie(go[i]);
+      tie(gq[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < HB; ++i) {
+      dv[HB + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, go[i], dv[HB + i], 0, 0, 0);
+      dk[HB + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsf, gq[i], dk[HB + i], 0, 0, 0);
+    }
+    l0 = nl0;
+    l1 = nl1;
+    d0 = nd0;
+    d1 = nd1;
   }
   unsigned short* dK = a.dK + b * a.sdkb + h * hd;
   unsigned short* dV = a.dV + b * a.sdvb + h * hd;
@@ -406,9 +515,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NKS = HDPV / 32, NNB = HDPV / 16;
   constexpr int IMG = 64 * HDPV * 2;
-  char* Kk = smem;            // K-major image of the key tile   (S^T = K Q^T)
-  char* Vk = smem + IMG;      // K-major image of V              (dP^T = V dO^T)
-  char* Kt = smem + 2 * IMG;  // MN-major image of K             (dQ += dS K)
+  char* Kk = smem;        // K-major image of the key tile: S^T = K Q^T, and (read transposed) dQ += dS K
+  char* Vk = smem + IMG;  // K-major image of V:            dP^T = V dO^T
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, r = lane & 15;
@@ -431,12 +539,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a) {
     qf[ks] = load_rowfrag(Q, a.ldq, qrow, ks, lane, hd);
     dof[ks] = load_rowfrag(dO, a.lddo, qrow, ks, lane, hd);
   }
-  const float lse = a.lse[((int64_t)b * a.H + h) * a.Tqp + qrow];
+  const float lse2 = a.lse[((int64_t)b * a.H + h) * a.Tqp + qrow] * LOG2E;
   const float dq_row = a.Dq[((int64_t)b * a.H + h) * a.Tqp + qrow];
   f32x4_t acc[NNB];
 #pragma unroll
   for (int nb = 0; nb < NNB; ++nb) acc[nb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   const float scale = a.scale;
+  const float c2 = scale * LOG2E;
   int ntile = (kl + 63) / 64;
   if (a.causal) {
     const int last = (tile * 64 + 63) / 64 + 1;  // keys beyond the tile's last query are masked
@@ -445,9 +554,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a) {
   for (int kt = 0; kt < ntile; ++kt) {
     load_kmajor_image<64, HDPV>(Kk, K, a.ldk, kt * 64, a.Tk, hd, wave, lane);
     load_kmajor_image<64, HDPV>(Vk, V, a.ldv, kt * 64, a.Tk, hd, wave, lane);
-    load_mnmajor_image<64, HDPV>(Kt, K, a.ldk, kt * 64, a.Tk, hd, wave, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    const bool full = (kt * 64 + 64 <= kl) && !a.causal;  // uniform: no key of this tile is masked
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       float ds[8];
@@ -463,15 +572,19 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a) {
           }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const int key = kt * 64 + 32 * s + 8 * g + 4 * bb + e;
-          const bool ok = key < kl && (!a.causal || key <= qi);
-          ds[4 * bb + e] = ok ? __expf(sacc[e] * scale - lse) * (pacc[e] - dq_row) * scale : 0.f;
+          float dsv = __builtin_amdgcn_exp2f(fmaf(sacc[e], c2, -lse2)) * (pacc[e] - dq_row) * scale;
+          if (!full) {
+            const int key = kt * 64 + 32 * s + 8 * g + 4 * bb + e;
+            const bool ok = key < kl && (!a.causal || key <= qi);
+            dsv = ok ? dsv : 0.f;
+          }
+          ds[4 * bb + e] = dsv;
         }
       }
       const bf16x8_t dsf = pack8(ds);
 #pragma unroll
       for (int nb = 0; nb < NNB; ++nb)
-        acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsf, timg_frag<HDPV>(Kt, s, nb, lane), acc[nb], 0, 0, 0);
+        acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsf, timg_frag_k<64>(Kk, s, nb, lane), acc[nb], 0, 0, 0);
     }
     __syncthreads();
   }
@@ -538,10 +651,10 @@ extern "C" int ca_attn_bwd(const CaAttnDesc* desc, void* stream) {
   dim3 gk(attn_grid((desc->Tk + 63) / 64, desc->H, desc->B)), gq(attn_grid((desc->Tq + 63) / 64, desc->H, desc->B)), block(256);
   if (desc->hd <= 64) {
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<64>), gk, block, 4 * 32 * 64 * 2, s, a);
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<64>), gq, block, 3 * 64 * 64 * 2, s, a);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<64>), gq, block, 2 * 64 * 64 * 2, s, a);
   } else {
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<128>), gk, block, 4 * 32 * 128 * 2, s, a);
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<128>), gq, block, 3 * 64 * 128 * 2, s, a);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<128>), gq, block, 2 * 64 * 128 * 2, s, a);
   }
   CA_CHECK_LAUNCH("ca_attn_bwd");
   return CA_OK;
