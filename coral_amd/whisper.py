@@ -352,6 +352,75 @@ class WhisperEngine:
         self._last_logits = logits
         return logits.view(B, L, Vp)[:, :, :V]
 
+    # ---- incremental decoding (self-attention K|V cache) ----------------------------------------
+    def new_decode_cache(self, B: int, max_len: int):
+        """Per decoder layer a bf16 [B, max_len, 2d] buffer holding K|V of the tokens decoded so far — the
+        self-attention half of the cache HF keeps in `EncoderDecoderCache`
+        ($TF/models/whisper/modeling_whisper.py:312-335, generation with use_cache)."""
+        d = self.s.d_model
+        return dict(kv=[torch.zeros(B * max_len * 2 * d, dtype=torch.bfloat16, device=self.device)
+                        for _ in range(self.s.decoder_layers)], max_len=max_len, pos=0, B=B)
+
+    def decode_step(self, new_ids: torch.Tensor, cross_kv: list, cache: dict) -> torch.Tensor:
+        """Feed `new_ids` [B, n] (the forced prefix at position 0, then one token per call) through the
+        decoder, appending their K|V to `cache`; returns fp32 logits [B, V] of the last position.
+        Same arithmetic as `decode(...)[:, -1]`: each new query attends to all cached keys."""
+        s, st = self.s, self.store
+        p32, p16, o = st.p32, st.p16, st.off
+        dev = self.device
+        B, n = new_ids.shape
+        pos0, Lmax = cache["pos"], cache["max_len"]
+        if B != cache["B"] or pos0 + n > Lmax or pos0 + n > s.max_target_positions:
+            raise ValueError("decode cache too small / batch mismatch")
+        if pos0 > 0 and n != 1:
+            raise ValueError("after the first call tokens are appended one at a time")
+        d, f, H, Te = s.d_model, s.decoder_ffn_dim, s.decoder_attention_heads, s.max_source_positions
+        hd = d // H
+        M = B * n
+        w = self._decoder_ws(B, n)
+        ids = new_ids.to(dev, torch.int32).contiguous().view(-1)
+        pos = (torch.arange(n, dtype=torch.int32, device=dev) + pos0).repeat(B)
+        ops.embed_tokens(p16[o("model.decoder.embed_tokens.weight"):], p16[o("model.decoder.embed_positions.weight"):],
+                         ids, pos, w["h"][0], M, d)
+        Lk = pos0 + n
+        nqp = (n + 31) // 32 * 32
+        for l in range(s.decoder_layers):
+            p = f"model.decoder.layers.{l}."
+            h0, h1 = w["h"][0], w["h"][1]
+            ckv = cache["kv"][l]
+            ops.layernorm_fwd(h0, st.view(p + "self_attn_layer_norm.weight"), st.view(p + "self_attn_layer_norm.bias"),
+                              w["x"], None, M, d, s.layer_norm_eps)
+            ops.gemm(w["x"], p16, w["q"], M=M, N=d, K=d, lda=d, ldb=d, ldc=d, b_off=o(p + "self_attn.q_proj.weight"),
+                     bias=p32, bias_off=o(p + "self_attn.q_proj.bias"))
+            # K|V of the new tokens go straight into the cache rows (batch b, position pos0..)
+            ops.gemm(w["x"], p16, ckv, M=n, N=2 * d, K=d, lda=d, ldb=d, ldc=2 * d, c_off=pos0 * 2 * d,
+                     b_off=o(p + "self_attn.k_proj.weight"), bias=p32, bias_off=o(p + "self_attn.k_proj.bias__zero"),
+                     batch2=B, sA=(0, n * d), sC=(0, Lmax * 2 * d))
+            ops.attn_fwd(w["q"], ckv, ckv, w["ctx"], self._lse(B * H * nqp), B=B, H=H, Tq=n, Tk=Lk, hd=hd, Tqp=nqp,
+                         scale=hd ** -0.5, ldq=d, ldk=2 * d, ldv=2 * d, ldo=d, sqb=n * d, skb=Lmax * 2 * d,
+                         svb=Lmax * 2 * d, sob=n * d, k_off=0, v_off=d, causal=(n > 1))
+            ops.gemm(w["ctx"], p16, h1, M=M, N=d, K=d, lda=d, ldb=d, ldc=d, b_off=o(p + "self_attn.out_proj.weight"),
+                     bias=p32, bias_off=o(p + "self_attn.out_proj.bias"), epilogue=EPI_RESIDUAL, R=h0, ldr=d)
+            ops.layernorm_fwd(h1, st.view(p + "encoder_attn_layer_norm.weight"), st.view(p + "encoder_attn_layer_norm.bias"),
+                              w["x"], None, M, d, s.layer_norm_eps)
+            ops.gemm(w["x"], p16, w["q"], M=M, N=d, K=d, lda=d, ldb=d, ldc=d, b_off=o(p + "encoder_attn.q_proj.weight"),
+                     bias=p32, bias_off=o(p + "encoder_attn.q_proj.bias"))
+            ops.attn_fwd(w["q"], cross_kv[l], cross_kv[l], w["ctx"], self._lse(B * H * nqp), B=B, H=H, Tq=n, Tk=Te, hd=hd,
+                         Tqp=nqp, scale=hd ** -0.5, ldq=d, ldk=2 * d, ldv=2 * d, ldo=d, sqb=n * d, skb=Te * 2 * d,
+                         svb=Te * 2 * d, sob=n * d, k_off=0, v_off=d)
+            ops.gemm(w["ctx"], p16, h0, M=M, N=d, K=d, lda=d, ldb=d, ldc=d, b_off=o(p + "encoder_attn.out_proj.weight"),
+                     bias=p32, bias_off=o(p + "encoder_attn.out_proj.bias"), epilogue=EPI_RESIDUAL, R=h1, ldr=d)
+            self._ffn(w, h0, h1, p, M, d, f)
+            w["h"][0], w["h"][1] = h1, h0
+        ops.layernorm_fwd(w["h"][0], st.view("model.decoder.layer_norm.weight"), st.view("model.decoder.layer_norm.bias"),
+                          w["hf"], None, M, d, s.layer_norm_eps)
+        V, Vp = s.vocab_size, _r8(s.vocab_size)
+        rows = w["hf"].view(B, n, d)[:, -1, :].contiguous()
+        logits = torch.zeros(B, Vp, dtype=torch.float32, device=dev)
+        ops.gemm(rows, p16, logits, M=B, N=V, K=d, lda=d, ldb=d, ldc=Vp, b_off=o("model.decoder.embed_tokens.weight"))
+        cache["pos"] = Lk
+        return logits[:, :V]
+
     # ---- model-level API -------------------------------------------------------------------------
     def forward(self, input_features, labels=None, decoder_input_ids=None):
         """-> dict(loss, logits): `WhisperForConditionalGeneration.forward(input_features, labels)`."""
@@ -378,7 +447,7 @@ class WhisperEngine:
         return out
 
     def generate(self, input_features, prefix: list[int], max_length: int, suppress_tokens=None,
-                 begin_suppress_tokens=None) -> list[list[int]]:
+                 begin_suppress_tokens=None, use_cache: bool = True) -> list[list[int]]:
         """Greedy decoding with a forced prefix (<|sot|><|da|><|transcribe|><|notimestamps|> in CoRal's
         evaluation): masked argmax on the GPU (ca_argmax_masked), stop at EOS / max_length."""
         s, dev = self.s, self.device
@@ -395,11 +464,17 @@ class WhisperEngine:
         ids = torch.tensor([prefix] * B, dtype=torch.int64, device=dev)
         done = torch.zeros(B, dtype=torch.bool, device=dev)
         nxt = torch.empty(B, dtype=torch.int32, device=dev)
+        cache = self.new_decode_cache(B, max_length) if use_cache else None
+        feed = ids
         while ids.shape[1] < max_length and not bool(done.all()):
-            base = self.decode(ids, enc, kv, last_only=True)[:, 0, :].contiguous()  # fp32 [B, V]
+            if use_cache:
+                base = self.decode_step(feed, kv, cache).contiguous()  # fp32 [B, V]
+            else:
+                base = self.decode(ids, enc, kv, last_only=True)[:, 0, :].contiguous()
             mask = sup_begin if ids.shape[1] == len(prefix) else sup
             ops.argmax_masked(base, mask, nxt, B, V, V)
             step = torch.where(done, torch.full_like(nxt, s.pad_token_id), nxt).to(torch.int64)
             ids = torch.cat([ids, step[:, None]], 1)
+            feed = step[:, None]
             done |= step == s.eos_token_id
         return ids.tolist()

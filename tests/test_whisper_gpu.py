@@ -250,3 +250,32 @@ def test_whisper_finetune_entry_point(tmp_path):
     assert moved == ["model.decoder.embed_tokens.weight"], moved
     again = WhisperForConditionalGeneration.from_pretrained(str(mdir)).engine.state_dict()
     assert all(torch.equal(again[n], trained[n]) for n in trained)
+
+
+def test_whisper_cached_decode_matches_full_recompute(golden_dir):
+    """Incremental decoding with the self-attention K|V cache gives the logits of the teacher-forced
+    decoder at every position, and `generate` returns the same ids with and without the cache."""
+    from coral_amd.whisper import WhisperEngine, WhisperShape
+    from oracle import whisper_ref as w
+
+    kw, c = _tiny()
+    P = w.synth_params(c)
+    eng = WhisperEngine(WhisperShape(**kw), DEV)
+    eng.load_state_dict(P)
+    g = torch.Generator().manual_seed(11)
+    feats = torch.randn(3, 80, 3000, generator=g) * 0.5
+    ids = torch.randint(0, 150, (3, 9), generator=g)
+    enc = eng.encode(feats)
+    kv = eng.cross_kv(enc)
+    full = eng.decode(ids, enc, kv).float().cpu()  # [B, L, V]
+    cache = eng.new_decode_cache(3, 16)
+    got = [eng.decode_step(ids[:, :4], kv, cache).float().cpu()]
+    for t_ in range(4, 9):
+        got.append(eng.decode_step(ids[:, t_:t_ + 1], kv, cache).float().cpu())
+    torch.cuda.synchronize()
+    assert cache["pos"] == 9
+    for j, t_ in enumerate(range(3, 9)):
+        assert (got[j] - full[:, t_, :]).abs().max() <= 3e-2, t_
+    a = eng.generate(feats, [151, 3, 4, 5], 14, use_cache=True)
+    b = eng.generate(feats, [151, 3, 4, 5], 14, use_cache=False)
+    assert a == b
