@@ -209,6 +209,9 @@ def main():
     ap.add_argument("--seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-specaugment", action="store_true")
+    ap.add_argument("--from-host-pcm", action="store_true",
+                    help="feed every step from raw int16 PCM in host memory through the device input pipeline "
+                         "(pinned staging + side-stream H2D + on-GPU normalisation): the PCIe-inclusive rate")
     ap.add_argument("--gemm-breakdown", action="store_true", help="print the per-kernel GEMM timing table to stderr")
     ap.add_argument("--decode", action="store_true", help="whisper models: time greedy decoding instead of training")
     ap.add_argument("--decode-tokens", type=int, default=32)
@@ -257,8 +260,19 @@ def main():
 
     rng = np.random.RandomState(4242 + rank)
 
+    pipe = None
+    if args.from_host_pcm:
+        from coral_amd.input_pipeline import DeviceInputPipeline
+
+        pipe = DeviceInputPipeline(device, B, N, dtype=np.int16, padding="max_length")
+        pcm = [(np.clip(0.1 * rng.randn(N), -1, 1) * 32767).astype(np.int16) for _ in range(B)]
+        pipe.submit(pcm)
+
     def make_step_batch():
         mb = dict(batch)
+        if pipe is not None:  # this step's batch was staged during the previous step; stage the next one now
+            mb.update(pipe.get())
+            pipe.submit(pcm)
         if not args.no_specaugment:
             mt, mf = specaugment.sample_masks(B, T, shape.hidden_size, [T] * B, 0.5, 10, 0.5, 64, rng=rng)
             mb["mask_time"] = torch.from_numpy(mt)
@@ -322,6 +336,7 @@ def main():
                                    f"ffn={shape.intermediate_size}) CTC finetune, {B} x {args.seconds:g} s per GPU, "
                                    f"SpecAugment {'off' if args.no_specaugment else 'on'}, activation_dropout 0.1, "
                                    "layerdrop 0 (multi-GPU rule), fp32 master + AdamW + clip 1.0"
+                                   + (", inputs from host int16 PCM through the device input pipeline" if pipe is not None else "")
                                    + (f", gradient all-reduce on {args.grad_wire} wire, per-layer buckets overlapped with backward" if world > 1 else ""),
                        "global_batch": world * B, "frames_per_utt": T, "parallelism": f"dp{world}",
                        "loss": round(loss_val, 3)},

@@ -58,6 +58,97 @@ extern "C" int ca_wave_normalize(const float* x, const int32_t* lengths, float* 
   return CA_OK;
 }
 
+// ---- raw PCM -> model input (row N1 of SURVEY.md §8f) -------------------------------------------
+// One workgroup per utterance: int16 (or fp32) samples -> optional peak normalisation (x / max|x|,
+// `ta.PeakNormalization`, R/src/coral/data.py:710) -> zero-mean / unit-variance over the valid samples
+// ($TF/models/wav2vec2/feature_extraction_wav2vec2.py:77-97) -> padding 0 + attention mask
+// (:99-236 as used by R/src/coral/data_collators.py:72-77).  Three sweeps over the utterance (max and
+// sum, centred sum of squares, write), all from L2 after the first.
+template <typename T>
+__device__ __forceinline__ float pcm_load(const T* p, int64_t i);
+template <>
+__device__ __forceinline__ float pcm_load<float>(const float* p, int64_t i) { return p[i]; }
+template <>
+__device__ __forceinline__ float pcm_load<int16_t>(const int16_t* p, int64_t i) { return (float)p[i] * (1.0f / 32768.0f); }
+
+template <typename T>
+__global__ __launch_bounds__(1024) void pcm_prepare_kernel(const T* __restrict__ pcm, int64_t ld_in,
+                                                           const int32_t* __restrict__ lengths, float* __restrict__ y,
+                                                           int32_t* __restrict__ mask, int64_t N, int peak, int znorm,
+                                                           float eps) {
+  __shared__ float red[2][16];
+  __shared__ float bc[2];
+  const int b = blockIdx.x;
+  const T* xb = pcm + (int64_t)b * ld_in;
+  float* yb = y + (int64_t)b * N;
+  int64_t len = lengths ? lengths[b] : N;
+  if (len > N) len = N;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float s = 0.f, mx = 0.f;
+  for (int64_t i = threadIdx.x; i < len; i += 1024) {
+    const float v = pcm_load<T>(xb, i);
+    s += v;
+    mx = fmaxf(mx, fabsf(v));
+  }
+  s = wave_sum(s);
+  mx = wave_max(mx);
+  if (lane == 0) {
+    red[0][wave] = s;
+    red[1][wave] = mx;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f, m = 0.f;
+    for (int w = 0; w < 16; ++w) {
+      t += red[0][w];
+      m = fmaxf(m, red[1][w]);
+    }
+    const float g = (peak && m > 0.f) ? 1.0f / m : 1.0f;  // gain of the peak normalisation
+    bc[0] = len > 0 ? t / (float)len * g : 0.f;            // mean of the gained signal
+    bc[1] = g;
+  }
+  __syncthreads();
+  const float mean = bc[0], gain = bc[1];
+  float rstd = 1.f, shift = 0.f;
+  if (znorm) {
+    float s2 = 0.f;
+    for (int64_t i = threadIdx.x; i < len; i += 1024) {
+      const float d = pcm_load<T>(xb, i) * gain - mean;
+      s2 += d * d;
+    }
+    s2 = wave_sum(s2);
+    __syncthreads();
+    if (lane == 0) red[0][wave] = s2;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float t = 0.f;
+      for (int w = 0; w < 16; ++w) t += red[0][w];
+      bc[0] = len > 0 ? rsqrtf(t / (float)len + eps) : 0.f;
+    }
+    __syncthreads();
+    rstd = bc[0];
+    shift = mean;
+  }
+  for (int64_t i = threadIdx.x; i < N; i += 1024) {
+    yb[i] = i < len ? (pcm_load<T>(xb, i) * gain - shift) * rstd : 0.f;
+    if (mask) mask[(int64_t)b * N + i] = i < len ? 1 : 0;
+  }
+}
+
+extern "C" int ca_pcm_prepare(const void* pcm, int32_t is_int16, int64_t ld_in, const int32_t* lengths, float* y,
+                              int32_t* mask, int32_t B, int64_t N, int32_t peak_normalize, int32_t zero_mean_unit_var,
+                              float eps, void* stream) {
+  CA_CHECK_ARG(pcm && y && B > 0 && N > 0 && ld_in >= 0, "ca_pcm_prepare: bad argument");
+  if (is_int16)
+    hipLaunchKernelGGL(pcm_prepare_kernel<int16_t>, dim3(B), dim3(1024), 0, (hipStream_t)stream, (const int16_t*)pcm,
+                       ld_in, lengths, y, mask, N, peak_normalize, zero_mean_unit_var, eps);
+  else
+    hipLaunchKernelGGL(pcm_prepare_kernel<float>, dim3(B), dim3(1024), 0, (hipStream_t)stream, (const float*)pcm, ld_in,
+                       lengths, y, mask, N, peak_normalize, zero_mean_unit_var, eps);
+  CA_CHECK_LAUNCH("ca_pcm_prepare");
+  return CA_OK;
+}
+
 // ---- feature-encoder layer 0, fused ---------------------------------------------------------
 // One wave per output frame: lane owns 8 consecutive channels (C = 512), the k input samples
 // are wave-uniform.  LN statistics by wave shuffles; the frame is stored as one 1-KiB row.

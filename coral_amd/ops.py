@@ -17,7 +17,7 @@ from ._lib import (CaAttnDesc, EPI_DGELU, EPI_GELU, EPI_GELU_RESIDUAL, EPI_NONE,
 __all__ = ["KMAJOR", "MNMAJOR", "EPI_NONE", "EPI_GELU", "EPI_RESIDUAL", "EPI_DGELU",
            "EPI_GELU_RESIDUAL", "CoralAmdError"]
 
-_ELT = {torch.bfloat16: 2, torch.float32: 4, torch.int32: 4, torch.uint8: 1, torch.int64: 8}
+_ELT = {torch.bfloat16: 2, torch.float32: 4, torch.int32: 4, torch.uint8: 1, torch.int64: 8, torch.int16: 2}
 
 
 def _stream() -> int:
@@ -109,6 +109,14 @@ def dgelu_mul(dy, u, out, n):
 def wave_normalize(x, lengths, y, B, N, eps=1e-7):
     check(lib().ca_wave_normalize(_p(x), _p(lengths), _p(y), B, N, eps, _stream()),
           "ca_wave_normalize")
+
+
+def pcm_prepare(pcm, lengths, y, mask, B, N, ld_in, peak_normalize=False, zero_mean_unit_var=True, eps=1e-7):
+    """Raw PCM rows (int16 or fp32, device) -> normalised fp32 input_values + int32 attention_mask."""
+    if pcm.dtype not in (torch.int16, torch.float32):
+        raise CoralAmdError("pcm_prepare: PCM must be int16 or float32")
+    check(lib().ca_pcm_prepare(_p(pcm), int(pcm.dtype == torch.int16), ld_in, _p(lengths), _p(y), _p(mask), B, N,
+                               int(peak_normalize), int(zero_mean_unit_var), eps, _stream()), "ca_pcm_prepare")
 
 
 def conv0_fwd(x, w, bias, gamma, beta, y, B, N, Cn, k, stride, eps=1e-5):

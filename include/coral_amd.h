@@ -149,6 +149,16 @@ int ca_dgelu_mul(const void* dy, const void* u, void* out, int64_t n, void* stre
  * ---------------------------------------------------------------------------------- */
 int ca_wave_normalize(const float* x, const int32_t* lengths, float* y, int32_t B,
                       int64_t N, float eps, void* stream);
+/* ca_pcm_prepare: raw PCM batch -> model input on the device (replaces the per-example
+ *   host featurisation `processor(audio)` at R/src/coral/data.py:747 plus the collator's padding at
+ *   R/src/coral/data_collators.py:72-77).  pcm: int16 (is_int16 != 0, scaled by 1/32768) or fp32, B rows of
+ *   ld_in samples; lengths int32 [B] (NULL = full rows).  Optional peak normalisation (x / max|x|,
+ *   R/src/coral/data.py:710), optional zero-mean / unit-variance over the valid samples
+ *   ($TF/models/wav2vec2/feature_extraction_wav2vec2.py:77-97, eps 1e-7); y fp32 [B,N] with padding 0,
+ *   mask int32 [B,N] (attention_mask) or NULL. */
+int ca_pcm_prepare(const void* pcm, int32_t is_int16, int64_t ld_in, const int32_t* lengths, float* y,
+                   int32_t* mask, int32_t B, int64_t N, int32_t peak_normalize, int32_t zero_mean_unit_var,
+                   float eps, void* stream);
 int ca_conv0_ln_gelu_fwd(const float* x, const float* w, const float* bias,
                          const float* gamma, const float* beta, void* y, int32_t B,
                          int64_t N, int32_t C, int32_t k, int32_t stride, float eps,
