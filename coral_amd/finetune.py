@@ -65,6 +65,8 @@ def finetune(config, n_examples: int | None = None) -> dict:
             else:
                 metrics = evaluate_split(model, dataset["val"], collator, compute_metrics, B)
             history.append(dict(step=step + 1, **{f"val_{k}": v for k, v in metrics.items()}))
+    trainer.finish()  # the last optimiser step may still be running on the trainer's side stream
+    torch.cuda.synchronize()
     if is_main:
         model.save_pretrained(config.model_dir)
     return dict(history=history, model=model, processor=processor)

@@ -133,7 +133,7 @@ class DataParallelTrainer:
 
     def __init__(self, engine, learning_rate=1e-4, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.0,
                  max_grad_norm=1.0, warmup_steps=1000, max_steps=100_000, grad_accum=1,
-                 process_group=None, overlap=True, compress_grads=False):
+                 process_group=None, overlap=True, compress_grads=False, overlap_optimizer=True):
         self.model = engine                          # HF-shaped wrapper or the bare engine
         engine = getattr(engine, "engine", engine)  # the kernel-sequencing engine underneath
         self.engine = engine
@@ -155,6 +155,12 @@ class DataParallelTrainer:
         else:
             lo, hi = st.buckets["head"] if engine.freeze_base else (0, st.numel)
         self.train_range = (lo, hi)
+        # AdamW is HBM-bound, the next forward MFMA-bound: run the update bucket by bucket on a side stream
+        # and let the next forward wait per bucket (engine._await) instead of for the whole optimiser.
+        self.overlap_optimizer = (overlap_optimizer and st.p32.is_cuda and hasattr(engine, "_await")
+                                  and (lo, hi) == (0, st.numel))
+        self.opt_stream = torch.cuda.Stream(device=st.device) if self.overlap_optimizer else None
+        self.opt_done = None
 
     # ---- one optimiser step ----------------------------------------------------------------------
     def train_step(self, micro_batches) -> float | torch.Tensor:
@@ -163,12 +169,14 @@ class DataParallelTrainer:
         tensor (device) of this rank, scaled as Trainer does (1/grad_accum)."""
         eng = self.engine
         self.model.train()
-        eng.zero_grad(matrices=eng.freeze_base)
         eng.step_seed = self.opt_step * 64 + (int(os.environ.get("RANK", "0")) % 64)
         total = None
         n = len(micro_batches)
         for i, mb in enumerate(micro_batches):
             out = self.model(**mb)
+            if i == 0:  # the previous optimiser step may still be reading the gradients
+                self.finish()
+                eng.zero_grad(matrices=eng.freeze_base)
             last = i == n - 1
             hook = self.sync.start if (self.world > 1 and last and self.overlap) else None
             eng.backward(loss_scale=1.0 / n, overwrite_matrices=(i == 0), bucket_done=hook)
@@ -179,6 +187,12 @@ class DataParallelTrainer:
         self.optimizer_step()
         return total
 
+    def finish(self):
+        """Make the current stream wait for an optimiser step that is still running on the side stream."""
+        if self.opt_done is not None:
+            torch.cuda.current_stream().wait_event(self.opt_done)
+            self.opt_done = None
+
     def optimizer_step(self):
         eng, st = self.engine, self.engine.store
         lo, hi = self.train_range
@@ -186,11 +200,34 @@ class DataParallelTrainer:
         lr = cosine_lr(self.opt_step, self.lr, self.warmup_steps, self.max_steps)
         self.opt_step += 1
         ops.sumsq(st.g32[lo:hi], n, self.gnorm_sq, self.partial)
-        ops.adamw_step(st.p32[lo:hi], self.m[lo:hi], self.v[lo:hi], st.g32[lo:hi], st.p16[lo:hi], n, lr,
-                       self.betas[0], self.betas[1], self.eps, self.wd, self.opt_step,
-                       grad_scale=1.0 / self.world, max_norm=self.max_grad_norm, gnorm_sq=self.gnorm_sq)
-        if not eng.freeze_base:
-            eng.refresh_derived()
+
+        def update(a, b):
+            ops.adamw_step(st.p32[a:b], self.m[a:b], self.v[a:b], st.g32[a:b], st.p16[a:b], b - a, lr,
+                           self.betas[0], self.betas[1], self.eps, self.wd, self.opt_step,
+                           grad_scale=1.0 / self.world, max_norm=self.max_grad_norm, gnorm_sq=self.gnorm_sq)
+
+        if not self.overlap_optimizer:
+            update(lo, hi)
+            if not eng.freeze_base:
+                eng.refresh_derived()
+            return
+        # buckets in the order the next forward consumes them; one event per bucket
+        self.opt_stream.wait_stream(torch.cuda.current_stream())
+        events = {}
+        with torch.cuda.stream(self.opt_stream):
+            order = sorted(st.buckets.items(), key=lambda kv: kv[1][0])
+            for name, (a, b) in order:
+                update(a, b)
+                if name == "front":
+                    eng.refresh_derived()
+                ev = torch.cuda.Event()
+                ev.record(self.opt_stream)
+                events[name] = ev
+            if "front" not in events:
+                eng.refresh_derived()
+            self.opt_done = torch.cuda.Event()
+            self.opt_done.record(self.opt_stream)
+        eng.weights_ready = events
 
     def grad_norm(self) -> float:
         """Global gradient norm of the last step (after the DDP mean), host scalar."""

@@ -206,6 +206,16 @@ class Wav2Vec2CTCEngine:
     def grad_dict(self) -> dict:
         return {n: self.store.view(n, "g32") for n in self.store.names()}
 
+    # The trainer may still be updating parameter buckets on its optimiser stream when the next forward
+    # starts (trainer.py: the HBM-bound AdamW overlaps the MFMA-bound forward); the forward waits for a
+    # bucket's event right before the first kernel that reads its weights.
+    weights_ready: dict | None = None
+
+    def _await(self, bucket: str):
+        ev = self.weights_ready.get(bucket) if self.weights_ready else None
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+
     def zero_grad(self, matrices: bool = True):
         """Clear gradients.  matrices=False clears everything except the transformer layers' weight
         matrices (>99 % of the bytes): the next backward(overwrite_matrices=True) writes those
@@ -365,6 +375,7 @@ class Wav2Vec2CTCEngine:
             flen = torch.full((B,), T, dtype=torch.int32, device=dev)
         keep = [True] * L if layer_keep is None else list(layer_keep)
         w["flen"] = flen
+        self._await("front")
 
         # feature encoder
         p0 = "wav2vec2.feature_extractor.conv_layers.0."
@@ -410,6 +421,7 @@ class Wav2Vec2CTCEngine:
             if not keep[l]:
                 hout.copy_(hin)
                 continue
+            self._await(f"layer{l}")
             pl = f"wav2vec2.encoder.layers.{l}."
             ops.layernorm_fwd(hin, st.view(pl + "layer_norm.weight"), st.view(pl + "layer_norm.bias"),
                               w["x1"][l], w["st1"][l], M, d, eps)
@@ -430,6 +442,10 @@ class Wav2Vec2CTCEngine:
                      bias_off=o(pl + "feed_forward.output_dense.bias"), epilogue=EPI_RESIDUAL,
                      R=w["h1"][l], ldr=d)
         # final LN + lm_head (fp32 logits, ld = Vp)
+        self._await("head")
+        for l in range(L):  # dropped layers were not waited for above; the backward reads every layer's weights
+            if not keep[l]:
+                self._await(f"layer{l}")
         ops.layernorm_fwd(w["h"][L], st.view("wav2vec2.encoder.layer_norm.weight"),
                           st.view("wav2vec2.encoder.layer_norm.bias"), w["hf"], w["stf"], M, d, eps)
         V = s.vocab_size
