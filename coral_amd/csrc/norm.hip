@@ -247,8 +247,46 @@ __global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __re
   }
 }
 
+// few parts, long rows (split-K weight gradients): a plain streaming sum, 4 floats per thread, fixed order
+__global__ __launch_bounds__(256) void reduce_few_parts_kernel(const float* __restrict__ partial, int nparts,
+                                                               int64_t stride, int n, float* __restrict__ out,
+                                                               int accumulate) {
+  const int64_t i4 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i4 >= n) return;
+  if (i4 + 4 <= n) {
+    f32x4_t acc = *(const f32x4_t*)(partial + i4);
+    for (int p = 1; p < nparts; ++p) {
+      const f32x4_t v = *(const f32x4_t*)(partial + (int64_t)p * stride + i4);
+      acc[0] += v[0];
+      acc[1] += v[1];
+      acc[2] += v[2];
+      acc[3] += v[3];
+    }
+    if (accumulate) {
+      const f32x4_t o = *(const f32x4_t*)(out + i4);
+      acc[0] += o[0];
+      acc[1] += o[1];
+      acc[2] += o[2];
+      acc[3] += o[3];
+    }
+    *(f32x4_t*)(out + i4) = acc;
+  } else {
+    for (int64_t i = i4; i < n; ++i) {
+      float a = partial[i];
+      for (int p = 1; p < nparts; ++p) a += partial[(int64_t)p * stride + i];
+      out[i] = accumulate ? out[i] + a : a;
+    }
+  }
+}
+
 void ca_reduce_partials_launch(const float* partial, int nparts, int64_t stride, int n, float* out,
                                int accumulate, hipStream_t s) {
+  const bool aligned = ((uintptr_t)partial % 16) == 0 && ((uintptr_t)out % 16) == 0 && (stride % 4) == 0;
+  if (nparts <= 16 && n >= 65536 && aligned) {
+    hipLaunchKernelGGL(reduce_few_parts_kernel, dim3((unsigned)(((int64_t)n + 1023) / 1024)), dim3(256), 0, s, partial,
+                       nparts, stride, n, out, accumulate);
+    return;
+  }
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((n + 63) / 64), dim3(1024), 0, s, partial, nparts,
                      stride, n, out, accumulate);
 }

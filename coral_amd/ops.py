@@ -73,6 +73,37 @@ def gemm(A, B, Cout, *, M, N, K, lda, ldb, ldc, a_layout=KMAJOR, b_layout=KMAJOR
     check(lib().ca_gemm_bf16(C.byref(d), _stream()), "ca_gemm_bf16")
 
 
+_SPLITK_WS: dict = {}
+
+
+def wgrad_gemm(dY, X, G, *, M, N, K, lda, ldb, c_off, accumulate, a_off=0, b_off=0):
+    """Weight gradient G[c_off : c_off + M*N] (+)= dY^T X  (dY [K, M] and X [K, N] token-major bf16, G fp32
+    row-major [M, N]).  Shapes that would leave most of the chip idle (fewer 128x128 tiles than half the
+    workgroup slots) are split along K: the slices run as one batched GEMM into an fp32 workspace and a
+    deterministic second pass adds them up (no atomics: the result does not depend on scheduling)."""
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    xt = ((M + 255) // 256) * ((N + 255) // 256)
+    splits = 1
+    if xt < 160 and tiles <= 256:
+        for s in (8, 4, 2):
+            if tiles * s <= 512 and K % s == 0 and K // s >= 256:
+                splits = s
+                break
+    if splits == 1:
+        gemm(dY, X, G, M=M, N=N, K=K, a_layout=MNMAJOR, lda=lda, b_layout=MNMAJOR, ldb=ldb, ldc=N, c_off=c_off,
+             a_off=a_off, b_off=b_off, out_f32=True, accumulate=accumulate)
+        return
+    key = (G.device, splits * M * N)
+    ws = _SPLITK_WS.get(G.device)
+    if ws is None or ws.numel() < splits * M * N:
+        ws = torch.empty(splits * M * N, dtype=torch.float32, device=G.device)
+        _SPLITK_WS[G.device] = ws
+    Kc = K // splits
+    gemm(dY, X, ws, M=M, N=N, K=Kc, a_layout=MNMAJOR, lda=lda, b_layout=MNMAJOR, ldb=ldb, ldc=N, a_off=a_off,
+         b_off=b_off, out_f32=True, batch2=splits, sA=(0, Kc * lda), sB=(0, Kc * ldb), sC=(0, M * N))
+    reduce_rows(ws, splits, M * N, M * N, G[c_off:], accumulate=accumulate)
+
+
 def layernorm_fwd(x, gamma, beta, y, stats, rows, Cn, eps=1e-5, act=0, x_off=0, y_off=0):
     check(lib().ca_layernorm_fwd(_p(x, x_off), _p(gamma), _p(beta), _p(y, y_off), _p(stats), rows,
                                  Cn, eps, act, _stream()), "ca_layernorm_fwd")
