@@ -155,6 +155,20 @@ class WhisperEngine:
         self._enc_ws = {}
         self._dec_ws = {}
 
+    # The trainer may still be updating parameter buckets on its optimiser stream (trainer.py); every
+    # path that reads weights waits for the bucket events first.
+    weights_ready: dict | None = None
+
+    def _await(self, bucket: str):
+        ev = self.weights_ready.get(bucket) if self.weights_ready else None
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+
+    def _await_all(self):
+        if self.weights_ready:
+            for ev in self.weights_ready.values():
+                torch.cuda.current_stream().wait_event(ev)
+
     # ---- parameters ------------------------------------------------------------------------
     def exported_names(self):
         return [n for n in self.store.names() if not n.endswith("__zero")]
@@ -168,6 +182,7 @@ class WhisperEngine:
         self.refresh_compute_weights()
 
     def state_dict(self):
+        self._await_all()
         return {n: self.store.view(n).detach().clone() for n in self.exported_names()}
 
     def refresh_compute_weights(self):
@@ -225,6 +240,7 @@ class WhisperEngine:
 
     def encode(self, input_features: torch.Tensor) -> torch.Tensor:
         """input_features f32 [B, mels, 3000] -> encoder states bf16 [B, 1500, d]."""
+        self._await_all()
         s, st = self.s, self.store
         p32, p16, o = st.p32, st.p16, st.off
         x = input_features.to(self.device, torch.float32).contiguous()
@@ -269,6 +285,7 @@ class WhisperEngine:
     def cross_kv(self, enc: torch.Tensor) -> list[torch.Tensor]:
         """Per decoder layer: K|V projections of the encoder states, bf16 [B*1500, 2d] (computed once
         per clip, like the cross-attention cache at $TF/models/whisper/modeling_whisper.py:312-335)."""
+        self._await_all()
         s, st = self.s, self.store
         d = s.d_model
         B, T, _ = enc.shape
@@ -297,6 +314,7 @@ class WhisperEngine:
     def decode(self, input_ids: torch.Tensor, enc: torch.Tensor, kv: list | None = None, last_only: bool = False):
         """Teacher-forced decoder: input_ids [B, L] -> fp32 logits [B, L, V] (or [B, 1, V] for the
         last position only)."""
+        self._await_all()
         s, st = self.s, self.store
         p32, p16, o = st.p32, st.p16, st.off
         dev = self.device
@@ -365,6 +383,7 @@ class WhisperEngine:
         """Feed `new_ids` [B, n] (the forced prefix at position 0, then one token per call) through the
         decoder, appending their K|V to `cache`; returns fp32 logits [B, V] of the last position.
         Same arithmetic as `decode(...)[:, -1]`: each new query attends to all cached keys."""
+        self._await_all()
         s, st = self.s, self.store
         p32, p16, o = st.p32, st.p16, st.off
         dev = self.device

@@ -145,6 +145,7 @@ class WhisperTrainEngine(WhisperEngine):
         w = self._train_ws(B, L)
         Me, Md = B * T, B * L
         drop = self.activation_dropout if self.training else 0.0
+        self._await("front")
         # encoder stem
         for b in range(B):
             ops.transpose_f32_bf16(x[b], w["xin"][(b * (Tin + 2) + 1) * mels:], mels, Tin)
@@ -161,12 +162,15 @@ class WhisperTrainEngine(WhisperEngine):
         ek = [True] * s.encoder_layers if enc_keep is None else [bool(k) for k in enc_keep]
         dk = [True] * s.decoder_layers if dec_keep is None else [bool(k) for k in dec_keep]
         for l, (sa, ff) in enumerate(self.enc_blocks):
+            self._await(f"enc{l}")
             if not ek[l]:
                 w["eh"][2 * l + 2].copy_(w["eh"][2 * l])
                 continue
             sv_a, sv_f = w["enc_sv"][l]
             sa.forward(w["eh"][2 * l], w["eh"][2 * l + 1], sv_a, B, T)
             ff.forward(w["eh"][2 * l + 1], w["eh"][2 * l + 2], sv_f, Me, drop, self.step_seed * 4096 + l)
+        self._await("encf")
+        self._await("emb")
         ops.layernorm_fwd(w["eh"][-1], st.view("model.encoder.layer_norm.weight"), st.view("model.encoder.layer_norm.bias"),
                           w["enc_out"], w["enc_st"], Me, d, s.layer_norm_eps)
         # decoder
@@ -175,6 +179,7 @@ class WhisperTrainEngine(WhisperEngine):
         ops.embed_tokens(p16[o("model.decoder.embed_tokens.weight"):], p16[o("model.decoder.embed_positions.weight"):],
                          ids, pos, w["dh"][0], Md, d)
         for l, (sa, ca, ff) in enumerate(self.dec_blocks):
+            self._await(f"dec{l}")
             if not dk[l]:
                 w["dh"][3 * l + 3].copy_(w["dh"][3 * l])
                 continue
@@ -183,6 +188,7 @@ class WhisperTrainEngine(WhisperEngine):
             sa.forward(w["dh"][3 * l], w["dh"][3 * l + 1], sv_a, B, L)
             ca.forward(w["dh"][3 * l + 1], w["dh"][3 * l + 2], sv_c, B, L, T)
             ff.forward(w["dh"][3 * l + 2], w["dh"][3 * l + 3], sv_f, Md, drop, self.step_seed * 4096 + 2048 + l)
+        self._await_all()  # decf and anything not waited for above
         ops.layernorm_fwd(w["dh"][-1], st.view("model.decoder.layer_norm.weight"), st.view("model.decoder.layer_norm.bias"),
                           w["dec_out"], w["dec_st"], Md, d, s.layer_norm_eps)
         V, Vp = s.vocab_size, _r8(s.vocab_size)
