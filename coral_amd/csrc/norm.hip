@@ -321,8 +321,12 @@ extern "C" int ca_layernorm_bwd(const void* dy, const void* x, const float* gamm
   }
 #undef LN_BWD
   CA_CHECK_LAUNCH("ca_layernorm_bwd");
-  if (dgamma) ca_reduce_partials_launch(partial, g, (int64_t)2 * C, C, dgamma, 1, s);
-  if (dbeta) ca_reduce_partials_launch(partial + C, g, (int64_t)2 * C, C, dbeta, 1, s);
+  if (dgamma && dbeta == dgamma + C) {  // weight and bias gradients are adjacent in the flat buffer: one launch
+    ca_reduce_partials_launch(partial, g, (int64_t)2 * C, 2 * C, dgamma, 1, s);
+  } else {
+    if (dgamma) ca_reduce_partials_launch(partial, g, (int64_t)2 * C, C, dgamma, 1, s);
+    if (dbeta) ca_reduce_partials_launch(partial + C, g, (int64_t)2 * C, C, dbeta, 1, s);
+  }
   CA_CHECK_LAUNCH("ca_layernorm_bwd(reduce)");
   return CA_OK;
 }
