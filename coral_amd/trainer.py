@@ -80,17 +80,30 @@ class GradSync:
             buf = self.g16
         return torch.distributed.all_reduce(buf[lo:hi], op=torch.distributed.ReduceOp.SUM, group=self.pg, async_op=True)
 
-    def start(self, name: str):
+    def start(self, name: str, post=None):
+        """post(name): run on the communication stream as soon as the bucket's reduced gradients are in
+        the fp32 buffer (the trainer computes the bucket's squared norm there, off the critical path)."""
         if self.world == 1:
             return
         lo, hi = self.buckets[name]
         self.launched.append(name)
+
+        def go():
+            h = self._launch(lo, hi)
+            if post is None:
+                return h
+            h.wait()  # stream-level wait on a GPU, blocking on the CPU backends
+            if self.compress:
+                self._from_wire(lo, hi)
+            post(name)
+            return None
+
         if self.comm_stream is not None:
             self.comm_stream.wait_stream(torch.cuda.current_stream())  # the bucket's grads are enqueued
             with torch.cuda.stream(self.comm_stream):
-                h = self._launch(lo, hi)
+                h = go()
         else:
-            h = self._launch(lo, hi)
+            h = go()
         self._pending.append((h, lo, hi))
 
     def start_all(self):
@@ -100,6 +113,8 @@ class GradSync:
     def finish(self):
         def drain():
             for h, lo, hi in self._pending:
+                if h is None:
+                    continue  # completed on the communication stream in start()
                 h.wait()
                 if self.compress:
                     self._from_wire(lo, hi)
@@ -161,6 +176,10 @@ class DataParallelTrainer:
                                   and (lo, hi) == (0, st.numel))
         self.opt_stream = torch.cuda.Stream(device=st.device) if self.overlap_optimizer else None
         self.opt_done = None
+        # per-bucket squared gradient norms, computed on the side stream as the buckets complete
+        self.bucket_index = {name: i for i, name in enumerate(st.buckets)}
+        self.bucket_sq = torch.zeros(len(st.buckets), dtype=torch.float32, device=st.device)
+        self._norms_ready = False
 
     # ---- one optimiser step ----------------------------------------------------------------------
     def train_step(self, micro_batches) -> float | torch.Tensor:
@@ -178,7 +197,13 @@ class DataParallelTrainer:
                 self.finish()
                 eng.zero_grad(matrices=eng.freeze_base)
             last = i == n - 1
-            hook = self.sync.start if (self.world > 1 and last and self.overlap) else None
+            hook = None
+            self._norms_ready = False
+            if last and self.overlap_optimizer and (self.world == 1 or self.overlap):
+                hook = self._bucket_ready
+                self._norms_ready = True
+            elif self.world > 1 and last and self.overlap:
+                hook = self.sync.start
             eng.backward(loss_scale=1.0 / n, overwrite_matrices=(i == 0), bucket_done=hook)
             total = out.loss / n if total is None else total + out.loss / n
         if self.world > 1 and not self.overlap:
@@ -186,6 +211,21 @@ class DataParallelTrainer:
         self.sync.finish()
         self.optimizer_step()
         return total
+
+    def _bucket_sumsq(self, name: str):
+        lo, hi = self.engine.store.buckets[name]
+        i = self.bucket_index[name]
+        ops.sumsq(self.engine.store.g32[lo:hi], hi - lo, self.bucket_sq[i:i + 1], self.partial)
+
+    def _bucket_ready(self, name: str):
+        """Backward hook: all gradients of bucket `name` are enqueued.  N>1: all-reduce it on the
+        communication stream, then its squared norm there; N=1: squared norm on the optimiser stream."""
+        if self.world > 1:
+            self.sync.start(name, post=self._bucket_sumsq)
+            return
+        self.opt_stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.opt_stream):
+            self._bucket_sumsq(name)
 
     def finish(self):
         """Make the current stream wait for an optimiser step that is still running on the side stream."""
@@ -199,7 +239,13 @@ class DataParallelTrainer:
         n = hi - lo
         lr = cosine_lr(self.opt_step, self.lr, self.warmup_steps, self.max_steps)
         self.opt_step += 1
-        ops.sumsq(st.g32[lo:hi], n, self.gnorm_sq, self.partial)
+        if self._norms_ready:  # every bucket's squared norm was produced during the backward
+            if self.world == 1:
+                torch.cuda.current_stream().wait_stream(self.opt_stream)
+            self.gnorm_sq.copy_(self.bucket_sq.sum().reshape(1))
+            self._norms_ready = False
+        else:
+            ops.sumsq(st.g32[lo:hi], n, self.gnorm_sq, self.partial)
 
         def update(a, b):
             ops.adamw_step(st.p32[a:b], self.m[a:b], self.v[a:b], st.g32[a:b], st.p16[a:b], b - a, lr,
