@@ -778,6 +778,7 @@ __global__ __launch_bounds__(512) void ca_gemm_kernel_l(const CaGemmDesc d) {
 // When enabled, every ca_gemm_bf16 launch is bracketed by two hipEvents on the launch stream and
 // its algorithmic FLOPs (2*M*N*K*batch) are recorded per template variant (index kernel*8 +
 // segmented-K*4 + a_layout*2 + b_layout; kernel 0 = S, 1 = L, 2 = X).  ca_prof_end synchronises the events and returns the totals.
+#include <hip/hip_ext.h>
 #include <vector>
 struct ProfRec {
   hipEvent_t e0, e1;
@@ -786,6 +787,17 @@ struct ProfRec {
 };
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof;
+static hipEvent_t g_prof_e0 = nullptr, g_prof_e1 = nullptr;  // events of the launch being profiled
+// While profiling, the kernel is launched with start/stop events attached to the dispatch itself
+// (hipExtLaunchKernelGGL): they carry the kernel's own begin/end timestamps, like rocprofv3's kernel trace,
+// instead of the gaps between stream operations.
+#define CA_LAUNCH(kernel, grid, block, lds, stream, ...)                                                    \
+  do {                                                                                                       \
+    if (g_prof_e0)                                                                                           \
+      hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, g_prof_e0, g_prof_e1, 0, __VA_ARGS__);         \
+    else                                                                                                     \
+      hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                     \
+  } while (0)
 
 extern "C" int ca_prof_begin(void) {
   g_prof.clear();
@@ -829,9 +841,10 @@ extern "C" int ca_gemm_bf16(const CaGemmDesc* desc, void* stream) {
   hipEventCreate(&r.e0);
   hipEventCreate(&r.e1);
   r.flops = 2.0 * desc->M * (double)desc->N * desc->K * desc->batch1 * desc->batch2;
-  hipEventRecord(r.e0, (hipStream_t)stream);
+  g_prof_e0 = r.e0;
+  g_prof_e1 = r.e1;
   const int rc = ca_gemm_launch(desc, stream);
-  hipEventRecord(r.e1, (hipStream_t)stream);
+  g_prof_e0 = g_prof_e1 = nullptr;
   r.variant = g_last_kind * 8 + ((desc->a_kseg > 0 || desc->b_kseg > 0) ? 4 : 0) + (desc->a_layout ? 2 : 0) +
               (desc->b_layout ? 1 : 0);
   g_prof.push_back(r);
@@ -896,14 +909,14 @@ static int ca_gemm_launch(const CaGemmDesc* desc, void* stream) {
     dim3 grid(tile_grid<4, 8>(xtm, xtn), 1, (unsigned)nb);
     dim3 block(512);
     switch (lay + (ks ? 4 : 0)) {
-      case 0: hipLaunchKernelGGL((XK(0, 0, false)), grid, block, X_LDS_BYTES, s, d); break;
-      case 1: hipLaunchKernelGGL((XK(0, 1, false)), grid, block, X_LDS_BYTES, s, d); break;
-      case 2: hipLaunchKernelGGL((XK(1, 0, false)), grid, block, X_LDS_BYTES, s, d); break;
-      case 3: hipLaunchKernelGGL((XK(1, 1, false)), grid, block, X_LDS_BYTES, s, d); break;
-      case 4: hipLaunchKernelGGL((XK(0, 0, true)), grid, block, X_LDS_BYTES, s, d); break;
-      case 5: hipLaunchKernelGGL((XK(0, 1, true)), grid, block, X_LDS_BYTES, s, d); break;
-      case 6: hipLaunchKernelGGL((XK(1, 0, true)), grid, block, X_LDS_BYTES, s, d); break;
-      default: hipLaunchKernelGGL((XK(1, 1, true)), grid, block, X_LDS_BYTES, s, d); break;
+      case 0: CA_LAUNCH((XK(0, 0, false)), grid, block, X_LDS_BYTES, s, d); break;
+      case 1: CA_LAUNCH((XK(0, 1, false)), grid, block, X_LDS_BYTES, s, d); break;
+      case 2: CA_LAUNCH((XK(1, 0, false)), grid, block, X_LDS_BYTES, s, d); break;
+      case 3: CA_LAUNCH((XK(1, 1, false)), grid, block, X_LDS_BYTES, s, d); break;
+      case 4: CA_LAUNCH((XK(0, 0, true)), grid, block, X_LDS_BYTES, s, d); break;
+      case 5: CA_LAUNCH((XK(0, 1, true)), grid, block, X_LDS_BYTES, s, d); break;
+      case 6: CA_LAUNCH((XK(1, 0, true)), grid, block, X_LDS_BYTES, s, d); break;
+      default: CA_LAUNCH((XK(1, 1, true)), grid, block, X_LDS_BYTES, s, d); break;
     }
 #undef XK
     CA_CHECK_LAUNCH("ca_gemm_bf16");
@@ -921,10 +934,10 @@ static int ca_gemm_launch(const CaGemmDesc* desc, void* stream) {
     dim3 grid(tile_grid<4, 8>((d.M + LBM - 1) / LBM, (d.N + LBN - 1) / LBN), 1, (unsigned)nb);
     dim3 block(512);
     switch (lay) {
-      case 0: hipLaunchKernelGGL((ca_gemm_kernel_l<0, 0>), grid, block, L_LDS_BYTES, s, d); break;
-      case 1: hipLaunchKernelGGL((ca_gemm_kernel_l<0, 1>), grid, block, L_LDS_BYTES, s, d); break;
-      case 2: hipLaunchKernelGGL((ca_gemm_kernel_l<1, 0>), grid, block, L_LDS_BYTES, s, d); break;
-      default: hipLaunchKernelGGL((ca_gemm_kernel_l<1, 1>), grid, block, L_LDS_BYTES, s, d); break;
+      case 0: CA_LAUNCH((ca_gemm_kernel_l<0, 0>), grid, block, L_LDS_BYTES, s, d); break;
+      case 1: CA_LAUNCH((ca_gemm_kernel_l<0, 1>), grid, block, L_LDS_BYTES, s, d); break;
+      case 2: CA_LAUNCH((ca_gemm_kernel_l<1, 0>), grid, block, L_LDS_BYTES, s, d); break;
+      default: CA_LAUNCH((ca_gemm_kernel_l<1, 1>), grid, block, L_LDS_BYTES, s, d); break;
     }
   } else {
     const int ntm = (d.M + BM - 1) / BM, ntn = (d.N + BN - 1) / BN;
@@ -933,14 +946,14 @@ static int ca_gemm_launch(const CaGemmDesc* desc, void* stream) {
     const size_t lds = LDS_BYTES;
     const bool ks = d.a_kseg > 0 || d.b_kseg > 0;
     switch (lay + (ks ? 4 : 0)) {
-      case 0: hipLaunchKernelGGL((ca_gemm_kernel<0, 0, false>), grid, block, lds, s, d); break;
-      case 1: hipLaunchKernelGGL((ca_gemm_kernel<0, 1, false>), grid, block, lds, s, d); break;
-      case 2: hipLaunchKernelGGL((ca_gemm_kernel<1, 0, false>), grid, block, lds, s, d); break;
-      case 3: hipLaunchKernelGGL((ca_gemm_kernel<1, 1, false>), grid, block, lds, s, d); break;
-      case 4: hipLaunchKernelGGL((ca_gemm_kernel<0, 0, true>), grid, block, lds, s, d); break;
-      case 5: hipLaunchKernelGGL((ca_gemm_kernel<0, 1, true>), grid, block, lds, s, d); break;
-      case 6: hipLaunchKernelGGL((ca_gemm_kernel<1, 0, true>), grid, block, lds, s, d); break;
-      default: hipLaunchKernelGGL((ca_gemm_kernel<1, 1, true>), grid, block, lds, s, d); break;
+      case 0: CA_LAUNCH((ca_gemm_kernel<0, 0, false>), grid, block, lds, s, d); break;
+      case 1: CA_LAUNCH((ca_gemm_kernel<0, 1, false>), grid, block, lds, s, d); break;
+      case 2: CA_LAUNCH((ca_gemm_kernel<1, 0, false>), grid, block, lds, s, d); break;
+      case 3: CA_LAUNCH((ca_gemm_kernel<1, 1, false>), grid, block, lds, s, d); break;
+      case 4: CA_LAUNCH((ca_gemm_kernel<0, 0, true>), grid, block, lds, s, d); break;
+      case 5: CA_LAUNCH((ca_gemm_kernel<0, 1, true>), grid, block, lds, s, d); break;
+      case 6: CA_LAUNCH((ca_gemm_kernel<1, 0, true>), grid, block, lds, s, d); break;
+      default: CA_LAUNCH((ca_gemm_kernel<1, 1, true>), grid, block, lds, s, d); break;
     }
   }
   CA_CHECK_LAUNCH("ca_gemm_bf16");
