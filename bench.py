@@ -195,6 +195,16 @@ def whisper_bench(args, world, rank, device):
             "config": {"workload": f"{args.model} {mode}, {B} x 30 s per GPU, log-mel on GPU", "global_batch": world * B,
                        "label_len": int(labels.shape[1]), "parallelism": f"dp{world}"}}), flush=True)
     if world > 1:
+        if args.check_replicas and not args.decode:
+            torch.cuda.synchronize()
+            p = eng.store.p32
+            lo, hi = p.clone(), p.clone()
+            torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
+            torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
+            spread = float((hi - lo).abs().max())
+            if rank == 0:
+                print(json.dumps({"replica_param_spread": spread}), flush=True)
+            assert spread == 0.0, f"replicas diverged: {spread}"
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 
