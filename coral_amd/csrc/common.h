@@ -91,12 +91,6 @@ __device__ __forceinline__ uint32_t ca_hash32(uint64_t seed, uint64_t idx) {
   z = z ^ (z >> 31);
   return (uint32_t)(z >> 32);
 }
-__device__ __forceinline__ uint64_t ca_hash64(uint64_t seed, uint64_t idx) {
-  uint64_t z = idx + seed * 0x9E3779B97F4A7C15ull + 0x9E3779B97F4A7C15ull;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  return z ^ (z >> 31);
-}
 // Dropout keep decisions.  The mask of element `idx` (a flat index) depends only on (seed, idx), so the
 // forward GELU epilogue and the backward GELU' epilogue regenerate the same mask instead of storing
 // it.  One 32-bit integer hash (two multiply-xorshift rounds) plus one cheap second word serve the 4
