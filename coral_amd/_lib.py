@@ -99,6 +99,10 @@ SIGNATURES = {
     "ca_dgelu_mul": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
     "ca_reduce_rows_f32": (C.c_int, [_vp, _i32, _i64, _i32, _vp, _i32, _vp]),
     "ca_wave_normalize": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _f32, _vp]),
+    "ca_wave_scale": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _vp]),
+    "ca_fir_filter": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _i32, _i64, _vp]),
+    "ca_mix_noise": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _i32, _i64, _vp]),
+    "ca_white_noise": (C.c_int, [_vp, _i64, C.c_uint64, _vp]),
     "ca_pcm_prepare": (C.c_int, [_vp, _i32, _i64, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _f32, _vp]),
     "ca_conv0_ln_gelu_fwd": (
         C.c_int,

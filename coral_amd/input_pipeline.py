@@ -25,7 +25,8 @@ class DeviceInputPipeline:
     kind="whisper":  -> {"input_features": f32 [B, mels, 3000]} (30 s pad/trim + log-mel on the GPU)."""
 
     def __init__(self, device, batch: int, max_samples: int, kind: str = "wav2vec2", dtype=np.int16, depth: int = 2,
-                 padding: str = "longest", peak_normalize: bool = False, mel_filters: torch.Tensor | None = None):
+                 padding: str = "longest", peak_normalize: bool = False, mel_filters: torch.Tensor | None = None,
+                 augment=None):
         if not torch.cuda.is_available():
             raise ops.CoralAmdError("DeviceInputPipeline needs a GPU")
         if kind not in ("wav2vec2", "whisper"):
@@ -46,6 +47,7 @@ class DeviceInputPipeline:
         self.ready = [torch.cuda.Event() for _ in range(depth)]
         self.free = [torch.cuda.Event() for _ in range(depth)]  # the compute stream is done with slot i
         self.mel_filters = mel_filters
+        self.augment = augment  # coral_amd.augment.DeviceAugment or None (training only, like `augment_audio`)
         self._queue: list[tuple[int, int, int]] = []  # (slot, rows, longest)
         self._next = 0
 
@@ -81,18 +83,27 @@ class DeviceInputPipeline:
         k, rows, longest = self._queue.pop(0)
         cur = torch.cuda.current_stream()
         cur.wait_event(self.ready[k])
+        src, src_ld = self.dev[k], self.N
+        if self.augment is not None:
+            # normalise -> augment -> featurise, the order of R/src/coral/data.py:708-747
+            n_aug = longest if self.kind == "wav2vec2" else min(self.N, longest)
+            raw = torch.empty(rows, n_aug, dtype=torch.float32, device=self.device)
+            ops.pcm_prepare(self.dev[k], self.dev_len[k], raw, None, rows, n_aug, self.N, peak_normalize=True,
+                            zero_mean_unit_var=False)
+            src, src_ld = self.augment(raw, self.dev_len[k][:rows]), n_aug
+        peak = self.peak and self.augment is None
         if self.kind == "wav2vec2":
             n_out = self.N if self.padding == "max_length" else longest
             y = torch.empty(rows, n_out, dtype=torch.float32, device=self.device)
             mask = torch.empty(rows, n_out, dtype=torch.int32, device=self.device)
-            ops.pcm_prepare(self.dev[k], self.dev_len[k], y, mask, rows, n_out, self.N, peak_normalize=self.peak)
+            ops.pcm_prepare(src, self.dev_len[k], y, mask, rows, n_out, src_ld, peak_normalize=peak)
             out = {"input_values": y, "attention_mask": mask}
         else:
             from .whisper import HOP, N_SAMPLES
 
             wave = torch.empty(rows, N_SAMPLES, dtype=torch.float32, device=self.device)
             # pad / trim to 30 s; Whisper's extractor does no per-utterance normalisation
-            ops.pcm_prepare(self.dev[k], self.dev_len[k], wave, None, rows, N_SAMPLES, self.N, peak_normalize=self.peak,
+            ops.pcm_prepare(src, self.dev_len[k], wave, None, rows, N_SAMPLES, src_ld, peak_normalize=peak,
                             zero_mean_unit_var=False)
             mels = self.mel_filters.shape[0] if self.mel_filters.shape[0] in (80, 128) else self.mel_filters.shape[1]
             feats = torch.empty(rows, mels, N_SAMPLES // HOP, dtype=torch.float32, device=self.device)

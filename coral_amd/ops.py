@@ -150,6 +150,24 @@ def pcm_prepare(pcm, lengths, y, mask, B, N, ld_in, peak_normalize=False, zero_m
                                int(peak_normalize), int(zero_mean_unit_var), eps, _stream()), "ca_pcm_prepare")
 
 
+def wave_scale(x, scale, y, B, N):
+    check(lib().ca_wave_scale(_p(x), _p(scale), _p(y), B, N, _stream()), "ca_wave_scale")
+
+
+def fir_filter(x, lengths, taps, ntaps, mode, y, B, N, max_taps):
+    check(lib().ca_fir_filter(_p(x), _p(lengths), _p(taps), _p(ntaps), _p(mode), taps.shape[1], max_taps, _p(y), B, N,
+                              _stream()), "ca_fir_filter")
+
+
+def mix_noise(x, lengths, noise, noise_ld, noise_len, noise_off, snr_db, active, y, B, N):
+    check(lib().ca_mix_noise(_p(x), _p(lengths), _p(noise), noise_ld, noise_len, _p(noise_off), _p(snr_db), _p(active),
+                             _p(y), B, N, _stream()), "ca_mix_noise")
+
+
+def white_noise(out, n, seed):
+    check(lib().ca_white_noise(_p(out), n, seed, _stream()), "ca_white_noise")
+
+
 def conv0_fwd(x, w, bias, gamma, beta, y, B, N, Cn, k, stride, eps=1e-5):
     check(lib().ca_conv0_ln_gelu_fwd(_p(x), _p(w), _p(bias), _p(gamma), _p(beta), _p(y), B, N, Cn,
                                      k, stride, eps, _stream()), "ca_conv0_ln_gelu_fwd")

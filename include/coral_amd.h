@@ -159,6 +159,27 @@ int ca_wave_normalize(const float* x, const int32_t* lengths, float* y, int32_t 
 int ca_pcm_prepare(const void* pcm, int32_t is_int16, int64_t ld_in, const int32_t* lengths, float* y,
                    int32_t* mask, int32_t B, int64_t N, int32_t peak_normalize, int32_t zero_mean_unit_var,
                    float eps, void* stream);
+/* ------------------------------------------------------------------------------------
+ * On-device waveform augmentation (the chain torch_audiomentations builds at
+ * R/src/coral/data.py:708-738: Gain, AddBackgroundNoise, AddColoredNoise, Band/High/Low-pass, BandStop).
+ * Random draws and filter designs happen on the host (coral_amd/augment.py); these kernels are deterministic.
+ * x,y fp32 [B,N]; lengths int32 [B] (samples past the length are written as 0).
+ * ca_wave_scale:  y = x * scale[b].
+ * ca_fir_filter:  odd-length FIR centred on the output sample, edges replicated (julius low-pass filters);
+ *                 taps fp32 [B, ld_taps], ntaps int32 [B]; mode int32 [B]: 0 copy, 1 fir(x), 2 x - fir(x).
+ * ca_mix_noise:   y = x + noise * rms(x)/rms(noise) * 10^(-snr_db[b]/20) where active[b] != 0; noise rows of
+ *                 noise_len samples (row stride noise_ld, 0 = one shared row) are read cyclically from noise_off[b].
+ * ca_white_noise: n standard-normal samples from a counter hash of (seed, index).
+ * ---------------------------------------------------------------------------------- */
+int ca_wave_scale(const float* x, const float* scale, float* y, int32_t B, int64_t N, void* stream);
+int ca_fir_filter(const float* x, const int32_t* lengths, const float* taps, const int32_t* ntaps,
+                  const int32_t* mode, int64_t ld_taps, int32_t max_taps, float* y, int32_t B, int64_t N,
+                  void* stream);
+int ca_mix_noise(const float* x, const int32_t* lengths, const float* noise, int64_t noise_ld, int64_t noise_len,
+                 const int64_t* noise_off, const float* snr_db, const int32_t* active, float* y, int32_t B,
+                 int64_t N, void* stream);
+int ca_white_noise(float* out, int64_t n, uint64_t seed, void* stream);
+
 int ca_conv0_ln_gelu_fwd(const float* x, const float* w, const float* bias,
                          const float* gamma, const float* beta, void* y, int32_t B,
                          int64_t N, int32_t C, int32_t k, int32_t stride, float eps,

@@ -74,3 +74,21 @@ def test_whisper_pipeline_matches_processor():
     torch.cuda.synchronize()
     assert got.shape == want.shape == (4, 80, 3000)
     assert float((got - want).abs().max()) <= 1e-6
+
+
+def test_pipeline_with_augmentation_keeps_shapes_masks_and_normalisation():
+    from coral_amd.augment import DeviceAugment
+    from coral_amd.input_pipeline import DeviceInputPipeline
+
+    audios = _ragged(6, np.int16)
+    pipe = DeviceInputPipeline(DEV, batch=4, max_samples=32000, dtype=np.int16,
+                               augment=DeviceAugment(DEV, seed=1, p_coloured=1.0, p_filter=1.0))
+    pipe.submit(audios)
+    got = pipe.get()
+    torch.cuda.synchronize()
+    x, m = got["input_values"].cpu().numpy(), got["attention_mask"].cpu().numpy()
+    assert x.shape == (4, 23456) and np.isfinite(x).all()
+    for i, a in enumerate(audios):
+        n = len(a)
+        assert m[i].sum() == n and np.all(x[i, n:] == 0)
+        assert abs(x[i, :n].mean()) < 1e-3 and abs(x[i, :n].var() - 1.0) < 1e-2  # still zero-mean / unit-variance
