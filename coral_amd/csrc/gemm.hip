@@ -774,6 +774,74 @@ __global__ __launch_bounds__(512) void ca_gemm_kernel_l(const CaGemmDesc d) {
   gemm_epilogue(d, acc, smem, wave, lane, m0 + wm * 64, n0 + wn * 64, z, z1, z2);
 }
 
+// ---- skinny-M kernel: M <= 16 rows (one decoded token per clip) -------------------------------------
+// C[m, n] = epilogue(alpha * sum_k A[m, k] W[n, k]): a weight-streaming problem (every weight byte is used once),
+// so there is no LDS staging: each wave owns 16 output columns and a quarter of K, loads its W fragment
+// (16 rows x 64 B) and the matching A fragment straight from global memory into MFMA operands, eight k-steps
+// in flight; the four waves of a workgroup add their partial tiles through LDS and wave 0 runs the epilogue.
+// N/16 workgroups: 64 (N = 1024) to 3242 (the 51865-entry vocabulary).
+__global__ __launch_bounds__(256) void ca_gemm_skinny_kernel(const CaGemmDesc d) {
+  __shared__ float part[4][16 * 16];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n0 = blockIdx.x * 16;
+  const int r = lane & 15, g = lane >> 4;
+  const __bf16* A = (const __bf16*)d.A;
+  const __bf16* W = (const __bf16*)d.B;
+  const int nrow = n0 + r < d.N ? n0 + r : d.N - 1;
+  const int mrow = r < d.M ? r : d.M - 1;
+  const __bf16* wp = W + (int64_t)nrow * d.ldb + 8 * g;
+  const __bf16* ap = A + (int64_t)mrow * d.lda + 8 * g;
+  const int ksteps = (d.K + 31) / 32;
+  const int per = (ksteps + 3) / 4;
+  const int ks0 = wave * per, ks1 = (ks0 + per < ksteps) ? ks0 + per : ksteps;
+  f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+  const bf16x8_t zero = __builtin_bit_cast(bf16x8_t, (f32x4_t){0.f, 0.f, 0.f, 0.f});
+  for (int ks = ks0; ks < ks1; ks += 8) {
+    bf16x8_t wf[8], af[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int k = (ks + u) * 32 + 8 * g;
+      const bool ok = ks + u < ks1 && k < d.K;  // K is a multiple of 8 (lda/ldb rule), so a chunk is all-or-nothing
+      wf[u] = ok ? *(const bf16x8_t*)(wp + (int64_t)(ks + u) * 32) : zero;
+      af[u] = (ok && r < d.M) ? *(const bf16x8_t*)(ap + (int64_t)(ks + u) * 32) : zero;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u], af[u], acc, 0, 0, 0);
+  }
+  // D[n = 4g + e][m = r]: lane holds 4 consecutive n of row m
+#pragma unroll
+  for (int e = 0; e < 4; ++e) part[wave][r * 16 + 4 * g + e] = acc[e];
+  __syncthreads();
+  if (wave != 0) return;
+  const int m = r;
+  if (m >= d.M) return;
+  const int epi = d.epilogue;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int n = n0 + 4 * g + e;
+    if (n >= d.N) continue;
+    const int i = r * 16 + 4 * g + e;
+    float v = (part[0][i] + part[1][i]) + (part[2][i] + part[3][i]);
+    v = v * d.alpha + (d.bias ? d.bias[n] : 0.f);
+    float v2 = 0.f;
+    if (epi == CA_EPI_GELU || epi == CA_EPI_GELU_RESIDUAL) {
+      v2 = gelu_erf(v);
+      if (epi == CA_EPI_GELU_RESIDUAL) v2 += bf2f(((const unsigned short*)d.R)[(int64_t)m * d.ldr + n]);
+    } else if (epi == CA_EPI_RESIDUAL) {
+      v += bf2f(((const unsigned short*)d.R)[(int64_t)m * d.ldr + n]);
+    }
+    const int64_t off = (int64_t)m * d.ldc + n;
+    if (d.C) {
+      if (d.out_f32)
+        ((float*)d.C)[off] = d.accumulate ? ((float*)d.C)[off] + v : v;
+      else
+        ((unsigned short*)d.C)[off] = f2bf(d.accumulate ? bf2f(((unsigned short*)d.C)[off]) + v : v);
+    }
+    if ((epi == CA_EPI_GELU || epi == CA_EPI_GELU_RESIDUAL) && d.C2) ((unsigned short*)d.C2)[off] = f2bf(v2);
+  }
+}
+
 // ---- optional per-launch timing (bench.py's live roofline measurement) -----------------------
 // When enabled, every ca_gemm_bf16 launch is bracketed by two hipEvents on the launch stream and
 // its algorithmic FLOPs (2*M*N*K*batch) are recorded per template variant (index kernel*8 +
@@ -874,6 +942,14 @@ static int ca_gemm_launch(const CaGemmDesc* desc, void* stream) {
   const int lay = (d.a_layout ? 2 : 0) + (d.b_layout ? 1 : 0);
   CA_CHECK_ARG(d.a_layout == CA_KMAJOR || d.a_layout == CA_MNMAJOR, "ca_gemm_bf16: bad a_layout");
   CA_CHECK_ARG(d.b_layout == CA_KMAJOR || d.b_layout == CA_MNMAJOR, "ca_gemm_bf16: bad b_layout");
+  // Skinny M (greedy decoding: one token per clip): weight streaming without LDS staging.
+  if (g_force_kernel == 0 && d.M <= 16 && d.a_layout == CA_KMAJOR && d.b_layout == CA_KMAJOR && d.batch1 == 1 &&
+      d.batch2 == 1 && d.a_kseg == 0 && d.b_kseg == 0 && d.dropout_p == 0.f && d.epilogue != CA_EPI_DGELU) {
+    g_last_kind = 0;
+    CA_LAUNCH(ca_gemm_skinny_kernel, dim3((unsigned)((d.N + 15) / 16)), dim3(256), 0, s, d);
+    CA_CHECK_LAUNCH("ca_gemm_bf16");
+    return CA_OK;
+  }
   // Kernel choice: the 256x128 pipelined kernel runs one workgroup per CU, so it needs enough
   // tiles to fill the chip; small or heavily batched problems use the 128x128 kernel.
   const int64_t nb = (int64_t)d.batch1 * d.batch2;

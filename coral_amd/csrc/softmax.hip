@@ -167,42 +167,55 @@ extern "C" int ca_cross_entropy_fwd_bwd(const float* logits, const int32_t* labe
 }
 
 // ---- masked argmax (greedy generation) -------------------------------------------------------
-__global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ lg,
-                                                     const uint8_t* __restrict__ suppress,
-                                                     int32_t* __restrict__ out, int64_t rows,
-                                                     int V, int64_t ldv) {
+// one 1024-thread workgroup per row (greedy decoding has B rows of ~52 k logits: a wave per row would walk
+// 800 dependent loads); ties resolve to the lowest index like torch.argmax.
+__global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ lg,
+                                                      const uint8_t* __restrict__ suppress,
+                                                      int32_t* __restrict__ out, int64_t rows,
+                                                      int V, int64_t ldv) {
+  __shared__ float sb[16];
+  __shared__ int si[16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
-    const float* l = lg + row * ldv;
-    float best = NEG_INF;
-    int bi = 0x7fffffff;
-    for (int c = lane; c < V; c += 64) {
-      if (suppress && suppress[c]) continue;
-      const float v = l[c];
-      if (v > best || (v == best && c < bi)) {
-        best = v;
-        bi = c;
-      }
+  const int64_t row = blockIdx.x;
+  const float* l = lg + row * ldv;
+  float best = NEG_INF;
+  int bi = 0x7fffffff;
+  for (int c = threadIdx.x; c < V; c += 1024) {
+    if (suppress && suppress[c]) continue;
+    const float v = l[c];
+    if (v > best || (v == best && c < bi)) {
+      best = v;
+      bi = c;
     }
+  }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const float ob = __shfl_xor(best, o, 64);
-      const int oi = __shfl_xor(bi, o, 64);
-      if (ob > best || (ob == best && oi < bi)) {
-        best = ob;
-        bi = oi;
-      }
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ob = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ob > best || (ob == best && oi < bi)) {
+      best = ob;
+      bi = oi;
     }
-    if (lane == 0) out[row] = bi == 0x7fffffff ? 0 : bi;
+  }
+  if (lane == 0) {
+    sb[wave] = best;
+    si[wave] = bi;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 16; ++w)
+      if (sb[w] > best || (sb[w] == best && si[w] < bi)) {
+        best = sb[w];
+        bi = si[w];
+      }
+    out[row] = bi == 0x7fffffff ? 0 : bi;
   }
 }
 
 extern "C" int ca_argmax_masked(const float* logits, const uint8_t* suppress, int32_t* out,
                                 int64_t rows, int32_t V, int64_t ldv, void* stream) {
   CA_CHECK_ARG(logits && out && rows > 0 && V > 0 && ldv >= V, "ca_argmax_masked: bad argument");
-  int64_t g = (rows + 3) / 4;
-  if (g > 8192) g = 8192;
-  hipLaunchKernelGGL(argmax_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, logits,
+  hipLaunchKernelGGL(argmax_kernel, dim3((unsigned)rows), dim3(1024), 0, (hipStream_t)stream, logits,
                      suppress, out, rows, V, ldv);
   CA_CHECK_LAUNCH("ca_argmax_masked");
   return CA_OK;

@@ -440,6 +440,75 @@ class WhisperEngine:
         cache["pos"] = Lk
         return logits[:, :V]
 
+    # ---- one-token step with static shapes and pointers (capturable in a HIP graph) -----------------
+    def _graph_state(self, cache: dict, cross_kv: list, pad_id: int, eos_id: int):
+        """Static buffers of the per-token step: everything that changes from token to token (position,
+        cached length, token ids, finished flags) lives in device memory, so the launch sequence is
+        identical for every token and can be replayed as one graph."""
+        B, Lmax, dev = cache["B"], cache["max_len"], self.device
+        s = self.s
+        st = dict(
+            tok=torch.zeros(B, dtype=torch.int32, device=dev), pos=torch.zeros(B, dtype=torch.int32, device=dev),
+            klen=torch.zeros(B, dtype=torch.int32, device=dev), cur=torch.zeros(1, dtype=torch.int64, device=dev),
+            done=torch.zeros(B, dtype=torch.bool, device=dev), nxt=torch.zeros(B, dtype=torch.int32, device=dev),
+            out=torch.full((B, Lmax), pad_id, dtype=torch.int64, device=dev),
+            logits=torch.zeros(B, _r8(s.vocab_size), dtype=torch.float32, device=dev),
+            kvnew=torch.zeros(B * 2 * s.d_model, dtype=torch.bfloat16, device=dev),
+            rows=torch.arange(B, device=dev), pad=torch.full((B,), pad_id, dtype=torch.int32, device=dev),
+            eos=eos_id, cross=cross_kv)
+        return st
+
+    def _token_step(self, cache: dict, g: dict, suppress: torch.Tensor):
+        """Decode the token in g["tok"] at position g["pos"], pick the next one (masked argmax), record it."""
+        s, st = self.s, self.store
+        p32, p16, o = st.p32, st.p16, st.off
+        B, Lmax = cache["B"], cache["max_len"]
+        d, f, H, Te = s.d_model, s.decoder_ffn_dim, s.decoder_attention_heads, s.max_source_positions
+        hd = d // H
+        w = self._decoder_ws(B, 1)
+        ops.embed_tokens(p16[o("model.decoder.embed_tokens.weight"):], p16[o("model.decoder.embed_positions.weight"):],
+                         g["tok"], g["pos"], w["h"][0], B, d)
+        h0, h1 = w["h"][0], w["h"][1]
+        for l in range(s.decoder_layers):
+            p = f"model.decoder.layers.{l}."
+            ckv = cache["kv"][l]
+            ops.layernorm_fwd(h0, st.view(p + "self_attn_layer_norm.weight"), st.view(p + "self_attn_layer_norm.bias"),
+                              w["x"], None, B, d, s.layer_norm_eps)
+            ops.gemm(w["x"], p16, w["q"], M=B, N=d, K=d, lda=d, ldb=d, ldc=d, b_off=o(p + "self_attn.q_proj.weight"),
+                     bias=p32, bias_off=o(p + "self_attn.q_proj.bias"))
+            ops.gemm(w["x"], p16, g["kvnew"], M=B, N=2 * d, K=d, lda=d, ldb=d, ldc=2 * d,
+                     b_off=o(p + "self_attn.k_proj.weight"), bias=p32, bias_off=o(p + "self_attn.k_proj.bias__zero"))
+            # append at the device-side position (plain indexed copy: the position is data, not a launch argument)
+            ckv.view(B, Lmax, 2 * d)[g["rows"], g["pos"].long()] = g["kvnew"].view(B, 2 * d)
+            ops.attn_fwd(w["q"], ckv, ckv, w["ctx"], self._lse(B * H * 32), B=B, H=H, Tq=1, Tk=Lmax, hd=hd, Tqp=32,
+                         scale=hd ** -0.5, ldq=d, ldk=2 * d, ldv=2 * d, ldo=d, sqb=d, skb=Lmax * 2 * d,
+                         svb=Lmax * 2 * d, sob=d, k_off=0, v_off=d, klen=g["klen"])
+            ops.gemm(w["ctx"], p16, h1, M=B, N=d, K=d, lda=d, ldb=d, ldc=d, b_off=o(p + "self_attn.out_proj.weight"),
+                     bias=p32, bias_off=o(p + "self_attn.out_proj.bias"), epilogue=EPI_RESIDUAL, R=h0, ldr=d)
+            ops.layernorm_fwd(h1, st.view(p + "encoder_attn_layer_norm.weight"), st.view(p + "encoder_attn_layer_norm.bias"),
+                              w["x"], None, B, d, s.layer_norm_eps)
+            ops.gemm(w["x"], p16, w["q"], M=B, N=d, K=d, lda=d, ldb=d, ldc=d, b_off=o(p + "encoder_attn.q_proj.weight"),
+                     bias=p32, bias_off=o(p + "encoder_attn.q_proj.bias"))
+            ops.attn_fwd(w["q"], g["cross"][l], g["cross"][l], w["ctx"], self._lse(B * H * 32), B=B, H=H, Tq=1, Tk=Te,
+                         hd=hd, Tqp=32, scale=hd ** -0.5, ldq=d, ldk=2 * d, ldv=2 * d, ldo=d, sqb=d, skb=Te * 2 * d,
+                         svb=Te * 2 * d, sob=d, k_off=0, v_off=d)
+            ops.gemm(w["ctx"], p16, h0, M=B, N=d, K=d, lda=d, ldb=d, ldc=d, b_off=o(p + "encoder_attn.out_proj.weight"),
+                     bias=p32, bias_off=o(p + "encoder_attn.out_proj.bias"), epilogue=EPI_RESIDUAL, R=h1, ldr=d)
+            self._ffn(w, h0, h1, p, B, d, f)
+            h0, h1 = h1, h0
+        ops.layernorm_fwd(h0, st.view("model.decoder.layer_norm.weight"), st.view("model.decoder.layer_norm.bias"),
+                          w["hf"], None, B, d, s.layer_norm_eps)
+        V, Vp = s.vocab_size, _r8(s.vocab_size)
+        ops.gemm(w["hf"], p16, g["logits"], M=B, N=V, K=d, lda=d, ldb=d, ldc=Vp, b_off=o("model.decoder.embed_tokens.weight"))
+        ops.argmax_masked(g["logits"], suppress, g["nxt"], B, V, Vp)
+        step = torch.where(g["done"], g["pad"], g["nxt"])
+        g["out"][g["rows"], g["cur"].expand(B)] = step.long()
+        g["done"] |= step == g["eos"]
+        g["tok"].copy_(step)
+        g["pos"] += 1
+        g["klen"] += 1
+        g["cur"] += 1
+
     # ---- model-level API -------------------------------------------------------------------------
     def forward(self, input_features, labels=None, decoder_input_ids=None):
         """-> dict(loss, logits): `WhisperForConditionalGeneration.forward(input_features, labels)`."""
@@ -466,7 +535,7 @@ class WhisperEngine:
         return out
 
     def generate(self, input_features, prefix: list[int], max_length: int, suppress_tokens=None,
-                 begin_suppress_tokens=None, use_cache: bool = True) -> list[list[int]]:
+                 begin_suppress_tokens=None, use_cache: bool = True, use_graph: bool = True) -> list[list[int]]:
         """Greedy decoding with a forced prefix (<|sot|><|da|><|transcribe|><|notimestamps|> in CoRal's
         evaluation): masked argmax on the GPU (ca_argmax_masked), stop at EOS / max_length."""
         s, dev = self.s, self.device
@@ -480,6 +549,8 @@ class WhisperEngine:
         sup_begin = sup.clone()
         if begin_suppress_tokens:
             sup_begin[torch.tensor(list(begin_suppress_tokens), device=dev)] = 1
+        if use_cache and use_graph and max_length > len(prefix) + 2:
+            return self._generate_graph(kv, prefix, max_length, sup, sup_begin)
         ids = torch.tensor([prefix] * B, dtype=torch.int64, device=dev)
         done = torch.zeros(B, dtype=torch.bool, device=dev)
         nxt = torch.empty(B, dtype=torch.int32, device=dev)
@@ -497,3 +568,45 @@ class WhisperEngine:
             feed = step[:, None]
             done |= step == s.eos_token_id
         return ids.tolist()
+
+    def _generate_graph(self, kv, prefix, max_length, sup, sup_begin):
+        """Greedy loop with the per-token step captured once in a HIP graph and replayed: the ~350 small
+        launches of a token (24-32 layers x 14 kernels) cost one graph launch instead of 350 host calls."""
+        s, dev = self.s, self.device
+        B, V, P = kv[0].shape[0] // (s.max_source_positions * 2 * s.d_model), s.vocab_size, len(prefix)
+        cache = self.new_decode_cache(B, max_length)
+        g = self._graph_state(cache, kv, s.pad_token_id, s.eos_token_id)
+        # the forced prefix and the first free token run eagerly (different shapes / begin-suppress mask)
+        ids0 = torch.tensor([prefix] * B, dtype=torch.int64, device=dev)
+        base = self.decode_step(ids0, kv, cache).contiguous()
+        ops.argmax_masked(base, sup_begin, g["nxt"], B, V, V)
+        g["out"][:, :P] = ids0
+        g["out"][:, P] = g["nxt"].long()
+        g["done"] |= g["nxt"] == s.eos_token_id
+        g["tok"].copy_(g["nxt"])
+        g["pos"].fill_(P)
+        g["klen"].fill_(P + 1)
+        g["cur"].fill_(P + 1)
+        n_done = P + 1
+        if n_done < max_length and not bool(g["done"].all()):
+            self._token_step(cache, g, sup)  # eager warm-up of the captured sequence (allocations, attributes)
+            n_done += 1
+        graph = None
+        while n_done < max_length:
+            if (n_done - P) % 8 == 2 and bool(g["done"].all()):  # host check every 8 tokens
+                break
+            if graph is None:  # capture records the launches without running them
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    self._token_step(cache, g, sup)
+            graph.replay()
+            n_done += 1
+        out = g["out"][:, :n_done]
+        # trim like the eager loop: stop at the first column where every row had already finished
+        fin = (out == s.eos_token_id).cumsum(1) > 0
+        allfin = fin.all(0)
+        keep = n_done
+        if bool(allfin.any()):
+            keep = int(torch.nonzero(allfin)[0]) + 1
+        return out[:, :keep].tolist()

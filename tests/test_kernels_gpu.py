@@ -494,3 +494,28 @@ def test_fused_attention_fwd_bwd(ops, hd, H, Tq, Tk, causal, pad):
         want = unheads(want, T)
         err = (got.float().cpu() - want).abs().max().item()
         assert err < 3e-2 * max(1.0, want.abs().max().item()), (err, want.abs().max().item())
+
+
+@pytest.mark.parametrize("M,N,K", [(8, 1024, 1024), (3, 1000, 4096), (16, 51865, 384), (1, 72, 40)])
+def test_skinny_gemm_matches_torch(ops, M, N, K):
+    """M <= 16 (one decoded token per clip) takes the weight-streaming kernel: bias, GELU (second output),
+    residual, fp32 output with a padded leading dimension (the LM head)."""
+    g = torch.Generator().manual_seed(M * 1000 + N)
+    A = (torch.randn(M, K, generator=g) * 0.5).to(torch.bfloat16)
+    W = (torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16)
+    bias = torch.randn(N, generator=g)
+    R = torch.randn(M, N, generator=g).to(torch.bfloat16)
+    ref = A.float() @ W.float().t() + bias
+    Ad, Wd, bd, Rd = A.to(DEV), W.to(DEV), bias.to(DEV), R.to(DEV)
+    Np = (N + 7) // 8 * 8
+    out32 = torch.zeros(M, Np, dtype=torch.float32, device=DEV)
+    ops.gemm(Ad, Wd, out32, M=M, N=N, K=K, lda=K, ldb=K, ldc=Np, bias=bd)
+    assert (out32[:, :N].cpu() - ref).abs().max() <= 2e-3 * max(1.0, float(ref.abs().max()))
+    out = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(Ad, Wd, out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=bd, epilogue=ops.EPI_RESIDUAL, R=Rd, ldr=N)
+    want = ref + R.float()
+    assert (out.float().cpu() - want).abs().max() <= 2e-2 * max(1.0, float(want.abs().max()))
+    g2 = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(Ad, Wd, None, C2=g2, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=bd, epilogue=ops.EPI_GELU)
+    want = torch.nn.functional.gelu(ref)
+    assert (g2.float().cpu() - want).abs().max() <= 2e-2 * max(1.0, float(want.abs().max()))

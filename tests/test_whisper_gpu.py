@@ -276,6 +276,12 @@ def test_whisper_cached_decode_matches_full_recompute(golden_dir):
     assert cache["pos"] == 9
     for j, t_ in enumerate(range(3, 9)):
         assert (got[j] - full[:, t_, :]).abs().max() <= 3e-2, t_
-    a = eng.generate(feats, [151, 3, 4, 5], 14, use_cache=True)
+    a = eng.generate(feats, [151, 3, 4, 5], 14, use_cache=True, use_graph=False)
     b = eng.generate(feats, [151, 3, 4, 5], 14, use_cache=False)
     assert a == b
+    # the per-token step replayed from a HIP graph (device-side position / length / token state)
+    c2 = eng.generate(feats, [151, 3, 4, 5], 14, use_cache=True, use_graph=True)
+    assert c2 == a
+    long_a = eng.generate(feats, [151, 3, 4, 5], 40, use_graph=False)
+    long_g = eng.generate(feats, [151, 3, 4, 5], 40, use_graph=True)
+    assert long_g == long_a
