@@ -285,3 +285,36 @@ def test_whisper_cached_decode_matches_full_recompute(golden_dir):
     long_a = eng.generate(feats, [151, 3, 4, 5], 40, use_graph=False)
     long_g = eng.generate(feats, [151, 3, 4, 5], 40, use_graph=True)
     assert long_g == long_a
+
+
+def test_whisper_large_turbo_shape_training_step_vs_oracle():
+    """BASELINE configs[4]'s architecture (whisper-large-v3-turbo: d 1280, 20 heads, 128 mel bins, 51866 tokens)
+    at reduced depth, bf16: teacher-forced loss and a few gradients against autograd on the oracle.  (The fp8
+    weight format named in that config is not built; this pins the shape plumbing it would reuse.)"""
+    from coral_amd.whisper import CORAL_WHISPER_SHAPES, WhisperShape
+    from coral_amd.whisper_train import WhisperTrainEngine
+    from oracle import whisper_ref as w
+
+    kw = dict(CORAL_WHISPER_SHAPES["whisper-large-turbo"])
+    kw.update(encoder_layers=2, decoder_layers=2)
+    c = w.WhisperConfig(**{k: v for k, v in kw.items()})
+    P = w.synth_params(c)
+    g = torch.Generator().manual_seed(9)
+    feats = torch.randn(1, 128, 3000, generator=g) * 0.5
+    labels = torch.randint(0, 51000, (1, 10), generator=g)
+    Pr = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    loss_ref, logits_ref = w.forward_loss(feats, labels, Pr, c)
+    loss_ref.backward()
+    eng = WhisperTrainEngine(WhisperShape(**kw), DEV)
+    eng.load_state_dict(P)
+    eng.zero_grad()
+    out = eng.forward_train(feats, labels)
+    eng.backward()
+    torch.cuda.synchronize()
+    assert abs(float(out["loss"]) - float(loss_ref.detach())) <= 1e-2 * float(loss_ref.detach())
+    assert (out["logits"].float().cpu() - logits_ref.detach()).abs().max() <= 6e-2
+    gd = eng.grad_dict()
+    for name in ["model.encoder.conv1.weight", "model.encoder.layers.1.fc1.weight", "model.decoder.embed_tokens.weight",
+                 "model.decoder.layers.0.encoder_attn.v_proj.weight", "model.decoder.layers.1.self_attn.q_proj.weight"]:
+        a, b = gd[name].double().cpu().flatten(), Pr[name].grad.double().flatten()
+        assert float(a @ b / (a.norm() * b.norm())) >= 0.99, name
