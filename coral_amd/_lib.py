@@ -82,6 +82,7 @@ SIGNATURES = {
     "ca_version": (C.c_int, []),
     "ca_last_error": (C.c_char_p, []),
     "ca_device_count": (C.c_int, []),
+    "ca_gemm_bf16_group": (C.c_int, [_vp, _i32, _vp]),
     "ca_gemm_bf16": (C.c_int, [C.POINTER(CaGemmDesc), _vp]),
     "ca_gemm_force_kernel": (C.c_int, [C.c_int]),
     "ca_prof_begin": (C.c_int, []),

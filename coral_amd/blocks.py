@@ -70,16 +70,16 @@ class SelfAttnBlock:
         M = B * T
         o, g32, p16 = st.off, st.g32, st.p16
         ops.colsum(dh, d, M, d, g32, sc.part, out_off=o(self.attn + "out_proj.bias"))
-        ops.wgrad_gemm(dh, sv["ctx"], g32, M=d, N=d, K=M, lda=d, ldb=d,
-                       c_off=o(self.attn + "out_proj.weight"), accumulate=True)
+        wg = [dict(dY=dh, X=sv["ctx"], M=d, N=d, K=M, lda=d, ldb=d, c_off=o(self.attn + "out_proj.weight"), accumulate=True)]
         ops.gemm(dh, p16, sc.dctx, M=M, N=d, K=d, lda=d, b_layout=MNMAJOR, ldb=d, ldc=d, b_off=o(self.attn + "out_proj.weight"))
         qkv, dqkv = sv["qkv"], sc.dqkv
         ops.attn_bwd(qkv, qkv, qkv, sv["ctx"], sv["lse"], sc.dctx, sv["Dq"], dqkv, dqkv, dqkv, lddo=d, sdob=T * d, lddq=3 * d,
                      lddk=3 * d, lddv=3 * d, sdqb=T * 3 * d, sdkb=T * 3 * d, sdvb=T * 3 * d, dq_off=0, dk_off=d, dv_off=2 * d,
                      **self._akw(B, T, sv, sv["klen"]))
         ops.colsum(dqkv, 3 * d, M, 3 * d, g32, sc.part, out_off=o(self.qbias))
-        ops.wgrad_gemm(dqkv, sv["x"], g32, M=3 * d, N=d, K=M, lda=3 * d, ldb=d,
-                       c_off=o(self.attn + "q_proj.weight"), accumulate=True)
+        wg.append(dict(dY=dqkv, X=sv["x"], M=3 * d, N=d, K=M, lda=3 * d, ldb=d, c_off=o(self.attn + "q_proj.weight"),
+                       accumulate=True))
+        ops.wgrad_gemm_group(wg, g32)  # both weight gradients of the block in one grouped launch
         ops.gemm(dqkv, p16, sc.dx, M=M, N=d, K=3 * d, lda=3 * d, b_layout=MNMAJOR, ldb=d, ldc=d, b_off=o(self.attn + "q_proj.weight"))
         ops.layernorm_bwd(sc.dx, sv["hin"], st.view(self.ln + ".weight"), None, sv["st"], dh, dhin,
                           st.view(self.ln + ".weight", "g32"), st.view(self.ln + ".bias", "g32"), sc.part, M, d)
@@ -172,13 +172,12 @@ class FFNBlock:
         o, g32, p16 = st.off, st.g32, st.p16
         p, seed = sv["drop"]
         ops.colsum(dh, d, M, d, g32, sc.part, out_off=o(self.fc2 + ".bias"))
-        ops.wgrad_gemm(dh, sv["g"], g32, M=d, N=f, K=M, lda=d, ldb=f,
-                       c_off=o(self.fc2 + ".weight"), accumulate=True)
+        wg = [dict(dY=dh, X=sv["g"], M=d, N=f, K=M, lda=d, ldb=f, c_off=o(self.fc2 + ".weight"), accumulate=True)]
         ops.gemm(dh, p16, sc.du, M=M, N=f, K=d, lda=d, b_layout=MNMAJOR, ldb=f, ldc=f, b_off=o(self.fc2 + ".weight"),
                  epilogue=EPI_DGELU, R=sv["u"], ldr=f, dropout_p=p, dropout_seed=seed)
         ops.colsum(sc.du, f, M, f, g32, sc.part, out_off=o(self.fc1 + ".bias"))
-        ops.wgrad_gemm(sc.du, sv["x"], g32, M=f, N=d, K=M, lda=f, ldb=d,
-                       c_off=o(self.fc1 + ".weight"), accumulate=True)
+        wg.append(dict(dY=sc.du, X=sv["x"], M=f, N=d, K=M, lda=f, ldb=d, c_off=o(self.fc1 + ".weight"), accumulate=True))
+        ops.wgrad_gemm_group(wg, g32)
         ops.gemm(sc.du, p16, sc.dx, M=M, N=d, K=f, lda=f, b_layout=MNMAJOR, ldb=d, ldc=d, b_off=o(self.fc1 + ".weight"))
         ops.layernorm_bwd(sc.dx, sv["hin"], st.view(self.ln + ".weight"), None, sv["st"], dh, dhin,
                           st.view(self.ln + ".weight", "g32"), st.view(self.ln + ".bias", "g32"), sc.part, M, d)

@@ -435,15 +435,36 @@ __global__ __launch_bounds__(256) void ca_gemm_kernel(const CaGemmDesc d) {
 #define XSTAGE (2 * XTILE)
 #define X_LDS_BYTES (8 * 64 * EPI_PITCH * 4)  // 139264 >= 2 stages * 64 KiB
 
+// grp.count > 1: a grouped launch of up to four independent problems of the same operand form
+// (ca_gemm_bf16_group): block ranges map to problems, each with plain row-major tile numbering.
+struct CaGemmGroup {
+  CaGemmDesc d[4];
+  int first[4];  // first block of problem i (first[0] = 0); count = number of problems (0 = plain launch of d[0])
+  int count;
+};
 template <int AL, int BL, bool KS>
-__global__ __launch_bounds__(512) void ca_gemm_kernel_x(const CaGemmDesc d) {
+__global__ __launch_bounds__(512) void ca_gemm_kernel_x(const CaGemmGroup grp) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;  // 2 x 4 waves, 128 (M) x 64 (N) each
+  int which = 0;
+  if (grp.count > 1) {
+    which = (int)blockIdx.x >= grp.first[1] ? 1 : 0;
+    if (grp.count > 2 && (int)blockIdx.x >= grp.first[2]) which = 2;
+    if (grp.count > 3 && (int)blockIdx.x >= grp.first[3]) which = 3;
+  }
+  const CaGemmDesc d = grp.d[which];
   int tm, tn;
-  if (!tile_of_block<4, 8>(blockIdx.x, (d.M + XBM - 1) / XBM, (d.N + XBN - 1) / XBN, tm, tn)) return;
+  if (grp.count > 1) {
+    const int bid = (int)blockIdx.x - grp.first[which];
+    const int ntn = (d.N + XBN - 1) / XBN;
+    tm = bid / ntn;
+    tn = bid % ntn;
+  } else if (!tile_of_block<4, 8>(blockIdx.x, (d.M + XBM - 1) / XBM, (d.N + XBN - 1) / XBN, tm, tn)) {
+    return;
+  }
   const int m0 = tm * XBM, n0 = tn * XBN;
   const int z = blockIdx.z;
   const int z1 = z / d.batch2, z2 = z % d.batch2;
@@ -919,6 +940,54 @@ extern "C" int ca_gemm_bf16(const CaGemmDesc* desc, void* stream) {
   return rc;
 }
 
+// Up to four independent GEMMs of the same operand form in one launch of kernel X (grouped launch): used where
+// the problems do not fill the chip one by one (the four weight gradients of a transformer layer: 240 + 240 +
+// 184 + 64 tiles on 256 CUs at XLS-R-2B, 64 + 64 + 48 + 16 at d = 1024).  All must be un-batched, un-segmented
+// and plain (no epilogue, no bias).
+extern "C" int ca_gemm_bf16_group(const CaGemmDesc* descs, int32_t count, void* stream) {
+  CA_CHECK_ARG(descs && count >= 1 && count <= 4, "ca_gemm_bf16_group: 1..4 problems");
+  CaGemmGroup g;
+  int total = 0;
+  for (int i = 0; i < count; ++i) {
+    const CaGemmDesc* p = descs + i;
+    CA_CHECK_ARG(p->A && p->B && p->C && p->M > 0 && p->N > 0 && p->K >= 64, "ca_gemm_bf16_group: bad problem %d", i);
+    CA_CHECK_ARG(p->batch1 == 1 && p->batch2 == 1 && p->a_kseg == 0 && p->b_kseg == 0 && p->epilogue == CA_EPI_NONE &&
+                     p->bias == nullptr && p->dropout_p == 0.f,
+                 "ca_gemm_bf16_group: only plain un-batched problems");
+    CA_CHECK_ARG((p->lda % 8) == 0 && (p->ldb % 8) == 0 && ((uintptr_t)p->A % 16) == 0 && ((uintptr_t)p->B % 16) == 0,
+                 "ca_gemm_bf16_group: alignment");
+    CA_CHECK_ARG(p->a_layout == descs->a_layout && p->b_layout == descs->b_layout,
+                 "ca_gemm_bf16_group: the problems differ in operand form");
+    g.d[i] = *p;
+    g.first[i] = total;
+    total += ((p->M + XBM - 1) / XBM) * ((p->N + XBN - 1) / XBN);
+  }
+  for (int i = count; i < 4; ++i) {
+    g.d[i] = descs[0];
+    g.first[i] = total;
+  }
+  g.count = count > 1 ? count : 0;
+  static bool attr = false;
+#define XK(x, y) ca_gemm_kernel_x<x, y, false>
+  if (!attr) {
+    const void* fs[4] = {(const void*)XK(0, 0), (const void*)XK(0, 1), (const void*)XK(1, 0), (const void*)XK(1, 1)};
+    for (int i = 0; i < 4; ++i) hipFuncSetAttribute(fs[i], hipFuncAttributeMaxDynamicSharedMemorySize, X_LDS_BYTES);
+    attr = true;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((unsigned)(count > 1 ? total : tile_grid<4, 8>((descs->M + XBM - 1) / XBM, (descs->N + XBN - 1) / XBN))),
+      block(512);
+  switch ((descs->a_layout ? 2 : 0) + (descs->b_layout ? 1 : 0)) {
+    case 0: hipLaunchKernelGGL((XK(0, 0)), grid, block, X_LDS_BYTES, s, g); break;
+    case 1: hipLaunchKernelGGL((XK(0, 1)), grid, block, X_LDS_BYTES, s, g); break;
+    case 2: hipLaunchKernelGGL((XK(1, 0)), grid, block, X_LDS_BYTES, s, g); break;
+    default: hipLaunchKernelGGL((XK(1, 1)), grid, block, X_LDS_BYTES, s, g); break;
+  }
+#undef XK
+  CA_CHECK_LAUNCH("ca_gemm_bf16_group");
+  return CA_OK;
+}
+
 static int ca_gemm_launch(const CaGemmDesc* desc, void* stream) {
   CA_CHECK_ARG(desc != nullptr, "ca_gemm_bf16: null descriptor");
   const CaGemmDesc& d = *desc;
@@ -984,15 +1053,19 @@ static int ca_gemm_launch(const CaGemmDesc* desc, void* stream) {
     }
     dim3 grid(tile_grid<4, 8>(xtm, xtn), 1, (unsigned)nb);
     dim3 block(512);
+    CaGemmGroup one;
+    one.d[0] = d;
+    one.count = 0;
+    one.first[0] = 0;
     switch (lay + (ks ? 4 : 0)) {
-      case 0: CA_LAUNCH((XK(0, 0, false)), grid, block, X_LDS_BYTES, s, d); break;
-      case 1: CA_LAUNCH((XK(0, 1, false)), grid, block, X_LDS_BYTES, s, d); break;
-      case 2: CA_LAUNCH((XK(1, 0, false)), grid, block, X_LDS_BYTES, s, d); break;
-      case 3: CA_LAUNCH((XK(1, 1, false)), grid, block, X_LDS_BYTES, s, d); break;
-      case 4: CA_LAUNCH((XK(0, 0, true)), grid, block, X_LDS_BYTES, s, d); break;
-      case 5: CA_LAUNCH((XK(0, 1, true)), grid, block, X_LDS_BYTES, s, d); break;
-      case 6: CA_LAUNCH((XK(1, 0, true)), grid, block, X_LDS_BYTES, s, d); break;
-      default: CA_LAUNCH((XK(1, 1, true)), grid, block, X_LDS_BYTES, s, d); break;
+      case 0: CA_LAUNCH((XK(0, 0, false)), grid, block, X_LDS_BYTES, s, one); break;
+      case 1: CA_LAUNCH((XK(0, 1, false)), grid, block, X_LDS_BYTES, s, one); break;
+      case 2: CA_LAUNCH((XK(1, 0, false)), grid, block, X_LDS_BYTES, s, one); break;
+      case 3: CA_LAUNCH((XK(1, 1, false)), grid, block, X_LDS_BYTES, s, one); break;
+      case 4: CA_LAUNCH((XK(0, 0, true)), grid, block, X_LDS_BYTES, s, one); break;
+      case 5: CA_LAUNCH((XK(0, 1, true)), grid, block, X_LDS_BYTES, s, one); break;
+      case 6: CA_LAUNCH((XK(1, 0, true)), grid, block, X_LDS_BYTES, s, one); break;
+      default: CA_LAUNCH((XK(1, 1, true)), grid, block, X_LDS_BYTES, s, one); break;
     }
 #undef XK
     CA_CHECK_LAUNCH("ca_gemm_bf16");

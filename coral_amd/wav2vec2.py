@@ -547,16 +547,19 @@ class Wav2Vec2CTCEngine:
             hin = w["h"][l]
             # FFN2: h_out = h1 + W2 g + b2
             ops.colsum(dh, d, M, d, g32, part, out_off=o(pl + "feed_forward.output_dense.bias"))
-            ops.wgrad_gemm(dh, w["g"][l], g32, M=d, N=f, K=M, lda=d, ldb=f,
-                           c_off=o(pl + "feed_forward.output_dense.weight"), accumulate=lacc)
+            # the four weight gradients of the layer are launched together at the end of the layer (one grouped
+            # launch: 240 + 240 + 184 + 64 tiles = 2.84 rounds of 256 CUs instead of four under-filled ones);
+            # dh, du, dh1 and dqkv all stay untouched until then
+            wg = [dict(dY=dh, X=w["g"][l], M=d, N=f, K=M, lda=d, ldb=f,
+                       c_off=o(pl + "feed_forward.output_dense.weight"), accumulate=lacc)]
             ops.gemm(dh, p16, w["du"], M=M, N=f, K=d, lda=d, b_layout=MNMAJOR, ldb=f, ldc=f,
                      b_off=o(pl + "feed_forward.output_dense.weight"), epilogue=EPI_DGELU, R=w["u"][l],
                      ldr=f, dropout_p=drop_p, dropout_seed=self.step_seed * 1000 + l)
             # FFN1
             du = w["du"]
             ops.colsum(du, f, M, f, g32, part, out_off=o(pl + "feed_forward.intermediate_dense.bias"))
-            ops.wgrad_gemm(du, w["x2"][l], g32, M=f, N=d, K=M, lda=f, ldb=d,
-                           c_off=o(pl + "feed_forward.intermediate_dense.weight"), accumulate=lacc)
+            wg.append(dict(dY=du, X=w["x2"][l], M=f, N=d, K=M, lda=f, ldb=d,
+                           c_off=o(pl + "feed_forward.intermediate_dense.weight"), accumulate=lacc))
             ops.gemm(du, p16, other, M=M, N=d, K=f, lda=f, b_layout=MNMAJOR, ldb=d, ldc=d,
                      b_off=o(pl + "feed_forward.intermediate_dense.weight"))
             # LN2: dh1 = dh + LN'(dx2)
@@ -566,16 +569,17 @@ class Wav2Vec2CTCEngine:
                               st.view(pl + "final_layer_norm.bias", "g32"), part, M, d)
             # out_proj: h1 = h + Wo ctx + bo
             ops.colsum(dh1, d, M, d, g32, part, out_off=o(pl + "attention.out_proj.bias"))
-            ops.wgrad_gemm(dh1, w["ctx"][l], g32, M=d, N=d, K=M, lda=d, ldb=d,
-                           c_off=o(pl + "attention.out_proj.weight"), accumulate=lacc)
+            wg.append(dict(dY=dh1, X=w["ctx"][l], M=d, N=d, K=M, lda=d, ldb=d,
+                           c_off=o(pl + "attention.out_proj.weight"), accumulate=lacc))
             dctx = other
             ops.gemm(dh1, p16, dctx, M=M, N=d, K=d, lda=d, b_layout=MNMAJOR, ldb=d, ldc=d,
                      b_off=o(pl + "attention.out_proj.weight"))
             self._attention_bwd(w, l, dctx, B, T, Tp, H, hd, d, scale)
             dqkv = w["dqkv"]
             ops.colsum(dqkv, 3 * d, M, 3 * d, g32, part, out_off=o(pl + "attention.q_proj.bias"))
-            ops.wgrad_gemm(dqkv, w["x1"][l], g32, M=3 * d, N=d, K=M, lda=3 * d, ldb=d,
-                           c_off=o(pl + "attention.q_proj.weight"), accumulate=lacc)
+            wg.append(dict(dY=dqkv, X=w["x1"][l], M=3 * d, N=d, K=M, lda=3 * d, ldb=d,
+                           c_off=o(pl + "attention.q_proj.weight"), accumulate=lacc))
+            ops.wgrad_gemm_group(wg, g32)
             dx1 = other
             ops.gemm(dqkv, p16, dx1, M=M, N=d, K=3 * d, lda=3 * d, b_layout=MNMAJOR, ldb=d, ldc=d,
                      b_off=o(pl + "attention.q_proj.weight"))

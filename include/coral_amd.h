@@ -94,6 +94,10 @@ typedef struct CaGemmDesc {
 } CaGemmDesc;
 
 int ca_gemm_bf16(const CaGemmDesc* desc, void* stream);
+/* Up to four independent plain GEMMs of the same operand form (same a_layout / b_layout, un-batched, no epilogue,
+ * no bias) in one launch of the 256x256 kernel: for problems that under-fill the chip one by one, e.g. the four
+ * weight gradients of a transformer layer (each replaces a `torch.mm(dY.T, X)` of autograd's Linear backward). */
+int ca_gemm_bf16_group(const CaGemmDesc* descs, int32_t count, void* stream);
 
 /* Live kernel timing for bench.py's roofline line: between ca_prof_begin() and ca_prof_end()
  * every ca_gemm_bf16 launch is bracketed by hipEvents on its own stream.  ca_prof_end fills
