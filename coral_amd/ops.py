@@ -353,7 +353,8 @@ def prof_end():
             for v in range(4):
                 i = k * 8 + ks * 4 + v
                 targs = f"{v >> 1}, {v & 1}" if k == 1 else f"{v >> 1}, {v & 1}, {'true' if ks else 'false'}"
-                out.append(dict(kernel=f"void {sym}<{targs}>(CaGemmDesc)", ms=ms[i], count=cnt[i], flops=fl[i]))
+                arg = "CaGemmGroup" if k == 2 else "CaGemmDesc"  # kernel X takes the (possibly one-problem) group struct
+                out.append(dict(kernel=f"void {sym}<{targs}>({arg})", ms=ms[i], count=cnt[i], flops=fl[i]))
     return out
 
 
