@@ -59,6 +59,7 @@ class CaGemmDesc(C.Structure):
         ("alpha", C.c_float),
         ("dropout_p", C.c_float),
         ("dropout_seed", C.c_uint64),
+        ("a_colsum", C.c_void_p),
     ]
 
 

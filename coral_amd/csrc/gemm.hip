@@ -487,6 +487,8 @@ __global__ __launch_bounds__(512) void ca_gemm_kernel_x(const CaGemmGroup grp) {
   for (int i = 0; i < 8; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const bool do_colsum = d.a_colsum != nullptr && tn == 0;
+  float csum0 = 0.f, csum1 = 0.f;  // this lane's share of sum_k A[k, m] for m = m0 + wm*128 + (ih*4 + wn)*16 + (lane & 15)
 
   const int K = d.K;
   const int nk = (K + BK - 1) / BK;
@@ -555,17 +557,44 @@ __global__ __launch_bounds__(512) void ca_gemm_kernel_x(const CaGemmGroup grp) {
           acc[ih * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], acc[ih * 4 + i][j], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
     };
+    // bias gradient from the streaming A tile (a_colsum): the four waves of an m-half share the work, wave wn
+    // taking fragment i == wn of every block; only the workgroups of tile column 0 do it
+    auto colsum_acc = [&](int ih, bf16x8_t (&af)[4]) {
+      if (AL == CA_MNMAJOR && do_colsum) {
+        // (wn is wave-uniform: a branch per case keeps the fragments in registers - indexing af[] by a run-time
+        // value would send the whole array through scratch memory)
+        f32x4_t z;
+        if (wn == 0)
+          z = __builtin_bit_cast(f32x4_t, af[0]);
+        else if (wn == 1)
+          z = __builtin_bit_cast(f32x4_t, af[1]);
+        else if (wn == 2)
+          z = __builtin_bit_cast(f32x4_t, af[2]);
+        else
+          z = __builtin_bit_cast(f32x4_t, af[3]);
+        const unsigned int* w = (const unsigned int*)&z;
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s += __uint_as_float(w[q] << 16) + __uint_as_float(w[q] & 0xFFFF0000u);
+        if (ih == 0)
+          csum0 += s;
+        else
+          csum1 += s;
+      }
+    };
     bf16x8_t A0[4], A1[4], B0[4], B1[4];
     read_b(0, B0);
     read_a(0, 0, A0);
     if (wave < 4) burst();
     lds_wait(B0);
     lds_wait(A0);
+    colsum_acc(0, A0);
     read_a(0, 1, A1);
     __builtin_amdgcn_sched_barrier(0);
     mma(0, A0, B0);
     __builtin_amdgcn_sched_barrier(0);
     lds_wait(A1);
+    colsum_acc(1, A1);
     read_b(1, B1);
     read_a(1, 0, A0);
     __builtin_amdgcn_sched_barrier(0);
@@ -574,12 +603,25 @@ __global__ __launch_bounds__(512) void ca_gemm_kernel_x(const CaGemmGroup grp) {
     if (wave >= 4) burst();
     lds_wait(B1);
     lds_wait(A0);
+    colsum_acc(0, A0);
     read_a(1, 1, A1);
     __builtin_amdgcn_sched_barrier(0);
     mma(0, A0, B1);
     __builtin_amdgcn_sched_barrier(0);
     lds_wait(A1);
+    colsum_acc(1, A1);
     mma(1, A1, B1);
+  }
+  if (AL == CA_MNMAJOR && do_colsum) {
+    // a lane's fragment holds k = 8g..8g+7 of a 32-k step: add the four lane groups, then lanes 0-15 own 16 rows
+#pragma unroll
+    for (int ih = 0; ih < 2; ++ih) {
+      float s = ih == 0 ? csum0 : csum1;
+      s += __shfl_xor(s, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      const int m = m0 + wm * 128 + (ih * 4 + wn) * 16 + (lane & 15);
+      if (lane < 16 && m < d.M) d.a_colsum[m] += s;  // always accumulates, like ca_colsum_bf16 on this path
+    }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -1021,6 +1063,9 @@ static int ca_gemm_launch(const CaGemmDesc* desc, void* stream) {
   if (d.epilogue == CA_EPI_RESIDUAL || d.epilogue == CA_EPI_DGELU || d.epilogue == CA_EPI_GELU_RESIDUAL)
     CA_CHECK_ARG(d.R != nullptr, "ca_gemm_bf16: epilogue needs R");
   CA_CHECK_ARG(d.dropout_p >= 0.f && d.dropout_p < 1.f, "ca_gemm_bf16: bad dropout_p");
+  if (d.a_colsum)
+    CA_CHECK_ARG(d.a_layout == CA_MNMAJOR && d.b_layout == CA_MNMAJOR && d.batch1 == 1 && d.batch2 == 1 && d.a_kseg == 0,
+                 "ca_gemm_bf16: a_colsum needs the un-batched weight-gradient form");
 
   hipStream_t s = (hipStream_t)stream;
   const int lay = (d.a_layout ? 2 : 0) + (d.b_layout ? 1 : 0);
@@ -1053,7 +1098,7 @@ static int ca_gemm_launch(const CaGemmDesc* desc, void* stream) {
   // for S inside the training step), so it switches at a lower fill than the other forms.
   const bool tn = d.a_layout == CA_MNMAJOR && d.b_layout == CA_MNMAJOR;
   int use_x = (g_force_kernel == 0 && d.K >= 512 && xt >= (tn ? 160 : 224) && xeff * xfill >= (tn ? 0.60 : 0.80)) ? 1 : 0;
-  if (g_force_kernel == 3) use_x = 1;
+  if (g_force_kernel == 3 || d.a_colsum) use_x = 1;  // the column sums live in kernel X only
   g_last_kind = use_x ? 2 : (use_l ? 1 : 0);
   if (use_x) {
     static bool xattr = false;

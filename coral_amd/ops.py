@@ -41,8 +41,10 @@ def _gemm_desc(A, B, Cout, *, M, N, K, lda, ldb, ldc, a_layout=KMAJOR, b_layout=
          b_off=0, c_off=0, bias=None, bias_off=0, R=None, r_off=0, ldr=0, C2=None, c2_off=None,
          epilogue=EPI_NONE, out_f32=None, accumulate=False, alpha=1.0, batch1=1, batch2=1,
          sA=(0, 0), sB=(0, 0), sC=(0, 0), sR=(0, 0), sBias=(0, 0), a_kseg=0, a_kseg_stride=0, b_kseg=0,
-         b_kseg_stride=0, dropout_p=0.0, dropout_seed=0):
+         b_kseg_stride=0, dropout_p=0.0, dropout_seed=0, a_colsum=None, a_colsum_off=0):
     d = CaGemmDesc()
+    if a_colsum is not None:
+        d.a_colsum = _p(a_colsum, a_colsum_off)
     d.A, d.B = _p(A, a_off), _p(B, b_off)
     d.C = _p(Cout, c_off) if Cout is not None else None
     if C2 is not None:
@@ -81,11 +83,13 @@ def gemm(A, B, Cout, **kw):
 _SPLITK_WS: dict = {}
 
 
-def wgrad_gemm(dY, X, G, *, M, N, K, lda, ldb, c_off, accumulate, a_off=0, b_off=0):
+def wgrad_gemm(dY, X, G, *, M, N, K, lda, ldb, c_off, accumulate, a_off=0, b_off=0, bias_off=None, part=None):
     """Weight gradient G[c_off : c_off + M*N] (+)= dY^T X  (dY [K, M] and X [K, N] token-major bf16, G fp32
-    row-major [M, N]).  Shapes that would leave most of the chip idle (fewer 128x128 tiles than half the
-    workgroup slots) are split along K: the slices run as one batched GEMM into an fp32 workspace and a
-    deterministic second pass adds them up (no atomics: the result does not depend on scheduling)."""
+    row-major [M, N]) and, with bias_off, the bias gradient G[bias_off : bias_off + M] += dY.sum(0).
+    Shapes that would leave most of the chip idle (fewer 128x128 tiles than half the workgroup slots) are split
+    along K: the slices run as one batched GEMM into an fp32 workspace and a deterministic second pass adds them
+    up (no atomics: the result does not depend on scheduling).  Otherwise the bias gradient rides on the
+    256x256 kernel's A stream (CaGemmDesc.a_colsum) when that kernel fits, else it is a separate column sum."""
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     xt = ((M + 255) // 256) * ((N + 255) // 256)
     splits = 1
@@ -94,11 +98,14 @@ def wgrad_gemm(dY, X, G, *, M, N, K, lda, ldb, c_off, accumulate, a_off=0, b_off
             if tiles * s <= 512 and K % s == 0 and K // s >= 256:
                 splits = s
                 break
+    fuse_bias = bias_off is not None and splits == 1 and xt >= 160 and K >= 512 and a_off == 0
+    if bias_off is not None and not fuse_bias:
+        colsum(dY, lda, K, M, G, part, x_off=a_off, out_off=bias_off)
     if splits == 1:
         gemm(dY, X, G, M=M, N=N, K=K, a_layout=MNMAJOR, lda=lda, b_layout=MNMAJOR, ldb=ldb, ldc=N, c_off=c_off,
-             a_off=a_off, b_off=b_off, out_f32=True, accumulate=accumulate)
+             a_off=a_off, b_off=b_off, out_f32=True, accumulate=accumulate,
+             a_colsum=G if fuse_bias else None, a_colsum_off=bias_off if fuse_bias else 0)
         return
-    key = (G.device, splits * M * N)
     ws = _SPLITK_WS.get(G.device)
     if ws is None or ws.numel() < splits * M * N:
         ws = torch.empty(splits * M * N, dtype=torch.float32, device=G.device)
@@ -134,7 +141,8 @@ def wgrad_gemm_group(problems: list, G):
             for i, p in enumerate(chunk):
                 arr[i] = _gemm_desc(p["dY"], p["X"], G, M=p["M"], N=p["N"], K=p["K"], a_layout=MNMAJOR, lda=p["lda"],
                                     b_layout=MNMAJOR, ldb=p["ldb"], ldc=p["N"], c_off=p["c_off"], out_f32=True,
-                                    accumulate=p["accumulate"])
+                                    accumulate=p["accumulate"], a_colsum=G if p.get("bias_off") is not None else None,
+                                    a_colsum_off=p.get("bias_off") or 0)
             check(lib().ca_gemm_bf16_group(arr, len(chunk), _stream()), "ca_gemm_bf16_group")
         else:
             for p in chunk:

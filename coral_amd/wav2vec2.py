@@ -546,20 +546,22 @@ class Wav2Vec2CTCEngine:
             pl = f"wav2vec2.encoder.layers.{l}."
             hin = w["h"][l]
             # FFN2: h_out = h1 + W2 g + b2
-            ops.colsum(dh, d, M, d, g32, part, out_off=o(pl + "feed_forward.output_dense.bias"))
+            # (bias gradients = column sums of the same dY: taken inside the weight-gradient kernel where it runs
+            # on the 256x256 tiles, see ops.wgrad_gemm)
             # the four weight gradients of the layer are launched together at the end of the layer (one grouped
             # launch: 240 + 240 + 184 + 64 tiles = 2.84 rounds of 256 CUs instead of four under-filled ones);
             # dh, du, dh1 and dqkv all stay untouched until then
-            wg = [dict(dY=dh, X=w["g"][l], M=d, N=f, K=M, lda=d, ldb=f,
-                       c_off=o(pl + "feed_forward.output_dense.weight"), accumulate=lacc)]
+            wg = [dict(dY=dh, X=w["g"][l], M=d, N=f, K=M, lda=d, ldb=f, part=part,
+                       c_off=o(pl + "feed_forward.output_dense.weight"), accumulate=lacc,
+                       bias_off=o(pl + "feed_forward.output_dense.bias"))]
             ops.gemm(dh, p16, w["du"], M=M, N=f, K=d, lda=d, b_layout=MNMAJOR, ldb=f, ldc=f,
                      b_off=o(pl + "feed_forward.output_dense.weight"), epilogue=EPI_DGELU, R=w["u"][l],
                      ldr=f, dropout_p=drop_p, dropout_seed=self.step_seed * 1000 + l)
             # FFN1
             du = w["du"]
-            ops.colsum(du, f, M, f, g32, part, out_off=o(pl + "feed_forward.intermediate_dense.bias"))
-            wg.append(dict(dY=du, X=w["x2"][l], M=f, N=d, K=M, lda=f, ldb=d,
-                           c_off=o(pl + "feed_forward.intermediate_dense.weight"), accumulate=lacc))
+            wg.append(dict(dY=du, X=w["x2"][l], M=f, N=d, K=M, lda=f, ldb=d, part=part,
+                           c_off=o(pl + "feed_forward.intermediate_dense.weight"), accumulate=lacc,
+                           bias_off=o(pl + "feed_forward.intermediate_dense.bias")))
             ops.gemm(du, p16, other, M=M, N=d, K=f, lda=f, b_layout=MNMAJOR, ldb=d, ldc=d,
                      b_off=o(pl + "feed_forward.intermediate_dense.weight"))
             # LN2: dh1 = dh + LN'(dx2)
@@ -568,17 +570,17 @@ class Wav2Vec2CTCEngine:
                               dh, dh1, st.view(pl + "final_layer_norm.weight", "g32"),
                               st.view(pl + "final_layer_norm.bias", "g32"), part, M, d)
             # out_proj: h1 = h + Wo ctx + bo
-            ops.colsum(dh1, d, M, d, g32, part, out_off=o(pl + "attention.out_proj.bias"))
-            wg.append(dict(dY=dh1, X=w["ctx"][l], M=d, N=d, K=M, lda=d, ldb=d,
-                           c_off=o(pl + "attention.out_proj.weight"), accumulate=lacc))
+            wg.append(dict(dY=dh1, X=w["ctx"][l], M=d, N=d, K=M, lda=d, ldb=d, part=part,
+                           c_off=o(pl + "attention.out_proj.weight"), accumulate=lacc,
+                           bias_off=o(pl + "attention.out_proj.bias")))
             dctx = other
             ops.gemm(dh1, p16, dctx, M=M, N=d, K=d, lda=d, b_layout=MNMAJOR, ldb=d, ldc=d,
                      b_off=o(pl + "attention.out_proj.weight"))
             self._attention_bwd(w, l, dctx, B, T, Tp, H, hd, d, scale)
             dqkv = w["dqkv"]
-            ops.colsum(dqkv, 3 * d, M, 3 * d, g32, part, out_off=o(pl + "attention.q_proj.bias"))
-            wg.append(dict(dY=dqkv, X=w["x1"][l], M=3 * d, N=d, K=M, lda=3 * d, ldb=d,
-                           c_off=o(pl + "attention.q_proj.weight"), accumulate=lacc))
+            wg.append(dict(dY=dqkv, X=w["x1"][l], M=3 * d, N=d, K=M, lda=3 * d, ldb=d, part=part,
+                           c_off=o(pl + "attention.q_proj.weight"), accumulate=lacc,
+                           bias_off=o(pl + "attention.q_proj.bias")))
             ops.wgrad_gemm_group(wg, g32)
             dx1 = other
             ops.gemm(dqkv, p16, dx1, M=M, N=d, K=3 * d, lda=3 * d, b_layout=MNMAJOR, ldb=d, ldc=d,
