@@ -572,14 +572,21 @@ __global__ __launch_bounds__(512) void ca_gemm_kernel_x(const CaGemmGroup grp) {
           z = __builtin_bit_cast(f32x4_t, af[2]);
         else
           z = __builtin_bit_cast(f32x4_t, af[3]);
-        const unsigned int* w = (const unsigned int*)&z;
-        float s = 0.f;
+        // v_dot2c_f32_bf16 with a vector of ones: two bf16 values added to the fp32 sum per instruction
+        typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+        const bf16x2_t ones = __builtin_bit_cast(bf16x2_t, 0x3F803F80u);
+        float s = ih == 0 ? csum0 : csum1;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) s += __uint_as_float(w[q] << 16) + __uint_as_float(w[q] & 0xFFFF0000u);
+        for (int q = 0; q < 4; ++q) {
+          // through an integer word on purpose: bit-casting element q of the float vector straight to a bf16 pair
+          // makes hipcc 7.2 read element 0 four times (seen in the ISA)
+          const unsigned int wq = __float_as_uint(z[q]);
+          s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, wq), ones, s, false);
+        }
         if (ih == 0)
-          csum0 += s;
+          csum0 = s;
         else
-          csum1 += s;
+          csum1 = s;
       }
     };
     bf16x8_t A0[4], A1[4], B0[4], B1[4];

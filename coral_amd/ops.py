@@ -81,6 +81,7 @@ def gemm(A, B, Cout, **kw):
 
 
 _SPLITK_WS: dict = {}
+FUSE_BIAS_GRAD = True  # tests flip this to compare the fused bias gradient with the separate column-sum pass
 
 
 def wgrad_gemm(dY, X, G, *, M, N, K, lda, ldb, c_off, accumulate, a_off=0, b_off=0, bias_off=None, part=None):
@@ -98,7 +99,7 @@ def wgrad_gemm(dY, X, G, *, M, N, K, lda, ldb, c_off, accumulate, a_off=0, b_off
             if tiles * s <= 512 and K % s == 0 and K // s >= 256:
                 splits = s
                 break
-    fuse_bias = bias_off is not None and splits == 1 and xt >= 160 and K >= 512 and a_off == 0
+    fuse_bias = FUSE_BIAS_GRAD and bias_off is not None and splits == 1 and xt >= 160 and K >= 512 and a_off == 0
     if bias_off is not None and not fuse_bias:
         colsum(dY, lda, K, M, G, part, x_off=a_off, out_off=bias_off)
     if splits == 1:
@@ -137,6 +138,11 @@ def wgrad_gemm_group(problems: list, G):
         total = sum(tiles(p) for p in chunk)
         alone = sum(tiles(p) / fill(tiles(p)) for p in chunk)  # CU-rounds x 256 if launched one by one
         if len(chunk) > 1 and fill(total) >= 0.7 and total / fill(total) < 0.9 * alone:
+            if not FUSE_BIAS_GRAD:
+                for p in chunk:
+                    if p.get("bias_off") is not None:
+                        colsum(p["dY"], p["lda"], p["K"], p["M"], G, p["part"], out_off=p["bias_off"])
+                chunk = [{**p, "bias_off": None} for p in chunk]
             arr = (CaGemmDesc * len(chunk))()
             for i, p in enumerate(chunk):
                 arr[i] = _gemm_desc(p["dY"], p["X"], G, M=p["M"], N=p["N"], K=p["K"], a_layout=MNMAJOR, lda=p["lda"],

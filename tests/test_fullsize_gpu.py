@@ -91,6 +91,33 @@ def test_full_size_gradient_linearity_and_determinism(big):
         assert float(g1[n].abs().max()) > 0.0, n
 
 
+def test_full_size_bias_gradients_fused_equals_separate(big):
+    """Linear bias gradients come out of the weight-gradient kernel's A stream at this size (solo and grouped
+    launches); they must equal the separate column-sum pass up to fp32 summation order."""
+    from coral_amd import ops
+
+    eng, x, labels = big
+    names = [f"wav2vec2.encoder.layers.{l}.{p}.bias" for l in (0, 31, 47)
+             for p in ("feed_forward.output_dense", "feed_forward.intermediate_dense", "attention.out_proj", "attention.q_proj")]
+
+    def run(fuse):
+        ops.FUSE_BIAS_GRAD = fuse
+        try:
+            eng.zero_grad()
+            eng.forward(x, None, labels)
+            eng.backward()
+            torch.cuda.synchronize()
+            return {n: eng.store.view(n, "g32").clone() for n in names}
+        finally:
+            ops.FUSE_BIAS_GRAD = True
+
+    a, b = run(True), run(False)
+    for n in names:
+        scale = float(b[n].abs().max())
+        assert scale > 0.0, n
+        assert float((a[n] - b[n]).abs().max()) <= 1e-4 * scale, n
+
+
 def test_full_size_whisper_medium_properties():
     """BASELINE configs[3] at full size (whisper-medium, bf16, 30 s clips): clips are independent (batch
     permutation permutes the logits bit for bit) and the three greedy-decoding paths (prefix recompute, K|V
