@@ -7,6 +7,7 @@ or a non-GPU tensor raises.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -81,7 +82,8 @@ def gemm(A, B, Cout, **kw):
 
 
 _SPLITK_WS: dict = {}
-FUSE_BIAS_GRAD = True  # tests flip this to compare the fused bias gradient with the separate column-sum pass
+# tests (and CA_FUSE_BIAS=0) flip this to compare the fused bias gradient with the separate column-sum pass
+FUSE_BIAS_GRAD = os.environ.get("CA_FUSE_BIAS", "1") == "1"
 
 
 def wgrad_gemm(dY, X, G, *, M, N, K, lda, ldb, c_off, accumulate, a_off=0, b_off=0, bias_off=None, part=None):
