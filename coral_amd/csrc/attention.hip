@@ -200,8 +200,10 @@ static inline unsigned attn_grid(int ntile, int H, int B) { return (unsigned)(((
 // query (one shuffle per row) and are only touched when some maximum in the wave moved.  Tiles that lie
 // fully inside the valid key range take a path without any per-element masking.
 #define NEG_BIG (-1.0e30f)
+// 1024 workgroups at the path's shape (8 query tiles x 128 heads): at 4 waves per SIMD they are all resident at
+// once; at 3 (148 VGPRs) a second round runs one third full.
 template <int HDPV>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_fwd_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NKS = HDPV / 32, NNB = HDPV / 16;
   char* Kimg = smem;                  // K-major image of the key tile
@@ -511,7 +513,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a) {
 
 // ---- backward: dQ (workgroup = 64 queries, loops over the keys) ------------------------------------------
 template <int HDPV>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_bwd_dq_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NKS = HDPV / 32, NNB = HDPV / 16;
   constexpr int IMG = 64 * HDPV * 2;
