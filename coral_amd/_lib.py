@@ -60,6 +60,7 @@ class CaGemmDesc(C.Structure):
         ("dropout_p", C.c_float),
         ("dropout_seed", C.c_uint64),
         ("a_colsum", C.c_void_p),
+        ("a_colsum_ld", C.c_int64),
     ]
 
 

@@ -487,7 +487,8 @@ __global__ __launch_bounds__(512) void ca_gemm_kernel_x(const CaGemmGroup grp) {
   for (int i = 0; i < 8; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  const bool do_colsum = d.a_colsum != nullptr && tn == 0;
+  const int cs_parts = ((d.N + XBN - 1) / XBN) < 8 ? ((d.N + XBN - 1) / XBN) : 8;  // tile columns sharing the column sums
+  const bool do_colsum = d.a_colsum != nullptr && tn < cs_parts;
   float csum0 = 0.f, csum1 = 0.f;  // this lane's share of sum_k A[k, m] for m = m0 + wm*128 + (ih*4 + wn)*16 + (lane & 15)
 
   const int K = d.K;
@@ -557,10 +558,12 @@ __global__ __launch_bounds__(512) void ca_gemm_kernel_x(const CaGemmGroup grp) {
           acc[ih * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], acc[ih * 4 + i][j], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
     };
-    // bias gradient from the streaming A tile (a_colsum): the four waves of an m-half share the work, wave wn
-    // taking fragment i == wn of every block; only the workgroups of tile column 0 do it
+    // bias gradient from the streaming A tile (a_colsum): the K-steps are dealt round-robin to the first
+    // cs_parts tile columns; inside a workgroup the four waves of an m-half share the work, wave wn taking
+    // fragment i == wn of every block
+    const bool cs_step = do_colsum && (kt % cs_parts) == tn;  // this K-step belongs to this tile column
     auto colsum_acc = [&](int ih, bf16x8_t (&af)[4]) {
-      if (AL == CA_MNMAJOR && do_colsum) {
+      if (AL == CA_MNMAJOR && cs_step) {
         // (wn is wave-uniform: a branch per case keeps the fragments in registers - indexing af[] by a run-time
         // value would send the whole array through scratch memory)
         f32x4_t z;
@@ -627,7 +630,7 @@ __global__ __launch_bounds__(512) void ca_gemm_kernel_x(const CaGemmGroup grp) {
       s += __shfl_xor(s, 16, 64);
       s += __shfl_xor(s, 32, 64);
       const int m = m0 + wm * 128 + (ih * 4 + wn) * 16 + (lane & 15);
-      if (lane < 16 && m < d.M) d.a_colsum[m] += s;  // always accumulates, like ca_colsum_bf16 on this path
+      if (lane < 16 && m < d.M) d.a_colsum[(int64_t)tn * d.a_colsum_ld + m] = s;  // this tile column's share
     }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

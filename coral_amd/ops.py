@@ -42,10 +42,12 @@ def _gemm_desc(A, B, Cout, *, M, N, K, lda, ldb, ldc, a_layout=KMAJOR, b_layout=
          b_off=0, c_off=0, bias=None, bias_off=0, R=None, r_off=0, ldr=0, C2=None, c2_off=None,
          epilogue=EPI_NONE, out_f32=None, accumulate=False, alpha=1.0, batch1=1, batch2=1,
          sA=(0, 0), sB=(0, 0), sC=(0, 0), sR=(0, 0), sBias=(0, 0), a_kseg=0, a_kseg_stride=0, b_kseg=0,
-         b_kseg_stride=0, dropout_p=0.0, dropout_seed=0, a_colsum=None, a_colsum_off=0):
+         b_kseg_stride=0, dropout_p=0.0, dropout_seed=0, a_colsum=None, a_colsum_off=0,
+         a_colsum_ld=0):
     d = CaGemmDesc()
     if a_colsum is not None:
         d.a_colsum = _p(a_colsum, a_colsum_off)
+        d.a_colsum_ld = a_colsum_ld
     d.A, d.B = _p(A, a_off), _p(B, b_off)
     d.C = _p(Cout, c_off) if Cout is not None else None
     if C2 is not None:
@@ -86,28 +88,35 @@ _SPLITK_WS: dict = {}
 FUSE_BIAS_GRAD = os.environ.get("CA_FUSE_BIAS", "1") == "1"
 
 
-def wgrad_gemm(dY, X, G, *, M, N, K, lda, ldb, c_off, accumulate, a_off=0, b_off=0, bias_off=None, part=None):
-    """Weight gradient G[c_off : c_off + M*N] (+)= dY^T X  (dY [K, M] and X [K, N] token-major bf16, G fp32
-    row-major [M, N]) and, with bias_off, the bias gradient G[bias_off : bias_off + M] += dY.sum(0).
-    Shapes that would leave most of the chip idle (fewer 128x128 tiles than half the workgroup slots) are split
-    along K: the slices run as one batched GEMM into an fp32 workspace and a deterministic second pass adds them
-    up (no atomics: the result does not depend on scheduling).  Otherwise the bias gradient rides on the
-    256x256 kernel's A stream (CaGemmDesc.a_colsum) when that kernel fits, else it is a separate column sum."""
+COLSUM_PARTS = 8  # rows of the fused bias-gradient partials (CaGemmDesc.a_colsum)
+
+
+def _wgrad_splits(M, N, K):
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     xt = ((M + 255) // 256) * ((N + 255) // 256)
-    splits = 1
     if xt < 160 and tiles <= 256:
         for s in (8, 4, 2):
             if tiles * s <= 512 and K % s == 0 and K // s >= 256:
-                splits = s
-                break
-    fuse_bias = FUSE_BIAS_GRAD and bias_off is not None and splits == 1 and xt >= 160 and K >= 512 and a_off == 0
-    if bias_off is not None and not fuse_bias:
+                return s
+    return 1
+
+
+def wgrad_gemm(dY, X, G, *, M, N, K, lda, ldb, c_off, accumulate, a_off=0, b_off=0, bias_off=None, part=None,
+               cs=None):
+    """Weight gradient G[c_off : c_off + M*N] (+)= dY^T X  (dY [K, M] and X [K, N] token-major bf16, G fp32
+    row-major [M, N]).  Bias gradient (dY.sum(0)): either `bias_off` (+ `part` workspace) for a separate column-sum
+    pass into G[bias_off:], or `cs = (ws, off, ld)` to take partial column sums from the 256x256 kernel's A stream
+    (CaGemmDesc.a_colsum; the caller adds the COLSUM_PARTS rows).
+    Shapes that would leave most of the chip idle (fewer 128x128 tiles than half the workgroup slots) are split
+    along K: the slices run as one batched GEMM into an fp32 workspace and a deterministic second pass adds them
+    up (no atomics: the result does not depend on scheduling)."""
+    splits = 1 if cs is not None else _wgrad_splits(M, N, K)
+    if bias_off is not None:
         colsum(dY, lda, K, M, G, part, x_off=a_off, out_off=bias_off)
     if splits == 1:
+        kw = dict(a_colsum=cs[0], a_colsum_off=cs[1], a_colsum_ld=cs[2]) if cs is not None else {}
         gemm(dY, X, G, M=M, N=N, K=K, a_layout=MNMAJOR, lda=lda, b_layout=MNMAJOR, ldb=ldb, ldc=N, c_off=c_off,
-             a_off=a_off, b_off=b_off, out_f32=True, accumulate=accumulate,
-             a_colsum=G if fuse_bias else None, a_colsum_off=bias_off if fuse_bias else 0)
+             a_off=a_off, b_off=b_off, out_f32=True, accumulate=accumulate, **kw)
         return
     ws = _SPLITK_WS.get(G.device)
     if ws is None or ws.numel() < splits * M * N:
@@ -119,42 +128,63 @@ def wgrad_gemm(dY, X, G, *, M, N, K, lda, ldb, c_off, accumulate, a_off=0, b_off
     reduce_rows(ws, splits, M * N, M * N, G[c_off:], accumulate=accumulate)
 
 
-def wgrad_gemm_group(problems: list, G):
-    """Weight gradients of one layer (argument dicts of wgrad_gemm: dY, X, M, N, K, lda, ldb, c_off, accumulate) in
-    one grouped launch of the 256x256 kernel when together they fill at least 70 % of a round of CUs and beat
-    separate launches (they all contract over the same token dimension); otherwise one by one (split-K when tiny).
-    Measured: XLS-R-300M step 25.7 -> 23.6 ms, XLS-R-2B 92.0 -> 89.4 ms; Whisper blocks (128 tiles) stay on split-K."""
-    def tiles(p):
-        return ((p["M"] + 255) // 256) * ((p["N"] + 255) // 256)
+def _xtiles(p):
+    return ((p["M"] + 255) // 256) * ((p["N"] + 255) // 256)
 
-    def fill(t):
-        return t / (256.0 * ((t + 255) // 256))
 
-    # problems that fill the chip on their own keep their own launch (XCD-aware tile order); the rest share one
-    solo = [p for p in problems if fill(tiles(p)) >= 0.85 or p["K"] < 512]
-    rest = [p for p in problems if not (fill(tiles(p)) >= 0.85 or p["K"] < 512)]
-    for p in solo:
-        wgrad_gemm(p["dY"], p["X"], G, **{k: v for k, v in p.items() if k not in ("dY", "X")})
+def _fill(t):
+    return t / (256.0 * ((t + 255) // 256))
+
+
+def wgrad_plan(problems: list):
+    """-> (solo, groups, fallback): which weight gradients of a layer get their own launch of the 256x256 kernel,
+    which share grouped launches (lists of <= 4) and which fall back to the general path (split-K when tiny)."""
+    solo = [p for p in problems if _fill(_xtiles(p)) >= 0.85 and p["K"] >= 512]
+    rest = [p for p in problems if not (_fill(_xtiles(p)) >= 0.85 and p["K"] >= 512)]
+    groups, fallback = [], []
     while rest:
         chunk, rest = rest[:4], rest[4:]
-        total = sum(tiles(p) for p in chunk)
-        alone = sum(tiles(p) / fill(tiles(p)) for p in chunk)  # CU-rounds x 256 if launched one by one
-        if len(chunk) > 1 and fill(total) >= 0.7 and total / fill(total) < 0.9 * alone:
-            if not FUSE_BIAS_GRAD:
-                for p in chunk:
-                    if p.get("bias_off") is not None:
-                        colsum(p["dY"], p["lda"], p["K"], p["M"], G, p["part"], out_off=p["bias_off"])
-                chunk = [{**p, "bias_off": None} for p in chunk]
-            arr = (CaGemmDesc * len(chunk))()
-            for i, p in enumerate(chunk):
-                arr[i] = _gemm_desc(p["dY"], p["X"], G, M=p["M"], N=p["N"], K=p["K"], a_layout=MNMAJOR, lda=p["lda"],
-                                    b_layout=MNMAJOR, ldb=p["ldb"], ldc=p["N"], c_off=p["c_off"], out_f32=True,
-                                    accumulate=p["accumulate"], a_colsum=G if p.get("bias_off") is not None else None,
-                                    a_colsum_off=p.get("bias_off") or 0)
-            check(lib().ca_gemm_bf16_group(arr, len(chunk), _stream()), "ca_gemm_bf16_group")
+        total = sum(_xtiles(p) for p in chunk)
+        alone = sum(_xtiles(p) / _fill(_xtiles(p)) for p in chunk)  # CU-rounds x 256 if launched one by one
+        if len(chunk) > 1 and _fill(total) >= 0.7 and total / _fill(total) < 0.9 * alone and all(p["K"] >= 512 for p in chunk):
+            groups.append(chunk)
         else:
-            for p in chunk:
-                wgrad_gemm(p["dY"], p["X"], G, **{k: v for k, v in p.items() if k not in ("dY", "X")})
+            fallback += chunk
+    return solo, groups, fallback
+
+
+def wgrad_gemm_group(problems: list, G, colsum_ws=None, colsum_ld=0) -> bool:
+    """Weight gradients of one layer (dicts: dY, X, M, N, K, lda, ldb, c_off, accumulate, bias_off, part, cs_off).
+    Under-filled problems that contract over the same tokens share one grouped launch of the 256x256 kernel when
+    together they fill >= 70 % of a round of CUs and beat separate launches; well-filled ones keep their own launch.
+    Measured: XLS-R-300M step 25.7 -> 23.6 ms, XLS-R-2B 92.0 -> 89.4 ms; Whisper blocks (128 tiles) stay on split-K.
+
+    Bias gradients: when every problem is served by the 256x256 kernel and `colsum_ws` is given, each launch leaves
+    COLSUM_PARTS rows of partial column sums at colsum_ws[p * colsum_ld + cs_off + m] and the function returns True
+    (the caller adds the rows with one reduce_rows); otherwise they are separate column-sum passes into
+    G[bias_off:] and the function returns False."""
+    solo, groups, fallback = wgrad_plan(problems)
+    fused = FUSE_BIAS_GRAD and colsum_ws is not None and not fallback and all("cs_off" in p for p in problems)
+
+    def bias_kw(p):
+        return dict(cs=(colsum_ws, p["cs_off"], colsum_ld)) if fused else dict(bias_off=p.get("bias_off"), part=p.get("part"))
+
+    def base(p):
+        return {k: p[k] for k in ("M", "N", "K", "lda", "ldb", "c_off", "accumulate")}
+
+    for p in solo + fallback:
+        wgrad_gemm(p["dY"], p["X"], G, **base(p), **bias_kw(p))
+    for chunk in groups:
+        arr = (CaGemmDesc * len(chunk))()
+        for i, p in enumerate(chunk):
+            if not fused and p.get("bias_off") is not None:
+                colsum(p["dY"], p["lda"], p["K"], p["M"], G, p["part"], out_off=p["bias_off"])
+            kw = dict(a_colsum=colsum_ws, a_colsum_off=p["cs_off"], a_colsum_ld=colsum_ld) if fused else {}
+            arr[i] = _gemm_desc(p["dY"], p["X"], G, M=p["M"], N=p["N"], K=p["K"], a_layout=MNMAJOR, lda=p["lda"],
+                                b_layout=MNMAJOR, ldb=p["ldb"], ldc=p["N"], c_off=p["c_off"], out_f32=True,
+                                accumulate=p["accumulate"], **kw)
+        check(lib().ca_gemm_bf16_group(arr, len(chunk), _stream()), "ca_gemm_bf16_group")
+    return fused
 
 
 def layernorm_fwd(x, gamma, beta, y, stats, rows, Cn, eps=1e-5, act=0, x_off=0, y_off=0):

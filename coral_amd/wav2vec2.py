@@ -125,11 +125,13 @@ def w2v2_param_list(s: Wav2Vec2Shape) -> list[tuple[str, tuple, str]]:
         b = f"layer{l}"
         # small tensors first (one contiguous slice to clear per step), then the matrices whose
         # gradients are written -- not accumulated -- by the first micro-batch's wgrad GEMMs
-        out += [(p + "layer_norm.weight", (d,), b), (p + "layer_norm.bias", (d,), b)]
+        out += [(p + "layer_norm.weight", (d,), b), (p + "layer_norm.bias", (d,), b),
+                (p + "final_layer_norm.weight", (d,), b), (p + "final_layer_norm.bias", (d,), b)]
+        # the four Linear biases are contiguous (q|k|v, out, ffn1, ffn2 = 5d + f floats): their gradients come out of
+        # the weight-gradient kernels as partial column sums and are added in one pass (backward())
         for n in ("q_proj", "k_proj", "v_proj"):
             out.append((p + f"attention.{n}.bias", (d,), b))
         out += [(p + "attention.out_proj.bias", (d,), b),
-                (p + "final_layer_norm.weight", (d,), b), (p + "final_layer_norm.bias", (d,), b),
                 (p + "feed_forward.intermediate_dense.bias", (f,), b),
                 (p + "feed_forward.output_dense.bias", (d,), b)]
         for n in ("q_proj", "k_proj", "v_proj"):
@@ -333,6 +335,9 @@ class Wav2Vec2CTCEngine:
         w["du"] = z(M * f)
         w["dxg"] = z(B * G * (T + K) * Cg + 8 * Cg)
         w["dwf"] = z(d * K * Cg, dt=f32)
+        # partial column sums of the layer's four dY (fused bias gradients): rows that a problem with fewer than
+        # COLSUM_PARTS tile columns never writes stay zero
+        w["bias_ws"] = z(ops.COLSUM_PARTS * (5 * d + s.intermediate_size), dt=f32)
         nmax = max(B * Ts[i] * s.conv_kernel[i] * s.conv_dim[i - 1] for i in range(1, 7))
         w["dcol"] = z(nmax)
         w["dconv"] = [z(B * Ts[i] * s.conv_dim[i]) for i in range(7)]   # grads wrt conv block outputs
@@ -553,7 +558,7 @@ class Wav2Vec2CTCEngine:
             # dh, du, dh1 and dqkv all stay untouched until then
             wg = [dict(dY=dh, X=w["g"][l], M=d, N=f, K=M, lda=d, ldb=f, part=part,
                        c_off=o(pl + "feed_forward.output_dense.weight"), accumulate=lacc,
-                       bias_off=o(pl + "feed_forward.output_dense.bias"))]
+                       bias_off=o(pl + "feed_forward.output_dense.bias"), cs_off=4 * d + f)]
             ops.gemm(dh, p16, w["du"], M=M, N=f, K=d, lda=d, b_layout=MNMAJOR, ldb=f, ldc=f,
                      b_off=o(pl + "feed_forward.output_dense.weight"), epilogue=EPI_DGELU, R=w["u"][l],
                      ldr=f, dropout_p=drop_p, dropout_seed=self.step_seed * 1000 + l)
@@ -561,7 +566,7 @@ class Wav2Vec2CTCEngine:
             du = w["du"]
             wg.append(dict(dY=du, X=w["x2"][l], M=f, N=d, K=M, lda=f, ldb=d, part=part,
                            c_off=o(pl + "feed_forward.intermediate_dense.weight"), accumulate=lacc,
-                           bias_off=o(pl + "feed_forward.intermediate_dense.bias")))
+                           bias_off=o(pl + "feed_forward.intermediate_dense.bias"), cs_off=4 * d))
             ops.gemm(du, p16, other, M=M, N=d, K=f, lda=f, b_layout=MNMAJOR, ldb=d, ldc=d,
                      b_off=o(pl + "feed_forward.intermediate_dense.weight"))
             # LN2: dh1 = dh + LN'(dx2)
@@ -572,7 +577,7 @@ class Wav2Vec2CTCEngine:
             # out_proj: h1 = h + Wo ctx + bo
             wg.append(dict(dY=dh1, X=w["ctx"][l], M=d, N=d, K=M, lda=d, ldb=d, part=part,
                            c_off=o(pl + "attention.out_proj.weight"), accumulate=lacc,
-                           bias_off=o(pl + "attention.out_proj.bias")))
+                           bias_off=o(pl + "attention.out_proj.bias"), cs_off=3 * d))
             dctx = other
             ops.gemm(dh1, p16, dctx, M=M, N=d, K=d, lda=d, b_layout=MNMAJOR, ldb=d, ldc=d,
                      b_off=o(pl + "attention.out_proj.weight"))
@@ -580,8 +585,10 @@ class Wav2Vec2CTCEngine:
             dqkv = w["dqkv"]
             wg.append(dict(dY=dqkv, X=w["x1"][l], M=3 * d, N=d, K=M, lda=3 * d, ldb=d, part=part,
                            c_off=o(pl + "attention.q_proj.weight"), accumulate=lacc,
-                           bias_off=o(pl + "attention.q_proj.bias")))
-            ops.wgrad_gemm_group(wg, g32)
+                           bias_off=o(pl + "attention.q_proj.bias"), cs_off=0))
+            nb = 5 * d + f  # q|k|v, out, ffn1, ffn2 biases: contiguous in the flat buffer (w2v2_param_list)
+            if ops.wgrad_gemm_group(wg, g32, colsum_ws=w["bias_ws"], colsum_ld=nb):
+                ops.reduce_rows(w["bias_ws"], ops.COLSUM_PARTS, nb, nb, g32[o(pl + "attention.q_proj.bias"):], accumulate=True)
             dx1 = other
             ops.gemm(dqkv, p16, dx1, M=M, N=d, K=3 * d, lda=3 * d, b_layout=MNMAJOR, ldb=d, ldc=d,
                      b_off=o(pl + "attention.q_proj.weight"))

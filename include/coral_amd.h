@@ -91,11 +91,14 @@ typedef struct CaGemmDesc {
    * keep-mask = hash(seed, m*N+n) >= p; kept values scaled by 1/(1-p). p = 0 disables. */
   float dropout_p;
   uint64_t dropout_seed;
-  /* Optional, weight-gradient form only (a_layout = b_layout = MNMAJOR, served by the 256x256 kernel): fp32
-   * vector [M] receiving sum_k A[k, m] — the bias gradient that autograd's Linear backward computes as
-   * dY.sum(0) — taken from the A tiles as they stream through the kernel instead of a second pass over dY.
-   * Always accumulated (+=): bias gradients live in the per-step-zeroed part of the gradient buffer.  NULL = off. */
+  /* Optional, weight-gradient form only (a_layout = b_layout = MNMAJOR, served by the 256x256 kernel): partial
+   * column sums of A — the bias gradient that autograd's Linear backward computes as dY.sum(0) — taken from the A
+   * tiles as they stream through the kernel instead of a second pass over dY.  The K-steps are dealt round-robin
+   * to the first P = min(8, ceil(N/256)) tile columns, and tile column p stores its share to
+   * a_colsum[p * a_colsum_ld + m] (plain stores; rows p >= P are not touched).  The caller adds the P rows
+   * (ca_reduce_rows_f32).  NULL = off. */
   float* a_colsum;
+  int64_t a_colsum_ld;
 } CaGemmDesc;
 
 int ca_gemm_bf16(const CaGemmDesc* desc, void* stream);

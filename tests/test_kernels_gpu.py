@@ -522,51 +522,33 @@ def test_skinny_gemm_matches_torch(ops, M, N, K):
 
 
 def test_weight_gradient_with_fused_bias_gradient_and_grouped_launch(ops):
-    """ops.wgrad_gemm (+ bias gradient from the kernel's A stream, CaGemmDesc.a_colsum) and
-    ops.wgrad_gemm_group (several problems in one launch) against torch, overwrite and accumulate."""
+    """ops.wgrad_gemm_group: grouped / solo launches of the 256x256 kernel with the bias gradients taken from the
+    kernel's A stream as partial column sums (CaGemmDesc.a_colsum), and the unfused fallback, against torch."""
     g = torch.Generator().manual_seed(21)
     K = 1000
-    specs = [(2304, 768), (768, 768), (768, 3072), (3072, 768)]  # q|k|v, out-proj, fc2, fc1 of a d = 768 layer
-    dYs = [(torch.randn(K, m, generator=g) * 0.5).to(torch.bfloat16) for m, _ in specs]
-    Xs = [(torch.randn(K, n, generator=g) * 0.5).to(torch.bfloat16) for _, n in specs]
-    sizes = [m * n for m, n in specs]
-    offs = np.concatenate([[0], np.cumsum(sizes)]).tolist()
-    boff = offs[-1]
-    boffs = [boff + int(sum(m for m, _ in specs[:i])) for i in range(len(specs))]
-    total = boffs[-1] + specs[-1][0]
-    G = torch.full((total + 8,), 0.25, dtype=torch.float32, device=DEV)
-    part = torch.zeros(max(ops.colsum_partial_floats(K, 3072), 4096), dtype=torch.float32, device=DEV)
-    probs = [dict(dY=dYs[i].to(DEV), X=Xs[i].to(DEV), M=specs[i][0], N=specs[i][1], K=K, lda=specs[i][0], ldb=specs[i][1],
-                  c_off=offs[i], accumulate=True, bias_off=boffs[i], part=part) for i in range(4)]
-    ops.wgrad_gemm_group(probs, G)
-    torch.cuda.synchronize()
-    Gc = G.cpu()
-    for i, (m, n) in enumerate(specs):
-        want = dYs[i].float().t() @ Xs[i].float() + 0.25
-        got = Gc[offs[i]:offs[i] + m * n].view(m, n)
-        assert (got - want).abs().max() <= 2e-3 * float(want.abs().max()), i
-        wb = dYs[i].float().sum(0) + 0.25
-        gb = Gc[boffs[i]:boffs[i] + m]
-        assert (gb - wb).abs().max() <= 2e-3 * max(1.0, float(wb.abs().max())), ("bias", i)
-    # a single large problem: kernel X alone with the fused column sum, overwrite mode
-    m, n = 4096, 2048
-    dY = (torch.randn(K, m, generator=g) * 0.5).to(torch.bfloat16)
-    X = (torch.randn(K, n, generator=g) * 0.5).to(torch.bfloat16)
-    G2 = torch.full((m * n + m,), 7.0, dtype=torch.float32, device=DEV)
-    ops.wgrad_gemm(dY.to(DEV), X.to(DEV), G2, M=m, N=n, K=K, lda=m, ldb=n, c_off=0, accumulate=False, bias_off=m * n, part=part)
-    torch.cuda.synchronize()
-    want = dY.float().t() @ X.float()
-    assert (G2[:m * n].view(m, n).cpu() - want).abs().max() <= 2e-3 * float(want.abs().max())
-    wb = dY.float().sum(0) + 7.0  # bias gradients always accumulate
-    assert (G2[m * n:].cpu() - wb).abs().max() <= 2e-3 * float(wb.abs().max())
-    # ... and the same through kernel X's fused column sum (forced by a shape that selects it)
-    m, n = 7680, 1920
-    dY = (torch.randn(K, m, generator=g) * 0.5).to(torch.bfloat16)
-    X = (torch.randn(K, n, generator=g) * 0.5).to(torch.bfloat16)
-    G3 = torch.full((m * n + m,), 1.5, dtype=torch.float32, device=DEV)
-    ops.wgrad_gemm(dY.to(DEV), X.to(DEV), G3, M=m, N=n, K=K, lda=m, ldb=n, c_off=0, accumulate=False, bias_off=m * n, part=part)
-    torch.cuda.synchronize()
-    want = dY.float().t() @ X.float()
-    assert (G3[:m * n].view(m, n).cpu() - want).abs().max() <= 2e-3 * float(want.abs().max())
-    wb = dY.float().sum(0) + 1.5
-    assert (G3[m * n:].cpu() - wb).abs().max() <= 2e-3 * float(wb.abs().max())
+    for specs, expect_fused in ([(5760, 1920), (1920, 1920), (1920, 7680), (7680, 1920)], True), \
+                               ([(2304, 768), (768, 768), (768, 3072), (3072, 768)], False):
+        dYs = [(torch.randn(K, m, generator=g) * 0.5).to(torch.bfloat16) for m, _ in specs]
+        Xs = [(torch.randn(K, n, generator=g) * 0.5).to(torch.bfloat16) for _, n in specs]
+        offs = np.concatenate([[0], np.cumsum([m * n for m, n in specs])]).tolist()
+        nb = sum(m for m, _ in specs)
+        cs_offs = np.concatenate([[0], np.cumsum([m for m, _ in specs])]).tolist()
+        G = torch.full((offs[-1] + nb,), 0.25, dtype=torch.float32, device=DEV)
+        ws = torch.zeros(ops.COLSUM_PARTS * nb, dtype=torch.float32, device=DEV)
+        part = torch.zeros(max(ops.colsum_partial_floats(K, 7680), 4096), dtype=torch.float32, device=DEV)
+        probs = [dict(dY=dYs[i].to(DEV), X=Xs[i].to(DEV), M=specs[i][0], N=specs[i][1], K=K, lda=specs[i][0],
+                      ldb=specs[i][1], c_off=offs[i], accumulate=True, bias_off=offs[-1] + cs_offs[i], part=part,
+                      cs_off=cs_offs[i]) for i in range(4)]
+        fused = ops.wgrad_gemm_group(probs, G, colsum_ws=ws, colsum_ld=nb)
+        assert fused == expect_fused
+        if fused:
+            ops.reduce_rows(ws, ops.COLSUM_PARTS, nb, nb, G[offs[-1]:], accumulate=True)
+        torch.cuda.synchronize()
+        Gc = G.cpu()
+        for i, (m, n) in enumerate(specs):
+            want = dYs[i].float().t() @ Xs[i].float() + 0.25
+            got = Gc[offs[i]:offs[i] + m * n].view(m, n)
+            assert (got - want).abs().max() <= 2e-3 * float(want.abs().max()), i
+            wb = dYs[i].float().sum(0) + 0.25
+            gb = Gc[offs[-1] + cs_offs[i]:offs[-1] + cs_offs[i] + m]
+            assert (gb - wb).abs().max() <= 2e-3 * max(1.0, float(wb.abs().max())), ("bias", i, fused)
