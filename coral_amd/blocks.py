@@ -64,8 +64,10 @@ class SelfAttnBlock:
                  bias=st.p32, bias_off=st.off(self.attn + "out_proj.bias"), epilogue=EPI_RESIDUAL, R=hin, ldr=d)
         sv["hin"], sv["klen"] = hin, klen
 
-    def backward(self, dh, dhin, sv, sc: Scratch, B, T):
-        """dh: grad wrt h_out (kept intact); dhin: output buffer for grad wrt h_in (may alias nothing of sv)."""
+    def backward(self, dh, dhin, sv, sc: Scratch, B, T, defer=None):
+        """dh: grad wrt h_out (kept intact); dhin: output buffer for grad wrt h_in (may alias nothing of sv).
+        defer: list collecting the block's weight-gradient problems instead of launching them (the caller launches
+        the whole layer's group once dh and sc.dqkv are no longer needed elsewhere)."""
         st, d = self.st, self.d
         M = B * T
         o, g32, p16 = st.off, st.g32, st.p16
@@ -79,7 +81,10 @@ class SelfAttnBlock:
         ops.colsum(dqkv, 3 * d, M, 3 * d, g32, sc.part, out_off=o(self.qbias))
         wg.append(dict(dY=dqkv, X=sv["x"], M=3 * d, N=d, K=M, lda=3 * d, ldb=d, c_off=o(self.attn + "q_proj.weight"),
                        accumulate=True))
-        ops.wgrad_gemm_group(wg, g32)  # both weight gradients of the block in one grouped launch
+        if defer is not None:
+            defer.extend(wg)
+        else:
+            ops.wgrad_gemm_group(wg, g32)  # both weight gradients of the block in one grouped launch
         ops.gemm(dqkv, p16, sc.dx, M=M, N=d, K=3 * d, lda=3 * d, b_layout=MNMAJOR, ldb=d, ldc=d, b_off=o(self.attn + "q_proj.weight"))
         ops.layernorm_bwd(sc.dx, sv["hin"], st.view(self.ln + ".weight"), None, sv["st"], dh, dhin,
                           st.view(self.ln + ".weight", "g32"), st.view(self.ln + ".bias", "g32"), sc.part, M, d)
@@ -167,7 +172,7 @@ class FFNBlock:
                  bias_off=st.off(self.fc2 + ".bias"), epilogue=EPI_RESIDUAL, R=hin, ldr=d)
         sv["hin"], sv["drop"] = hin, (dropout_p, seed)
 
-    def backward(self, dh, dhin, sv, sc: Scratch, M):
+    def backward(self, dh, dhin, sv, sc: Scratch, M, defer=None):
         st, d, f = self.st, self.d, self.f
         o, g32, p16 = st.off, st.g32, st.p16
         p, seed = sv["drop"]
@@ -177,7 +182,10 @@ class FFNBlock:
                  epilogue=EPI_DGELU, R=sv["u"], ldr=f, dropout_p=p, dropout_seed=seed)
         ops.colsum(sc.du, f, M, f, g32, sc.part, out_off=o(self.fc1 + ".bias"))
         wg.append(dict(dY=sc.du, X=sv["x"], M=f, N=d, K=M, lda=f, ldb=d, c_off=o(self.fc1 + ".weight"), accumulate=True))
-        ops.wgrad_gemm_group(wg, g32)
+        if defer is not None:
+            defer.extend(wg)
+        else:
+            ops.wgrad_gemm_group(wg, g32)
         ops.gemm(sc.du, p16, sc.dx, M=M, N=d, K=f, lda=f, b_layout=MNMAJOR, ldb=d, ldc=d, b_off=o(self.fc1 + ".weight"))
         ops.layernorm_bwd(sc.dx, sv["hin"], st.view(self.ln + ".weight"), None, sv["st"], dh, dhin,
                           st.view(self.ln + ".weight", "g32"), st.view(self.ln + ".bias", "g32"), sc.part, M, d)

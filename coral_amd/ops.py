@@ -142,14 +142,27 @@ def wgrad_plan(problems: list):
     solo = [p for p in problems if _fill(_xtiles(p)) >= 0.85 and p["K"] >= 512]
     rest = [p for p in problems if not (_fill(_xtiles(p)) >= 0.85 and p["K"] >= 512)]
     groups, fallback = [], []
-    while rest:
-        chunk, rest = rest[:4], rest[4:]
-        total = sum(_xtiles(p) for p in chunk)
-        alone = sum(_xtiles(p) / _fill(_xtiles(p)) for p in chunk)  # CU-rounds x 256 if launched one by one
-        if len(chunk) > 1 and _fill(total) >= 0.7 and total / _fill(total) < 0.9 * alone and all(p["K"] >= 512 for p in chunk):
-            groups.append(chunk)
-        else:
-            fallback += chunk
+    import itertools
+
+    rest = [p for p in rest if p["K"] >= 512] + [p for p in rest if p["K"] < 512]
+    small_k = [p for p in rest if p["K"] < 512]
+    rest = [p for p in rest if p["K"] >= 512]
+    while len(rest) > 1:
+        # the subset (2..4 problems) that fills its rounds of CUs best; stop when nothing reaches 70 %
+        best, best_fill = None, 0.0
+        for r in range(min(4, len(rest)), 1, -1):
+            for combo in itertools.combinations(range(len(rest)), r):
+                total = sum(_xtiles(rest[i]) for i in combo)
+                alone = sum(_xtiles(rest[i]) / _fill(_xtiles(rest[i])) for i in combo)
+                f = _fill(total)
+                if f >= 0.7 and total / f < 0.9 * alone and (f > best_fill + 1e-9 or (abs(f - best_fill) < 1e-9 and best is not None
+                                                                                 and len(combo) > len(best))):
+                    best, best_fill = combo, f
+        if best is None:
+            break
+        groups.append([rest[i] for i in best])
+        rest = [p for i, p in enumerate(rest) if i not in best]
+    fallback = rest + small_k
     return solo, groups, fallback
 
 

@@ -114,7 +114,7 @@ class WhisperTrainEngine(WhisperEngine):
             dlogits16=_z(Md * _r8(s.vocab_size), dev),
             loss_sum=_z(1, dev, f32), count=torch.zeros(1, dtype=torch.int32, device=dev),
             sc_e=Scratch(Me, d, s.encoder_ffn_dim, dev), sc_d=Scratch(Md, d, s.decoder_ffn_dim, dev, Mkv=Me),
-            g_e=[_z(Me * d, dev), _z(Me * d, dev)], g_d=[_z(Md * d, dev), _z(Md * d, dev)],
+            g_e=[_z(Me * d, dev), _z(Me * d, dev), _z(Me * d, dev)], g_d=[_z(Md * d, dev), _z(Md * d, dev)],
             denc32=_z(Me * d, dev, f32), dpre=_z(B * (Tin + 2) * d + 64, dev),
             dcol=_z(Me * 3 * d, dev), dwr_part=_z(B * d * 3 * max(d, s.num_mel_bins), dev, f32),
             dwr=_z(d * 3 * max(d, s.num_mel_bins), dev, f32))
@@ -250,22 +250,25 @@ class WhisperTrainEngine(WhisperEngine):
                              dpos_off=o("model.decoder.embed_positions.weight"))
         done("emb")
         # encoder
-        ea, eb = w["g_e"]
+        ea, eb, ec = w["g_e"]
         ops.cast_f32_bf16(w["denc32"], ea, Me * d)
         ops.layernorm_bwd(ea, w["eh"][-1], st.view("model.encoder.layer_norm.weight"), None, w["enc_st"], None, eb,
                           st.view("model.encoder.layer_norm.weight", "g32"), st.view("model.encoder.layer_norm.bias", "g32"),
                           sc_e.part, Me, d)
-        cur, other = eb, ea
+        cur, other, third = eb, ea, ec
         for l in reversed(range(s.encoder_layers)):
             if not sv["ek"][l]:
                 done(f"enc{l}")
                 continue
             sa, ff = self.enc_blocks[l]
             sv_a, sv_f = w["enc_sv"][l]
-            ff.backward(cur, other, sv_f, sc_e, Me)
-            cur, other = other, cur
-            sa.backward(cur, other, sv_a, sc_e, B, T)
-            cur, other = other, cur
+            # three rotating buffers: both blocks' dY stay alive until the layer's four weight gradients go out as
+            # one grouped launch (192 tiles of the 256x256 kernel at d = 1024 instead of four split-K launches)
+            wg = []
+            ff.backward(cur, other, sv_f, sc_e, Me, defer=wg)
+            sa.backward(other, third, sv_a, sc_e, B, T, defer=wg)
+            ops.wgrad_gemm_group(wg, g32)
+            cur, other, third = third, cur, other
             self.clear_internal_grads_of(f"model.encoder.layers.{l}.")
             done(f"enc{l}")
         done("encf")
