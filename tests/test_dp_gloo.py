@@ -47,7 +47,23 @@ def _worker(rank, world, port, q):
     s3.start_all()
     s3.finish()
     ok_bf16 = bool((g3 - want3.to(torch.bfloat16).float()).abs().max() <= 1e-6 + 0.008 * want3.abs().max())
-    q.put((rank, ok_sum, ok_mean, ok_partial, launched == order and ok_bf16, shard_indices(8, rank, world)))
+    # post-reduction callback (the trainer's per-bucket squared norm): runs once per bucket, after the bucket holds
+    # the reduced values (also through the bf16 wire), in launch order
+    g4 = (torch.arange(200, dtype=torch.float32) * 0.5 + rank).clone()
+    want4 = sum((torch.arange(200, dtype=torch.float32) * 0.5 + r) for r in range(world))
+    seen = []
+    s4 = GradSync(g4, buckets)
+
+    def post(name):
+        lo, hi = buckets[name]
+        seen.append((name, float((g4[lo:hi] ** 2).sum())))
+
+    for name in ("head", "layer1", "layer0", "front"):
+        s4.start(name, post=post)
+    s4.finish()
+    ok_post = [n for n, _ in seen] == ["head", "layer1", "layer0", "front"] and torch.equal(g4, want4) and all(
+        abs(v - float((want4[buckets[n][0]:buckets[n][1]] ** 2).sum())) <= 1e-3 * v for n, v in seen)
+    q.put((rank, ok_sum, ok_mean, ok_partial, launched == order and ok_bf16 and ok_post, shard_indices(8, rank, world)))
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 
