@@ -71,16 +71,21 @@ class SelfAttnBlock:
         st, d = self.st, self.d
         M = B * T
         o, g32, p16 = st.off, st.g32, st.p16
-        ops.colsum(dh, d, M, d, g32, sc.part, out_off=o(self.attn + "out_proj.bias"))
-        wg = [dict(dY=dh, X=sv["ctx"], M=d, N=d, K=M, lda=d, ldb=d, c_off=o(self.attn + "out_proj.weight"), accumulate=True)]
+        # with `defer` the bias gradients travel with the problems (fused into the grouped launch or done by it)
+        if defer is None:
+            ops.colsum(dh, d, M, d, g32, sc.part, out_off=o(self.attn + "out_proj.bias"))
+        wg = [dict(dY=dh, X=sv["ctx"], M=d, N=d, K=M, lda=d, ldb=d, c_off=o(self.attn + "out_proj.weight"), accumulate=True,
+                   **(dict(bias_off=o(self.attn + "out_proj.bias"), part=sc.part, cs_off=3 * d) if defer is not None else {}))]
         ops.gemm(dh, p16, sc.dctx, M=M, N=d, K=d, lda=d, b_layout=MNMAJOR, ldb=d, ldc=d, b_off=o(self.attn + "out_proj.weight"))
         qkv, dqkv = sv["qkv"], sc.dqkv
         ops.attn_bwd(qkv, qkv, qkv, sv["ctx"], sv["lse"], sc.dctx, sv["Dq"], dqkv, dqkv, dqkv, lddo=d, sdob=T * d, lddq=3 * d,
                      lddk=3 * d, lddv=3 * d, sdqb=T * 3 * d, sdkb=T * 3 * d, sdvb=T * 3 * d, dq_off=0, dk_off=d, dv_off=2 * d,
                      **self._akw(B, T, sv, sv["klen"]))
-        ops.colsum(dqkv, 3 * d, M, 3 * d, g32, sc.part, out_off=o(self.qbias))
+        if defer is None:
+            ops.colsum(dqkv, 3 * d, M, 3 * d, g32, sc.part, out_off=o(self.qbias))
         wg.append(dict(dY=dqkv, X=sv["x"], M=3 * d, N=d, K=M, lda=3 * d, ldb=d, c_off=o(self.attn + "q_proj.weight"),
-                       accumulate=True))
+                       accumulate=True,
+                       **(dict(bias_off=o(self.qbias), part=sc.part, cs_off=0) if defer is not None else {})))
         if defer is not None:
             defer.extend(wg)
         else:
@@ -176,12 +181,16 @@ class FFNBlock:
         st, d, f = self.st, self.d, self.f
         o, g32, p16 = st.off, st.g32, st.p16
         p, seed = sv["drop"]
-        ops.colsum(dh, d, M, d, g32, sc.part, out_off=o(self.fc2 + ".bias"))
-        wg = [dict(dY=dh, X=sv["g"], M=d, N=f, K=M, lda=d, ldb=f, c_off=o(self.fc2 + ".weight"), accumulate=True)]
+        if defer is None:
+            ops.colsum(dh, d, M, d, g32, sc.part, out_off=o(self.fc2 + ".bias"))
+        wg = [dict(dY=dh, X=sv["g"], M=d, N=f, K=M, lda=d, ldb=f, c_off=o(self.fc2 + ".weight"), accumulate=True,
+                   **(dict(bias_off=o(self.fc2 + ".bias"), part=sc.part, cs_off=4 * d + f) if defer is not None else {}))]
         ops.gemm(dh, p16, sc.du, M=M, N=f, K=d, lda=d, b_layout=MNMAJOR, ldb=f, ldc=f, b_off=o(self.fc2 + ".weight"),
                  epilogue=EPI_DGELU, R=sv["u"], ldr=f, dropout_p=p, dropout_seed=seed)
-        ops.colsum(sc.du, f, M, f, g32, sc.part, out_off=o(self.fc1 + ".bias"))
-        wg.append(dict(dY=sc.du, X=sv["x"], M=f, N=d, K=M, lda=f, ldb=d, c_off=o(self.fc1 + ".weight"), accumulate=True))
+        if defer is None:
+            ops.colsum(sc.du, f, M, f, g32, sc.part, out_off=o(self.fc1 + ".bias"))
+        wg.append(dict(dY=sc.du, X=sv["x"], M=f, N=d, K=M, lda=f, ldb=d, c_off=o(self.fc1 + ".weight"), accumulate=True,
+                       **(dict(bias_off=o(self.fc1 + ".bias"), part=sc.part, cs_off=4 * d) if defer is not None else {})))
         if defer is not None:
             defer.extend(wg)
         else:

@@ -115,7 +115,7 @@ class WhisperTrainEngine(WhisperEngine):
             loss_sum=_z(1, dev, f32), count=torch.zeros(1, dtype=torch.int32, device=dev),
             sc_e=Scratch(Me, d, s.encoder_ffn_dim, dev), sc_d=Scratch(Md, d, s.decoder_ffn_dim, dev, Mkv=Me),
             g_e=[_z(Me * d, dev), _z(Me * d, dev), _z(Me * d, dev)], g_d=[_z(Md * d, dev), _z(Md * d, dev)],
-            denc32=_z(Me * d, dev, f32), dpre=_z(B * (Tin + 2) * d + 64, dev),
+            bias_ws=_z(ops.COLSUM_PARTS * (5 * d + s.encoder_ffn_dim), dev, f32), denc32=_z(Me * d, dev, f32), dpre=_z(B * (Tin + 2) * d + 64, dev),
             dcol=_z(Me * 3 * d, dev), dwr_part=_z(B * d * 3 * max(d, s.num_mel_bins), dev, f32),
             dwr=_z(d * 3 * max(d, s.num_mel_bins), dev, f32))
         self._tw, self._tw_key = w, key
@@ -267,7 +267,10 @@ class WhisperTrainEngine(WhisperEngine):
             wg = []
             ff.backward(cur, other, sv_f, sc_e, Me, defer=wg)
             sa.backward(other, third, sv_a, sc_e, B, T, defer=wg)
-            ops.wgrad_gemm_group(wg, g32)
+            nb = 5 * d + s.encoder_ffn_dim
+            if ops.wgrad_gemm_group(wg, g32, colsum_ws=w["bias_ws"], colsum_ld=nb):
+                ops.reduce_rows(w["bias_ws"], ops.COLSUM_PARTS, nb, nb,
+                                g32[o(f"model.encoder.layers.{l}.self_attn.q_proj.bias"):], accumulate=True)
             cur, other, third = third, cur, other
             self.clear_internal_grads_of(f"model.encoder.layers.{l}.")
             done(f"enc{l}")
