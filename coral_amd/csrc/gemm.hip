@@ -165,12 +165,53 @@ __device__ __forceinline__ void lds_wait(bf16x8_t (&f)[4]) {
 // cut into super-blocks of SBM x SBN tiles (= the number of tiles one XCD holds at once); the
 // i-th workgroup of XCD x works on tile (i % (SBM*SBN)) of super-block (i / (SBM*SBN))*8 + x.
 // Placement only affects speed: any dispatch order gives the same result.
-template <int SBM, int SBN>
-__device__ __forceinline__ bool tile_of_block(int bid, int ntm, int ntn, int& tm, int& tn) {
-  if ((int)gridDim.x == ntm * ntn) {  // small problem: plain row-major tiles, no padding blocks
+// Small / medium grids: the tile grid is cut into exactly 8 rectangular blocks, one per XCD (bm x bn blocks with
+// bm * bn = 8, the split that minimises block height + width = the operand bands an XCD has to stream).
+// xcd_split returns bm; the block is hb x wb tiles.
+__host__ __device__ __forceinline__ int xcd_split(int ntm, int ntn, int& hb, int& wb) {
+  int best = 1, cost = 1 << 30;
+#pragma unroll
+  for (int bm = 1; bm <= 8; bm *= 2) {
+    const int bn = 8 / bm;
+    const int c = (ntm + bm - 1) / bm + (ntn + bn - 1) / bn;
+    if (c < cost) {
+      cost = c;
+      best = bm;
+    }
+  }
+  hb = (ntm + best - 1) / best;
+  wb = (ntn + 8 / best - 1) / (8 / best);
+  return best;
+}
+__host__ __device__ __forceinline__ int xcd_grid(int ntm, int ntn) {
+  if (ntm * ntn <= 8) return ntm * ntn;  // a handful of tiles (batched attention-sized problems): plain numbering
+  int hb, wb;
+  xcd_split(ntm, ntn, hb, wb);
+  return 8 * hb * wb;
+}
+// tile of block `bid` under that split (false = padding block)
+__device__ __forceinline__ bool xcd_tile(int bid, int ntm, int ntn, int& tm, int& tn) {
+  if (ntm * ntn <= 8) {
     tm = bid / ntn;
     tn = bid % ntn;
     return true;
+  }
+  int hb, wb;
+  const int bm = xcd_split(ntm, ntn, hb, wb);
+  const int bn = 8 / bm;
+  const int x = bid & 7, idx = bid >> 3;
+  const int bi = x / bn, bj = x % bn;
+  tm = bi * hb + idx / wb;
+  tn = bj * wb + idx % wb;
+  return tm < ntm && tn < ntn;
+}
+template <int SBM, int SBN>
+__device__ __forceinline__ bool tile_of_block(int bid, int ntm, int ntn, int& tm, int& tn) {
+  if ((int)gridDim.x == xcd_grid(ntm, ntn)) {
+    // small problem (fewer than 4 super-blocks per XCD): one rectangular block of tiles per XCD, so an L2 only
+    // streams the operand bands of its block.  (Plain round-robin numbering gave each XCD one tile COLUMN: all of
+    // A streamed into every L2, 8x the bytes in the PMC counters.)
+    return xcd_tile(bid, ntm, ntn, tm, tn);
   }
   const int x = bid & 7, i = bid >> 3;
   const int per = SBM * SBN;
@@ -183,7 +224,7 @@ __device__ __forceinline__ bool tile_of_block(int bid, int ntm, int ntn, int& tm
 }
 template <int SBM, int SBN>
 static inline unsigned tile_grid(int ntm, int ntn) {
-  if (ntm * ntn < 4 * 8 * SBM * SBN) return (unsigned)(ntm * ntn);  // fewer than 4 super-blocks per XCD
+  if (ntm * ntn < 4 * 8 * SBM * SBN) return (unsigned)xcd_grid(ntm, ntn);  // fewer than 4 super-blocks per XCD
   const int nsb = ((ntm + SBM - 1) / SBM) * ((ntn + SBN - 1) / SBN);
   return (unsigned)(((nsb + 7) / 8) * 8 * SBM * SBN);
 }
@@ -458,10 +499,8 @@ __global__ __launch_bounds__(512) void ca_gemm_kernel_x(const CaGemmGroup grp) {
   const CaGemmDesc d = grp.d[which];
   int tm, tn;
   if (grp.count > 1) {
-    const int bid = (int)blockIdx.x - grp.first[which];
-    const int ntn = (d.N + XBN - 1) / XBN;
-    tm = bid / ntn;
-    tn = bid % ntn;
+    const int bid = (int)blockIdx.x - grp.first[which];  // first[] are multiples of 8: bid & 7 is the XCD
+    if (!xcd_tile(bid, (d.M + XBM - 1) / XBM, (d.N + XBN - 1) / XBN, tm, tn)) return;
   } else if (!tile_of_block<4, 8>(blockIdx.x, (d.M + XBM - 1) / XBM, (d.N + XBN - 1) / XBN, tm, tn)) {
     return;
   }
@@ -1012,7 +1051,7 @@ extern "C" int ca_gemm_bf16_group(const CaGemmDesc* descs, int32_t count, void* 
                  "ca_gemm_bf16_group: the problems differ in operand form");
     g.d[i] = *p;
     g.first[i] = total;
-    total += ((p->M + XBM - 1) / XBM) * ((p->N + XBN - 1) / XBN);
+    total += xcd_grid((p->M + XBM - 1) / XBM, (p->N + XBN - 1) / XBN);
   }
   for (int i = count; i < 4; ++i) {
     g.d[i] = descs[0];
