@@ -183,10 +183,27 @@ __host__ __device__ __forceinline__ int xcd_split(int ntm, int ntn, int& hb, int
   wb = (ntn + 8 / best - 1) / (8 / best);
   return best;
 }
+// Tile `l` of a grid in run order: the shorter grid dimension runs fastest, so a run of consecutive tiles covers a
+// compact band of the grid.
+__device__ __forceinline__ void run_tile(int l, int ntm, int ntn, int& tm, int& tn) {
+  if (ntn <= ntm) {
+    tm = l / ntn;
+    tn = l % ntn;
+  } else {
+    tn = l / ntm;
+    tm = l % ntm;
+  }
+}
+// The rectangular split leaves XCDs unevenly loaded when the grid does not divide (5 x 5 tiles: 6, 6, 3, 0, 4, 4, 2,
+// 0 per XCD): where it would pad by more than a quarter, each XCD takes a run of ceil(T / 8) consecutive tiles.
+__host__ __device__ __forceinline__ bool xcd_use_runs(int ntm, int ntn, int hb, int wb) {
+  return 8 * hb * wb * 4 > ntm * ntn * 5;
+}
 __host__ __device__ __forceinline__ int xcd_grid(int ntm, int ntn) {
   if (ntm * ntn <= 8) return ntm * ntn;  // a handful of tiles (batched attention-sized problems): plain numbering
   int hb, wb;
   xcd_split(ntm, ntn, hb, wb);
+  if (xcd_use_runs(ntm, ntn, hb, wb)) return 8 * ((ntm * ntn + 7) / 8);
   return 8 * hb * wb;
 }
 // tile of block `bid` under that split (false = padding block)
@@ -200,6 +217,11 @@ __device__ __forceinline__ bool xcd_tile(int bid, int ntm, int ntn, int& tm, int
   const int bm = xcd_split(ntm, ntn, hb, wb);
   const int bn = 8 / bm;
   const int x = bid & 7, idx = bid >> 3;
+  if (xcd_use_runs(ntm, ntn, hb, wb)) {
+    const int l = x * ((ntm * ntn + 7) / 8) + idx;
+    run_tile(l, ntm, ntn, tm, tn);
+    return l < ntm * ntn;
+  }
   const int bi = x / bn, bj = x % bn;
   tm = bi * hb + idx / wb;
   tn = bj * wb + idx % wb;
@@ -480,8 +502,9 @@ __global__ __launch_bounds__(256) void ca_gemm_kernel(const CaGemmDesc d) {
 // (ca_gemm_bf16_group): block ranges map to problems, each with plain row-major tile numbering.
 struct CaGemmGroup {
   CaGemmDesc d[4];
-  int first[4];  // first block of problem i (first[0] = 0); count = number of problems (0 = plain launch of d[0])
-  int count;
+  int first[4];  // first tile of problem i in the group's tile list (first[0] = 0)
+  int count;     // number of problems (0 = plain launch of d[0])
+  int total;     // tiles in the group
 };
 template <int AL, int BL, bool KS>
 __global__ __launch_bounds__(512) void ca_gemm_kernel_x(const CaGemmGroup grp) {
@@ -490,17 +513,21 @@ __global__ __launch_bounds__(512) void ca_gemm_kernel_x(const CaGemmGroup grp) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;  // 2 x 4 waves, 128 (M) x 64 (N) each
-  int which = 0;
+  int which = 0, gt = 0;
   if (grp.count > 1) {
-    which = (int)blockIdx.x >= grp.first[1] ? 1 : 0;
-    if (grp.count > 2 && (int)blockIdx.x >= grp.first[2]) which = 2;
-    if (grp.count > 3 && (int)blockIdx.x >= grp.first[3]) which = 3;
+    // grouped launch: the group's tiles form one list (problem after problem, each in run order) and XCD x
+    // (= blockIdx & 7) takes the x-th run of ceil(total / 8) of them: every XCD gets the same number of tiles
+    // whatever the shapes, and a run covers a compact band of one or two problems.
+    gt = ((int)blockIdx.x & 7) * ((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3);
+    if (gt >= grp.total) return;
+    which = gt >= grp.first[1] ? 1 : 0;
+    if (grp.count > 2 && gt >= grp.first[2]) which = 2;
+    if (grp.count > 3 && gt >= grp.first[3]) which = 3;
   }
   const CaGemmDesc d = grp.d[which];
   int tm, tn;
   if (grp.count > 1) {
-    const int bid = (int)blockIdx.x - grp.first[which];  // first[] are multiples of 8: bid & 7 is the XCD
-    if (!xcd_tile(bid, (d.M + XBM - 1) / XBM, (d.N + XBN - 1) / XBN, tm, tn)) return;
+    run_tile(gt - grp.first[which], (d.M + XBM - 1) / XBM, (d.N + XBN - 1) / XBN, tm, tn);
   } else if (!tile_of_block<4, 8>(blockIdx.x, (d.M + XBM - 1) / XBM, (d.N + XBN - 1) / XBN, tm, tn)) {
     return;
   }
@@ -1051,8 +1078,9 @@ extern "C" int ca_gemm_bf16_group(const CaGemmDesc* descs, int32_t count, void* 
                  "ca_gemm_bf16_group: the problems differ in operand form");
     g.d[i] = *p;
     g.first[i] = total;
-    total += xcd_grid((p->M + XBM - 1) / XBM, (p->N + XBN - 1) / XBN);
+    total += ((p->M + XBM - 1) / XBM) * ((p->N + XBN - 1) / XBN);
   }
+  g.total = total;
   for (int i = count; i < 4; ++i) {
     g.d[i] = descs[0];
     g.first[i] = total;
@@ -1066,7 +1094,7 @@ extern "C" int ca_gemm_bf16_group(const CaGemmDesc* descs, int32_t count, void* 
     attr = true;
   }
   hipStream_t s = (hipStream_t)stream;
-  dim3 grid((unsigned)(count > 1 ? total : tile_grid<4, 8>((descs->M + XBM - 1) / XBM, (descs->N + XBN - 1) / XBN))),
+  dim3 grid((unsigned)(count > 1 ? 8 * ((total + 7) / 8) : tile_grid<4, 8>((descs->M + XBM - 1) / XBM, (descs->N + XBN - 1) / XBN))),
       block(512);
   const int lay = (descs->a_layout ? 2 : 0) + (descs->b_layout ? 1 : 0);
   ProfRec r;
@@ -1166,6 +1194,7 @@ static int ca_gemm_launch(const CaGemmDesc* desc, void* stream) {
     one.d[0] = d;
     one.count = 0;
     one.first[0] = 0;
+    one.total = 0;
     switch (lay + (ks ? 4 : 0)) {
       case 0: CA_LAUNCH((XK(0, 0, false)), grid, block, X_LDS_BYTES, s, one); break;
       case 1: CA_LAUNCH((XK(0, 1, false)), grid, block, X_LDS_BYTES, s, one); break;
