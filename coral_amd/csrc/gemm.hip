@@ -12,6 +12,7 @@
 //     transpose), so NT / NN / TN / TT all run natively without transposed copies.
 //   * out-of-range rows are clamped (results discarded), out-of-range k reads a zero page.
 #include "common.h"
+#include <type_traits>
 
 #define BM 128
 #define BN 128
@@ -149,6 +150,24 @@ __device__ __forceinline__ bf16x8_t frag_mnmajor(const char* tile, int cb, int s
   s16x4_t lo, hi;
   asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a0));
   asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(a0), "n"(4 * PITCH));
+  typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+  s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+// fragment reads with the stage / k-half / fragment folded into the immediate offset (completion through lds_wait)
+template <int OFF>
+__device__ __forceinline__ bf16x8_t lds_read_b128(uint32_t a) {
+  static_assert(OFF >= 0 && OFF < 65536, "DS immediate offset");
+  bf16x8_t v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF));
+  return v;
+}
+template <int OFF, int HI>
+__device__ __forceinline__ bf16x8_t lds_read_tr(uint32_t a) {
+  static_assert(OFF >= 0 && OFF + HI < 65536, "DS immediate offset");
+  s16x4_t lo, hi;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(a), "n"(OFF));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(a), "n"(OFF + HI));
   typedef __attribute__((ext_vector_type(8))) short s16x8_t;
   s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   return __builtin_bit_cast(bf16x8_t, v);
@@ -559,135 +578,216 @@ __global__ __launch_bounds__(512) void ca_gemm_kernel_x(const CaGemmGroup grp) {
 
   const int K = d.K;
   const int nk = (K + BK - 1) / BK;
-  auto issue_stage = [&](int kt) {
-    char* st = smem + (kt & 1) * XSTAGE;
-    if (AL == CA_KMAJOR)
-      la_k.issue(st, wave, kt * BK, K);
-    else
-      la_m.issue(st, wave, lane, kt * BK, K);
-    if (BL == CA_KMAJOR)
-      lb_k.issue(st + XTILE, wave, kt * BK, K);
-    else
-      lb_m.issue(st + XTILE, wave, lane, kt * BK, K);
-  };
 
-  issue_stage(0);
-  for (int kt = 0; kt < nk; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    const bool more = kt + 1 < nk;
-    char* nst = smem + ((kt + 1) & 1) * XSTAGE;
-    auto issue_part = [&](int part) {
-      if (!more) return;
+  // Software pipeline over K-steps of 64; LDS holds two stages of each operand tile: A0 | A1 | B0 | B1 (32 KiB each).
+  // One barrier per K-step, placed in FRONT of the last of the four MFMA blocks (k-half s x m-half ih, 16 MFMAs
+  // each): by then every wave has read all of tile kt and tile kt+1 has landed, so the first fragments of tile kt+1
+  // are read behind the barrier and their LDS latency hides under block 3.  Fragments are double-buffered in
+  // registers: the reads for block b+1 are issued BETWEEN the MFMAs of block b (one read after every second MFMA,
+  // all in the first half of the block) from per-lane base addresses computed once, with the stage / k-half /
+  // fragment selected by the instruction's immediate offset - no address arithmetic and no MFMA-free phase between
+  // blocks.  A tile's 8 LDS-DMA go out as one burst per wave into the stage the barrier just freed: waves 0-3
+  // behind the barrier, waves 4-7 one block later (SIMD partners never issue their bursts together;
+  // profiles/r01_gemm_ablation.txt).
+  auto burst = [&](int kt) {  // this wave's share of tile kt
+    if (kt >= nk) return;
+    char* na = smem + (kt & 1) * XTILE;
+    char* nb = na + 2 * XTILE;
+#pragma unroll
+    for (int part = 0; part < 4; ++part) {
       if (AL == CA_KMAJOR)
-        la_k.issue_one(nst, wave, (kt + 1) * BK, K, part);
+        la_k.issue_one(na, wave, kt * BK, K, part);
       else
-        la_m.issue_one(nst, wave, lane, (kt + 1) * BK, K, part);
+        la_m.issue_one(na, wave, lane, kt * BK, K, part);
       if (BL == CA_KMAJOR)
-        lb_k.issue_one(nst + XTILE, wave, (kt + 1) * BK, K, part);
+        lb_k.issue_one(nb, wave, kt * BK, K, part);
       else
-        lb_m.issue_one(nst + XTILE, wave, lane, (kt + 1) * BK, K, part);
-    };
-    const char* ta = smem + (kt & 1) * XSTAGE;
-    const char* tb = ta + XTILE;
-    // Four MFMA blocks per K-step (k-half s x m-half ih, 16 MFMAs each).  Fragments are double-buffered
-    // in registers: the reads of block b+1 are issued before the MFMAs of block b, so only the first
-    // block of a K-step waits on LDS latency.  The next tile's 8 LDS-DMA go out as one burst per wave,
-    // the two halves of the workgroup half a K-step apart (waves 0-3 in front of block 0, waves 4-7 in
-    // front of block 2): SIMD partners alternate between issuing DMA and feeding the matrix pipe
-    // instead of doing both in lockstep (TN +20 %; profiles/r01_gemm_ablation.txt).
-    auto burst = [&]() {
-      issue_part(0);
-      issue_part(1);
-      issue_part(2);
-      issue_part(3);
-    };
-    auto read_a = [&](int s, int ih, bf16x8_t (&af)[4]) {
+        lb_m.issue_one(nb, wave, lane, kt * BK, K, part);
+    }
+  };
+  // per-lane fragment base addresses (stage 0, k-half 0, fragment 0 unless noted)
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
+  uint32_t abase[8], bbase[4];  // K-major: [0], [1] = k-half 0, 1; MN-major: one per fragment (XOR swizzle)
+  if (AL == CA_KMAJOR) {
+    const int r = wm * 128 + (lane & 15);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        af[i] = (AL == CA_KMAJOR) ? frag_kmajor_async(ta, wm * 128 + (ih * 4 + i) * 16, s, lane)
-                                  : frag_mnmajor<512>(ta, wm * 128 + (ih * 4 + i) * 16, s, lane);
-    };
-    auto read_b = [&](int s, bf16x8_t (&bf)[4]) {
+    for (int sh = 0; sh < 2; ++sh) abase[sh] = lds0 + r * 128 + (((4 * sh + (lane >> 4)) ^ ((r >> 1) & 7)) * 16);
+  } else {
+    const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+    const int swz = q | ((g & 1) << 2);
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        bf[j] = (BL == CA_KMAJOR) ? frag_kmajor_async(tb, wn * 64 + j * 16, s, lane)
-                                  : frag_mnmajor<512>(tb, wn * 64 + j * 16, s, lane);
-    };
-    auto mma = [&](int ih, bf16x8_t (&af)[4], bf16x8_t (&bf)[4]) {
-      __builtin_amdgcn_s_setprio(1);
+    for (int f = 0; f < 8; ++f) {
+      const int c = ((((wm * 128 + f * 16) >> 3) + (pp >> 1)) ^ (swz << 1));
+      abase[f] = lds0 + (8 * g + q) * 512 + c * 16 + (pp & 1) * 8;
+    }
+  }
+  if (BL == CA_KMAJOR) {
+    const int r = wn * 64 + (lane & 15);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+    for (int sh = 0; sh < 2; ++sh)
+      bbase[sh] = lds0 + 2 * XTILE + r * 128 + (((4 * sh + (lane >> 4)) ^ ((r >> 1) & 7)) * 16);
+  } else {
+    const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+    const int swz = q | ((g & 1) << 2);
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[ih * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], acc[ih * 4 + i][j], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
-    };
-    // bias gradient from the streaming A tile (a_colsum): the K-steps are dealt round-robin to the first
-    // cs_parts tile columns; inside a workgroup the four waves of an m-half share the work, wave wn taking
-    // fragment i == wn of every block
-    const bool cs_step = do_colsum && (kt % cs_parts) == tn;  // this K-step belongs to this tile column
-    auto colsum_acc = [&](int ih, bf16x8_t (&af)[4]) {
-      if (AL == CA_MNMAJOR && cs_step) {
-        // (wn is wave-uniform: a branch per case keeps the fragments in registers - indexing af[] by a run-time
-        // value would send the whole array through scratch memory)
-        f32x4_t z;
-        if (wn == 0)
-          z = __builtin_bit_cast(f32x4_t, af[0]);
-        else if (wn == 1)
-          z = __builtin_bit_cast(f32x4_t, af[1]);
-        else if (wn == 2)
-          z = __builtin_bit_cast(f32x4_t, af[2]);
-        else
-          z = __builtin_bit_cast(f32x4_t, af[3]);
-        // v_dot2c_f32_bf16 with a vector of ones: two bf16 values added to the fp32 sum per instruction
-        typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
-        const bf16x2_t ones = __builtin_bit_cast(bf16x2_t, 0x3F803F80u);
-        float s = ih == 0 ? csum0 : csum1;
+    for (int f = 0; f < 4; ++f) {
+      const int c = ((((wn * 64 + f * 16) >> 3) + (pp >> 1)) ^ (swz << 1));
+      bbase[f] = lds0 + 2 * XTILE + (8 * g + q) * 512 + c * 16 + (pp & 1) * 8;
+    }
+  }
+  bf16x8_t A0[4], A1[4], B0[4], B1[4];
+  // fragment f (0..7 for A, 0..3 for B) of k-half SH from stage ST, all compile-time
+#define X_RD_A(ST, SH, F, dst)                                                            \
+  do {                                                                                    \
+    if (AL == CA_KMAJOR)                                                                  \
+      dst = lds_read_b128<(ST) * XTILE + (F) * 2048>(abase[SH]);                          \
+    else                                                                                  \
+      dst = lds_read_tr<(ST) * XTILE + (SH) * 16384, 2048>(abase[F]);                     \
+  } while (0)
+#define X_RD_B(ST, SH, F, dst)                                                            \
+  do {                                                                                    \
+    if (BL == CA_KMAJOR)                                                                  \
+      dst = lds_read_b128<(ST) * XTILE + (F) * 2048>(bbase[SH]);                          \
+    else                                                                                  \
+      dst = lds_read_tr<(ST) * XTILE + (SH) * 16384, 2048>(bbase[F]);                     \
+  } while (0)
+#define X_SB __builtin_amdgcn_sched_barrier(0)
+  // two MFMAs of block (m-half IH, fragments AF x BF): A fragment I against B fragments J and J+1
+#define X_MM2(IH, AF, BF, I, J)                                                                                   \
+  do {                                                                                                            \
+    acc[(IH) * 4 + (I)][J] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[J], AF[I], acc[(IH) * 4 + (I)][J], 0, 0, 0); \
+    acc[(IH) * 4 + (I)][(J) + 1] =                                                                                \
+        __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[(J) + 1], AF[I], acc[(IH) * 4 + (I)][(J) + 1], 0, 0, 0);       \
+    X_SB;                                                                                                         \
+  } while (0)
+  // bias gradient from the streaming A tile (a_colsum): the K-steps are dealt round-robin to the first
+  // cs_parts tile columns; inside a workgroup the four waves of an m-half share the work, wave wn taking
+  // fragment i == wn of every block
+  auto colsum_acc = [&](bool cs_step, int ih, bf16x8_t (&af)[4]) {
+    if (AL == CA_MNMAJOR && cs_step) {
+      // (wn is wave-uniform: a branch per case keeps the fragments in registers - indexing af[] by a run-time
+      // value would send the whole array through scratch memory)
+      f32x4_t z;
+      if (wn == 0)
+        z = __builtin_bit_cast(f32x4_t, af[0]);
+      else if (wn == 1)
+        z = __builtin_bit_cast(f32x4_t, af[1]);
+      else if (wn == 2)
+        z = __builtin_bit_cast(f32x4_t, af[2]);
+      else
+        z = __builtin_bit_cast(f32x4_t, af[3]);
+      // v_dot2c_f32_bf16 with a vector of ones: two bf16 values added to the fp32 sum per instruction
+      typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+      const bf16x2_t ones = __builtin_bit_cast(bf16x2_t, 0x3F803F80u);
+      float s = ih == 0 ? csum0 : csum1;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          // through an integer word on purpose: bit-casting element q of the float vector straight to a bf16 pair
-          // makes hipcc 7.2 read element 0 four times (seen in the ISA)
-          const unsigned int wq = __float_as_uint(z[q]);
-          s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, wq), ones, s, false);
-        }
-        if (ih == 0)
-          csum0 = s;
-        else
-          csum1 = s;
+      for (int q = 0; q < 4; ++q) {
+        // through an integer word on purpose: bit-casting element q of the float vector straight to a bf16 pair
+        // makes hipcc 7.2 read element 0 four times (seen in the ISA)
+        const unsigned int wq = __float_as_uint(z[q]);
+        s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, wq), ones, s, false);
       }
-    };
-    bf16x8_t A0[4], A1[4], B0[4], B1[4];
-    read_b(0, B0);
-    read_a(0, 0, A0);
-    if (wave < 4) burst();
+      if (ih == 0)
+        csum0 = s;
+      else
+        csum1 = s;
+    }
+  };
+  // one K-step on stage ST (compile-time); reads of the next tile come from stage 1 - ST
+  auto kstep = [&](auto st_c, int kt) {
+    constexpr int ST = decltype(st_c)::value;
+    const bool cs_step = do_colsum && (kt % cs_parts) == tn;  // this K-step belongs to this tile column
+    if (wave >= 4) burst(kt + 1);
+    // block 0: A(s0, m-half 0) x B(s0); reads A(s0, m-half 1)
     lds_wait(B0);
     lds_wait(A0);
-    colsum_acc(0, A0);
-    read_a(0, 1, A1);
-    __builtin_amdgcn_sched_barrier(0);
-    mma(0, A0, B0);
-    __builtin_amdgcn_sched_barrier(0);
+    colsum_acc(cs_step, 0, A0);
+    X_SB;
+    __builtin_amdgcn_s_setprio(1);
+    X_MM2(0, A0, B0, 0, 0); X_RD_A(ST, 0, 4, A1[0]); X_SB;
+    X_MM2(0, A0, B0, 0, 2); X_RD_A(ST, 0, 5, A1[1]); X_SB;
+    X_MM2(0, A0, B0, 1, 0); X_RD_A(ST, 0, 6, A1[2]); X_SB;
+    X_MM2(0, A0, B0, 1, 2); X_RD_A(ST, 0, 7, A1[3]); X_SB;
+    X_MM2(0, A0, B0, 2, 0);
+    X_MM2(0, A0, B0, 2, 2);
+    X_MM2(0, A0, B0, 3, 0);
+    X_MM2(0, A0, B0, 3, 2);
+    __builtin_amdgcn_s_setprio(0);
+    // block 1: A(s0, m-half 1) x B(s0); reads B(s1) and A(s1, m-half 0)
     lds_wait(A1);
-    colsum_acc(1, A1);
-    read_b(1, B1);
-    read_a(1, 0, A0);
-    __builtin_amdgcn_sched_barrier(0);
-    mma(1, A1, B0);
-    __builtin_amdgcn_sched_barrier(0);
-    if (wave >= 4) burst();
+    colsum_acc(cs_step, 1, A1);
+    X_SB;
+    __builtin_amdgcn_s_setprio(1);
+    X_MM2(1, A1, B0, 0, 0); X_RD_B(ST, 1, 0, B1[0]); X_SB;
+    X_MM2(1, A1, B0, 0, 2); X_RD_B(ST, 1, 1, B1[1]); X_SB;
+    X_MM2(1, A1, B0, 1, 0); X_RD_B(ST, 1, 2, B1[2]); X_SB;
+    X_MM2(1, A1, B0, 1, 2); X_RD_B(ST, 1, 3, B1[3]); X_SB;
+    X_MM2(1, A1, B0, 2, 0); X_RD_A(ST, 1, 0, A0[0]); X_SB;
+    X_MM2(1, A1, B0, 2, 2); X_RD_A(ST, 1, 1, A0[1]); X_SB;
+    X_MM2(1, A1, B0, 3, 0); X_RD_A(ST, 1, 2, A0[2]); X_SB;
+    X_MM2(1, A1, B0, 3, 2); X_RD_A(ST, 1, 3, A0[3]); X_SB;
+    __builtin_amdgcn_s_setprio(0);
+    // block 2: A(s1, m-half 0) x B(s1); reads A(s1, m-half 1)
     lds_wait(B1);
     lds_wait(A0);
-    colsum_acc(0, A0);
-    read_a(1, 1, A1);
-    __builtin_amdgcn_sched_barrier(0);
-    mma(0, A0, B1);
-    __builtin_amdgcn_sched_barrier(0);
-    lds_wait(A1);
-    colsum_acc(1, A1);
-    mma(1, A1, B1);
+    colsum_acc(cs_step, 0, A0);
+    X_SB;
+    __builtin_amdgcn_s_setprio(1);
+    X_MM2(0, A0, B1, 0, 0); X_RD_A(ST, 1, 4, A1[0]); X_SB;
+    X_MM2(0, A0, B1, 0, 2); X_RD_A(ST, 1, 5, A1[1]); X_SB;
+    X_MM2(0, A0, B1, 1, 0); X_RD_A(ST, 1, 6, A1[2]); X_SB;
+    X_MM2(0, A0, B1, 1, 2); X_RD_A(ST, 1, 7, A1[3]); X_SB;
+    X_MM2(0, A0, B1, 2, 0);
+    X_MM2(0, A0, B1, 2, 2);
+    X_MM2(0, A0, B1, 3, 0);
+    X_MM2(0, A0, B1, 3, 2);
+    __builtin_amdgcn_s_setprio(0);
+    lds_wait(A1);  // the last fragment reads of tile kt have returned
+    colsum_acc(cs_step, 1, A1);
+    // tile kt+1 has landed (this wave's share; the barrier covers the others) and stage ST is free
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (wave < 4) burst(kt + 2);
+    X_SB;
+    // block 3: A(s1, m-half 1) x B(s1); reads B(s0), A(s0, m-half 0) of tile kt+1 (harmless stale data after the
+    // last tile)
+    __builtin_amdgcn_s_setprio(1);
+    X_MM2(1, A1, B1, 0, 0); X_RD_B(1 - ST, 0, 0, B0[0]); X_SB;
+    X_MM2(1, A1, B1, 0, 2); X_RD_B(1 - ST, 0, 1, B0[1]); X_SB;
+    X_MM2(1, A1, B1, 1, 0); X_RD_B(1 - ST, 0, 2, B0[2]); X_SB;
+    X_MM2(1, A1, B1, 1, 2); X_RD_B(1 - ST, 0, 3, B0[3]); X_SB;
+    X_MM2(1, A1, B1, 2, 0); X_RD_A(1 - ST, 0, 0, A0[0]); X_SB;
+    X_MM2(1, A1, B1, 2, 2); X_RD_A(1 - ST, 0, 1, A0[1]); X_SB;
+    X_MM2(1, A1, B1, 3, 0); X_RD_A(1 - ST, 0, 2, A0[2]); X_SB;
+    X_MM2(1, A1, B1, 3, 2); X_RD_A(1 - ST, 0, 3, A0[3]); X_SB;
+    __builtin_amdgcn_s_setprio(0);
+  };
+  {
+    char* st = smem;
+    if (AL == CA_KMAJOR)
+      la_k.issue(st, wave, 0, K);
+    else
+      la_m.issue(st, wave, lane, 0, K);
+    if (BL == CA_KMAJOR)
+      lb_k.issue(st + 2 * XTILE, wave, 0, K);
+    else
+      lb_m.issue(st + 2 * XTILE, wave, lane, 0, K);
   }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  X_RD_B(0, 0, 0, B0[0]); X_RD_B(0, 0, 1, B0[1]); X_RD_B(0, 0, 2, B0[2]); X_RD_B(0, 0, 3, B0[3]);
+  X_RD_A(0, 0, 0, A0[0]); X_RD_A(0, 0, 1, A0[1]); X_RD_A(0, 0, 2, A0[2]); X_RD_A(0, 0, 3, A0[3]);
+  if (wave < 4) burst(1);
+  for (int kt = 0; kt < nk; kt += 2) {
+    kstep(std::integral_constant<int, 0>{}, kt);
+    if (kt + 1 < nk) kstep(std::integral_constant<int, 1>{}, kt + 1);
+  }
+#undef X_RD_A
+#undef X_RD_B
+#undef X_MM2
+#undef X_SB
   if (AL == CA_MNMAJOR && do_colsum) {
     // a lane's fragment holds k = 8g..8g+7 of a 32-k step: add the four lane groups, then lanes 0-15 own 16 rows
 #pragma unroll
