@@ -113,6 +113,87 @@ struct MNMajorLoader {
   }
 };
 
+// LDS-DMA with the scalar-base addressing form: 16 B per lane from base + off (off: 32-bit, zero-extended) to the
+// wave's 1-KiB LDS piece at byte address lds_piece (wave-uniform, goes through M0)
+__device__ __forceinline__ void glds16_sbase(const char* base, uint32_t off, uint32_t lds_piece) {
+  asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1"
+               :
+               : "v"(off), "s"(base), "s"(lds_piece)
+               : "memory", "m0");
+}
+// ---- loaders of kernel X: one wave-uniform base per operand tile + a 32-bit offset per lane and piece ----------
+// The base walks down K by scalar adds; a full K-step issues its LDS-DMA without any per-lane address arithmetic or
+// predicate.  Only the last, partial K-step (K % 64 != 0) selects the zero page per lane.  Rows / columns beyond
+// the operand are clamped to its last one (their products are never stored).
+template <int NI>
+struct KMajorStream {  // operand stored [row][k], k contiguous; LDS image [rows][64 k], 128-B rows
+  const char* base;    // wave-uniform: first row of the tile, current k
+  uint32_t off[NI];    // byte offset of this lane's 16-B chunk
+  int kc[NI];          // element offset of the chunk inside the K-step (tail predicate)
+  __device__ __forceinline__ void init(const __bf16* b, int64_t ld, int row0, int nrows, int wave, int lane) {
+    base = (const char*)(b + (int64_t)row0 * ld);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int r = (wave * NI + i) * 8 + (lane >> 3);
+      const int c = (lane & 7) ^ ((r >> 1) & 7);
+      int rr = row0 + r;
+      rr = (rr < nrows ? rr : nrows - 1) - row0;
+      kc[i] = c * 8;
+      off[i] = (uint32_t)(((int64_t)rr * ld + c * 8) * 2);
+    }
+  }
+  __device__ __forceinline__ void issue_one(char* tile, int wave, int i) {
+    glds16_sbase(base, off[i], (uint32_t)(uintptr_t)(lptr_t)(tile + (wave * NI + i) * 1024));
+  }
+  // partial K-step: chunks beyond K load some valid bytes instead (offset 0) and are zeroed in LDS by zero_fix()
+  __device__ __forceinline__ void issue_one_tail(char* tile, int wave, int krem, int i) {
+    glds16_sbase(base, kc[i] < krem ? off[i] : 0u, (uint32_t)(uintptr_t)(lptr_t)(tile + (wave * NI + i) * 1024));
+  }
+  // after this wave's LDS-DMA of the partial K-step has landed, before the barrier that publishes the tile
+  __device__ __forceinline__ void zero_fix(char* tile, int wave, int lane, int krem) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+      if (kc[i] >= krem) *(uint4*)(tile + (wave * NI + i) * 1024 + lane * 16) = make_uint4(0, 0, 0, 0);
+  }
+  __device__ __forceinline__ void advance() { base += BK * 2; }
+};
+template <int NI, int PC>
+struct MNMajorStream {  // operand stored [k][mn], mn contiguous (plain rows, no segments); LDS image [64 k][PC*8 mn]
+  const char* base;     // wave-uniform: column col0 of row k0
+  uint32_t off[NI];
+  int64_t step;
+  static constexpr int RPI = 64 / PC;  // k-rows per LDS-DMA instruction
+  __device__ __forceinline__ void init(const __bf16* b, int64_t ld, int col0, int ncols, int wave, int lane) {
+    base = (const char*)(b + col0);
+    step = (int64_t)BK * ld * 2;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int kr = (wave * NI + i) * RPI + lane / PC;
+      const int swz = (kr & 3) | (((kr >> 3) & 1) << 2);
+      const int c = (lane % PC) ^ (swz << 1);
+      int cc = col0 + c * 8;
+      const int nc8 = (ncols + 7) & ~7;  // rows are readable up to ncols rounded up to 8
+      cc = (cc <= nc8 - 8 ? cc : nc8 - 8) - col0;
+      off[i] = (uint32_t)(((int64_t)kr * ld + cc) * 2);
+    }
+  }
+  __device__ __forceinline__ void issue_one(char* tile, int wave, int i) {
+    glds16_sbase(base, off[i], (uint32_t)(uintptr_t)(lptr_t)(tile + (wave * NI + i) * 1024));
+  }
+  __device__ __forceinline__ void issue_one_tail(char* tile, int wave, int lane, int krem, int i) {
+    const int kr = (wave * NI + i) * RPI + lane / PC;
+    glds16_sbase(base, kr < krem ? off[i] : 0u, (uint32_t)(uintptr_t)(lptr_t)(tile + (wave * NI + i) * 1024));
+  }
+  __device__ __forceinline__ void zero_fix(char* tile, int wave, int lane, int krem) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int kr = (wave * NI + i) * RPI + lane / PC;
+      if (kr >= krem) *(uint4*)(tile + (wave * NI + i) * 1024 + lane * 16) = make_uint4(0, 0, 0, 0);
+    }
+  }
+  __device__ __forceinline__ void advance() { base += step; }
+};
+
 // ---- fragment reads ----------------------------------------------------------------------
 // KMAJOR tile: 16 rows starting at rb, k-step s (32 k): lane gets row rb+(lane&15),
 // k = 32 s + 8 (lane>>4) .. +7.
@@ -556,16 +637,23 @@ __global__ __launch_bounds__(512) void ca_gemm_kernel_x(const CaGemmGroup grp) {
   const __bf16* A = (const __bf16*)d.A + z1 * d.sA1 + z2 * d.sA2;
   const __bf16* B = (const __bf16*)d.B + z1 * d.sB1 + z2 * d.sB2;
 
-  KMajorLoader<4> la_k, lb_k;
+  // K-major operands and plain MN-major ones stream through a scalar base (KMajorStream / MNMajorStream); MN-major
+  // operands with segmented rows (KS) keep the per-lane pointer walk
+  KMajorStream<4> la_k, lb_k;
+  MNMajorStream<4, 32> la_f, lb_f;
   MNMajorLoader<4, 32, KS> la_m, lb_m;
   if (AL == CA_KMAJOR)
     la_k.init(A, d.lda, m0, d.M, wave, lane);
-  else
+  else if (KS)
     la_m.init(A, d.lda, d.a_kseg, d.a_kseg_stride, m0, d.M, wave, lane);
+  else
+    la_f.init(A, d.lda, m0, d.M, wave, lane);
   if (BL == CA_KMAJOR)
     lb_k.init(B, d.ldb, n0, d.N, wave, lane);
-  else
+  else if (KS)
     lb_m.init(B, d.ldb, d.b_kseg, d.b_kseg_stride, n0, d.N, wave, lane);
+  else
+    lb_f.init(B, d.ldb, n0, d.N, wave, lane);
 
   f32x4_t acc[8][4];
 #pragma unroll
@@ -589,21 +677,60 @@ __global__ __launch_bounds__(512) void ca_gemm_kernel_x(const CaGemmGroup grp) {
   // blocks.  A tile's 8 LDS-DMA go out as one burst per wave into the stage the barrier just freed: waves 0-3
   // behind the barrier, waves 4-7 one block later (SIMD partners never issue their bursts together;
   // profiles/r01_gemm_ablation.txt).
-  auto burst = [&](int kt) {  // this wave's share of tile kt
+  auto burst = [&](int kt) {  // this wave's share of tile kt (called once per tile, in K order)
     if (kt >= nk) return;
     char* na = smem + (kt & 1) * XTILE;
     char* nb = na + 2 * XTILE;
+    const bool full = (kt + 1) * BK <= K;  // wave-uniform
+    if (full) {
 #pragma unroll
-    for (int part = 0; part < 4; ++part) {
-      if (AL == CA_KMAJOR)
-        la_k.issue_one(na, wave, kt * BK, K, part);
-      else
-        la_m.issue_one(na, wave, lane, kt * BK, K, part);
-      if (BL == CA_KMAJOR)
-        lb_k.issue_one(nb, wave, kt * BK, K, part);
-      else
-        lb_m.issue_one(nb, wave, lane, kt * BK, K, part);
+      for (int part = 0; part < 4; ++part) {
+        if (AL == CA_MNMAJOR && KS)
+          la_m.issue_one(na, wave, lane, kt * BK, K, part);
+        else if (AL == CA_KMAJOR)
+          la_k.issue_one(na, wave, part);
+        else
+          la_f.issue_one(na, wave, part);
+        if (BL == CA_MNMAJOR && KS)
+          lb_m.issue_one(nb, wave, lane, kt * BK, K, part);
+        else if (BL == CA_KMAJOR)
+          lb_k.issue_one(nb, wave, part);
+        else
+          lb_f.issue_one(nb, wave, part);
+      }
+    } else {
+#pragma unroll
+      for (int part = 0; part < 4; ++part) {
+        if (AL == CA_MNMAJOR && KS)
+          la_m.issue_one(na, wave, lane, kt * BK, K, part);
+        else if (AL == CA_KMAJOR)
+          la_k.issue_one_tail(na, wave, K - kt * BK, part);
+        else
+          la_f.issue_one_tail(na, wave, lane, K - kt * BK, part);
+        if (BL == CA_MNMAJOR && KS)
+          lb_m.issue_one(nb, wave, lane, kt * BK, K, part);
+        else if (BL == CA_KMAJOR)
+          lb_k.issue_one_tail(nb, wave, K - kt * BK, part);
+        else
+          lb_f.issue_one_tail(nb, wave, lane, K - kt * BK, part);
+      }
     }
+    if (AL == CA_KMAJOR) la_k.advance();
+    if (AL == CA_MNMAJOR && !KS) la_f.advance();
+    if (BL == CA_KMAJOR) lb_k.advance();
+    if (BL == CA_MNMAJOR && !KS) lb_f.advance();
+  };
+  // the partial last K-step (K % 64 != 0): zero what this wave loaded beyond K, once its LDS-DMA has landed
+  auto zero_tail = [&](int kt) {
+    if (kt != nk - 1 || nk * BK == K) return;
+    char* na = smem + (kt & 1) * XTILE;
+    char* nb = na + 2 * XTILE;
+    const int krem = K - kt * BK;
+    if (AL == CA_KMAJOR) la_k.zero_fix(na, wave, lane, krem);
+    if (AL == CA_MNMAJOR && !KS) la_f.zero_fix(na, wave, lane, krem);
+    if (BL == CA_KMAJOR) lb_k.zero_fix(nb, wave, lane, krem);
+    if (BL == CA_MNMAJOR && !KS) lb_f.zero_fix(nb, wave, lane, krem);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   };
   // per-lane fragment base addresses (stage 0, k-half 0, fragment 0 unless noted)
   const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
@@ -746,6 +873,7 @@ __global__ __launch_bounds__(512) void ca_gemm_kernel_x(const CaGemmGroup grp) {
     colsum_acc(cs_step, 1, A1);
     // tile kt+1 has landed (this wave's share; the barrier covers the others) and stage ST is free
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    zero_tail(kt + 1);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (wave < 4) burst(kt + 2);
@@ -763,18 +891,9 @@ __global__ __launch_bounds__(512) void ca_gemm_kernel_x(const CaGemmGroup grp) {
     X_MM2(1, A1, B1, 3, 2); X_RD_A(1 - ST, 0, 3, A0[3]); X_SB;
     __builtin_amdgcn_s_setprio(0);
   };
-  {
-    char* st = smem;
-    if (AL == CA_KMAJOR)
-      la_k.issue(st, wave, 0, K);
-    else
-      la_m.issue(st, wave, lane, 0, K);
-    if (BL == CA_KMAJOR)
-      lb_k.issue(st + 2 * XTILE, wave, 0, K);
-    else
-      lb_m.issue(st + 2 * XTILE, wave, lane, 0, K);
-  }
+  burst(0);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  zero_tail(0);
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   X_RD_B(0, 0, 0, B0[0]); X_RD_B(0, 0, 1, B0[1]); X_RD_B(0, 0, 2, B0[2]); X_RD_B(0, 0, 3, B0[3]);
