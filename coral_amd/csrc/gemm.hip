@@ -510,16 +510,22 @@ __global__ __launch_bounds__(256) void ca_gemm_kernel(const CaGemmDesc d) {
   const __bf16* A = (const __bf16*)d.A + z1 * d.sA1 + z2 * d.sA2;
   const __bf16* B = (const __bf16*)d.B + z1 * d.sB1 + z2 * d.sB2;
 
-  KMajorLoader<4> la_k, lb_k;
+  // (loaders and pipeline as in kernel X below, at half the tile: see the comments there)
+  KMajorStream<4> la_k, lb_k;
+  MNMajorStream<4, 16> la_f, lb_f;
   MNMajorLoader<4, 16, KS> la_m, lb_m;
   if (AL == CA_KMAJOR)
     la_k.init(A, d.lda, m0, d.M, wave, lane);
-  else
+  else if (KS)
     la_m.init(A, d.lda, d.a_kseg, d.a_kseg_stride, m0, d.M, wave, lane);
+  else
+    la_f.init(A, d.lda, m0, d.M, wave, lane);
   if (BL == CA_KMAJOR)
     lb_k.init(B, d.ldb, n0, d.N, wave, lane);
-  else
+  else if (KS)
     lb_m.init(B, d.ldb, d.b_kseg, d.b_kseg_stride, n0, d.N, wave, lane);
+  else
+    lb_f.init(B, d.ldb, n0, d.N, wave, lane);
 
   f32x4_t acc[4][4];
 #pragma unroll
@@ -530,29 +536,76 @@ __global__ __launch_bounds__(256) void ca_gemm_kernel(const CaGemmDesc d) {
   const int K = d.K;
   const int nk = (K + BK - 1) / BK;
 
-  auto issue_stage = [&](int kt) {
-    char* st = smem + (kt & 1) * STAGE_BYTES;
-    if (AL == CA_KMAJOR)
-      la_k.issue(st, wave, kt * BK, K);
-    else
-      la_m.issue(st, wave, lane, kt * BK, K);
-    if (BL == CA_KMAJOR)
-      lb_k.issue(st + TILE_BYTES, wave, kt * BK, K);
-    else
-      lb_m.issue(st + TILE_BYTES, wave, lane, kt * BK, K);
+  // LDS: A0 | A1 | B0 | B1 (two stages of each 16-KiB operand tile).  A tile's 8 LDS-DMA per wave go out as one burst
+  // behind the barrier, a full K-step before the tile is needed.
+  auto burst = [&](int kt) {
+    if (kt >= nk) return;
+    char* na = smem + (kt & 1) * TILE_BYTES;
+    char* nb = na + 2 * TILE_BYTES;
+    const bool full = (kt + 1) * BK <= K;  // wave-uniform
+    if (full) {
+#pragma unroll
+      for (int part = 0; part < 4; ++part) {
+        if (AL == CA_MNMAJOR && KS)
+          la_m.issue_one(na, wave, lane, kt * BK, K, part);
+        else if (AL == CA_KMAJOR)
+          la_k.issue_one(na, wave, part);
+        else
+          la_f.issue_one(na, wave, part);
+        if (BL == CA_MNMAJOR && KS)
+          lb_m.issue_one(nb, wave, lane, kt * BK, K, part);
+        else if (BL == CA_KMAJOR)
+          lb_k.issue_one(nb, wave, part);
+        else
+          lb_f.issue_one(nb, wave, part);
+      }
+    } else {
+#pragma unroll
+      for (int part = 0; part < 4; ++part) {
+        if (AL == CA_MNMAJOR && KS)
+          la_m.issue_one(na, wave, lane, kt * BK, K, part);
+        else if (AL == CA_KMAJOR)
+          la_k.issue_one_tail(na, wave, K - kt * BK, part);
+        else
+          la_f.issue_one_tail(na, wave, lane, K - kt * BK, part);
+        if (BL == CA_MNMAJOR && KS)
+          lb_m.issue_one(nb, wave, lane, kt * BK, K, part);
+        else if (BL == CA_KMAJOR)
+          lb_k.issue_one_tail(nb, wave, K - kt * BK, part);
+        else
+          lb_f.issue_one_tail(nb, wave, lane, K - kt * BK, part);
+      }
+    }
+    if (AL == CA_KMAJOR) la_k.advance();
+    if (AL == CA_MNMAJOR && !KS) la_f.advance();
+    if (BL == CA_KMAJOR) lb_k.advance();
+    if (BL == CA_MNMAJOR && !KS) lb_f.advance();
   };
-
+  auto zero_tail = [&](int kt) {
+    if (kt != nk - 1 || nk * BK == K) return;
+    char* na = smem + (kt & 1) * TILE_BYTES;
+    char* nb = na + 2 * TILE_BYTES;
+    const int krem = K - kt * BK;
+    if (AL == CA_KMAJOR) la_k.zero_fix(na, wave, lane, krem);
+    if (AL == CA_MNMAJOR && !KS) la_f.zero_fix(na, wave, lane, krem);
+    if (BL == CA_KMAJOR) lb_k.zero_fix(nb, wave, lane, krem);
+    if (BL == CA_MNMAJOR && !KS) lb_f.zero_fix(nb, wave, lane, krem);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
   // One barrier per K-step: a wave arrives at barrier(kt) only after it consumed every fragment of
   // tile kt-1 (lgkmcnt(0) below), so the stage of tile kt-1 may be re-staged right after the barrier.
-  issue_stage(0);
+  // (Two workgroups share a CU and fall into complementary phases by themselves - one reads while the other
+  // multiplies; kernel X's finer interleaving of reads and MFMAs was measured 5-10 % slower here.)
+  burst(0);
   for (int kt = 0; kt < nk; ++kt) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // tile kt landed; my reads of kt-1 done
+    zero_tail(kt);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (kt + 1 < nk) issue_stage(kt + 1);  // (splitting this burst across the MFMA blocks was measured slower here)
+    burst(kt + 1);  // (splitting this burst across the MFMA blocks was measured slower here)
 
-    const char* ta = smem + (kt & 1) * STAGE_BYTES;
-    const char* tb = ta + TILE_BYTES;
+    const char* ta = smem + (kt & 1) * TILE_BYTES;
+    const char* tb = ta + 2 * TILE_BYTES;
     // two k-halves per K-step; the fragments of the second half are read before the MFMAs of the first
     auto read_frags = [&](int s, bf16x8_t (&af)[4], bf16x8_t (&bf)[4]) {
 #pragma unroll
