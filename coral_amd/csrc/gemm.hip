@@ -28,8 +28,13 @@ __device__ __attribute__((aligned(16))) uint32_t g_ca_zero_page[4];
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+// LDS-DMA, 16 B per lane from a per-lane address to the wave's 1-KiB LDS piece.  Inline asm like the scalar-base
+// form below, so that M0 is only ever written inside these statements (the compiler does not track M0 across them).
 __device__ __forceinline__ void glds16(const void* g, char* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)lds_wave_base, 16, 0, 0);
+  asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off"
+               :
+               : "v"(g), "s"((uint32_t)(uintptr_t)(lptr_t)lds_wave_base)
+               : "memory", "m0");
 }
 
 // ---- per-lane loader state -------------------------------------------------------------
