@@ -1442,7 +1442,7 @@ static int ca_gemm_launch(const CaGemmDesc* desc, void* stream) {
   // because its second workgroup hides the epilogue; the L kernel is kept selectable for tuning.
   (void)tiles_l;
   int use_l = g_force_kernel == 2 ? 1 : 0;
-  // Kernel X (256x256): only where it fills the chip -- at least ~0.9 tiles per CU and little tail waste.
+  // Kernel X (256x256): only where it fills the chip -- at least ~0.7 tiles per CU in its last round.
   const int xtm = (d.M + XBM - 1) / XBM, xtn = (d.N + XBN - 1) / XBN;
   const int64_t xt = (int64_t)xtm * xtn * nb;
   const double xwaves = (double)xt / 256.0;
@@ -1451,7 +1451,9 @@ static int ca_gemm_launch(const CaGemmDesc* desc, void* stream) {
   // The MN-major x MN-major (weight-gradient) form gains most from the 256x256 tile (1.0 PFLOP/s against 0.63
   // for S inside the training step), so it switches at a lower fill than the other forms.
   const bool tn = d.a_layout == CA_MNMAJOR && d.b_layout == CA_MNMAJOR;
-  int use_x = (g_force_kernel == 0 && d.K >= 512 && xt >= (tn ? 160 : 224) && xeff * xfill >= (tn ? 0.60 : 0.80)) ? 1 : 0;
+  // (thresholds from tools/dev_gemm_rule.py on the models' shapes: X wins from ~73 % occupancy of its last round
+  // - 188 / 192 / 564 tiles - and loses at 68 % - 368 tiles)
+  int use_x = (g_force_kernel == 0 && d.K >= 512 && xt >= 160 && xeff * xfill >= (tn ? 0.60 : 0.70)) ? 1 : 0;
   if (g_force_kernel == 3 || d.a_colsum) use_x = 1;  // the column sums live in kernel X only
   g_last_kind = use_x ? 2 : (use_l ? 1 : 0);
   if (use_x) {
