@@ -61,6 +61,8 @@ class CaGemmDesc(C.Structure):
         ("dropout_seed", C.c_uint64),
         ("a_colsum", C.c_void_p),
         ("a_colsum_ld", C.c_int64),
+        ("c_row_index", C.c_void_p),
+        ("c_row_mul", C.c_int64),
     ]
 
 

@@ -15,6 +15,7 @@
 // probabilities never leave registers.  The forward is one pass with a running maximum (online softmax);
 // the backward kernels recompute probabilities from the saved log-sum-exp.
 #include "common.h"
+#include <type_traits>
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -328,16 +329,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   }
 }
 
-// ---- forward for a handful of queries (greedy decoding: Tq = 1 per clip and head) --------------------------
-// With <= 16 queries only one wave of the general kernel does useful work and walks all key tiles alone (24 tiles
-// of the 1500 encoder positions: 27 us per call, 48 calls per token).  Here the four waves split the KEY tiles
-// (tile kt belongs to wave kt % 4), each with a private K/V image in LDS (no barrier inside the loop) and its own
-// running (max, sum, output); the four partial results are merged through LDS at the end.  hd <= 64, not causal.
+// Greedy decoding (Tq <= 16 queries per head, hd <= 64): one workgroup per (clip, head), the four waves split the
+// keys in tiles of 64 and merge their (m, l, O) at the end.  The kernel is bound by how many bytes a CU keeps in
+// flight (one tile at a time per wave streamed 24 GB/s per CU: 16 us for the 1500 cross-attention keys), so each
+// wave keeps THREE tiles in flight: the K fragments go straight from global memory into MFMA operand registers
+// (a K row is an A-operand row: no LDS image), the V tile through a wave-private ring of three LDS images
+// (LDS-DMA + transposed reads).  All vector-memory operations of the loop are inline asm in a fixed order (16 per
+// tile), so the waits are counted by hand: vmcnt(32) leaves the two younger tiles in flight.
+__device__ __forceinline__ bf16x8_t gload16_async(const void* p) {
+  bf16x8_t v;
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+__device__ __forceinline__ void glds16_async(const void* g, char* lds_wave_base) {
+  asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off"
+               :
+               : "v"(g), "s"((uint32_t)(uintptr_t)(lptr_t)lds_wave_base)
+               : "memory", "m0");
+}
 template <int HDPV>
 __global__ __launch_bounds__(256) void attn_fwd_smallq_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NKS = HDPV / 32, NNB = HDPV / 16;
   constexpr int IMG = 64 * HDPV * 2;
+  constexpr int D = 3;  // tiles in flight per wave
+  static_assert(HDPV == 64, "16 vector-memory operations per tile are assumed by the counted waits");
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, r = lane & 15;
@@ -346,8 +362,7 @@ __global__ __launch_bounds__(256) void attn_fwd_smallq_kernel(const AttnArgs a) 
   const unsigned short* Q = a.Q + b * a.sqb + h * hd;
   const unsigned short* K = a.K + b * a.skb + h * hd;
   const unsigned short* V = a.V + b * a.svb + h * hd;
-  char* Kimg = smem + wave * 2 * IMG;
-  char* Vimg = Kimg + IMG;
+  char* Vring = smem + wave * D * IMG;
   const int qrow = r < a.Tq ? r : a.Tq - 1;
   int kl = a.Tk;
   if (a.klen) kl = a.klen[b] < kl ? a.klen[b] : kl;
@@ -355,23 +370,69 @@ __global__ __launch_bounds__(256) void attn_fwd_smallq_kernel(const AttnArgs a) 
 #pragma unroll
   for (int ks = 0; ks < NKS; ++ks) qf[ks] = load_rowfrag(Q, a.ldq, qrow, ks, lane, hd);
   const int ntile = (kl + 63) / 64;
+  const int nw = ntile > wave ? (ntile - wave + 3) / 4 : 0;  // this wave's tiles: kt = wave + 4 j
   const float c2 = a.scale * LOG2E;
   float m = NEG_BIG, l = 0.f;
   f32x4_t o[NNB];
 #pragma unroll
   for (int nb = 0; nb < NNB; ++nb) o[nb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  for (int kt = wave; kt < ntile; kt += 4) {
-    load_kmajor_image<64, HDPV, 1>(Kimg, K, a.ldk, kt * 64, a.Tk, hd, 0, lane);
-    load_mnmajor_image<64, HDPV, 1>(Vimg, V, a.ldv, kt * 64, a.Tk, hd, 0, lane);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // wave-private image: no barrier needed
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // Q / klen have arrived: from here on the counts are the loop's
+  bf16x8_t kf[D][4][NKS];
+  // 8 K-fragment loads + 8 LDS-DMA pieces of V for tile j of this wave, into slot S
+  auto issue = [&](auto slot_c, int j) {
+    constexpr int S = decltype(slot_c)::value;
+    const int kt = wave + 4 * j;
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk) {
+      int key = kt * 64 + 32 * (blk >> 1) + rowperm(blk & 1, r);
+      key = key < a.Tk ? key : a.Tk - 1;  // clamped rows are masked below (key >= kl)
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        const int dim = 32 * ks + 8 * g;
+        kf[S][blk][ks] = gload16_async(K + (int64_t)key * a.ldk + (dim < hd ? dim : 0));
+      }
+    }
+    constexpr int PC = HDPV / 8, RPI = 64 / PC;
+    char* img = Vring + S * IMG;
+#pragma unroll
+    for (int i = 0; i < 64 * HDPV * 2 / 1024; ++i) {
+      const int kr = i * RPI + lane / PC;
+      const int swz = (kr & 3) | (((kr >> 3) & 1) << 2);
+      const int c = (lane % PC) ^ ((swz << 1) & (PC - 1));
+      const int dim = c * 8;
+      const int row = kt * 64 + kr;
+      const void* src = (row < a.Tk && dim < hd) ? (const void*)(V + (int64_t)row * a.ldv + dim)
+                                                 : (const void*)g_attn_zero_page;
+      glds16_async(src, img + i * 1024);
+    }
+  };
+  auto step = [&](auto slot_c, int j) {
+    constexpr int S = decltype(slot_c)::value;
+    const int kt = wave + 4 * j;
+    const int rem = nw - 1 - j;  // younger tiles already issued (at most D - 1)
+    if (rem >= 2)
+      asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+    else if (rem == 1)
+      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const char* Vimg = Vring + S * IMG;
+    // the V fragments are asked for first: their LDS latency hides under the score MFMAs
+    bf16x8_t vf[2][NNB];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int nb = 0; nb < NNB; ++nb) vf[s][nb] = timg_frag_async<HDPV>(Vimg, s, nb, lane);
     f32x4_t sc[4];
 #pragma unroll
     for (int blk = 0; blk < 4; ++blk) {
       f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-      const int row = 32 * (blk >> 1) + rowperm(blk & 1, r);
 #pragma unroll
-      for (int ks = 0; ks < NKS; ++ks)
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kimg_frag<64>(Kimg, row, ks, lane), qf[ks], acc, 0, 0, 0);
+      for (int ks = 0; ks < NKS; ++ks) {
+        tie(kf[S][blk][ks]);
+        if (32 * ks + 8 * g >= hd) kf[S][blk][ks] = __builtin_bit_cast(bf16x8_t, (f32x4_t){0.f, 0.f, 0.f, 0.f});
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[S][blk][ks], qf[ks], acc, 0, 0, 0);
+      }
       sc[blk] = acc;
     }
     const bool full = kt * 64 + 64 <= kl;
@@ -412,6 +473,7 @@ __global__ __launch_bounds__(256) void attn_fwd_smallq_kernel(const AttnArgs a) 
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[nb][e] *= ar[e];
     m = m_new;
+    lds_wait_all();
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       float ps[8];
@@ -419,9 +481,20 @@ __global__ __launch_bounds__(256) void attn_fwd_smallq_kernel(const AttnArgs a) 
       for (int e = 0; e < 8; ++e) ps[e] = p[8 * s + e];
       const bf16x8_t pf = pack8(ps);
 #pragma unroll
-      for (int nb = 0; nb < NNB; ++nb)
-        o[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, timg_frag<HDPV>(Vimg, s, nb, lane), o[nb], 0, 0, 0);
+      for (int nb = 0; nb < NNB; ++nb) {
+        tie(vf[s][nb]);
+        o[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, vf[s][nb], o[nb], 0, 0, 0);
+      }
     }
+    if (j + D < nw) issue(slot_c, j + D);  // slot S is free again: its registers and its LDS image have been consumed
+  };
+  if (nw > 0) issue(std::integral_constant<int, 0>{}, 0);
+  if (nw > 1) issue(std::integral_constant<int, 1>{}, 1);
+  if (nw > 2) issue(std::integral_constant<int, 2>{}, 2);
+  for (int j = 0; j < nw; j += D) {
+    step(std::integral_constant<int, 0>{}, j);
+    if (j + 1 < nw) step(std::integral_constant<int, 1>{}, j + 1);
+    if (j + 2 < nw) step(std::integral_constant<int, 2>{}, j + 2);
   }
   // merge the four waves: (m, l) per query and the output rows, through LDS (the images are dead now)
   l += __shfl_xor(l, 16, 64);
@@ -776,7 +849,13 @@ extern "C" int ca_attn_fwd(const CaAttnDesc* desc, void* stream) {
   dim3 grid(attn_grid((desc->Tq + 63) / 64, desc->H, desc->B)), block(256);
   hipStream_t s = (hipStream_t)stream;
   if (desc->Tq <= 16 && desc->hd <= 64 && !desc->causal) {  // greedy decoding: the waves split the keys
-    hipLaunchKernelGGL((attn_fwd_smallq_kernel<64>), dim3((unsigned)(desc->B * desc->H)), block, 4 * 2 * 64 * 64 * 2, s, a);
+    constexpr int SMALLQ_LDS = 4 * 3 * 64 * 64 * 2;  // four waves x ring of three 8-KiB V images
+    static bool attr = false;
+    if (!attr) {
+      hipFuncSetAttribute((const void*)attn_fwd_smallq_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, SMALLQ_LDS);
+      attr = true;
+    }
+    hipLaunchKernelGGL((attn_fwd_smallq_kernel<64>), dim3((unsigned)(desc->B * desc->H)), block, SMALLQ_LDS, s, a);
     CA_CHECK_LAUNCH("ca_attn_fwd");
     return CA_OK;
   }

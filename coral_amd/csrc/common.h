@@ -82,6 +82,10 @@ __device__ __forceinline__ float wave_max(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
 }
+// ---- LayerNorm row arithmetic (one expression wherever a normalised value is formed) ----
+__device__ __forceinline__ float ln_apply(float v, float mean, float rstd, float gm, float bt) {
+  return (v - mean) * rstd * gm + bt;
+}
 
 // counter-based hash for fused dropout masks (same bits in forward and backward)
 __device__ __forceinline__ uint32_t ca_hash32(uint64_t seed, uint64_t idx) {

@@ -1213,6 +1213,25 @@ __global__ __launch_bounds__(256) void ca_gemm_skinny_kernel(const CaGemmDesc d)
   const int ks0 = wave * per, ks1 = (ks0 + per < ksteps) ? ks0 + per : ksteps;
   f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
   const bf16x8_t zero = __builtin_bit_cast(bf16x8_t, (f32x4_t){0.f, 0.f, 0.f, 0.f});
+  // The kernel is a short chain of memory round trips behind a ~4 us dependent launch (measured: 4.0 us per launch
+  // in a graph at N = K = 1024, +1 us per 24 KB a workgroup streams - the per-CU fill rate - tools/dev_skinny_time.py),
+  // so the epilogue's operands (bias, residual, destination row) are asked for up front, beside the first K-steps.
+  const int epi = d.epilogue;
+  const bool fin = wave == 0 && r < d.M;  // lanes that finish output row m = r, columns n0 + 4g .. +3
+  float e_bias[4] = {0.f, 0.f, 0.f, 0.f}, e_res[4] = {0.f, 0.f, 0.f, 0.f};
+  int64_t crow = r;
+  if (fin) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int n = n0 + 4 * g + e;
+      if (n < d.N) {
+        if (d.bias) e_bias[e] = d.bias[n];
+        if (epi == CA_EPI_GELU_RESIDUAL || epi == CA_EPI_RESIDUAL)
+          e_res[e] = bf2f(((const unsigned short*)d.R)[(int64_t)r * d.ldr + n]);
+      }
+    }
+    if (d.c_row_index) crow = (int64_t)r * d.c_row_mul + d.c_row_index[r];
+  }
   for (int ks = ks0; ks < ks1; ks += 8) {
     bf16x8_t wf[8], af[8];
 #pragma unroll
@@ -1229,25 +1248,22 @@ __global__ __launch_bounds__(256) void ca_gemm_skinny_kernel(const CaGemmDesc d)
 #pragma unroll
   for (int e = 0; e < 4; ++e) part[wave][r * 16 + 4 * g + e] = acc[e];
   __syncthreads();
-  if (wave != 0) return;
-  const int m = r;
-  if (m >= d.M) return;
-  const int epi = d.epilogue;
+  if (!fin) return;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int n = n0 + 4 * g + e;
     if (n >= d.N) continue;
     const int i = r * 16 + 4 * g + e;
     float v = (part[0][i] + part[1][i]) + (part[2][i] + part[3][i]);
-    v = v * d.alpha + (d.bias ? d.bias[n] : 0.f);
+    v = v * d.alpha + e_bias[e];
     float v2 = 0.f;
     if (epi == CA_EPI_GELU || epi == CA_EPI_GELU_RESIDUAL) {
       v2 = gelu_erf(v);
-      if (epi == CA_EPI_GELU_RESIDUAL) v2 += bf2f(((const unsigned short*)d.R)[(int64_t)m * d.ldr + n]);
+      if (epi == CA_EPI_GELU_RESIDUAL) v2 += e_res[e];
     } else if (epi == CA_EPI_RESIDUAL) {
-      v += bf2f(((const unsigned short*)d.R)[(int64_t)m * d.ldr + n]);
+      v += e_res[e];
     }
-    const int64_t off = (int64_t)m * d.ldc + n;
+    const int64_t off = crow * d.ldc + n;
     if (d.C) {
       if (d.out_f32)
         ((float*)d.C)[off] = d.accumulate ? ((float*)d.C)[off] + v : v;
@@ -1433,6 +1449,7 @@ static int ca_gemm_launch(const CaGemmDesc* desc, void* stream) {
     CA_CHECK_LAUNCH("ca_gemm_bf16");
     return CA_OK;
   }
+  CA_CHECK_ARG(!d.c_row_index, "ca_gemm_bf16: c_row_index exists in the skinny form only (M <= 16, K-major operands, un-batched)");
   // Kernel choice: the 256x128 pipelined kernel runs one workgroup per CU, so it needs enough
   // tiles to fill the chip; small or heavily batched problems use the 128x128 kernel.
   const int64_t nb = (int64_t)d.batch1 * d.batch2;

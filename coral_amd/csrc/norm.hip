@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const unsigned short* __res
         for (int e = 0; e < 8; ++e) {
           const float gm = e < 4 ? g0[e] : g1[e - 4];
           const float bt = e < 4 ? b0[e] : b1[e - 4];
-          float u = (v[c][e] - mean) * rstd * gm + bt;
+          float u = ln_apply(v[c][e], mean, rstd, gm, bt);
           if (act) u = gelu_erf(u);
           o[e] = f2bf(u);
         }

@@ -43,8 +43,10 @@ def _gemm_desc(A, B, Cout, *, M, N, K, lda, ldb, ldc, a_layout=KMAJOR, b_layout=
          epilogue=EPI_NONE, out_f32=None, accumulate=False, alpha=1.0, batch1=1, batch2=1,
          sA=(0, 0), sB=(0, 0), sC=(0, 0), sR=(0, 0), sBias=(0, 0), a_kseg=0, a_kseg_stride=0, b_kseg=0,
          b_kseg_stride=0, dropout_p=0.0, dropout_seed=0, a_colsum=None, a_colsum_off=0,
-         a_colsum_ld=0):
+         a_colsum_ld=0, c_row_index=None, c_row_mul=0):
     d = CaGemmDesc()
+    if c_row_index is not None:
+        d.c_row_index, d.c_row_mul = _p(c_row_index), c_row_mul
     if a_colsum is not None:
         d.a_colsum = _p(a_colsum, a_colsum_off)
         d.a_colsum_ld = a_colsum_ld

@@ -481,10 +481,11 @@ class WhisperEngine:
                               w["x"], None, B, d, s.layer_norm_eps)
             ops.gemm(w["x"], p16, w["q"], M=B, N=d, K=d, lda=d, ldb=d, ldc=d, b_off=o(p + "self_attn.q_proj.weight"),
                      bias=p32, bias_off=o(p + "self_attn.q_proj.bias"))
-            ops.gemm(w["x"], p16, g["kvnew"], M=B, N=2 * d, K=d, lda=d, ldb=d, ldc=2 * d,
-                     b_off=o(p + "self_attn.k_proj.weight"), bias=p32, bias_off=o(p + "self_attn.k_proj.bias__zero"))
-            # append at the device-side position (plain indexed copy: the position is data, not a launch argument)
-            ckv.view(B, Lmax, 2 * d)[g["rows"], g["pos"].long()] = g["kvnew"].view(B, 2 * d)
+            # the new K|V rows go straight into the cache at the device-side position (CaGemmDesc.c_row_index: the
+            # position is data, not a launch argument, so the launch sequence can be replayed as a graph)
+            ops.gemm(w["x"], p16, ckv, M=B, N=2 * d, K=d, lda=d, ldb=d, ldc=2 * d,
+                     b_off=o(p + "self_attn.k_proj.weight"), bias=p32, bias_off=o(p + "self_attn.k_proj.bias__zero"),
+                     c_row_index=g["pos"], c_row_mul=Lmax)
             ops.attn_fwd(w["q"], ckv, ckv, w["ctx"], self._lse(B * H * 32), B=B, H=H, Tq=1, Tk=Lmax, hd=hd, Tqp=32,
                          scale=hd ** -0.5, ldq=d, ldk=2 * d, ldv=2 * d, ldo=d, sqb=d, skb=Lmax * 2 * d,
                          svb=Lmax * 2 * d, sob=d, k_off=0, v_off=d, klen=g["klen"])

@@ -553,3 +553,29 @@ def test_weight_gradient_with_fused_bias_gradient_and_grouped_launch(ops):
             wb = dYs[i].float().sum(0) + 0.25
             gb = Gc[offs[-1] + cs_offs[i]:offs[-1] + cs_offs[i] + m]
             assert (gb - wb).abs().max() <= 2e-3 * max(1.0, float(wb.abs().max())), ("bias", i, fused)
+
+
+@pytest.mark.parametrize("M,N,K", [(8, 1024, 1024), (5, 1000, 1280), (16, 264, 384)])
+def test_gemm_skinny_row_index(ops, M, N, K):
+    """CaGemmDesc.c_row_index (one decoded token per clip): the output rows land at device-side positions of a
+    [M, L, N] cache, bit-identical to the plain GEMM's rows; the tiled kernels refuse the option."""
+    x = bf(rnd(M, K, seed=21, scale=0.5)).to(DEV)
+    W = bf(rnd(N, K, seed=22, scale=0.1)).to(DEV)
+    bias = rnd(N, seed=25).to(DEV)
+    Np = (N + 7) // 8 * 8
+    ref = torch.zeros(M, Np, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(x, W, ref, M=M, N=N, K=K, lda=K, ldb=K, ldc=Np, bias=bias)
+    want = x.float() @ W.float().t() + bias
+    assert (ref[:, :N].float() - want).abs().max().item() <= 2e-2 * max(1.0, want.abs().max().item())
+    L = 7
+    pos = torch.tensor([(3 * m + 1) % L for m in range(M)], dtype=torch.int32, device=DEV)
+    cache = torch.zeros(M, L, Np, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(x, W, cache, M=M, N=N, K=K, lda=K, ldb=K, ldc=Np, bias=bias, c_row_index=pos, c_row_mul=L)
+    torch.cuda.synchronize()
+    want_cache = torch.zeros_like(cache)
+    want_cache[torch.arange(M, device=DEV), pos.long()] = ref
+    assert torch.equal(cache, want_cache)
+    with pytest.raises(Exception):
+        big = torch.zeros(64 * L, Np, dtype=torch.bfloat16, device=DEV)
+        ops.gemm(torch.zeros(64, K, dtype=torch.bfloat16, device=DEV), W, big, M=64, N=N, K=K, lda=K, ldb=K, ldc=Np,
+                 c_row_index=torch.zeros(64, dtype=torch.int32, device=DEV), c_row_mul=L)
