@@ -24,6 +24,7 @@ from dataclasses import dataclass
 import torch
 
 from . import ops
+from .staging import PinnedStager
 from .ops import EPI_DGELU, EPI_GELU, EPI_GELU_RESIDUAL, EPI_NONE, EPI_RESIDUAL, KMAJOR, MNMAJOR
 
 
@@ -176,6 +177,7 @@ class Wav2Vec2CTCEngine:
         self.training = False
         self._ws = None
         self._ws_key = None
+        self._stager = PinnedStager(self.device)
         self._saved = None
         self.step_seed = 0
         d = s.hidden_size
@@ -363,7 +365,7 @@ class Wav2Vec2CTCEngine:
         output), attention_mask [B,N] or None, labels i64/i32 [B,L] (-100 padded) or None."""
         s, st = self.s, self.store
         dev = self.device
-        x = input_values.to(dev, torch.float32).contiguous()
+        x = self._stager.to_device(input_values, torch.float32, "x")
         B, N = x.shape
         w = self._workspace(B, N)
         d, f, H, hd = s.hidden_size, s.intermediate_size, s.num_attention_heads, s.head_dim
@@ -374,7 +376,7 @@ class Wav2Vec2CTCEngine:
         o = st.off
 
         if attention_mask is not None:
-            slen = attention_mask.to(dev).sum(-1)
+            slen = self._stager.to_device(attention_mask, attention_mask.dtype, "am").sum(-1)
             flen = self.feat_lengths(slen).to(torch.int32).contiguous()
         else:
             flen = torch.full((B,), T, dtype=torch.int32, device=dev)
@@ -406,8 +408,10 @@ class Wav2Vec2CTCEngine:
         ops.gemm(w["xln"], p16, w["h0"], M=M, N=d, K=C6, lda=C6, ldb=C6, ldc=d,
                  b_off=o(fp + "projection.weight"), bias=p32, bias_off=o(fp + "projection.bias"))
         # SpecAugment + padding
-        tm = mask_time.to(dev, torch.uint8).contiguous() if mask_time is not None else None
-        fm = mask_feature.to(dev, torch.uint8).contiguous() if mask_feature is not None else None
+        # (host-sampled masks and labels go through pinned staging: a pageable .to(device) here would stall the host
+        # until the GPU had drained the previous step)
+        tm = self._stager.to_device(mask_time, torch.uint8, "tm") if mask_time is not None else None
+        fm = self._stager.to_device(mask_feature, torch.uint8, "fm") if mask_feature is not None else None
         ops.mask_frames(w["h0"], tm, fm, p16[o("wav2vec2.masked_spec_embed"):], flen, B, T, d)
         # positional conv embedding: h = h0 + gelu(conv(h0) + b)
         G, K = s.num_conv_pos_embedding_groups, s.num_conv_pos_embeddings
@@ -461,7 +465,7 @@ class Wav2Vec2CTCEngine:
         self._saved = dict(w=w, x=x, flen=flen, keep=keep, tm=tm, fm=fm, drop_p=drop_p, B=B, N=N,
                            has_loss=False)
         if labels is not None:
-            lab = labels.to(dev, torch.int32).contiguous()
+            lab = self._stager.to_device(labels, torch.int32, "lab")
             Lmax = lab.shape[1]
             in_len = flen
             key = (B, T, Lmax)

@@ -17,6 +17,7 @@ from __future__ import annotations
 import torch
 
 from . import ops
+from .staging import PinnedStager
 from .blocks import CrossAttnBlock, FFNBlock, Scratch, SelfAttnBlock, _z
 from .ops import EPI_GELU, EPI_GELU_RESIDUAL, MNMAJOR
 from .wav2vec2 import _r8
@@ -29,6 +30,7 @@ class WhisperTrainEngine(WhisperEngine):
     def __init__(self, shape: WhisperShape, device="cuda:0", activation_dropout: float = 0.0,
                  freeze_base: bool = False):
         super().__init__(shape, device)
+        self._stager = PinnedStager(self.device)
         self.freeze_base = freeze_base
         s, st = shape, self.store
         d, eps = s.d_model, s.layer_norm_eps
@@ -129,7 +131,7 @@ class WhisperTrainEngine(WhisperEngine):
         s, st = self.s, self.store
         p32, p16, o = st.p32, st.p16, st.off
         dev = self.device
-        x = input_features.to(dev, torch.float32).contiguous()
+        x = self._stager.to_device(input_features, torch.float32, "x")  # pinned staging: no host stall (staging.py)
         B, mels, Tin = x.shape
         T, d = s.max_source_positions, s.d_model
         if mels != s.num_mel_bins or Tin != 2 * T:
@@ -145,13 +147,15 @@ class WhisperTrainEngine(WhisperEngine):
         w = self._train_ws(B, L)
         Me, Md = B * T, B * L
         drop = self.activation_dropout if self.training else 0.0
+        mask_time_d = self._stager.to_device(mask_time, torch.uint8, "tm") if mask_time is not None else None
+        mask_feature_d = self._stager.to_device(mask_feature, torch.uint8, "fm") if mask_feature is not None else None
         self._await("front")
         # encoder stem
         for b in range(B):
             ops.transpose_f32_bf16(x[b], w["xin"][(b * (Tin + 2) + 1) * mels:], mels, Tin)
             if mask_time is not None or mask_feature is not None:  # SpecAugment on the input features
-                tm = mask_time[b:b + 1].to(dev, torch.uint8).contiguous() if mask_time is not None else None
-                fm = mask_feature[b:b + 1].to(dev, torch.uint8).contiguous() if mask_feature is not None else None
+                tm = mask_time_d[b:b + 1].contiguous() if mask_time_d is not None else None
+                fm = mask_feature_d[b:b + 1].contiguous() if mask_feature_d is not None else None
                 ops.mask_frames(w["xin"][(b * (Tin + 2) + 1) * mels:], tm, fm, self.zero_mel, None, 1, Tin, mels)
         ops.gemm(w["xin"], self.conv1_wr, w["pre1"], C2=w["c1"], c_off=d, c2_off=d, M=Tin, N=d, K=3 * mels, lda=mels,
                  ldb=3 * mels, ldc=d, bias=p32, bias_off=o("model.encoder.conv1.bias"), epilogue=EPI_GELU, batch2=B,
@@ -174,7 +178,7 @@ class WhisperTrainEngine(WhisperEngine):
         ops.layernorm_fwd(w["eh"][-1], st.view("model.encoder.layer_norm.weight"), st.view("model.encoder.layer_norm.bias"),
                           w["enc_out"], w["enc_st"], Me, d, s.layer_norm_eps)
         # decoder
-        ids = dec_in.to(dev, torch.int32).contiguous().view(-1)
+        ids = self._stager.to_device(dec_in, torch.int32, "ids").view(-1)
         pos = torch.arange(L, dtype=torch.int32, device=dev).repeat(B)
         ops.embed_tokens(p16[o("model.decoder.embed_tokens.weight"):], p16[o("model.decoder.embed_positions.weight"):],
                          ids, pos, w["dh"][0], Md, d)
@@ -195,7 +199,7 @@ class WhisperTrainEngine(WhisperEngine):
         ops.gemm(w["dec_out"], p16, w["logits"], M=Md, N=V, K=d, lda=d, ldb=d, ldc=Vp, b_off=o("model.decoder.embed_tokens.weight"))
         w["loss_sum"].zero_()
         w["count"].zero_()
-        lab32 = lab.to(dev, torch.int32).contiguous().view(-1)
+        lab32 = self._stager.to_device(lab, torch.int32, "lab").view(-1)
         ops.cross_entropy_fwd_bwd(w["logits"], lab32, w["loss_sum"], w["count"], w["dlogits"], Md, V, Vp, -100)
         cnt = w["count"].clamp(min=1).to(torch.float32)
         loss = (w["loss_sum"] / cnt)[0]
