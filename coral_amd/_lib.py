@@ -104,6 +104,7 @@ SIGNATURES = {
     "ca_dgelu_mul": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
     "ca_reduce_rows_f32": (C.c_int, [_vp, _i32, _i64, _i32, _vp, _i32, _vp]),
     "ca_wave_normalize": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _f32, _vp]),
+    "ca_frame_lengths": (C.c_int, [_vp, _i32, _i64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _i32, _vp, _vp]),
     "ca_wave_scale": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _vp]),
     "ca_fir_filter": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _i32, _i64, _vp]),
     "ca_mix_noise": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _i32, _i64, _vp]),

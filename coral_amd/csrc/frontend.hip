@@ -58,6 +58,50 @@ extern "C" int ca_wave_normalize(const float* x, const int32_t* lengths, float* 
   return CA_OK;
 }
 
+// ---- attention mask -> frames per utterance -----------------------------------------------------
+// `_get_feat_extract_output_lengths(attention_mask.sum(-1))` ($TF/models/wav2vec2/modeling_wav2vec2.py:1093-1108):
+// the row sum of the int mask pushed through the conv stack's floor((n - k) / s) + 1, one launch instead of the two
+// dozen tiny elementwise kernels the same arithmetic takes as tensor ops.
+struct ConvStack {
+  int32_t n, k[8], s[8];
+};
+__global__ __launch_bounds__(256) void frame_lengths_kernel(const int32_t* __restrict__ mask, int64_t N, ConvStack cs,
+                                                            int32_t* __restrict__ out) {
+  __shared__ int red[4];
+  const int b = blockIdx.x;
+  const int32_t* mb = mask + (int64_t)b * N;
+  int s = 0;
+  for (int64_t i = threadIdx.x; i < N; i += 256) s += mb[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int64_t n = (int64_t)red[0] + red[1] + red[2] + red[3];
+    for (int i = 0; i < cs.n; ++i) {
+      const int64_t d = n - cs.k[i];
+      const int64_t q = d >= 0 ? d / cs.s[i] : -((-d + cs.s[i] - 1) / cs.s[i]);  // floor division
+      n = q + 1;
+    }
+    out[b] = (int32_t)n;
+  }
+}
+extern "C" int ca_frame_lengths(const int32_t* attention_mask, int32_t B, int64_t N, const int32_t* kernels,
+                                const int32_t* strides, int32_t nconv, int32_t* out, void* stream) {
+  CA_CHECK_ARG(attention_mask && out && kernels && strides && B > 0 && N > 0 && nconv >= 0 && nconv <= 8,
+               "ca_frame_lengths: bad argument");
+  ConvStack cs;
+  cs.n = nconv;
+  for (int i = 0; i < nconv; ++i) {
+    CA_CHECK_ARG(strides[i] > 0, "ca_frame_lengths: stride must be positive");
+    cs.k[i] = kernels[i];
+    cs.s[i] = strides[i];
+  }
+  hipLaunchKernelGGL(frame_lengths_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, attention_mask, N, cs, out);
+  CA_CHECK_LAUNCH("ca_frame_lengths");
+  return CA_OK;
+}
+
 // ---- raw PCM -> model input (row N1 of SURVEY.md §8f) -------------------------------------------
 // One workgroup per utterance: int16 (or fp32) samples -> optional peak normalisation (x / max|x|,
 // `ta.PeakNormalization`, R/src/coral/data.py:710) -> zero-mean / unit-variance over the valid samples

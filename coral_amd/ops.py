@@ -240,6 +240,15 @@ def wave_normalize(x, lengths, y, B, N, eps=1e-7):
           "ca_wave_normalize")
 
 
+def frame_lengths(attention_mask, kernels, strides, out):
+    """int32 device mask [B, N] -> int32 [B] frames after the conv stack (one launch)."""
+    B, N = attention_mask.shape
+    n = len(kernels)
+    k = (C.c_int32 * n)(*kernels)
+    s = (C.c_int32 * n)(*strides)
+    check(lib().ca_frame_lengths(_p(attention_mask), B, N, k, s, n, _p(out), _stream()), "ca_frame_lengths")
+
+
 def pcm_prepare(pcm, lengths, y, mask, B, N, ld_in, peak_normalize=False, zero_mean_unit_var=True, eps=1e-7):
     """Raw PCM rows (int16 or fp32, device) -> normalised fp32 input_values + int32 attention_mask."""
     if pcm.dtype not in (torch.int16, torch.float32):

@@ -231,10 +231,19 @@ class Wav2Vec2CTCEngine:
         for name in ("front", "head"):
             lo, hi = st.buckets[name]
             st.g32[lo:hi].zero_()
-        for l in range(self.s.num_hidden_layers):
-            lo = st.off(f"wav2vec2.encoder.layers.{l}.layer_norm.weight")
-            hi = st.off(f"wav2vec2.encoder.layers.{l}.attention.q_proj.weight")
-            st.g32[lo:hi].zero_()
+        # the layers' small parameters (LayerNorms, biases) sit at the same offset of equally sized layer buckets:
+        # one strided fill instead of one launch per layer
+        L = self.s.num_hidden_layers
+        lo0 = st.off("wav2vec2.encoder.layers.0.layer_norm.weight")
+        n = st.off("wav2vec2.encoder.layers.0.attention.q_proj.weight") - lo0
+        stride = st.off("wav2vec2.encoder.layers.1.layer_norm.weight") - lo0 if L > 1 else n
+        uniform = all(st.off(f"wav2vec2.encoder.layers.{l}.layer_norm.weight") == lo0 + l * stride for l in range(L))
+        if uniform and L > 1:
+            st.g32[lo0:lo0 + (L - 1) * stride + n].as_strided((L, n), (stride, 1)).zero_()
+        else:
+            for l in range(L):
+                lo = st.off(f"wav2vec2.encoder.layers.{l}.layer_norm.weight")
+                st.g32[lo:lo + n].zero_()
 
     def train(self, mode: bool = True):
         self.training = mode
@@ -376,8 +385,9 @@ class Wav2Vec2CTCEngine:
         o = st.off
 
         if attention_mask is not None:
-            slen = self._stager.to_device(attention_mask, attention_mask.dtype, "am").sum(-1)
-            flen = self.feat_lengths(slen).to(torch.int32).contiguous()
+            am = self._stager.to_device(attention_mask, torch.int32, "am")
+            flen = torch.empty(B, dtype=torch.int32, device=dev)
+            ops.frame_lengths(am, s.conv_kernel, s.conv_stride, flen)
         else:
             flen = torch.full((B,), T, dtype=torch.int32, device=dev)
         keep = [True] * L if layer_keep is None else list(layer_keep)

@@ -167,6 +167,12 @@ int ca_dgelu_mul(const void* dy, const void* u, void* out, int64_t n, void* stre
  * ---------------------------------------------------------------------------------- */
 int ca_wave_normalize(const float* x, const int32_t* lengths, float* y, int32_t B,
                       int64_t N, float eps, void* stream);
+
+/* out[b] = _get_feat_extract_output_lengths(attention_mask[b].sum()) for the conv stack (kernels[i], strides[i]),
+ * i < nconv <= 8: floor((n - k) / s) + 1 per layer ($TF/models/wav2vec2/modeling_wav2vec2.py:1093-1108).  kernels /
+ * strides are HOST arrays; attention_mask is int32 [B, N] on the device. */
+int ca_frame_lengths(const int32_t* attention_mask, int32_t B, int64_t N, const int32_t* kernels,
+                     const int32_t* strides, int32_t nconv, int32_t* out, void* stream);
 /* ca_pcm_prepare: raw PCM batch -> model input on the device (replaces the per-example
  *   host featurisation `processor(audio)` at R/src/coral/data.py:747 plus the collator's padding at
  *   R/src/coral/data_collators.py:72-77).  pcm: int16 (is_int16 != 0, scaled by 1/32768) or fp32, B rows of

@@ -579,3 +579,18 @@ def test_gemm_skinny_row_index(ops, M, N, K):
         big = torch.zeros(64 * L, Np, dtype=torch.bfloat16, device=DEV)
         ops.gemm(torch.zeros(64, K, dtype=torch.bfloat16, device=DEV), W, big, M=64, N=N, K=K, lda=K, ldb=K, ldc=Np,
                  c_row_index=torch.zeros(64, dtype=torch.int32, device=DEV), c_row_mul=L)
+
+
+def test_frame_lengths(ops):
+    """ca_frame_lengths against `_get_feat_extract_output_lengths` arithmetic on ragged masks (one shorter than the
+    first kernel)."""
+    B, N = 5, 16000
+    lens = torch.tensor([16000, 12345, 400, 7, 9999])
+    mask = (torch.arange(N)[None, :] < lens[:, None]).to(torch.int32).to(DEV)
+    kernels, strides = (10, 3, 3, 3, 3, 2, 2), (5, 2, 2, 2, 2, 2, 2)
+    out = torch.zeros(B, dtype=torch.int32, device=DEV)
+    ops.frame_lengths(mask, kernels, strides, out)
+    n = lens.clone()
+    for k, s in zip(kernels, strides):
+        n = torch.div(n - k, s, rounding_mode="floor") + 1
+    assert out.cpu().tolist() == n.tolist()
