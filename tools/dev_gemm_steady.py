@@ -11,7 +11,7 @@ from coral_amd import ops  # noqa: E402
 
 dev = "cuda:0"
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
-ops.lib().ca_gemm_force_kernel(3)
+ops.lib().ca_gemm_force_kernel(int(sys.argv[2]) if len(sys.argv) > 2 else 3)
 
 
 def timeit(fn, iters=10):
