@@ -180,6 +180,12 @@ class DataParallelTrainer:
         self.bucket_index = {name: i for i, name in enumerate(st.buckets)}
         self.bucket_sq = torch.zeros(len(st.buckets), dtype=torch.float32, device=st.device)
         self._norms_ready = False
+        # N = 1: the squared norm of the gradients that are final early in the backward is taken on the side stream
+        # while the rest of the backward runs (one HBM-bound pass beside MFMA-bound GEMMs), see _early_norm
+        self.partial_early = torch.zeros(4096, dtype=torch.float32, device=st.device)
+        self.early_fraction = float(os.environ.get("CA_EARLY_NORM", "0.8"))
+        self._early_lo = None   # [self._early_lo, hi) is already inside gnorm_sq
+        self._done_lo = None
 
     # ---- one optimiser step ----------------------------------------------------------------------
     def train_step(self, micro_batches) -> float | torch.Tensor:
@@ -207,6 +213,9 @@ class DataParallelTrainer:
                 self._norms_ready = True
             elif self.world > 1 and last and self.overlap:
                 hook = self.sync.start
+            elif self.world == 1 and last and self.overlap_optimizer and self.early_fraction > 0:
+                self._done_lo, self._early_lo = self.train_range[1], None
+                hook = self._early_norm
             eng.backward(loss_scale=1.0 / n, overwrite_matrices=(i == 0), bucket_done=hook)
             total = out.loss / n if total is None else total + out.loss / n
         if self.world > 1 and not self.overlap:
@@ -230,6 +239,25 @@ class DataParallelTrainer:
         with torch.cuda.stream(self.opt_stream):
             self._bucket_sumsq(name)
 
+    def _early_norm(self, name: str):
+        """Backward hook (N = 1).  Buckets complete from the end of the flat gradient buffer towards its start; once
+        the completed tail [done_lo, hi) covers `early_fraction` of the gradients its squared norm is started on the
+        side stream (fixed split, fixed order: deterministic) and only the head of the buffer is left for the pass
+        behind the backward."""
+        if self._early_lo is not None:
+            return
+        a, b = self.engine.store.buckets[name]
+        lo, hi = self.train_range
+        if b != self._done_lo:  # not adjacent to the completed tail (e.g. the head bucket of another layout)
+            return
+        self._done_lo = a
+        if hi - a < self.early_fraction * (hi - lo) or a <= lo:
+            return
+        self._early_lo = a
+        self.opt_stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.opt_stream):
+            ops.sumsq(self.engine.store.g32[a:hi], hi - a, self.gnorm_sq, self.partial_early)
+
     def finish(self):
         """Make the current stream wait for an optimiser step that is still running on the side stream."""
         if self.opt_done is not None:
@@ -247,6 +275,10 @@ class DataParallelTrainer:
                 torch.cuda.current_stream().wait_stream(self.opt_stream)
             self.gnorm_sq.copy_(self.bucket_sq.sum().reshape(1))
             self._norms_ready = False
+        elif self._early_lo is not None:  # the tail's squared norm is already in gnorm_sq (side stream)
+            torch.cuda.current_stream().wait_stream(self.opt_stream)
+            ops.sumsq(st.g32[lo:self._early_lo], self._early_lo - lo, self.gnorm_sq, self.partial, accumulate=True)
+            self._early_lo = None
         else:
             ops.sumsq(st.g32[lo:hi], n, self.gnorm_sq, self.partial)
 
