@@ -299,11 +299,19 @@ class DataParallelTrainer:
             order = sorted(st.buckets.items(), key=lambda kv: kv[1][0])
             for name, (a, b) in order:
                 update(a, b)
-                if name == "front":
+                parts = getattr(eng, "derived_parts", None) if name == "front" else None
+                if name == "front" and not parts:
                     eng.refresh_derived()
+                if parts:
+                    eng.refresh_derived(parts[0])
                 ev = torch.cuda.Event()
                 ev.record(self.opt_stream)
                 events[name] = ev
+                for part in (parts or ())[1:]:  # later parts of the derived weights get events of their own
+                    eng.refresh_derived(part)
+                    ev = torch.cuda.Event()
+                    ev.record(self.opt_stream)
+                    events[f"front_{part}"] = ev
             if "front" not in events:
                 eng.refresh_derived()
             self.opt_done = torch.cuda.Event()

@@ -257,14 +257,21 @@ class Wav2Vec2CTCEngine:
         self.store.refresh_bf16()
         self.refresh_derived()
 
-    def refresh_derived(self):
+    # the derived weights in the order the forward needs them: the trainer records one event per part, so the conv
+    # stack does not wait for the weight-normed positional conv to be rebuilt (_await("front_posconv"))
+    derived_parts = ("conv", "posconv")
+
+    def refresh_derived(self, part: str | None = None):
         """Weights whose compute copy is not a plain cast (after an optimiser step the flat bf16
-        copy is already written by ca_adamw_step)."""
+        copy is already written by ca_adamw_step).  part: None = all, or one of `derived_parts`."""
         s, st = self.s, self.store
-        for i in range(1, len(s.conv_dim)):
-            ops.conv_weight_reorder(st.p32, self.conv_wr[i], s.conv_dim[i], s.conv_dim[i - 1],
-                                    s.conv_kernel[i],
-                                    w_off=st.off(f"wav2vec2.feature_extractor.conv_layers.{i}.conv.weight"))
+        if part in (None, "conv"):
+            for i in range(1, len(s.conv_dim)):
+                ops.conv_weight_reorder(st.p32, self.conv_wr[i], s.conv_dim[i], s.conv_dim[i - 1],
+                                        s.conv_kernel[i],
+                                        w_off=st.off(f"wav2vec2.feature_extractor.conv_layers.{i}.conv.weight"))
+        if part not in (None, "posconv"):
+            return
         d, G, K = s.hidden_size, s.num_conv_pos_embedding_groups, s.num_conv_pos_embeddings
         pre = "wav2vec2.encoder.pos_conv_embed.conv.parametrizations.weight."
         ops.posconv_weight(st.view(pre + "original1"), st.view(pre + "original0"), self.pc_wf, self.pc_wb,
@@ -424,6 +431,7 @@ class Wav2Vec2CTCEngine:
         fm = self._stager.to_device(mask_feature, torch.uint8, "fm") if mask_feature is not None else None
         ops.mask_frames(w["h0"], tm, fm, p16[o("wav2vec2.masked_spec_embed"):], flen, B, T, d)
         # positional conv embedding: h = h0 + gelu(conv(h0) + b)
+        self._await("front_posconv")
         G, K = s.num_conv_pos_embedding_groups, s.num_conv_pos_embeddings
         Cg = d // G
         Tpad = T + K
