@@ -185,7 +185,7 @@ class DataParallelTrainer:
         self.partial_early = torch.zeros(4096, dtype=torch.float32, device=st.device)
         self.early_fraction = float(os.environ.get("CA_EARLY_NORM", "0.8"))
         self._early_lo = None   # [self._early_lo, hi) is already inside gnorm_sq
-        self._done_lo = None
+        self._done = {}
 
     # ---- one optimiser step ----------------------------------------------------------------------
     def train_step(self, micro_batches) -> float | torch.Tensor:
@@ -214,7 +214,7 @@ class DataParallelTrainer:
             elif self.world > 1 and last and self.overlap:
                 hook = self.sync.start
             elif self.world == 1 and last and self.overlap_optimizer and self.early_fraction > 0:
-                self._done_lo, self._early_lo = self.train_range[1], None
+                self._done, self._early_lo = {}, None
                 hook = self._early_norm
             eng.backward(loss_scale=1.0 / n, overwrite_matrices=(i == 0), bucket_done=hook)
             total = out.loss / n if total is None else total + out.loss / n
@@ -240,23 +240,24 @@ class DataParallelTrainer:
             self._bucket_sumsq(name)
 
     def _early_norm(self, name: str):
-        """Backward hook (N = 1).  Buckets complete from the end of the flat gradient buffer towards its start; once
-        the completed tail [done_lo, hi) covers `early_fraction` of the gradients its squared norm is started on the
-        side stream (fixed split, fixed order: deterministic) and only the head of the buffer is left for the pass
-        behind the backward."""
+        """Backward hook (N = 1).  Buckets complete roughly from the end of the flat gradient buffer towards its start;
+        once the completed tail [x, hi) covers `early_fraction` of the gradients its squared norm is started on the
+        side stream (the split depends only on the bucket layout: deterministic) and only the head of the buffer is
+        left for the pass behind the backward."""
         if self._early_lo is not None:
             return
         a, b = self.engine.store.buckets[name]
         lo, hi = self.train_range
-        if b != self._done_lo:  # not adjacent to the completed tail (e.g. the head bucket of another layout)
+        self._done[b] = a  # completed interval, keyed by its end
+        x = hi
+        while x in self._done:
+            x = self._done[x]
+        if hi - x < self.early_fraction * (hi - lo) or x <= lo:
             return
-        self._done_lo = a
-        if hi - a < self.early_fraction * (hi - lo) or a <= lo:
-            return
-        self._early_lo = a
+        self._early_lo = x
         self.opt_stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self.opt_stream):
-            ops.sumsq(self.engine.store.g32[a:hi], hi - a, self.gnorm_sq, self.partial_early)
+            ops.sumsq(self.engine.store.g32[x:hi], hi - x, self.gnorm_sq, self.partial_early)
 
     def finish(self):
         """Make the current stream wait for an optimiser step that is still running on the side stream."""
