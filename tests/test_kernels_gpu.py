@@ -28,7 +28,8 @@ def rnd(*shape, seed=0, scale=1.0):
 
 
 @pytest.mark.parametrize("al,bl", [(0, 0), (0, 1), (1, 0), (1, 1)])
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (499, 120, 504), (1000, 1920, 328), (46, 1024, 3992)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (499, 120, 504), (1000, 1920, 328), (46, 1024, 3992), (100, 72, 40),
+                                   (260, 264, 136)])
 def test_gemm_layouts(ops, al, bl, M, N, K):
     A, B = bf(rnd(M, K, seed=1, scale=0.5)), bf(rnd(N, K, seed=2, scale=0.5))
     ref = A.float() @ B.float().t()
