@@ -64,3 +64,35 @@ def test_training_reduces_loss_on_a_fixed_batch():
     assert np.isfinite(losses).all()
     assert losses[-1] < 0.6 * losses[1], losses
     assert tr.grad_norm() > 0
+
+
+def test_early_gradient_norm_pass_matches_the_single_pass():
+    """N = 1: the squared gradient norm taken in two pieces (tail of the flat buffer on the side stream during the
+    backward, head behind it) gives the same clip factor as one pass: same parameters after the steps up to fp32
+    summation order."""
+    from coral_amd.trainer import DataParallelTrainer
+    from coral_amd.wav2vec2 import Wav2Vec2CTCEngine, Wav2Vec2Shape
+    from oracle import wav2vec2_ref as ref
+
+    kw = dict(hidden_size=128, num_hidden_layers=4, num_attention_heads=4, intermediate_size=256)
+    g = torch.Generator().manual_seed(0)
+    waves = [(0.1 * torch.randn(n, generator=g)).numpy() for n in (8000, 6400, 7000, 8000)]
+    iv, am = ref.zero_mean_unit_var_norm(waves)
+    labels = torch.randint(0, 42, (4, 6), generator=g)
+    out = {}
+    for frac in (0.0, 0.5):
+        eng = Wav2Vec2CTCEngine(Wav2Vec2Shape(**kw), "cuda:0")
+        eng.load_state_dict(ref.synth_params(ref.W2V2Config(**kw)))
+        tr = DataParallelTrainer(eng, learning_rate=1e-3, warmup_steps=1, max_steps=100, max_grad_norm=0.05)
+        tr.early_fraction = frac
+        norms = []
+        for _ in range(3):
+            tr.train_step([dict(input_values=torch.from_numpy(iv), attention_mask=torch.from_numpy(am), labels=labels)])
+            norms.append(tr.grad_norm())
+        tr.finish()
+        torch.cuda.synchronize()
+        out[frac] = (norms, eng.store.p32.clone())
+    (n0, p0), (n1, p1) = out[0.0], out[0.5]
+    assert all(a > 0.05 for a in n0), n0  # the clip is active, so the norm matters
+    assert np.allclose(n0, n1, rtol=1e-5), (n0, n1)
+    assert torch.allclose(p0, p1, rtol=0, atol=2e-6)
