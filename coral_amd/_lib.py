@@ -63,6 +63,8 @@ class CaGemmDesc(C.Structure):
         ("a_colsum_ld", C.c_int64),
         ("c_row_index", C.c_void_p),
         ("c_row_mul", C.c_int64),
+        ("a_scale", C.c_void_p),
+        ("b_scale", C.c_void_p),
     ]
 
 
@@ -88,6 +90,8 @@ SIGNATURES = {
     "ca_device_count": (C.c_int, []),
     "ca_gemm_bf16_group": (C.c_int, [_vp, _i32, _vp]),
     "ca_gemm_bf16": (C.c_int, [C.POINTER(CaGemmDesc), _vp]),
+    "ca_gemm_fp8": (C.c_int, [C.POINTER(CaGemmDesc), _vp]),
+    "ca_quantize_fp8": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
     "ca_gemm_force_kernel": (C.c_int, [C.c_int]),
     "ca_prof_begin": (C.c_int, []),
     "ca_prof_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),

@@ -147,6 +147,19 @@ struct KMajorStream {  // operand stored [row][k], k contiguous; LDS image [rows
       off[i] = (uint32_t)(((int64_t)rr * ld + c * 8) * 2);
     }
   }
+  // one-byte elements (fp8): the same 128-B rows hold 128 k
+  __device__ __forceinline__ void init_bytes(const char* b, int64_t ld, int row0, int nrows, int wave, int lane) {
+    base = b + (int64_t)row0 * ld;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int r = (wave * NI + i) * 8 + (lane >> 3);
+      const int c = (lane & 7) ^ ((r >> 1) & 7);
+      int rr = row0 + r;
+      rr = (rr < nrows ? rr : nrows - 1) - row0;
+      kc[i] = c * 16;
+      off[i] = (uint32_t)((int64_t)rr * ld + c * 16);
+    }
+  }
   __device__ __forceinline__ void issue_one(char* tile, int wave, int i) {
     glds16_sbase(base, off[i], (uint32_t)(uintptr_t)(lptr_t)(tile + (wave * NI + i) * 1024));
   }
@@ -1349,6 +1362,141 @@ extern "C" int ca_gemm_bf16(const CaGemmDesc* desc, void* stream) {
               (desc->b_layout ? 1 : 0);
   g_prof.push_back(r);
   return rc;
+}
+
+// ---- fp8 (OCP e4m3) forward GEMM: C = epilogue(alpha * sa * sb * A B^T), A [M][K], B [N][K] one byte per element ----
+// BASELINE configs[4] ("fp8 weights, CDNA4 fp8 MFMA").  v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales
+// (the per-tensor scales sa, sb are device scalars folded into alpha): 4x the K of the bf16 MFMA at twice its cycles.
+// A 128-byte row of the LDS image now holds 128 k, so the tile images, the loaders and the XOR swizzle are the bf16
+// kernel's byte for byte; a lane's operand is the 32 consecutive bytes (two 16-B chunks) of its row and lane group,
+// for A and B alike - the dot product does not care which k a lane group owns as long as both sides agree.
+// Kernel S structure: 128 x 128 x 128 tile, 4 waves (64 x 64 each), 2 workgroups per CU.
+typedef __attribute__((ext_vector_type(8))) int fp8x32_t;
+typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+__global__ __launch_bounds__(256) void ca_gemm_fp8_kernel(const CaGemmDesc d) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  int tm, tn;
+  if (!tile_of_block<8, 8>(blockIdx.x, (d.M + BM - 1) / BM, (d.N + BN - 1) / BN, tm, tn)) return;
+  const int m0 = tm * BM, n0 = tn * BN;
+  KMajorStream<4> la, lb;
+  la.init_bytes((const char*)d.A, d.lda, m0, d.M, wave, lane);
+  lb.init_bytes((const char*)d.B, d.ldb, n0, d.N, wave, lane);
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const int K = d.K;
+  constexpr int FBK = 128;  // k per K-step
+  const int nk = (K + FBK - 1) / FBK;
+  auto burst = [&](int kt) {
+    if (kt >= nk) return;
+    char* na = smem + (kt & 1) * TILE_BYTES;
+    char* nb = na + 2 * TILE_BYTES;
+    const bool full = (kt + 1) * FBK <= K;
+    if (full) {
+#pragma unroll
+      for (int part = 0; part < 4; ++part) {
+        la.issue_one(na, wave, part);
+        lb.issue_one(nb, wave, part);
+      }
+    } else {
+#pragma unroll
+      for (int part = 0; part < 4; ++part) {
+        la.issue_one_tail(na, wave, K - kt * FBK, part);
+        lb.issue_one_tail(nb, wave, K - kt * FBK, part);
+      }
+    }
+    la.advance();
+    lb.advance();
+  };
+  auto zero_tail = [&](int kt) {
+    if (kt != nk - 1 || nk * FBK == K) return;
+    char* na = smem + (kt & 1) * TILE_BYTES;
+    la.zero_fix(na, wave, lane, K - kt * FBK);
+    lb.zero_fix(na + 2 * TILE_BYTES, wave, lane, K - kt * FBK);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
+  const int g = lane >> 4;
+  uint32_t abase[2], bbase[2];  // the two 16-B chunks of this lane's 32-byte operand
+  {
+    const int ra = wm * 64 + (lane & 15), rb = wn * 64 + (lane & 15);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      abase[h] = lds0 + ra * 128 + (((2 * g + h) ^ ((ra >> 1) & 7)) * 16);
+      bbase[h] = lds0 + 2 * TILE_BYTES + rb * 128 + (((2 * g + h) ^ ((rb >> 1) & 7)) * 16);
+    }
+  }
+  burst(0);
+  auto kstep = [&](auto st_c, int kt) {
+    constexpr int ST = decltype(st_c)::value;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // tile kt landed; my reads of kt-1 done
+    zero_tail(kt);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    burst(kt + 1);
+    bf16x8_t al[4], ah[4], bl[4], bh[4];
+#define F8_RD(dst, base, F) dst = lds_read_b128<ST * TILE_BYTES + (F) * 2048>(base)
+    F8_RD(al[0], abase[0], 0); F8_RD(ah[0], abase[1], 0); F8_RD(al[1], abase[0], 1); F8_RD(ah[1], abase[1], 1);
+    F8_RD(al[2], abase[0], 2); F8_RD(ah[2], abase[1], 2); F8_RD(al[3], abase[0], 3); F8_RD(ah[3], abase[1], 3);
+    F8_RD(bl[0], bbase[0], 0); F8_RD(bh[0], bbase[1], 0); F8_RD(bl[1], bbase[0], 1); F8_RD(bh[1], bbase[1], 1);
+    F8_RD(bl[2], bbase[0], 2); F8_RD(bh[2], bbase[1], 2); F8_RD(bl[3], bbase[0], 3); F8_RD(bh[3], bbase[1], 3);
+#undef F8_RD
+    lds_wait(al);
+    lds_wait(ah);
+    lds_wait(bl);
+    lds_wait(bh);
+    fp8x32_t af[4], bq[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const i32x4_t a0 = __builtin_bit_cast(i32x4_t, al[i]), a1 = __builtin_bit_cast(i32x4_t, ah[i]);
+      const i32x4_t b0 = __builtin_bit_cast(i32x4_t, bl[i]), b1 = __builtin_bit_cast(i32x4_t, bh[i]);
+      af[i] = (fp8x32_t){a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+      bq[i] = (fp8x32_t){b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(bq[j], af[i], acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0,
+                                                                     0x7f7f7f7f);
+  };
+  for (int kt = 0; kt < nk; kt += 2) {
+    kstep(std::integral_constant<int, 0>{}, kt);
+    if (kt + 1 < nk) kstep(std::integral_constant<int, 1>{}, kt + 1);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  CaGemmDesc dd = d;
+  dd.alpha = d.alpha * (d.a_scale ? *d.a_scale : 1.f) * (d.b_scale ? *d.b_scale : 1.f);
+  gemm_epilogue(dd, acc, smem, wave, lane, m0 + wm * 64, n0 + wn * 64, 0, 0, 0);
+}
+
+extern "C" int ca_gemm_fp8(const CaGemmDesc* desc, void* stream) {
+  CA_CHECK_ARG(desc != nullptr, "ca_gemm_fp8: null descriptor");
+  const CaGemmDesc& d = *desc;
+  CA_CHECK_ARG(d.A && d.B && (d.C || d.C2) && d.M > 0 && d.N > 0 && d.K > 0, "ca_gemm_fp8: bad argument");
+  CA_CHECK_ARG(d.a_layout == CA_KMAJOR && d.b_layout == CA_KMAJOR && d.batch1 == 1 && d.batch2 == 1 && d.a_kseg == 0 &&
+                   d.b_kseg == 0 && !d.a_colsum && !d.c_row_index,
+               "ca_gemm_fp8: K-major operands, un-batched, plain rows only");
+  CA_CHECK_ARG((d.K % 16) == 0 && (d.lda % 16) == 0 && (d.ldb % 16) == 0 && ((uintptr_t)d.A % 16) == 0 &&
+                   ((uintptr_t)d.B % 16) == 0,
+               "ca_gemm_fp8: K, lda, ldb must be multiples of 16 bytes and the operands 16-byte aligned");
+  static bool attr = false;
+  if (!attr) {
+    hipFuncSetAttribute((const void*)ca_gemm_fp8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    attr = true;
+  }
+  const int ntm = (d.M + BM - 1) / BM, ntn = (d.N + BN - 1) / BN;
+  hipLaunchKernelGGL(ca_gemm_fp8_kernel, dim3(tile_grid<8, 8>(ntm, ntn)), dim3(256), LDS_BYTES, (hipStream_t)stream, d);
+  CA_CHECK_LAUNCH("ca_gemm_fp8");
+  return CA_OK;
 }
 
 // Up to four independent GEMMs of the same operand form in one launch of kernel X (grouped launch): used where

@@ -1,0 +1,63 @@
+// Per-tensor fp8 (OCP e4m3) quantisation of bf16 tensors for ca_gemm_fp8 (BASELINE.json configs[4]: fp8 weights /
+// CDNA4 fp8 MFMA).  Two HBM-bound passes: amax (an order-independent max: deterministic with atomics), then
+// q = e4m3(x * 448 / amax) with v_cvt_pk_fp8_f32 (round to nearest even; the clamp makes the saturation explicit).
+#include "common.h"
+
+#define FP8_MAX 448.0f
+
+__global__ __launch_bounds__(256) void fp8_amax_kernel(const unsigned short* __restrict__ x, int64_t n8,
+                                                       unsigned int* __restrict__ amax_bits) {
+  float m = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+    const u16x8_t u = *(const u16x8_t*)(x + i * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf(bf2f(u[e])));
+  }
+  m = wave_max(m);
+  __shared__ float red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0)  // one atomic per workgroup; non-negative floats order like their bits
+    atomicMax(amax_bits, __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
+}
+
+__global__ __launch_bounds__(256) void fp8_cast_kernel(const unsigned short* __restrict__ x, int64_t n8,
+                                                       const float* __restrict__ amax, unsigned int* __restrict__ q,
+                                                       float* __restrict__ inv_scale) {
+  const float am = amax[0];
+  const float scale = am > 0.f ? FP8_MAX / am : 1.f;
+  if (blockIdx.x == 0 && threadIdx.x == 0) inv_scale[0] = am > 0.f ? am / FP8_MAX : 1.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+    const u16x8_t u = *(const u16x8_t*)(x + i * 8);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = fminf(fmaxf(bf2f(u[e]) * scale, -FP8_MAX), FP8_MAX);
+    unsigned int w0 = 0, w1 = 0;
+    w0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], w0, false);
+    w0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], w0, true);
+    w1 = __builtin_amdgcn_cvt_pk_fp8_f32(v[4], v[5], w1, false);
+    w1 = __builtin_amdgcn_cvt_pk_fp8_f32(v[6], v[7], w1, true);
+    q[i * 2] = w0;
+    q[i * 2 + 1] = w1;
+  }
+}
+
+extern "C" int ca_quantize_fp8(const void* x_bf16, int64_t n, void* q_fp8, float* inv_scale, float* amax_ws,
+                               void* stream) {
+  CA_CHECK_ARG(x_bf16 && q_fp8 && inv_scale && amax_ws && n > 0 && (n % 8) == 0,
+               "ca_quantize_fp8: null pointer or n not a multiple of 8");
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(amax_ws, 0, sizeof(float), s) != hipSuccess) {
+    ca_set_error("ca_quantize_fp8: memset failed");
+    return CA_ERR_LAUNCH;
+  }
+  const int64_t n8 = n / 8;
+  int64_t g = (n8 + 255) / 256;
+  if (g > 1024) g = 1024;
+  hipLaunchKernelGGL(fp8_amax_kernel, dim3((unsigned)g), dim3(256), 0, s, (const unsigned short*)x_bf16, n8,
+                     (unsigned int*)amax_ws);
+  hipLaunchKernelGGL(fp8_cast_kernel, dim3((unsigned)g), dim3(256), 0, s, (const unsigned short*)x_bf16, n8, amax_ws,
+                     (unsigned int*)q_fp8, inv_scale);
+  CA_CHECK_LAUNCH("ca_quantize_fp8");
+  return CA_OK;
+}

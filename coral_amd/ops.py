@@ -90,6 +90,20 @@ _SPLITK_WS: dict = {}
 FUSE_BIAS_GRAD = os.environ.get("CA_FUSE_BIAS", "1") == "1"
 
 
+def gemm_fp8(A8, B8, Cout, *, a_scale, b_scale, **kw):
+    """ca_gemm_fp8: A8 [M, K], B8 [N, K] uint8 tensors holding e4m3 bytes (ca_quantize_fp8), a_scale / b_scale the
+    device scalars it wrote; the other arguments as for gemm()."""
+    d = _gemm_desc(A8, B8, Cout, **kw)
+    d.a_scale, d.b_scale = _p(a_scale), _p(b_scale)
+    check(lib().ca_gemm_fp8(C.byref(d), _stream()), "ca_gemm_fp8")
+
+
+def quantize_fp8(x, q, inv_scale, amax_ws, n=None):
+    """bf16 tensor -> e4m3 bytes (uint8 tensor q) + inv_scale (1 float on the device)."""
+    check(lib().ca_quantize_fp8(_p(x), x.numel() if n is None else n, _p(q), _p(inv_scale), _p(amax_ws), _stream()),
+          "ca_quantize_fp8")
+
+
 COLSUM_PARTS = 8  # rows of the fused bias-gradient partials (CaGemmDesc.a_colsum)
 
 

@@ -105,9 +105,22 @@ typedef struct CaGemmDesc {
    * NULL = rows in place. */
   const int32_t* c_row_index;
   int64_t c_row_mul;
+  /* fp8 form only (ca_gemm_fp8): per-tensor dequantisation scales of A and B, device scalars (NULL = 1): the
+   * accumulator is multiplied by alpha * a_scale[0] * b_scale[0]. */
+  const float* a_scale;
+  const float* b_scale;
 } CaGemmDesc;
 
 int ca_gemm_bf16(const CaGemmDesc* desc, void* stream);
+/* The same descriptor with A [M][K] and B [N][K] holding OCP fp8 e4m3 bytes (both K-major, un-batched; lda, ldb, K in
+ * elements = bytes, multiples of 16): C = epilogue(alpha * a_scale * b_scale * A B^T) on the CDNA4 fp8 matrix
+ * instruction (BASELINE.json configs[4]: fp8 weights; replaces the bf16 `F.linear` of a forward projection whose
+ * input and weight went through ca_quantize_fp8).  Bias, epilogues, C / C2 / R as for ca_gemm_bf16. */
+int ca_gemm_fp8(const CaGemmDesc* desc, void* stream);
+/* Per-tensor fp8 quantisation of a bf16 tensor of n elements: amax -> scale = 448 / amax, q = e4m3(x * scale)
+ * (round to nearest even, saturating), inv_scale[0] = amax / 448 (the dequantisation factor ca_gemm_fp8 takes).
+ * amax_ws: one float of workspace.  n must be a multiple of 8. */
+int ca_quantize_fp8(const void* x_bf16, int64_t n, void* q_fp8, float* inv_scale, float* amax_ws, void* stream);
 /* Up to four independent plain GEMMs of the same operand form (same a_layout / b_layout, un-batched, no epilogue,
  * no bias) in one launch of the 256x256 kernel: for problems that under-fill the chip one by one, e.g. the four
  * weight gradients of a transformer layer (each replaces a `torch.mm(dY.T, X)` of autograd's Linear backward). */
