@@ -1475,6 +1475,16 @@ __global__ __launch_bounds__(256) void ca_gemm_fp8_kernel(const CaGemmDesc d) {
   asm volatile("" ::: "memory");
   CaGemmDesc dd = d;
   dd.alpha = d.alpha * (d.a_scale ? *d.a_scale : 1.f) * (d.b_scale ? *d.b_scale : 1.f);
+  if (d.a_row_scale) {  // one dequantisation factor per row of A (ca_layernorm_fwd_fp8): a lane's accumulators of
+                        // fragment row i all belong to output row m0 + wm*64 + 16 i + (lane & 15)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + wm * 64 + i * 16 + (lane & 15);
+      const float rs = d.a_row_scale[m < d.M ? m : d.M - 1];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] *= rs;
+    }
+  }
   gemm_epilogue(dd, acc, smem, wave, lane, m0 + wm * 64, n0 + wn * 64, 0, 0, 0);
 }
 

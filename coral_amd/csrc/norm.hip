@@ -108,6 +108,116 @@ extern "C" int ca_layernorm_fwd(const void* x, const float* gamma, const float* 
   return CA_OK;
 }
 
+// ---- forward with the output also quantised to fp8, one scale per row -------------------------------------------
+// The wave that normalises a row holds all of it, so the row's amax and the e4m3 cast cost no extra pass: q = e4m3(y *
+// 448 / amax_row) from the bf16-rounded y, row_scale[row] = amax_row / 448 for ca_gemm_fp8's a_row_scale
+// (the per-tensor quantiser needs two passes over the activation, which is what the fp8 GEMM saves).
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_fwd_fp8_kernel(const unsigned short* __restrict__ x,
+                                                         const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta,
+                                                         unsigned short* __restrict__ y, unsigned int* __restrict__ q,
+                                                         float* __restrict__ row_scale, int64_t rows, int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int nchunk = C >> 3;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+    const unsigned short* xr = x + row * C;
+    float v[NCH][8];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int ch = lane + c * 64;
+      if (ch < nchunk) {
+        const u16x8_t u = *(const u16x8_t*)(xr + ch * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          v[c][e] = bf2f(u[e]);
+          s += v[c][e];
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[c][e] = 0.f;
+      }
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int ch = lane + c * 64;
+      if (ch < nchunk) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float dlt = v[c][e] - mean;
+          s2 += dlt * dlt;
+        }
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(s2) / (float)C + eps);
+    float am = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int ch = lane + c * 64;
+      if (ch < nchunk) {
+        const f32x4_t g0 = *(const f32x4_t*)(gamma + ch * 8);
+        const f32x4_t g1 = *(const f32x4_t*)(gamma + ch * 8 + 4);
+        const f32x4_t b0 = *(const f32x4_t*)(beta + ch * 8);
+        const f32x4_t b1 = *(const f32x4_t*)(beta + ch * 8 + 4);
+        u16x8_t o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          o[e] = f2bf(ln_apply(v[c][e], mean, rstd, e < 4 ? g0[e] : g1[e - 4], e < 4 ? b0[e] : b1[e - 4]));
+          v[c][e] = bf2f(o[e]);  // the bf16 value the unquantised path would feed to the GEMM
+          am = fmaxf(am, fabsf(v[c][e]));
+        }
+        if (y) *(u16x8_t*)(y + row * C + ch * 8) = o;
+      }
+    }
+    am = wave_max(am);
+    const float scale = am > 0.f ? 448.0f / am : 1.f;
+    if (lane == 0) row_scale[row] = am > 0.f ? am / 448.0f : 1.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int ch = lane + c * 64;
+      if (ch < nchunk) {
+        float t[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t[e] = fminf(fmaxf(v[c][e] * scale, -448.0f), 448.0f);
+        unsigned int w0 = 0, w1 = 0;
+        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(t[0], t[1], w0, false);
+        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(t[2], t[3], w0, true);
+        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(t[4], t[5], w1, false);
+        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(t[6], t[7], w1, true);
+        q[(row * C + ch * 8) / 4] = w0;
+        q[(row * C + ch * 8) / 4 + 1] = w1;
+      }
+    }
+  }
+}
+
+extern "C" int ca_layernorm_fwd_fp8(const void* x, const float* gamma, const float* beta, void* y, void* q_fp8,
+                                    float* row_scale, int64_t rows, int32_t C, float eps, void* stream) {
+  CA_CHECK_ARG(x && gamma && beta && q_fp8 && row_scale, "ca_layernorm_fwd_fp8: null pointer");
+  CA_CHECK_ARG(rows > 0 && C > 0 && (C % 16) == 0 && C <= LN_MAXCH * 512,
+               "ca_layernorm_fwd_fp8: C=%d must be a multiple of 16 and <= %d", C, LN_MAXCH * 512);
+  const int nch = (C / 8 + 63) / 64;
+  dim3 grid(ln_grid(rows)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+#define LN_FP8(N)                                                                                 \
+  hipLaunchKernelGGL((ln_fwd_fp8_kernel<N>), grid, block, 0, s, (const unsigned short*)x, gamma, beta, \
+                     (unsigned short*)y, (unsigned int*)q_fp8, row_scale, rows, C, eps)
+  switch (nch) {
+    case 1: LN_FP8(1); break;
+    case 2: LN_FP8(2); break;
+    case 3: LN_FP8(3); break;
+    case 4: LN_FP8(4); break;
+    default: LN_FP8(8); break;
+  }
+#undef LN_FP8
+  CA_CHECK_LAUNCH("ca_layernorm_fwd_fp8");
+  return CA_OK;
+}
+
 // ---- backward ------------------------------------------------------------------------------
 // partial layout: [grid][2][C] (dgamma partials then dbeta partials per block).
 // Enough workgroups to keep ~16 MB of row loads in flight (one wave per row, 2 workgroups per CU at C = 1920

@@ -90,11 +90,11 @@ _SPLITK_WS: dict = {}
 FUSE_BIAS_GRAD = os.environ.get("CA_FUSE_BIAS", "1") == "1"
 
 
-def gemm_fp8(A8, B8, Cout, *, a_scale, b_scale, **kw):
-    """ca_gemm_fp8: A8 [M, K], B8 [N, K] uint8 tensors holding e4m3 bytes (ca_quantize_fp8), a_scale / b_scale the
-    device scalars it wrote; the other arguments as for gemm()."""
+def gemm_fp8(A8, B8, Cout, *, a_scale=None, b_scale=None, a_row_scale=None, **kw):
+    """ca_gemm_fp8: A8 [M, K], B8 [N, K] uint8 tensors holding e4m3 bytes, a_scale / b_scale the device scalars
+    ca_quantize_fp8 wrote, a_row_scale the [M] factors of layernorm_fwd_fp8; the other arguments as for gemm()."""
     d = _gemm_desc(A8, B8, Cout, **kw)
-    d.a_scale, d.b_scale = _p(a_scale), _p(b_scale)
+    d.a_scale, d.b_scale, d.a_row_scale = _p(a_scale), _p(b_scale), _p(a_row_scale)
     check(lib().ca_gemm_fp8(C.byref(d), _stream()), "ca_gemm_fp8")
 
 
@@ -219,6 +219,12 @@ def wgrad_gemm_group(problems: list, G, colsum_ws=None, colsum_ld=0) -> bool:
 def layernorm_fwd(x, gamma, beta, y, stats, rows, Cn, eps=1e-5, act=0, x_off=0, y_off=0):
     check(lib().ca_layernorm_fwd(_p(x, x_off), _p(gamma), _p(beta), _p(y, y_off), _p(stats), rows,
                                  Cn, eps, act, _stream()), "ca_layernorm_fwd")
+
+
+def layernorm_fwd_fp8(x, gamma, beta, y, q, row_scale, rows, Cn, eps=1e-5):
+    """LayerNorm whose output is (also) written as e4m3 bytes with one scale per row (y may be None)."""
+    check(lib().ca_layernorm_fwd_fp8(_p(x), _p(gamma), _p(beta), _p(y), _p(q), _p(row_scale), rows, Cn, eps, _stream()),
+          "ca_layernorm_fwd_fp8")
 
 
 def layernorm_bwd_partial_floats(rows, Cn):

@@ -243,6 +243,30 @@ class WhisperEngine:
         self._enc_ws[B] = w
         return w
 
+    # ---- fp8 encoder weights (BASELINE.json configs[4]) ------------------------------------------------
+    _fp8 = None
+
+    def enable_fp8_encoder(self, on: bool = True):
+        """Inference: keep the encoder's q|k|v and fc1 weights as OCP fp8 e4m3 (one scale per matrix) and run those
+        two projections of every layer on the fp8 matrix instruction; their inputs are the LayerNorm outputs, which
+        ca_layernorm_fwd_fp8 quantises per row in the pass that produces them.  (out_proj and fc2 stay bf16: their
+        inputs come out of the attention kernel / the GELU epilogue, where a row is spread over many workgroups.)
+        Call again after the weights change."""
+        if not on:
+            self._fp8 = None
+            return
+        s, st, dev = self.s, self.store, self.device
+        d, f = s.d_model, s.encoder_ffn_dim
+        p8 = torch.zeros(st.numel, dtype=torch.uint8, device=dev)
+        scales = torch.zeros(2 * s.encoder_layers, dtype=torch.float32, device=dev)
+        ws = torch.zeros(1, dtype=torch.float32, device=dev)
+        for l in range(s.encoder_layers):
+            p = f"model.encoder.layers.{l}."
+            for k, (name, n) in enumerate(((p + "self_attn.q_proj.weight", 3 * d * d), (p + "fc1.weight", f * d))):
+                off = st.off(name)
+                ops.quantize_fp8(st.p16[off:off + n], p8[off:off + n], scales[2 * l + k:2 * l + k + 1], ws, n=n)
+        self._fp8 = dict(p8=p8, scales=scales)
+
     def encode(self, input_features: torch.Tensor) -> torch.Tensor:
         """input_features f32 [B, mels, 3000] -> encoder states bf16 [B, 1500, d]."""
         self._await_all()
@@ -274,14 +298,34 @@ class WhisperEngine:
         for l in range(s.encoder_layers):
             p = f"model.encoder.layers.{l}."
             hin, hmid = w["h"][cur], w["h"][1 - cur]
-            ops.layernorm_fwd(hin, st.view(p + "self_attn_layer_norm.weight"), st.view(p + "self_attn_layer_norm.bias"),
-                              w["x"], None, M, d, s.layer_norm_eps)
-            ops.gemm(w["x"], p16, w["qkv"], M=M, N=3 * d, K=d, lda=d, ldb=d, ldc=3 * d,
-                     b_off=o(p + "self_attn.q_proj.weight"), bias=p32, bias_off=o(p + "self_attn.q_proj.bias"))
+            fp8 = self._fp8
+            if fp8 is not None:
+                if "x8" not in w:
+                    w["x8"] = torch.zeros(M * d, dtype=torch.uint8, device=self.device)
+                    w["rs"] = torch.zeros(M, dtype=torch.float32, device=self.device)
+                ops.layernorm_fwd_fp8(hin, st.view(p + "self_attn_layer_norm.weight"), st.view(p + "self_attn_layer_norm.bias"),
+                                      None, w["x8"], w["rs"], M, d, s.layer_norm_eps)
+                ops.gemm_fp8(w["x8"], fp8["p8"], w["qkv"], a_row_scale=w["rs"], b_scale=fp8["scales"][2 * l:2 * l + 1],
+                             M=M, N=3 * d, K=d, lda=d, ldb=d, ldc=3 * d, b_off=o(p + "self_attn.q_proj.weight"),
+                             bias=p32, bias_off=o(p + "self_attn.q_proj.bias"))
+            else:
+                ops.layernorm_fwd(hin, st.view(p + "self_attn_layer_norm.weight"), st.view(p + "self_attn_layer_norm.bias"),
+                                  w["x"], None, M, d, s.layer_norm_eps)
+                ops.gemm(w["x"], p16, w["qkv"], M=M, N=3 * d, K=d, lda=d, ldb=d, ldc=3 * d,
+                         b_off=o(p + "self_attn.q_proj.weight"), bias=p32, bias_off=o(p + "self_attn.q_proj.bias"))
             self._self_attention(w["qkv"], w["ctx"], B, T, H, hd, d, causal=False)
             ops.gemm(w["ctx"], p16, hmid, M=M, N=d, K=d, lda=d, ldb=d, ldc=d, b_off=o(p + "self_attn.out_proj.weight"),
                      bias=p32, bias_off=o(p + "self_attn.out_proj.bias"), epilogue=EPI_RESIDUAL, R=hin, ldr=d)
-            self._ffn(w, hmid, hin, p, M, d, f)  # result back in `hin`
+            if fp8 is not None:
+                ops.layernorm_fwd_fp8(hmid, st.view(p + "final_layer_norm.weight"), st.view(p + "final_layer_norm.bias"),
+                                      None, w["x8"], w["rs"], M, d, s.layer_norm_eps)
+                ops.gemm_fp8(w["x8"], fp8["p8"], None, C2=w["g"], a_row_scale=w["rs"],
+                             b_scale=fp8["scales"][2 * l + 1:2 * l + 2], M=M, N=f, K=d, lda=d, ldb=d, ldc=f,
+                             b_off=o(p + "fc1.weight"), bias=p32, bias_off=o(p + "fc1.bias"), epilogue=EPI_GELU)
+                ops.gemm(w["g"], p16, hin, M=M, N=d, K=f, lda=f, ldb=f, ldc=d, b_off=o(p + "fc2.weight"), bias=p32,
+                         bias_off=o(p + "fc2.bias"), epilogue=EPI_RESIDUAL, R=hmid, ldr=d)
+            else:
+                self._ffn(w, hmid, hin, p, M, d, f)  # result back in `hin`
         ops.layernorm_fwd(w["h"][cur], st.view("model.encoder.layer_norm.weight"), st.view("model.encoder.layer_norm.bias"),
                           w["out"], None, M, d, s.layer_norm_eps)
         return w["out"].view(B, T, d)

@@ -109,6 +109,7 @@ typedef struct CaGemmDesc {
    * accumulator is multiplied by alpha * a_scale[0] * b_scale[0]. */
   const float* a_scale;
   const float* b_scale;
+  const float* a_row_scale; /* fp8 form only: [M] per-row factors of A (ca_layernorm_fwd_fp8), NULL = none */
 } CaGemmDesc;
 
 int ca_gemm_bf16(const CaGemmDesc* desc, void* stream);
@@ -147,6 +148,11 @@ int ca_prof_end(double* ms, int64_t* count, double* flops);
 int ca_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y,
                      float* stats, int64_t rows, int32_t C, float eps, int32_t act,
                      void* stream);
+/* The same LayerNorm with the output also quantised to OCP fp8 e4m3, one scale per row (taken by the wave that holds
+ * the row, no extra pass): q[row] = e4m3(y[row] * 448 / amax(y[row])), row_scale[row] = amax / 448 for
+ * CaGemmDesc.a_row_scale.  y (bf16) may be NULL.  C must be a multiple of 16. */
+int ca_layernorm_fwd_fp8(const void* x, const float* gamma, const float* beta, void* y, void* q_fp8,
+                         float* row_scale, int64_t rows, int32_t C, float eps, void* stream);
 /* dx bf16 [rows,C] (+ dres if non-NULL: the residual-stream gradient that bypasses the LN);
  * dgamma/dbeta fp32 [C] are ACCUMULATED into (+=) through the fp32 partial buffer `partial`
  * of ca_layernorm_bwd_partial_floats(rows, C) floats. */

@@ -91,3 +91,78 @@ def test_gemm_fp8_gelu_epilogue_and_fp32_output(ops):
     assert (u.float().cpu() - (pre + bias)).abs().max().item() <= 1e-2 * max(1.0, pre.abs().max().item())
     want = torch.nn.functional.gelu(pre + bias)
     assert (gl.float().cpu() - want).abs().max().item() <= 1e-2 * max(1.0, want.abs().max().item())
+
+
+@pytest.mark.parametrize("M,C", [(300, 1024), (77, 1280), (64, 64)])
+def test_layernorm_fwd_fp8_rows(ops, M, C):
+    """ca_layernorm_fwd_fp8: the bf16 output is ca_layernorm_fwd's, the bytes are e4m3(y * 448 / amax_row) and the
+    row scales amax_row / 448 - bit-exact from the kernel's own y."""
+    x = (rnd(M, C, seed=11, scale=2.0) + 0.5).to(torch.bfloat16).to(DEV)
+    gamma = (1.0 + 0.2 * rnd(C, seed=12)).to(DEV)
+    beta = (0.3 * rnd(C, seed=13)).to(DEV)
+    y0 = torch.zeros(M, C, dtype=torch.bfloat16, device=DEV)
+    ops.layernorm_fwd(x, gamma, beta, y0, None, M, C, 1e-5)
+    y = torch.zeros_like(y0)
+    q = torch.zeros(M, C, dtype=torch.uint8, device=DEV)
+    rs = torch.zeros(M, dtype=torch.float32, device=DEV)
+    ops.layernorm_fwd_fp8(x, gamma, beta, y, q, rs, M, C, 1e-5)
+    torch.cuda.synchronize()
+    assert torch.equal(y, y0)
+    yf = y.float().cpu()
+    am = yf.abs().amax(dim=1, keepdim=True)
+    qr = (yf * (torch.tensor(448.0) / am)).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).view(torch.uint8)
+    assert torch.equal(q.cpu(), qr)
+    assert torch.allclose(rs.cpu(), (am / 448.0).squeeze(1), rtol=1e-7, atol=0)
+
+
+def test_gemm_fp8_with_row_scales(ops):
+    M, N, K = 333, 392, 1024
+    x = (rnd(M, K, seed=14) * torch.linspace(0.1, 30.0, M)[:, None]).to(torch.bfloat16)  # rows of very different size
+    w = rnd(N, K, seed=15, scale=0.05).to(torch.bfloat16)
+    g, b = torch.ones(K, device=DEV), torch.zeros(K, device=DEV)
+    y = torch.zeros(M, K, dtype=torch.bfloat16, device=DEV)
+    q = torch.zeros(M, K, dtype=torch.uint8, device=DEV)
+    rs = torch.zeros(M, dtype=torch.float32, device=DEV)
+    ops.layernorm_fwd_fp8(x.to(DEV), g, b, y, q, rs, M, K, 1e-5)
+    wq, sw = quantize_dev(ops, w.to(DEV))
+    out = torch.zeros(M, N, dtype=torch.float32, device=DEV)
+    ops.gemm_fp8(q, wq, out, a_row_scale=rs, b_scale=sw, M=M, N=N, K=K, lda=K, ldb=K, ldc=N)
+    torch.cuda.synchronize()
+    deq = q.cpu().view(torch.float8_e4m3fn).float() * rs.cpu()[:, None]
+    wr, swr = quantize_ref(w)
+    ref = (deq @ wr.float().t()) * swr
+    assert (out.cpu() - ref).abs().max().item() <= 2e-4 * max(1.0, ref.abs().max().item())
+    full = y.float().cpu() @ w.float().t()
+    assert ((out.cpu() - full).norm() / full.norm()).item() < 0.05
+
+
+def test_whisper_encoder_with_fp8_weights_tracks_the_bf16_encoder():
+    """enable_fp8_encoder(): q|k|v and fc1 of every encoder layer on the fp8 path.  With random weights a dot product
+    carries the operands' e4m3 rounding noise (3 mantissa bits, about 3 % RMS each) at full strength, so the states
+    differ from the bf16 encoder's by a few per cent (7 % over the 24 layers of whisper-medium); greedy decoding
+    still runs and switching the option off restores the bf16 result exactly."""
+    from coral_amd.whisper import CORAL_WHISPER_SHAPES, WhisperEngine, WhisperShape
+
+    kw = dict(CORAL_WHISPER_SHAPES["whisper-medium"])
+    kw.update(encoder_layers=3, decoder_layers=2)
+    eng = WhisperEngine(WhisperShape(**kw), DEV)
+    g = torch.Generator(device=DEV).manual_seed(1)
+    for n in eng.exported_names():
+        v = eng.store.view(n)
+        if n.endswith("layer_norm.weight"):
+            v.fill_(1.0)
+        elif n.endswith(".bias"):
+            v.zero_()
+        else:
+            v.normal_(0.0, 0.02, generator=g)
+    eng.refresh_compute_weights()
+    feats = torch.randn(2, 80, 3000) * 0.3
+    ref = eng.encode(feats).float().clone()
+    eng.enable_fp8_encoder()
+    out = eng.encode(feats).float()
+    rel = ((out - ref).norm() / ref.norm()).item()
+    assert 0.0 < rel < 0.10, rel  # (> 0: the fp8 path really ran)
+    ids = eng.generate(feats, [50258, 50285, 50359, 50363], 8)
+    assert ids[0][:4] == [50258, 50285, 50359, 50363]
+    eng.enable_fp8_encoder(False)
+    assert torch.equal(eng.encode(feats).float(), ref)
