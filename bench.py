@@ -167,6 +167,8 @@ def whisper_bench(args, world, rank, device):
 
     if args.decode and args.fp8_encoder:
         eng.enable_fp8_encoder()
+    if args.fp8_forward and not args.decode:
+        eng.enable_fp8_forward()
 
     def step():
         feats = eng.log_mel(waves)  # front end on the GPU, inside the step
@@ -194,7 +196,7 @@ def whisper_bench(args, world, rank, device):
             "metric": f"audio-seconds/sec ({mode}), {args.model}, 30 s clips", "value": round(audio_s / dt, 2),
             "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16 + fp8 e4m3 (encoder q|k|v, fc1)" if (args.decode and args.fp8_encoder) else "bf16",
+            "vs_baseline": None, "dtype": "bf16 + fp8 e4m3 (encoder q|k|v, fc1 forward)" if ((args.decode and args.fp8_encoder) or (args.fp8_forward and not args.decode)) else "bf16",
             "data": "synthetic",
             "config": {"workload": f"{args.model} {mode}, {B} x 30 s per GPU, log-mel on GPU", "global_batch": world * B,
                        "label_len": int(labels.shape[1]), "parallelism": f"dp{world}"}}), flush=True)
@@ -229,6 +231,8 @@ def main():
     ap.add_argument("--gemm-breakdown", action="store_true", help="print the per-kernel GEMM timing table to stderr")
     ap.add_argument("--decode", action="store_true", help="whisper models: time greedy decoding instead of training")
     ap.add_argument("--decode-tokens", type=int, default=32)
+    ap.add_argument("--fp8-forward", action="store_true",
+                    help="whisper finetune step: encoder q|k|v and fc1 forward projections in fp8 (DESIGN.md 4.4)")
     ap.add_argument("--fp8-encoder", action="store_true",
                     help="whisper --decode: encoder q|k|v and fc1 projections with fp8 weights (DESIGN.md 4.4)")
     ap.add_argument("--grad-wire", default="bf16", choices=["bf16", "fp32"],

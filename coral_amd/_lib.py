@@ -99,7 +99,7 @@ SIGNATURES = {
     "ca_attn_fwd": (C.c_int, [C.POINTER(CaAttnDesc), _vp]),
     "ca_attn_bwd": (C.c_int, [C.POINTER(CaAttnDesc), _vp]),
     "ca_layernorm_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _i32, _vp]),
-    "ca_layernorm_fwd_fp8": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp]),
+    "ca_layernorm_fwd_fp8": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp]),
     "ca_layernorm_bwd_partial_floats": (_i64, [_i64, _i32]),
     "ca_layernorm_bwd": (
         C.c_int,

@@ -56,9 +56,17 @@ class SelfAttnBlock:
     def forward(self, hin, hout, sv, B, T, klen=None):
         st, d = self.st, self.d
         M = B * T
-        ops.layernorm_fwd(hin, st.view(self.ln + ".weight"), st.view(self.ln + ".bias"), sv["x"], sv["st"], M, d, self.eps)
-        ops.gemm(sv["x"], st.p16, sv["qkv"], M=M, N=3 * d, K=d, lda=d, ldb=d, ldc=3 * d, b_off=st.off(self.attn + "q_proj.weight"),
-                 bias=st.p32, bias_off=st.off(self.qbias))
+        fp8 = getattr(self, "fp8", None)  # (p8, scale, x8, rs): forward projection on the fp8 path
+        if fp8 is not None:
+            p8, scale, x8, rs = fp8
+            ops.layernorm_fwd_fp8(hin, st.view(self.ln + ".weight"), st.view(self.ln + ".bias"), sv["x"], x8, rs, M, d, self.eps,
+                                  stats=sv["st"])
+            ops.gemm_fp8(x8, p8, sv["qkv"], a_row_scale=rs, b_scale=scale, M=M, N=3 * d, K=d, lda=d, ldb=d, ldc=3 * d,
+                         b_off=st.off(self.attn + "q_proj.weight"), bias=st.p32, bias_off=st.off(self.qbias))
+        else:
+            ops.layernorm_fwd(hin, st.view(self.ln + ".weight"), st.view(self.ln + ".bias"), sv["x"], sv["st"], M, d, self.eps)
+            ops.gemm(sv["x"], st.p16, sv["qkv"], M=M, N=3 * d, K=d, lda=d, ldb=d, ldc=3 * d,
+                     b_off=st.off(self.attn + "q_proj.weight"), bias=st.p32, bias_off=st.off(self.qbias))
         ops.attn_fwd(sv["qkv"], sv["qkv"], sv["qkv"], sv["ctx"], sv["lse"], **self._akw(B, T, sv, klen))
         ops.gemm(sv["ctx"], st.p16, hout, M=M, N=d, K=d, lda=d, ldb=d, ldc=d, b_off=st.off(self.attn + "out_proj.weight"),
                  bias=st.p32, bias_off=st.off(self.attn + "out_proj.bias"), epilogue=EPI_RESIDUAL, R=hin, ldr=d)
@@ -170,9 +178,19 @@ class FFNBlock:
 
     def forward(self, hin, hout, sv, M, dropout_p=0.0, seed=0):
         st, d, f = self.st, self.d, self.f
-        ops.layernorm_fwd(hin, st.view(self.ln + ".weight"), st.view(self.ln + ".bias"), sv["x"], sv["st"], M, d, self.eps)
-        ops.gemm(sv["x"], st.p16, sv["u"], C2=sv["g"], M=M, N=f, K=d, lda=d, ldb=d, ldc=f, b_off=st.off(self.fc1 + ".weight"),
-                 bias=st.p32, bias_off=st.off(self.fc1 + ".bias"), epilogue=EPI_GELU, dropout_p=dropout_p, dropout_seed=seed)
+        fp8 = getattr(self, "fp8", None)
+        if fp8 is not None:
+            p8, scale, x8, rs = fp8
+            ops.layernorm_fwd_fp8(hin, st.view(self.ln + ".weight"), st.view(self.ln + ".bias"), sv["x"], x8, rs, M, d, self.eps,
+                                  stats=sv["st"])
+            ops.gemm_fp8(x8, p8, sv["u"], C2=sv["g"], a_row_scale=rs, b_scale=scale, M=M, N=f, K=d, lda=d, ldb=d, ldc=f,
+                         b_off=st.off(self.fc1 + ".weight"), bias=st.p32, bias_off=st.off(self.fc1 + ".bias"),
+                         epilogue=EPI_GELU, dropout_p=dropout_p, dropout_seed=seed)
+        else:
+            ops.layernorm_fwd(hin, st.view(self.ln + ".weight"), st.view(self.ln + ".bias"), sv["x"], sv["st"], M, d, self.eps)
+            ops.gemm(sv["x"], st.p16, sv["u"], C2=sv["g"], M=M, N=f, K=d, lda=d, ldb=d, ldc=f, b_off=st.off(self.fc1 + ".weight"),
+                     bias=st.p32, bias_off=st.off(self.fc1 + ".bias"), epilogue=EPI_GELU, dropout_p=dropout_p,
+                     dropout_seed=seed)
         ops.gemm(sv["g"], st.p16, hout, M=M, N=d, K=f, lda=f, ldb=f, ldc=d, b_off=st.off(self.fc2 + ".weight"), bias=st.p32,
                  bias_off=st.off(self.fc2 + ".bias"), epilogue=EPI_RESIDUAL, R=hin, ldr=d)
         sv["hin"], sv["drop"] = hin, (dropout_p, seed)

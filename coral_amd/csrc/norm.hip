@@ -117,7 +117,8 @@ __global__ __launch_bounds__(256) void ln_fwd_fp8_kernel(const unsigned short* _
                                                          const float* __restrict__ gamma,
                                                          const float* __restrict__ beta,
                                                          unsigned short* __restrict__ y, unsigned int* __restrict__ q,
-                                                         float* __restrict__ row_scale, int64_t rows, int C, float eps) {
+                                                         float* __restrict__ row_scale, float* __restrict__ stats,
+                                                         int64_t rows, int C, float eps) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int nchunk = C >> 3;
@@ -154,6 +155,10 @@ __global__ __launch_bounds__(256) void ln_fwd_fp8_kernel(const unsigned short* _
       }
     }
     const float rstd = rsqrtf(wave_sum(s2) / (float)C + eps);
+    if (lane == 0 && stats) {
+      stats[row * 2] = mean;
+      stats[row * 2 + 1] = rstd;
+    }
     float am = 0.f;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
@@ -196,7 +201,7 @@ __global__ __launch_bounds__(256) void ln_fwd_fp8_kernel(const unsigned short* _
 }
 
 extern "C" int ca_layernorm_fwd_fp8(const void* x, const float* gamma, const float* beta, void* y, void* q_fp8,
-                                    float* row_scale, int64_t rows, int32_t C, float eps, void* stream) {
+                                    float* row_scale, float* stats, int64_t rows, int32_t C, float eps, void* stream) {
   CA_CHECK_ARG(x && gamma && beta && q_fp8 && row_scale, "ca_layernorm_fwd_fp8: null pointer");
   CA_CHECK_ARG(rows > 0 && C > 0 && (C % 16) == 0 && C <= LN_MAXCH * 512,
                "ca_layernorm_fwd_fp8: C=%d must be a multiple of 16 and <= %d", C, LN_MAXCH * 512);
@@ -205,7 +210,7 @@ extern "C" int ca_layernorm_fwd_fp8(const void* x, const float* gamma, const flo
   hipStream_t s = (hipStream_t)stream;
 #define LN_FP8(N)                                                                                 \
   hipLaunchKernelGGL((ln_fwd_fp8_kernel<N>), grid, block, 0, s, (const unsigned short*)x, gamma, beta, \
-                     (unsigned short*)y, (unsigned int*)q_fp8, row_scale, rows, C, eps)
+                     (unsigned short*)y, (unsigned int*)q_fp8, row_scale, stats, rows, C, eps)
   switch (nch) {
     case 1: LN_FP8(1); break;
     case 2: LN_FP8(2); break;

@@ -221,10 +221,10 @@ def layernorm_fwd(x, gamma, beta, y, stats, rows, Cn, eps=1e-5, act=0, x_off=0, 
                                  Cn, eps, act, _stream()), "ca_layernorm_fwd")
 
 
-def layernorm_fwd_fp8(x, gamma, beta, y, q, row_scale, rows, Cn, eps=1e-5):
-    """LayerNorm whose output is (also) written as e4m3 bytes with one scale per row (y may be None)."""
-    check(lib().ca_layernorm_fwd_fp8(_p(x), _p(gamma), _p(beta), _p(y), _p(q), _p(row_scale), rows, Cn, eps, _stream()),
-          "ca_layernorm_fwd_fp8")
+def layernorm_fwd_fp8(x, gamma, beta, y, q, row_scale, rows, Cn, eps=1e-5, stats=None):
+    """LayerNorm whose output is (also) written as e4m3 bytes with one scale per row (y, stats may be None)."""
+    check(lib().ca_layernorm_fwd_fp8(_p(x), _p(gamma), _p(beta), _p(y), _p(q), _p(row_scale), _p(stats), rows, Cn, eps,
+                                     _stream()), "ca_layernorm_fwd_fp8")
 
 
 def layernorm_bwd_partial_floats(rows, Cn):

@@ -288,10 +288,14 @@ class DataParallelTrainer:
                            self.betas[0], self.betas[1], self.eps, self.wd, self.opt_step,
                            grad_scale=1.0 / self.world, max_norm=self.max_grad_norm, gnorm_sq=self.gnorm_sq)
 
+        rebucket = getattr(eng, "refresh_bucket", None)  # engines with derived per-bucket weight copies (fp8)
         if not self.overlap_optimizer:
             update(lo, hi)
             if not eng.freeze_base:
                 eng.refresh_derived()
+            if rebucket is not None:
+                for name in st.buckets:
+                    rebucket(name)
             return
         # buckets in the order the next forward consumes them; one event per bucket
         self.opt_stream.wait_stream(torch.cuda.current_stream())
@@ -300,6 +304,8 @@ class DataParallelTrainer:
             order = sorted(st.buckets.items(), key=lambda kv: kv[1][0])
             for name, (a, b) in order:
                 update(a, b)
+                if rebucket is not None:
+                    rebucket(name)
                 parts = getattr(eng, "derived_parts", None) if name == "front" else None
                 if name == "front" and not parts:
                     eng.refresh_derived()

@@ -55,6 +55,43 @@ class WhisperTrainEngine(WhisperEngine):
         self._tw_key = None
         self.zero_mel = torch.zeros(s.num_mel_bins, dtype=torch.bfloat16, device=self.device)
 
+    # ---- fp8 forward projections (BASELINE.json configs[4]) ------------------------------------------
+    _fp8_train = None
+
+    def enable_fp8_forward(self, on: bool = True):
+        """Training: the encoder's q|k|v and fc1 forward projections on the fp8 matrix instruction - e4m3 copies of
+        those weights (one scale per matrix, re-quantised after every optimiser step: refresh_bucket) and LayerNorm
+        outputs quantised per row by the LayerNorm kernel itself.  The backward is unchanged (bf16 weights and saved
+        bf16 activations, i.e. straight-through gradients)."""
+        if not on:
+            self._fp8_train = None
+            for sa, ff in self.enc_blocks:
+                sa.fp8 = ff.fp8 = None
+            return
+        st, dev = self.store, self.device
+        self._fp8_train = dict(p8=torch.zeros(st.numel, dtype=torch.uint8, device=dev),
+                               scales=torch.zeros(2 * self.s.encoder_layers, dtype=torch.float32, device=dev),
+                               ws=torch.zeros(1, dtype=torch.float32, device=dev), x8=None, rs=None)
+        self._tw_key = None  # the workspace hands the blocks their staging buffers
+        self.refresh_fp8()
+
+    def refresh_fp8(self, layer: int | None = None):
+        f8 = self._fp8_train
+        if f8 is None:
+            return
+        s, st = self.s, self.store
+        d, f = s.d_model, s.encoder_ffn_dim
+        for l in (range(s.encoder_layers) if layer is None else (layer,)):
+            p = f"model.encoder.layers.{l}."
+            for k, (name, n) in enumerate(((p + "self_attn.q_proj.weight", 3 * d * d), (p + "fc1.weight", f * d))):
+                off = st.off(name)
+                ops.quantize_fp8(st.p16[off:off + n], f8["p8"][off:off + n], f8["scales"][2 * l + k:2 * l + k + 1], f8["ws"], n=n)
+
+    def refresh_bucket(self, name: str):
+        """Trainer hook: bucket `name` has just been updated (on the trainer's optimiser stream)."""
+        if self._fp8_train is not None and name.startswith("enc") and name[3:].isdigit():
+            self.refresh_fp8(int(name[3:]))
+
     def trainable_range(self):
         """`freeze_feature_encoder` (R/src/coral/whisper.py:88-92) leaves only `proj_out` trainable, and
         proj_out is tied to the token embedding: the one matrix keeps both of its gradients."""
@@ -120,6 +157,14 @@ class WhisperTrainEngine(WhisperEngine):
             bias_ws=_z(ops.COLSUM_PARTS * (5 * d + s.encoder_ffn_dim), dev, f32), denc32=_z(Me * d, dev, f32), dpre=_z(B * (Tin + 2) * d + 64, dev),
             dcol=_z(Me * 3 * d, dev), dwr_part=_z(B * d * 3 * max(d, s.num_mel_bins), dev, f32),
             dwr=_z(d * 3 * max(d, s.num_mel_bins), dev, f32))
+        f8 = self._fp8_train
+        if f8 is not None:
+            Me = B * s.max_source_positions
+            f8["x8"] = torch.zeros(Me * s.d_model, dtype=torch.uint8, device=dev)
+            f8["rs"] = torch.zeros(Me, dtype=torch.float32, device=dev)
+            for l, (sa, ff) in enumerate(self.enc_blocks):
+                sa.fp8 = (f8["p8"], f8["scales"][2 * l:2 * l + 1], f8["x8"], f8["rs"])
+                ff.fp8 = (f8["p8"], f8["scales"][2 * l + 1:2 * l + 2], f8["x8"], f8["rs"])
         self._tw, self._tw_key = w, key
         return w
 

@@ -150,9 +150,10 @@ int ca_layernorm_fwd(const void* x, const float* gamma, const float* beta, void*
                      void* stream);
 /* The same LayerNorm with the output also quantised to OCP fp8 e4m3, one scale per row (taken by the wave that holds
  * the row, no extra pass): q[row] = e4m3(y[row] * 448 / amax(y[row])), row_scale[row] = amax / 448 for
- * CaGemmDesc.a_row_scale.  y (bf16) may be NULL.  C must be a multiple of 16. */
+ * CaGemmDesc.a_row_scale.  y (bf16) and stats ([rows][2] mean, rstd for ca_layernorm_bwd) may be NULL.  C must be a
+ * multiple of 16. */
 int ca_layernorm_fwd_fp8(const void* x, const float* gamma, const float* beta, void* y, void* q_fp8,
-                         float* row_scale, int64_t rows, int32_t C, float eps, void* stream);
+                         float* row_scale, float* stats, int64_t rows, int32_t C, float eps, void* stream);
 /* dx bf16 [rows,C] (+ dres if non-NULL: the residual-stream gradient that bypasses the LN);
  * dgamma/dbeta fp32 [C] are ACCUMULATED into (+=) through the fp32 partial buffer `partial`
  * of ca_layernorm_bwd_partial_floats(rows, C) floats. */

@@ -166,3 +166,47 @@ def test_whisper_encoder_with_fp8_weights_tracks_the_bf16_encoder():
     assert ids[0][:4] == [50258, 50285, 50359, 50363]
     eng.enable_fp8_encoder(False)
     assert torch.equal(eng.encode(feats).float(), ref)
+
+
+def test_whisper_training_with_fp8_forward_projections():
+    """enable_fp8_forward(): loss and gradients stay close to the bf16 step's (the backward is the bf16 one), the e4m3
+    weight copies follow the optimiser (refresh_bucket) and the loss on a fixed batch still goes down."""
+    import numpy as np
+
+    from coral_amd.trainer import DataParallelTrainer
+    from coral_amd.whisper import WhisperShape
+    from coral_amd.whisper_train import WhisperTrainEngine
+    from oracle import whisper_ref as w
+
+    kw = dict(d_model=64, encoder_layers=2, decoder_layers=2, encoder_attention_heads=4, decoder_attention_heads=4,
+              encoder_ffn_dim=128, decoder_ffn_dim=128, num_mel_bins=80, vocab_size=200, max_target_positions=64,
+              pad_token_id=150, decoder_start_token_id=151, eos_token_id=150)
+    c = w.WhisperConfig(**kw)
+    g = torch.Generator().manual_seed(5)
+    batch = dict(input_features=torch.randn(2, 80, 3000, generator=g) * 0.5, labels=torch.randint(0, 150, (2, 10), generator=g))
+    res = {}
+    for mode in ("bf16", "fp8"):
+        eng = WhisperTrainEngine(WhisperShape(**kw), DEV)
+        eng.load_state_dict(w.synth_params(c))
+        if mode == "fp8":
+            eng.enable_fp8_forward()
+        eng.zero_grad()
+        out = eng(**batch)
+        eng.backward()
+        torch.cuda.synchronize()
+        res[mode] = (float(out.loss), eng.store.g32.clone())
+    (l0, g0), (l1, g1) = res["bf16"], res["fp8"]
+    assert abs(l1 - l0) <= 0.02 * abs(l0), (l0, l1)
+    cos = torch.nn.functional.cosine_similarity(g0.flatten(), g1.flatten(), dim=0).item()
+    assert cos > 0.98, cos
+    assert not torch.equal(g0, g1)  # the fp8 path really ran
+    eng = WhisperTrainEngine(WhisperShape(**kw), DEV)
+    eng.load_state_dict(w.synth_params(c))
+    eng.enable_fp8_forward()
+    tr = DataParallelTrainer(eng, learning_rate=3e-3, warmup_steps=2, max_steps=30)
+    p8_before = eng._fp8_train["p8"].clone()
+    losses = [float(tr.train_step([batch])) for _ in range(14)]
+    tr.finish()
+    torch.cuda.synchronize()
+    assert np.isfinite(losses).all() and losses[-1] < 0.7 * losses[1], losses
+    assert not torch.equal(p8_before, eng._fp8_train["p8"])  # re-quantised after the optimiser steps
