@@ -48,8 +48,17 @@ def test_quantize_fp8_is_bit_exact(ops, shape, scale):
     assert abs(inv.item() - invr.item()) <= 1e-7 * abs(invr.item())
 
 
+@pytest.mark.parametrize("force", [1, 3])  # the 128 x 128 and the 256 x 256 kernel
 @pytest.mark.parametrize("M,N,K", [(128, 128, 128), (300, 264, 256), (1000, 520, 336), (3000, 1280, 1280), (70, 48, 16)])
-def test_gemm_fp8_matches_dequantised_product(ops, M, N, K):
+def test_gemm_fp8_matches_dequantised_product(ops, M, N, K, force):
+    ops.lib().ca_gemm_force_kernel(force)
+    try:
+        _gemm_fp8_case(ops, M, N, K)
+    finally:
+        ops.lib().ca_gemm_force_kernel(0)
+
+
+def _gemm_fp8_case(ops, M, N, K):
     x = rnd(M, K, seed=2, scale=0.7).to(torch.bfloat16)
     w = rnd(N, K, seed=3, scale=0.05).to(torch.bfloat16)
     bias = rnd(N, seed=4)
@@ -115,7 +124,16 @@ def test_layernorm_fwd_fp8_rows(ops, M, C):
     assert torch.allclose(rs.cpu(), (am / 448.0).squeeze(1), rtol=1e-7, atol=0)
 
 
-def test_gemm_fp8_with_row_scales(ops):
+@pytest.mark.parametrize("force", [1, 3])
+def test_gemm_fp8_with_row_scales(ops, force):
+    ops.lib().ca_gemm_force_kernel(force)
+    try:
+        _row_scale_case(ops)
+    finally:
+        ops.lib().ca_gemm_force_kernel(0)
+
+
+def _row_scale_case(ops):
     M, N, K = 333, 392, 1024
     x = (rnd(M, K, seed=14) * torch.linspace(0.1, 30.0, M)[:, None]).to(torch.bfloat16)  # rows of very different size
     w = rnd(N, K, seed=15, scale=0.05).to(torch.bfloat16)
