@@ -228,3 +228,17 @@ def test_whisper_training_with_fp8_forward_projections():
     torch.cuda.synchronize()
     assert np.isfinite(losses).all() and losses[-1] < 0.7 * losses[1], losses
     assert not torch.equal(p8_before, eng._fp8_train["p8"])  # re-quantised after the optimiser steps
+
+
+def test_gemm_fp8_random_shapes(ops):
+    rng = torch.Generator().manual_seed(99)
+    for _ in range(8):
+        M = int(torch.randint(1, 600, (1,), generator=rng))
+        N = int(torch.randint(1, 60, (1,), generator=rng)) * 8
+        K = int(torch.randint(1, 40, (1,), generator=rng)) * 16
+        for force in (1, 3):
+            ops.lib().ca_gemm_force_kernel(force)
+            try:
+                _gemm_fp8_case(ops, M, N, K)
+            finally:
+                ops.lib().ca_gemm_force_kernel(0)

@@ -595,3 +595,20 @@ def test_frame_lengths(ops):
     for k, s in zip(kernels, strides):
         n = torch.div(n - k, s, rounding_mode="floor") + 1
     assert out.cpu().tolist() == n.tolist()
+
+
+def test_gemm_random_shapes_all_kernels(ops):
+    """Seeded sweep of ragged shapes (M, N not multiples of the tiles, K with and without a partial K-step) through the
+    128 x 128 and the 256 x 256 kernel in all four operand forms."""
+    rng = np.random.RandomState(1234)
+    for _ in range(10):
+        M = int(rng.randint(1, 700))
+        N = int(rng.randint(1, 90)) * 8
+        K = int(rng.randint(1, 60)) * 8
+        al, bl = int(rng.randint(0, 2)), int(rng.randint(0, 2))
+        for force in (1, 3):
+            ops.lib().ca_gemm_force_kernel(force)
+            try:
+                test_gemm_layouts(ops, al, bl, M, N, K)
+            finally:
+                ops.lib().ca_gemm_force_kernel(0)
