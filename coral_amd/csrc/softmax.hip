@@ -219,7 +219,23 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ 
   const float* l = lg + row * ldv;
   float best = NEG_INF;
   int bi = 0x7fffffff;
-  for (int c = threadIdx.x; c < V; c += 1024) {
+  // four logits (and their four suppress bytes) per load where the row is 16-byte aligned; a thread's candidates
+  // come in increasing index order, so "strictly greater" keeps the lowest index of equal values
+  const bool vec = ((ldv & 3) == 0) && ((((uintptr_t)lg) & 15) == 0) && (!suppress || (((uintptr_t)suppress) & 3) == 0);
+  const int V4 = vec ? (V >> 2) : 0;
+  for (int q = threadIdx.x; q < V4; q += 1024) {
+    const f32x4_t v4 = *(const f32x4_t*)(l + 4 * q);
+    const unsigned int sm = suppress ? *(const unsigned int*)(suppress + 4 * q) : 0u;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if ((sm >> (8 * e)) & 0xffu) continue;
+      if (v4[e] > best) {
+        best = v4[e];
+        bi = 4 * q + e;
+      }
+    }
+  }
+  for (int c = 4 * V4 + threadIdx.x; c < V; c += 1024) {
     if (suppress && suppress[c]) continue;
     const float v = l[c];
     if (v > best || (v == best && c < bi)) {

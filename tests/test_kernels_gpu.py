@@ -612,3 +612,26 @@ def test_gemm_random_shapes_all_kernels(ops):
                 test_gemm_layouts(ops, al, bl, M, N, K)
             finally:
                 ops.lib().ca_gemm_force_kernel(0)
+
+
+@pytest.mark.parametrize("V,Vp", [(51865, 51872), (200, 200), (1003, 1008)])
+def test_argmax_masked_first_maximum_and_suppression(ops, V, Vp):
+    """ca_argmax_masked = np.argmax over the non-suppressed tokens (first maximum wins), on the vector path (row
+    pitch multiple of 4) with planted ties across the 4-wide groups and in the scalar tail."""
+    B = 8
+    lg = rnd(B, Vp, seed=31)
+    sup = np.zeros(V, dtype=np.uint8)
+    rng = np.random.RandomState(3)
+    sup[rng.choice(V, V // 50, replace=False)] = 1
+    top = float(lg.max()) + 1.0
+    for b in range(B):  # ties at the maximum: some suppressed, the first unsuppressed one must win
+        idx = np.sort(rng.choice(V, 6, replace=False))
+        lg[b, idx] = top
+        sup[idx[0]] = 1 if b % 2 == 0 else sup[idx[0]]
+    lg[3, V - 1] = top + 1.0  # the last valid token (scalar tail when V % 4 != 0)
+    sup[V - 1] = 0
+    out = torch.zeros(B, dtype=torch.int32, device=DEV)
+    ops.argmax_masked(lg.to(DEV), torch.from_numpy(sup).to(DEV), out, B, V, Vp)
+    torch.cuda.synchronize()
+    ref = np.where(sup[None, :] == 1, -np.inf, lg[:, :V].numpy()).argmax(-1)
+    assert out.cpu().numpy().tolist() == ref.tolist()
