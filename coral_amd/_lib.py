@@ -63,6 +63,9 @@ class CaGemmDesc(C.Structure):
         ("a_colsum_ld", C.c_int64),
         ("c_row_index", C.c_void_p),
         ("c_row_mul", C.c_int64),
+        ("c_split_n", C.c_int32),
+        ("C_hi", C.c_void_p),
+        ("ldc_hi", C.c_int64),
         ("a_scale", C.c_void_p),
         ("b_scale", C.c_void_p),
         ("a_row_scale", C.c_void_p),

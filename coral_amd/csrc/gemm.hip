@@ -1243,8 +1243,15 @@ __global__ __launch_bounds__(256) void ca_gemm_skinny_kernel(const CaGemmDesc d)
           e_res[e] = bf2f(((const unsigned short*)d.R)[(int64_t)r * d.ldr + n]);
       }
     }
-    if (d.c_row_index) crow = (int64_t)r * d.c_row_mul + d.c_row_index[r];
+    if (d.c_row_index && (d.c_split_n == 0 || n0 >= d.c_split_n)) crow = (int64_t)r * d.c_row_mul + d.c_row_index[r];
   }
+  // c_split_n: columns [c_split_n, N) go to a second output (C_hi, ldc_hi; column index n - c_split_n) and only they
+  // take the c_row_index rows - q and the cached K|V rows of a decoded token from one launch.  n0 is a multiple of
+  // 16 and so is c_split_n: a workgroup is on one side.
+  const bool hi = d.c_split_n > 0 && n0 >= d.c_split_n;
+  void* const Cdst = hi ? d.C_hi : d.C;
+  const int64_t ldcd = hi ? d.ldc_hi : d.ldc;
+  const int ncol0 = hi ? d.c_split_n : 0;
   for (int ks = ks0; ks < ks1; ks += 8) {
     bf16x8_t wf[8], af[8];
 #pragma unroll
@@ -1276,12 +1283,12 @@ __global__ __launch_bounds__(256) void ca_gemm_skinny_kernel(const CaGemmDesc d)
     } else if (epi == CA_EPI_RESIDUAL) {
       v += e_res[e];
     }
-    const int64_t off = crow * d.ldc + n;
-    if (d.C) {
+    const int64_t off = crow * ldcd + (n - ncol0);
+    if (Cdst) {
       if (d.out_f32)
-        ((float*)d.C)[off] = d.accumulate ? ((float*)d.C)[off] + v : v;
+        ((float*)Cdst)[off] = d.accumulate ? ((float*)Cdst)[off] + v : v;
       else
-        ((unsigned short*)d.C)[off] = f2bf(d.accumulate ? bf2f(((unsigned short*)d.C)[off]) + v : v);
+        ((unsigned short*)Cdst)[off] = f2bf(d.accumulate ? bf2f(((unsigned short*)Cdst)[off]) + v : v);
     }
     if ((epi == CA_EPI_GELU || epi == CA_EPI_GELU_RESIDUAL) && d.C2) ((unsigned short*)d.C2)[off] = f2bf(v2);
   }
@@ -1786,11 +1793,14 @@ static int ca_gemm_launch(const CaGemmDesc* desc, void* stream) {
   if (g_force_kernel == 0 && d.M <= 16 && d.a_layout == CA_KMAJOR && d.b_layout == CA_KMAJOR && d.batch1 == 1 &&
       d.batch2 == 1 && d.a_kseg == 0 && d.b_kseg == 0 && d.dropout_p == 0.f && d.epilogue != CA_EPI_DGELU) {
     g_last_kind = 0;
+    CA_CHECK_ARG(d.c_split_n == 0 || (d.C_hi && (d.c_split_n % 16) == 0 && d.c_split_n < d.N && d.epilogue == CA_EPI_NONE),
+                 "ca_gemm_bf16: c_split_n needs C_hi, a multiple of 16 below N and no epilogue");
     CA_LAUNCH(ca_gemm_skinny_kernel, dim3((unsigned)((d.N + 15) / 16)), dim3(256), 0, s, d);
     CA_CHECK_LAUNCH("ca_gemm_bf16");
     return CA_OK;
   }
-  CA_CHECK_ARG(!d.c_row_index, "ca_gemm_bf16: c_row_index exists in the skinny form only (M <= 16, K-major operands, un-batched)");
+  CA_CHECK_ARG(!d.c_row_index && d.c_split_n == 0,
+               "ca_gemm_bf16: c_row_index / c_split_n exist in the skinny form only (M <= 16, K-major operands, un-batched)");
   // Kernel choice: the 256x128 pipelined kernel runs one workgroup per CU, so it needs enough
   // tiles to fill the chip; small or heavily batched problems use the 128x128 kernel.
   const int64_t nb = (int64_t)d.batch1 * d.batch2;

@@ -43,8 +43,10 @@ def _gemm_desc(A, B, Cout, *, M, N, K, lda, ldb, ldc, a_layout=KMAJOR, b_layout=
          epilogue=EPI_NONE, out_f32=None, accumulate=False, alpha=1.0, batch1=1, batch2=1,
          sA=(0, 0), sB=(0, 0), sC=(0, 0), sR=(0, 0), sBias=(0, 0), a_kseg=0, a_kseg_stride=0, b_kseg=0,
          b_kseg_stride=0, dropout_p=0.0, dropout_seed=0, a_colsum=None, a_colsum_off=0,
-         a_colsum_ld=0, c_row_index=None, c_row_mul=0):
+         a_colsum_ld=0, c_row_index=None, c_row_mul=0, c_split_n=0, C_hi=None, c_hi_off=0, ldc_hi=0):
     d = CaGemmDesc()
+    if c_split_n:
+        d.c_split_n, d.C_hi, d.ldc_hi = c_split_n, _p(C_hi, c_hi_off), ldc_hi
     if c_row_index is not None:
         d.c_row_index, d.c_row_mul = _p(c_row_index), c_row_mul
     if a_colsum is not None:

@@ -523,12 +523,11 @@ class WhisperEngine:
             ckv = cache["kv"][l]
             ops.layernorm_fwd(h0, st.view(p + "self_attn_layer_norm.weight"), st.view(p + "self_attn_layer_norm.bias"),
                               w["x"], None, B, d, s.layer_norm_eps)
-            ops.gemm(w["x"], p16, w["q"], M=B, N=d, K=d, lda=d, ldb=d, ldc=d, b_off=o(p + "self_attn.q_proj.weight"),
-                     bias=p32, bias_off=o(p + "self_attn.q_proj.bias"))
-            # the new K|V rows go straight into the cache at the device-side position (CaGemmDesc.c_row_index: the
-            # position is data, not a launch argument, so the launch sequence can be replayed as a graph)
-            ops.gemm(w["x"], p16, ckv, M=B, N=2 * d, K=d, lda=d, ldb=d, ldc=2 * d,
-                     b_off=o(p + "self_attn.k_proj.weight"), bias=p32, bias_off=o(p + "self_attn.k_proj.bias__zero"),
+            # q and the new K|V rows from one launch over the adjacent q|k|v weights: q to its buffer, K|V straight
+            # into the cache at the device-side position (CaGemmDesc.c_split_n / c_row_index: the position is data,
+            # not a launch argument, so the launch sequence can be replayed as a graph)
+            ops.gemm(w["x"], p16, w["q"], M=B, N=3 * d, K=d, lda=d, ldb=d, ldc=d, b_off=o(p + "self_attn.q_proj.weight"),
+                     bias=p32, bias_off=o(p + "self_attn.q_proj.bias"), c_split_n=d, C_hi=ckv, ldc_hi=2 * d,
                      c_row_index=g["pos"], c_row_mul=Lmax)
             ops.attn_fwd(w["q"], ckv, ckv, w["ctx"], self._lse(B * H * 32), B=B, H=H, Tq=1, Tk=Lmax, hd=hd, Tqp=32,
                          scale=hd ** -0.5, ldq=d, ldk=2 * d, ldv=2 * d, ldo=d, sqb=d, skb=Lmax * 2 * d,

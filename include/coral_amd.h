@@ -105,6 +105,13 @@ typedef struct CaGemmDesc {
    * NULL = rows in place. */
   const int32_t* c_row_index;
   int64_t c_row_mul;
+  /* Optional, skinny form only: columns [c_split_n, N) are written to C_hi (leading dimension ldc_hi, column index
+   * n - c_split_n) instead of C, and c_row_index then applies to those columns only - the q projection and the
+   * cached K|V rows of a decoded token from one launch over the adjacent q|k|v weights.  0 = off; a multiple of 16;
+   * CA_EPI_NONE only. */
+  int32_t c_split_n;
+  void* C_hi;
+  int64_t ldc_hi;
   /* fp8 form only (ca_gemm_fp8): per-tensor dequantisation scales of A and B, device scalars (NULL = 1): the
    * accumulator is multiplied by alpha * a_scale[0] * b_scale[0]. */
   const float* a_scale;

@@ -635,3 +635,24 @@ def test_argmax_masked_first_maximum_and_suppression(ops, V, Vp):
     torch.cuda.synchronize()
     ref = np.where(sup[None, :] == 1, -np.inf, lg[:, :V].numpy()).argmax(-1)
     assert out.cpu().numpy().tolist() == ref.tolist()
+
+
+def test_gemm_skinny_split_output(ops):
+    """CaGemmDesc.c_split_n: columns [0, d) to one buffer in place, columns [d, 3d) to the rows of a cache at
+    device-side positions - the q projection and the new K|V rows of a decoded token from one launch."""
+    M, d, K, L = 8, 128, 256, 5
+    x = bf(rnd(M, K, seed=41, scale=0.5)).to(DEV)
+    W = bf(rnd(3 * d, K, seed=42, scale=0.1)).to(DEV)
+    bias = rnd(3 * d, seed=43).to(DEV)
+    ref = torch.zeros(M, 3 * d, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(x, W, ref, M=M, N=3 * d, K=K, lda=K, ldb=K, ldc=3 * d, bias=bias)
+    pos = torch.tensor([(2 * m + 1) % L for m in range(M)], dtype=torch.int32, device=DEV)
+    q = torch.zeros(M, d, dtype=torch.bfloat16, device=DEV)
+    cache = torch.zeros(M, L, 2 * d, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(x, W, q, M=M, N=3 * d, K=K, lda=K, ldb=K, ldc=d, bias=bias, c_split_n=d, C_hi=cache, ldc_hi=2 * d,
+             c_row_index=pos, c_row_mul=L)
+    torch.cuda.synchronize()
+    assert torch.equal(q, ref[:, :d])
+    want = torch.zeros_like(cache)
+    want[torch.arange(M, device=DEV), pos.long()] = ref[:, d:]
+    assert torch.equal(cache, want)
