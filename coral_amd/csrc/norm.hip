@@ -20,6 +20,21 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const unsigned short* __res
     const unsigned short* xr = x + row * C;
     float v[NCH][8];
     float s = 0.f;
+    // short rows (greedy decoding: a handful of rows of d <= 1536): gamma / beta are requested together with the row,
+    // so the kernel is one memory round trip instead of two; long-row shapes keep the registers for occupancy
+    f32x4_t gq[NCH <= 3 ? NCH : 1][2], bq[NCH <= 3 ? NCH : 1][2];
+    if (NCH <= 3) {
+#pragma unroll
+      for (int c = 0; c < (NCH <= 3 ? NCH : 1); ++c) {
+        const int ch = lane + c * 64;
+        if (ch < nchunk) {
+          gq[c][0] = *(const f32x4_t*)(gamma + ch * 8);
+          gq[c][1] = *(const f32x4_t*)(gamma + ch * 8 + 4);
+          bq[c][0] = *(const f32x4_t*)(beta + ch * 8);
+          bq[c][1] = *(const f32x4_t*)(beta + ch * 8 + 4);
+        }
+      }
+    }
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const int ch = lane + c * 64;
@@ -58,10 +73,18 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const unsigned short* __res
     for (int c = 0; c < NCH; ++c) {
       const int ch = lane + c * 64;
       if (ch < nchunk) {
-        const f32x4_t g0 = *(const f32x4_t*)(gamma + ch * 8);
-        const f32x4_t g1 = *(const f32x4_t*)(gamma + ch * 8 + 4);
-        const f32x4_t b0 = *(const f32x4_t*)(beta + ch * 8);
-        const f32x4_t b1 = *(const f32x4_t*)(beta + ch * 8 + 4);
+        f32x4_t g0, g1, b0, b1;
+        if (NCH <= 3) {
+          g0 = gq[NCH <= 3 ? c : 0][0];
+          g1 = gq[NCH <= 3 ? c : 0][1];
+          b0 = bq[NCH <= 3 ? c : 0][0];
+          b1 = bq[NCH <= 3 ? c : 0][1];
+        } else {
+          g0 = *(const f32x4_t*)(gamma + ch * 8);
+          g1 = *(const f32x4_t*)(gamma + ch * 8 + 4);
+          b0 = *(const f32x4_t*)(beta + ch * 8);
+          b1 = *(const f32x4_t*)(beta + ch * 8 + 4);
+        }
         u16x8_t o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
