@@ -41,9 +41,13 @@ class DeviceInputPipeline:
         self.np_dtype = np.int16 if tdt == torch.int16 else np.float32
         self.host = [torch.zeros(batch, max_samples, dtype=tdt).pin_memory() for _ in range(depth)]
         self.host_len = [torch.zeros(batch, dtype=torch.int32).pin_memory() for _ in range(depth)]
-        self.dev = [torch.zeros(batch, max_samples, dtype=tdt, device=self.device) for _ in range(depth)]
-        self.dev_len = [torch.zeros(batch, dtype=torch.int32, device=self.device) for _ in range(depth)]
+        # Device slots are only ever written by the side-stream copies of submit() and read up to dev_len: no fill
+        # (a zero-fill would be enqueued on the *current* stream and could land after the first side-stream copy).
+        self.dev = [torch.empty(batch, max_samples, dtype=tdt, device=self.device) for _ in range(depth)]
+        self.dev_len = [torch.empty(batch, dtype=torch.int32, device=self.device) for _ in range(depth)]
         self.copy_stream = torch.cuda.Stream(device=self.device)
+        # whatever the allocating stream still has queued on this memory (a previous owner's kernels) comes first
+        self.copy_stream.wait_stream(torch.cuda.current_stream(self.device))
         self.ready = [torch.cuda.Event() for _ in range(depth)]
         self.free = [torch.cuda.Event() for _ in range(depth)]  # the compute stream is done with slot i
         self.mel_filters = mel_filters
