@@ -86,19 +86,32 @@ def synth_batch(B, seconds, rank, device, ragged=False):
     return dict(input_values=y, attention_mask=am.to(device), labels=labels.to(device)), lens
 
 
-def cpu_baseline(model_key: str, seconds: float = 2.0, max_threads: int = 32):
-    """Time the oracle (fp32 torch CPU restatement of the HF path) on this box's host cores on a
-    BOUNDED sample of the same workload: ONE utterance of `seconds` s through the bench's
-    architecture (fwd + bwd incl. CTC).  Threads are capped at 32: torch's CPU GEMMs get slower,
-    not faster, when oversubscribed on the 256-thread GPU host (a 10 s sample took 647 s there)."""
+def cpu_model_name() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
+
+
+def cpu_baseline(max_threads: int = 32, budget_s: float = 75.0):
+    """the oracle (fp32 torch CPU restatement of the HF path, oracle/wav2vec2_ref.py) timed on this
+    box's host cores on BASELINE configs[0] — XLS-R-300M shape, 4 x 5 s utterances, forward + backward incl. CTC —
+    3 warm-up + 5 timed iterations, median (fewer if the wall budget runs out first; the counts are in `sample`).
+    Threads are capped at 32: torch's CPU GEMMs get slower, not faster, when oversubscribed on the 256-thread GPU
+    host (a 10 s utterance at the 2B shape took 647 s there with all threads)."""
+    import statistics
+
     import numpy as np
 
     from oracle import wav2vec2_ref as ref
 
     cores = min(os.cpu_count() or 1, max_threads)
     torch.set_num_threads(cores)
-    cfg = ref.W2V2Config(**ref.CORAL_SHAPES[model_key])
-    g = torch.Generator().manual_seed(1)
+    cfg = ref.W2V2Config(**ref.CORAL_SHAPES["wav2vec2-small"])
+    g = torch.Generator().manual_seed(4242)
     P = {}
     for name, shape in ref.param_shapes(cfg).items():
         fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else shape[0]
@@ -109,17 +122,51 @@ def cpu_baseline(model_key: str, seconds: float = 2.0, max_threads: int = 32):
         else:
             t = torch.empty(shape).normal_(0.0, fan_in ** -0.5, generator=g)
         P[name] = t.requires_grad_(True)
+    B, seconds = 4, 5.0
     N = int(16000 * seconds)
-    x = 0.1 * torch.randn(1, N, generator=g)
-    x = (x - x.mean()) / x.std()
-    labels = torch.randint(0, 42, (1, max(2, int(6 * seconds))), generator=g)
-    t0 = time.time()
-    loss, _, _ = ref.forward_loss(x, None, labels, P, cfg)
-    loss.backward()
-    dt = time.time() - t0
-    return {"value": round(seconds / dt, 4), "unit": "audio-seconds/sec", "cores": cores, "kind": "port",
-            "sample": f"1 x {seconds:g} s utterance, {model_key} shape, fwd+bwd+CTC fp32, {dt:.1f} s wall "
-                      f"(oracle/wav2vec2_ref.py, torch {torch.__version__} CPU, {cores} threads)"}
+    x = 0.1 * torch.randn(B, N, generator=g)
+    x = (x - x.mean(1, keepdim=True)) / x.std(1, keepdim=True)
+    labels = torch.randint(0, 42, (B, 40), generator=g)
+
+    def once():
+        for t in P.values():
+            t.grad = None
+        t0 = time.perf_counter()
+        loss, _, _ = ref.forward_loss(x, None, labels, P, cfg)
+        loss.backward()
+        return time.perf_counter() - t0
+
+    t_begin = time.perf_counter()
+    warm, times = 0, []
+    while warm < 3 and (warm == 0 or time.perf_counter() - t_begin < 0.3 * budget_s):
+        once()
+        warm += 1
+    while len(times) < 5 and (len(times) < 2 or time.perf_counter() - t_begin < budget_s):
+        times.append(once())
+    med = statistics.median(times)
+    return {"value": round(B * seconds / med, 3), "unit": "audio-seconds/sec", "cores": cores, "kind": "port",
+            "cpu": cpu_model_name(),
+            "sample": f"BASELINE configs[0]: {B} x {seconds:g} s utterances, wav2vec2-small (XLS-R-300M) shape, "
+                      f"fwd+bwd+CTC fp32; {warm} warm-up + {len(times)} timed iterations, median {med:.2f} s "
+                      f"(min {min(times):.2f}, max {max(times):.2f}); oracle/wav2vec2_ref.py, torch {torch.__version__} "
+                      f"CPU, {cores} threads (capped: oversubscribed CPU GEMMs get slower on the {os.cpu_count()}-thread host)"}
+
+
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) through torch.distributed.run as a
+    child process and return its exit code."""
+    import subprocess
+
+    ndev = torch.cuda.device_count()  # counts devices without initialising the GPU runtime
+    if ndev < n:
+        print(f"bench.py: --gpus {n} but only {ndev} GPU(s) are visible", file=sys.stderr)
+        return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--nnodes=1", f"--nproc-per-node={n}",
+           "--local-addr", "127.0.0.1", str(Path(__file__).resolve())] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
 
 
 def whisper_bench(args, world, rank, device):
@@ -215,69 +262,28 @@ def whisper_bench(args, world, rank, device):
         torch.distributed.destroy_process_group()
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--model", default="wav2vec2-large", help="CoRal model key (wav2vec2-small/medium/large)")
-    ap.add_argument("--batch", type=int, default=8, help="utterances per GPU")
-    ap.add_argument("--seconds", type=float, default=10.0)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-specaugment", action="store_true")
-    ap.add_argument("--from-host-pcm", action="store_true",
-                    help="feed every step from raw int16 PCM in host memory through the device input pipeline "
-                         "(pinned staging + side-stream H2D + on-GPU normalisation): the PCIe-inclusive rate")
-    ap.add_argument("--gemm-breakdown", action="store_true", help="print the per-kernel GEMM timing table to stderr")
-    ap.add_argument("--decode", action="store_true", help="whisper models: time greedy decoding instead of training")
-    ap.add_argument("--decode-tokens", type=int, default=32)
-    ap.add_argument("--fp8-forward", action="store_true",
-                    help="whisper finetune step: encoder q|k|v and fc1 forward projections in fp8 (DESIGN.md 4.4)")
-    ap.add_argument("--fp8-encoder", action="store_true",
-                    help="whisper --decode: encoder q|k|v and fc1 projections with fp8 weights (DESIGN.md 4.4)")
-    ap.add_argument("--grad-wire", default="bf16", choices=["bf16", "fp32"],
-                    help="dtype of the gradient all-reduce at N>1 (bf16 = DDP bf16_compress_hook equivalent)")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for 1-GPU debugging of the N>1 logic)")
-    ap.add_argument("--check-replicas", action="store_true", help="after the run, verify every rank holds identical parameters")
-    args = ap.parse_args()
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    ndev = torch.cuda.device_count()
-    local_rank = local_rank % max(1, ndev)  # (gloo debugging may put several ranks on one GPU)
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if args.backend == "nccl":
-            torch.distributed.init_process_group("nccl", device_id=device)
-        else:
-            torch.distributed.init_process_group(args.backend)
+def run_w2v2(model_key, args, world, rank, device, roofline: bool):
+    """Build the engine for one CoRal model key, run `--warmup` untimed and `--steps` timed finetune steps; with
+    `roofline`, two more steps with every GEMM launch bracketed by hipEvents on its stream."""
+    import numpy as np
 
     from coral_amd import ops, specaugment
     from coral_amd.trainer import DataParallelTrainer
     from coral_amd.wav2vec2 import CORAL_W2V2_SHAPES, Wav2Vec2CTCEngine, Wav2Vec2Shape
 
-    if args.model.startswith("whisper"):
-        return whisper_bench(args, world, rank, device)
-
     # CoRal model YAML values (R/config/model/wav2vec2-large.yaml:12-22); layerdrop is forced to 0
     # in the multi-GPU regime (R/src/scripts/finetune_asr_model.py:48-54) and kept 0 at N=1 so the
     # per-GPU work is identical at every N (weak scaling).
-    shape = Wav2Vec2Shape(**CORAL_W2V2_SHAPES[args.model], activation_dropout=0.1, layerdrop=0.0)
+    shape = Wav2Vec2Shape(**CORAL_W2V2_SHAPES[model_key], activation_dropout=0.1, layerdrop=0.0)
     eng = Wav2Vec2CTCEngine(shape, device)
     init_random_(eng, 4242)
     trainer = DataParallelTrainer(eng, learning_rate=1e-4, betas=(0.9, 0.98), max_grad_norm=1.0,
                                   warmup_steps=1000, max_steps=100_000, compress_grads=(args.grad_wire == "bf16"))
-    batch, lens = synth_batch(args.batch, args.seconds, rank, device)
+    batch, lens = synth_batch(args.batch, args.seconds, rank, device, ragged=args.ragged)
     B, N = batch["input_values"].shape
     Ts = eng.conv_lengths(N)
     T = Ts[-1]
-    import numpy as np
-
+    frame_lens = [eng.conv_lengths(int(n))[-1] for n in lens]  # SpecAugment spans fall on valid frames only
     rng = np.random.RandomState(4242 + rank)
 
     pipe = None
@@ -285,7 +291,7 @@ def main():
         from coral_amd.input_pipeline import DeviceInputPipeline
 
         pipe = DeviceInputPipeline(device, B, N, dtype=np.int16, padding="max_length")
-        pcm = [(np.clip(0.1 * rng.randn(N), -1, 1) * 32767).astype(np.int16) for _ in range(B)]
+        pcm = [(np.clip(0.1 * rng.randn(int(n)), -1, 1) * 32767).astype(np.int16) for n in lens]
         pipe.submit(pcm)
 
     def make_step_batch():
@@ -294,7 +300,7 @@ def main():
             mb.update(pipe.get())
             pipe.submit(pcm)
         if not args.no_specaugment:
-            mt, mf = specaugment.sample_masks(B, T, shape.hidden_size, [T] * B, 0.5, 10, 0.5, 64, rng=rng)
+            mt, mf = specaugment.sample_masks(B, T, shape.hidden_size, frame_lens, 0.5, 10, 0.5, 64, rng=rng)
             mb["mask_time"] = torch.from_numpy(mt)
             mb["mask_feature"] = torch.from_numpy(mf)
         return [mb]
@@ -316,61 +322,145 @@ def main():
     if world > 1:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
     dt = float(tmax.item())
-    loss_val = float(loss)
-
-    # live roofline: two more steps with every GEMM launch bracketed by hipEvents on its stream
-    ops.prof_begin()
-    for _ in range(2):
-        trainer.train_step(make_step_batch())
+    secs = torch.tensor([float(lens.sum()) / 16000.0], dtype=torch.float64, device=device)  # real (unpadded) audio
+    if world > 1:
+        torch.distributed.all_reduce(secs)
+    res = dict(engine=eng, shape=shape, B=B, T=T, loss=float(loss), ms_per_step=dt / args.steps * 1e3,
+               value=round(float(secs.item()) * args.steps / dt, 2),
+               step_tflop=3.0 * fwd_gflop_per_utt(shape, T, Ts) * B / 1e3)
+    if roofline:
+        ops.prof_begin()
+        for _ in range(2):
+            trainer.train_step(make_step_batch())
+        torch.cuda.synchronize()
+        prof = ops.prof_end()
+        res["prof"], res["dom"] = prof, max(prof, key=lambda r: r["ms"])
+        if rank == 0 and args.gemm_breakdown:
+            for r in sorted(prof, key=lambda r: -r["ms"]):
+                if r["count"]:
+                    print(f"{r['kernel']:55s} {r['count'] // 2:5d} launches/step {r['ms'] / 2:8.2f} ms/step "
+                          f"{r['flops'] / (r['ms'] * 1e-3) / 1e12:7.1f} TFLOP/s", file=sys.stderr)
+    trainer.finish()
     torch.cuda.synchronize()
-    prof = ops.prof_end()
-    dom = max(prof, key=lambda r: r["ms"])
-    tot_ms = sum(r["ms"] for r in prof)
-    tot_fl = sum(r["flops"] for r in prof)
+    res["trainer"] = None
+    return res
 
-    if rank == 0 and args.gemm_breakdown:
-        for r in sorted(prof, key=lambda r: -r["ms"]):
-            if r["count"]:
-                print(f"{r['kernel']:55s} {r['count'] // 2:5d} launches/step {r['ms'] / 2:8.2f} ms/step "
-                      f"{r['flops'] / (r['ms'] * 1e-3) / 1e12:7.1f} TFLOP/s", file=sys.stderr)
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--model", default="wav2vec2-large", help="CoRal model key (wav2vec2-small/medium/large)")
+    ap.add_argument("--batch", type=int, default=8, help="utterances per GPU")
+    ap.add_argument("--seconds", type=float, default=10.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-specaugment", action="store_true")
+    ap.add_argument("--from-host-pcm", action="store_true",
+                    help="feed every step from raw int16 PCM in host memory through the device input pipeline "
+                         "(pinned staging + side-stream H2D + on-GPU normalisation): the PCIe-inclusive rate")
+    ap.add_argument("--gemm-breakdown", action="store_true", help="print the per-kernel GEMM timing table to stderr")
+    ap.add_argument("--decode", action="store_true", help="whisper models: time greedy decoding instead of training")
+    ap.add_argument("--decode-tokens", type=int, default=32)
+    ap.add_argument("--fp8-forward", action="store_true",
+                    help="whisper finetune step: encoder q|k|v and fc1 forward projections in fp8 (DESIGN.md 4.4)")
+    ap.add_argument("--fp8-encoder", action="store_true",
+                    help="whisper --decode: encoder q|k|v and fc1 projections with fp8 weights (DESIGN.md 4.4)")
+    ap.add_argument("--grad-wire", default="fp32", choices=["bf16", "fp32"],
+                    help="dtype of the gradient all-reduce at N>1: fp32 = what the reference's DDP reduces (accelerate "
+                         "bf16 autocast keeps fp32 gradients); bf16 = the DDP bf16_compress_hook trade, a separate "
+                         "labelled measurement, never the headline")
+    ap.add_argument("--ragged", action="store_true",
+                    help="utterance lengths ~ U[1 s, --seconds] padded to --seconds (the regime of "
+                         "R/config/asr_finetuning.yaml:31-32): masked attention / CTC lengths / SpecAugment on valid frames")
+    ap.add_argument("--no-also", action="store_true", help="skip the second (24L/1024 = wav2vec2-small) measurement")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for 1-GPU debugging of the N>1 logic)")
+    ap.add_argument("--check-replicas", action="store_true", help="after the run, verify every rank holds identical parameters")
+    args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # One command starts all ranks (the reference's `accelerate launch ... finetune_asr_model.py`,
+        # R/src/scripts/finetune_asr_model.py:9-12): nothing in this process has touched the GPU yet, the ranks are
+        # fresh child processes and this process only relays their exit code.  Never a silent 1-GPU run.
+        raise SystemExit(spawn_ranks(args.gpus))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    ndev = torch.cuda.device_count()
+    local_rank = local_rank % max(1, ndev)  # (gloo debugging may put several ranks on one GPU)
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if args.backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=device)
+        else:
+            torch.distributed.init_process_group(args.backend)
+
+    if args.model.startswith("whisper"):
+        return whisper_bench(args, world, rank, device)
+
+    res = run_w2v2(args.model, args, world, rank, device, roofline=True)
+    eng, loss_val = res.pop("engine"), res["loss"]
     if rank == 0:
-        audio_s = world * B * args.seconds * args.steps
-        step_ms = dt / args.steps * 1e3
-        fwd = fwd_gflop_per_utt(shape, T, Ts)
-        step_tflop = 3.0 * fwd * B / 1e3
+        shape, B, T = res["shape"], res["B"], res["T"]
+        dom, prof = res["dom"], res["prof"]
+        tot_ms = sum(r["ms"] for r in prof)
+        tot_fl = sum(r["flops"] for r in prof)
+        step_ms = res["ms_per_step"]
         ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
-        traffic = None
+        traffic, traffic_source = None, None
         pmc = ROOT / "profiles" / "pmc_traffic.json"
         if pmc.exists():
             try:
                 traffic = json.loads(pmc.read_text()).get(dom["kernel"])
+                traffic_source = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, FETCH_SIZE x2 for gfx950; static table, not re-measured in this run)"
             except Exception:
                 traffic = None
+        wire = f"{args.grad_wire} wire" if world > 1 else "no collective (1 rank)"
         out = {
             "metric": "audio-seconds/sec (CTC finetune step: fwd+bwd+allreduce+clip+AdamW), wav2vec2-large, 10 s utterances",
-            "value": round(audio_s / dt, 2), "unit": "audio-seconds/sec", "n_gpus": world,
+            "value": res["value"], "unit": "audio-seconds/sec", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(step_ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
             "data": "synthetic",
+            "rccl_ranks": torch.distributed.get_world_size() if world > 1 else 1,
+            "grad_wire": args.grad_wire if world > 1 else None,
             "config": {"workload": f"{args.model} (XLS-R shape d={shape.hidden_size} L={shape.num_hidden_layers} "
-                                   f"ffn={shape.intermediate_size}) CTC finetune, {B} x {args.seconds:g} s per GPU, "
-                                   f"SpecAugment {'off' if args.no_specaugment else 'on'}, activation_dropout 0.1, "
+                                   f"ffn={shape.intermediate_size}) CTC finetune, {B} x {args.seconds:g} s per GPU"
+                                   + (" (ragged: lengths U[1 s, max], padded)" if args.ragged else "") +
+                                   f", SpecAugment {'off' if args.no_specaugment else 'on'}, activation_dropout 0.1, "
                                    "layerdrop 0 (multi-GPU rule), fp32 master + AdamW + clip 1.0"
-                                   + (", inputs from host int16 PCM through the device input pipeline" if pipe is not None else "")
-                                   + (f", gradient all-reduce on {args.grad_wire} wire, per-layer buckets overlapped with backward" if world > 1 else ""),
+                                   + (", inputs from host int16 PCM through the device input pipeline" if args.from_host_pcm else "")
+                                   + (f", gradient all-reduce ({args.backend}) on {wire}, per-layer buckets overlapped with backward" if world > 1 else ""),
                        "global_batch": world * B, "frames_per_utt": T, "parallelism": f"dp{world}",
                        "loss": round(loss_val, 3)},
             "roofline": {"bound": "mfma", "kernel": dom["kernel"], "achieved": round(ach, 1),
                          "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(ach / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic,
+                         "traffic_source": traffic_source,
                          "launches": dom["count"] // 2, "avg_us": round(dom["ms"] * 1e3 / max(1, dom["count"]), 2),
                          "all_gemm_tflops": round(tot_fl / (tot_ms * 1e-3) / 1e12, 1) if tot_ms else 0.0,
                          "gemm_ms_per_step": round(tot_ms / 2, 2),
-                         "step_algorithmic_tflop": round(step_tflop, 2),
-                         "step_frac_of_peak": round(step_tflop / (step_ms * 1e-3) / MFMA_BF16_DENSE_PEAK_TFLOPS, 4)},
+                         "step_algorithmic_tflop": round(res["step_tflop"], 2),
+                         "step_frac_of_peak": round(res["step_tflop"] / (step_ms * 1e-3) / MFMA_BF16_DENSE_PEAK_TFLOPS, 4)},
         }
+    if world == 1 and not args.no_also and args.model == "wav2vec2-large":
+        # SURVEY.md §0 decision 2: CoRal's `wav2vec2-large` key is the XLS-R-2B shape; the architecture most readers
+        # call "wav2vec2-large" (24 L / 1024 / 4096) is CoRal's `wav2vec2-small` key: report it beside the headline.
+        del res, eng
+        torch.cuda.empty_cache()
+        r2 = run_w2v2("wav2vec2-small", args, world, rank, device, roofline=False)
+        del r2["engine"]
+        out["config"]["also"] = {"workload": "wav2vec2-small (XLS-R-300M = classic wav2vec2-large shape 24L/1024/4096), same step",
+                                 "value": r2["value"], "unit": "audio-seconds/sec", "ms_per_step": round(r2["ms_per_step"], 3),
+                                 "step_frac_of_peak": round(r2["step_tflop"] / (r2["ms_per_step"] * 1e-3) / MFMA_BF16_DENSE_PEAK_TFLOPS, 4)}
+        eng = None
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.model)
+            out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:
         if args.check_replicas:
