@@ -47,16 +47,35 @@ def synthetic_whisper_examples(processor, n: int, seed: int, prefix, eos: int, m
         yield dict(input_features=feats, labels=list(prefix) + ids + [eos], input_length=len(wave))
 
 
+class ExampleStream:
+    """A re-iterable example stream (what a streaming `IterableDataset` is to `Trainer`): every `iter()` starts a
+    fresh pass, so the training loop can begin another epoch when a pass runs dry."""
+
+    def __init__(self, *factories):
+        self.factories = factories
+
+    def __iter__(self):
+        for f in self.factories:
+            yield from f()
+
+
 def load_data_for_finetuning(config, processor, n_examples: int | None = None, model=None):
     """-> {"train": iterable, "val": list}.  Only `datasets=synthetic` and local `.npz` directories
     (arrays `audio`, `text`) are supported offline."""
-    rank = 0
-    try:
-        import os
+    import os
 
-        rank = int(os.environ.get("RANK", "0"))
-    except ValueError:
-        pass
+    from .trainer import grad_accumulation_steps
+
+    rank, world = int(os.environ.get("RANK", "0") or 0), int(os.environ.get("WORLD_SIZE", "1") or 1)
+    try:
+        import torch
+
+        ndev = max(torch.cuda.device_count(), 1)
+    except Exception:
+        ndev = 1
+    # one pass of the synthetic stream covers the whole run: per-device batch x accumulation x steps
+    accum = grad_accumulation_steps(config.total_batch_size, ndev, config.per_device_batch_size)
+    n_run = n_examples or config.per_device_batch_size * accum * config.max_steps
     out_train = []
     if config.model.type == "whisper":
         from .whisper_setup import prefix_ids
@@ -66,35 +85,32 @@ def load_data_for_finetuning(config, processor, n_examples: int | None = None, m
             if ds["id"] != "synthetic":
                 raise RuntimeError(f"dataset {key!r} ({ds['id']}) needs the HuggingFace hub and the Whisper tokenizer "
                                    "files; this environment is offline — use datasets=synthetic")
-        n = n_examples or config.per_device_batch_size * config.max_steps
         mk = lambda k, sd, hi: synthetic_whisper_examples(  # noqa: E731
             processor, k, sd, prefix_ids(shape), shape.eos_token_id, config.min_seconds_per_example, hi,
             config.model.sampling_rate)
-        return {"train": mk(n, config.seed + 1000 * rank, config.max_seconds_per_example),
+        return {"train": ExampleStream(lambda: mk(n_run, config.seed + 1000 * rank, config.max_seconds_per_example)),
                 "val": list(mk(4, config.seed + 7, 3.0))}
     for key, ds in config.datasets.items():
         if ds["id"] == "synthetic":
-            n = n_examples or config.per_device_batch_size * config.max_steps
             fixed = config.padding == "max_length"
-            out_train.append(synthetic_examples(processor, n, config.seed + 1000 * rank,
-                                                config.min_seconds_per_example, config.max_seconds_per_example,
-                                                config.model.sampling_rate, fixed_length=fixed))
+            out_train.append(lambda fixed=fixed: synthetic_examples(
+                processor, n_run, config.seed + 1000 * rank, config.min_seconds_per_example,
+                config.max_seconds_per_example, config.model.sampling_rate, fixed_length=fixed))
         elif Path(ds["id"]).is_dir():
-            out_train.append(_npz_examples(Path(ds["id"]), processor, ds["text_column"], config.model.sampling_rate))
+            out_train.append(lambda ds=ds: _npz_examples(Path(ds["id"]), processor, ds["text_column"],
+                                                         config.model.sampling_rate, rank, world))
         else:
             raise RuntimeError(f"dataset {key!r} ({ds['id']}) needs the HuggingFace hub; this environment is "
                                "offline — use datasets=synthetic or a local directory of .npz shards")
 
-    def chain():
-        for it in out_train:
-            yield from it
-
     val = list(synthetic_examples(processor, 8, config.seed + 7, 1.0, 3.0, config.model.sampling_rate))
-    return {"train": chain(), "val": val}
+    return {"train": ExampleStream(*out_train), "val": val}
 
 
-def _npz_examples(root: Path, processor, text_column: str, sampling_rate: int):
-    for f in sorted(root.glob("*.npz")):
+def _npz_examples(root: Path, processor, text_column: str, sampling_rate: int, rank: int = 0, world: int = 1):
+    """Local shards, dealt round-robin to the ranks (file i goes to rank i % world) so that no two ranks train on the
+    same example — what `split_dataset_by_node` does for the reference's streaming datasets under accelerate."""
+    for f in sorted(root.glob("*.npz"))[rank::world]:
         z = np.load(f, allow_pickle=True)
         ex = processor(z["audio"].astype(np.float32), sampling_rate=sampling_rate)
         ex["labels"] = processor(text=str(z[text_column]), truncation=True)["input_ids"]

@@ -147,7 +147,9 @@ class Wav2Vec2ModelSetup(ModelSetup):
         m = self.config.model
         tok = self.processor.tokenizer
         model = Wav2Vec2ForCTC.from_pretrained(
-            m.pretrained_model_id, activation_dropout=m.activation_dropout, apply_spec_augment=True,
+            m.pretrained_model_id, activation_dropout=m.activation_dropout, attention_dropout=m.attention_dropout,
+            hidden_dropout=m.hidden_dropout, feat_proj_dropout=m.feat_proj_dropout, final_dropout=m.final_dropout,
+            apply_spec_augment=True,
             mask_time_prob=m.mask_time_prob, mask_time_length=m.mask_time_length,
             mask_feature_prob=m.mask_feature_prob, mask_feature_length=m.mask_feature_length,
             layerdrop=m.layerdrop, ctc_loss_reduction=m.ctc_loss_reduction, pad_token_id=tok.pad_token_id,

@@ -36,6 +36,34 @@ def _load_safetensors(path: Path) -> dict:
     return load_file(str(path))
 
 
+def load_checkpoint_tensors(model_dir: Path) -> dict:
+    """The weights of an HF model directory: `model.safetensors`, sharded safetensors through
+    `model.safetensors.index.json`, or the older `pytorch_model.bin` (many pretrained XLS-R repos ship only that)."""
+    model_dir = Path(model_dir)
+    if (model_dir / "model.safetensors").exists():
+        return _load_safetensors(model_dir / "model.safetensors")
+    idx = model_dir / "model.safetensors.index.json"
+    if idx.exists():
+        out = {}
+        for shard in sorted(set(json.loads(idx.read_text())["weight_map"].values())):
+            out.update(_load_safetensors(model_dir / shard))
+        return out
+    if (model_dir / "pytorch_model.bin").exists():
+        return torch.load(model_dir / "pytorch_model.bin", map_location="cpu", weights_only=True)
+    raise FileNotFoundError(f"{model_dir} holds neither model.safetensors nor pytorch_model.bin")
+
+
+def _warn_unsupported_dropouts(overrides: dict, cfg: dict):
+    """The reference passes five dropouts to `from_pretrained` (R/src/coral/wav2vec2.py:108-112); every CoRal model
+    YAML sets all but `activation_dropout` to 0.  The engine implements activation dropout only (the FFN GEMM's
+    epilogue): a non-zero value for one of the others must not pass silently."""
+    for k in ("attention_dropout", "hidden_dropout", "feat_proj_dropout", "final_dropout"):
+        v = float(overrides.get(k, 0.0) or 0.0)  # the checkpoint's own config values only matter in training
+        if v != 0.0:
+            raise NotImplementedError(f"{k}={v}: only activation_dropout is implemented on the MI355X engine "
+                                      "(every CoRal wav2vec2 config sets the other dropouts to 0.0)")
+
+
 class Wav2Vec2ForCTC:
     """`Wav2Vec2ForCTC` look-alike backed by `Wav2Vec2CTCEngine` (HIP kernels only)."""
 
@@ -71,8 +99,13 @@ class Wav2Vec2ForCTC:
                 activation_dropout=overrides.get("activation_dropout", cfg.get("activation_dropout", 0.0)),
                 layerdrop=overrides.get("layerdrop", cfg.get("layerdrop", 0.0)))
             model = cls(shape, device, freeze_base, spec)
-            sd = _load_safetensors(path / "model.safetensors")
-            model.engine.load_state_dict(sd)
+            rep = model.engine.load_state_dict(load_checkpoint_tensors(path), strict=False, seed=seed)
+            if rep["missing"]:
+                logger.warning("%s: %s newly initialised (not in the checkpoint, or of another size)", path, rep["missing"])
+            if rep["unexpected"]:
+                logger.info("%s: %d checkpoint tensors not used by Wav2Vec2ForCTC (e.g. %s)", path,
+                            len(rep["unexpected"]), rep["unexpected"][0])
+            _warn_unsupported_dropouts(overrides, cfg)
             return model
         if name_or_path not in HUB_SHAPES:
             raise ValueError(f"unknown model {name_or_path!r}: not a local directory and not one of {list(HUB_SHAPES)}")
@@ -82,6 +115,7 @@ class Wav2Vec2ForCTC:
                               ctc_zero_infinity=overrides.get("ctc_zero_infinity", True),
                               activation_dropout=overrides.get("activation_dropout", 0.0),
                               layerdrop=overrides.get("layerdrop", 0.0))
+        _warn_unsupported_dropouts(overrides, {})
         logger.warning("no network / hub cache here: %s is instantiated with seeded random weights "
                        "(pass a local directory holding model.safetensors for real weights)", name_or_path)
         model = cls(shape, device, freeze_base, spec)

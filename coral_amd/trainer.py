@@ -194,10 +194,13 @@ class DataParallelTrainer:
         tensor (device) of this rank, scaled as Trainer does (1/grad_accum)."""
         eng = self.engine
         self.model.train()
-        eng.step_seed = self.opt_step * 64 + (int(os.environ.get("RANK", "0")) % 64)
         total = None
         n = len(micro_batches)
+        rank = int(os.environ.get("RANK", "0")) % 64
         for i, mb in enumerate(micro_batches):
+            # fresh activation-dropout masks per micro-batch and rank (HF draws new masks in every forward); the
+            # backward of micro-batch i runs before the next forward and regenerates the masks from the same seed
+            eng.step_seed = (self.opt_step * n + i) * 64 + rank
             out = self.model(**mb)
             if i == 0:  # the previous optimiser step may still be reading the gradients
                 self.finish()

@@ -195,14 +195,50 @@ class Wav2Vec2CTCEngine:
         self.zero_embed = torch.zeros(d, dtype=torch.bfloat16, device=dev)
 
     # ---- parameters ------------------------------------------------------------------------
-    def load_state_dict(self, P: dict):
-        """Copy HF-named fp32 tensors into the flat master buffer and refresh compute copies."""
-        missing = [n for n in self.store.names() if n not in P]
-        if missing:
-            raise KeyError(f"missing parameters: {missing[:4]}...")
-        for n in self.store.names():
-            self.store.view(n).copy_(P[n].to(self.device, torch.float32).reshape(self.store.index[n][1]))
+    def load_state_dict(self, P: dict, strict: bool = True, seed: int = 4242) -> dict:
+        """Copy HF-named fp32 tensors into the flat master buffer and refresh compute copies.
+
+        strict=False follows `PreTrainedModel.from_pretrained` for the checkpoints CoRal finetunes from
+        (R/src/coral/wav2vec2.py:107-126: a pretrained XLS-R base plus a freshly initialised CTC head): a bare
+        `Wav2Vec2Model` state dict gets the `wav2vec2.` prefix, the pre-parametrize weight-norm names
+        `...pos_conv_embed.conv.weight_g / weight_v` map to `parametrizations.weight.original0 / original1`,
+        unexpected keys (`quantizer.*`, `project_q.*`, `project_hid.*` of the pretraining head) are ignored, and a
+        missing or differently sized `lm_head.*` / `masked_spec_embed` is initialised from `seed` the way HF's
+        `_init_weights` does (Linear: N(0, 0.02), zero bias; masked_spec_embed: U(0, 1)).  Anything else that is
+        missing still raises.  Returns {"missing": [...], "unexpected": [...]} like `load_state_dict` of torch."""
+        if not strict:
+            if not any(k.startswith("wav2vec2.") or k.startswith("lm_head.") for k in P):
+                P = {"wav2vec2." + k: v for k, v in P.items()}
+            ren = {}
+            for k, v in P.items():
+                if k.endswith("pos_conv_embed.conv.weight_g"):
+                    k = k[:-len("weight_g")] + "parametrizations.weight.original0"
+                elif k.endswith("pos_conv_embed.conv.weight_v"):
+                    k = k[:-len("weight_v")] + "parametrizations.weight.original1"
+                ren[k] = v
+            P = ren
+        names = self.store.names()
+        fresh_ok = ("lm_head.weight", "lm_head.bias", "wav2vec2.masked_spec_embed")
+        missing = [n for n in names if n not in P]
+        if not strict:
+            missing += [n for n in fresh_ok if n in P and int(P[n].numel()) != int(math.prod(self.store.index[n][1]))]
+        hard = [n for n in missing if strict or n not in fresh_ok]
+        if hard:
+            raise KeyError(f"missing parameters: {hard[:4]}...")
+        g = torch.Generator(device=self.device).manual_seed(seed)
+        for n in names:
+            v = self.store.view(n)
+            if n in missing:
+                if n == "lm_head.weight":
+                    v.normal_(0.0, 0.02, generator=g)
+                elif n == "lm_head.bias":
+                    v.zero_()
+                else:
+                    v.uniform_(0.0, 1.0, generator=g)
+                continue
+            v.copy_(P[n].to(self.device, torch.float32).reshape(self.store.index[n][1]))
         self.refresh_compute_weights()
+        return dict(missing=missing, unexpected=[k for k in P if k not in self.store.index])
 
     def state_dict(self) -> dict:
         return {n: self.store.view(n).detach().clone() for n in self.store.names()}

@@ -122,9 +122,9 @@ class WhisperForConditionalGeneration:
             cfg = json.loads((path / "config.json").read_text())
             fields = WhisperShape.__dataclass_fields__
             model = cls(WhisperShape(**{k: cfg[k] for k in fields if k in cfg}), device, **kw)
-            from safetensors.torch import load_file
+            from .modeling import load_checkpoint_tensors
 
-            sd = load_file(str(path / "model.safetensors"))
+            sd = load_checkpoint_tensors(path)
             sd = {(k if k.startswith("model.") else "model." + k): v for k, v in sd.items() if k != "proj_out.weight"}
             model.engine.load_state_dict(sd)
             model.engine.refresh_derived()

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Evaluate a speech model (greedy CTC) — key=value surface of R/src/scripts/evaluate_model.py:
+"""Evaluate a speech model (wav2vec2: greedy CTC; Whisper: greedy generation, language=danish task=transcribe) — key=value surface of R/src/scripts/evaluate_model.py:
     python scripts/evaluate_model.py model_id=models/wav2vec2-small-2026-10-02 batch_size=8
 """
 import logging

@@ -1,0 +1,62 @@
+"""One rank of the 2-process engine test (tests/test_dp_gpu.py).  Started through torch.distributed.run; both ranks
+share cuda:0 (the GPU box has one device), the process group is gloo.  Runs real `DataParallelTrainer` steps on the
+wav2vec2 engine with its shard of the global batch and writes {losses, parameters, gradient norm} for the test."""
+import os
+import sys
+from pathlib import Path
+
+import torch
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+
+
+def build_case():
+    """Engine + global batch shared by the worker and the 1-rank comparison in the test."""
+    from coral_amd.wav2vec2 import Wav2Vec2CTCEngine, Wav2Vec2Shape
+    from oracle import wav2vec2_ref as ref  # test infrastructure: the seeded parameters and the host featuriser only
+
+    kw = dict(hidden_size=128, num_hidden_layers=3, num_attention_heads=4, intermediate_size=256)
+    cfg = ref.W2V2Config(**kw)
+    eng = Wav2Vec2CTCEngine(Wav2Vec2Shape(**kw), "cuda:0")
+    eng.load_state_dict(ref.synth_params(cfg))
+    g = torch.Generator().manual_seed(99)
+    lens, lab_lens = [4000, 3600, 3200, 4000], [5, 4, 3, 6]
+    waves = [(0.1 * torch.randn(n, generator=g)).numpy() for n in lens]
+    labels = torch.full((4, 6), -100, dtype=torch.long)
+    for b, L in enumerate(lab_lens):
+        labels[b, :L] = torch.randint(0, 42, (L,), generator=g)
+
+    def shard(idx):
+        iv, am = ref.zero_mean_unit_var_norm([waves[i] for i in idx])
+        return dict(input_values=torch.from_numpy(iv), attention_mask=torch.from_numpy(am).long(), labels=labels[idx])
+
+    return eng, shard
+
+
+def main():
+    out_dir, wire, steps = Path(sys.argv[1]), sys.argv[2], int(sys.argv[3])
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    torch.cuda.set_device(0)
+    torch.distributed.init_process_group("gloo")
+    from coral_amd.trainer import DataParallelTrainer, shard_indices
+
+    eng, shard = build_case()
+    tr = DataParallelTrainer(eng, learning_rate=1e-3, warmup_steps=0, max_steps=100, max_grad_norm=1.0,
+                             compress_grads=(wire == "bf16"))
+    assert tr.world == world and tr.overlap
+    mb = shard(shard_indices(4, rank, world))
+    losses, norms = [], []
+    for _ in range(steps):
+        losses.append(float(tr.train_step([mb])))
+        norms.append(tr.grad_norm())
+    tr.finish()
+    torch.cuda.synchronize()
+    torch.save(dict(losses=losses, norms=norms, p32=eng.store.p32.cpu(), p16=eng.store.p16.float().cpu()),
+               out_dir / f"rank{rank}.pt")
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,63 @@
+"""The multi-GPU engine path with two real ranks: two processes, one process group (gloo; the GPU box
+has a single device, both ranks run on cuda:0), two optimiser steps of `DataParallelTrainer` on the wav2vec2 engine with
+the backward-hooked per-bucket all-reduce, per-bucket norms on the communication stream and the per-bucket AdamW.
+
+DDP semantics being matched (accelerate -> torch DDP under R/src/scripts/finetune_asr_model.py:9-12, $TF/trainer.py:
+1750-1759,1961): gradients averaged over ranks, clip + AdamW replicated  =>  replicas stay bit-identical, and the run
+equals ONE rank stepping on the two shards as two accumulation micro-batches (loss and gradients scaled by 1/2).
+"""
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def _run_two_ranks(tmp_path, wire, steps=2):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--nnodes=1", "--nproc-per-node=2",
+           "--local-addr", "127.0.0.1", str(ROOT / "tests" / "dp_worker.py"), str(tmp_path), wire, str(steps)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return [torch.load(tmp_path / f"rank{k}.pt") for k in range(2)]
+
+
+def _single_rank_reference(steps=2):
+    sys.path.insert(0, str(ROOT / "tests"))
+    import dp_worker
+
+    from coral_amd.trainer import DataParallelTrainer
+
+    eng, shard = dp_worker.build_case()
+    tr = DataParallelTrainer(eng, learning_rate=1e-3, warmup_steps=0, max_steps=100, max_grad_norm=1.0, grad_accum=2)
+    losses, norms = [], []
+    for _ in range(steps):
+        losses.append(float(tr.train_step([shard([0, 1]), shard([2, 3])])))
+        norms.append(tr.grad_norm())
+    tr.finish()
+    torch.cuda.synchronize()
+    return losses, norms, eng.store.p32.cpu()
+
+
+@pytest.mark.parametrize("wire", ["fp32", "bf16"])
+def test_two_ranks_match_one_rank_accumulating(tmp_path, wire):
+    r0, r1 = _run_two_ranks(tmp_path, wire)
+    # replicas: identical parameters (fp32 master and bf16 compute copy), bit for bit
+    assert torch.equal(r0["p32"], r1["p32"]) and torch.equal(r0["p16"], r1["p16"])
+    assert r0["norms"] == r1["norms"]
+    losses, norms, p32 = _single_rank_reference()
+    lr = 1e-3
+    tol = 1e-5 if wire == "fp32" else 2e-3   # the bf16 wire rounds each rank's gradient to 8 bits once
+    for s in range(2):
+        mean = 0.5 * (r0["losses"][s] + r1["losses"][s])  # the 1-rank run returns sum(loss_i / 2)
+        assert abs(mean - losses[s]) <= (1e-6 if s == 0 else 10 * tol) * abs(losses[s]), (s, mean, losses[s])
+        assert abs(r0["norms"][s] - norms[s]) <= 10 * tol * norms[s], (s, r0["norms"][s], norms[s])
+    # after two AdamW steps of size <= lr each: nearly every parameter moved exactly as in the 1-rank run
+    d = (r0["p32"] - p32).abs()
+    assert float(d.max()) <= 2.5 * lr
+    close = float((d <= 0.05 * lr).float().mean())
+    assert close >= (0.995 if wire == "fp32" else 0.9), close
+    assert float((r0["p32"] - p32).norm() / (2 ** 0.5 * lr * p32.numel() ** 0.5)) <= (0.02 if wire == "fp32" else 0.2)

@@ -96,3 +96,46 @@ def test_early_gradient_norm_pass_matches_the_single_pass():
     assert all(a > 0.05 for a in n0), n0  # the clip is active, so the norm matters
     assert np.allclose(n0, n1, rtol=1e-5), (n0, n1)
     assert torch.allclose(p0, p1, rtol=0, atol=2e-6)
+
+
+def test_checkpoints_rotate_and_resume_continues_the_run(tmp_path, monkeypatch):
+    """`save_steps` / `save_total_limit` / `resume_from_checkpoint` (R/src/coral/wav2vec2.py:224-236,244,
+    R/src/coral/finetune.py:79): a run stopped at step 4 and resumed to step 6 ends with the parameters of an
+    uninterrupted 6-step run (no host-drawn randomness in this configuration, data order continued), and the
+    synthetic stream covers per-device batch x accumulation x steps examples (it restarts instead of running dry)."""
+    import sys
+    from pathlib import Path
+
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1] / "scripts"))
+    import finetune_asr_model
+
+    from coral_amd import modeling
+
+    monkeypatch.setitem(modeling.HUB_SHAPES, "facebook/wav2vec2-xls-r-300m",
+                        dict(hidden_size=128, num_hidden_layers=2, intermediate_size=256, num_attention_heads=4))
+    common = ["model=test-wav2vec2", "datasets=synthetic", f"models_dir={tmp_path}", "total_batch_size=4",
+              "per_device_batch_size=2", "max_seconds_per_example=2.0", "min_seconds_per_example=1.0", "logging_steps=1",
+              "eval_steps=100", "model.freeze_feature_encoder=false", "model.mask_time_prob=0.0",
+              "model.mask_feature_prob=0.0", "model.activation_dropout=0.0", "model.layerdrop=0.0", "warmup_steps=2",
+              "save_steps=2", "save_total_limit=2"]
+    full = finetune_asr_model.main(common + ["model_id=full", "max_steps=6"])
+    assert full["steps_done"] == 6 and full["trainer"].grad_accum == 2  # 2 micro-batches per step, 24 examples used
+    names = sorted(p.name for p in (tmp_path / "full").glob("checkpoint-*"))
+    assert names == ["checkpoint-4", "checkpoint-6"]                     # rotation keeps the newest two
+    first = finetune_asr_model.main(common + ["model_id=part", "max_steps=4"])
+    assert first["steps_done"] == 4
+    # the interrupted run's schedule must be the 6-step one for the comparison: resume with max_steps=6
+    part = finetune_asr_model.main(common + ["model_id=part", "max_steps=6", "resume_from_checkpoint=true"])
+    assert part["steps_done"] == 6 and part["trainer"].opt_step == 6
+    assert [h["step"] for h in part["history"] if "loss" in h] == [5, 6]
+    a, b = full["model"].engine.store.p32, part["model"].engine.store.p32
+    # steps 1-4 of `part` ran under a 4-step cosine schedule, so only closeness (not equality) is expected there;
+    # what resume must guarantee is that optimiser moments, step count and data position were restored:
+    la = [h["loss"] for h in full["history"] if "loss" in h]
+    lb = [h["loss"] for h in part["history"] if "loss" in h]
+    assert abs(la[4] - lb[0]) <= 0.05 * abs(la[4]) and abs(la[5] - lb[1]) <= 0.05 * abs(la[5]), (la, lb)
+    assert float((a - b).abs().max()) <= 5e-3
+    # exact continuation: same schedule in both runs (max_steps=6 from the start, stopped by a save at step 4)
+    part2 = finetune_asr_model.main(common + ["model_id=full", "max_steps=6", "resume_from_checkpoint=" + str(tmp_path / "full" / "checkpoint-4")])
+    assert torch.equal(part2["model"].engine.store.p32, a)
+    assert [round(h["loss"], 6) for h in part2["history"] if "loss" in h] == [round(x, 6) for x in la[4:]]

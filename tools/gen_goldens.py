@@ -11,7 +11,7 @@ Weights: no checkpoints exist offline, so every parameter is overwritten with
 oracle.wav2vec2_ref.synth_params (name-keyed seeded values) — the tests regenerate the same
 weights instead of storing them.
 
-usage: python tools/gen_goldens.py [w2v2_tiny ctc featext tokenizer w2v2_cfg1 logmel whisper_tiny]
+usage: python tools/gen_goldens.py [w2v2_tiny ctc featext tokenizer w2v2_cfg1 logmel whisper_tiny whisper_mid hf_ckpt]
 """
 
 from __future__ import annotations
@@ -393,6 +393,155 @@ def gen_whisper_tiny():
     out["greedy_ids"] = ids.numpy()
     np.savez_compressed(GOLD / "whisper_tiny.npz", **out)
     print("whisper_tiny: loss", out["loss"], "greedy", ids.tolist())
+
+
+def gen_whisper_mid():
+    """A medium-depth Whisper (6 + 6 layers, d = 512, 8 heads of 64, ffn 2048): the fixture behind the GPU test of bf16
+    error accumulation through a deeper encoder / decoder stack (tests/test_depth_gpu.py)."""
+    from transformers import WhisperConfig, WhisperForConditionalGeneration
+
+    from oracle import whisper_ref as wref
+
+    kw = dict(d_model=512, encoder_layers=6, decoder_layers=6, encoder_attention_heads=8, decoder_attention_heads=8,
+              encoder_ffn_dim=2048, decoder_ffn_dim=2048, num_mel_bins=80, vocab_size=2000, max_target_positions=64,
+              pad_token_id=1950, decoder_start_token_id=1951, eos_token_id=1950)
+    c = wref.WhisperConfig(**kw)
+    hc = WhisperConfig(d_model=512, encoder_layers=6, decoder_layers=6, encoder_attention_heads=8,
+                       decoder_attention_heads=8, encoder_ffn_dim=2048, decoder_ffn_dim=2048, num_mel_bins=80,
+                       vocab_size=2000, max_source_positions=1500, max_target_positions=64, pad_token_id=1950,
+                       bos_token_id=1950, eos_token_id=1950, decoder_start_token_id=1951, dropout=0.0,
+                       attention_dropout=0.0, activation_dropout=0.0, encoder_layerdrop=0.0, decoder_layerdrop=0.0,
+                       apply_spec_augment=False, attn_implementation="eager", suppress_tokens=[],
+                       begin_suppress_tokens=[])
+    model = WhisperForConditionalGeneration(hc)
+    P = wref.synth_params(c)
+    sd = model.state_dict()
+    with torch.no_grad():
+        for k, v in P.items():
+            assert sd[k].shape == v.shape, (k, sd[k].shape, v.shape)
+            sd[k].copy_(v)
+    model.eval()
+    g = torch.Generator().manual_seed(11)
+    feats = torch.randn(2, 80, 3000, generator=g) * 0.5
+    labels = torch.randint(0, 1950, (2, 14), generator=g)
+    labels[1, 10:] = -100
+    res = model(input_features=feats, labels=labels)
+    res.loss.backward()
+    enc = model.model.encoder(feats).last_hidden_state
+    named = dict(model.named_parameters())
+    out = {"labels": labels.numpy(), "loss": res.loss.detach().numpy(), "logits": res.logits.detach().numpy(),
+           "enc_slice": enc.detach()[:, ::50, :].numpy(), "enc_abs_mean": enc.detach().abs().mean().numpy()}
+    for name in ["model.decoder.embed_tokens.weight", "model.encoder.conv1.weight",
+                 "model.encoder.layers.0.self_attn.q_proj.weight", "model.encoder.layers.5.fc2.weight",
+                 "model.decoder.layers.0.encoder_attn.k_proj.weight", "model.decoder.layers.5.fc1.weight"]:
+        out["gradnorm:" + name] = named[name].grad.norm().detach().numpy()
+    prefix = [1951, 1960, 1961, 1962]
+    ids = torch.tensor([prefix, prefix])
+    done = torch.zeros(2, dtype=torch.bool)
+    with torch.no_grad():
+        while ids.shape[1] < 24 and not bool(done.all()):
+            lg = model(input_features=feats, decoder_input_ids=ids).logits[:, -1].clone()
+            lg[:, [1970, 1971]] = float("-inf")
+            if ids.shape[1] == len(prefix):
+                lg[:, [20, 1950]] = float("-inf")
+            nxt = lg.argmax(-1)
+            nxt = torch.where(done, torch.full_like(nxt, 1950), nxt)
+            ids = torch.cat([ids, nxt[:, None]], 1)
+            done |= nxt == 1950
+    out["greedy_ids"] = ids.numpy()
+    np.savez_compressed(GOLD / "whisper_mid.npz", **out)
+    print("whisper_mid: loss", out["loss"], "greedy", ids.tolist())
+
+
+TINY_CKPT_W2V2 = dict(hidden_size=64, num_hidden_layers=2, num_attention_heads=4, intermediate_size=128,
+                      conv_dim=(512, 32, 32, 32, 32, 32, 32), num_conv_pos_embeddings=16, num_conv_pos_embedding_groups=4)
+
+
+def gen_hf_ckpt():
+    """N2: model directories WRITTEN BY TRANSFORMERS, loaded by the engine's `from_pretrained` in
+    tests/test_ckpt_gpu.py (R/src/coral/wav2vec2.py:253-305, R/src/coral/whisper.py:234-267 read exactly such
+    directories).  Weights are HF's own random init (torch.manual_seed), rounded to fp16 so the files stay small; the
+    golden outputs are computed in fp32 from the same rounded weights.
+      hf_ckpt_w2v2/           Wav2Vec2ForCTC.save_pretrained (safetensors)
+      hf_ckpt_w2v2_pretrain/  a head-less Wav2Vec2ForPreTraining state dict as `pytorch_model.bin` with the
+                              pre-parametrize weight-norm names (weight_g / weight_v) and quantizer / project_* extras
+      hf_ckpt_whisper/        WhisperForConditionalGeneration.save_pretrained (tied proj_out)"""
+    import shutil
+
+    from transformers import (Wav2Vec2Config, Wav2Vec2ForCTC, Wav2Vec2ForPreTraining, WhisperConfig,
+                              WhisperForConditionalGeneration)
+
+    torch.manual_seed(77)
+    kw = dict(TINY_CKPT_W2V2)
+    hc = Wav2Vec2Config(**{**kw, "conv_dim": list(kw["conv_dim"])}, feat_extract_norm="layer", conv_bias=True,
+                        do_stable_layer_norm=True, vocab_size=46, pad_token_id=45, ctc_loss_reduction="sum",
+                        ctc_zero_infinity=True, layerdrop=0.0, hidden_dropout=0.0, activation_dropout=0.0,
+                        attention_dropout=0.0, feat_proj_dropout=0.0, final_dropout=0.0, apply_spec_augment=False,
+                        attn_implementation="eager")
+    model = Wav2Vec2ForCTC(hc).half().float().eval()
+    with torch.no_grad():  # HF initialises lm_head / biases to values that make the comparison weak: perturb
+        for n, p_ in model.named_parameters():
+            if n.endswith(".bias") or n.endswith("layer_norm.weight"):
+                p_.add_(0.05 * torch.randn_like(p_))
+        model.half().float()
+    g = torch.Generator().manual_seed(5)
+    waves = [(0.1 * torch.randn(n, generator=g)).numpy() for n in (4000, 3300)]
+    iv, am = ref.zero_mean_unit_var_norm(waves)
+    labels = torch.tensor([[3, 7, 7, 1], [9, 2, -100, -100]])
+    out = model(input_values=torch.from_numpy(iv), attention_mask=torch.from_numpy(am).long(), labels=labels,
+                output_hidden_states=True)
+    d = GOLD / "hf_ckpt_w2v2"
+    shutil.rmtree(d, ignore_errors=True)
+    model.half().save_pretrained(d)
+    model.float()
+    np.savez_compressed(GOLD / "hf_ckpt_w2v2.npz", logits=out.logits.detach().numpy(), loss=out.loss.detach().numpy(),
+                        last_hidden=out.hidden_states[-1].detach().numpy(), lens=np.array([4000, 3300]),
+                        labels=labels.numpy())
+    # head-less pretraining checkpoint, legacy file and names
+    torch.manual_seed(78)
+    pre = Wav2Vec2ForPreTraining(hc).half().float().eval()
+    with torch.no_grad():
+        hid = pre.wav2vec2(input_values=torch.from_numpy(iv), attention_mask=torch.from_numpy(am).long()).last_hidden_state
+    sd = {}
+    for k, v in pre.state_dict().items():
+        k = k.replace("parametrizations.weight.original0", "weight_g").replace("parametrizations.weight.original1", "weight_v")
+        sd[k] = v.half().clone()
+    d = GOLD / "hf_ckpt_w2v2_pretrain"
+    shutil.rmtree(d, ignore_errors=True)
+    d.mkdir(parents=True)
+    torch.save(sd, d / "pytorch_model.bin")
+    cfgd = json.loads((GOLD / "hf_ckpt_w2v2" / "config.json").read_text())
+    cfgd["architectures"] = ["Wav2Vec2ForPreTraining"]
+    cfgd.pop("vocab_size", None)
+    cfgd["vocab_size"] = 32  # the pretraining config's placeholder: the finetune overrides it (R/src/coral/wav2vec2.py:124)
+    (d / "config.json").write_text(json.dumps(cfgd, indent=1))
+    np.savez_compressed(GOLD / "hf_ckpt_w2v2_pretrain.npz", last_hidden=hid.numpy(),
+                        extra_keys=np.array(sorted(k for k in sd if not k.startswith("wav2vec2."))))
+    # Whisper
+    torch.manual_seed(79)
+    wc = WhisperConfig(d_model=64, encoder_layers=2, decoder_layers=2, encoder_attention_heads=4,
+                       decoder_attention_heads=4, encoder_ffn_dim=128, decoder_ffn_dim=128, num_mel_bins=80,
+                       vocab_size=200, max_source_positions=1500, max_target_positions=64, pad_token_id=150,
+                       bos_token_id=150, eos_token_id=150, decoder_start_token_id=151, dropout=0.0,
+                       attention_dropout=0.0, activation_dropout=0.0, encoder_layerdrop=0.0, decoder_layerdrop=0.0,
+                       apply_spec_augment=False, attn_implementation="eager", suppress_tokens=[],
+                       begin_suppress_tokens=[])
+    wm = WhisperForConditionalGeneration(wc).half().float().eval()
+    with torch.no_grad():
+        for n, p_ in wm.named_parameters():
+            if p_.requires_grad and (n.endswith(".bias") or n.endswith("layer_norm.weight")):
+                p_.add_(0.05 * torch.randn_like(p_))
+        wm.half().float()
+    feats = torch.randn(2, 80, 3000, generator=g) * 0.5
+    wl = torch.randint(0, 150, (2, 9), generator=g)
+    res = wm(input_features=feats, labels=wl)
+    d = GOLD / "hf_ckpt_whisper"
+    shutil.rmtree(d, ignore_errors=True)
+    wm.half().save_pretrained(d)
+    np.savez_compressed(GOLD / "hf_ckpt_whisper.npz", logits=res.logits.detach().numpy(), loss=res.loss.detach().numpy(),
+                        labels=wl.numpy(), feats_seed=np.array(5))
+    for dd in ("hf_ckpt_w2v2", "hf_ckpt_w2v2_pretrain", "hf_ckpt_whisper"):
+        print(dd, {f.name: f.stat().st_size for f in (GOLD / dd).iterdir()})
 
 
 if __name__ == "__main__":
