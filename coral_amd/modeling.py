@@ -155,7 +155,12 @@ class Wav2Vec2ForCTC:
                    activation_dropout=s.activation_dropout, layerdrop=s.layerdrop, layer_norm_eps=s.layer_norm_eps,
                    **{k: v for k, v in self.spec.items()})
         (model_dir / "config.json").write_text(json.dumps(cfg, indent=2))
-        _save_safetensors(self.engine.state_dict(), model_dir / "model.safetensors")
+        sd = self.engine.state_dict()
+        if not (float(self.spec.get("mask_time_prob", 0.0)) > 0.0 or float(self.spec.get("mask_feature_prob", 0.0)) > 0.0):
+            # HF only creates `masked_spec_embed` when one of the two probabilities is positive
+            # ($TF/models/wav2vec2/modeling_wav2vec2.py, Wav2Vec2Model.__init__): keep the file's key set identical
+            sd.pop("wav2vec2.masked_spec_embed", None)
+        _save_safetensors(sd, model_dir / "model.safetensors")
 
     # ---- nn.Module-like surface --------------------------------------------------------------
     def train(self, mode=True):

@@ -19,4 +19,4 @@ def test_engine_saved_checkpoints_load_in_transformers(golden_dir):
 
     res = check_ckpt_with_hf.main(golden_dir)
     assert set(res) == {"wav2vec2", "whisper"}
-    assert res["wav2vec2"]["logits_max_abs_err"] <= 3e-2 and res["whisper"]["logits_max_abs_err"] <= 5e-2
+    assert res["wav2vec2"]["logits_max_abs_err"] <= 5e-2 and res["whisper"]["logits_max_abs_err"] <= 5e-2

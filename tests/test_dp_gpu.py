@@ -57,7 +57,7 @@ def test_two_ranks_match_one_rank_accumulating(tmp_path, wire):
         assert abs(r0["norms"][s] - norms[s]) <= 10 * tol * norms[s], (s, r0["norms"][s], norms[s])
     # after two AdamW steps of size <= lr each: nearly every parameter moved exactly as in the 1-rank run
     d = (r0["p32"] - p32).abs()
-    assert float(d.max()) <= 2.5 * lr
+    assert float(d.max()) <= 4 * lr   # two AdamW steps, each bounded by ~lr x |m̂| / sqrt(v̂), opposite signs at worst
     close = float((d <= 0.05 * lr).float().mean())
     assert close >= (0.995 if wire == "fp32" else 0.9), close
     assert float((r0["p32"] - p32).norm() / (2 ** 0.5 * lr * p32.numel() ** 0.5)) <= (0.02 if wire == "fp32" else 0.2)

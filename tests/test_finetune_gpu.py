@@ -100,8 +100,8 @@ def test_early_gradient_norm_pass_matches_the_single_pass():
 
 def test_checkpoints_rotate_and_resume_continues_the_run(tmp_path, monkeypatch):
     """`save_steps` / `save_total_limit` / `resume_from_checkpoint` (R/src/coral/wav2vec2.py:224-236,244,
-    R/src/coral/finetune.py:79): a run stopped at step 4 and resumed to step 6 ends with the parameters of an
-    uninterrupted 6-step run (no host-drawn randomness in this configuration, data order continued), and the
+    R/src/coral/finetune.py:79): a run resumed from its step-4 checkpoint ends, bit for bit, with the
+    parameters and losses of the uninterrupted 6-step run (no host-drawn randomness in this configuration, data order continued), and the
     synthetic stream covers per-device batch x accumulation x steps examples (it restarts instead of running dry)."""
     import sys
     from pathlib import Path
@@ -122,20 +122,14 @@ def test_checkpoints_rotate_and_resume_continues_the_run(tmp_path, monkeypatch):
     assert full["steps_done"] == 6 and full["trainer"].grad_accum == 2  # 2 micro-batches per step, 24 examples used
     names = sorted(p.name for p in (tmp_path / "full").glob("checkpoint-*"))
     assert names == ["checkpoint-4", "checkpoint-6"]                     # rotation keeps the newest two
-    first = finetune_asr_model.main(common + ["model_id=part", "max_steps=4"])
-    assert first["steps_done"] == 4
-    # the interrupted run's schedule must be the 6-step one for the comparison: resume with max_steps=6
-    part = finetune_asr_model.main(common + ["model_id=part", "max_steps=6", "resume_from_checkpoint=true"])
-    assert part["steps_done"] == 6 and part["trainer"].opt_step == 6
-    assert [h["step"] for h in part["history"] if "loss" in h] == [5, 6]
-    a, b = full["model"].engine.store.p32, part["model"].engine.store.p32
-    # steps 1-4 of `part` ran under a 4-step cosine schedule, so only closeness (not equality) is expected there;
-    # what resume must guarantee is that optimiser moments, step count and data position were restored:
+    a = full["model"].engine.store.p32.clone()
     la = [h["loss"] for h in full["history"] if "loss" in h]
-    lb = [h["loss"] for h in part["history"] if "loss" in h]
-    assert abs(la[4] - lb[0]) <= 0.05 * abs(la[4]) and abs(la[5] - lb[1]) <= 0.05 * abs(la[5]), (la, lb)
-    assert float((a - b).abs().max()) <= 5e-3
     # exact continuation: same schedule in both runs (max_steps=6 from the start, stopped by a save at step 4)
     part2 = finetune_asr_model.main(common + ["model_id=full", "max_steps=6", "resume_from_checkpoint=" + str(tmp_path / "full" / "checkpoint-4")])
     assert torch.equal(part2["model"].engine.store.p32, a)
-    assert [round(h["loss"], 6) for h in part2["history"] if "loss" in h] == [round(x, 6) for x in la[4:]]
+    assert part2["steps_done"] == 6 and part2["trainer"].opt_step == 6
+    assert [h["step"] for h in part2["history"] if "loss" in h] == [5, 6]
+    assert [h["loss"] for h in part2["history"] if "loss" in h] == la[4:]
+    # resume_from_checkpoint=true picks the newest checkpoint (step 6 = the end of the run): nothing left to do
+    done = finetune_asr_model.main(common + ["model_id=full", "max_steps=6", "resume_from_checkpoint=true"])
+    assert done["steps_done"] == 6 and torch.equal(done["model"].engine.store.p32, a)
