@@ -65,7 +65,12 @@ def load_checkpoint(model, trainer, ckpt: Path) -> dict:
     eng = trainer.engine
     if any(k.startswith("model.") for k in sd) or hasattr(eng, "exported_names"):
         sd = {(k if k.startswith("model.") else "model." + k): v for k, v in sd.items() if k != "proj_out.weight"}
-    eng.load_state_dict(sd)
+    if hasattr(eng, "exported_names"):
+        eng.load_state_dict(sd)
+    else:  # wav2vec2: `masked_spec_embed` is only in the file when SpecAugment is configured (as HF saves it)
+        rep = eng.load_state_dict(sd, strict=False)
+        if [n for n in rep["missing"] if n != "wav2vec2.masked_spec_embed"]:
+            raise KeyError(f"{ckpt}: checkpoint lacks {rep['missing']}")
     if hasattr(eng, "refresh_derived"):
         eng.refresh_derived()
     opt = load_file(str(ckpt / "optimizer.safetensors"))
