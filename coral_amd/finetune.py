@@ -68,7 +68,7 @@ def load_checkpoint(model, trainer, ckpt: Path) -> dict:
     if hasattr(eng, "exported_names"):
         eng.load_state_dict(sd)
     else:  # wav2vec2: `masked_spec_embed` is only in the file when SpecAugment is configured (as HF saves it)
-        rep = eng.load_state_dict(sd, strict=False)
+        rep = eng.load_state_dict(sd, strict=False, init_missing=False)
         if [n for n in rep["missing"] if n != "wav2vec2.masked_spec_embed"]:
             raise KeyError(f"{ckpt}: checkpoint lacks {rep['missing']}")
     if hasattr(eng, "refresh_derived"):

@@ -195,7 +195,7 @@ class Wav2Vec2CTCEngine:
         self.zero_embed = torch.zeros(d, dtype=torch.bfloat16, device=dev)
 
     # ---- parameters ------------------------------------------------------------------------
-    def load_state_dict(self, P: dict, strict: bool = True, seed: int = 4242) -> dict:
+    def load_state_dict(self, P: dict, strict: bool = True, seed: int = 4242, init_missing: bool = True) -> dict:
         """Copy HF-named fp32 tensors into the flat master buffer and refresh compute copies.
 
         strict=False follows `PreTrainedModel.from_pretrained` for the checkpoints CoRal finetunes from
@@ -205,7 +205,7 @@ class Wav2Vec2CTCEngine:
         unexpected keys (`quantizer.*`, `project_q.*`, `project_hid.*` of the pretraining head) are ignored, and a
         missing or differently sized `lm_head.*` / `masked_spec_embed` is initialised from `seed` the way HF's
         `_init_weights` does (Linear: N(0, 0.02), zero bias; masked_spec_embed: U(0, 1)).  Anything else that is
-        missing still raises.  Returns {"missing": [...], "unexpected": [...]} like `load_state_dict` of torch."""
+        missing still raises; init_missing=False leaves the tolerated missing tensors as they are.  Returns {"missing": [...], "unexpected": [...]} like `load_state_dict` of torch."""
         if not strict:
             if not any(k.startswith("wav2vec2.") or k.startswith("lm_head.") for k in P):
                 P = {"wav2vec2." + k: v for k, v in P.items()}
@@ -229,6 +229,8 @@ class Wav2Vec2CTCEngine:
         for n in names:
             v = self.store.view(n)
             if n in missing:
+                if not init_missing:
+                    continue  # keep the present value (resuming a run whose file follows HF's key set)
                 if n == "lm_head.weight":
                     v.normal_(0.0, 0.02, generator=g)
                 elif n == "lm_head.bias":

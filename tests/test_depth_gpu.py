@@ -13,7 +13,7 @@ Stated tolerances (bf16 storage / fp32 accumulation against fp32 CPU arithmetic;
                 which the 2-layer tests meet; DESIGN.md §2 puts the reference's own bf16-autocast path beside it),
                 cosine >= 0.9995
   loss          <= 1e-3 relative (the north-star bound, end to end through all 24 layers; measured 3.8e-4)
-  gradients     every tensor: norm within 5 % (the six named ones 3 %), cosine of the leading 512 elements >= 0.97
+  gradients     every tensor: norm within 5 % (the six named ones 3 %), cosine over 512 evenly spaced elements >= 0.97
 The measured values are printed (pytest -s) and recorded in DESIGN.md §2.
 """
 import numpy as np
@@ -73,7 +73,7 @@ def test_xlsr300m_cfg1_against_hf_fixture_and_oracle(golden_dir):
             print(f"  {key[9:]}: |g| {gn:.5f} vs {float(z[key]):.5f} (ratio {r:.4f})")
             assert 0.97 <= r <= 1.03, (key, gn, float(z[key]))
 
-    # --- the whole logits tensor and EVERY gradient tensor of the HF run (norm + leading 512 elements) ---
+    # --- the whole logits tensor and EVERY gradient tensor of the HF run (norm + 512 evenly spaced elements) ---
     # (the fixture carries them: re-running the fp32 reference arithmetic on the GPU box's host is not needed)
     logits_ref = torch.from_numpy(z["logits_full"])
     valid = torch.zeros(logits.shape[:2], dtype=torch.bool)
@@ -95,12 +95,12 @@ def test_xlsr300m_cfg1_against_hf_fixture_and_oracle(golden_dir):
         if name.endswith("k_proj.bias"):
             continue  # exactly zero in exact arithmetic (softmax shift invariance): rounding noise on both sides
         ratio = float(gq.norm()) / (float(z["grad_norms"][i]) + 1e-30)
-        n = min(512, gq.numel())
-        c = _cos(gq[:n].cpu(), torch.from_numpy(z["grad_heads"][i, :n]))
+        idx = torch.linspace(0, gq.numel() - 1, 512).long()
+        c = _cos(gq[idx.to(gq.device)].cpu(), torch.from_numpy(z["grad_samples"][i]))
         worst, worst_ratio = min(worst, c), max(worst_ratio, ratio, 1 / max(ratio, 1e-30))
         if not (c >= 0.97 and 0.95 <= ratio <= 1.05):
             bad.append((name, round(c, 4), round(ratio, 4)))
-    print(f"  {len(z['grad_names'])} gradient tensors: worst cosine (leading 512 elements) {worst:.5f}, "
+    print(f"  {len(z['grad_names'])} gradient tensors: worst cosine (512 evenly spaced elements) {worst:.5f}, "
           f"worst norm ratio {worst_ratio:.4f}")
     assert not bad, bad
 

@@ -256,13 +256,16 @@ def gen_w2v2_cfg1():
                  "wav2vec2.encoder.pos_conv_embed.conv.parametrizations.weight.original1"]:
         out["gradnorm:" + name] = sd[name].grad.norm().numpy()
     # for the GPU test at depth (tests/test_depth_gpu.py): the whole logits tensor, the norm of EVERY gradient tensor and
-    # the leading 512 elements of each (direction check) -- the fp32 reference does not have to be re-run on the GPU box
+    # 512 evenly spaced elements of each (direction check) -- the fp32 reference does not have to be re-run on the GPU box
     out["logits_full"] = res.logits.detach().numpy()
     names = [n for n, p_ in sd.items() if p_.grad is not None]
     out["grad_names"] = np.array(names)
     out["grad_norms"] = np.array([float(sd[n].grad.norm()) for n in names], dtype=np.float32)
-    out["grad_heads"] = np.stack([np.pad(sd[n].grad.flatten()[:512].numpy(), (0, max(0, 512 - sd[n].grad.numel())))
-                                  for n in names]).astype(np.float32)
+    def spread(t):  # 512 evenly spaced elements of the flattened tensor
+        t = t.flatten()
+        return t[torch.linspace(0, t.numel() - 1, 512).long()].numpy()
+
+    out["grad_samples"] = np.stack([spread(sd[n].grad) for n in names]).astype(np.float32)
     np.savez_compressed(GOLD / "w2v2_cfg1.npz", **out)
     print("w2v2_cfg1 loss", out["loss"], {k: float(v) for k, v in out.items() if k.startswith("gradnorm")})
 
