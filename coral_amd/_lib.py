@@ -111,6 +111,7 @@ SIGNATURES = {
     "ca_colsum_partial_floats": (_i64, [_i64, _i32]),
     "ca_colsum_bf16": (C.c_int, [_vp, _i64, _i64, _i32, _vp, _vp, _i32, _vp, _vp]),
     "ca_dgelu_mul": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
+    "ca_dropout_bf16": (C.c_int, [_vp, _vp, _i64, _f32, _u64, _vp]),
     "ca_reduce_rows_f32": (C.c_int, [_vp, _i32, _i64, _i32, _vp, _i32, _vp]),
     "ca_wave_normalize": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _f32, _vp]),
     "ca_frame_lengths": (C.c_int, [_vp, _i32, _i64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _i32, _vp, _vp]),

@@ -28,8 +28,19 @@ class Scratch:
         self.dqkv = _z(M * 3 * d, dev)
         self.du = _z(M * f, dev)
         self.dkv = _z(Mkv * 2 * d, dev) if Mkv else None
+        self.dm = _z(M * d, dev)  # dropout(dh): the gradient entering a sub-layer whose output was dropped (hidden dropout)
         npart = max(ops.layernorm_bwd_partial_floats(M, d), ops.colsum_partial_floats(max(M, Mkv), max(f, 3 * d)), 4096)
         self.part = _z(npart, dev, torch.float32)
+
+
+def _masked_grad(dh, sv, sc: "Scratch", n):
+    """Gradient wrt the sub-layer output: dh itself, or dropout(dh) with the forward's mask when the output went
+    through hidden-state dropout before the residual add."""
+    p, seed = sv.get("hdrop", (0.0, 0))
+    if p <= 0.0:
+        return dh
+    ops.dropout(dh, sc.dm, n, p, seed)
+    return sc.dm
 
 
 class SelfAttnBlock:
@@ -53,7 +64,7 @@ class SelfAttnBlock:
                     sqb=T * 3 * d, skb=T * 3 * d, svb=T * 3 * d, sob=T * d, q_off=0, k_off=d, v_off=2 * d, klen=klen,
                     causal=self.causal)
 
-    def forward(self, hin, hout, sv, B, T, klen=None):
+    def forward(self, hin, hout, sv, B, T, klen=None, hdrop=(0.0, 0)):
         st, d = self.st, self.d
         M = B * T
         fp8 = getattr(self, "fp8", None)  # (p8, scale, x8, rs): forward projection on the fp8 path
@@ -69,8 +80,9 @@ class SelfAttnBlock:
                      b_off=st.off(self.attn + "q_proj.weight"), bias=st.p32, bias_off=st.off(self.qbias))
         ops.attn_fwd(sv["qkv"], sv["qkv"], sv["qkv"], sv["ctx"], sv["lse"], **self._akw(B, T, sv, klen))
         ops.gemm(sv["ctx"], st.p16, hout, M=M, N=d, K=d, lda=d, ldb=d, ldc=d, b_off=st.off(self.attn + "out_proj.weight"),
-                 bias=st.p32, bias_off=st.off(self.attn + "out_proj.bias"), epilogue=EPI_RESIDUAL, R=hin, ldr=d)
-        sv["hin"], sv["klen"] = hin, klen
+                 bias=st.p32, bias_off=st.off(self.attn + "out_proj.bias"), epilogue=EPI_RESIDUAL, R=hin, ldr=d,
+                 dropout_p=hdrop[0], dropout_seed=hdrop[1])
+        sv["hin"], sv["klen"], sv["hdrop"] = hin, klen, hdrop
 
     def backward(self, dh, dhin, sv, sc: Scratch, B, T, defer=None):
         """dh: grad wrt h_out (kept intact); dhin: output buffer for grad wrt h_in (may alias nothing of sv).
@@ -79,12 +91,15 @@ class SelfAttnBlock:
         st, d = self.st, self.d
         M = B * T
         o, g32, p16 = st.off, st.g32, st.p16
+        dy = _masked_grad(dh, sv, sc, M * d)
+        if dy is not dh and defer is not None:
+            raise NotImplementedError("deferred weight gradients share sc.dm between blocks: launch them per block with hidden dropout")
         # with `defer` the bias gradients travel with the problems (fused into the grouped launch or done by it)
         if defer is None:
-            ops.colsum(dh, d, M, d, g32, sc.part, out_off=o(self.attn + "out_proj.bias"))
-        wg = [dict(dY=dh, X=sv["ctx"], M=d, N=d, K=M, lda=d, ldb=d, c_off=o(self.attn + "out_proj.weight"), accumulate=True,
+            ops.colsum(dy, d, M, d, g32, sc.part, out_off=o(self.attn + "out_proj.bias"))
+        wg = [dict(dY=dy, X=sv["ctx"], M=d, N=d, K=M, lda=d, ldb=d, c_off=o(self.attn + "out_proj.weight"), accumulate=True,
                    **(dict(bias_off=o(self.attn + "out_proj.bias"), part=sc.part, cs_off=3 * d) if defer is not None else {}))]
-        ops.gemm(dh, p16, sc.dctx, M=M, N=d, K=d, lda=d, b_layout=MNMAJOR, ldb=d, ldc=d, b_off=o(self.attn + "out_proj.weight"))
+        ops.gemm(dy, p16, sc.dctx, M=M, N=d, K=d, lda=d, b_layout=MNMAJOR, ldb=d, ldc=d, b_off=o(self.attn + "out_proj.weight"))
         qkv, dqkv = sv["qkv"], sc.dqkv
         ops.attn_bwd(qkv, qkv, qkv, sv["ctx"], sv["lse"], sc.dctx, sv["Dq"], dqkv, dqkv, dqkv, lddo=d, sdob=T * d, lddq=3 * d,
                      lddk=3 * d, lddv=3 * d, sdqb=T * 3 * d, sdkb=T * 3 * d, sdvb=T * 3 * d, dq_off=0, dk_off=d, dv_off=2 * d,
@@ -128,7 +143,7 @@ class CrossAttnBlock:
                  bias=st.p32, bias_off=st.off(self.attn + "k_proj.bias__zero"))
         sv["enc"] = enc
 
-    def forward(self, hin, hout, sv, B, L, Te):
+    def forward(self, hin, hout, sv, B, L, Te, hdrop=(0.0, 0)):
         st, d = self.st, self.d
         M = B * L
         ops.layernorm_fwd(hin, st.view(self.ln + ".weight"), st.view(self.ln + ".bias"), sv["x"], sv["st"], M, d, self.eps)
@@ -136,18 +151,20 @@ class CrossAttnBlock:
                  bias=st.p32, bias_off=st.off(self.attn + "q_proj.bias"))
         ops.attn_fwd(sv["q"], sv["kv"], sv["kv"], sv["ctx"], sv["lse"], **self._akw(B, L, Te, sv))
         ops.gemm(sv["ctx"], st.p16, hout, M=M, N=d, K=d, lda=d, ldb=d, ldc=d, b_off=st.off(self.attn + "out_proj.weight"),
-                 bias=st.p32, bias_off=st.off(self.attn + "out_proj.bias"), epilogue=EPI_RESIDUAL, R=hin, ldr=d)
-        sv["hin"] = hin
+                 bias=st.p32, bias_off=st.off(self.attn + "out_proj.bias"), epilogue=EPI_RESIDUAL, R=hin, ldr=d,
+                 dropout_p=hdrop[0], dropout_seed=hdrop[1])
+        sv["hin"], sv["hdrop"] = hin, hdrop
 
     def backward(self, dh, dhin, sv, sc: Scratch, denc32, B, L, Te):
         """denc32: fp32 [B*Te, d] accumulator of the gradient wrt the encoder states (+=)."""
         st, d = self.st, self.d
         M, Mk = B * L, B * Te
         o, g32, p16 = st.off, st.g32, st.p16
-        ops.colsum(dh, d, M, d, g32, sc.part, out_off=o(self.attn + "out_proj.bias"))
-        ops.wgrad_gemm(dh, sv["ctx"], g32, M=d, N=d, K=M, lda=d, ldb=d,
+        dy = _masked_grad(dh, sv, sc, M * d)
+        ops.colsum(dy, d, M, d, g32, sc.part, out_off=o(self.attn + "out_proj.bias"))
+        ops.wgrad_gemm(dy, sv["ctx"], g32, M=d, N=d, K=M, lda=d, ldb=d,
                        c_off=o(self.attn + "out_proj.weight"), accumulate=True)
-        ops.gemm(dh, p16, sc.dctx, M=M, N=d, K=d, lda=d, b_layout=MNMAJOR, ldb=d, ldc=d, b_off=o(self.attn + "out_proj.weight"))
+        ops.gemm(dy, p16, sc.dctx, M=M, N=d, K=d, lda=d, b_layout=MNMAJOR, ldb=d, ldc=d, b_off=o(self.attn + "out_proj.weight"))
         dq, dkv = sc.dx, sc.dkv
         ops.attn_bwd(sv["q"], sv["kv"], sv["kv"], sv["ctx"], sv["lse"], sc.dctx, sv["Dq"], dq, dkv, dkv, lddo=d, sdob=L * d,
                      lddq=d, lddk=2 * d, lddv=2 * d, sdqb=L * d, sdkb=Te * 2 * d, sdvb=Te * 2 * d, dk_off=0, dv_off=d,
@@ -176,7 +193,7 @@ class FFNBlock:
     def alloc(self, M, dev):
         return dict(x=_z(M * self.d, dev), st=_z(M * 2, dev, torch.float32), u=_z(M * self.f, dev), g=_z(M * self.f, dev))
 
-    def forward(self, hin, hout, sv, M, dropout_p=0.0, seed=0):
+    def forward(self, hin, hout, sv, M, dropout_p=0.0, seed=0, hdrop=(0.0, 0)):
         st, d, f = self.st, self.d, self.f
         fp8 = getattr(self, "fp8", None)
         if fp8 is not None:
@@ -192,18 +209,22 @@ class FFNBlock:
                      bias=st.p32, bias_off=st.off(self.fc1 + ".bias"), epilogue=EPI_GELU, dropout_p=dropout_p,
                      dropout_seed=seed)
         ops.gemm(sv["g"], st.p16, hout, M=M, N=d, K=f, lda=f, ldb=f, ldc=d, b_off=st.off(self.fc2 + ".weight"), bias=st.p32,
-                 bias_off=st.off(self.fc2 + ".bias"), epilogue=EPI_RESIDUAL, R=hin, ldr=d)
-        sv["hin"], sv["drop"] = hin, (dropout_p, seed)
+                 bias_off=st.off(self.fc2 + ".bias"), epilogue=EPI_RESIDUAL, R=hin, ldr=d, dropout_p=hdrop[0],
+                 dropout_seed=hdrop[1])
+        sv["hin"], sv["drop"], sv["hdrop"] = hin, (dropout_p, seed), hdrop
 
     def backward(self, dh, dhin, sv, sc: Scratch, M, defer=None):
         st, d, f = self.st, self.d, self.f
         o, g32, p16 = st.off, st.g32, st.p16
         p, seed = sv["drop"]
+        dy = _masked_grad(dh, sv, sc, M * d)
+        if dy is not dh and defer is not None:
+            raise NotImplementedError("deferred weight gradients share sc.dm between blocks: launch them per block with hidden dropout")
         if defer is None:
-            ops.colsum(dh, d, M, d, g32, sc.part, out_off=o(self.fc2 + ".bias"))
-        wg = [dict(dY=dh, X=sv["g"], M=d, N=f, K=M, lda=d, ldb=f, c_off=o(self.fc2 + ".weight"), accumulate=True,
+            ops.colsum(dy, d, M, d, g32, sc.part, out_off=o(self.fc2 + ".bias"))
+        wg = [dict(dY=dy, X=sv["g"], M=d, N=f, K=M, lda=d, ldb=f, c_off=o(self.fc2 + ".weight"), accumulate=True,
                    **(dict(bias_off=o(self.fc2 + ".bias"), part=sc.part, cs_off=4 * d + f) if defer is not None else {}))]
-        ops.gemm(dh, p16, sc.du, M=M, N=f, K=d, lda=d, b_layout=MNMAJOR, ldb=f, ldc=f, b_off=o(self.fc2 + ".weight"),
+        ops.gemm(dy, p16, sc.du, M=M, N=f, K=d, lda=d, b_layout=MNMAJOR, ldb=f, ldc=f, b_off=o(self.fc2 + ".weight"),
                  epilogue=EPI_DGELU, R=sv["u"], ldr=f, dropout_p=p, dropout_seed=seed)
         if defer is None:
             ops.colsum(sc.du, f, M, f, g32, sc.part, out_off=o(self.fc1 + ".bias"))

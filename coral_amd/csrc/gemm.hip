@@ -433,7 +433,7 @@ __device__ __forceinline__ void gemm_epilogue(const CaGemmDesc& d, f32x4_t (&acc
       }
     }
     unsigned int keep = 0xFFu;
-    if (d.dropout_p > 0.f && (has_gelu || epi == CA_EPI_DGELU)) {
+    if (d.dropout_p > 0.f && (has_gelu || epi == CA_EPI_DGELU || epi == CA_EPI_RESIDUAL)) {
       const uint64_t idx = ((uint64_t)z * M + m) * (uint64_t)N + nb;
       if ((idx & 3) == 0) {  // aligned group: two hashes for the 8 elements
         keep = ca_dropout_keep4(d.dropout_seed, idx, d.dropout_p) |
@@ -452,6 +452,11 @@ __device__ __forceinline__ void gemm_epilogue(const CaGemmDesc& d, f32x4_t (&acc
         v2[e] = g + r[e];  // r is zero unless GELU_RESIDUAL
       }
     } else if (epi == CA_EPI_RESIDUAL) {
+      // C = R + dropout(alpha A.B + bias): hidden-state dropout on the sub-layer output before the residual add
+      if (d.dropout_p > 0.f) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = ((keep >> e) & 1u) ? v[e] * keep_scale : 0.f;
+      }
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] += r[e];
     } else if (epi == CA_EPI_DGELU) {

@@ -1,6 +1,7 @@
 // Small HBM-bound pieces: SpecAugment/padding masks, grouped-conv regrouping, weight-norm for
 // the positional conv, dtype casts / weight reorders, gradient-norm + fused AdamW, embeddings.
 #include "common.h"
+#include <cstdlib>
 
 // ---- SpecAugment + padding --------------------------------------------------------------------
 // $TF/models/wav2vec2/modeling_wav2vec2.py:1272-1316 (masked_spec_embed on time spans, zeros on
@@ -411,9 +412,35 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
     coef *= c < 1.f ? c : 1.f;
   }
   const float step_size = lr / bc1;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+  const float decay = 1.f - lr * wd;
+  // 16 bytes per lane and array (f32x4; 8 bytes of bf16): the flat buffers and every bucket offset are 32-byte aligned
+  const bool vec = ((((uintptr_t)p | (uintptr_t)m | (uintptr_t)v | (uintptr_t)g) & 15) == 0) && (!p16 || ((uintptr_t)p16 & 7) == 0);
+  const int64_t n4 = vec ? (n >> 2) : 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const f32x4_t g4 = ((const f32x4_t*)g)[i];
+    f32x4_t p4 = ((const f32x4_t*)p)[i], m4 = ((const f32x4_t*)m)[i], v4 = ((const f32x4_t*)v)[i];
+    u16x4_t h4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float gi = g4[e] * coef;
+      float pi = p4[e] * decay;
+      const float mi = b1 * m4[e] + (1.f - b1) * gi;
+      const float vi = b2 * v4[e] + (1.f - b2) * gi * gi;
+      const float denom = sqrtf(vi) / bc2_sqrt + eps;
+      pi -= step_size * mi / denom;
+      p4[e] = pi;
+      m4[e] = mi;
+      v4[e] = vi;
+      h4[e] = f2bf(pi);
+    }
+    ((f32x4_t*)p)[i] = p4;
+    ((f32x4_t*)m)[i] = m4;
+    ((f32x4_t*)v)[i] = v4;
+    if (p16) ((u16x4_t*)p16)[i] = h4;
+  }
+  for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const float gi = g[i] * coef;
-    float pi = p[i] * (1.f - lr * wd);
+    float pi = p[i] * decay;
     const float mi = b1 * m[i] + (1.f - b1) * gi;
     const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
     const float denom = sqrtf(vi) / bc2_sqrt + eps;
@@ -431,7 +458,12 @@ extern "C" int ca_adamw_step(float* p, float* m, float* v, const float* g, void*
   CA_CHECK_ARG(p && m && v && g && n > 0 && step >= 1, "ca_adamw_step: bad argument");
   const float bc1 = 1.f - powf(beta1, (float)step);
   const float bc2 = 1.f - powf(beta2, (float)step);
-  hipLaunchKernelGGL(adamw_kernel, dim3(ew_grid(n, 1)), dim3(256), 0, (hipStream_t)stream, p, m,
+  // CA_ADAMW_BLOCKS caps the grid (tuning knob): a smaller grid leaves CU slots and HBM bandwidth to the forward
+  // GEMMs this update overlaps with (trainer.py runs it bucket by bucket on a side stream)
+  static const int cap = [] { const char* e = getenv("CA_ADAMW_BLOCKS"); return e ? atoi(e) : 0; }();
+  int grid = ew_grid(n, 4);
+  if (cap > 0 && grid > cap) grid = cap;
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, m,
                      v, g, (unsigned short*)p16, n, lr, beta1, beta2, eps, weight_decay, bc1,
                      sqrtf(bc2), grad_scale, max_norm, gnorm_sq);
   CA_CHECK_LAUNCH("ca_adamw_step");

@@ -559,6 +559,35 @@ extern "C" int ca_dgelu_mul(const void* dy, const void* u, void* out, int64_t n,
   return CA_OK;
 }
 
+// Hidden-state dropout as an element-wise pass: y = x * keep / (1 - p) over a dense [rows, N] bf16 matrix, with the
+// keep decision of element (m, n) taken from (seed, m * N + n) exactly as the GEMM epilogue takes it
+// (gemm_epilogue: CA_EPI_RESIDUAL with dropout_p > 0), so the backward regenerates the forward's mask:
+// dY = dropout(dH) feeds the data- and weight-gradient GEMMs of the projection whose output was dropped
+// ($TF/models/whisper/modeling_whisper.py:398,406,479,493,502,625,763: nn.functional.dropout on the sub-layer output /
+// on the embedded inputs).  x == y is allowed (in place).
+__global__ void dropout_bf16_kernel(const unsigned short* __restrict__ x, unsigned short* __restrict__ y, int64_t n8,
+                                    float p, uint64_t seed) {
+  const float ks = 1.f / (1.f - p);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+    const u16x8_t a = *(const u16x8_t*)(x + i * 8);
+    const unsigned int keep = ca_dropout_keep4(seed, (uint64_t)i * 8, p) | (ca_dropout_keep4(seed, (uint64_t)i * 8 + 4, p) << 4);
+    u16x8_t o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = ((keep >> e) & 1u) ? f2bf(bf2f(a[e]) * ks) : (unsigned short)0;
+    *(u16x8_t*)(y + i * 8) = o;
+  }
+}
+extern "C" int ca_dropout_bf16(const void* x, void* y, int64_t n, float p, uint64_t seed, void* stream) {
+  CA_CHECK_ARG(x && y && n > 0 && (n % 8) == 0, "ca_dropout_bf16: n must be a positive multiple of 8");
+  CA_CHECK_ARG(p >= 0.f && p < 1.f, "ca_dropout_bf16: bad p");
+  int64_t g = (n / 8 + 255) / 256;
+  if (g > 8192) g = 8192;
+  hipLaunchKernelGGL(dropout_bf16_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x,
+                     (unsigned short*)y, n / 8, p, seed);
+  CA_CHECK_LAUNCH("ca_dropout_bf16");
+  return CA_OK;
+}
+
 // out[i] (+)= sum_p partial[p*stride + i]: public form of the partial-sum reduction
 extern "C" int ca_reduce_rows_f32(const float* partial, int32_t nparts, int64_t stride, int32_t n, float* out,
                                   int32_t accumulate, void* stream) {

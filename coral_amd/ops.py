@@ -257,6 +257,11 @@ def dgelu_mul(dy, u, out, n):
     check(lib().ca_dgelu_mul(_p(dy), _p(u), _p(out), n, _stream()), "ca_dgelu_mul")
 
 
+def dropout(x, y, n, p, seed):
+    """y = x * keep / (1 - p) with the mask of (seed, flat index) - the one the EPI_RESIDUAL epilogue applies."""
+    check(lib().ca_dropout_bf16(_p(x), _p(y), n, float(p), int(seed), _stream()), "ca_dropout_bf16")
+
+
 def wave_normalize(x, lengths, y, B, N, eps=1e-7):
     check(lib().ca_wave_normalize(_p(x), _p(lengths), _p(y), B, N, eps, _stream()),
           "ca_wave_normalize")

@@ -174,7 +174,11 @@ class DataParallelTrainer:
         # and let the next forward wait per bucket (engine._await) instead of for the whole optimiser.
         self.overlap_optimizer = (overlap_optimizer and st.p32.is_cuda and hasattr(engine, "_await")
                                   and (lo, hi) == (0, st.numel))
-        self.opt_stream = torch.cuda.Stream(device=st.device) if self.overlap_optimizer else None
+        self.opt_stream = None
+        if self.overlap_optimizer:
+            # the HBM-bound update only fills what the MFMA-bound forward leaves free: lowest queue priority
+            prio = int(os.environ.get("CA_OPT_PRIO", "0"))
+            self.opt_stream = torch.cuda.Stream(device=st.device, priority=prio)
         self.opt_done = None
         # per-bucket squared gradient norms, computed on the side stream as the buckets complete
         self.bucket_index = {name: i for i, name in enumerate(st.buckets)}
@@ -324,6 +328,11 @@ class DataParallelTrainer:
                     events[f"front_{part}"] = ev
             if "front" not in events:
                 eng.refresh_derived()
+            if hasattr(eng, "clear_small_grads") and not eng.freeze_base and self.grad_accum >= 1:
+                # the gradients are consumed: clear what the next backward accumulates into (front / head buckets and
+                # the layers' small tensors) here, under the next forward
+                eng.clear_small_grads()
+                eng._pre_zeroed = True
             self.opt_done = torch.cuda.Event()
             self.opt_done.record(self.opt_stream)
         eng.weights_ready = events

@@ -265,7 +265,18 @@ class Wav2Vec2CTCEngine:
         st = self.store
         if matrices:
             st.g32.zero_()
+            self._pre_zeroed = False
             return
+        if getattr(self, "_pre_zeroed", False):
+            # the trainer already cleared these slices on its optimiser stream, right behind the AdamW launches that
+            # consumed them (hidden under the forward instead of sitting in front of the backward)
+            self._pre_zeroed = False
+            return
+        self.clear_small_grads()
+
+    def clear_small_grads(self):
+        """Zero everything except the transformer layers' weight matrices (see zero_grad)."""
+        st = self.store
         for name in ("front", "head"):
             lo, hi = st.buckets[name]
             st.g32[lo:hi].zero_()
@@ -386,9 +397,15 @@ class Wav2Vec2CTCEngine:
         w["dB"] = z(M * d)
         w["dC"] = z(M * d)
         w["dqkv"] = z(M * 3 * d)
+        # second copies of the buffers the weight gradients read (dY operands): with the weight gradients on their own
+        # stream (backward()) a layer's dY must stay intact while the next layer's data gradients are being written
+        w["dBr"] = [w["dB"], z(M * d), z(M * d)]
+        w["dCr"] = [w["dC"], z(M * d)]
+        w["dqkvr"] = [w["dqkv"], z(M * 3 * d)]
         if not self.fused_attention:
             w["dS"] = z(B * H * T * Tp)
         w["du"] = z(M * f)
+        w["dur"] = [w["du"], z(M * f)]
         w["dxg"] = z(B * G * (T + K) * Cg + 8 * Cg)
         w["dwf"] = z(d * K * Cg, dt=f32)
         # partial column sums of the layer's four dY (fused bias gradients): rows that a problem with fewer than
@@ -405,6 +422,7 @@ class Wav2Vec2CTCEngine:
             ops.colsum_partial_floats(M, max(f, 3 * d)), ops.colsum_partial_floats(B * Ts[1], 512),
             ops.conv0_bwd_partial_floats(B, N, C0, s.conv_kernel[0], s.conv_stride[0]), 4096)
         w["partial"] = z(pf, dt=f32)
+        w["partial_w"] = z(pf, dt=f32)  # the weight-gradient stream's own scratch
         self._ws, self._ws_key = w, key
         return w
 
@@ -601,6 +619,33 @@ class Wav2Vec2CTCEngine:
         other = w["dA"]
         scale = hd ** -0.5
         drop_p = sv["drop_p"]
+        # Weight gradients on their own stream: dW = dY^T X feeds only the optimiser, so a layer's three weight-gradient
+        # launches (MFMA-bound, 256x256 tiles, one workgroup per CU) run beside the NEXT layer's data-gradient chain
+        # (128x128-tile GEMMs, attention backward, LayerNorm backward: VALU / HBM-bound kernels and GEMM tails that
+        # leave matrix pipes idle).  The dY operands rotate through two (three for dh) buffers; the main stream waits
+        # for the weight gradients of layer i before layer i+2 reuses their buffers.
+        ws = self._wgrad_stream()
+        main = torch.cuda.current_stream()
+        wdone = {}
+        it = 0
+        nb = 5 * d + f  # q|k|v, out, ffn1, ffn2 biases: contiguous in the flat buffer (w2v2_param_list)
+
+        def on_side(ready_event, fn):
+            """Run fn on the weight-gradient stream once `ready_event` (main stream) has passed."""
+            if ws is None:
+                fn()
+                return
+            ws.wait_event(ready_event)
+            with torch.cuda.stream(ws):
+                fn()
+
+        def mark():
+            if ws is None:
+                return None
+            ev = torch.cuda.Event()
+            ev.record(main)
+            return ev
+
         for l in reversed(range(L)):
             if not keep[l]:
                 if overwrite_matrices:  # dropped layer: its matrices get no gradient this step
@@ -610,53 +655,75 @@ class Wav2Vec2CTCEngine:
                 continue
             pl = f"wav2vec2.encoder.layers.{l}."
             hin = w["h"][l]
+            if ws is not None:
+                if it - 2 in wdone:
+                    main.wait_event(wdone.pop(it - 2))
+                dh_next, du, dh1, dqkv = w["dBr"][(it + 1) % 3], w["dur"][it & 1], w["dCr"][it & 1], w["dqkvr"][it & 1]
+            else:
+                dh_next, du, dh1, dqkv = dh, w["du"], w["dC"], w["dqkv"]
             # FFN2: h_out = h1 + W2 g + b2
             # (bias gradients = column sums of the same dY: taken inside the weight-gradient kernel where it runs
             # on the 256x256 tiles, see ops.wgrad_gemm)
-            # the four weight gradients of the layer are launched together at the end of the layer (one grouped
-            # launch: 240 + 240 + 184 + 64 tiles = 2.84 rounds of 256 CUs instead of four under-filled ones);
-            # dh, du, dh1 and dqkv all stay untouched until then
-            wg = [dict(dY=dh, X=w["g"][l], M=d, N=f, K=M, lda=d, ldb=f, part=part,
+            wg = [dict(dY=dh, X=w["g"][l], M=d, N=f, K=M, lda=d, ldb=f, part=w["partial_w"],
                        c_off=o(pl + "feed_forward.output_dense.weight"), accumulate=lacc,
                        bias_off=o(pl + "feed_forward.output_dense.bias"), cs_off=4 * d + f)]
-            ops.gemm(dh, p16, w["du"], M=M, N=f, K=d, lda=d, b_layout=MNMAJOR, ldb=f, ldc=f,
+            ops.gemm(dh, p16, du, M=M, N=f, K=d, lda=d, b_layout=MNMAJOR, ldb=f, ldc=f,
                      b_off=o(pl + "feed_forward.output_dense.weight"), epilogue=EPI_DGELU, R=w["u"][l],
                      ldr=f, dropout_p=drop_p, dropout_seed=self.step_seed * 1000 + l)
             # FFN1
-            du = w["du"]
-            wg.append(dict(dY=du, X=w["x2"][l], M=f, N=d, K=M, lda=f, ldb=d, part=part,
+            wg.append(dict(dY=du, X=w["x2"][l], M=f, N=d, K=M, lda=f, ldb=d, part=w["partial_w"],
                            c_off=o(pl + "feed_forward.intermediate_dense.weight"), accumulate=lacc,
                            bias_off=o(pl + "feed_forward.intermediate_dense.bias"), cs_off=4 * d))
             ops.gemm(du, p16, other, M=M, N=d, K=f, lda=f, b_layout=MNMAJOR, ldb=d, ldc=d,
                      b_off=o(pl + "feed_forward.intermediate_dense.weight"))
             # LN2: dh1 = dh + LN'(dx2)
-            dh1 = w["dC"]
             ops.layernorm_bwd(other, w["h1"][l], st.view(pl + "final_layer_norm.weight"), None, w["st2"][l],
                               dh, dh1, st.view(pl + "final_layer_norm.weight", "g32"),
                               st.view(pl + "final_layer_norm.bias", "g32"), part, M, d)
             # out_proj: h1 = h + Wo ctx + bo
-            wg.append(dict(dY=dh1, X=w["ctx"][l], M=d, N=d, K=M, lda=d, ldb=d, part=part,
+            wg.append(dict(dY=dh1, X=w["ctx"][l], M=d, N=d, K=M, lda=d, ldb=d, part=w["partial_w"],
                            c_off=o(pl + "attention.out_proj.weight"), accumulate=lacc,
                            bias_off=o(pl + "attention.out_proj.bias"), cs_off=3 * d))
             dctx = other
             ops.gemm(dh1, p16, dctx, M=M, N=d, K=d, lda=d, b_layout=MNMAJOR, ldb=d, ldc=d,
                      b_off=o(pl + "attention.out_proj.weight"))
-            self._attention_bwd(w, l, dctx, B, T, Tp, H, hd, d, scale)
-            dqkv = w["dqkv"]
-            wg.append(dict(dY=dqkv, X=w["x1"][l], M=3 * d, N=d, K=M, lda=3 * d, ldb=d, part=part,
+            self._attention_bwd(w, l, dctx, B, T, Tp, H, hd, d, scale, dqkv)
+            wg.append(dict(dY=dqkv, X=w["x1"][l], M=3 * d, N=d, K=M, lda=3 * d, ldb=d, part=w["partial_w"],
                            c_off=o(pl + "attention.q_proj.weight"), accumulate=lacc,
                            bias_off=o(pl + "attention.q_proj.bias"), cs_off=0))
-            nb = 5 * d + f  # q|k|v, out, ffn1, ffn2 biases: contiguous in the flat buffer (w2v2_param_list)
-            if ops.wgrad_gemm_group(wg, g32, colsum_ws=w["bias_ws"], colsum_ld=nb):
-                ops.reduce_rows(w["bias_ws"], ops.COLSUM_PARTS, nb, nb, g32[o(pl + "attention.q_proj.bias"):], accumulate=True)
+
+            # the layer's weight gradients (one grouped launch plan: 240 + 240 + 184 + 64 tiles at XLS-R-2B) and the
+            # reduction of their fused bias-gradient partials
+            def wgrads(wg=wg, pl=pl):
+                if ops.wgrad_gemm_group(wg, g32, colsum_ws=w["bias_ws"], colsum_ld=nb):
+                    ops.reduce_rows(w["bias_ws"], ops.COLSUM_PARTS, nb, nb, g32[o(pl + "attention.q_proj.bias"):],
+                                    accumulate=True)
+
+            on_side(mark(), wgrads)
             dx1 = other
             ops.gemm(dqkv, p16, dx1, M=M, N=d, K=3 * d, lda=3 * d, b_layout=MNMAJOR, ldb=d, ldc=d,
                      b_off=o(pl + "attention.q_proj.weight"))
-            # LN1: dh_in = dh1 + LN'(dx1)   (written over the old dh buffer)
-            ops.layernorm_bwd(dx1, hin, st.view(pl + "layer_norm.weight"), None, w["st1"][l], dh1, dh,
+            # LN1: dh_in = dh1 + LN'(dx1)
+            ops.layernorm_bwd(dx1, hin, st.view(pl + "layer_norm.weight"), None, w["st1"][l], dh1, dh_next,
                               st.view(pl + "layer_norm.weight", "g32"), st.view(pl + "layer_norm.bias", "g32"),
                               part, M, d)
-            done(f"layer{l}")
+            dh = dh_next
+            if ws is None:
+                done(f"layer{l}")
+            else:
+                # the bucket is complete once the side stream has passed both its own launches and the main stream's
+                # LayerNorm gradients: the hook runs with the side stream current, so a trainer that makes its
+                # communication / optimiser stream wait for "the current stream" waits for all of the bucket
+                ev = mark()
+                ws.wait_event(ev)
+                with torch.cuda.stream(ws):
+                    wd = torch.cuda.Event()
+                    wd.record(ws)
+                    wdone[it] = wd
+                    done(f"layer{l}")
+            it += 1
+        if ws is not None:
+            main.wait_stream(ws)
         # dh: gradient wrt h[0] = h0m + gelu(pc_pre)
         G, K = s.num_conv_pos_embedding_groups, s.num_conv_pos_embeddings
         Cg = d // G
@@ -723,16 +790,27 @@ class Wav2Vec2CTCEngine:
                       part, B, N, s.conv_dim[0], s.conv_kernel[0], s.conv_stride[0], s.layer_norm_eps)
         done("front")
 
-    def _attention_bwd(self, w, l, dctx, B, T, Tp, H, hd, d, scale):
+    def _wgrad_stream(self):
+        """The weight gradients' stream (None = everything on the current stream; CA_WGRAD_STREAM=0)."""
+        import os
+
+        if os.environ.get("CA_WGRAD_STREAM", "1") == "0":
+            return None
+        if getattr(self, "_wstream", None) is None:
+            self._wstream = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("CA_WGRAD_PRIO", "0")))
+        return self._wstream
+
+    def _attention_bwd(self, w, l, dctx, B, T, Tp, H, hd, d, scale, dqkv=None):
+        dqkv = w["dqkv"] if dqkv is None else dqkv
         if self.fused_attention:
-            qkv, dqkv = w["qkv"][l], w["dqkv"]
+            qkv = w["qkv"][l]
             ops.attn_bwd(qkv, qkv, qkv, w["ctx"][l], w["lse"][l], dctx, w["Dq"], dqkv, dqkv, dqkv, lddo=d,
                          sdob=T * d, lddq=3 * d, lddk=3 * d, lddv=3 * d, sdqb=T * 3 * d, sdkb=T * 3 * d,
                          sdvb=T * 3 * d, dq_off=0, dk_off=d, dv_off=2 * d, B=B, H=H, Tq=T, Tk=T, hd=hd,
                          Tqp=w["Tqp"], scale=scale, ldq=3 * d, ldk=3 * d, ldv=3 * d, ldo=d, sqb=T * 3 * d,
                          skb=T * 3 * d, svb=T * 3 * d, sob=T * d, q_off=0, k_off=d, v_off=2 * d, klen=w["flen"])
             return
-        qkv, P, dP, dS, dqkv = w["qkv"][l], w["P"][l], w["S"], w["dS"], w["dqkv"]
+        qkv, P, dP, dS = w["qkv"][l], w["P"][l], w["S"], w["dS"]
         bs = dict(batch1=B, batch2=H)
         # dP = dctx V^T
         ops.gemm(dctx, qkv, dP, M=T, N=T, K=hd, lda=d, ldb=3 * d, b_off=2 * d, ldc=Tp, sA=(T * d, hd),

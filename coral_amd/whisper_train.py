@@ -28,8 +28,13 @@ class WhisperTrainEngine(WhisperEngine):
     """Adds forward_train()/backward() to the inference engine; gradients land in `store.g32`."""
 
     def __init__(self, shape: WhisperShape, device="cuda:0", activation_dropout: float = 0.0,
-                 freeze_base: bool = False):
+                 freeze_base: bool = False, dropout: float = 0.0):
         super().__init__(shape, device)
+        # `dropout`: the hidden-state dropout of WhisperConfig ($TF/models/whisper/modeling_whisper.py:398,406,479,493,
+        # 502 after every sub-layer, :625,763 on the embedded inputs; R/config/model/whisper-large-turbo.yaml:12 sets
+        # 0.1) - applied in the epilogue of the projection in front of each residual add, masks regenerated in the
+        # backward from (step seed, site, element)
+        self.dropout = dropout
         self._stager = PinnedStager(self.device)
         self.freeze_base = freeze_base
         s, st = shape, self.store
@@ -192,6 +197,11 @@ class WhisperTrainEngine(WhisperEngine):
         w = self._train_ws(B, L)
         Me, Md = B * T, B * L
         drop = self.activation_dropout if self.training else 0.0
+        hp = self.dropout if self.training else 0.0
+        base = self.step_seed * 4096
+
+        def hd(site):  # (p, seed) of one hidden-dropout site
+            return (hp, base + site)
         mask_time_d = self._stager.to_device(mask_time, torch.uint8, "tm") if mask_time is not None else None
         mask_feature_d = self._stager.to_device(mask_feature, torch.uint8, "fm") if mask_feature is not None else None
         self._await("front")
@@ -208,6 +218,8 @@ class WhisperTrainEngine(WhisperEngine):
         ops.gemm(w["c1"], self.conv2_wr, w["pre2"], C2=w["eh"][0], M=T, N=d, K=3 * d, lda=2 * d, ldb=3 * d, ldc=d, bias=p32,
                  bias_off=o("model.encoder.conv2.bias"), epilogue=EPI_GELU_RESIDUAL, R=p16, r_off=o("model.encoder.embed_positions.weight"),
                  ldr=d, batch2=B, sA=(0, (Tin + 2) * d), sC=(0, T * d), sR=(0, 0))
+        if hp > 0.0:
+            ops.dropout(w["eh"][0], w["eh"][0], Me * d, *hd(1000))
         ek = [True] * s.encoder_layers if enc_keep is None else [bool(k) for k in enc_keep]
         dk = [True] * s.decoder_layers if dec_keep is None else [bool(k) for k in dec_keep]
         for l, (sa, ff) in enumerate(self.enc_blocks):
@@ -216,8 +228,8 @@ class WhisperTrainEngine(WhisperEngine):
                 w["eh"][2 * l + 2].copy_(w["eh"][2 * l])
                 continue
             sv_a, sv_f = w["enc_sv"][l]
-            sa.forward(w["eh"][2 * l], w["eh"][2 * l + 1], sv_a, B, T)
-            ff.forward(w["eh"][2 * l + 1], w["eh"][2 * l + 2], sv_f, Me, drop, self.step_seed * 4096 + l)
+            sa.forward(w["eh"][2 * l], w["eh"][2 * l + 1], sv_a, B, T, hdrop=hd(256 + l))
+            ff.forward(w["eh"][2 * l + 1], w["eh"][2 * l + 2], sv_f, Me, drop, self.step_seed * 4096 + l, hdrop=hd(512 + l))
         self._await("encf")
         self._await("emb")
         ops.layernorm_fwd(w["eh"][-1], st.view("model.encoder.layer_norm.weight"), st.view("model.encoder.layer_norm.bias"),
@@ -227,6 +239,8 @@ class WhisperTrainEngine(WhisperEngine):
         pos = torch.arange(L, dtype=torch.int32, device=dev).repeat(B)
         ops.embed_tokens(p16[o("model.decoder.embed_tokens.weight"):], p16[o("model.decoder.embed_positions.weight"):],
                          ids, pos, w["dh"][0], Md, d)
+        if hp > 0.0:
+            ops.dropout(w["dh"][0], w["dh"][0], Md * d, *hd(3000))
         for l, (sa, ca, ff) in enumerate(self.dec_blocks):
             self._await(f"dec{l}")
             if not dk[l]:
@@ -234,9 +248,10 @@ class WhisperTrainEngine(WhisperEngine):
                 continue
             sv_a, sv_c, sv_f = w["dec_sv"][l]
             ca.project_kv(w["enc_out"], sv_c, B, T)
-            sa.forward(w["dh"][3 * l], w["dh"][3 * l + 1], sv_a, B, L)
-            ca.forward(w["dh"][3 * l + 1], w["dh"][3 * l + 2], sv_c, B, L, T)
-            ff.forward(w["dh"][3 * l + 2], w["dh"][3 * l + 3], sv_f, Md, drop, self.step_seed * 4096 + 2048 + l)
+            sa.forward(w["dh"][3 * l], w["dh"][3 * l + 1], sv_a, B, L, hdrop=hd(2304 + l))
+            ca.forward(w["dh"][3 * l + 1], w["dh"][3 * l + 2], sv_c, B, L, T, hdrop=hd(2560 + l))
+            ff.forward(w["dh"][3 * l + 2], w["dh"][3 * l + 3], sv_f, Md, drop, self.step_seed * 4096 + 2048 + l,
+                       hdrop=hd(2816 + l))
         self._await_all()  # decf and anything not waited for above
         ops.layernorm_fwd(w["dh"][-1], st.view("model.decoder.layer_norm.weight"), st.view("model.decoder.layer_norm.bias"),
                           w["dec_out"], w["dec_st"], Md, d, s.layer_norm_eps)
@@ -248,7 +263,8 @@ class WhisperTrainEngine(WhisperEngine):
         ops.cross_entropy_fwd_bwd(w["logits"], lab32, w["loss_sum"], w["count"], w["dlogits"], Md, V, Vp, -100)
         cnt = w["count"].clamp(min=1).to(torch.float32)
         loss = (w["loss_sum"] / cnt)[0]
-        self._saved = dict(w=w, B=B, L=L, ids=ids, pos=pos, inv_count=(1.0 / cnt), x=x, ek=ek, dk=dk)
+        self._saved = dict(w=w, B=B, L=L, ids=ids, pos=pos, inv_count=(1.0 / cnt), x=x, ek=ek, dk=dk,
+                           embed_drop=(hd(1000), hd(3000)))
         return dict(loss=loss, logits=w["logits"].view(B, L, Vp)[:, :, :V])
 
     # ---- backward ----------------------------------------------------------------------------
@@ -295,6 +311,9 @@ class WhisperTrainEngine(WhisperEngine):
             self.clear_internal_grads_of(f"model.decoder.layers.{l}.")
             done(f"dec{l}")
         done("decf")
+        (ep, eseed), (dp, dseed) = sv["embed_drop"]
+        if dp > 0.0:  # dropout on the embedded decoder inputs (:763)
+            ops.dropout(cur, cur, Md * d, dp, dseed)
         ops.embed_tokens_bwd(cur, sv["ids"], sv["pos"], g32, g32, Md, d, dtable_off=o("model.decoder.embed_tokens.weight"),
                              dpos_off=o("model.decoder.embed_positions.weight"))
         done("emb")
@@ -313,18 +332,21 @@ class WhisperTrainEngine(WhisperEngine):
             sv_a, sv_f = w["enc_sv"][l]
             # three rotating buffers: both blocks' dY stay alive until the layer's four weight gradients go out as
             # one grouped launch (192 tiles of the 256x256 kernel at d = 1024 instead of four split-K launches)
-            wg = []
+            # (with hidden dropout each block's dY is a masked copy in one shared scratch buffer: per-block launches)
+            wg = [] if ep <= 0.0 else None
             ff.backward(cur, other, sv_f, sc_e, Me, defer=wg)
             sa.backward(other, third, sv_a, sc_e, B, T, defer=wg)
             nb = 5 * d + s.encoder_ffn_dim
-            if ops.wgrad_gemm_group(wg, g32, colsum_ws=w["bias_ws"], colsum_ld=nb):
+            if wg is not None and ops.wgrad_gemm_group(wg, g32, colsum_ws=w["bias_ws"], colsum_ld=nb):
                 ops.reduce_rows(w["bias_ws"], ops.COLSUM_PARTS, nb, nb,
                                 g32[o(f"model.encoder.layers.{l}.self_attn.q_proj.bias"):], accumulate=True)
             cur, other, third = third, cur, other
             self.clear_internal_grads_of(f"model.encoder.layers.{l}.")
             done(f"enc{l}")
         done("encf")
-        # conv2: h0 = gelu(pre2) + pos
+        # conv2: h0 = dropout(gelu(pre2) + pos)
+        if ep > 0.0:
+            ops.dropout(cur, cur, Me * d, ep, eseed)
         dpre2 = other
         ops.dgelu_mul(cur, w["pre2"], dpre2, Me * d)
         ops.colsum(dpre2, d, Me, d, g32, sc_e.part, out_off=o("model.encoder.conv2.bias"))

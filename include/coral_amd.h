@@ -88,7 +88,10 @@ typedef struct CaGemmDesc {
   float alpha;
   /* activation dropout fused into CA_EPI_GELU / CA_EPI_DGELU
    * ($TF/models/wav2vec2/modeling_wav2vec2.py:556,567; R/config/model/wav2vec2-large.yaml:12):
-   * keep-mask = hash(seed, m*N+n) >= p; kept values scaled by 1/(1-p). p = 0 disables. */
+   * keep-mask = hash(seed, m*N+n) >= p; kept values scaled by 1/(1-p). p = 0 disables.
+   * With CA_EPI_RESIDUAL: C = R + dropout(alpha A.B + bias), the hidden-state dropout in front of a residual add
+   * ($TF/models/whisper/modeling_whisper.py:398,406,479,493,502; R/config/model/whisper-large-turbo.yaml:12);
+   * ca_dropout_bf16 regenerates the same mask for the backward. */
   float dropout_p;
   uint64_t dropout_seed;
   /* Optional, weight-gradient form only (a_layout = b_layout = MNMAJOR, served by the 256x256 kernel): partial
@@ -181,6 +184,11 @@ int ca_reduce_rows_f32(const float* partial, int32_t nparts, int64_t stride, int
                        int32_t accumulate, void* stream);
 /* out = dy * gelu_erf'(u), bf16 elementwise (backward of the pos-conv GELU, :374). */
 int ca_dgelu_mul(const void* dy, const void* u, void* out, int64_t n, void* stream);
+/* y = x * keep / (1 - p), keep of element i from (seed, i): hidden-state dropout as its own pass and the mask the
+ * CA_EPI_RESIDUAL epilogue (dropout_p > 0) applies to element (m, n) of a dense [M, N] output at i = m * N + n.
+ * Replaces nn.functional.dropout at $TF/models/whisper/modeling_whisper.py:398,406,479,493,502,625,763 (backward: the
+ * same call on the incoming gradient).  n % 8 == 0; x == y allowed. */
+int ca_dropout_bf16(const void* x, void* y, int64_t n, float p, uint64_t seed, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Waveform front end.

@@ -205,40 +205,51 @@ def _ln(x, P, p, eps):
     return F.layer_norm(x, (x.shape[-1],), P[p + ".weight"], P[p + ".bias"], eps)
 
 
-def encoder(input_features: torch.Tensor, P: dict, c: WhisperConfig, keep=None) -> torch.Tensor:
+def _drop(x, masks, key):
+    """Training-time hidden-state dropout with an INJECTED multiplicative mask (keep / (1 - p) per element, same shape as
+    x): `nn.functional.dropout(hidden_states, p=self.dropout)` at $TF/models/whisper/modeling_whisper.py:398,406 (encoder
+    layer), :479,493,502 (decoder layer), :625,763 (embedded inputs).  masks None / key absent = evaluation."""
+    if masks is None or key not in masks:
+        return x
+    return x * masks[key].reshape(x.shape)
+
+
+def encoder(input_features: torch.Tensor, P: dict, c: WhisperConfig, keep=None, masks=None) -> torch.Tensor:
     """input_features f32 [B, mels, 3000] -> [B, 1500, d].  keep[l] False = the layer is skipped
-    (training-time LayerDrop, $TF/models/whisper/modeling_whisper.py:626-634)."""
+    (training-time LayerDrop, $TF/models/whisper/modeling_whisper.py:626-634); masks: see `_drop`
+    (keys "enc_embed", "enc{l}.attn", "enc{l}.ffn")."""
     x = F.gelu(F.conv1d(input_features, P["model.encoder.conv1.weight"], P["model.encoder.conv1.bias"], padding=1))
     x = F.gelu(F.conv1d(x, P["model.encoder.conv2.weight"], P["model.encoder.conv2.bias"], stride=2, padding=1))
-    h = x.permute(0, 2, 1) + P["model.encoder.embed_positions.weight"]
+    h = _drop(x.permute(0, 2, 1) + P["model.encoder.embed_positions.weight"], masks, "enc_embed")
     for l in range(c.encoder_layers):
         if keep is not None and not keep[l]:
             continue
         p = f"model.encoder.layers.{l}."
         x = _ln(h, P, p + "self_attn_layer_norm", c.layer_norm_eps)
-        h = h + _attn(x, x, P, p + "self_attn.", c.encoder_attention_heads)
+        h = h + _drop(_attn(x, x, P, p + "self_attn.", c.encoder_attention_heads), masks, f"enc{l}.attn")
         y = _ln(h, P, p + "final_layer_norm", c.layer_norm_eps)
         y = F.linear(F.gelu(F.linear(y, P[p + "fc1.weight"], P[p + "fc1.bias"])), P[p + "fc2.weight"], P[p + "fc2.bias"])
-        h = h + y
+        h = h + _drop(y, masks, f"enc{l}.ffn")
     return _ln(h, P, "model.encoder.layer_norm", c.layer_norm_eps)
 
 
-def decoder(input_ids: torch.Tensor, enc: torch.Tensor, P: dict, c: WhisperConfig, keep=None) -> torch.Tensor:
+def decoder(input_ids: torch.Tensor, enc: torch.Tensor, P: dict, c: WhisperConfig, keep=None, masks=None) -> torch.Tensor:
     """input_ids i64 [B, L], enc [B, 1500, d] -> logits [B, L, V] (tied projection); keep as in
-    `encoder` (:771-779)."""
+    `encoder` (:771-779); masks keys "dec_embed", "dec{l}.self", "dec{l}.cross", "dec{l}.ffn"."""
     L = input_ids.shape[1]
-    h = P["model.decoder.embed_tokens.weight"][input_ids] + P["model.decoder.embed_positions.weight"][:L]
+    h = _drop(P["model.decoder.embed_tokens.weight"][input_ids] + P["model.decoder.embed_positions.weight"][:L], masks,
+              "dec_embed")
     for l in range(c.decoder_layers):
         if keep is not None and not keep[l]:
             continue
         p = f"model.decoder.layers.{l}."
         x = _ln(h, P, p + "self_attn_layer_norm", c.layer_norm_eps)
-        h = h + _attn(x, x, P, p + "self_attn.", c.decoder_attention_heads, causal=True)
+        h = h + _drop(_attn(x, x, P, p + "self_attn.", c.decoder_attention_heads, causal=True), masks, f"dec{l}.self")
         x = _ln(h, P, p + "encoder_attn_layer_norm", c.layer_norm_eps)
-        h = h + _attn(x, enc, P, p + "encoder_attn.", c.decoder_attention_heads)
+        h = h + _drop(_attn(x, enc, P, p + "encoder_attn.", c.decoder_attention_heads), masks, f"dec{l}.cross")
         y = _ln(h, P, p + "final_layer_norm", c.layer_norm_eps)
         y = F.linear(F.gelu(F.linear(y, P[p + "fc1.weight"], P[p + "fc1.bias"])), P[p + "fc2.weight"], P[p + "fc2.bias"])
-        h = h + y
+        h = h + _drop(y, masks, f"dec{l}.ffn")
     h = _ln(h, P, "model.decoder.layer_norm", c.layer_norm_eps)
     return F.linear(h, P["model.decoder.embed_tokens.weight"])
 
@@ -250,10 +261,10 @@ def shift_tokens_right(labels: torch.Tensor, pad_id: int, start_id: int) -> torc
     return out.masked_fill(out == -100, pad_id)
 
 
-def forward_loss(input_features, labels, P, c: WhisperConfig, enc_keep=None, dec_keep=None):
+def forward_loss(input_features, labels, P, c: WhisperConfig, enc_keep=None, dec_keep=None, masks=None):
     """WhisperForConditionalGeneration.forward(input_features, labels) -> (loss, logits)."""
     dec_in = shift_tokens_right(labels, c.pad_token_id, c.decoder_start_token_id)
-    logits = decoder(dec_in, encoder(input_features, P, c, enc_keep), P, c, dec_keep)
+    logits = decoder(dec_in, encoder(input_features, P, c, enc_keep, masks), P, c, dec_keep, masks)
     loss = F.cross_entropy(logits.reshape(-1, c.vocab_size), labels.reshape(-1), ignore_index=-100)
     return loss, logits
 

@@ -318,3 +318,76 @@ def test_whisper_large_turbo_shape_training_step_vs_oracle():
                  "model.decoder.layers.0.encoder_attn.v_proj.weight", "model.decoder.layers.1.self_attn.q_proj.weight"]:
         a, b = gd[name].double().cpu().flatten(), Pr[name].grad.double().flatten()
         assert float(a @ b / (a.norm() * b.norm())) >= 0.99, name
+
+
+def test_whisper_hidden_dropout_matches_oracle_with_the_same_masks():
+    """WhisperConfig.dropout (R/config/model/whisper-large-turbo.yaml:12 sets 0.1): dropout on the embedded inputs and on
+    every sub-layer output in front of its residual add ($TF/models/whisper/modeling_whisper.py:398,406,479,493,502,625,
+    763).  The engine's masks are a hash of (step seed, site, element); extracted with `ops.dropout` on a matrix of ones
+    and injected into the oracle they must give the same loss, logits and gradients - forward placement, the
+    1 / (1 - p) scale and the backward's regenerated masks all checked at once."""
+    from coral_amd import ops
+    from coral_amd.whisper import WhisperShape
+    from coral_amd.whisper_train import WhisperTrainEngine
+    from oracle import whisper_ref as w
+
+    kw, c = _tiny()
+    P = w.synth_params(c)
+    g = torch.Generator().manual_seed(21)
+    B, L, T, d, p = 2, 10, 1500, c.d_model, 0.25
+    feats = torch.randn(B, 80, 3000, generator=g) * 0.5
+    labels = torch.randint(0, 150, (B, L), generator=g)
+    labels[1, 7:] = -100
+    eng = WhisperTrainEngine(WhisperShape(**kw), DEV, dropout=p)
+    eng.load_state_dict(P)
+    eng.step_seed = 3
+    base = eng.step_seed * 4096
+
+    def mask(rows, site):
+        ones = torch.ones(rows * d, dtype=torch.bfloat16, device=DEV)
+        out = torch.empty_like(ones)
+        ops.dropout(ones, out, rows * d, p, base + site)
+        m = out.float().cpu().view(rows, d)
+        assert set(m.unique().tolist()) <= {0.0, float(torch.tensor(1 / (1 - p)).bfloat16())}
+        return m
+
+    masks = {"enc_embed": mask(B * T, 1000), "dec_embed": mask(B * L, 3000)}
+    for l in range(c.encoder_layers):
+        masks[f"enc{l}.attn"], masks[f"enc{l}.ffn"] = mask(B * T, 256 + l), mask(B * T, 512 + l)
+    for l in range(c.decoder_layers):
+        masks[f"dec{l}.self"], masks[f"dec{l}.cross"], masks[f"dec{l}.ffn"] = (
+            mask(B * L, 2304 + l), mask(B * L, 2560 + l), mask(B * L, 2816 + l))
+    keep = float(masks["enc_embed"].ne(0).float().mean())
+    assert abs(keep - (1 - p)) < 0.01, keep
+    assert not torch.equal(masks["enc0.attn"], masks["enc0.ffn"])  # sites draw different masks
+    # bf16(1 / (1 - p)) is what the kernel multiplies by in fp32?  No: it scales in fp32 and rounds the product; on a
+    # matrix of ones the product IS the rounded scale, so give the oracle the exact fp32 scale instead
+    scale = 1.0 / (1.0 - p)
+    masks = {k: (v != 0).float() * scale for k, v in masks.items()}
+
+    Pr = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    loss_ref, logits_ref = w.forward_loss(feats, labels, Pr, c, masks=masks)
+    loss_ref.backward()
+    eng.zero_grad()
+    out = eng.forward_train(feats, labels)
+    eng.backward()
+    torch.cuda.synchronize()
+    assert abs(float(out["loss"]) - float(loss_ref)) <= 1e-2 * float(loss_ref), (float(out["loss"]), float(loss_ref))
+    assert (out["logits"].float().cpu() - logits_ref.detach()).abs().max() <= 6e-2
+    loss_eval, _ = w.forward_loss(feats, labels, P, c)
+    assert abs(float(loss_eval) - float(loss_ref)) > 1e-3      # the masks really change the forward
+    bad = []
+    for name, gq in eng.grad_dict().items():
+        gr = Pr[name].grad
+        if name == "model.encoder.embed_positions.weight" or name.endswith("k_proj.bias"):
+            continue
+        a, b = gq.double().cpu().flatten(), gr.double().flatten()
+        cos = float(a @ b / (a.norm() * b.norm() + 1e-30))
+        ratio = float(a.norm() / (b.norm() + 1e-30))
+        if not (cos >= 0.99 and 0.94 <= ratio <= 1.06):
+            bad.append((name, round(cos, 4), round(ratio, 4)))
+    assert not bad, bad
+    # evaluation mode: no dropout
+    eng.training = False
+    out_eval = eng.forward_train(feats, labels)
+    assert abs(float(out_eval["loss"]) - float(loss_eval)) <= 1e-2 * float(loss_eval)
