@@ -139,6 +139,88 @@ __device__ __forceinline__ bf16x8_t timg_frag_async(const char* img, int s, int 
 __device__ __forceinline__ void lds_wait_all() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void tie(bf16x8_t& f) { asm volatile("" : "+v"(f)); }
 
+// ---- fast-path tile loads ---------------------------------------------------------------------------------------
+// A tile that lies fully inside its tensor and is not the tensor's last needs no row clamp, and its columns beyond
+// head_dim may hold whatever follows in memory (the neighbouring head or the next row: finite activations that only
+// ever meet the zero-padded register operand or land in output columns that are never stored).  Its per-lane byte
+// offsets relative to the tile's first row are then constants of the kernel and only a wave-uniform base moves from
+// tile to tile: one LDS-DMA instruction per 1-KiB piece, no per-lane address arithmetic (the general loaders above
+// spend ~20 vector instructions per piece on row clamps, zero-page selects and 64-bit multiplies).  The last tile of
+// a tensor always takes the general loader (rows beyond the end, and no read past the allocation).
+__device__ __forceinline__ void glds16_sb(const char* base, uint32_t off, uint32_t lds_piece) {
+  asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(off), "s"(base), "s"(lds_piece) : "memory", "m0");
+}
+template <int ROWS, int HDPV, int NW = 4>
+struct KImgFast {
+  static constexpr int NCH = HDPV / 64, IPW = ROWS / 8 / NW;
+  uint32_t off[NCH * IPW];
+  __device__ __forceinline__ void init(int64_t ld, int wave, int lane) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int i = 0; i < IPW; ++i) {
+        const int r = (wave * IPW + i) * 8 + (lane >> 3);
+        const int cc = (lane & 7) ^ ((r >> 1) & 7);
+        off[c * IPW + i] = (uint32_t)((r * ld + c * 64 + cc * 8) * 2);
+      }
+  }
+  __device__ __forceinline__ void issue(char* lds, const unsigned short* tile_base, int wave) const {
+    const uint32_t l0 = (uint32_t)(uintptr_t)(lptr_t)lds;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int i = 0; i < IPW; ++i)
+        glds16_sb((const char*)tile_base, off[c * IPW + i], l0 + c * ROWS * 128 + (wave * IPW + i) * 1024);
+  }
+};
+template <int ROWS, int HDPV, int NW = 4>
+struct MnImgFast {
+  static constexpr int PC = HDPV / 8, RPI = 64 / PC, IPW = ROWS * HDPV * 2 / 1024 / NW;
+  uint32_t off[IPW];
+  __device__ __forceinline__ void init(int64_t ld, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < IPW; ++i) {
+      const int kr = (wave * IPW + i) * RPI + lane / PC;
+      const int swz = (kr & 3) | (((kr >> 3) & 1) << 2);
+      const int c = (lane % PC) ^ ((swz << 1) & (PC - 1));
+      off[i] = (uint32_t)((kr * ld + c * 8) * 2);
+    }
+  }
+  __device__ __forceinline__ void issue(char* lds, const unsigned short* tile_base, int wave) const {
+    const uint32_t l0 = (uint32_t)(uintptr_t)(lptr_t)lds;
+#pragma unroll
+    for (int i = 0; i < IPW; ++i) glds16_sb((const char*)tile_base, off[i], l0 + (wave * IPW + i) * 1024);
+  }
+};
+// number of leading tiles of `rows_per_tile` rows that are fully inside a tensor of n rows and are not its last tile
+__device__ __forceinline__ int fast_tiles(int n, int rows_per_tile) { return (n - 1) / rows_per_tile; }
+
+// ---- wave-private output staging: 16 rows x HDPV columns, accumulator layout -> 16-byte row stores --------------
+// o[nb][e] is element (row 4g + e, column 16 nb + r) of the wave's 16-row tile.  Stored straight from the registers
+// that is one 2-byte store per lane and element (32 branches + stores per lane for 128 columns, 32-byte segments);
+// through LDS the tile goes out as whole 16-byte chunks of rows.
+template <int HDPV>
+__device__ __forceinline__ void store_tile16(char* st, const f32x4_t (&o)[HDPV / 16], const float (&rs)[4],
+                                             unsigned short* dst, int64_t ld, int row0, int nrows, int hd, int lane) {
+  constexpr int PITCH = HDPV * 2 + 16;  // bytes: consecutive rows start 4 banks apart
+  const int g = lane >> 4, r = lane & 15;
+#pragma unroll
+  for (int nb = 0; nb < HDPV / 16; ++nb)
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      *(unsigned short*)(st + (4 * g + e) * PITCH + (16 * nb + r) * 2) = f2bf(o[nb][e] * rs[e]);
+  __builtin_amdgcn_wave_barrier();
+  constexpr int CPR = HDPV / 8;  // 16-byte chunks per row
+#pragma unroll
+  for (int i = 0; i < 16 * CPR / 64; ++i) {
+    const int idx = i * 64 + lane;
+    const int row = idx / CPR, ch = idx % CPR;
+    const int q = row0 + row;
+    if (q < nrows && ch * 8 < hd) *(u16x8_t*)(dst + (int64_t)q * ld + ch * 8) = *(const u16x8_t*)(st + row * PITCH + ch * 16);
+  }
+}
+constexpr int attn_stage_bytes(int hdpv) { return 4 * 16 * (hdpv * 2 + 16); }
+
 // row of a 32-row step that lane-row r of block bb must read so that lane group g ends up holding the
 // contraction indices 8g .. 8g+7 (bb = 0: +0..3, bb = 1: +4..7)
 __device__ __forceinline__ int rowperm(int bb, int r) { return 8 * (r >> 2) + 4 * bb + (r & 3); }
@@ -237,9 +319,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
   for (int nb = 0; nb < NNB; ++nb) o[nb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
+  KImgFast<64, HDPV> kfast;
+  MnImgFast<64, HDPV> vfast;
+  kfast.init(a.ldk, wave, lane);
+  vfast.init(a.ldv, wave, lane);
+  const int nfast = fast_tiles(a.Tk, 64);
   for (int kt = 0; kt < ntile; ++kt) {
-    load_kmajor_image<64, HDPV>(Kimg, K, a.ldk, kt * 64, a.Tk, hd, wave, lane);
-    load_mnmajor_image<64, HDPV>(Vimg, V, a.ldv, kt * 64, a.Tk, hd, wave, lane);
+    if (kt < nfast) {
+      kfast.issue(Kimg, K + (int64_t)kt * 64 * a.ldk, wave);
+      vfast.issue(Vimg, V + (int64_t)kt * 64 * a.ldv, wave);
+    } else {
+      load_kmajor_image<64, HDPV>(Kimg, K, a.ldk, kt * 64, a.Tk, hd, wave, lane);
+      load_mnmajor_image<64, HDPV>(Vimg, V, a.ldv, kt * 64, a.Tk, hd, wave, lane);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     // transposed scores of the 64 keys: block (s, bb) holds keys 32 s + 8 g + 4 bb + {0..3} of query qi
@@ -316,17 +408,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
   for (int e = 0; e < 4; ++e) ir[e] = __shfl(inv, 4 * g + e, 64);
   unsigned short* O = a.O + b * a.sob + h * hd;
-#pragma unroll
-  for (int nb = 0; nb < NNB; ++nb) {
-    const int n = 16 * nb + r;
-    if (n < hd) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int q = q0 + 4 * g + e;
-        if (q < a.Tq) O[(int64_t)q * a.ldo + n] = f2bf(o[nb][e] * ir[e]);
-      }
-    }
-  }
+  // (every loop iteration ended with a workgroup barrier: the images are free)
+  store_tile16<HDPV>(smem + wave * (attn_stage_bytes(HDPV) / 4), o, ir, O, a.ldo, q0, a.Tq, hd, lane);
 }
 
 // Greedy decoding (Tq <= 16 queries per head, hd <= 64): one workgroup per (clip, head), the four waves split the
@@ -611,9 +694,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a) {
   const int s0 = a.causal ? (tile * 64) / 32 : 0;  // queries before the tile's first key see none of it
   // Double-buffered: the images and the per-query statistics of step qs+1 are requested right after the barrier
   // of step qs (one barrier per step: every wave has finished reading the other buffer when it arrives).
+  KImgFast<32, HDPV> qfast, dofast;
+  qfast.init(a.ldq, wave, lane);
+  dofast.init(a.lddo, wave, lane);
+  const int nfast = fast_tiles(a.Tq, 32);
   auto issue = [&](int qs, int buf) {
-    load_kmajor_image<32, HDPV>(Qk + buf * 2 * IMG, Q, a.ldq, qs * 32, a.Tq, hd, wave, lane);
-    load_kmajor_image<32, HDPV>(dOk + buf * 2 * IMG, dO, a.lddo, qs * 32, a.Tq, hd, wave, lane);
+    if (qs < nfast) {
+      qfast.issue(Qk + buf * 2 * IMG, Q + (int64_t)qs * 32 * a.ldq, wave);
+      dofast.issue(dOk + buf * 2 * IMG, dO + (int64_t)qs * 32 * a.lddo, wave);
+    } else {
+      load_kmajor_image<32, HDPV>(Qk + buf * 2 * IMG, Q, a.ldq, qs * 32, a.Tq, hd, wave, lane);
+      load_kmajor_image<32, HDPV>(dOk + buf * 2 * IMG, dO, a.lddo, qs * 32, a.Tq, hd, wave, lane);
+    }
   };
   f32x4_t l0, l1, d0, d1;  // statistics of the current step: indices 8g .. 8g+7 are contiguous
   if (s0 < nstep) {
@@ -711,20 +803,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a) {
   }
   unsigned short* dK = a.dK + b * a.sdkb + h * hd;
   unsigned short* dV = a.dV + b * a.sdvb + h * hd;
-#pragma unroll
-  for (int nb = 0; nb < NNB; ++nb) {
-    const int n = 16 * nb + r;
-    if (n < hd) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int kk = k0 + 4 * g + e;
-        if (kk < a.Tk) {
-          dK[(int64_t)kk * a.lddk + n] = f2bf(dk[nb][e]);
-          dV[(int64_t)kk * a.lddv + n] = f2bf(dv[nb][e]);
-        }
-      }
-    }
-  }
+  __syncthreads();  // the last step's image reads are done in every wave: the LDS becomes output staging
+  const float one[4] = {1.f, 1.f, 1.f, 1.f};
+  char* st = smem + wave * (attn_stage_bytes(HDPV) / 4);
+  store_tile16<HDPV>(st, dk, one, dK, a.lddk, k0, a.Tk, hd, lane);
+  __builtin_amdgcn_wave_barrier();
+  store_tile16<HDPV>(st, dv, one, dV, a.lddv, k0, a.Tk, hd, lane);
 }
 
 // ---- backward: dQ (workgroup = 64 queries, loops over the keys) ------------------------------------------
@@ -769,9 +853,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int last = (tile * 64 + 63) / 64 + 1;  // keys beyond the tile's last query are masked
     ntile = ntile < last ? ntile : last;
   }
+  KImgFast<64, HDPV> kfast, vfast;
+  kfast.init(a.ldk, wave, lane);
+  vfast.init(a.ldv, wave, lane);
+  const int nfast = fast_tiles(a.Tk, 64);
   for (int kt = 0; kt < ntile; ++kt) {
-    load_kmajor_image<64, HDPV>(Kk, K, a.ldk, kt * 64, a.Tk, hd, wave, lane);
-    load_kmajor_image<64, HDPV>(Vk, V, a.ldv, kt * 64, a.Tk, hd, wave, lane);
+    if (kt < nfast) {
+      kfast.issue(Kk, K + (int64_t)kt * 64 * a.ldk, wave);
+      vfast.issue(Vk, V + (int64_t)kt * 64 * a.ldv, wave);
+    } else {
+      load_kmajor_image<64, HDPV>(Kk, K, a.ldk, kt * 64, a.Tk, hd, wave, lane);
+      load_kmajor_image<64, HDPV>(Vk, V, a.ldv, kt * 64, a.Tk, hd, wave, lane);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const bool full = (kt * 64 + 64 <= kl) && !a.causal;  // uniform: no key of this tile is masked
@@ -807,17 +900,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     __syncthreads();
   }
   unsigned short* dQ = a.dQ + b * a.sdqb + h * hd;
-#pragma unroll
-  for (int nb = 0; nb < NNB; ++nb) {
-    const int n = 16 * nb + r;
-    if (n < hd) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int q = q0 + 4 * g + e;
-        if (q < a.Tq) dQ[(int64_t)q * a.lddq + n] = f2bf(acc[nb][e]);
-      }
-    }
-  }
+  const float one[4] = {1.f, 1.f, 1.f, 1.f};
+  // (every loop iteration ended with a workgroup barrier: the images are free)
+  store_tile16<HDPV>(smem + wave * (attn_stage_bytes(HDPV) / 4), acc, one, dQ, a.lddq, q0, a.Tq, hd, lane);
 }
 
 // ---- C ABI ------------------------------------------------------------------------------------------------
