@@ -82,6 +82,27 @@ __device__ __forceinline__ float wave_max(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
 }
+// The same sum without LDS-crossbar traffic: DPP butterflies inside each row of 16 lanes (quad swaps, then row
+// rotations by 4 and 8: every lane ends with its row's total), then the four row totals through v_readlane.  A
+// __shfl_xor butterfly is six dependent ds_bpermute_b32 per reduction; this form is ~15 dependent VALU / SALU steps.
+// Measured (same box, rocprofv3): it pays where a wave has little else in flight - the fused conv0 + LayerNorm + GELU
+// kernels, one output frame per wave at a time: forward 881 -> 761 us, backward 478 -> 331 us - and costs 15 % in the
+// LayerNorm kernels, whose many resident waves already hide the crossbar latency and are short of VALU issue slots.
+// The result is wave-uniform; all 64 lanes must be active.
+template <int CTRL>
+__device__ __forceinline__ float ca_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float ca_lane(float v, int l) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v += ca_dpp<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += ca_dpp<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += ca_dpp<0x124>(v);  // row_ror:4
+  v += ca_dpp<0x128>(v);  // row_ror:8
+  return (ca_lane(v, 0) + ca_lane(v, 16)) + (ca_lane(v, 32) + ca_lane(v, 48));
+}
 // ---- LayerNorm row arithmetic (one expression wherever a normalised value is formed) ----
 __device__ __forceinline__ float ln_apply(float v, float mean, float rstd, float gm, float bt) {
   return (v - mean) * rstd * gm + bt;
