@@ -343,6 +343,8 @@ extern "C" int ca_conv0_ln_gelu_fwd(const float* x, const float* w, const float*
 // backward: recompute conv + LN from x; accumulate dw[C][k], dbias, dgamma, dbeta per wave in
 // registers, reduce over the block's waves in LDS, one partial row per block:
 // partial[blk][C*(k+3)] laid out as [dw (C*k) | dbias (C) | dgamma (C) | dbeta (C)].
+// Same structure as the forward: blocks of CONV0_FPB frames with their samples staged in LDS, centred weights (no mean
+// pass), two frames per iteration, and the next iteration's dy rows requested before the current ones are used.
 #define CONV0_BWD_GRID 512
 template <int KW>
 __global__ __launch_bounds__(256) void conv0_bwd_kernel(
@@ -350,70 +352,120 @@ __global__ __launch_bounds__(256) void conv0_bwd_kernel(
     const float* __restrict__ gamma, const float* __restrict__ beta,
     const unsigned short* __restrict__ dy, float* __restrict__ partial, int B, int64_t N,
     int64_t T0, int stride, float eps) {
-  __shared__ float red[4][C0];
+  extern __shared__ float smem_f[];
+  float* xs_lds = smem_f;                                          // CONV0_FPB * stride + KW samples
+  float(*red)[C0] = (float(*)[C0])(smem_f + CONV0_FPB * 16 + 16);  // [4][C0] cross-wave reduction (stride <= 16)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float wr[8][KW], bs[8], gm[8], bt[8];
+  float wc[8][KW], bc[8], gm[8], bt[8];
   float dw[8][KW], dbs[8], dgm[8], dbt[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const int c = lane * 8 + e;
 #pragma unroll
     for (int j = 0; j < KW; ++j) {
-      wr[e][j] = w[c * KW + j];
+      wc[e][j] = w[c * KW + j];
       dw[e][j] = 0.f;
     }
-    bs[e] = bias[c];
+    bc[e] = bias[c];
     gm[e] = gamma[c];
     bt[e] = beta[c];
     dbs[e] = dgm[e] = dbt[e] = 0.f;
   }
-  const int64_t total = (int64_t)B * T0;
-  for (int64_t f = (int64_t)blockIdx.x * 4 + wave; f < total; f += (int64_t)gridDim.x * 4) {
-    const int64_t b = f / T0, t = f % T0;
-    const float* xp = x + b * N + t * stride;
-    float xs[KW];
+  {  // centre weights and bias over the 512 channels: the convolution then yields v - mean
+    float sb = 0.f;
 #pragma unroll
-    for (int j = 0; j < KW; ++j) xs[j] = xp[j];
-    const u16x8_t ud = *(const u16x8_t*)(dy + f * C0 + lane * 8);
-    float v[8], s = 0.f;
+    for (int e = 0; e < 8; ++e) sb += bc[e];
+    sb = wave_sum_dpp(sb) * (1.f / C0);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float a = bs[e];
+    for (int e = 0; e < 8; ++e) bc[e] -= sb;
 #pragma unroll
-      for (int j = 0; j < KW; ++j) a = fmaf(wr[e][j], xs[j], a);
-      v[e] = a;
-      s += a;
+    for (int j = 0; j < KW; ++j) {
+      float sw = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sw += wc[e][j];
+      sw = wave_sum_dpp(sw) * (1.f / C0);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) wc[e][j] -= sw;
     }
-    const float mean = wave_sum_dpp(s) * (1.f / C0);
-    float s2 = 0.f;
+  }
+  const int64_t bpu = (T0 + CONV0_FPB - 1) / CONV0_FPB;  // frame blocks per utterance
+  const int64_t nblk = bpu * B;
+  for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    const int64_t b = blk / bpu, t0 = (blk % bpu) * CONV0_FPB;
+    const int nf = (int)(T0 - t0 < CONV0_FPB ? T0 - t0 : CONV0_FPB);
+    const int nx = (nf - 1) * stride + KW;
+    const float* xb = x + b * N + t0 * stride;
+    __syncthreads();  // the previous block's reads of xs_lds are done
+    for (int i = threadIdx.x; i < nx; i += 256) xs_lds[i] = xb[i];
+    __syncthreads();
+    const unsigned short* dyb = dy + (b * T0 + t0) * C0 + lane * 8;
+    constexpr int NF = 2;
+    u16x8_t ud[NF], un[NF];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float d = v[e] - mean;
-      s2 += d * d;
+    for (int q = 0; q < NF; ++q) {
+      const int f = wave + 4 * q;
+      ud[q] = *(const u16x8_t*)(dyb + (int64_t)(f < nf ? f : 0) * C0);
     }
-    const float rstd = rsqrtf(wave_sum_dpp(s2) * (1.f / C0) + eps);
-    float h[8], dh[8], a1 = 0.f, a2 = 0.f;
+    for (int f0 = wave; f0 < nf; f0 += 4 * NF) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      h[e] = (v[e] - mean) * rstd;
-      const float du = bf2f(ud[e]) * dgelu_erf(h[e] * gm[e] + bt[e]);
-      dgm[e] += du * h[e];
-      dbt[e] += du;
-      dh[e] = du * gm[e];
-      a1 += dh[e];
-      a2 += dh[e] * h[e];
-    }
-    const float m1 = wave_sum_dpp(a1) * (1.f / C0), m2 = wave_sum_dpp(a2) * (1.f / C0);
+      for (int q = 0; q < NF; ++q) {  // next iteration's rows (clamped: unused when beyond the block)
+        const int f = f0 + 4 * NF + 4 * q;
+        un[q] = *(const u16x8_t*)(dyb + (int64_t)(f < nf ? f : 0) * C0);
+      }
+      float v[NF][8], px[NF][KW];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float dv = rstd * (dh[e] - m1 - h[e] * m2);
-      dbs[e] += dv;
+      for (int q = 0; q < NF; ++q) {
+        const int f = f0 + 4 * q;
+        const float* xp = xs_lds + (f < nf ? f : f0) * stride;
 #pragma unroll
-      for (int j = 0; j < KW; ++j) dw[e][j] = fmaf(dv, xs[j], dw[e][j]);
+        for (int j = 0; j < KW; ++j) px[q][j] = xp[j];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[q][e] = bc[e];
+      }
+#pragma unroll
+      for (int j = 0; j < KW; ++j)
+#pragma unroll
+        for (int q = 0; q < NF; ++q)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[q][e] = fmaf(wc[e][j], px[q][j], v[q][e]);
+      float rstd[NF];
+#pragma unroll
+      for (int q = 0; q < NF; ++q) {
+        float s2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s2 = fmaf(v[q][e], v[q][e], s2);
+        rstd[q] = rsqrtf(wave_sum_dpp(s2) * (1.f / C0) + eps);
+      }
+#pragma unroll
+      for (int q = 0; q < NF; ++q) {
+        const bool live = f0 + 4 * q < nf;  // wave-uniform
+        float h[8], dh[8], a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          h[e] = v[q][e] * rstd[q];
+          const float du = live ? bf2f(ud[q][e]) * dgelu_erf(h[e] * gm[e] + bt[e]) : 0.f;
+          dgm[e] += du * h[e];
+          dbt[e] += du;
+          dh[e] = du * gm[e];
+          a1 += dh[e];
+          a2 += dh[e] * h[e];
+        }
+        const float m1 = wave_sum_dpp(a1) * (1.f / C0), m2 = wave_sum_dpp(a2) * (1.f / C0);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float dv = rstd[q] * (dh[e] - m1 - h[e] * m2);
+          dbs[e] += dv;
+#pragma unroll
+          for (int j = 0; j < KW; ++j) dw[e][j] = fmaf(dv, px[q][j], dw[e][j]);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < NF; ++q) ud[q] = un[q];
     }
   }
   float* pout = partial + (int64_t)blockIdx.x * (C0 * (KW + 3));
   // reduce each of the KW+3 channel vectors over the 4 waves through LDS
+  __syncthreads();
   for (int q = 0; q < KW + 3; ++q) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -445,7 +497,7 @@ __global__ __launch_bounds__(256) void conv0_bwd_kernel(
 }
 
 static int conv0_bwd_grid(int32_t B, int64_t T0) {
-  int64_t g = ((int64_t)B * T0 + 3) / 4;
+  int64_t g = (int64_t)B * ((T0 + CONV0_FPB - 1) / CONV0_FPB);
   if (g > CONV0_BWD_GRID) g = CONV0_BWD_GRID;
   if (g < 1) g = 1;
   return (int)g;
@@ -464,11 +516,12 @@ extern "C" int ca_conv0_ln_gelu_bwd(const float* x, const float* w, const float*
                                     int32_t stride, float eps, void* stream) {
   CA_CHECK_ARG(x && w && bias && gamma && beta && dy && dw && dbias && dgamma && dbeta && partial,
                "ca_conv0_ln_gelu_bwd: null pointer");
-  CA_CHECK_ARG(C == C0 && k == 10, "ca_conv0_ln_gelu_bwd: needs C=512, k=10");
+  CA_CHECK_ARG(C == C0 && k == 10 && stride >= 1 && stride <= 16, "ca_conv0_ln_gelu_bwd: needs C=512, k=10, stride 1..16");
   const int64_t T0 = (N - k) / stride + 1;
   const int g = conv0_bwd_grid(B, T0);
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL((conv0_bwd_kernel<10>), dim3(g), dim3(256), 0, s, x, w, bias, gamma, beta,
+  const size_t lds = (size_t)(CONV0_FPB * 16 + 16 + 4 * C0) * sizeof(float);
+  hipLaunchKernelGGL((conv0_bwd_kernel<10>), dim3(g), dim3(256), lds, s, x, w, bias, gamma, beta,
                      (const unsigned short*)dy, partial, B, N, T0, stride, eps);
   const int64_t st = (int64_t)C0 * (k + 3);
   ca_reduce_partials_launch(partial, g, st, C0 * k, dw, 1, s);
