@@ -1010,18 +1010,20 @@ __global__ __launch_bounds__(512) void ca_gemm_kernel_x(const CaGemmGroup grp) {
   }
 }
 
-// ---- kernel L: 256x128 tile, 8 waves (4x2), 3-stage LDS ring, ONE barrier per K-step --------
-// Software pipeline: LDS-DMA runs two K-tiles ahead behind a counted vmcnt (never drained in the
-// loop); the second half (k = 32..63) of each tile's fragments is held in registers across the
-// barrier so the MFMA pipe always has 16 independent MFMAs to issue while the next tile's first
-// fragments are being read.  One workgroup per CU (144 KiB LDS).
+// ---- kernel L: 256x128 tile, 8 waves (4x2, 64x64 each), 2 LDS stages, one workgroup per CU ---------------------
+// For the N = d shapes of the path (out-projection, FFN2 and the data gradients that produce [tokens, d]): 128
+// tiles of 256x256 leave half the chip idle, and the 128x128 kernel with its two workgroups per CU runs at the
+// per-CU LDS-fill limit (2 x 32 KiB per 64-k step for 2 x 128 x 128 outputs = ~95 GB/s per CU at its in-step rate;
+// MI355X_MICROARCH: 66-73 GB/s L2-served).  256x128 tiles give every CU one workgroup (240 tiles at M = 3992,
+// N = 1920) at 3/4 of S's fill bytes per FLOP.  Built like kernel X: scalar-base LDS-DMA streams, fragments
+// double-buffered in registers with the reads issued BETWEEN the MFMAs of the running block (immediate-offset
+// addressing), one barrier per K-step in front of its last block, staggered DMA bursts (waves 0-3 right behind the
+// barrier, waves 4-7 one block later).  A K-step has two blocks of 16 MFMAs (k-half 0, k-half 1) per wave.
 #define LBM 256
 #define LBN 128
-#define LA_BYTES (LBM * BK * 2)
-#define LB_BYTES (LBN * BK * 2)
-#define LSTAGE (LA_BYTES + LB_BYTES)
-#define L_NSTAGE 3
-#define L_LDS_BYTES (L_NSTAGE * LSTAGE)  // 147456 >= 8 waves * 64*68*4 (139264) epilogue staging
+#define LA_BYTES (LBM * BK * 2)  // 32 KiB
+#define LB_BYTES (LBN * BK * 2)  // 16 KiB
+#define L_LDS_BYTES (8 * 64 * EPI_PITCH * 4)  // 139264: epilogue staging >= 2 stages * 48 KiB
 
 template <int AL, int BL>
 __global__ __launch_bounds__(512) void ca_gemm_kernel_l(const CaGemmDesc d) {
@@ -1035,25 +1037,23 @@ __global__ __launch_bounds__(512) void ca_gemm_kernel_l(const CaGemmDesc d) {
   const int m0 = tm * LBM, n0 = tn * LBN;
   const int z = blockIdx.z;
   const int z1 = z / d.batch2, z2 = z % d.batch2;
-
   const __bf16* A = (const __bf16*)d.A + z1 * d.sA1 + z2 * d.sA2;
   const __bf16* B = (const __bf16*)d.B + z1 * d.sB1 + z2 * d.sB2;
-
   const int K = d.K;
   const int nk = (K + BK - 1) / BK;
 
-  KMajorLoader<4> la_k;
-  KMajorLoader<2> lb_k;
-  MNMajorLoader<4, 32> la_m;
-  MNMajorLoader<2, 16> lb_m;
+  KMajorStream<4> la_k;
+  KMajorStream<2> lb_k;
+  MNMajorStream<4, 32> la_f;
+  MNMajorStream<2, 16> lb_f;
   if (AL == CA_KMAJOR)
     la_k.init(A, d.lda, m0, d.M, wave, lane);
   else
-    la_m.init(A, d.lda, d.a_kseg, d.a_kseg_stride, m0, d.M, wave, lane);
+    la_f.init(A, d.lda, m0, d.M, wave, lane);
   if (BL == CA_KMAJOR)
     lb_k.init(B, d.ldb, n0, d.N, wave, lane);
   else
-    lb_m.init(B, d.ldb, d.b_kseg, d.b_kseg_stride, n0, d.N, wave, lane);
+    lb_f.init(B, d.ldb, n0, d.N, wave, lane);
 
   f32x4_t acc[4][4];
 #pragma unroll
@@ -1061,148 +1061,161 @@ __global__ __launch_bounds__(512) void ca_gemm_kernel_l(const CaGemmDesc d) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-  auto issue_stage = [&](int kt, int stage) {
-    char* st = smem + stage * LSTAGE;
-    if (AL == CA_KMAJOR)
-      la_k.issue(st, wave, kt * BK, K);
-    else
-      la_m.issue(st, wave, lane, kt * BK, K);
-    if (BL == CA_KMAJOR)
-      lb_k.issue(st + LA_BYTES, wave, kt * BK, K);
-    else
-      lb_m.issue(st + LA_BYTES, wave, lane, kt * BK, K);
+  // LDS: A0 | A1 (32 KiB each) | B0 | B1 (16 KiB each)
+  auto burst = [&](int kt) {  // this wave's share of tile kt: 4 A pieces + 2 B pieces
+    if (kt >= nk) return;
+    char* na = smem + (kt & 1) * LA_BYTES;
+    char* nb = smem + 2 * LA_BYTES + (kt & 1) * LB_BYTES;
+    const bool full = (kt + 1) * BK <= K;  // wave-uniform
+    if (full) {
+#pragma unroll
+      for (int part = 0; part < 4; ++part) {
+        if (AL == CA_KMAJOR)
+          la_k.issue_one(na, wave, part);
+        else
+          la_f.issue_one(na, wave, part);
+        if (part < 2) {
+          if (BL == CA_KMAJOR)
+            lb_k.issue_one(nb, wave, part);
+          else
+            lb_f.issue_one(nb, wave, part);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int part = 0; part < 4; ++part) {
+        if (AL == CA_KMAJOR)
+          la_k.issue_one_tail(na, wave, K - kt * BK, part);
+        else
+          la_f.issue_one_tail(na, wave, lane, K - kt * BK, part);
+        if (part < 2) {
+          if (BL == CA_KMAJOR)
+            lb_k.issue_one_tail(nb, wave, K - kt * BK, part);
+          else
+            lb_f.issue_one_tail(nb, wave, lane, K - kt * BK, part);
+        }
+      }
+    }
+    if (AL == CA_KMAJOR) la_k.advance(); else la_f.advance();
+    if (BL == CA_KMAJOR) lb_k.advance(); else lb_f.advance();
   };
-  // Fragment reads are inline asm so that hipcc's own (conservative, lgkmcnt(0)) waits do not
-  // serialise the register pipeline; completion is tracked by the explicit s_waitcnt below.
+  auto zero_tail = [&](int kt) {
+    if (kt != nk - 1 || nk * BK == K) return;
+    char* na = smem + (kt & 1) * LA_BYTES;
+    char* nb = smem + 2 * LA_BYTES + (kt & 1) * LB_BYTES;
+    const int krem = K - kt * BK;
+    if (AL == CA_KMAJOR) la_k.zero_fix(na, wave, lane, krem); else la_f.zero_fix(na, wave, lane, krem);
+    if (BL == CA_KMAJOR) lb_k.zero_fix(nb, wave, lane, krem); else lb_f.zero_fix(nb, wave, lane, krem);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
+  // per-lane fragment base addresses (stage 0; K-major: one per k-half, fragment = immediate offset;
+  // MN-major: one per fragment, k-half = immediate offset)
   const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
-  uint32_t a_addr[2], b_addr[2];  // per-lane LDS byte address of fragment (i or j = 0) for s = 0, 1
+  uint32_t abase[4], bbase[4];
+  if (AL == CA_KMAJOR) {
+    const int r = wm * 64 + (lane & 15);
 #pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    if (AL == CA_KMAJOR) {
-      const int r = wm * 64 + (lane & 15);
-      a_addr[s] = lds0 + r * 128 + (((4 * s + (lane >> 4)) ^ ((r >> 1) & 7)) * 16);
-    } else {
-      const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
-      const int c = (((wm * 64) >> 3) + (p >> 1)) ^ ((q | ((g & 1) << 2)) << 1);
-      a_addr[s] = lds0 + (32 * s + 8 * g + q) * 512 + c * 16 + (p & 1) * 8;
-    }
-    if (BL == CA_KMAJOR) {
-      const int r = wn * 64 + (lane & 15);
-      b_addr[s] = lds0 + LA_BYTES + r * 128 + (((4 * s + (lane >> 4)) ^ ((r >> 1) & 7)) * 16);
-    } else {
-      const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
-      const int c = (((wn * 64) >> 3) + (p >> 1)) ^ ((q | ((g & 1) << 2)) << 1);
-      b_addr[s] = lds0 + LA_BYTES + (32 * s + 8 * g + q) * 256 + c * 16 + (p & 1) * 8;
-    }
-  }
-  typedef __attribute__((ext_vector_type(8))) short s16x8_t;
-#define LDS_B128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
-#define LDS_TR(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
-  auto read_frags = [&](int stage, int s, bf16x8_t (&af)[4], bf16x8_t (&bfr)[4]) {
-    const uint32_t so = (uint32_t)stage * LSTAGE;
-    const uint32_t aa = a_addr[s] + so, ba = b_addr[s] + so;
-    if (AL == CA_KMAJOR) {
-      LDS_B128(af[0], aa, 0);
-      LDS_B128(af[1], aa, 2048);
-      LDS_B128(af[2], aa, 4096);
-      LDS_B128(af[3], aa, 6144);
-    } else {
-      // 16 columns further = 2 chunks of 16 B: the swizzle XOR only touches chunk bits 1..3, and
-      // (cb>>3) advances by 2 per fragment, so fragment i sits at +32*i bytes before the XOR; the
-      // XOR is folded into the base only when it commutes, so compute each address explicitly.
-      s16x4_t lo[4], hi[4];
-      const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
-      const int sw = (q | ((g & 1) << 2)) << 1;
-      const uint32_t rowb = lds0 + so + (32 * s + 8 * g + q) * 512 + (p & 1) * 8;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const uint32_t ad = rowb + ((((wm * 64 + i * 16) >> 3) + (p >> 1)) ^ sw) * 16;
-        LDS_TR(lo[i], ad, 0);
-        LDS_TR(hi[i], ad, 2048);
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        s16x8_t v = {lo[i][0], lo[i][1], lo[i][2], lo[i][3], hi[i][0], hi[i][1], hi[i][2], hi[i][3]};
-        af[i] = __builtin_bit_cast(bf16x8_t, v);
-      }
-    }
-    if (BL == CA_KMAJOR) {
-      LDS_B128(bfr[0], ba, 0);
-      LDS_B128(bfr[1], ba, 2048);
-      LDS_B128(bfr[2], ba, 4096);
-      LDS_B128(bfr[3], ba, 6144);
-    } else {
-      s16x4_t lo[4], hi[4];
-      const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
-      const int sw = (q | ((g & 1) << 2)) << 1;
-      const uint32_t rowb = lds0 + so + LA_BYTES + (32 * s + 8 * g + q) * 256 + (p & 1) * 8;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const uint32_t ad = rowb + ((((wn * 64 + j * 16) >> 3) + (p >> 1)) ^ sw) * 16;
-        LDS_TR(lo[j], ad, 0);
-        LDS_TR(hi[j], ad, 1024);
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        s16x8_t v = {lo[j][0], lo[j][1], lo[j][2], lo[j][3], hi[j][0], hi[j][1], hi[j][2], hi[j][3]};
-        bfr[j] = __builtin_bit_cast(bf16x8_t, v);
-      }
-    }
-  };
-  auto mma = [&](bf16x8_t (&af)[4], bf16x8_t (&bfr)[4]) {
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-  };
-
-  bf16x8_t a0[4], b0[4], a1[4], b1[4];
-  // prologue: two tiles in flight (6 LDS-DMA per wave per tile)
-  issue_stage(0, 0);
-  if (nk > 1) {
-    issue_stage(1, 1);
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    for (int sh = 0; sh < 2; ++sh) abase[sh] = lds0 + r * 128 + (((4 * sh + (lane >> 4)) ^ ((r >> 1) & 7)) * 16);
   } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+    const int swz = q | ((g & 1) << 2);
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      const int c = ((((wm * 64 + f * 16) >> 3) + (pp >> 1)) ^ (swz << 1));
+      abase[f] = lds0 + (8 * g + q) * 512 + c * 16 + (pp & 1) * 8;
+    }
   }
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  if (nk > 2) issue_stage(2, 2);
-  read_frags(0, 0, a0, b0);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_sched_barrier(0);
-  read_frags(0, 1, a1, b1);
-  __builtin_amdgcn_sched_barrier(0);
-  mma(a0, b0);
-  int stage = 1;  // stage holding tile kt
-  for (int kt = 1; kt < nk; ++kt) {
-    // frag1(kt-1) has landed in registers; tile kt has landed in LDS (tile kt+1 may be in flight)
-    if (kt + 1 < nk)
-      asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-    else
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  if (BL == CA_KMAJOR) {
+    const int r = wn * 64 + (lane & 15);
+#pragma unroll
+    for (int sh = 0; sh < 2; ++sh)
+      bbase[sh] = lds0 + 2 * LA_BYTES + r * 128 + (((4 * sh + (lane >> 4)) ^ ((r >> 1) & 7)) * 16);
+  } else {
+    const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+    const int swz = q | ((g & 1) << 2);
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      const int c = ((((wn * 64 + f * 16) >> 3) + (pp >> 1)) ^ (swz << 1));
+      bbase[f] = lds0 + 2 * LA_BYTES + (8 * g + q) * 256 + c * 16 + (pp & 1) * 8;
+    }
+  }
+  bf16x8_t A0[4], A1[4], B0[4], B1[4];
+#define L_RD_A(ST, SH, F, dst)                                                  \
+  do {                                                                          \
+    if (AL == CA_KMAJOR)                                                        \
+      dst = lds_read_b128<(ST) * LA_BYTES + (F) * 2048>(abase[SH]);             \
+    else                                                                        \
+      dst = lds_read_tr<(ST) * LA_BYTES + (SH) * 16384, 2048>(abase[F]);        \
+  } while (0)
+#define L_RD_B(ST, SH, F, dst)                                                  \
+  do {                                                                          \
+    if (BL == CA_KMAJOR)                                                        \
+      dst = lds_read_b128<(ST) * LB_BYTES + (F) * 2048>(bbase[SH]);             \
+    else                                                                        \
+      dst = lds_read_tr<(ST) * LB_BYTES + (SH) * 8192, 1024>(bbase[F]);         \
+  } while (0)
+#define L_SB __builtin_amdgcn_sched_barrier(0)
+#define L_MM2(AF, BF, I, J)                                                                             \
+  do {                                                                                                  \
+    acc[I][J] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[J], AF[I], acc[I][J], 0, 0, 0);              \
+    acc[I][(J) + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[(J) + 1], AF[I], acc[I][(J) + 1], 0, 0, 0); \
+    L_SB;                                                                                               \
+  } while (0)
+  auto kstep = [&](auto st_c, int kt) {
+    constexpr int ST = decltype(st_c)::value;
+    if (wave >= 4) burst(kt + 1);
+    // block 0: k-half 0 of tile kt; reads k-half 1 (same stage)
+    lds_wait(B0);
+    lds_wait(A0);
+    L_SB;
+    __builtin_amdgcn_s_setprio(1);
+    L_MM2(A0, B0, 0, 0); L_RD_B(ST, 1, 0, B1[0]); L_SB;
+    L_MM2(A0, B0, 0, 2); L_RD_B(ST, 1, 1, B1[1]); L_SB;
+    L_MM2(A0, B0, 1, 0); L_RD_B(ST, 1, 2, B1[2]); L_SB;
+    L_MM2(A0, B0, 1, 2); L_RD_B(ST, 1, 3, B1[3]); L_SB;
+    L_MM2(A0, B0, 2, 0); L_RD_A(ST, 1, 0, A1[0]); L_SB;
+    L_MM2(A0, B0, 2, 2); L_RD_A(ST, 1, 1, A1[1]); L_SB;
+    L_MM2(A0, B0, 3, 0); L_RD_A(ST, 1, 2, A1[2]); L_SB;
+    L_MM2(A0, B0, 3, 2); L_RD_A(ST, 1, 3, A1[3]); L_SB;
+    __builtin_amdgcn_s_setprio(0);
+    lds_wait(B1);
+    lds_wait(A1);  // the last fragment reads of tile kt have returned
+    // tile kt+1 has landed (this wave's share; the barrier covers the others) and stage ST is free
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    zero_tail(kt + 1);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    // the stage that held tile kt-1 is free now: every wave finished reading it before arriving
-    if (kt + 2 < nk) issue_stage(kt + 2, stage == 0 ? 2 : stage - 1);
-    read_frags(stage, 0, a0, b0);
-    __builtin_amdgcn_sched_barrier(0);
-    mma(a1, b1);  // second half of tile kt-1, from registers: covers the LDS read latency
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // a0/b0 (issued a whole MFMA block ago)
-    __builtin_amdgcn_sched_barrier(0);
-    read_frags(stage, 1, a1, b1);
-    __builtin_amdgcn_sched_barrier(0);
-    mma(a0, b0);
-    stage = stage == 2 ? 0 : stage + 1;
+    if (wave < 4) burst(kt + 2);
+    L_SB;
+    // block 1: k-half 1 of tile kt; reads k-half 0 of tile kt+1 (harmless stale data after the last tile)
+    __builtin_amdgcn_s_setprio(1);
+    L_MM2(A1, B1, 0, 0); L_RD_B(1 - ST, 0, 0, B0[0]); L_SB;
+    L_MM2(A1, B1, 0, 2); L_RD_B(1 - ST, 0, 1, B0[1]); L_SB;
+    L_MM2(A1, B1, 1, 0); L_RD_B(1 - ST, 0, 2, B0[2]); L_SB;
+    L_MM2(A1, B1, 1, 2); L_RD_B(1 - ST, 0, 3, B0[3]); L_SB;
+    L_MM2(A1, B1, 2, 0); L_RD_A(1 - ST, 0, 0, A0[0]); L_SB;
+    L_MM2(A1, B1, 2, 2); L_RD_A(1 - ST, 0, 1, A0[1]); L_SB;
+    L_MM2(A1, B1, 3, 0); L_RD_A(1 - ST, 0, 2, A0[2]); L_SB;
+    L_MM2(A1, B1, 3, 2); L_RD_A(1 - ST, 0, 3, A0[3]); L_SB;
+    __builtin_amdgcn_s_setprio(0);
+  };
+  burst(0);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  zero_tail(0);
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  L_RD_B(0, 0, 0, B0[0]); L_RD_B(0, 0, 1, B0[1]); L_RD_B(0, 0, 2, B0[2]); L_RD_B(0, 0, 3, B0[3]);
+  L_RD_A(0, 0, 0, A0[0]); L_RD_A(0, 0, 1, A0[1]); L_RD_A(0, 0, 2, A0[2]); L_RD_A(0, 0, 3, A0[3]);
+  if (wave < 4) burst(1);
+  for (int kt = 0; kt < nk; kt += 2) {
+    kstep(std::integral_constant<int, 0>{}, kt);
+    if (kt + 1 < nk) kstep(std::integral_constant<int, 1>{}, kt + 1);
   }
+#undef L_RD_A
+#undef L_RD_B
+#undef L_MM2
+#undef L_SB
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_sched_barrier(0);
-  mma(a1, b1);
-  // all waves are done with the staging ring before it is reused for the epilogue
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   gemm_epilogue(d, acc, smem, wave, lane, m0 + wm * 64, n0 + wn * 64, z, z1, z2);
@@ -1814,7 +1827,7 @@ static int ca_gemm_launch(const CaGemmDesc* desc, void* stream) {
   // the 128x128 kernel with two workgroups per CU equals or beats the 256x128 one-per-CU kernel,
   // because its second workgroup hides the epilogue; the L kernel is kept selectable for tuning.
   (void)tiles_l;
-  int use_l = g_force_kernel == 2 ? 1 : 0;
+  int use_l = (g_force_kernel == 2 && d.a_kseg == 0 && d.b_kseg == 0) ? 1 : 0;
   // Kernel X (256x256): only where it fills the chip -- at least ~0.7 tiles per CU in its last round.
   const int xtm = (d.M + XBM - 1) / XBM, xtn = (d.N + XBN - 1) / XBN;
   const int64_t xt = (int64_t)xtm * xtn * nb;
