@@ -13,6 +13,7 @@
 //   * out-of-range rows are clamped (results discarded), out-of-range k reads a zero page.
 #include "common.h"
 #include <type_traits>
+#include <cstdlib>
 
 #define BM 128
 #define BN 128
@@ -1826,8 +1827,9 @@ static int ca_gemm_launch(const CaGemmDesc* desc, void* stream) {
   // Measured on MI355X (profiles/r01_gemm_shapes.txt): at the path's shapes (K = 1920..7680, M = 3992)
   // the 128x128 kernel with two workgroups per CU equals or beats the 256x128 one-per-CU kernel,
   // because its second workgroup hides the epilogue; the L kernel is kept selectable for tuning.
-  (void)tiles_l;
   int use_l = (g_force_kernel == 2 && d.a_kseg == 0 && d.b_kseg == 0) ? 1 : 0;
+  // tuning knob: CA_GEMM_PREFER_L=1 sends the one-round 256x128 grids (160..256 tiles: the N = d shapes) to kernel L
+  static const int prefer_l = [] { const char* e = getenv("CA_GEMM_PREFER_L"); return e ? atoi(e) : 0; }();
   // Kernel X (256x256): only where it fills the chip -- at least ~0.7 tiles per CU in its last round.
   const int xtm = (d.M + XBM - 1) / XBM, xtn = (d.N + XBN - 1) / XBN;
   const int64_t xt = (int64_t)xtm * xtn * nb;
@@ -1841,6 +1843,9 @@ static int ca_gemm_launch(const CaGemmDesc* desc, void* stream) {
   // - 188 / 192 / 564 tiles - and loses at 68 % - 368 tiles)
   int use_x = (g_force_kernel == 0 && d.K >= 512 && xt >= 160 && xeff * xfill >= (tn ? 0.60 : 0.70)) ? 1 : 0;
   if (g_force_kernel == 3 || d.a_colsum) use_x = 1;  // the column sums live in kernel X only
+  if (prefer_l && !use_x && g_force_kernel == 0 && d.a_kseg == 0 && d.b_kseg == 0 && d.K >= 512 && tiles_l >= 160 &&
+      tiles_l <= 256 * prefer_l)
+    use_l = 1;
   g_last_kind = use_x ? 2 : (use_l ? 1 : 0);
   if (use_x) {
     static bool xattr = false;

@@ -397,6 +397,7 @@ extern "C" int ca_sumsq_f32(const float* g, int64_t n, float* out, int32_t accum
 }
 
 // torch.optim.AdamW (decoupled decay) with the clip coefficient of clip_grad_norm_ folded in.
+template <bool NT>
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ m,
                                                     float* __restrict__ v,
                                                     const float* __restrict__ g,
@@ -404,7 +405,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
                                                     float lr, float b1, float b2, float eps,
                                                     float wd, float bc1, float bc2_sqrt,
                                                     float grad_scale, float max_norm,
-                                                    const float* __restrict__ gnorm_sq) {
+                                                    const float* __restrict__ gnorm_sq, int allow_vec) {
   float coef = grad_scale;
   if (gnorm_sq && max_norm > 0.f) {
     const float nrm = sqrtf(gnorm_sq[0]) * grad_scale;
@@ -414,11 +415,16 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
   const float step_size = lr / bc1;
   const float decay = 1.f - lr * wd;
   // 16 bytes per lane and array (f32x4; 8 bytes of bf16): the flat buffers and every bucket offset are 32-byte aligned
-  const bool vec = ((((uintptr_t)p | (uintptr_t)m | (uintptr_t)v | (uintptr_t)g) & 15) == 0) && (!p16 || ((uintptr_t)p16 & 7) == 0);
+  const bool vec = allow_vec && ((((uintptr_t)p | (uintptr_t)m | (uintptr_t)v | (uintptr_t)g) & 15) == 0) && (!p16 || ((uintptr_t)p16 & 7) == 0);
   const int64_t n4 = vec ? (n >> 2) : 0;
+  // The 28 bytes per parameter of fp32 state are touched once per step: non-temporal loads and stores keep them from
+  // displacing the operand panels of the forward GEMMs this kernel runs beside (trainer.py) from the L2s / Infinity
+  // Cache.  The bf16 compute copy is stored with the default policy: the next forward reads it within a millisecond.
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-    const f32x4_t g4 = ((const f32x4_t*)g)[i];
-    f32x4_t p4 = ((const f32x4_t*)p)[i], m4 = ((const f32x4_t*)m)[i], v4 = ((const f32x4_t*)v)[i];
+    const f32x4_t g4 = NT ? __builtin_nontemporal_load((const f32x4_t*)g + i) : ((const f32x4_t*)g)[i];
+    f32x4_t p4 = NT ? __builtin_nontemporal_load((const f32x4_t*)p + i) : ((const f32x4_t*)p)[i];
+    f32x4_t m4 = NT ? __builtin_nontemporal_load((const f32x4_t*)m + i) : ((const f32x4_t*)m)[i];
+    f32x4_t v4 = NT ? __builtin_nontemporal_load((const f32x4_t*)v + i) : ((const f32x4_t*)v)[i];
     u16x4_t h4;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -433,9 +439,15 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
       v4[e] = vi;
       h4[e] = f2bf(pi);
     }
-    ((f32x4_t*)p)[i] = p4;
-    ((f32x4_t*)m)[i] = m4;
-    ((f32x4_t*)v)[i] = v4;
+    if (NT) {
+      __builtin_nontemporal_store(p4, (f32x4_t*)p + i);
+      __builtin_nontemporal_store(m4, (f32x4_t*)m + i);
+      __builtin_nontemporal_store(v4, (f32x4_t*)v + i);
+    } else {
+      ((f32x4_t*)p)[i] = p4;
+      ((f32x4_t*)m)[i] = m4;
+      ((f32x4_t*)v)[i] = v4;
+    }
     if (p16) ((u16x4_t*)p16)[i] = h4;
   }
   for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
@@ -461,11 +473,18 @@ extern "C" int ca_adamw_step(float* p, float* m, float* v, const float* g, void*
   // CA_ADAMW_BLOCKS caps the grid (tuning knob): a smaller grid leaves CU slots and HBM bandwidth to the forward
   // GEMMs this update overlaps with (trainer.py runs it bucket by bucket on a side stream)
   static const int cap = [] { const char* e = getenv("CA_ADAMW_BLOCKS"); return e ? atoi(e) : 0; }();
-  int grid = ew_grid(n, 4);
+  static const int vec = [] { const char* e = getenv("CA_ADAMW_VEC"); return e ? atoi(e) : 1; }();
+  static const int nt = [] { const char* e = getenv("CA_ADAMW_NT"); return e ? atoi(e) : 1; }();
+  int grid = ew_grid(n, vec ? 4 : 1);
   if (cap > 0 && grid > cap) grid = cap;
-  hipLaunchKernelGGL(adamw_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, m,
-                     v, g, (unsigned short*)p16, n, lr, beta1, beta2, eps, weight_decay, bc1,
-                     sqrtf(bc2), grad_scale, max_norm, gnorm_sq);
+  if (nt)
+    hipLaunchKernelGGL(adamw_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, m, v, g,
+                       (unsigned short*)p16, n, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2), grad_scale,
+                       max_norm, gnorm_sq, vec);
+  else
+    hipLaunchKernelGGL(adamw_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, m, v, g,
+                       (unsigned short*)p16, n, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2), grad_scale,
+                       max_norm, gnorm_sq, vec);
   CA_CHECK_LAUNCH("ca_adamw_step");
   return CA_OK;
 }

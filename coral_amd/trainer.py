@@ -172,7 +172,9 @@ class DataParallelTrainer:
         self.train_range = (lo, hi)
         # AdamW is HBM-bound, the next forward MFMA-bound: run the update bucket by bucket on a side stream
         # and let the next forward wait per bucket (engine._await) instead of for the whole optimiser.
-        self.overlap_optimizer = (overlap_optimizer and st.p32.is_cuda and hasattr(engine, "_await")
+        # (CA_OPT_OVERLAP=0: everything on one stream - the regime the per-kernel profiles are taken in)
+        self.overlap_optimizer = (overlap_optimizer and os.environ.get("CA_OPT_OVERLAP", "1") != "0"
+                                  and st.p32.is_cuda and hasattr(engine, "_await")
                                   and (lo, hi) == (0, st.numel))
         self.opt_stream = None
         if self.overlap_optimizer:

@@ -423,6 +423,10 @@ class Wav2Vec2CTCEngine:
             ops.conv0_bwd_partial_floats(B, N, C0, s.conv_kernel[0], s.conv_stride[0]), 4096)
         w["partial"] = z(pf, dt=f32)
         w["partial_w"] = z(pf, dt=f32)  # the weight-gradient stream's own scratch
+        # LayerNorm-backward partials (d gamma | d beta per row block) of a layer's two norms, two layers in flight:
+        # their second-stage reductions run on the weight-gradient stream (backward())
+        w["ln_parts"] = ops.layernorm_bwd_partial_floats(M, d) // (2 * d)
+        w["ln_partial"] = [[z(ops.layernorm_bwd_partial_floats(M, d), dt=f32) for _ in range(2)] for _ in range(2)]
         self._ws, self._ws_key = w, key
         return w
 
@@ -677,9 +681,16 @@ class Wav2Vec2CTCEngine:
             ops.gemm(du, p16, other, M=M, N=d, K=f, lda=f, b_layout=MNMAJOR, ldb=d, ldc=d,
                      b_off=o(pl + "feed_forward.intermediate_dense.weight"))
             # LN2: dh1 = dh + LN'(dx2)
-            ops.layernorm_bwd(other, w["h1"][l], st.view(pl + "final_layer_norm.weight"), None, w["st2"][l],
-                              dh, dh1, st.view(pl + "final_layer_norm.weight", "g32"),
-                              st.view(pl + "final_layer_norm.bias", "g32"), part, M, d)
+            # (with the side stream, the d gamma | d beta partials of the layer's two norms are reduced there: two
+            # tiny dependent launches less per layer on the critical stream)
+            lnp = w["ln_partial"][it & 1] if ws is not None else None
+            if ws is None:
+                ops.layernorm_bwd(other, w["h1"][l], st.view(pl + "final_layer_norm.weight"), None, w["st2"][l],
+                                  dh, dh1, st.view(pl + "final_layer_norm.weight", "g32"),
+                                  st.view(pl + "final_layer_norm.bias", "g32"), part, M, d)
+            else:
+                ops.layernorm_bwd(other, w["h1"][l], st.view(pl + "final_layer_norm.weight"), None, w["st2"][l],
+                                  dh, dh1, None, None, lnp[0], M, d)
             # out_proj: h1 = h + Wo ctx + bo
             wg.append(dict(dY=dh1, X=w["ctx"][l], M=d, N=d, K=M, lda=d, ldb=d, part=w["partial_w"],
                            c_off=o(pl + "attention.out_proj.weight"), accumulate=lacc,
@@ -704,9 +715,13 @@ class Wav2Vec2CTCEngine:
             ops.gemm(dqkv, p16, dx1, M=M, N=d, K=3 * d, lda=3 * d, b_layout=MNMAJOR, ldb=d, ldc=d,
                      b_off=o(pl + "attention.q_proj.weight"))
             # LN1: dh_in = dh1 + LN'(dx1)
-            ops.layernorm_bwd(dx1, hin, st.view(pl + "layer_norm.weight"), None, w["st1"][l], dh1, dh_next,
-                              st.view(pl + "layer_norm.weight", "g32"), st.view(pl + "layer_norm.bias", "g32"),
-                              part, M, d)
+            if ws is None:
+                ops.layernorm_bwd(dx1, hin, st.view(pl + "layer_norm.weight"), None, w["st1"][l], dh1, dh_next,
+                                  st.view(pl + "layer_norm.weight", "g32"), st.view(pl + "layer_norm.bias", "g32"),
+                                  part, M, d)
+            else:
+                ops.layernorm_bwd(dx1, hin, st.view(pl + "layer_norm.weight"), None, w["st1"][l], dh1, dh_next,
+                                  None, None, lnp[1], M, d)
             dh = dh_next
             if ws is None:
                 done(f"layer{l}")
@@ -717,6 +732,11 @@ class Wav2Vec2CTCEngine:
                 ev = mark()
                 ws.wait_event(ev)
                 with torch.cuda.stream(ws):
+                    # (weight and bias gradients of a norm are adjacent in the flat buffer: one reduction each)
+                    ops.reduce_rows(lnp[0], w["ln_parts"], 2 * d, 2 * d, g32[o(pl + "final_layer_norm.weight"):],
+                                    accumulate=True)
+                    ops.reduce_rows(lnp[1], w["ln_parts"], 2 * d, 2 * d, g32[o(pl + "layer_norm.weight"):],
+                                    accumulate=True)
                     wd = torch.cuda.Event()
                     wd.record(ws)
                     wdone[it] = wd

@@ -1,0 +1,42 @@
+"""`python bench.py --gpus N` as the driver calls it without a launcher: the parent process starts the N ranks itself
+(the reference's one-command launch is `accelerate launch ... finetune_asr_model.py`,
+R/src/scripts/finetune_asr_model.py:9-12) and relays their exit code; the JSON line reports the real number of ranks
+and the gradient wire format (fp32 = what the reference's DDP reduces).  The GPU box has one device, so the two ranks
+share it through the gloo backend (CA_BENCH_SHARE_GPU=1): everything but the RCCL transport is the production path."""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def test_bench_spawns_its_ranks_and_reports_them():
+    env = dict(os.environ, CA_BENCH_SHARE_GPU="1")
+    env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--backend", "gloo", "--model", "wav2vec2-small",
+           "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--check-replicas"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=str(ROOT))
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    main = [d for d in lines if "metric" in d]
+    assert len(main) == 1, r.stdout[-1500:]              # rank 0 prints ONE line
+    d = main[0]
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["grad_wire"] == "fp32" and d["scaling"] == "weak"
+    assert d["config"]["global_batch"] == 16 and d["config"]["parallelism"] == "dp2"
+    assert d["value"] > 0 and d["steps"] == 2 and d["warmup"] == 1
+    spread = [x for x in lines if "replica_param_spread" in x]
+    assert spread and spread[0]["replica_param_spread"] == 0.0   # DDP invariant: identical replicas
+
+
+def test_bench_refuses_more_ranks_than_devices():
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("CA_BENCH_SHARE_GPU", None)
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "64"], env=env, capture_output=True, text=True,
+                       timeout=300, cwd=str(ROOT))
+    assert r.returncode != 0 and "only" in r.stderr   # never a silent 1-GPU run

@@ -23,8 +23,8 @@ def one(pattern):
 stats = one(f"prof_{tag}_stats/*/*kernel_stats.csv")
 rows = list(csv.DictReader(open(stats)))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
-lines = [f"# CA_WGRAD_STREAM=0 rocprofv3 --kernel-trace --stats --output-format csv -- {cmd}",
-         "# (kernels serialised on one stream for per-kernel durations; the timed bench runs the weight gradients on a second stream)",
+lines = [f"# CA_WGRAD_STREAM=0 CA_OPT_OVERLAP=0 rocprofv3 --kernel-trace --stats --output-format csv -- {cmd}",
+         "# (kernels serialised on one stream for per-kernel durations; the timed bench overlaps the optimiser and the weight gradients on side streams)",
          f"# 1x MI355X; {nsteps} train steps in the run (warm-up + timed + 2 hipEvent-profiled); "
          f"total kernel time {tot / 1e6:.1f} ms = {tot / 1e6 / nsteps:.2f} ms/step",
          "Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs,StdDev"]
