@@ -182,7 +182,13 @@ def whisper_bench(args, world, rank, device):
     from coral_amd.whisper_train import WhisperTrainEngine
 
     shape = WhisperShape(**CORAL_WHISPER_SHAPES[args.model])
-    eng = WhisperTrainEngine(shape, device, activation_dropout=0.1)
+    # dropouts of the CoRal model key (config/model/<key>.yaml = R/config/model/<key>.yaml): whisper-medium trains with
+    # activation_dropout 0.1, whisper-large-turbo with hidden-state dropout 0.1
+    import yaml
+
+    mcfg = yaml.safe_load((ROOT / "config" / "model" / f"{args.model}.yaml").read_text())
+    eng = WhisperTrainEngine(shape, device, activation_dropout=float(mcfg.get("activation_dropout", 0.0)),
+                             dropout=float(mcfg.get("dropout", 0.0)))
     g = torch.Generator(device=device).manual_seed(4242)
     for n in eng.exported_names():
         v = eng.store.view(n)
@@ -247,7 +253,8 @@ def whisper_bench(args, world, rank, device):
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16 + fp8 e4m3 (encoder q|k|v, fc1 forward)" if ((args.decode and args.fp8_encoder) or (args.fp8_forward and not args.decode)) else "bf16",
             "data": "synthetic",
-            "config": {"workload": f"{args.model} {mode}, {B} x 30 s per GPU, log-mel on GPU", "global_batch": world * B,
+            "config": {"workload": f"{args.model} {mode}, {B} x 30 s per GPU, log-mel on GPU, dropout {eng.dropout:g} / "
+                                   f"activation_dropout {eng.activation_dropout:g}", "global_batch": world * B,
                        "label_len": int(labels.shape[1]), "parallelism": f"dp{world}"}}), flush=True)
     if world > 1:
         if args.check_replicas and not args.decode:

@@ -28,19 +28,21 @@ class Scratch:
         self.dqkv = _z(M * 3 * d, dev)
         self.du = _z(M * f, dev)
         self.dkv = _z(Mkv * 2 * d, dev) if Mkv else None
-        self.dm = _z(M * d, dev)  # dropout(dh): the gradient entering a sub-layer whose output was dropped (hidden dropout)
+        # dropout(dh): the gradient entering a sub-layer whose output was dropped (hidden dropout); one buffer per block
+        # kind so that a layer's deferred weight gradients can read both
+        self.dm = {"attn": _z(M * d, dev), "ffn": _z(M * d, dev), "cross": _z(M * d, dev)}
         npart = max(ops.layernorm_bwd_partial_floats(M, d), ops.colsum_partial_floats(max(M, Mkv), max(f, 3 * d)), 4096)
         self.part = _z(npart, dev, torch.float32)
 
 
-def _masked_grad(dh, sv, sc: "Scratch", n):
+def _masked_grad(dh, sv, sc: "Scratch", n, kind):
     """Gradient wrt the sub-layer output: dh itself, or dropout(dh) with the forward's mask when the output went
     through hidden-state dropout before the residual add."""
     p, seed = sv.get("hdrop", (0.0, 0))
     if p <= 0.0:
         return dh
-    ops.dropout(dh, sc.dm, n, p, seed)
-    return sc.dm
+    ops.dropout(dh, sc.dm[kind], n, p, seed)
+    return sc.dm[kind]
 
 
 class SelfAttnBlock:
@@ -91,9 +93,7 @@ class SelfAttnBlock:
         st, d = self.st, self.d
         M = B * T
         o, g32, p16 = st.off, st.g32, st.p16
-        dy = _masked_grad(dh, sv, sc, M * d)
-        if dy is not dh and defer is not None:
-            raise NotImplementedError("deferred weight gradients share sc.dm between blocks: launch them per block with hidden dropout")
+        dy = _masked_grad(dh, sv, sc, M * d, "attn")
         # with `defer` the bias gradients travel with the problems (fused into the grouped launch or done by it)
         if defer is None:
             ops.colsum(dy, d, M, d, g32, sc.part, out_off=o(self.attn + "out_proj.bias"))
@@ -160,7 +160,7 @@ class CrossAttnBlock:
         st, d = self.st, self.d
         M, Mk = B * L, B * Te
         o, g32, p16 = st.off, st.g32, st.p16
-        dy = _masked_grad(dh, sv, sc, M * d)
+        dy = _masked_grad(dh, sv, sc, M * d, "cross")
         ops.colsum(dy, d, M, d, g32, sc.part, out_off=o(self.attn + "out_proj.bias"))
         ops.wgrad_gemm(dy, sv["ctx"], g32, M=d, N=d, K=M, lda=d, ldb=d,
                        c_off=o(self.attn + "out_proj.weight"), accumulate=True)
@@ -217,9 +217,7 @@ class FFNBlock:
         st, d, f = self.st, self.d, self.f
         o, g32, p16 = st.off, st.g32, st.p16
         p, seed = sv["drop"]
-        dy = _masked_grad(dh, sv, sc, M * d)
-        if dy is not dh and defer is not None:
-            raise NotImplementedError("deferred weight gradients share sc.dm between blocks: launch them per block with hidden dropout")
+        dy = _masked_grad(dh, sv, sc, M * d, "ffn")
         if defer is None:
             ops.colsum(dy, d, M, d, g32, sc.part, out_off=o(self.fc2 + ".bias"))
         wg = [dict(dY=dy, X=sv["g"], M=d, N=f, K=M, lda=d, ldb=f, c_off=o(self.fc2 + ".weight"), accumulate=True,

@@ -332,12 +332,11 @@ class WhisperTrainEngine(WhisperEngine):
             sv_a, sv_f = w["enc_sv"][l]
             # three rotating buffers: both blocks' dY stay alive until the layer's four weight gradients go out as
             # one grouped launch (192 tiles of the 256x256 kernel at d = 1024 instead of four split-K launches)
-            # (with hidden dropout each block's dY is a masked copy in one shared scratch buffer: per-block launches)
-            wg = [] if ep <= 0.0 else None
+            wg = []
             ff.backward(cur, other, sv_f, sc_e, Me, defer=wg)
             sa.backward(other, third, sv_a, sc_e, B, T, defer=wg)
             nb = 5 * d + s.encoder_ffn_dim
-            if wg is not None and ops.wgrad_gemm_group(wg, g32, colsum_ws=w["bias_ws"], colsum_ld=nb):
+            if ops.wgrad_gemm_group(wg, g32, colsum_ws=w["bias_ws"], colsum_ld=nb):
                 ops.reduce_rows(w["bias_ws"], ops.COLSUM_PARTS, nb, nb,
                                 g32[o(f"model.encoder.layers.{l}.self_attn.q_proj.bias"):], accumulate=True)
             cur, other, third = third, cur, other
