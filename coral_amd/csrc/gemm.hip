@@ -347,8 +347,15 @@ __device__ __forceinline__ bool xcd_tile(int bid, int ntm, int ntn, int& tm, int
   return tm < ntm && tn < ntn;
 }
 template <int SBM, int SBN>
+__device__ __forceinline__ bool tile_of_block_g(int bid, int grid, int ntm, int ntn, int& tm, int& tn);
+template <int SBM, int SBN>
 __device__ __forceinline__ bool tile_of_block(int bid, int ntm, int ntn, int& tm, int& tn) {
-  if ((int)gridDim.x == xcd_grid(ntm, ntn)) {
+  return tile_of_block_g<SBM, SBN>(bid, (int)gridDim.x, ntm, ntn, tm, tn);
+}
+// the same with the size of the (virtual) grid given: persistent workgroups walk a grid larger than the launch
+template <int SBM, int SBN>
+__device__ __forceinline__ bool tile_of_block_g(int bid, int grid, int ntm, int ntn, int& tm, int& tn) {
+  if (grid == xcd_grid(ntm, ntn)) {
     // small problem (fewer than 4 super-blocks per XCD): one rectangular block of tiles per XCD, so an L2 only
     // streams the operand bands of its block.  (Plain round-robin numbering gave each XCD one tile COLUMN: all of
     // A streamed into every L2, 8x the bytes in the PMC counters.)
@@ -682,7 +689,15 @@ struct CaGemmGroup {
   int first[4];  // first tile of problem i in the group's tile list (first[0] = 0)
   int count;     // number of problems (0 = plain launch of d[0])
   int total;     // tiles in the group
+  // Persistent form (vgrid > gridDim.x): the launch has one workgroup per CU; the workgroups of XCD x (blockIdx & 7)
+  // take the virtual blocks x, x + 8, x + 16, ... - the first one each statically, the following ones in the order the
+  // workgroups become free, through one counter per XCD (cnt[x], zero between launches: the last pull resets it).
+  int vgrid;      // blocks of the virtual grid (= gridDim.x in the one-tile-per-workgroup form)
+  unsigned* cnt;  // 8 counters, or null
 };
+// counter slots for persistent launches: launches that may be in flight together (two streams) use different slots
+#define X_CNT_SLOTS 64
+__device__ unsigned g_x_cnt[X_CNT_SLOTS][8];
 template <int AL, int BL, bool KS>
 __global__ __launch_bounds__(512) void ca_gemm_kernel_x(const CaGemmGroup grp) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -690,24 +705,49 @@ __global__ __launch_bounds__(512) void ca_gemm_kernel_x(const CaGemmGroup grp) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;  // 2 x 4 waves, 128 (M) x 64 (N) each
+  // ---- persistent tile loop ------------------------------------------------------------------------------------
+  // One tile per workgroup when the launch covers the virtual grid (vgrid == gridDim.x).  Otherwise the workgroup
+  // keeps pulling virtual blocks of its XCD until they run out: a CU that finishes early starts its next tile at once
+  // (no round structure: the tiles of a "round" stop finishing together, so their output bursts spread out in time
+  // and the next tile's first operand fetch runs under the previous tile's store drain).  Which workgroup computes a
+  // tile never changes its result.
+  const int vgrid = grp.vgrid;
+  const int xcd = (int)blockIdx.x & 7;
+  const int npx = ((int)gridDim.x - xcd + 7) >> 3;  // workgroups of this XCD in the launch
+  const int nvx = (vgrid - xcd + 7) >> 3;           // virtual blocks of this XCD
+  const int ndyn = nvx > npx ? nvx - npx : 0;       // ... handed out dynamically
+  volatile unsigned* nextw = (volatile unsigned*)(smem + X_LDS_BYTES);  // two words, alternating per iteration
+  int vb = (int)blockIdx.x;
+  for (int iter = 0; vb < vgrid; ++iter) {
+  if (grp.cnt != nullptr && tid == 0) {
+    // this workgroup's NEXT block (the answer is read after the tile): relaxed device-scope counter
+    const unsigned i = __hip_atomic_fetch_add(&grp.cnt[xcd], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (i == (unsigned)(ndyn + npx - 1)) __hip_atomic_store(&grp.cnt[xcd], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    nextw[iter & 1] = i;
+  }
+  bool live = true;
   int which = 0, gt = 0;
   if (grp.count > 1) {
     // grouped launch: the group's tiles form one list (problem after problem, each in run order) and XCD x
-    // (= blockIdx & 7) takes the x-th run of ceil(total / 8) of them: every XCD gets the same number of tiles
+    // (= block & 7) takes the x-th run of ceil(total / 8) of them: every XCD gets the same number of tiles
     // whatever the shapes, and a run covers a compact band of one or two problems.
-    gt = ((int)blockIdx.x & 7) * ((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3);
-    if (gt >= grp.total) return;
-    which = gt >= grp.first[1] ? 1 : 0;
-    if (grp.count > 2 && gt >= grp.first[2]) which = 2;
-    if (grp.count > 3 && gt >= grp.first[3]) which = 3;
+    gt = (vb & 7) * (vgrid >> 3) + (vb >> 3);
+    live = gt < grp.total;
+    if (live) {
+      which = gt >= grp.first[1] ? 1 : 0;
+      if (grp.count > 2 && gt >= grp.first[2]) which = 2;
+      if (grp.count > 3 && gt >= grp.first[3]) which = 3;
+    }
   }
   const CaGemmDesc d = grp.d[which];
-  int tm, tn;
-  if (grp.count > 1) {
-    run_tile(gt - grp.first[which], (d.M + XBM - 1) / XBM, (d.N + XBN - 1) / XBN, tm, tn);
-  } else if (!tile_of_block<4, 8>(blockIdx.x, (d.M + XBM - 1) / XBM, (d.N + XBN - 1) / XBN, tm, tn)) {
-    return;
+  int tm = 0, tn = 0;
+  if (live) {
+    if (grp.count > 1)
+      run_tile(gt - grp.first[which], (d.M + XBM - 1) / XBM, (d.N + XBN - 1) / XBN, tm, tn);
+    else
+      live = tile_of_block_g<4, 8>(vb, vgrid, (d.M + XBM - 1) / XBM, (d.N + XBN - 1) / XBN, tm, tn);
   }
+  if (live) {
   const int m0 = tm * XBM, n0 = tn * XBN;
   const int z = blockIdx.z;
   const int z1 = z / d.batch2, z2 = z % d.batch2;
@@ -1009,6 +1049,12 @@ __global__ __launch_bounds__(512) void ca_gemm_kernel_x(const CaGemmGroup grp) {
     gemm_epilogue(d, half, smem, wave, lane, m0 + wm * 128 + ih * 64, n0 + wn * 64, z, z1, z2);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // staging reads done before it is overwritten
   }
+  }  // live
+  if (grp.cnt == nullptr) break;
+  __syncthreads();  // every wave is done with the staging area; the next block's index is in LDS
+  const unsigned i = (unsigned)__builtin_amdgcn_readfirstlane((int)nextw[iter & 1]);  // wave-uniform by construction
+  vb = i < (unsigned)ndyn ? xcd + 8 * (npx + (int)i) : vgrid;
+  }  // persistent tile loop
 }
 
 // ---- kernel L: 256x128 tile, 8 waves (4x2, 64x64 each), 2 LDS stages, one workgroup per CU ---------------------
@@ -1722,6 +1768,29 @@ extern "C" int ca_gemm_fp8(const CaGemmDesc* desc, void* stream) {
 // the problems do not fill the chip one by one (the four weight gradients of a transformer layer: 240 + 240 +
 // 184 + 64 tiles on 256 CUs at XLS-R-2B, 64 + 64 + 48 + 16 at d = 1024).  All must be un-batched, un-segmented
 // and plain (no epilogue, no bias).
+// Launch geometry of kernel X.  Default: persistent workgroups (one per CU) with dynamic tile pulls whenever the tile
+// grid is larger than the chip and un-batched; CA_X_PERSIST=0 restores one workgroup per tile.
+#define X_LAUNCH_LDS (X_LDS_BYTES + 64)
+static void x_launch_geometry(CaGemmGroup& g, unsigned vgrid, unsigned nbz, dim3& grid) {
+  static const int persist = [] { const char* e = getenv("CA_X_PERSIST"); return e ? atoi(e) : 1; }();
+  static const unsigned ncu = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return (unsigned)(n >= 8 ? (n / 8) * 8 : 8);
+  }();
+  static unsigned seq = 0;
+  g.vgrid = (int)vgrid;
+  g.cnt = nullptr;
+  grid = dim3(vgrid, 1, nbz);
+  if (persist && nbz == 1 && vgrid > ncu) {
+    unsigned* base = nullptr;
+    if (hipGetSymbolAddress((void**)&base, HIP_SYMBOL(g_x_cnt)) == hipSuccess && base) {
+      g.cnt = base + (size_t)(seq++ % X_CNT_SLOTS) * 8;
+      grid.x = ncu;
+    }
+  }
+}
+
 extern "C" int ca_gemm_bf16_group(const CaGemmDesc* descs, int32_t count, void* stream) {
   CA_CHECK_ARG(descs && count >= 1 && count <= 4, "ca_gemm_bf16_group: 1..4 problems");
   CaGemmGroup g;
@@ -1750,12 +1819,13 @@ extern "C" int ca_gemm_bf16_group(const CaGemmDesc* descs, int32_t count, void* 
 #define XK(x, y) ca_gemm_kernel_x<x, y, false>
   if (!attr) {
     const void* fs[4] = {(const void*)XK(0, 0), (const void*)XK(0, 1), (const void*)XK(1, 0), (const void*)XK(1, 1)};
-    for (int i = 0; i < 4; ++i) hipFuncSetAttribute(fs[i], hipFuncAttributeMaxDynamicSharedMemorySize, X_LDS_BYTES);
+    for (int i = 0; i < 4; ++i) hipFuncSetAttribute(fs[i], hipFuncAttributeMaxDynamicSharedMemorySize, X_LAUNCH_LDS);
     attr = true;
   }
   hipStream_t s = (hipStream_t)stream;
-  dim3 grid((unsigned)(count > 1 ? 8 * ((total + 7) / 8) : tile_grid<4, 8>((descs->M + XBM - 1) / XBM, (descs->N + XBN - 1) / XBN))),
-      block(512);
+  dim3 grid, block(512);
+  x_launch_geometry(g, (unsigned)(count > 1 ? 8 * ((total + 7) / 8)
+                                            : tile_grid<4, 8>((descs->M + XBM - 1) / XBM, (descs->N + XBN - 1) / XBN)), 1, grid);
   const int lay = (descs->a_layout ? 2 : 0) + (descs->b_layout ? 1 : 0);
   ProfRec r;
   if (g_prof_on) {  // live roofline timing (bench.py): the group counts as one launch of kernel X
@@ -1768,10 +1838,10 @@ extern "C" int ca_gemm_bf16_group(const CaGemmDesc* descs, int32_t count, void* 
     g_prof_e1 = r.e1;
   }
   switch (lay) {
-    case 0: CA_LAUNCH((XK(0, 0)), grid, block, X_LDS_BYTES, s, g); break;
-    case 1: CA_LAUNCH((XK(0, 1)), grid, block, X_LDS_BYTES, s, g); break;
-    case 2: CA_LAUNCH((XK(1, 0)), grid, block, X_LDS_BYTES, s, g); break;
-    default: CA_LAUNCH((XK(1, 1)), grid, block, X_LDS_BYTES, s, g); break;
+    case 0: CA_LAUNCH((XK(0, 0)), grid, block, X_LAUNCH_LDS, s, g); break;
+    case 1: CA_LAUNCH((XK(0, 1)), grid, block, X_LAUNCH_LDS, s, g); break;
+    case 2: CA_LAUNCH((XK(1, 0)), grid, block, X_LAUNCH_LDS, s, g); break;
+    default: CA_LAUNCH((XK(1, 1)), grid, block, X_LAUNCH_LDS, s, g); break;
   }
 #undef XK
   if (g_prof_on) {
@@ -1855,25 +1925,25 @@ static int ca_gemm_launch(const CaGemmDesc* desc, void* stream) {
       const void* fs[8] = {(const void*)XK(0, 0, false), (const void*)XK(0, 1, false), (const void*)XK(1, 0, false),
                            (const void*)XK(1, 1, false), (const void*)XK(0, 0, true),  (const void*)XK(0, 1, true),
                            (const void*)XK(1, 0, true),  (const void*)XK(1, 1, true)};
-      for (int i = 0; i < 8; ++i) hipFuncSetAttribute(fs[i], hipFuncAttributeMaxDynamicSharedMemorySize, X_LDS_BYTES);
+      for (int i = 0; i < 8; ++i) hipFuncSetAttribute(fs[i], hipFuncAttributeMaxDynamicSharedMemorySize, X_LAUNCH_LDS);
       xattr = true;
     }
-    dim3 grid(tile_grid<4, 8>(xtm, xtn), 1, (unsigned)nb);
-    dim3 block(512);
+    dim3 grid, block(512);
     CaGemmGroup one;
     one.d[0] = d;
     one.count = 0;
     one.first[0] = 0;
     one.total = 0;
+    x_launch_geometry(one, tile_grid<4, 8>(xtm, xtn), (unsigned)nb, grid);
     switch (lay + (ks ? 4 : 0)) {
-      case 0: CA_LAUNCH((XK(0, 0, false)), grid, block, X_LDS_BYTES, s, one); break;
-      case 1: CA_LAUNCH((XK(0, 1, false)), grid, block, X_LDS_BYTES, s, one); break;
-      case 2: CA_LAUNCH((XK(1, 0, false)), grid, block, X_LDS_BYTES, s, one); break;
-      case 3: CA_LAUNCH((XK(1, 1, false)), grid, block, X_LDS_BYTES, s, one); break;
-      case 4: CA_LAUNCH((XK(0, 0, true)), grid, block, X_LDS_BYTES, s, one); break;
-      case 5: CA_LAUNCH((XK(0, 1, true)), grid, block, X_LDS_BYTES, s, one); break;
-      case 6: CA_LAUNCH((XK(1, 0, true)), grid, block, X_LDS_BYTES, s, one); break;
-      default: CA_LAUNCH((XK(1, 1, true)), grid, block, X_LDS_BYTES, s, one); break;
+      case 0: CA_LAUNCH((XK(0, 0, false)), grid, block, X_LAUNCH_LDS, s, one); break;
+      case 1: CA_LAUNCH((XK(0, 1, false)), grid, block, X_LAUNCH_LDS, s, one); break;
+      case 2: CA_LAUNCH((XK(1, 0, false)), grid, block, X_LAUNCH_LDS, s, one); break;
+      case 3: CA_LAUNCH((XK(1, 1, false)), grid, block, X_LAUNCH_LDS, s, one); break;
+      case 4: CA_LAUNCH((XK(0, 0, true)), grid, block, X_LAUNCH_LDS, s, one); break;
+      case 5: CA_LAUNCH((XK(0, 1, true)), grid, block, X_LAUNCH_LDS, s, one); break;
+      case 6: CA_LAUNCH((XK(1, 0, true)), grid, block, X_LAUNCH_LDS, s, one); break;
+      default: CA_LAUNCH((XK(1, 1, true)), grid, block, X_LAUNCH_LDS, s, one); break;
     }
 #undef XK
     CA_CHECK_LAUNCH("ca_gemm_bf16");
