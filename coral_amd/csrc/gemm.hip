@@ -1057,7 +1057,7 @@ __global__ __launch_bounds__(512) void ca_gemm_kernel_x(const CaGemmGroup grp) {
   }  // persistent tile loop
 }
 
-// ---- kernel L: 256x128 tile, 8 waves (4x2, 64x64 each), 2 LDS stages, one workgroup per CU ---------------------
+// ---- kernel L: 256x128 tile, 8 waves (4x2, 64x64 each), 3 LDS stages, one workgroup per CU ---------------------
 // For the N = d shapes of the path (out-projection, FFN2 and the data gradients that produce [tokens, d]): 128
 // tiles of 256x256 leave half the chip idle, and the 128x128 kernel with its two workgroups per CU runs at the
 // per-CU LDS-fill limit (2 x 32 KiB per 64-k step for 2 x 128 x 128 outputs = ~95 GB/s per CU at its in-step rate;
@@ -1065,12 +1065,15 @@ __global__ __launch_bounds__(512) void ca_gemm_kernel_x(const CaGemmGroup grp) {
 // N = 1920) at 3/4 of S's fill bytes per FLOP.  Built like kernel X: scalar-base LDS-DMA streams, fragments
 // double-buffered in registers with the reads issued BETWEEN the MFMAs of the running block (immediate-offset
 // addressing), one barrier per K-step in front of its last block, staggered DMA bursts (waves 0-3 right behind the
-// barrier, waves 4-7 one block later).  A K-step has two blocks of 16 MFMAs (k-half 0, k-half 1) per wave.
+// barrier, waves 4-7 one block later).  A K-step has two blocks of 16 MFMAs (k-half 0, k-half 1) per wave.  The 48-KiB
+// stages leave room for a ring of three: the LDS-DMA runs TWO tiles ahead behind a counted vmcnt (6 pieces per wave and
+// tile), which is what keeps the loop fed when the optimiser's traffic beside the forward stretches the fetch latency.
 #define LBM 256
 #define LBN 128
 #define LA_BYTES (LBM * BK * 2)  // 32 KiB
 #define LB_BYTES (LBN * BK * 2)  // 16 KiB
-#define L_LDS_BYTES (8 * 64 * EPI_PITCH * 4)  // 139264: epilogue staging >= 2 stages * 48 KiB
+#define L_NST 3
+#define L_LDS_BYTES (L_NST * (LA_BYTES + LB_BYTES))  // 147456 >= 8 waves * 64*68*4 (139264) epilogue staging
 
 template <int AL, int BL>
 __global__ __launch_bounds__(512) void ca_gemm_kernel_l(const CaGemmDesc d) {
@@ -1108,11 +1111,13 @@ __global__ __launch_bounds__(512) void ca_gemm_kernel_l(const CaGemmDesc d) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-  // LDS: A0 | A1 (32 KiB each) | B0 | B1 (16 KiB each)
+  // LDS: A0 | A1 | A2 (32 KiB each) | B0 | B1 | B2 (16 KiB each)
+  int bst = 0;  // stage of this wave's next burst (every wave issues its share of every tile, in order)
   auto burst = [&](int kt) {  // this wave's share of tile kt: 4 A pieces + 2 B pieces
     if (kt >= nk) return;
-    char* na = smem + (kt & 1) * LA_BYTES;
-    char* nb = smem + 2 * LA_BYTES + (kt & 1) * LB_BYTES;
+    char* na = smem + bst * LA_BYTES;
+    char* nb = smem + L_NST * LA_BYTES + bst * LB_BYTES;
+    bst = bst == L_NST - 1 ? 0 : bst + 1;
     const bool full = (kt + 1) * BK <= K;  // wave-uniform
     if (full) {
 #pragma unroll
@@ -1148,8 +1153,8 @@ __global__ __launch_bounds__(512) void ca_gemm_kernel_l(const CaGemmDesc d) {
   };
   auto zero_tail = [&](int kt) {
     if (kt != nk - 1 || nk * BK == K) return;
-    char* na = smem + (kt & 1) * LA_BYTES;
-    char* nb = smem + 2 * LA_BYTES + (kt & 1) * LB_BYTES;
+    char* na = smem + (kt % L_NST) * LA_BYTES;
+    char* nb = smem + L_NST * LA_BYTES + (kt % L_NST) * LB_BYTES;
     const int krem = K - kt * BK;
     if (AL == CA_KMAJOR) la_k.zero_fix(na, wave, lane, krem); else la_f.zero_fix(na, wave, lane, krem);
     if (BL == CA_KMAJOR) lb_k.zero_fix(nb, wave, lane, krem); else lb_f.zero_fix(nb, wave, lane, krem);
@@ -1176,23 +1181,27 @@ __global__ __launch_bounds__(512) void ca_gemm_kernel_l(const CaGemmDesc d) {
     const int r = wn * 64 + (lane & 15);
 #pragma unroll
     for (int sh = 0; sh < 2; ++sh)
-      bbase[sh] = lds0 + 2 * LA_BYTES + r * 128 + (((4 * sh + (lane >> 4)) ^ ((r >> 1) & 7)) * 16);
+      bbase[sh] = lds0 + L_NST * LA_BYTES + r * 128 + (((4 * sh + (lane >> 4)) ^ ((r >> 1) & 7)) * 16);
   } else {
     const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
     const int swz = q | ((g & 1) << 2);
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
       const int c = ((((wn * 64 + f * 16) >> 3) + (pp >> 1)) ^ (swz << 1));
-      bbase[f] = lds0 + 2 * LA_BYTES + (8 * g + q) * 256 + c * 16 + (pp & 1) * 8;
+      bbase[f] = lds0 + L_NST * LA_BYTES + (8 * g + q) * 256 + c * 16 + (pp & 1) * 8;
     }
   }
+  // (DS immediate offsets end at 64 KiB: the third A stage gets base registers of its own)
+  uint32_t abase2[4];
+#pragma unroll
+  for (int f = 0; f < 4; ++f) abase2[f] = abase[f] + 2 * LA_BYTES;
   bf16x8_t A0[4], A1[4], B0[4], B1[4];
-#define L_RD_A(ST, SH, F, dst)                                                  \
-  do {                                                                          \
-    if (AL == CA_KMAJOR)                                                        \
-      dst = lds_read_b128<(ST) * LA_BYTES + (F) * 2048>(abase[SH]);             \
-    else                                                                        \
-      dst = lds_read_tr<(ST) * LA_BYTES + (SH) * 16384, 2048>(abase[F]);        \
+#define L_RD_A(ST, SH, F, dst)                                                                      \
+  do {                                                                                              \
+    if (AL == CA_KMAJOR)                                                                            \
+      dst = lds_read_b128<((ST) % 2) * LA_BYTES + (F) * 2048>((ST) == 2 ? abase2[SH] : abase[SH]);  \
+    else                                                                                            \
+      dst = lds_read_tr<((ST) % 2) * LA_BYTES + (SH) * 16384, 2048>((ST) == 2 ? abase2[F] : abase[F]); \
   } while (0)
 #define L_RD_B(ST, SH, F, dst)                                                  \
   do {                                                                          \
@@ -1210,7 +1219,8 @@ __global__ __launch_bounds__(512) void ca_gemm_kernel_l(const CaGemmDesc d) {
   } while (0)
   auto kstep = [&](auto st_c, int kt) {
     constexpr int ST = decltype(st_c)::value;
-    if (wave >= 4) burst(kt + 1);
+    constexpr int NS = (ST + 1) % L_NST;  // stage of tile kt + 1
+    if (wave >= 4) burst(kt + 2);
     // block 0: k-half 0 of tile kt; reads k-half 1 (same stage)
     lds_wait(B0);
     lds_wait(A0);
@@ -1227,36 +1237,44 @@ __global__ __launch_bounds__(512) void ca_gemm_kernel_l(const CaGemmDesc d) {
     __builtin_amdgcn_s_setprio(0);
     lds_wait(B1);
     lds_wait(A1);  // the last fragment reads of tile kt have returned
-    // tile kt+1 has landed (this wave's share; the barrier covers the others) and stage ST is free
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // tile kt+1 has landed (this wave's share; the barrier covers the others), tile kt+2 may still be in flight
+    if (kt + 2 < nk)
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     zero_tail(kt + 1);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (wave < 4) burst(kt + 2);
+    if (wave < 4) burst(kt + 3);  // into stage ST: every wave has finished reading tile kt
     L_SB;
     // block 1: k-half 1 of tile kt; reads k-half 0 of tile kt+1 (harmless stale data after the last tile)
     __builtin_amdgcn_s_setprio(1);
-    L_MM2(A1, B1, 0, 0); L_RD_B(1 - ST, 0, 0, B0[0]); L_SB;
-    L_MM2(A1, B1, 0, 2); L_RD_B(1 - ST, 0, 1, B0[1]); L_SB;
-    L_MM2(A1, B1, 1, 0); L_RD_B(1 - ST, 0, 2, B0[2]); L_SB;
-    L_MM2(A1, B1, 1, 2); L_RD_B(1 - ST, 0, 3, B0[3]); L_SB;
-    L_MM2(A1, B1, 2, 0); L_RD_A(1 - ST, 0, 0, A0[0]); L_SB;
-    L_MM2(A1, B1, 2, 2); L_RD_A(1 - ST, 0, 1, A0[1]); L_SB;
-    L_MM2(A1, B1, 3, 0); L_RD_A(1 - ST, 0, 2, A0[2]); L_SB;
-    L_MM2(A1, B1, 3, 2); L_RD_A(1 - ST, 0, 3, A0[3]); L_SB;
+    L_MM2(A1, B1, 0, 0); L_RD_B(NS, 0, 0, B0[0]); L_SB;
+    L_MM2(A1, B1, 0, 2); L_RD_B(NS, 0, 1, B0[1]); L_SB;
+    L_MM2(A1, B1, 1, 0); L_RD_B(NS, 0, 2, B0[2]); L_SB;
+    L_MM2(A1, B1, 1, 2); L_RD_B(NS, 0, 3, B0[3]); L_SB;
+    L_MM2(A1, B1, 2, 0); L_RD_A(NS, 0, 0, A0[0]); L_SB;
+    L_MM2(A1, B1, 2, 2); L_RD_A(NS, 0, 1, A0[1]); L_SB;
+    L_MM2(A1, B1, 3, 0); L_RD_A(NS, 0, 2, A0[2]); L_SB;
+    L_MM2(A1, B1, 3, 2); L_RD_A(NS, 0, 3, A0[3]); L_SB;
     __builtin_amdgcn_s_setprio(0);
   };
   burst(0);
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  burst(1);
+  if (nk > 1)
+    asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+  else
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   zero_tail(0);
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   L_RD_B(0, 0, 0, B0[0]); L_RD_B(0, 0, 1, B0[1]); L_RD_B(0, 0, 2, B0[2]); L_RD_B(0, 0, 3, B0[3]);
   L_RD_A(0, 0, 0, A0[0]); L_RD_A(0, 0, 1, A0[1]); L_RD_A(0, 0, 2, A0[2]); L_RD_A(0, 0, 3, A0[3]);
-  if (wave < 4) burst(1);
-  for (int kt = 0; kt < nk; kt += 2) {
+  if (wave < 4) burst(2);
+  for (int kt = 0; kt < nk; kt += 3) {
     kstep(std::integral_constant<int, 0>{}, kt);
     if (kt + 1 < nk) kstep(std::integral_constant<int, 1>{}, kt + 1);
+    if (kt + 2 < nk) kstep(std::integral_constant<int, 2>{}, kt + 2);
   }
 #undef L_RD_A
 #undef L_RD_B
@@ -1898,8 +1916,12 @@ static int ca_gemm_launch(const CaGemmDesc* desc, void* stream) {
   // the 128x128 kernel with two workgroups per CU equals or beats the 256x128 one-per-CU kernel,
   // because its second workgroup hides the epilogue; the L kernel is kept selectable for tuning.
   int use_l = (g_force_kernel == 2 && d.a_kseg == 0 && d.b_kseg == 0) ? 1 : 0;
-  // tuning knob: CA_GEMM_PREFER_L=1 sends the one-round 256x128 grids (160..256 tiles: the N = d shapes) to kernel L
-  static const int prefer_l = [] { const char* e = getenv("CA_GEMM_PREFER_L"); return e ? atoi(e) : 0; }();
+  // Kernel L (256x128, three-stage ring) takes the shapes kernel X does not fill and that give it 160 .. 768 tiles
+  // (0.6 .. 3 rounds of one workgroup per CU): the N = d projections and data gradients and q|k|v at the 2B shape.  Its
+  // two-tiles-ahead LDS-DMA keeps it fed under the optimiser's HBM traffic, where the 128x128 kernel (one tile ahead)
+  // loses 25 %: XLS-R-2B step 79.2 -> 76.5 ms on one box (tools/exp_l3.sh).  CA_GEMM_PREFER_L=0 turns it off, a larger
+  // value widens the tile-count window (x 256).
+  static const int prefer_l = [] { const char* e = getenv("CA_GEMM_PREFER_L"); return e ? atoi(e) : 3; }();
   // Kernel X (256x256): only where it fills the chip -- at least ~0.7 tiles per CU in its last round.
   const int xtm = (d.M + XBM - 1) / XBM, xtn = (d.N + XBN - 1) / XBN;
   const int64_t xt = (int64_t)xtm * xtn * nb;
@@ -1913,9 +1935,12 @@ static int ca_gemm_launch(const CaGemmDesc* desc, void* stream) {
   // - 188 / 192 / 564 tiles - and loses at 68 % - 368 tiles)
   int use_x = (g_force_kernel == 0 && d.K >= 512 && xt >= 160 && xeff * xfill >= (tn ? 0.60 : 0.70)) ? 1 : 0;
   if (g_force_kernel == 3 || d.a_colsum) use_x = 1;  // the column sums live in kernel X only
-  if (prefer_l && !use_x && g_force_kernel == 0 && d.a_kseg == 0 && d.b_kseg == 0 && d.K >= 512 && tiles_l >= 160 &&
-      tiles_l <= 256 * prefer_l)
+  static const int l_over_x = [] { const char* e = getenv("CA_GEMM_L_OVER_X"); return e ? atoi(e) : 0; }();
+  if (prefer_l && g_force_kernel == 0 && d.a_kseg == 0 && d.b_kseg == 0 && d.K >= 512 && tiles_l >= 160 &&
+      tiles_l <= 256 * prefer_l && !d.a_colsum && (!use_x || (l_over_x && (l_over_x > 1 || !tn)))) {
     use_l = 1;
+    use_x = 0;
+  }
   g_last_kind = use_x ? 2 : (use_l ? 1 : 0);
   if (use_x) {
     static bool xattr = false;
