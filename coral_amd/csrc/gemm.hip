@@ -1917,7 +1917,8 @@ static int ca_gemm_launch(const CaGemmDesc* desc, void* stream) {
   // because its second workgroup hides the epilogue; the L kernel is kept selectable for tuning.
   int use_l = (g_force_kernel == 2 && d.a_kseg == 0 && d.b_kseg == 0) ? 1 : 0;
   // Kernel L (256x128, three-stage ring) takes the shapes kernel X does not fill and that give it 160 .. 768 tiles
-  // (0.6 .. 3 rounds of one workgroup per CU): the N = d projections and data gradients and q|k|v at the 2B shape.  Its
+  // (0.4 .. 3 rounds of one workgroup per CU; CA_GEMM_L_MIN, default 100 tiles: from there it also beats the 128x128
+  // kernel on the d = 1024 models, XLS-R-300M step 19.95 -> 19.1 ms): the N = d projections and data gradients and q|k|v at the 2B shape.  Its
   // two-tiles-ahead LDS-DMA keeps it fed under the optimiser's HBM traffic, where the 128x128 kernel (one tile ahead)
   // loses 25 %: XLS-R-2B step 79.2 -> 76.5 ms on one box (tools/exp_l3.sh).  CA_GEMM_PREFER_L=0 turns it off, a larger
   // value widens the tile-count window (x 256).
@@ -1936,8 +1937,10 @@ static int ca_gemm_launch(const CaGemmDesc* desc, void* stream) {
   int use_x = (g_force_kernel == 0 && d.K >= 512 && xt >= 160 && xeff * xfill >= (tn ? 0.60 : 0.70)) ? 1 : 0;
   if (g_force_kernel == 3 || d.a_colsum) use_x = 1;  // the column sums live in kernel X only
   static const int l_over_x = [] { const char* e = getenv("CA_GEMM_L_OVER_X"); return e ? atoi(e) : 0; }();
-  if (prefer_l && g_force_kernel == 0 && d.a_kseg == 0 && d.b_kseg == 0 && d.K >= 512 && tiles_l >= 160 &&
-      tiles_l <= 256 * prefer_l && !d.a_colsum && (!use_x || (l_over_x && (l_over_x > 1 || !tn)))) {
+  static const int l_min = [] { const char* e = getenv("CA_GEMM_L_MIN"); return e ? atoi(e) : 100; }();
+  if (prefer_l && g_force_kernel == 0 && d.a_kseg == 0 && d.b_kseg == 0 && d.K >= 512 && tiles_l >= l_min &&
+      (tiles_l <= 256 * prefer_l || (use_x && l_over_x)) && !d.a_colsum &&
+      (!use_x || (l_over_x == 1 && !tn) || l_over_x == 2 || (l_over_x == 3 && lay == 0))) {
     use_l = 1;
     use_x = 0;
   }
