@@ -79,7 +79,7 @@ class CaAttnDesc(C.Structure):
                 + [(n, C.c_int64) for n in ("ldq", "ldk", "ldv", "ldo", "lddo", "lddq", "lddk", "lddv",
                                              "sqb", "skb", "svb", "sob", "sdob", "sdqb", "sdkb", "sdvb")]
                 + [(n, C.c_int32) for n in ("B", "H", "Tq", "Tk", "hd", "Tqp", "causal")]
-                + [("scale", C.c_float)])
+                + [("scale", C.c_float), ("dropout_p", C.c_float), ("dropout_seed", C.c_uint64)])
 
 
 KMAJOR, MNMAJOR = 0, 1

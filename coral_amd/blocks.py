@@ -62,13 +62,17 @@ class SelfAttnBlock:
     def _akw(self, B, T, sv, klen):
         d, H = self.d, self.H
         hd = d // H
+        ap, aseed = sv.get("adrop", (0.0, 0))
         return dict(B=B, H=H, Tq=T, Tk=T, hd=hd, Tqp=sv["Tqp"], scale=hd ** -0.5, ldq=3 * d, ldk=3 * d, ldv=3 * d, ldo=d,
                     sqb=T * 3 * d, skb=T * 3 * d, svb=T * 3 * d, sob=T * d, q_off=0, k_off=d, v_off=2 * d, klen=klen,
-                    causal=self.causal)
+                    causal=self.causal, dropout_p=ap, dropout_seed=aseed)
 
-    def forward(self, hin, hout, sv, B, T, klen=None, hdrop=(0.0, 0)):
+    def forward(self, hin, hout, sv, B, T, klen=None, hdrop=(0.0, 0), adrop=(0.0, 0)):
+        """hdrop: (p, seed) of the hidden-state dropout on the block's output; adrop: of the dropout on the attention
+        probabilities ($TF/models/whisper/modeling_whisper.py:234)."""
         st, d = self.st, self.d
         M = B * T
+        sv["adrop"] = adrop
         fp8 = getattr(self, "fp8", None)  # (p8, scale, x8, rs): forward projection on the fp8 path (DESIGN.md 4.4)
         if fp8 is not None:
             p8, scale, x8, rs = fp8
@@ -134,8 +138,9 @@ class CrossAttnBlock:
     def _akw(self, B, L, Te, sv):
         d, H = self.d, self.H
         hd = d // H
+        ap, aseed = sv.get("adrop", (0.0, 0))
         return dict(B=B, H=H, Tq=L, Tk=Te, hd=hd, Tqp=sv["Tqp"], scale=hd ** -0.5, ldq=d, ldk=2 * d, ldv=2 * d, ldo=d,
-                    sqb=L * d, skb=Te * 2 * d, svb=Te * 2 * d, sob=L * d, k_off=0, v_off=d)
+                    sqb=L * d, skb=Te * 2 * d, svb=Te * 2 * d, sob=L * d, k_off=0, v_off=d, dropout_p=ap, dropout_seed=aseed)
 
     def project_kv(self, enc, sv, B, Te):
         st, d = self.st, self.d
@@ -143,9 +148,10 @@ class CrossAttnBlock:
                  bias=st.p32, bias_off=st.off(self.attn + "k_proj.bias__zero"))
         sv["enc"] = enc
 
-    def forward(self, hin, hout, sv, B, L, Te, hdrop=(0.0, 0)):
+    def forward(self, hin, hout, sv, B, L, Te, hdrop=(0.0, 0), adrop=(0.0, 0)):
         st, d = self.st, self.d
         M = B * L
+        sv["adrop"] = adrop
         ops.layernorm_fwd(hin, st.view(self.ln + ".weight"), st.view(self.ln + ".bias"), sv["x"], sv["st"], M, d, self.eps)
         ops.gemm(sv["x"], st.p16, sv["q"], M=M, N=d, K=d, lda=d, ldb=d, ldc=d, b_off=st.off(self.attn + "q_proj.weight"),
                  bias=st.p32, bias_off=st.off(self.attn + "q_proj.bias"))

@@ -254,7 +254,16 @@ struct AttnArgs {
   const float* Dq;                       // [B, H, Tqp] rowsum(dO * O)
   unsigned short *dQ, *dK, *dV;
   int64_t lddq, lddk, lddv, sdqb, sdkb, sdvb;
+  // dropout on the attention probabilities (training): keep decision of (b, h, q, k) from (seed, flat index)
+  float drop_p;
+  uint64_t drop_seed;
 };
+// Flat index of probability (b, h, q, key): rows are padded to a multiple of 4 keys so that 4 consecutive keys from a
+// multiple of 4 share one hash (ca_dropout_keep4); the backward kernels regenerate the forward's decisions from it.
+__device__ __forceinline__ uint64_t attn_drop_index(const AttnArgs& a, int b, int h, int q, int key) {
+  const uint64_t tkp = (uint64_t)((a.Tk + 3) & ~3);
+  return (((uint64_t)b * a.H + h) * (uint64_t)a.Tq + (uint64_t)q) * tkp + (uint64_t)key;
+}
 
 #define NEG_INF (-__builtin_inff())
 #define LOG2E 1.44269504088896340736f
@@ -286,7 +295,7 @@ static inline unsigned attn_grid(int ntile, int H, int B) { return (unsigned)(((
 #define NEG_BIG (-1.0e30f)
 // 1024 workgroups at the path's shape (8 query tiles x 128 heads): at 4 waves per SIMD they are all resident at
 // once; at 3 (148 VGPRs) a second round runs one third full.
-template <int HDPV>
+template <int HDPV, bool DROP = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_fwd_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NKS = HDPV / 32, NNB = HDPV / 16;
@@ -373,8 +382,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         float pv = __builtin_amdgcn_exp2f(fmaf(sc[blk][e], c2, -m_new));
         if (!full) pv = sc[blk][e] > 0.5f * NEG_BIG ? pv : 0.f;
         p[4 * blk + e] = pv;
-        sum += pv;
+        sum += pv;  // the normaliser is the sum of ALL probabilities: dropout acts on the normalised ones
       }
+    if constexpr (DROP) {
+      const float ks = 1.f / (1.f - a.drop_p);
+#pragma unroll
+      for (int blk = 0; blk < 4; ++blk) {
+        const int key0 = kt * 64 + 32 * (blk >> 1) + 8 * g + 4 * (blk & 1);
+        const unsigned keep = ca_dropout_keep4(a.drop_seed, attn_drop_index(a, b, h, qrow, key0), a.drop_p);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) p[4 * blk + e] = ((keep >> e) & 1u) ? p[4 * blk + e] * ks : 0.f;
+      }
+    }
     l = fmaf(l, alpha, sum);
     if (__builtin_amdgcn_ballot_w64(m_new > m) != 0) {  // some query of this wave moved its maximum
       float ar[4];
@@ -545,8 +564,9 @@ __global__ __launch_bounds__(256) void attn_fwd_smallq_kernel(const AttnArgs a) 
         float pv = __builtin_amdgcn_exp2f(fmaf(sc[blk][e], c2, -m_new));
         if (!full) pv = sc[blk][e] > 0.5f * NEG_BIG ? pv : 0.f;
         p[4 * blk + e] = pv;
-        sum += pv;
+        sum += pv;  // the normaliser is the sum of ALL probabilities: dropout acts on the normalised ones
       }
+
     l = fmaf(l, alpha, sum);
     float ar[4];
 #pragma unroll
@@ -653,7 +673,7 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const unsigned short
 }
 
 // ---- backward: dK, dV (workgroup = 64 keys, loops over the queries) ------------------------------------
-template <int HDPV>
+template <int HDPV, bool DROP = false>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NKS = HDPV / 32, NNB = HDPV / 16;
@@ -757,7 +777,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a) {
         const float ls2 = (bb == 0 ? l0[e] : l1[e]) * LOG2E;
         const float dq = bb == 0 ? d0[e] : d1[e];
         float pv = __builtin_amdgcn_exp2f(fmaf(sacc[bb][e], c2, -ls2));
-        float dsv = pv * (pacc[bb][e] - dq) * scale;
+        float dpv = pacc[bb][e];  // d/dP of the (dropped) probabilities
+        float pdrop = pv;         // the probability as the forward used it against V
+        if constexpr (DROP) {
+          const int qd = qs * 32 + 8 * g + 4 * bb + e;
+          const bool keep = ca_dropout_keep(a.drop_seed, attn_drop_index(a, b, h, qd < a.Tq ? qd : a.Tq - 1, krow), a.drop_p);
+          const float ks = 1.f / (1.f - a.drop_p);
+          dpv = keep ? dpv * ks : 0.f;
+          pdrop = keep ? pv * ks : 0.f;
+        }
+        float dsv = pv * (dpv - dq) * scale;
+        pv = pdrop;
         if (!full) {  // statistics of padded queries are not initialised: select, never multiply by a mask
           const int qi = qs * 32 + 8 * g + 4 * bb + e;
           const bool ok = qi < a.Tq && key < kl && (!a.causal || key <= qi);
@@ -812,7 +842,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a) {
 }
 
 // ---- backward: dQ (workgroup = 64 queries, loops over the keys) ------------------------------------------
-template <int HDPV>
+template <int HDPV, bool DROP = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_bwd_dq_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NKS = HDPV / 32, NNB = HDPV / 16;
@@ -881,9 +911,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kimg_frag<64>(Kk, row, ks, lane), qf[ks], sacc, 0, 0, 0);
             pacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kimg_frag<64>(Vk, row, ks, lane), dof[ks], pacc, 0, 0, 0);
           }
+        unsigned keep = 0xFu;
+        if constexpr (DROP)
+          keep = ca_dropout_keep4(a.drop_seed, attn_drop_index(a, b, h, qrow, kt * 64 + 32 * s + 8 * g + 4 * bb), a.drop_p);
+        const float kscale = DROP ? 1.f / (1.f - a.drop_p) : 1.f;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float dsv = __builtin_amdgcn_exp2f(fmaf(sacc[e], c2, -lse2)) * (pacc[e] - dq_row) * scale;
+          const float dpv = DROP ? (((keep >> e) & 1u) ? pacc[e] * kscale : 0.f) : pacc[e];
+          float dsv = __builtin_amdgcn_exp2f(fmaf(sacc[e], c2, -lse2)) * (dpv - dq_row) * scale;
           if (!full) {
             const int key = kt * 64 + 32 * s + 8 * g + 4 * bb + e;
             const bool ok = key < kl && (!a.causal || key <= qi);
@@ -912,6 +947,7 @@ static int attn_check(const CaAttnDesc* d, const char* who) {
   CA_CHECK_ARG(d->hd >= 8 && d->hd <= 128 && (d->hd % 8) == 0, "%s: head_dim must be a multiple of 8 in [8,128]", who);
   CA_CHECK_ARG((d->ldq % 8) == 0 && (d->ldk % 8) == 0 && (d->ldv % 8) == 0, "%s: strides must be multiples of 8", who);
   CA_CHECK_ARG(d->lse != nullptr && d->Tqp >= d->Tq && (d->Tqp % 32) == 0, "%s: lse needs Tqp %% 32 == 0 rows", who);
+  CA_CHECK_ARG(d->dropout_p >= 0.f && d->dropout_p < 1.f, "%s: bad dropout_p", who);
   return CA_OK;
 }
 static AttnArgs to_args(const CaAttnDesc& d) {
@@ -924,6 +960,7 @@ static AttnArgs to_args(const CaAttnDesc& d) {
   a.dO = (const unsigned short*)d.dO; a.lddo = d.lddo; a.sdob = d.sdob; a.Dq = d.Dq;
   a.dQ = (unsigned short*)d.dQ; a.dK = (unsigned short*)d.dK; a.dV = (unsigned short*)d.dV;
   a.lddq = d.lddq; a.lddk = d.lddk; a.lddv = d.lddv; a.sdqb = d.sdqb; a.sdkb = d.sdkb; a.sdvb = d.sdvb;
+  a.drop_p = d.dropout_p; a.drop_seed = d.dropout_seed;
   return a;
 }
 
@@ -933,6 +970,14 @@ extern "C" int ca_attn_fwd(const CaAttnDesc* desc, void* stream) {
   const AttnArgs a = to_args(*desc);
   dim3 grid(attn_grid((desc->Tq + 63) / 64, desc->H, desc->B)), block(256);
   hipStream_t s = (hipStream_t)stream;
+  if (desc->dropout_p > 0.f) {  // training with dropout on the attention probabilities: the general kernels only
+    if (desc->hd <= 64)
+      hipLaunchKernelGGL((attn_fwd_kernel<64, true>), grid, block, 2 * 64 * 64 * 2, s, a);
+    else
+      hipLaunchKernelGGL((attn_fwd_kernel<128, true>), grid, block, 2 * 64 * 128 * 2, s, a);
+    CA_CHECK_LAUNCH("ca_attn_fwd");
+    return CA_OK;
+  }
   if (desc->Tq <= 16 && desc->hd <= 64 && !desc->causal) {  // greedy decoding: the waves split the keys
     constexpr int SMALLQ_LDS = 4 * 3 * 64 * 64 * 2;  // four waves x ring of three 8-KiB V images
     static bool attr = false;
@@ -963,7 +1008,15 @@ extern "C" int ca_attn_bwd(const CaAttnDesc* desc, void* stream) {
                      (const unsigned short*)desc->dO, desc->lddo, desc->sdob, (const unsigned short*)desc->O,
                      desc->ldo, desc->sob, (float*)desc->Dq, desc->H, desc->Tq, desc->Tqp, desc->hd, desc->B);
   dim3 gk(attn_grid((desc->Tk + 63) / 64, desc->H, desc->B)), gq(attn_grid((desc->Tq + 63) / 64, desc->H, desc->B)), block(256);
-  if (desc->hd <= 64) {
+  if (desc->dropout_p > 0.f) {
+    if (desc->hd <= 64) {
+      hipLaunchKernelGGL((attn_bwd_dkv_kernel<64, true>), gk, block, 4 * 32 * 64 * 2, s, a);
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<64, true>), gq, block, 2 * 64 * 64 * 2, s, a);
+    } else {
+      hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, true>), gk, block, 4 * 32 * 128 * 2, s, a);
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<128, true>), gq, block, 2 * 64 * 128 * 2, s, a);
+    }
+  } else if (desc->hd <= 64) {
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<64>), gk, block, 4 * 32 * 64 * 2, s, a);
     hipLaunchKernelGGL((attn_bwd_dq_kernel<64>), gq, block, 2 * 64 * 64 * 2, s, a);
   } else {

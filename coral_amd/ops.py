@@ -456,13 +456,14 @@ def prof_end():
 
 
 def _attn_desc(Q, K, V, O, lse, *, B, H, Tq, Tk, hd, Tqp, scale, ldq, ldk, ldv, ldo, sqb, skb, svb, sob,
-               q_off=0, k_off=0, v_off=0, o_off=0, klen=None, causal=False):
+               q_off=0, k_off=0, v_off=0, o_off=0, klen=None, causal=False, dropout_p=0.0, dropout_seed=0):
     d = CaAttnDesc()
     d.Q, d.K, d.V, d.O = _p(Q, q_off), _p(K, k_off), _p(V, v_off), _p(O, o_off)
     d.lse, d.klen = _p(lse), _p(klen)
     d.ldq, d.ldk, d.ldv, d.ldo = ldq, ldk, ldv, ldo
     d.sqb, d.skb, d.svb, d.sob = sqb, skb, svb, sob
     d.B, d.H, d.Tq, d.Tk, d.hd, d.Tqp, d.causal, d.scale = B, H, Tq, Tk, hd, Tqp, int(causal), scale
+    d.dropout_p, d.dropout_seed = float(dropout_p), int(dropout_seed)
     return d
 
 

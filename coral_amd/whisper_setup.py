@@ -88,10 +88,10 @@ class WhisperForConditionalGeneration:
     the reference's order, and runs the training forward (activations saved for `backward`)."""
 
     def __init__(self, shape: WhisperShape, device=None, activation_dropout: float = 0.0, freeze_base: bool = False,
-                 spec=None, layerdrop: float = 0.0, dropout: float = 0.0):
+                 spec=None, layerdrop: float = 0.0, dropout: float = 0.0, attention_dropout: float = 0.0):
         device = device or f"cuda:{torch.cuda.current_device() if torch.cuda.is_available() else 0}"
         self.engine = WhisperTrainEngine(shape, device, activation_dropout=activation_dropout, freeze_base=freeze_base,
-                                         dropout=dropout)
+                                         dropout=dropout, attention_dropout=attention_dropout)
         self.shape = shape
         self.spec = spec or dict(apply_spec_augment=False, mask_time_prob=0.0, mask_time_length=10,
                                  mask_feature_prob=0.0, mask_feature_length=64)
@@ -114,12 +114,9 @@ class WhisperForConditionalGeneration:
                                               "mask_feature_prob", "mask_feature_length") if k in overrides}
         kw = dict(activation_dropout=float(overrides.pop("activation_dropout", 0.0)),
                   dropout=float(overrides.pop("dropout", 0.0)),
+                  attention_dropout=float(overrides.pop("attention_dropout", 0.0)),
                   freeze_base=bool(overrides.pop("freeze_base", False)), spec=spec or None,
                   layerdrop=float(overrides.pop("encoder_layerdrop", overrides.pop("layerdrop", 0.0))))
-        # every production CoRal Whisper config sets attention_dropout 0 (R/config/model/whisper-*.yaml:14-17); only the
-        # reference's CPU smoke config test-whisper has 0.1 there
-        if float(overrides.pop("attention_dropout", 0.0)) != 0.0:
-            raise NotImplementedError("attention_dropout > 0 (dropout on the attention probabilities) is not implemented")
         path = Path(name_or_path)
         if path.is_dir() and (path / "config.json").exists():
             cfg = json.loads((path / "config.json").read_text())

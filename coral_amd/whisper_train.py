@@ -28,13 +28,16 @@ class WhisperTrainEngine(WhisperEngine):
     """Adds forward_train()/backward() to the inference engine; gradients land in `store.g32`."""
 
     def __init__(self, shape: WhisperShape, device="cuda:0", activation_dropout: float = 0.0,
-                 freeze_base: bool = False, dropout: float = 0.0):
+                 freeze_base: bool = False, dropout: float = 0.0, attention_dropout: float = 0.0):
         super().__init__(shape, device)
         # `dropout`: the hidden-state dropout of WhisperConfig ($TF/models/whisper/modeling_whisper.py:398,406,479,493,
         # 502 after every sub-layer, :625,763 on the embedded inputs; R/config/model/whisper-large-turbo.yaml:12 sets
         # 0.1) - applied in the epilogue of the projection in front of each residual add, masks regenerated in the
         # backward from (step seed, site, element)
         self.dropout = dropout
+        # dropout on the attention probabilities (:234), inside the fused attention kernels; only the reference's smoke
+        # config test-whisper sets it (R/config/model/test-whisper.yaml:14)
+        self.attention_dropout = attention_dropout
         self._stager = PinnedStager(self.device)
         self.freeze_base = freeze_base
         s, st = shape, self.store
@@ -202,6 +205,11 @@ class WhisperTrainEngine(WhisperEngine):
 
         def hd(site):  # (p, seed) of one hidden-dropout site
             return (hp, base + site)
+
+        apd = self.attention_dropout if self.training else 0.0
+
+        def ad(site):  # (p, seed) of one attention-probability dropout site
+            return (apd, base + site)
         mask_time_d = self._stager.to_device(mask_time, torch.uint8, "tm") if mask_time is not None else None
         mask_feature_d = self._stager.to_device(mask_feature, torch.uint8, "fm") if mask_feature is not None else None
         self._await("front")
@@ -228,7 +236,7 @@ class WhisperTrainEngine(WhisperEngine):
                 w["eh"][2 * l + 2].copy_(w["eh"][2 * l])
                 continue
             sv_a, sv_f = w["enc_sv"][l]
-            sa.forward(w["eh"][2 * l], w["eh"][2 * l + 1], sv_a, B, T, hdrop=hd(256 + l))
+            sa.forward(w["eh"][2 * l], w["eh"][2 * l + 1], sv_a, B, T, hdrop=hd(256 + l), adrop=ad(768 + l))
             ff.forward(w["eh"][2 * l + 1], w["eh"][2 * l + 2], sv_f, Me, drop, self.step_seed * 4096 + l, hdrop=hd(512 + l))
         self._await("encf")
         self._await("emb")
@@ -248,8 +256,8 @@ class WhisperTrainEngine(WhisperEngine):
                 continue
             sv_a, sv_c, sv_f = w["dec_sv"][l]
             ca.project_kv(w["enc_out"], sv_c, B, T)
-            sa.forward(w["dh"][3 * l], w["dh"][3 * l + 1], sv_a, B, L, hdrop=hd(2304 + l))
-            ca.forward(w["dh"][3 * l + 1], w["dh"][3 * l + 2], sv_c, B, L, T, hdrop=hd(2560 + l))
+            sa.forward(w["dh"][3 * l], w["dh"][3 * l + 1], sv_a, B, L, hdrop=hd(2304 + l), adrop=ad(3072 + l))
+            ca.forward(w["dh"][3 * l + 1], w["dh"][3 * l + 2], sv_c, B, L, T, hdrop=hd(2560 + l), adrop=ad(3328 + l))
             ff.forward(w["dh"][3 * l + 2], w["dh"][3 * l + 3], sv_f, Md, drop, self.step_seed * 4096 + 2048 + l,
                        hdrop=hd(2816 + l))
         self._await_all()  # decf and anything not waited for above

@@ -292,6 +292,11 @@ typedef struct CaAttnDesc {
   int64_t sqb, skb, svb, sob, sdob, sdqb, sdkb, sdvb;
   int32_t B, H, Tq, Tk, hd, Tqp, causal;
   float scale;
+  /* dropout on the attention probabilities (training only; $TF/models/whisper/modeling_whisper.py:234,
+   * nn.functional.dropout(attn_weights, p=attention_dropout)): P' = P * keep / (1 - p) after the softmax, keep of
+   * (b, h, q, k) from a hash of (seed, flat index); forward and backward must be given the same p and seed. 0 = off. */
+  float dropout_p;
+  uint64_t dropout_seed;
 } CaAttnDesc;
 int ca_attn_fwd(const CaAttnDesc* desc, void* stream);
 int ca_attn_bwd(const CaAttnDesc* desc, void* stream);

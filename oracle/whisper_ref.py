@@ -186,7 +186,9 @@ def synth_params(c: WhisperConfig, seed: int = 4242) -> dict[str, torch.Tensor]:
     return out
 
 
-def _attn(xq, xkv, P, p, H, causal=False):
+def _attn(xq, xkv, P, p, H, causal=False, pmask=None):
+    """pmask: injected dropout mask on the attention probabilities (keep / (1 - p), [B, H, Tq, Tk]) or None -
+    `nn.functional.dropout(attn_weights, p=dropout)` at $TF/models/whisper/modeling_whisper.py:234."""
     B, Tq, d = xq.shape
     Tk = xkv.shape[1]
     hd = d // H
@@ -197,7 +199,10 @@ def _attn(xq, xkv, P, p, H, causal=False):
     if causal:
         m = torch.ones(Tq, Tk, dtype=torch.bool).tril(Tk - Tq)
         s = s.masked_fill(~m, float("-inf"))
-    o = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B, Tq, d)
+    pr = torch.softmax(s, -1)
+    if pmask is not None:
+        pr = pr * pmask
+    o = (pr @ v).transpose(1, 2).reshape(B, Tq, d)
     return F.linear(o, P[p + "out_proj.weight"], P[p + "out_proj.bias"])
 
 
@@ -226,7 +231,8 @@ def encoder(input_features: torch.Tensor, P: dict, c: WhisperConfig, keep=None, 
             continue
         p = f"model.encoder.layers.{l}."
         x = _ln(h, P, p + "self_attn_layer_norm", c.layer_norm_eps)
-        h = h + _drop(_attn(x, x, P, p + "self_attn.", c.encoder_attention_heads), masks, f"enc{l}.attn")
+        h = h + _drop(_attn(x, x, P, p + "self_attn.", c.encoder_attention_heads, pmask=(masks or {}).get(f"enc{l}.probs")),
+                      masks, f"enc{l}.attn")
         y = _ln(h, P, p + "final_layer_norm", c.layer_norm_eps)
         y = F.linear(F.gelu(F.linear(y, P[p + "fc1.weight"], P[p + "fc1.bias"])), P[p + "fc2.weight"], P[p + "fc2.bias"])
         h = h + _drop(y, masks, f"enc{l}.ffn")
@@ -244,9 +250,11 @@ def decoder(input_ids: torch.Tensor, enc: torch.Tensor, P: dict, c: WhisperConfi
             continue
         p = f"model.decoder.layers.{l}."
         x = _ln(h, P, p + "self_attn_layer_norm", c.layer_norm_eps)
-        h = h + _drop(_attn(x, x, P, p + "self_attn.", c.decoder_attention_heads, causal=True), masks, f"dec{l}.self")
+        h = h + _drop(_attn(x, x, P, p + "self_attn.", c.decoder_attention_heads, causal=True,
+                            pmask=(masks or {}).get(f"dec{l}.self_probs")), masks, f"dec{l}.self")
         x = _ln(h, P, p + "encoder_attn_layer_norm", c.layer_norm_eps)
-        h = h + _drop(_attn(x, enc, P, p + "encoder_attn.", c.decoder_attention_heads), masks, f"dec{l}.cross")
+        h = h + _drop(_attn(x, enc, P, p + "encoder_attn.", c.decoder_attention_heads,
+                            pmask=(masks or {}).get(f"dec{l}.cross_probs")), masks, f"dec{l}.cross")
         y = _ln(h, P, p + "final_layer_norm", c.layer_norm_eps)
         y = F.linear(F.gelu(F.linear(y, P[p + "fc1.weight"], P[p + "fc1.bias"])), P[p + "fc2.weight"], P[p + "fc2.bias"])
         h = h + _drop(y, masks, f"dec{l}.ffn")

@@ -391,3 +391,87 @@ def test_whisper_hidden_dropout_matches_oracle_with_the_same_masks():
     eng.training = False
     out_eval = eng.forward_train(feats, labels)
     assert abs(float(out_eval["loss"]) - float(loss_eval)) <= 1e-2 * float(loss_eval)
+
+
+def _keep_mask_np(seed: int, n_rows: int, Tk: int, p: float) -> np.ndarray:
+    """NumPy restatement of the kernels' keep decision (common.h: ca_mix32 / ca_dropout_words / ca_dropout_keep) for the
+    attention-probability index space: row = (b * H + h) * Tq + q, flat index = row * round_up(Tk, 4) + key.
+    -> bool [n_rows, Tk]."""
+    M = np.uint64(0xFFFFFFFF)
+    tkp = (Tk + 3) & ~3
+    idx = (np.arange(n_rows, dtype=np.uint64)[:, None] * np.uint64(tkp) + np.arange(Tk, dtype=np.uint64)[None, :])
+    group = idx >> np.uint64(2)
+    s = (np.uint64(seed & 0xFFFFFFFF) * np.uint64(0x9E3779B9) + np.uint64(seed >> 32)) & M
+
+    def mix32(x):
+        x = x ^ (x >> np.uint64(16))
+        x = (x * np.uint64(0x7FEB352D)) & M
+        x = x ^ (x >> np.uint64(15))
+        x = (x * np.uint64(0x846CA68B)) & M
+        return x ^ (x >> np.uint64(16))
+
+    w0 = mix32(((group & M) ^ s ^ (((group >> np.uint64(32)) * np.uint64(0x85EBCA6B)) & M)) & M)
+    w1 = (w0 * np.uint64(0xC2B2AE35)) & M
+    w1 = w1 ^ (w1 >> np.uint64(15))
+    w = np.where((idx & np.uint64(2)) != 0, w1, w0)
+    half = (w >> (np.uint64(16) * (idx & np.uint64(1)))) & np.uint64(0xFFFF)
+    thr = np.uint64(int(np.float32(p) * np.float32(65536.0)))
+    return half >= thr
+
+
+def test_whisper_attention_dropout_matches_oracle_with_the_same_masks():
+    """Dropout on the attention probabilities ($TF/models/whisper/modeling_whisper.py:234; the reference's smoke config
+    test-whisper sets attention_dropout 0.1): applied inside the fused attention kernels after the softmax normaliser,
+    regenerated in both backward kernels.  The keep decisions are restated in NumPy from the hash in common.h and
+    injected into the oracle: loss, logits and every gradient must agree (forward scale, the dV / dP paths of the
+    backward, and the three index conventions - queries in the forward and dQ kernels, keys in the dK/dV kernel)."""
+    from coral_amd.whisper import WhisperShape
+    from coral_amd.whisper_train import WhisperTrainEngine
+    from oracle import whisper_ref as w
+
+    kw, c = _tiny()
+    P = w.synth_params(c)
+    g = torch.Generator().manual_seed(22)
+    B, L, T, H, p = 2, 10, 1500, c.encoder_attention_heads, 0.2
+    feats = torch.randn(B, 80, 3000, generator=g) * 0.5
+    labels = torch.randint(0, 150, (B, L), generator=g)
+    labels[0, 8:] = -100
+    eng = WhisperTrainEngine(WhisperShape(**kw), DEV, attention_dropout=p)
+    eng.load_state_dict(P)
+    eng.step_seed = 5
+    base = eng.step_seed * 4096
+    scale = 1.0 / (1.0 - p)
+
+    def pm(site, Tq, Tk):
+        keep = _keep_mask_np(base + site, B * H * Tq, Tk, p)
+        return torch.from_numpy(keep.reshape(B, H, Tq, Tk).astype(np.float32)) * scale
+
+    masks = {}
+    for l in range(c.encoder_layers):
+        masks[f"enc{l}.probs"] = pm(768 + l, T, T)
+    for l in range(c.decoder_layers):
+        masks[f"dec{l}.self_probs"] = pm(3072 + l, L, L)
+        masks[f"dec{l}.cross_probs"] = pm(3328 + l, L, T)
+    assert abs(float((masks["enc0.probs"] != 0).float().mean()) - (1 - p)) < 2e-3
+    Pr = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    loss_ref, logits_ref = w.forward_loss(feats, labels, Pr, c, masks=masks)
+    loss_ref.backward()
+    eng.zero_grad()
+    out = eng.forward_train(feats, labels)
+    eng.backward()
+    torch.cuda.synchronize()
+    assert abs(float(out["loss"]) - float(loss_ref)) <= 1e-2 * float(loss_ref), (float(out["loss"]), float(loss_ref))
+    assert (out["logits"].float().cpu() - logits_ref.detach()).abs().max() <= 6e-2
+    loss_eval, _ = w.forward_loss(feats, labels, P, c)
+    assert abs(float(loss_eval) - float(loss_ref)) > 1e-4      # the masks change the forward
+    bad = []
+    for name, gq in eng.grad_dict().items():
+        gr = Pr[name].grad
+        if name == "model.encoder.embed_positions.weight" or name.endswith("k_proj.bias"):
+            continue
+        a, b = gq.double().cpu().flatten(), gr.double().flatten()
+        cos = float(a @ b / (a.norm() * b.norm() + 1e-30))
+        ratio = float(a.norm() / (b.norm() + 1e-30))
+        if not (cos >= 0.99 and 0.94 <= ratio <= 1.06):
+            bad.append((name, round(cos, 4), round(ratio, 4)))
+    assert not bad, bad
