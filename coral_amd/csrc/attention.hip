@@ -147,6 +147,11 @@ __device__ __forceinline__ void tie(bf16x8_t& f) { asm volatile("" : "+v"(f)); }
 // tile to tile: one LDS-DMA instruction per 1-KiB piece, no per-lane address arithmetic (the general loaders above
 // spend ~20 vector instructions per piece on row clamps, zero-page selects and 64-bit multiplies).  The last tile of
 // a tensor always takes the general loader (rows beyond the end, and no read past the allocation).
+__device__ __forceinline__ const char* uniform_ptr(const void* p) {  // a wave-uniform pointer the compiler cannot prove uniform
+  const uint64_t v = (uint64_t)(uintptr_t)p;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return (const char*)(uintptr_t)(((uint64_t)hi << 32) | lo);
+}
 __device__ __forceinline__ void glds16_sb(const char* base, uint32_t off, uint32_t lds_piece) {
   asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(off), "s"(base), "s"(lds_piece) : "memory", "m0");
 }
@@ -165,12 +170,13 @@ struct KImgFast {
       }
   }
   __device__ __forceinline__ void issue(char* lds, const unsigned short* tile_base, int wave) const {
-    const uint32_t l0 = (uint32_t)(uintptr_t)(lptr_t)lds;
+    const uint32_t l0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lptr_t)lds);
+    const char* tb = uniform_ptr(tile_base);
 #pragma unroll
     for (int c = 0; c < NCH; ++c)
 #pragma unroll
       for (int i = 0; i < IPW; ++i)
-        glds16_sb((const char*)tile_base, off[c * IPW + i], l0 + c * ROWS * 128 + (wave * IPW + i) * 1024);
+        glds16_sb(tb, off[c * IPW + i], l0 + c * ROWS * 128 + (wave * IPW + i) * 1024);
   }
 };
 template <int ROWS, int HDPV, int NW = 4>
@@ -187,9 +193,10 @@ struct MnImgFast {
     }
   }
   __device__ __forceinline__ void issue(char* lds, const unsigned short* tile_base, int wave) const {
-    const uint32_t l0 = (uint32_t)(uintptr_t)(lptr_t)lds;
+    const uint32_t l0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lptr_t)lds);
+    const char* tb = uniform_ptr(tile_base);
 #pragma unroll
-    for (int i = 0; i < IPW; ++i) glds16_sb((const char*)tile_base, off[i], l0 + (wave * IPW + i) * 1024);
+    for (int i = 0; i < IPW; ++i) glds16_sb(tb, off[i], l0 + (wave * IPW + i) * 1024);
   }
 };
 // number of leading tiles of `rows_per_tile` rows that are fully inside a tensor of n rows and are not its last tile
@@ -429,6 +436,270 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   unsigned short* O = a.O + b * a.sob + h * hd;
   // (every loop iteration ended with a workgroup barrier: the images are free)
   store_tile16<HDPV>(smem + wave * (attn_stage_bytes(HDPV) / 4), o, ir, O, a.ldo, q0, a.Tq, hd, lane);
+}
+
+// ---- forward, wide workgroups ---------------------------------------------------------------------------------------
+// NW waves x 32 queries per workgroup (two 16-query blocks per wave: every K / V fragment read feeds two MFMAs), key /
+// value tiles in a ring of NST image pairs with NST - 1 tiles in flight and counted waits (the fast path's LDS-DMA is
+// inline asm in a fixed order: DPT instructions per wave and tile).  Tiles fully inside the valid keys run a body
+// without any per-element compare / select (written as a run-time `if`, the compiler turns the masks into selects that
+// run for every tile: ~190 of ~540 vector instructions per 64 MFMAs); the ragged last tile and causal tiles run the
+// masked body in a loop of their own.
+// Measured at the XLS-R-2B shape (B 8, H 16, T 499, hd 120; by switching parts of the kernel off): 10 us before the
+// first MFMA (launch, the query fragments and the first tile at the ~12 B/clk a CU takes in), 22 us of loop, 5 us of
+// output burst.  In the loop the two waves of a SIMD run in lock step behind the per-tile barrier, so per tile and SIMD
+// 2 x 64 MFMAs (2048 cycles) and 2 x ~250 vector instructions (~2200 cycles) add up instead of overlapping.  128
+// queries x 4 waves x 2 image pairs (two workgroups per CU, which drift apart) runs 9 % faster than the 64-query
+// kernel; 256 queries x 8 waves x 4 pairs (one workgroup per CU) measured the same or slower, so only the former is
+// instantiated.
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+template <int HDPV, bool DROP, int NW, int NST>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_fwd_wide_kernel(const AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NQ = 2, NKS = HDPV / 32, NNB = HDPV / 16;
+  constexpr int IMG = 64 * HDPV * 2, PAIR = 2 * IMG;  // a tile = K-major image of the keys + MN-major image of the values
+  constexpr int QPB = NW * 16 * NQ;                   // queries per workgroup
+  constexpr int DPT = (HDPV / 64) * (64 / 8 / NW) + 64 * HDPV * 2 / 1024 / NW;  // LDS-DMA instructions per wave and tile
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, r = lane & 15;
+  int tile, h, b;
+  if (!attn_tile_of_block((a.Tq + QPB - 1) / QPB, a.H, a.B, tile, h, b)) return;
+  const int hd = a.hd;
+  const unsigned short* Q = a.Q + b * a.sqb + h * hd;
+  const unsigned short* K = a.K + b * a.skb + h * hd;
+  const unsigned short* V = a.V + b * a.svb + h * hd;
+  const int q0 = tile * QPB + wave * 16 * NQ;
+  int qi[NQ], qrow[NQ];  // this lane's queries (columns of the transposed score tiles)
+#pragma unroll
+  for (int j = 0; j < NQ; ++j) {
+    qi[j] = q0 + 16 * j + r;
+    qrow[j] = qi[j] < a.Tq ? qi[j] : a.Tq - 1;
+  }
+  int kl = a.Tk;
+  if (a.klen) kl = a.klen[b] < kl ? a.klen[b] : kl;
+  int ntile = (kl + 63) / 64;
+  if (a.causal) {  // keys beyond the workgroup's last query are masked
+    const int last = (tile * QPB + QPB - 1) / 64 + 1;
+    ntile = ntile < last ? ntile : last;
+  }
+  KImgFast<64, HDPV, NW> kfast;
+  MnImgFast<64, HDPV, NW> vfast;
+  kfast.init(a.ldk, wave, lane);
+  vfast.init(a.ldv, wave, lane);
+  const int nfast = fast_tiles(a.Tk, 64);
+  auto issue = [&](int kt, int stage) __attribute__((always_inline)) {
+    char* img = smem + stage * PAIR;
+    if (kt < nfast) {
+      kfast.issue(img, K + (int64_t)kt * 64 * a.ldk, wave);
+      vfast.issue(img + IMG, V + (int64_t)kt * 64 * a.ldv, wave);
+    } else {
+      load_kmajor_image<64, HDPV, NW>(img, K, a.ldk, kt * 64, a.Tk, hd, wave, lane);
+      load_mnmajor_image<64, HDPV, NW>(img + IMG, V, a.ldv, kt * 64, a.Tk, hd, wave, lane);
+    }
+  };
+#pragma unroll
+  for (int t = 0; t < NST - 1; ++t)
+    if (t < ntile) issue(t, t);
+  // all HDPV/32 k-steps and HDPV/16 column blocks are computed: dims >= hd are zero in every LDS image
+  bf16x8_t qf[NQ][NKS];
+#pragma unroll
+  for (int j = 0; j < NQ; ++j)
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) qf[j][ks] = load_rowfrag(Q, a.ldq, qrow[j], ks, lane, hd);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the query fragments are younger than the first tiles)
+  const float c2 = a.scale * LOG2E;
+
+  float m[NQ], l[NQ];  // running max (log2 units, same in the 4 lanes of a query) / this lane's partial sum
+  f32x4_t o[NQ][NNB];
+#pragma unroll
+  for (int j = 0; j < NQ; ++j) {
+    m[j] = NEG_BIG;
+    l[j] = 0.f;
+#pragma unroll
+    for (int nb = 0; nb < NNB; ++nb) o[j][nb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  }
+  // LDS address of this lane's value fragments (column block nb, rows 8g + q of half 0) inside value image 0; the
+  // half, the +4 rows of the second read and nothing else are immediates
+  uint32_t voff[NNB];
+  {
+    constexpr int PC = HDPV / 8;
+    const int q4 = (lane & 15) >> 2, p4 = lane & 3;
+    const int swz = q4 | ((g & 1) << 2);
+#pragma unroll
+    for (int nb = 0; nb < NNB; ++nb) {
+      const int c = ((2 * nb) + (p4 >> 1)) ^ ((swz << 1) & (PC - 1));
+      voff[nb] = (uint32_t)(uintptr_t)(lptr_t)smem + IMG + (8 * g + q4) * (HDPV * 2) + c * 16 + (p4 & 1) * 8;
+    }
+  }
+  auto tile_body = [&](auto full_c, int kt, int stage) __attribute__((always_inline)) {
+    constexpr bool FULL = decltype(full_c)::value;
+    const char* Kimg = smem + stage * PAIR;
+    // transposed scores of the 64 keys: block (s, bb) holds keys 32 s + 8 g + 4 bb + {0..3} of query qi
+    f32x4_t sc[NQ][4];
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk) {
+      const int row = 32 * (blk >> 1) + rowperm(blk & 1, r);
+#pragma unroll
+      for (int j = 0; j < NQ; ++j) sc[j][blk] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        const bf16x8_t kfr = kimg_frag<64>(Kimg, row, ks, lane);
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) sc[j][blk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr, qf[j][ks], sc[j][blk], 0, 0, 0);
+      }
+    }
+    bf16x8_t pf[NQ][2];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+      if constexpr (!FULL) {
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int key = kt * 64 + 32 * (blk >> 1) + 8 * g + 4 * (blk & 1) + e;
+            const bool ok = key < kl && (!a.causal || key <= qi[j]);
+            sc[j][blk][e] = ok ? sc[j][blk][e] : NEG_BIG;
+          }
+      }
+      // scores in log2 units first: the products are canonical values, so the maximum below compiles to plain
+      // v_max3_f32 (fmaxf straight on MFMA outputs makes the compiler canonicalise every operand: v_max x, x), and a
+      // probability is one subtraction and one v_exp_f32.  (A hand-written v_max3_f32 on the accumulators is not an
+      // option: the hazard recogniser does not see inline asm, and the MFMA -> VALU read then returns stale registers.)
+      float t[16];
+#pragma unroll
+      for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t[4 * blk + e] = sc[j][blk][e] * c2;
+      float tmax = fmaxf(fmaxf(t[0], t[1]), t[2]);
+#pragma unroll
+      for (int i = 3; i < 15; i += 2) tmax = fmaxf(fmaxf(tmax, t[i]), t[i + 1]);
+      tmax = fmaxf(tmax, t[15]);
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+      const float m_new = fmaxf(m[j], tmax);
+      const float alpha = __builtin_amdgcn_exp2f(m[j] - m_new);
+      float p[16];
+      float sum = 0.f;
+#pragma unroll
+      for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float pv = __builtin_amdgcn_exp2f(t[4 * blk + e] - m_new);
+          if constexpr (!FULL) pv = sc[j][blk][e] > 0.5f * NEG_BIG ? pv : 0.f;
+          p[4 * blk + e] = pv;
+          sum += pv;  // the normaliser is the sum of ALL probabilities: dropout acts on the normalised ones
+        }
+      if constexpr (DROP) {
+        const float ks = 1.f / (1.f - a.drop_p);
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) {
+          const int key0 = kt * 64 + 32 * (blk >> 1) + 8 * g + 4 * (blk & 1);
+          const unsigned keep = ca_dropout_keep4(a.drop_seed, attn_drop_index(a, b, h, qrow[j], key0), a.drop_p);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) p[4 * blk + e] = ((keep >> e) & 1u) ? p[4 * blk + e] * ks : 0.f;
+        }
+      }
+      l[j] = fmaf(l[j], alpha, sum);
+      if (__builtin_amdgcn_ballot_w64(m_new > m[j]) != 0) {  // some query of this block moved its maximum
+        float ar[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ar[e] = __shfl(alpha, 4 * g + e, 64);
+#pragma unroll
+        for (int nb = 0; nb < NNB; ++nb)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[j][nb][e] *= ar[e];
+      }
+      m[j] = m_new;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        float ps[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ps[e] = p[8 * s + e];
+        pf[j][s] = pack8(ps);
+      }
+    }
+    // value fragments in batches of four column blocks; the next batch is in flight while the current one is used
+    // (inline-asm reads: the builtin would be ordered behind the LDS-DMA of the tiles in flight)
+    constexpr int NBATCH = 2 * NNB / 4, PITCH = HDPV * 2;
+    const uint32_t sbase = (uint32_t)(stage * PAIR);
+    bf16x8_t fa[4], fb[4];
+    auto read_batch = [&](auto bt_c, bf16x8_t (&f)[4]) {
+      constexpr int BT = decltype(bt_c)::value;
+      constexpr int S = BT / (NNB / 4), NB0 = (BT % (NNB / 4)) * 4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        s16x4_t lo, hi;
+        const uint32_t ad = voff[NB0 + i] + sbase;
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(ad), "n"(S * 32 * PITCH));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(ad), "n"(S * 32 * PITCH + 4 * PITCH));
+        s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        f[i] = __builtin_bit_cast(bf16x8_t, v);
+      }
+    };
+    auto step = [&](auto bt_c, bf16x8_t (&cur)[4], bf16x8_t (&nxt)[4]) {
+      constexpr int BT = decltype(bt_c)::value;
+      constexpr int S = BT / (NNB / 4), NB0 = (BT % (NNB / 4)) * 4;
+      lds_wait_all();
+#pragma unroll
+      for (int i = 0; i < 4; ++i) tie(cur[i]);
+      if constexpr (BT + 1 < NBATCH) read_batch(std::integral_constant<int, BT + 1>{}, nxt);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NQ; ++j)
+          o[j][NB0 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[j][S], cur[i], o[j][NB0 + i], 0, 0, 0);
+    };
+    read_batch(std::integral_constant<int, 0>{}, fa);
+    step(std::integral_constant<int, 0>{}, fa, fb);
+    step(std::integral_constant<int, 1>{}, fb, fa);
+    if constexpr (NBATCH > 2) {
+      step(std::integral_constant<int, 2>{}, fa, fb);
+      step(std::integral_constant<int, 3>{}, fb, fa);
+    }
+  };
+  // tile kt lives in image pair kt % NST; tiles kt + 1 .. kt + NST - 2 stay in flight across the wait for tile kt, and
+  // the request for tile kt + NST - 1 goes out right after the barrier that frees its pair (one barrier per tile)
+  int stage = 0;
+  auto run = [&](auto full_c, int kt0, int kt1) __attribute__((always_inline)) {
+    for (int kt = kt0; kt < kt1; ++kt) {
+      const int ahead = ntile - 1 - kt;
+      if (NST >= 4 && ahead >= 2)
+        wait_vm<2 * DPT>();
+      else if (NST >= 3 && ahead >= 1)
+        wait_vm<DPT>();
+      else
+        wait_vm<0>();
+      __syncthreads();
+      if (kt + NST - 1 < ntile) issue(kt + NST - 1, stage == 0 ? NST - 1 : stage - 1);
+      tile_body(full_c, kt, stage);
+      stage = stage + 1 == NST ? 0 : stage + 1;
+    }
+  };
+  const int nfull = a.causal ? 0 : (kl / 64 < ntile ? kl / 64 : ntile);
+  run(std::true_type{}, 0, nfull);
+  run(std::false_type{}, nfull, ntile);
+  __syncthreads();  // every wave is done with the images: the LDS becomes output staging
+  unsigned short* O = a.O + b * a.sob + h * hd;
+  char* st = smem + wave * (16 * (HDPV * 2 + 16));
+#pragma unroll
+  for (int j = 0; j < NQ; ++j) {
+    // total of the four lane groups that share a query; lse in natural-log units for the backward
+    float lt = l[j];
+    lt += __shfl_xor(lt, 16, 64);
+    lt += __shfl_xor(lt, 32, 64);
+    const float lse = lt > 0.f ? (m[j] + __builtin_amdgcn_logf(lt)) * 0.69314718055994530942f : __builtin_inff();
+    if (g == 0 && qi[j] < a.Tq && a.lse) a.lse[((int64_t)b * a.H + h) * a.Tqp + qi[j]] = lse;
+    const float inv = lt > 0.f ? 1.0f / lt : 0.f;  // nothing attended -> zero output
+    float ir[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ir[e] = __shfl(inv, 4 * g + e, 64);
+    if (j) __builtin_amdgcn_wave_barrier();
+    store_tile16<HDPV>(st, o[j], ir, O, a.ldo, q0 + 16 * j, a.Tq, hd, lane);
+  }
 }
 
 // Greedy decoding (Tq <= 16 queries per head, hd <= 64): one workgroup per (clip, head), the four waves split the
@@ -940,6 +1211,173 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   store_tile16<HDPV>(smem + wave * (attn_stage_bytes(HDPV) / 4), acc, one, dQ, a.lddq, q0, a.Tq, hd, lane);
 }
 
+// ---- backward: dQ, wide workgroups (same reasoning and ring as attn_fwd_wide_kernel) -----------------------------------
+// NW waves x 32 queries; per 64-key tile a K-major image of K (S^T = K Q^T and, read transposed, dQ += dS K) and one of
+// V (dP^T = V dO^T): every fragment read feeds the MFMAs of both 16-query blocks of the wave.
+template <int HDPV, bool DROP, int NW, int NST>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_dq_wide_kernel(const AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NQ = 2, NKS = HDPV / 32, NNB = HDPV / 16;
+  constexpr int IMG = 64 * HDPV * 2, PAIR = 2 * IMG;
+  constexpr int QPB = NW * 16 * NQ;
+  constexpr int DPT = 2 * (HDPV / 64) * (64 / 8 / NW);  // LDS-DMA instructions per wave and tile
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, r = lane & 15;
+  int tile, h, b;
+  if (!attn_tile_of_block((a.Tq + QPB - 1) / QPB, a.H, a.B, tile, h, b)) return;
+  const int hd = a.hd;
+  const unsigned short* Q = a.Q + b * a.sqb + h * hd;
+  const unsigned short* K = a.K + b * a.skb + h * hd;
+  const unsigned short* V = a.V + b * a.svb + h * hd;
+  const unsigned short* dO = a.dO + b * a.sdob + h * hd;
+  const int q0 = tile * QPB + wave * 16 * NQ;
+  int qi[NQ], qrow[NQ];
+#pragma unroll
+  for (int j = 0; j < NQ; ++j) {
+    qi[j] = q0 + 16 * j + r;
+    qrow[j] = qi[j] < a.Tq ? qi[j] : a.Tq - 1;
+  }
+  int kl = a.Tk;
+  if (a.klen) kl = a.klen[b] < kl ? a.klen[b] : kl;
+  int ntile = (kl + 63) / 64;
+  if (a.causal) {
+    const int last = (tile * QPB + QPB - 1) / 64 + 1;  // keys beyond the workgroup's last query are masked
+    ntile = ntile < last ? ntile : last;
+  }
+  KImgFast<64, HDPV, NW> kfast, vfast;
+  kfast.init(a.ldk, wave, lane);
+  vfast.init(a.ldv, wave, lane);
+  const int nfast = fast_tiles(a.Tk, 64);
+  auto issue = [&](int kt, int stage) __attribute__((always_inline)) {
+    char* img = smem + stage * PAIR;
+    if (kt < nfast) {
+      kfast.issue(img, K + (int64_t)kt * 64 * a.ldk, wave);
+      vfast.issue(img + IMG, V + (int64_t)kt * 64 * a.ldv, wave);
+    } else {
+      load_kmajor_image<64, HDPV, NW>(img, K, a.ldk, kt * 64, a.Tk, hd, wave, lane);
+      load_kmajor_image<64, HDPV, NW>(img + IMG, V, a.ldv, kt * 64, a.Tk, hd, wave, lane);
+    }
+  };
+#pragma unroll
+  for (int t = 0; t < NST - 1; ++t)
+    if (t < ntile) issue(t, t);
+  // all HDPV/32 k-steps and HDPV/16 column blocks are computed: dims >= hd are zero in every LDS image
+  bf16x8_t qf[NQ][NKS], dof[NQ][NKS];
+  float lse2[NQ], dq_row[NQ];
+#pragma unroll
+  for (int j = 0; j < NQ; ++j) {
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      qf[j][ks] = load_rowfrag(Q, a.ldq, qrow[j], ks, lane, hd);
+      dof[j][ks] = load_rowfrag(dO, a.lddo, qrow[j], ks, lane, hd);
+    }
+    lse2[j] = a.lse[((int64_t)b * a.H + h) * a.Tqp + qrow[j]] * LOG2E;
+    dq_row[j] = a.Dq[((int64_t)b * a.H + h) * a.Tqp + qrow[j]];
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (these loads are younger than the first tiles)
+  f32x4_t acc[NQ][NNB];
+#pragma unroll
+  for (int j = 0; j < NQ; ++j)
+#pragma unroll
+    for (int nb = 0; nb < NNB; ++nb) acc[j][nb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const float scale = a.scale;
+  const float c2 = scale * LOG2E;
+  auto tile_body = [&](auto full_c, int kt, int stage) __attribute__((always_inline)) {
+    constexpr bool FULL = decltype(full_c)::value;
+    const char* Kk = smem + stage * PAIR;
+    const char* Vk = Kk + IMG;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      float ds[NQ][8];
+#pragma unroll
+      for (int bb = 0; bb < 2; ++bb) {
+        f32x4_t sacc[NQ], pacc[NQ];
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) sacc[j] = pacc[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        const int row = 32 * s + rowperm(bb, r);
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+          const bf16x8_t kfr = kimg_frag<64>(Kk, row, ks, lane), vfr = kimg_frag<64>(Vk, row, ks, lane);
+#pragma unroll
+          for (int j = 0; j < NQ; ++j) {
+            sacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr, qf[j][ks], sacc[j], 0, 0, 0);
+            pacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr, dof[j][ks], pacc[j], 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+          unsigned keep = 0xFu;
+          if constexpr (DROP)
+            keep = ca_dropout_keep4(a.drop_seed, attn_drop_index(a, b, h, qrow[j], kt * 64 + 32 * s + 8 * g + 4 * bb), a.drop_p);
+          const float kscale = DROP ? 1.f / (1.f - a.drop_p) : 1.f;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float dpv = DROP ? (((keep >> e) & 1u) ? pacc[j][e] * kscale : 0.f) : pacc[j][e];
+            float dsv = __builtin_amdgcn_exp2f(fmaf(sacc[j][e], c2, -lse2[j])) * (dpv - dq_row[j]) * scale;
+            if constexpr (!FULL) {
+              const int key = kt * 64 + 32 * s + 8 * g + 4 * bb + e;
+              const bool ok = key < kl && (!a.causal || key <= qi[j]);
+              dsv = ok ? dsv : 0.f;
+            }
+            ds[j][4 * bb + e] = dsv;
+          }
+        }
+      }
+      bf16x8_t dsf[NQ];
+#pragma unroll
+      for (int j = 0; j < NQ; ++j) dsf[j] = pack8(ds[j]);
+      // transposed key fragments in batches of four column blocks, the next batch in flight while one is used
+      bf16x8_t fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = timg_frag_k_async<64>(Kk, s, i, lane);
+#pragma unroll
+      for (int bt = 0; bt < NNB / 4; ++bt) {
+        lds_wait_all();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) tie((bt & 1) ? fb[i] : fa[i]);
+        if (bt + 1 < NNB / 4) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) ((bt & 1) ? fa[i] : fb[i]) = timg_frag_k_async<64>(Kk, s, 4 * (bt + 1) + i, lane);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < NQ; ++j)
+            acc[j][4 * bt + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsf[j], (bt & 1) ? fb[i] : fa[i], acc[j][4 * bt + i], 0, 0, 0);
+      }
+    }
+  };
+  int stage = 0;
+  auto run = [&](auto full_c, int kt0, int kt1) __attribute__((always_inline)) {
+    for (int kt = kt0; kt < kt1; ++kt) {
+      const int ahead = ntile - 1 - kt;
+      if (NST >= 4 && ahead >= 2)
+        wait_vm<2 * DPT>();
+      else if (NST >= 3 && ahead >= 1)
+        wait_vm<DPT>();
+      else
+        wait_vm<0>();
+      __syncthreads();
+      if (kt + NST - 1 < ntile) issue(kt + NST - 1, stage == 0 ? NST - 1 : stage - 1);
+      tile_body(full_c, kt, stage);
+      stage = stage + 1 == NST ? 0 : stage + 1;
+    }
+  };
+  const int nfull = a.causal ? 0 : (kl / 64 < ntile ? kl / 64 : ntile);
+  run(std::true_type{}, 0, nfull);
+  run(std::false_type{}, nfull, ntile);
+  __syncthreads();  // every wave is done with the images: the LDS becomes output staging
+  unsigned short* dQ = a.dQ + b * a.sdqb + h * hd;
+  const float one[4] = {1.f, 1.f, 1.f, 1.f};
+  char* st = smem + wave * (16 * (HDPV * 2 + 16));
+#pragma unroll
+  for (int j = 0; j < NQ; ++j) {
+    if (j) __builtin_amdgcn_wave_barrier();
+    store_tile16<HDPV>(st, acc[j], one, dQ, a.lddq, q0 + 16 * j, a.Tq, hd, lane);
+  }
+}
+
 // ---- C ABI ------------------------------------------------------------------------------------------------
 static int attn_check(const CaAttnDesc* d, const char* who) {
   CA_CHECK_ARG(d && d->Q && d->K && d->V, "%s: null pointer", who);
@@ -970,6 +1408,22 @@ extern "C" int ca_attn_fwd(const CaAttnDesc* desc, void* stream) {
   const AttnArgs a = to_args(*desc);
   dim3 grid(attn_grid((desc->Tq + 63) / 64, desc->H, desc->B)), block(256);
   hipStream_t s = (hipStream_t)stream;
+  // 128-query workgroups when the query side fills them; CA_ATTN_WIDE=0 keeps the 64-query kernel
+  static const int wide = [] { const char* e = getenv("CA_ATTN_WIDE"); return e ? atoi(e) : 1; }();
+  if (wide && desc->Tq >= 100) {
+    const bool drop = desc->dropout_p > 0.f;
+#define CA_FWD_WIDE(HDPV, DROP)                                                                                   \
+  hipLaunchKernelGGL((attn_fwd_wide_kernel<HDPV, DROP, 4, 2>), dim3(attn_grid((desc->Tq + 127) / 128, desc->H, desc->B)), \
+                     dim3(256), 2 * 2 * 64 * HDPV * 2, s, a)
+    if (desc->hd <= 64) {
+      if (drop) CA_FWD_WIDE(64, true); else CA_FWD_WIDE(64, false);
+    } else {
+      if (drop) CA_FWD_WIDE(128, true); else CA_FWD_WIDE(128, false);
+    }
+#undef CA_FWD_WIDE
+    CA_CHECK_LAUNCH("ca_attn_fwd");
+    return CA_OK;
+  }
   if (desc->dropout_p > 0.f) {  // training with dropout on the attention probabilities: the general kernels only
     if (desc->hd <= 64)
       hipLaunchKernelGGL((attn_fwd_kernel<64, true>), grid, block, 2 * 64 * 64 * 2, s, a);
@@ -1008,21 +1462,32 @@ extern "C" int ca_attn_bwd(const CaAttnDesc* desc, void* stream) {
                      (const unsigned short*)desc->dO, desc->lddo, desc->sdob, (const unsigned short*)desc->O,
                      desc->ldo, desc->sob, (float*)desc->Dq, desc->H, desc->Tq, desc->Tqp, desc->hd, desc->B);
   dim3 gk(attn_grid((desc->Tk + 63) / 64, desc->H, desc->B)), gq(attn_grid((desc->Tq + 63) / 64, desc->H, desc->B)), block(256);
-  if (desc->dropout_p > 0.f) {
-    if (desc->hd <= 64) {
-      hipLaunchKernelGGL((attn_bwd_dkv_kernel<64, true>), gk, block, 4 * 32 * 64 * 2, s, a);
-      hipLaunchKernelGGL((attn_bwd_dq_kernel<64, true>), gq, block, 2 * 64 * 64 * 2, s, a);
-    } else {
-      hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, true>), gk, block, 4 * 32 * 128 * 2, s, a);
-      hipLaunchKernelGGL((attn_bwd_dq_kernel<128, true>), gq, block, 2 * 64 * 128 * 2, s, a);
-    }
-  } else if (desc->hd <= 64) {
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<64>), gk, block, 4 * 32 * 64 * 2, s, a);
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<64>), gq, block, 2 * 64 * 64 * 2, s, a);
+  const bool drop = desc->dropout_p > 0.f;
+  static const int wide = [] { const char* e = getenv("CA_ATTN_WIDE"); return e ? atoi(e) : 1; }();
+  // dK, dV: 64 keys per workgroup (a 128-key, 8-wave variant with a 4-deep ring measured no faster at T = 499 and 5 %
+  // slower at T = 1500: dropped)
+#define CA_DKV(HDPV, DROP) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HDPV, DROP>), gk, block, 4 * 32 * HDPV * 2, s, a)
+  if (desc->hd <= 64) {
+    if (drop) CA_DKV(64, true); else CA_DKV(64, false);
   } else {
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<128>), gk, block, 4 * 32 * 128 * 2, s, a);
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<128>), gq, block, 2 * 64 * 128 * 2, s, a);
+    if (drop) CA_DKV(128, true); else CA_DKV(128, false);
   }
+#undef CA_DKV
+  // dQ: 128-query workgroups when the query side fills them
+#define CA_DQ(HDPV, DROP)                                                                                          \
+  do {                                                                                                             \
+    if (wide && desc->Tq >= 100)                                                                                   \
+      hipLaunchKernelGGL((attn_bwd_dq_wide_kernel<HDPV, DROP, 4, 2>),                                              \
+                         dim3(attn_grid((desc->Tq + 127) / 128, desc->H, desc->B)), dim3(256), 2 * 2 * 64 * HDPV * 2, s, a); \
+    else                                                                                                           \
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<HDPV, DROP>), gq, block, 2 * 64 * HDPV * 2, s, a);                    \
+  } while (0)
+  if (desc->hd <= 64) {
+    if (drop) CA_DQ(64, true); else CA_DQ(64, false);
+  } else {
+    if (drop) CA_DQ(128, true); else CA_DQ(128, false);
+  }
+#undef CA_DQ
   CA_CHECK_LAUNCH("ca_attn_bwd");
   return CA_OK;
 }

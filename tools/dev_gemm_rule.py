@@ -26,7 +26,7 @@ def timeit(fn, iters=12):
 
 
 shapes = []
-for name, M, d, f in (("xlsr-2b", 3992, 1920, 7680), ("xlsr-300m", 3992, 1024, 4096), ("whisper-medium", 12000, 1024, 4096),
+for name, M, d, f in (("xlsr-2b", 3992, 1920, 7680), ("xlsr-300m", 3992, 1024, 4096), ("xlsr-1b", 3992, 1280, 5120), ("whisper-medium", 12000, 1024, 4096),
                       ("whisper-turbo", 12000, 1280, 5120)):
     for bl in (0, 1):
         shapes += [(name, M, d, d, bl), (name, M, 3 * d, d, bl), (name, M, d, 3 * d, bl), (name, M, f, d, bl), (name, M, d, f, bl)]
@@ -37,12 +37,15 @@ for name, M, N, K, bl in shapes:
     Cd = torch.zeros(M, N, dtype=torch.bfloat16, device=dev)
     kw = dict(M=M, N=N, K=K, a_layout=0, b_layout=bl, lda=K, ldb=N if bl else K, ldc=N)
     t = {}
-    for force in (1, 3, 0):
+    for force in (1, 2, 3, 0):
         ops.lib().ca_gemm_force_kernel(force)
         t[force] = timeit(lambda: ops.gemm(A, Bt, Cd, **kw))
     ops.lib().ca_gemm_force_kernel(0)
-    best = "S" if t[1] <= t[3] else "X"
-    auto = "S" if abs(t[0] - t[1]) < abs(t[0] - t[3]) else "X"
-    flag = "" if best == auto or abs(t[1] - t[3]) / min(t[1], t[3]) < 0.03 else "   <-- rule picks the slower one"
+    names = {1: "S", 2: "L", 3: "X"}
+    best = min((1, 2, 3), key=lambda k: t[k])
+    auto = min((1, 2, 3), key=lambda k: abs(t[0] - t[k]))
+    flag = "" if best == auto or (t[auto] - t[best]) / t[best] < 0.03 else "   <-- rule picks a slower one"
     xt = ((M + 255) // 256) * ((N + 255) // 256)
-    print(f"{name:15s} M{M:6d} N{N:5d} K{K:5d} {'NT' if not bl else 'NN'}  S {t[1]:7.1f}  X {t[3]:7.1f}  auto {t[0]:7.1f} ({auto}) xtiles {xt:4d}{flag}")
+    tf = 2.0 * M * N * K / t[0] / 1e6
+    print(f"{name:15s} M{M:6d} N{N:5d} K{K:5d} {'NT' if not bl else 'NN'}  S {t[1]:7.1f}  L {t[2]:7.1f}  X {t[3]:7.1f}  auto {t[0]:7.1f} "
+          f"({names[auto]}, {tf:6.0f} TF) xtiles {xt:4d}{flag}")
