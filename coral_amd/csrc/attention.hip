@@ -446,7 +446,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 // run for every tile: ~190 of ~540 vector instructions per 64 MFMAs); the ragged last tile and causal tiles run the
 // masked body in a loop of their own.
 // Measured at the XLS-R-2B shape (B 8, H 16, T 499, hd 120; by switching parts of the kernel off): 10 us before the
-// first MFMA (launch, the query fragments and the first tile at the ~12 B/clk a CU takes in), 22 us of loop, 5 us of
+// first MFMA (launch, the query fragments and the first tile: latency, not bandwidth), 22 us of loop, 5 us of
 // output burst.  In the loop the two waves of a SIMD run in lock step behind the per-tile barrier, so per tile and SIMD
 // 2 x 64 MFMAs (2048 cycles) and 2 x ~250 vector instructions (~2200 cycles) add up instead of overlapping.  128
 // queries x 4 waves x 2 image pairs (two workgroups per CU, which drift apart) runs 9 % faster than the 64-query

@@ -698,6 +698,12 @@ struct CaGemmGroup {
 // counter slots for persistent launches: launches that may be in flight together (two streams) use different slots
 #define X_CNT_SLOTS 64
 __device__ unsigned g_x_cnt[X_CNT_SLOTS][8];
+#ifdef X_STAMPS
+__device__ long long g_x_stamps[512 * 8 * 8];
+extern "C" int ca_gemm_x_stamps(long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_x_stamps), (size_t)n * sizeof(long long));
+}
+#endif
 template <int AL, int BL, bool KS>
 __global__ __launch_bounds__(512) void ca_gemm_kernel_x(const CaGemmGroup grp) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -777,6 +783,9 @@ __global__ __launch_bounds__(512) void ca_gemm_kernel_x(const CaGemmGroup grp) {
   for (int i = 0; i < 8; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#ifdef X_STAMPS
+  long long stamp_dma = 0, stamp_bar = 0;
+#endif
   const int cs_parts = ((d.N + XBN - 1) / XBN) < 8 ? ((d.N + XBN - 1) / XBN) : 8;  // tile columns sharing the column sums
   const bool do_colsum = d.a_colsum != nullptr && tn < cs_parts;
   float csum0 = 0.f, csum1 = 0.f;  // this lane's share of sum_k A[k, m] for m = m0 + wm*128 + (ih*4 + wn)*16 + (lane & 15)
@@ -989,10 +998,21 @@ __global__ __launch_bounds__(512) void ca_gemm_kernel_x(const CaGemmGroup grp) {
     lds_wait(A1);  // the last fragment reads of tile kt have returned
     colsum_acc(cs_step, 1, A1);
     // tile kt+1 has landed (this wave's share; the barrier covers the others) and stage ST is free
+#ifdef X_STAMPS
+    const long long st0 = __builtin_amdgcn_s_memtime();
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef X_STAMPS
+    const long long st1 = __builtin_amdgcn_s_memtime();
+#endif
     zero_tail(kt + 1);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+#ifdef X_STAMPS
+    const long long st2 = __builtin_amdgcn_s_memtime();
+    stamp_dma += st1 - st0;
+    stamp_bar += st2 - st1;
+#endif
     if (wave < 4) burst(kt + 2);
     X_SB;
     // block 3: A(s1, m-half 1) x B(s1); reads B(s0), A(s0, m-half 0) of tile kt+1 (harmless stale data after the
@@ -1008,11 +1028,17 @@ __global__ __launch_bounds__(512) void ca_gemm_kernel_x(const CaGemmGroup grp) {
     X_MM2(1, A1, B1, 3, 2); X_RD_A(1 - ST, 0, 3, A0[3]); X_SB;
     __builtin_amdgcn_s_setprio(0);
   };
+#ifdef X_STAMPS
+  const long long stamp_t0 = __builtin_amdgcn_s_memtime();
+#endif
   burst(0);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   zero_tail(0);
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
+#ifdef X_STAMPS
+  const long long stamp_t1 = __builtin_amdgcn_s_memtime();
+#endif
   X_RD_B(0, 0, 0, B0[0]); X_RD_B(0, 0, 1, B0[1]); X_RD_B(0, 0, 2, B0[2]); X_RD_B(0, 0, 3, B0[3]);
   X_RD_A(0, 0, 0, A0[0]); X_RD_A(0, 0, 1, A0[1]); X_RD_A(0, 0, 2, A0[2]); X_RD_A(0, 0, 3, A0[3]);
   if (wave < 4) burst(1);
@@ -1024,6 +1050,9 @@ __global__ __launch_bounds__(512) void ca_gemm_kernel_x(const CaGemmGroup grp) {
 #undef X_RD_B
 #undef X_MM2
 #undef X_SB
+#ifdef X_STAMPS
+  const long long stamp_t2 = __builtin_amdgcn_s_memtime();
+#endif
   if (AL == CA_MNMAJOR && do_colsum) {
     // a lane's fragment holds k = 8g..8g+7 of a 32-k step: add the four lane groups, then lanes 0-15 own 16 rows
 #pragma unroll
@@ -1049,6 +1078,21 @@ __global__ __launch_bounds__(512) void ca_gemm_kernel_x(const CaGemmGroup grp) {
     gemm_epilogue(d, half, smem, wave, lane, m0 + wm * 128 + ih * 64, n0 + wn * 64, z, z1, z2);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // staging reads done before it is overwritten
   }
+#ifdef X_STAMPS
+  {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const long long stamp_t3 = __builtin_amdgcn_s_memtime();
+    if (lane == 0 && iter == 0) {
+      long long* o = g_x_stamps + ((size_t)blockIdx.x * 8 + wave) * 8;
+      o[0] = stamp_t1 - stamp_t0;  // prologue: first tile
+      o[1] = stamp_t2 - stamp_t1;  // main loop
+      o[2] = stamp_t3 - stamp_t2;  // epilogue incl. store drain
+      o[3] = stamp_dma;
+      o[4] = stamp_bar;
+      o[5] = nk;
+    }
+  }
+#endif
   }  // live
   if (grp.cnt == nullptr) break;
   __syncthreads();  // every wave is done with the staging area; the next block's index is in LDS
