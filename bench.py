@@ -402,6 +402,9 @@ def main():
     ap.add_argument("--no-also", action="store_true", help="skip the second (24L/1024 = wav2vec2-small) measurement")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for 1-GPU debugging of the N>1 logic)")
     ap.add_argument("--check-replicas", action="store_true", help="after the run, verify every rank holds identical parameters")
+    ap.add_argument("--one-rank-exchange", action="store_true",
+                    help="N=1 diagnostic: run the N>1 exchange path (RCCL group of one rank, per-bucket all-reduce on the "
+                         "communication stream, per-bucket norms and AdamW behind it) at full size; never a reported number")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -418,6 +421,15 @@ def main():
     local_rank = local_rank % max(1, ndev)  # (gloo debugging may put several ranks on one GPU)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    if world == 1 and args.one_rank_exchange:
+        import socket
+
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.environ["CA_DP_FORCE"] = "1"
+        torch.distributed.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                                             device_id=device)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.backend == "nccl":
@@ -460,7 +472,8 @@ def main():
                                    f", SpecAugment {'off' if args.no_specaugment else 'on'}, activation_dropout 0.1, "
                                    "layerdrop 0 (multi-GPU rule), fp32 master + AdamW + clip 1.0"
                                    + (", inputs from host int16 PCM through the device input pipeline" if args.from_host_pcm else "")
-                                   + (f", gradient all-reduce ({args.backend}) on {wire}, per-layer buckets overlapped with backward" if world > 1 else ""),
+                                   + (f", gradient all-reduce ({args.backend}) on {wire}, per-layer buckets overlapped with backward" if world > 1 else "")
+                                   + (f" [DIAGNOSTIC: N>1 exchange path forced over an RCCL group of one rank, {args.grad_wire} wire]" if args.one_rank_exchange and world == 1 else ""),
                        "global_batch": world * B, "frames_per_utt": T, "parallelism": f"dp{world}",
                        "loss": round(loss_val, 3)},
             "roofline": {"bound": "mfma", "kernel": dom["kernel"], "achieved": round(ach, 1),
@@ -502,6 +515,8 @@ def main():
                 print(json.dumps({"replica_param_spread": spread, "loss_rank0": loss_val}), flush=True)
             assert spread == 0.0, f"replicas diverged: {spread}"
         torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+    elif torch.distributed.is_initialized():  # --one-rank-exchange
         torch.distributed.destroy_process_group()
 
 

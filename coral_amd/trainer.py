@@ -47,16 +47,21 @@ class GradSync:
     4.3 GB instead of 8.6 GB per step for XLS-R-2B — for one bf16 rounding of each rank's gradient);
     the fp32 buffer is refilled from the reduced bf16 values."""
 
-    def __init__(self, flat_grad: torch.Tensor, buckets: dict, process_group=None, compress: bool = False):
+    def __init__(self, flat_grad: torch.Tensor, buckets: dict, process_group=None, compress: bool = False,
+                 force: bool = False):
         self.g = flat_grad
         self.buckets = buckets
         self.pg = process_group
         self.world = 1
         if torch.distributed.is_available() and torch.distributed.is_initialized():
             self.world = torch.distributed.get_world_size(process_group)
+        # force (or CA_DP_FORCE=1): run the whole exchange path with a process group of one rank - how the RCCL
+        # plumbing (communication stream, asynchronous handles, per-bucket callbacks) is exercised on a 1-GPU box
+        force = force or os.environ.get("CA_DP_FORCE", "0") == "1"
+        self.active = self.world > 1 or (force and torch.distributed.is_available() and torch.distributed.is_initialized())
         self.on_gpu = flat_grad.is_cuda
-        self.comm_stream = torch.cuda.Stream(device=flat_grad.device) if (self.on_gpu and self.world > 1) else None
-        self.compress = compress and self.world > 1
+        self.comm_stream = torch.cuda.Stream(device=flat_grad.device) if (self.on_gpu and self.active) else None
+        self.compress = compress and self.active
         self.g16 = torch.empty_like(flat_grad, dtype=torch.bfloat16) if self.compress else None
         self._pending = []
         self.launched: list[str] = []
@@ -83,7 +88,7 @@ class GradSync:
     def start(self, name: str, post=None):
         """post(name): run on the communication stream as soon as the bucket's reduced gradients are in
         the fp32 buffer (the trainer computes the bucket's squared norm there, off the critical path)."""
-        if self.world == 1:
+        if not self.active:
             return
         lo, hi = self.buckets[name]
         self.launched.append(name)
@@ -164,7 +169,8 @@ class DataParallelTrainer:
         self.partial = torch.zeros(4096, dtype=torch.float32, device=st.device)
         self.sync = GradSync(st.g32, st.buckets, process_group, compress=compress_grads)
         self.world = self.sync.world
-        self.overlap = overlap and self.world > 1
+        self.dist = self.sync.active  # gradients are exchanged (world > 1, or a forced one-rank group)
+        self.overlap = overlap and self.dist
         if hasattr(engine, "trainable_range"):
             lo, hi = engine.trainable_range()
         else:
@@ -217,17 +223,17 @@ class DataParallelTrainer:
             # Per-bucket norms during the backward pay off where the buckets are being all-reduced anyway (N > 1: the
             # squared norm rides behind each bucket's reduction on the communication stream).  At N = 1 the side-stream
             # kernels only contend with the backward GEMMs for HBM (+20 % on the weight-gradient kernel for 0.2 ms).
-            if last and self.overlap_optimizer and self.world > 1 and self.overlap:
+            if last and self.overlap_optimizer and self.dist and self.overlap:
                 hook = self._bucket_ready
                 self._norms_ready = True
-            elif self.world > 1 and last and self.overlap:
+            elif self.dist and last and self.overlap:
                 hook = self.sync.start
-            elif self.world == 1 and last and self.overlap_optimizer and self.early_fraction > 0:
+            elif not self.dist and last and self.overlap_optimizer and self.early_fraction > 0:
                 self._done, self._early_lo = {}, None
                 hook = self._early_norm
             eng.backward(loss_scale=1.0 / n, overwrite_matrices=(i == 0), bucket_done=hook)
             total = out.loss / n if total is None else total + out.loss / n
-        if self.world > 1 and not self.overlap:
+        if self.dist and not self.overlap:
             self.sync.start_all()
         self.sync.finish()
         self.optimizer_step()
@@ -241,7 +247,7 @@ class DataParallelTrainer:
     def _bucket_ready(self, name: str):
         """Backward hook: all gradients of bucket `name` are enqueued.  N>1: all-reduce it on the
         communication stream, then its squared norm there; N=1: squared norm on the optimiser stream."""
-        if self.world > 1:
+        if self.dist:
             self.sync.start(name, post=self._bucket_sumsq)
             return
         self.opt_stream.wait_stream(torch.cuda.current_stream())
@@ -281,7 +287,7 @@ class DataParallelTrainer:
         lr = cosine_lr(self.opt_step, self.lr, self.warmup_steps, self.max_steps)
         self.opt_step += 1
         if self._norms_ready:  # every bucket's squared norm was produced during the backward
-            if self.world == 1:
+            if not self.dist:
                 torch.cuda.current_stream().wait_stream(self.opt_stream)
             self.gnorm_sq.copy_(self.bucket_sq.sum().reshape(1))
             self._norms_ready = False

@@ -1,0 +1,48 @@
+"""RCCL plumbing on a 1-GPU box (tests/test_dp_gpu.py): one process, backend "nccl" (= RCCL) with a process group of
+ONE rank, the trainer's exchange path forced on (CA_DP_FORCE=1).  A sum over one rank is the identity, so the run must
+reproduce the plain single-process trainer: bit for bit on the fp32 wire, to bf16 rounding on the bf16 wire.  What this
+covers that the two-rank gloo test cannot: RCCL initialisation and its asynchronous handles on the communication stream,
+with the per-bucket callbacks and the per-bucket AdamW behind them."""
+import os
+import sys
+from pathlib import Path
+
+import torch
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+
+
+def run(forced, wire, steps):
+    import dp_worker
+
+    from coral_amd.trainer import DataParallelTrainer
+
+    os.environ["CA_DP_FORCE"] = "1" if forced else "0"
+    eng, shard = dp_worker.build_case()
+    tr = DataParallelTrainer(eng, learning_rate=1e-3, warmup_steps=0, max_steps=100, max_grad_norm=1.0,
+                             compress_grads=(wire == "bf16"))
+    assert tr.dist == forced and tr.overlap == forced and tr.world == 1
+    mb = shard([0, 1, 2, 3])
+    losses, norms = [], []
+    for _ in range(steps):
+        losses.append(float(tr.train_step([mb])))
+        norms.append(tr.grad_norm())
+    tr.finish()
+    torch.cuda.synchronize()
+    return dict(losses=losses, norms=norms, p32=eng.store.p32.cpu(), launched=list(tr.sync.buckets))
+
+
+def main():
+    out, steps = Path(sys.argv[1]), int(sys.argv[2])
+    torch.cuda.set_device(0)
+    torch.distributed.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{sys.argv[3]}", rank=0, world_size=1,
+                                         device_id=torch.device("cuda:0"))
+    res = {"plain": run(False, "fp32", steps), "fp32": run(True, "fp32", steps), "bf16": run(True, "bf16", steps)}
+    torch.save(res, out)
+    torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -61,3 +61,27 @@ def test_two_ranks_match_one_rank_accumulating(tmp_path, wire):
     close = float((d <= 0.05 * lr).float().mean())
     assert close >= (0.995 if wire == "fp32" else 0.9), close
     assert float((r0["p32"] - p32).norm() / (2 ** 0.5 * lr * p32.numel() ** 0.5)) <= (0.02 if wire == "fp32" else 0.2)
+
+
+def test_rccl_one_rank_group_reproduces_the_plain_trainer(tmp_path):
+    """backend "nccl" (RCCL) with one rank and the exchange path forced on: see tests/rccl_one_rank_worker.py."""
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    out = tmp_path / "one_rank.pt"
+    r = subprocess.run([sys.executable, str(ROOT / "tests" / "rccl_one_rank_worker.py"), str(out), "2", str(port)],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    res = torch.load(out)
+    plain, f32, b16 = res["plain"], res["fp32"], res["bf16"]
+    # fp32 wire: the identity exchange changes nothing, bit for bit
+    assert torch.equal(plain["p32"], f32["p32"]) and plain["losses"] == f32["losses"]
+    assert all(abs(a - b) <= 1e-6 * a for a, b in zip(plain["norms"], f32["norms"]))  # (norm: per-bucket sums vs one pass)
+    # bf16 wire: one rounding of the gradients to 8 bits
+    lr = 1e-3
+    assert plain["losses"][0] == b16["losses"][0]
+    assert abs(plain["norms"][0] - b16["norms"][0]) <= 2e-3 * plain["norms"][0]
+    d = (plain["p32"] - b16["p32"]).abs()
+    assert float(d.max()) <= 4 * lr and float((d <= 0.05 * lr).float().mean()) >= 0.9
