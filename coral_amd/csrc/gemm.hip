@@ -382,17 +382,29 @@ static inline unsigned tile_grid(int ntm, int ntn) {
 // then walks it 4 rows x 64 columns at a time in a rolled loop so the generic (runtime-selected)
 // epilogue is emitted once and every row is stored as one contiguous 128-B (bf16) / 256-B (fp32)
 // segment.  mw/nw: global row/column of the wave's tile origin.
+// the 8 bias values of a lane's columns (nw: the wave tile's first column); requested early by the kernels that can
+// spare the registers, so that the memory round trip is over when the epilogue starts
+__device__ __forceinline__ void epi_load_bias(const CaGemmDesc& d, int lane, int nw, int z1, int z2, float (&bias8)[8]) {
+  const int nb = nw + 8 * (lane & 7);
+  const int nvalid = (d.N - nb) < 8 ? (d.N - nb) : 8;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
+  if (d.bias && nvalid > 0) {
+    const float* bz = d.bias + z1 * d.sBias1 + z2 * d.sBias2 + nb;
+    if (nvalid == 8 && (((uintptr_t)bz) & 15) == 0) {
+      const f32x4_t b0 = *(const f32x4_t*)bz, b1 = *(const f32x4_t*)(bz + 4);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bias8[e] = e < 4 ? b0[e] : b1[e - 4];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (e < nvalid) bias8[e] = bz[e];
+    }
+  }
+}
 __device__ __forceinline__ void gemm_epilogue(const CaGemmDesc& d, f32x4_t (&acc)[4][4], char* smem,
                                               int wave, int lane, int mw, int nw, int z, int z1,
-                                              int z2) {
-  float* wt = (float*)smem + wave * (64 * EPI_PITCH);
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      *(f32x4_t*)(wt + (i * 16 + (lane & 15)) * EPI_PITCH + j * 16 + 4 * (lane >> 4)) = acc[i][j];
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private region: no barrier
-
+                                              int z2, const float (*bias_pre)[8] = nullptr) {
   // lane -> 8 consecutive columns of one row; 8 rows per pass, 8 passes; 16-byte bf16 stores
   const int M = d.M, N = d.N;
   const int64_t zoffC = z1 * d.sC1 + z2 * d.sC2;
@@ -401,22 +413,43 @@ __device__ __forceinline__ void gemm_epilogue(const CaGemmDesc& d, f32x4_t (&acc
   const float keep_scale = d.dropout_p > 0.f ? 1.f / (1.f - d.dropout_p) : 1.f;
   const int nb = nw + 8 * (lane & 7);
   const int nvalid = (N - nb) < 8 ? (N - nb) : 8;
-  if (nvalid <= 0) return;
   const bool full = nvalid == 8 && vec_ok;
-  float bias8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  if (d.bias) {
-    const float* bz = d.bias + z1 * d.sBias1 + z2 * d.sBias2;
-#pragma unroll
-    for (int e = 0; e < 8; ++e)
-      if (e < nvalid) bias8[e] = bz[nb + e];
-  }
   const int epi = d.epilogue;
   const bool has_gelu = epi == CA_EPI_GELU || epi == CA_EPI_GELU_RESIDUAL;
   const bool needs_r = epi == CA_EPI_RESIDUAL || epi == CA_EPI_DGELU || epi == CA_EPI_GELU_RESIDUAL;
+  // Everything the epilogue reads from global memory is requested BEFORE the accumulators go through LDS, and the R
+  // row of pass it + 1 before pass it is computed: requested where they were used, the bias (8 dword loads per lane)
+  // and each pass's R row put one exposed memory round trip each in front of the stores (+11 us for the bias and
+  // +5..10 us for R on a 120-us launch at [3992 x 7680 x 1920]).
+  float bias8[8];
+  if (bias_pre) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bias8[e] = (*bias_pre)[e];
+  } else {
+    epi_load_bias(d, lane, nw, z1, z2, bias8);
+  }
+  const unsigned short* Rbase = (const unsigned short*)d.R + zoffR + nb;
+  auto load_r = [&](int it, u16x8_t& u) {  // R row of pass `it` (fast form only; ragged columns load in the pass)
+    const int m = mw + it * 8 + (lane >> 3);
+    if (needs_r && full && it < 8 && m < M) u = *(const u16x8_t*)(Rbase + (int64_t)m * d.ldr);
+  };
+  u16x8_t r_next = {0, 0, 0, 0, 0, 0, 0, 0};
+  load_r(0, r_next);
+
+  float* wt = (float*)smem + wave * (64 * EPI_PITCH);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      *(f32x4_t*)(wt + (i * 16 + (lane & 15)) * EPI_PITCH + j * 16 + 4 * (lane >> 4)) = acc[i][j];
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private region: no barrier
+  if (nvalid <= 0) return;
 #pragma unroll 1
   for (int it = 0; it < 8; ++it) {
     const int ml = it * 8 + (lane >> 3);
     const int m = mw + ml;
+    const u16x8_t r_cur = r_next;
+    load_r(it + 1, r_next);
     if (m >= M) continue;
     const f32x4_t a4 = *(const f32x4_t*)(wt + ml * EPI_PITCH + 8 * (lane & 7));
     const f32x4_t b4 = *(const f32x4_t*)(wt + ml * EPI_PITCH + 8 * (lane & 7) + 4);
@@ -429,12 +462,11 @@ __device__ __forceinline__ void gemm_epilogue(const CaGemmDesc& d, f32x4_t (&acc
     }
     const int64_t coff = zoffC + (int64_t)m * d.ldc + nb;
     if (needs_r) {
-      const unsigned short* R = (const unsigned short*)d.R + zoffR + (int64_t)m * d.ldr + nb;
       if (full) {
-        const u16x8_t u = *(const u16x8_t*)R;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) r[e] = bf2f(u[e]);
+        for (int e = 0; e < 8; ++e) r[e] = bf2f(r_cur[e]);
       } else {
+        const unsigned short* R = Rbase + (int64_t)m * d.ldr;
 #pragma unroll
         for (int e = 0; e < 8; ++e)
           if (e < nvalid) r[e] = bf2f(R[e]);
@@ -783,6 +815,9 @@ __global__ __launch_bounds__(512) void ca_gemm_kernel_x(const CaGemmGroup grp) {
   for (int i = 0; i < 8; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  float xbias[8];  // the lane's bias values, requested a whole main loop ahead of the epilogue (the segmented-K
+                   // instantiations - convolution weight gradients, no bias - have no registers to spare for it)
+  if constexpr (!KS) epi_load_bias(d, lane, n0 + wn * 64, z1, z2, xbias);
 #ifdef X_STAMPS
   long long stamp_dma = 0, stamp_bar = 0;
 #endif
@@ -1075,7 +1110,7 @@ __global__ __launch_bounds__(512) void ca_gemm_kernel_x(const CaGemmGroup grp) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) half[i][j] = acc[ih * 4 + i][j];
-    gemm_epilogue(d, half, smem, wave, lane, m0 + wm * 128 + ih * 64, n0 + wn * 64, z, z1, z2);
+    gemm_epilogue(d, half, smem, wave, lane, m0 + wm * 128 + ih * 64, n0 + wn * 64, z, z1, z2, KS ? nullptr : &xbias);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // staging reads done before it is overwritten
   }
 #ifdef X_STAMPS
@@ -1154,6 +1189,8 @@ __global__ __launch_bounds__(512) void ca_gemm_kernel_l(const CaGemmDesc d) {
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  float lbias[8];  // the lane's bias values, requested a whole main loop ahead of the epilogue
+  epi_load_bias(d, lane, n0 + wn * 64, z1, z2, lbias);
 
   // LDS: A0 | A1 | A2 (32 KiB each) | B0 | B1 | B2 (16 KiB each)
   int bst = 0;  // stage of this wave's next burst (every wave issues its share of every tile, in order)
@@ -1327,7 +1364,7 @@ __global__ __launch_bounds__(512) void ca_gemm_kernel_l(const CaGemmDesc d) {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
-  gemm_epilogue(d, acc, smem, wave, lane, m0 + wm * 64, n0 + wn * 64, z, z1, z2);
+  gemm_epilogue(d, acc, smem, wave, lane, m0 + wm * 64, n0 + wn * 64, z, z1, z2, &lbias);
 }
 
 // ---- skinny-M kernel: M <= 16 rows (one decoded token per clip) -------------------------------------
