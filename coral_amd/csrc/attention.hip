@@ -150,10 +150,15 @@ __device__ __forceinline__ void tie(bf16x8_t& f) { asm volatile("" : "+v"(f)); }
 __device__ __forceinline__ const char* uniform_ptr(const void* p) {  // a wave-uniform pointer the compiler cannot prove uniform
   const uint64_t v = (uint64_t)(uintptr_t)p;
   const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
-  return (const char*)(uintptr_t)(((uint64_t)hi << 32) | lo);
+  // SGPRs written by a VALU instruction (v_readfirstlane) need five wait states before a VMEM instruction reads them,
+  // and the LDS-DMA below is inline asm the hazard recogniser does not see: pass the pair through a scalar move, whose
+  // result carries no such hazard
+  uint64_t r;
+  asm volatile("s_mov_b64 %0, %1" : "=s"(r) : "s"(((uint64_t)hi << 32) | lo));
+  return (const char*)(uintptr_t)r;
 }
 __device__ __forceinline__ void glds16_sb(const char* base, uint32_t off, uint32_t lds_piece) {
-  asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(off), "s"(base), "s"(lds_piece) : "memory", "m0");
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(off), "s"(base), "s"(lds_piece) : "memory", "m0");
 }
 template <int ROWS, int HDPV, int NW = 4>
 struct KImgFast {
@@ -715,7 +720,7 @@ __device__ __forceinline__ bf16x8_t gload16_async(const void* p) {
   return v;
 }
 __device__ __forceinline__ void glds16_async(const void* g, char* lds_wave_base) {
-  asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off"
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
                :
                : "v"(g), "s"((uint32_t)(uintptr_t)(lptr_t)lds_wave_base)
                : "memory", "m0");

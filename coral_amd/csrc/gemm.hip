@@ -31,8 +31,12 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 // LDS-DMA, 16 B per lane from a per-lane address to the wave's 1-KiB LDS piece.  Inline asm like the scalar-base
 // form below, so that M0 is only ever written inside these statements (the compiler does not track M0 across them).
+// The hazard recogniser does not look inside an asm string, so the wait state between the SALU write of M0 and the
+// LDS-DMA that reads it is written out (hipcc pads its own LDS-DMA the same way).  The scalar-base form's other
+// hazard - a VMEM instruction reading SGPRs that a VALU instruction (v_readfirstlane) wrote needs five states - does
+// not arise here: every base below is the result of scalar arithmetic on kernel arguments and tile indices.
 __device__ __forceinline__ void glds16(const void* g, char* lds_wave_base) {
-  asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off"
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
                :
                : "v"(g), "s"((uint32_t)(uintptr_t)(lptr_t)lds_wave_base)
                : "memory", "m0");
@@ -122,7 +126,7 @@ struct MNMajorLoader {
 // LDS-DMA with the scalar-base addressing form: 16 B per lane from base + off (off: 32-bit, zero-extended) to the
 // wave's 1-KiB LDS piece at byte address lds_piece (wave-uniform, goes through M0)
 __device__ __forceinline__ void glds16_sbase(const char* base, uint32_t off, uint32_t lds_piece) {
-  asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1"
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
                :
                : "v"(off), "s"(base), "s"(lds_piece)
                : "memory", "m0");

@@ -20,14 +20,14 @@ __global__ __launch_bounds__(512) void ingest_kernel(const char* __restrict__ sr
   size_t off = 0;
   const long long t0 = __builtin_amdgcn_s_memtime();
   for (int i = 0; i < NINF; ++i) {  // fill the pipeline
-    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(base + off), "s"(l0 + i * 1024) : "memory", "m0");
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(base + off), "s"(l0 + i * 1024) : "memory", "m0");
     off = (off + 8192) % span;
   }
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int i = 0; i < NINF; ++i) {
       asm volatile("s_waitcnt vmcnt(%0)" : : "n"(NINF - 1) : "memory");
-      asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(base + off), "s"(l0 + i * 1024) : "memory", "m0");
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(base + off), "s"(l0 + i * 1024) : "memory", "m0");
       off = (off + 8192) % span;
     }
   }
