@@ -337,6 +337,33 @@ def run_w2v2(model_key, args, world, rank, device, roofline: bool):
     res = dict(engine=eng, shape=shape, B=B, T=T, loss=float(loss), ms_per_step=dt / args.steps * 1e3,
                value=round(float(secs.item()) * args.steps / dt, 2),
                step_tflop=3.0 * fwd_gflop_per_utt(shape, T, Ts) * B / 1e3)
+    if world == 1 and roofline:
+        # BASELINE.json words its metric "fwd+bwd"; `value` above is the whole finetune step (clip + AdamW included, the
+        # conservative reading).  The same steps without the optimiser, reported beside it, never instead of it.
+        trainer.finish()
+        torch.cuda.synchronize()
+        eng.weights_ready = None
+
+        def fwd_bwd(i):
+            mb = make_step_batch()[0]
+            eng.step_seed = 100000 + i
+            trainer.model.train()
+            trainer.model(**mb)
+            eng.zero_grad(matrices=eng.freeze_base)
+            eng.backward(loss_scale=1.0, overwrite_matrices=True, bucket_done=None)
+
+        for i in range(2):
+            fwd_bwd(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            fwd_bwd(2 + i)
+        torch.cuda.synchronize()
+        fb = (time.perf_counter() - t0) / args.steps
+        res["fwd_bwd"] = {"ms_per_step": round(fb * 1e3, 3), "value": round(float(lens.sum()) / 16000.0 / fb, 2),
+                          "unit": "audio-seconds/sec",
+                          "note": "forward + backward only (BASELINE.json's wording of the metric); `value` is the whole "
+                                  "step with gradient-norm clip and AdamW"}
     if roofline:
         # Per-kernel durations are only meaningful with the kernels serialised: the timed steps above run the weight
         # gradients on their own stream beside the data-gradient chain (wav2vec2.py backward) and the HBM-bound AdamW
@@ -475,7 +502,10 @@ def main():
                                    + (f", gradient all-reduce ({args.backend}) on {wire}, per-layer buckets overlapped with backward" if world > 1 else "")
                                    + (f" [DIAGNOSTIC: N>1 exchange path forced over an RCCL group of one rank, {args.grad_wire} wire]" if args.one_rank_exchange and world == 1 else ""),
                        "global_batch": world * B, "frames_per_utt": T, "parallelism": f"dp{world}",
-                       "loss": round(loss_val, 3)},
+                       "loss": round(loss_val, 3),
+                       **({"fwd_bwd": dict(res["fwd_bwd"], frac_of_peak=round(
+                           res["step_tflop"] / (res["fwd_bwd"]["ms_per_step"] * 1e-3) / MFMA_BF16_DENSE_PEAK_TFLOPS, 4))}
+                          if "fwd_bwd" in res else {})},
             "roofline": {"bound": "mfma", "kernel": dom["kernel"], "achieved": round(ach, 1),
                          "timing": "hipEvents around every launch of two extra steps run with all kernels on one stream "
                                    "(the timed steps overlap the optimiser and the weight gradients on side streams)",

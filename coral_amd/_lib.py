@@ -69,6 +69,7 @@ class CaGemmDesc(C.Structure):
         ("a_scale", C.c_void_p),
         ("b_scale", C.c_void_p),
         ("a_row_scale", C.c_void_p),
+        ("c_sumsq", C.c_void_p),
     ]
 
 
@@ -155,6 +156,8 @@ SIGNATURES = {
     "ca_conv_weight_reorder": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
     "ca_conv_weight_grad_reorder": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
     "ca_sumsq_f32": (C.c_int, [_vp, _i64, _vp, _i32, _vp, _vp]),
+    "ca_sumsq_ranges_f32": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _vp, _vp]),
+    "ca_sum_f32": (C.c_int, [_vp, _i64, _vp, _i32, _vp, _vp]),
     "ca_adamw_step": (
         C.c_int,
         [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i32, _f32, _f32, _vp, _vp],

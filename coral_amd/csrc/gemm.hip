@@ -447,14 +447,15 @@ __device__ __forceinline__ void gemm_epilogue(const CaGemmDesc& d, f32x4_t (&acc
     for (int j = 0; j < 4; ++j)
       *(f32x4_t*)(wt + (i * 16 + (lane & 15)) * EPI_PITCH + j * 16 + 4 * (lane >> 4)) = acc[i][j];
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private region: no barrier
-  if (nvalid <= 0) return;
+  if (nvalid <= 0 && d.c_sumsq == nullptr) return;
+  float ssq = 0.f;  // sum of squares of the fp32 values this lane stores (c_sumsq)
 #pragma unroll 1
   for (int it = 0; it < 8; ++it) {
     const int ml = it * 8 + (lane >> 3);
     const int m = mw + ml;
     const u16x8_t r_cur = r_next;
     load_r(it + 1, r_next);
-    if (m >= M) continue;
+    if (m >= M || nvalid <= 0) continue;
     const f32x4_t a4 = *(const f32x4_t*)(wt + ml * EPI_PITCH + 8 * (lane & 7));
     const f32x4_t b4 = *(const f32x4_t*)(wt + ml * EPI_PITCH + 8 * (lane & 7) + 4);
     float v[8], v2[8], r[8];
@@ -521,10 +522,16 @@ __device__ __forceinline__ void gemm_epilogue(const CaGemmDesc& d, f32x4_t (&acc
         }
         *(f32x4_t*)C = (f32x4_t){v[0], v[1], v[2], v[3]};
         *(f32x4_t*)(C + 4) = (f32x4_t){v[4], v[5], v[6], v[7]};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ssq = fmaf(v[e], v[e], ssq);
       } else {
 #pragma unroll
         for (int e = 0; e < 8; ++e)
-          if (e < nvalid) C[e] = d.accumulate ? C[e] + v[e] : v[e];
+          if (e < nvalid) {
+            const float t = d.accumulate ? C[e] + v[e] : v[e];
+            C[e] = t;
+            ssq = fmaf(t, t, ssq);
+          }
       }
     } else if (d.C) {
       unsigned short* C = (unsigned short*)d.C + coff;
@@ -557,6 +564,12 @@ __device__ __forceinline__ void gemm_epilogue(const CaGemmDesc& d, f32x4_t (&acc
           if (e < nvalid) C2[e] = f2bf(v2[e]);
       }
     }
+  }
+  if (d.c_sumsq != nullptr) {
+    // (every lane of the wave arrives here: fixed butterfly order, the same bits on every run)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ssq += __shfl_xor(ssq, o, 64);
+    if (lane == 0 && mw < M && nw < N) d.c_sumsq[(int64_t)(mw >> 6) * ((N + 63) >> 6) + (nw >> 6)] = ssq;
   }
 }
 
@@ -1908,6 +1921,7 @@ extern "C" int ca_gemm_bf16_group(const CaGemmDesc* descs, int32_t count, void* 
                  "ca_gemm_bf16_group: alignment");
     CA_CHECK_ARG(p->a_layout == descs->a_layout && p->b_layout == descs->b_layout,
                  "ca_gemm_bf16_group: the problems differ in operand form");
+    CA_CHECK_ARG(p->c_sumsq == nullptr || p->out_f32, "ca_gemm_bf16_group: c_sumsq needs an fp32 output");
     g.d[i] = *p;
     g.first[i] = total;
     total += ((p->M + XBM - 1) / XBM) * ((p->N + XBN - 1) / XBN);
@@ -1976,6 +1990,9 @@ static int ca_gemm_launch(const CaGemmDesc* desc, void* stream) {
   if (d.a_colsum)
     CA_CHECK_ARG(d.a_layout == CA_MNMAJOR && d.b_layout == CA_MNMAJOR && d.batch1 == 1 && d.batch2 == 1 && d.a_kseg == 0,
                  "ca_gemm_bf16: a_colsum needs the un-batched weight-gradient form");
+  if (d.c_sumsq)
+    CA_CHECK_ARG(d.out_f32 && d.batch1 == 1 && d.batch2 == 1 && d.c_row_index == nullptr && d.c_split_n == 0,
+                 "ca_gemm_bf16: c_sumsq needs an un-batched fp32 output");
 
   hipStream_t s = (hipStream_t)stream;
   const int lay = (d.a_layout ? 2 : 0) + (d.b_layout ? 1 : 0);

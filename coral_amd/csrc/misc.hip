@@ -396,6 +396,64 @@ extern "C" int ca_sumsq_f32(const float* g, int64_t n, float* out, int32_t accum
   return CA_OK;
 }
 
+// out[0] (+)= sum over the listed chunks of g of g^2.  chunks: device array of (offset, length) pairs in floats
+// (offsets multiples of 4, lengths any); one block per chunk and pass, partial[chunk] holds its sum.  The trainer lists
+// everything of the flat gradient buffer that is NOT a transformer weight matrix this way (those arrive as per-tile
+// partials from the weight-gradient GEMMs, CaGemmDesc.c_sumsq).
+__global__ __launch_bounds__(256) void sumsq_chunks_kernel(const float* __restrict__ g, const int64_t* __restrict__ chunks,
+                                                           int nchunks, float* __restrict__ partial) {
+  __shared__ float red[4];
+  for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    const float* x = g + chunks[2 * c];
+    const int64_t n = chunks[2 * c + 1];
+    const int64_t n4 = n >> 2;
+    float a = 0.f;
+    for (int64_t i = threadIdx.x; i < n4; i += 256) {
+      const f32x4_t v = *(const f32x4_t*)(x + i * 4);
+      a += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+    if (threadIdx.x < (n & 3)) {
+      const float v = x[(n4 << 2) + threadIdx.x];
+      a += v * v;
+    }
+    a = wave_sum(a);
+    __syncthreads();  // (red is reused by the next chunk)
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[c] = red[0] + red[1] + red[2] + red[3];
+  }
+}
+extern "C" int ca_sumsq_ranges_f32(const float* g, const int64_t* chunks, int32_t nchunks, float* out,
+                                   int32_t accumulate, float* partial, void* stream) {
+  CA_CHECK_ARG(g && chunks && out && partial && nchunks > 0, "ca_sumsq_ranges_f32: bad argument");
+  CA_CHECK_ARG(((uintptr_t)g % 16) == 0, "ca_sumsq_ranges_f32: g must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = nchunks < 2048 ? nchunks : 2048;
+  hipLaunchKernelGGL(sumsq_chunks_kernel, dim3(grid), dim3(256), 0, s, g, chunks, nchunks, partial);
+  hipLaunchKernelGGL(sumsq_finish_kernel, dim3(1), dim3(256), 0, s, partial, nchunks, out, accumulate);
+  CA_CHECK_LAUNCH("ca_sumsq_ranges_f32");
+  return CA_OK;
+}
+// out[0] (+)= sum x[i] (fixed order: the per-tile partials of CaGemmDesc.c_sumsq)
+__global__ __launch_bounds__(256) void sum_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ partial) {
+  __shared__ float red[4];
+  float a = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) a += x[i];
+  a = wave_sum(a);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+extern "C" int ca_sum_f32(const float* x, int64_t n, float* out, int32_t accumulate, float* partial, void* stream) {
+  CA_CHECK_ARG(x && out && partial && n > 0, "ca_sum_f32: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = (int)((n + 255) / 256 < 256 ? (n + 255) / 256 : 256);
+  hipLaunchKernelGGL(sum_kernel, dim3(grid), dim3(256), 0, s, x, n, partial);
+  hipLaunchKernelGGL(sumsq_finish_kernel, dim3(1), dim3(256), 0, s, partial, grid, out, accumulate);
+  CA_CHECK_LAUNCH("ca_sum_f32");
+  return CA_OK;
+}
+
 // torch.optim.AdamW (decoupled decay) with the clip coefficient of clip_grad_norm_ folded in.
 template <bool NT>
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ m,

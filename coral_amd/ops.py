@@ -43,8 +43,11 @@ def _gemm_desc(A, B, Cout, *, M, N, K, lda, ldb, ldc, a_layout=KMAJOR, b_layout=
          epilogue=EPI_NONE, out_f32=None, accumulate=False, alpha=1.0, batch1=1, batch2=1,
          sA=(0, 0), sB=(0, 0), sC=(0, 0), sR=(0, 0), sBias=(0, 0), a_kseg=0, a_kseg_stride=0, b_kseg=0,
          b_kseg_stride=0, dropout_p=0.0, dropout_seed=0, a_colsum=None, a_colsum_off=0,
-         a_colsum_ld=0, c_row_index=None, c_row_mul=0, c_split_n=0, C_hi=None, c_hi_off=0, ldc_hi=0):
+         a_colsum_ld=0, c_row_index=None, c_row_mul=0, c_split_n=0, C_hi=None, c_hi_off=0, ldc_hi=0,
+         c_sumsq=None, c_sumsq_off=0):
     d = CaGemmDesc()
+    if c_sumsq is not None:
+        d.c_sumsq = _p(c_sumsq, c_sumsq_off)
     if c_split_n:
         d.c_split_n, d.C_hi, d.ldc_hi = c_split_n, _p(C_hi, c_hi_off), ldc_hi
     if c_row_index is not None:
@@ -119,20 +122,29 @@ def _wgrad_splits(M, N, K):
     return 1
 
 
+def sumsq_slots(M, N):
+    """Per-tile partials CaGemmDesc.c_sumsq writes for an [M, N] fp32 output."""
+    return ((M + 63) // 64) * ((N + 63) // 64)
+
+
 def wgrad_gemm(dY, X, G, *, M, N, K, lda, ldb, c_off, accumulate, a_off=0, b_off=0, bias_off=None, part=None,
-               cs=None):
+               cs=None, sq=None):
     """Weight gradient G[c_off : c_off + M*N] (+)= dY^T X  (dY [K, M] and X [K, N] token-major bf16, G fp32
     row-major [M, N]).  Bias gradient (dY.sum(0)): either `bias_off` (+ `part` workspace) for a separate column-sum
     pass into G[bias_off:], or `cs = (ws, off, ld)` to take partial column sums from the 256x256 kernel's A stream
     (CaGemmDesc.a_colsum; the caller adds the COLSUM_PARTS rows).
     Shapes that would leave most of the chip idle (fewer 128x128 tiles than half the workgroup slots) are split
     along K: the slices run as one batched GEMM into an fp32 workspace and a deterministic second pass adds them
-    up (no atomics: the result does not depend on scheduling)."""
+    up (no atomics: the result does not depend on scheduling).
+    sq = (slots, off): the squared norm of the result as sumsq_slots(M, N) partials at slots[off:] (from the GEMM's
+    epilogue; on the split-K path the whole sum lands in slots[off] and the matrix's other slots keep their zeros)."""
     splits = 1 if cs is not None else _wgrad_splits(M, N, K)
     if bias_off is not None:
         colsum(dY, lda, K, M, G, part, x_off=a_off, out_off=bias_off)
     if splits == 1:
         kw = dict(a_colsum=cs[0], a_colsum_off=cs[1], a_colsum_ld=cs[2]) if cs is not None else {}
+        if sq is not None:
+            kw.update(c_sumsq=sq[0], c_sumsq_off=sq[1])
         gemm(dY, X, G, M=M, N=N, K=K, a_layout=MNMAJOR, lda=lda, b_layout=MNMAJOR, ldb=ldb, ldc=N, c_off=c_off,
              a_off=a_off, b_off=b_off, out_f32=True, accumulate=accumulate, **kw)
         return
@@ -144,6 +156,8 @@ def wgrad_gemm(dY, X, G, *, M, N, K, lda, ldb, c_off, accumulate, a_off=0, b_off
     gemm(dY, X, ws, M=M, N=N, K=Kc, a_layout=MNMAJOR, lda=lda, b_layout=MNMAJOR, ldb=ldb, ldc=N, a_off=a_off,
          b_off=b_off, out_f32=True, batch2=splits, sA=(0, Kc * lda), sB=(0, Kc * ldb), sC=(0, M * N))
     reduce_rows(ws, splits, M * N, M * N, G[c_off:], accumulate=accumulate)
+    if sq is not None:
+        sumsq(G[c_off:], M * N, sq[0][sq[1]:], ws)  # (ws: free again, >= 4096 floats)
 
 
 def _xtiles(p):
@@ -201,7 +215,7 @@ def wgrad_gemm_group(problems: list, G, colsum_ws=None, colsum_ld=0) -> bool:
         return dict(cs=(colsum_ws, p["cs_off"], colsum_ld)) if fused else dict(bias_off=p.get("bias_off"), part=p.get("part"))
 
     def base(p):
-        return {k: p[k] for k in ("M", "N", "K", "lda", "ldb", "c_off", "accumulate")}
+        return {k: p[k] for k in ("M", "N", "K", "lda", "ldb", "c_off", "accumulate", "sq") if k in p}
 
     for p in solo + fallback:
         wgrad_gemm(p["dY"], p["X"], G, **base(p), **bias_kw(p))
@@ -211,6 +225,8 @@ def wgrad_gemm_group(problems: list, G, colsum_ws=None, colsum_ld=0) -> bool:
             if not fused and p.get("bias_off") is not None:
                 colsum(p["dY"], p["lda"], p["K"], p["M"], G, p["part"], out_off=p["bias_off"])
             kw = dict(a_colsum=colsum_ws, a_colsum_off=p["cs_off"], a_colsum_ld=colsum_ld) if fused else {}
+            if p.get("sq") is not None:
+                kw.update(c_sumsq=p["sq"][0], c_sumsq_off=p["sq"][1])
             arr[i] = _gemm_desc(p["dY"], p["X"], G, M=p["M"], N=p["N"], K=p["K"], a_layout=MNMAJOR, lda=p["lda"],
                                 b_layout=MNMAJOR, ldb=p["ldb"], ldc=p["N"], c_off=p["c_off"], out_f32=True,
                                 accumulate=p["accumulate"], **kw)
@@ -396,6 +412,16 @@ def conv_weight_grad_reorder(dwr, dw, Co, Ci, k, dw_off=0):
 def sumsq(g, n, out, partial, accumulate=False):
     check(lib().ca_sumsq_f32(_p(g), n, _p(out), int(accumulate), _p(partial), _stream()),
           "ca_sumsq_f32")
+
+
+def sumsq_ranges(g, chunks, nchunks, out, partial, accumulate=False):
+    """out[0] (+)= sum of g^2 over `chunks` (device int64 [nchunks, 2]: offset, length in floats)."""
+    check(lib().ca_sumsq_ranges_f32(_p(g), _p(chunks), nchunks, _p(out), int(accumulate), _p(partial), _stream()),
+          "ca_sumsq_ranges_f32")
+
+
+def sum_f32(x, n, out, partial, accumulate=False):
+    check(lib().ca_sum_f32(_p(x), n, _p(out), int(accumulate), _p(partial), _stream()), "ca_sum_f32")
 
 
 def adamw_step(p, m, v, g, p16, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0,

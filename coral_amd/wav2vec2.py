@@ -258,6 +258,44 @@ class Wav2Vec2CTCEngine:
         if ev is not None:
             torch.cuda.current_stream().wait_event(ev)
 
+    # the four weight matrices of an encoder layer: (first parameter name, rows, columns)
+    def _layer_matrices(self, l: int):
+        d, f = self.s.hidden_size, self.s.intermediate_size
+        pl = f"wav2vec2.encoder.layers.{l}."
+        return [("qkv", pl + "attention.q_proj.weight", 3 * d, d), ("o", pl + "attention.out_proj.weight", d, d),
+                ("fc1", pl + "feed_forward.intermediate_dense.weight", f, d),
+                ("fc2", pl + "feed_forward.output_dense.weight", d, f)]
+
+    def norm_plan(self):
+        """Squared gradient norm without a pass over the layer weight matrices (>99 % of the buffer): their
+        weight-gradient GEMMs leave per-tile sums of squares in `slots` (CaGemmDesc.c_sumsq; backward() passes the
+        slices), everything else of the flat buffer is listed as chunks for ca_sumsq_ranges_f32.  None when the model
+        is frozen up to the head (the norm then covers the head bucket only)."""
+        if self.freeze_base:
+            return None
+        if getattr(self, "_norm_plan", None) is not None:
+            return self._norm_plan
+        st, L = self.store, self.s.num_hidden_layers
+        off, soff, mats = 0, {}, []
+        for l in range(L):
+            for key, name, M, N in self._layer_matrices(l):
+                soff[(l, key)] = off
+                off += ops.sumsq_slots(M, N)
+                mats.append((st.off(name), M * N))
+        # complement of the matrices inside [0, numel), cut into chunks of <= 64 Ki floats
+        chunks, pos = [], 0
+        for a, n in sorted(mats) + [(st.numel, 0)]:
+            while pos < a:
+                m = min(65536, a - pos)
+                chunks.append((pos, m))
+                pos += m
+            pos = max(pos, a + n)
+        plan = dict(slots=torch.zeros(off, dtype=torch.float32, device=self.device), nslots=off, slot_off=soff,
+                    chunks=torch.tensor(chunks, dtype=torch.int64, device=self.device), nchunks=len(chunks),
+                    partial=torch.zeros(max(4096, len(chunks)), dtype=torch.float32, device=self.device))
+        self._norm_plan = plan
+        return plan
+
     def zero_grad(self, matrices: bool = True):
         """Clear gradients.  matrices=False clears everything except the transformer layers' weight
         matrices (>99 % of the bytes): the next backward(overwrite_matrices=True) writes those
@@ -650,11 +688,20 @@ class Wav2Vec2CTCEngine:
             ev.record(main)
             return ev
 
+        plan = self.norm_plan()
+
+        def sq(l, key):  # where the weight-gradient GEMM of matrix `key` leaves its per-tile sums of squares
+            return (plan["slots"], plan["slot_off"][(l, key)]) if plan is not None else None
+
         for l in reversed(range(L)):
             if not keep[l]:
                 if overwrite_matrices:  # dropped layer: its matrices get no gradient this step
                     lo = o(f"wav2vec2.encoder.layers.{l}.attention.q_proj.weight")
                     g32[lo:st.buckets[f"layer{l}"][1]].zero_()
+                    if plan is not None:
+                        a0 = plan["slot_off"][(l, "qkv")]
+                        a1 = plan["slot_off"][(l + 1, "qkv")] if l + 1 < L else plan["nslots"]
+                        plan["slots"][a0:a1].zero_()
                 done(f"layer{l}")
                 continue
             pl = f"wav2vec2.encoder.layers.{l}."
@@ -670,14 +717,14 @@ class Wav2Vec2CTCEngine:
             # on the 256x256 tiles, see ops.wgrad_gemm)
             wg = [dict(dY=dh, X=w["g"][l], M=d, N=f, K=M, lda=d, ldb=f, part=w["partial_w"],
                        c_off=o(pl + "feed_forward.output_dense.weight"), accumulate=lacc,
-                       bias_off=o(pl + "feed_forward.output_dense.bias"), cs_off=4 * d + f)]
+                       bias_off=o(pl + "feed_forward.output_dense.bias"), cs_off=4 * d + f, sq=sq(l, "fc2"))]
             ops.gemm(dh, p16, du, M=M, N=f, K=d, lda=d, b_layout=MNMAJOR, ldb=f, ldc=f,
                      b_off=o(pl + "feed_forward.output_dense.weight"), epilogue=EPI_DGELU, R=w["u"][l],
                      ldr=f, dropout_p=drop_p, dropout_seed=self.step_seed * 1000 + l)
             # FFN1
             wg.append(dict(dY=du, X=w["x2"][l], M=f, N=d, K=M, lda=f, ldb=d, part=w["partial_w"],
                            c_off=o(pl + "feed_forward.intermediate_dense.weight"), accumulate=lacc,
-                           bias_off=o(pl + "feed_forward.intermediate_dense.bias"), cs_off=4 * d))
+                           bias_off=o(pl + "feed_forward.intermediate_dense.bias"), cs_off=4 * d, sq=sq(l, "fc1")))
             ops.gemm(du, p16, other, M=M, N=d, K=f, lda=f, b_layout=MNMAJOR, ldb=d, ldc=d,
                      b_off=o(pl + "feed_forward.intermediate_dense.weight"))
             # LN2: dh1 = dh + LN'(dx2)
@@ -694,14 +741,14 @@ class Wav2Vec2CTCEngine:
             # out_proj: h1 = h + Wo ctx + bo
             wg.append(dict(dY=dh1, X=w["ctx"][l], M=d, N=d, K=M, lda=d, ldb=d, part=w["partial_w"],
                            c_off=o(pl + "attention.out_proj.weight"), accumulate=lacc,
-                           bias_off=o(pl + "attention.out_proj.bias"), cs_off=3 * d))
+                           bias_off=o(pl + "attention.out_proj.bias"), cs_off=3 * d, sq=sq(l, "o")))
             dctx = other
             ops.gemm(dh1, p16, dctx, M=M, N=d, K=d, lda=d, b_layout=MNMAJOR, ldb=d, ldc=d,
                      b_off=o(pl + "attention.out_proj.weight"))
             self._attention_bwd(w, l, dctx, B, T, Tp, H, hd, d, scale, dqkv)
             wg.append(dict(dY=dqkv, X=w["x1"][l], M=3 * d, N=d, K=M, lda=3 * d, ldb=d, part=w["partial_w"],
                            c_off=o(pl + "attention.q_proj.weight"), accumulate=lacc,
-                           bias_off=o(pl + "attention.q_proj.bias"), cs_off=0))
+                           bias_off=o(pl + "attention.q_proj.bias"), cs_off=0, sq=sq(l, "qkv")))
 
             # the layer's weight gradients (one grouped launch plan: 240 + 240 + 184 + 64 tiles at XLS-R-2B) and the
             # reduction of their fused bias-gradient partials

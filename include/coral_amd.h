@@ -120,6 +120,12 @@ typedef struct CaGemmDesc {
   const float* a_scale;
   const float* b_scale;
   const float* a_row_scale; /* fp8 form only: [M] per-row factors of A (ca_layernorm_fwd_fp8), NULL = none */
+  /* Optional, fp32 output (out_f32 = 1), un-batched: the sum of squares of the values stored to C (after `accumulate`),
+   * one partial per 64 x 64 output block at c_sumsq[(m / 64) * ceil(N / 64) + n / 64] (plain stores, every block of the
+   * output written once per launch: no atomics, the same bits on every run).  The squared norm of a weight gradient
+   * then costs no second pass over it: Trainer's clip_grad_norm_ ($TF/trainer.py:1778-1796) adds the partials of all
+   * matrices (ca_sum_f32) to the squared norm of the small tensors (ca_sumsq_ranges_f32).  NULL = off. */
+  float* c_sumsq;
 } CaGemmDesc;
 
 int ca_gemm_bf16(const CaGemmDesc* desc, void* stream);
@@ -367,6 +373,13 @@ int ca_conv_weight_grad_reorder(const float* dwr, float* dw, int32_t Co, int32_t
  * ---------------------------------------------------------------------------------- */
 int ca_sumsq_f32(const float* g, int64_t n, float* out, int32_t accumulate, float* partial,
                  void* stream);
+/* out[0] (+)= sum of g^2 over the listed chunks: chunks = device array of nchunks (offset, length) pairs in floats,
+ * offsets multiples of 4; partial: >= nchunks floats.  ca_sum_f32: out[0] (+)= sum x[i] in a fixed order (partial: >= 256
+ * floats) - the per-tile partials CaGemmDesc.c_sumsq collects.  Together they are clip_grad_norm_'s squared norm
+ * ($TF/trainer.py:1778-1796) without a pass over the weight-matrix gradients. */
+int ca_sumsq_ranges_f32(const float* g, const int64_t* chunks, int32_t nchunks, float* out, int32_t accumulate,
+                        float* partial, void* stream);
+int ca_sum_f32(const float* x, int64_t n, float* out, int32_t accumulate, float* partial, void* stream);
 int ca_adamw_step(float* p, float* m, float* v, const float* g, void* p16, int64_t n,
                   float lr, float beta1, float beta2, float eps, float weight_decay,
                   int32_t step, float grad_scale, float max_norm, const float* gnorm_sq,

@@ -66,10 +66,57 @@ def test_training_reduces_loss_on_a_fixed_batch():
     assert tr.grad_norm() > 0
 
 
-def test_early_gradient_norm_pass_matches_the_single_pass():
+def test_gradient_norm_from_the_weight_gradient_epilogues_matches_a_pass_over_the_buffer(monkeypatch):
+    """N = 1, whole model trainable: the squared norm assembled from the weight-gradient GEMMs' per-tile sums of squares
+    (CaGemmDesc.c_sumsq) plus one pass over the small tensors equals the norm of the flat gradient buffer, with and
+    without layerdrop in either accumulation micro-batch, and agrees with the pass that reads the buffer again
+    (CA_FUSED_NORM=0) to fp32 summation order.  Reference: clip_grad_norm_ in $TF/trainer.py:1778-1796."""
+    from coral_amd.trainer import DataParallelTrainer
+    from coral_amd.wav2vec2 import Wav2Vec2CTCEngine, Wav2Vec2Shape
+    from oracle import wav2vec2_ref as ref
+
+    kw = dict(hidden_size=256, num_hidden_layers=3, num_attention_heads=4, intermediate_size=328)  # ragged 64-tiles
+    g = torch.Generator().manual_seed(0)
+    waves = [(0.1 * torch.randn(n, generator=g)).numpy() for n in (8000, 6400, 7000, 8000)]
+    iv, am = ref.zero_mean_unit_var_norm(waves)
+    labels = torch.randint(0, 42, (4, 6), generator=g)
+    mb = lambda idx, **kw2: dict(input_values=torch.from_numpy(iv[idx]), attention_mask=torch.from_numpy(am[idx]),  # noqa: E731
+                                 labels=labels[idx], **kw2)
+    out = {}
+    for fused, overlap in (("1", True), ("1", False), ("0", True)):
+        monkeypatch.setenv("CA_FUSED_NORM", fused)
+        eng = Wav2Vec2CTCEngine(Wav2Vec2Shape(**kw), "cuda:0")
+        eng.load_state_dict(ref.synth_params(ref.W2V2Config(**kw)))
+        tr = DataParallelTrainer(eng, learning_rate=1e-3, warmup_steps=1, max_steps=100, max_grad_norm=0.05, grad_accum=2,
+                                 overlap_optimizer=overlap)
+        assert (tr._norm_plan() is not None) == (fused == "1")
+        norms = []
+        for step in range(3):
+            # two accumulation micro-batches; in step 1 the second one drops layer 1, in step 2 the first one does
+            keep = [[True, step != 2, True], [True, step != 1, True]]
+            tr.train_step([mb([0, 1], layer_keep=keep[0]), mb([2, 3], layer_keep=keep[1])])
+            norms.append(tr.grad_norm())
+            if not overlap:  # against the buffer itself (without the overlapped optimiser nothing clears gradients early)
+                torch.cuda.synchronize()
+                direct = float(eng.store.g32.double().pow(2).sum().sqrt())
+                assert abs(norms[-1] - direct) <= 1e-5 * direct, (step, norms[-1], direct)
+        tr.finish()
+        torch.cuda.synchronize()
+        out[(fused, overlap)] = (norms, eng.store.p32.clone())
+    (n1, p1), (n2, p2), (n0, p0) = out[("1", True)], out[("1", False)], out[("0", True)]
+    assert all(a > 0.05 for a in n0), n0  # the clip is active, so the norm matters
+    # across runs only the first two steps are comparable: the two ways of summing differ in the 7th digit, the
+    # parameters after step 1 therefore by ~1e-7, and a handful of bf16 weight copies that flip by one ulp move the third
+    # step's gradients by 1e-3 (each run agrees with its own buffer above, at every step)
+    assert np.allclose(n0[:2], n1[:2], rtol=1e-6) and np.allclose(n0[:2], n2[:2], rtol=1e-6), (n0, n1, n2)
+    assert n1 == n2 and torch.equal(p1, p2)  # the overlapped optimiser changes nothing
+
+
+def test_early_gradient_norm_pass_matches_the_single_pass(monkeypatch):
     """N = 1: the squared gradient norm taken in two pieces (tail of the flat buffer on the side stream during the
     backward, head behind it) gives the same clip factor as one pass: same parameters after the steps up to fp32
-    summation order."""
+    summation order.  (The path engines without a norm plan take: CA_FUSED_NORM=0 here.)"""
+    monkeypatch.setenv("CA_FUSED_NORM", "0")
     from coral_amd.trainer import DataParallelTrainer
     from coral_amd.wav2vec2 import Wav2Vec2CTCEngine, Wav2Vec2Shape
     from oracle import wav2vec2_ref as ref

@@ -656,3 +656,51 @@ def test_gemm_skinny_split_output(ops):
     want = torch.zeros_like(cache)
     want[torch.arange(M, device=DEV), pos.long()] = ref[:, d:]
     assert torch.equal(cache, want)
+
+
+@pytest.mark.parametrize("M,N,K,force", [(7680, 1920, 512, 0), (1920, 1920, 512, 0), (296, 200, 256, 0), (520, 392, 192, 1),
+                                         (520, 392, 192, 2), (1000, 1496, 320, 3)])
+@pytest.mark.parametrize("accumulate", [False, True])
+def test_gemm_sum_of_squares_partials(ops, M, N, K, force, accumulate):
+    """CaGemmDesc.c_sumsq: the weight-gradient form (both operands MN-major, fp32 output) leaves, per 64 x 64 block of
+    the output, the sum of squares of what it stored - every kernel (S / L / X forced), ragged edges, with accumulate."""
+    g = torch.Generator().manual_seed(M + N + K)
+    dY = bf(torch.randn(K, M, generator=g)).to(DEV)
+    X = bf(torch.randn(K, N, generator=g)).to(DEV)
+    G0 = torch.randn(M * N, generator=g).to(DEV)
+    G = G0.clone()
+    nbm, nbn = (M + 63) // 64, (N + 63) // 64
+    slots = torch.full((nbm * nbn + 8,), -1.0, device=DEV)
+    ops.lib().ca_gemm_force_kernel(force)
+    try:
+        ops.gemm(dY, X, G, M=M, N=N, K=K, a_layout=1, lda=M, b_layout=1, ldb=N, ldc=N, out_f32=True, accumulate=accumulate,
+                 c_sumsq=slots, c_sumsq_off=0)
+    finally:
+        ops.lib().ca_gemm_force_kernel(0)
+    torch.cuda.synchronize()
+    want = dY.float().t() @ X.float() + (G0.view(M, N) if accumulate else 0)
+    got = G.view(M, N)
+    assert (got - want).abs().max() <= 2e-3 * want.abs().max()
+    sq = torch.zeros(nbm * 64, nbn * 64, dtype=torch.float64, device=DEV)
+    sq[:M, :N] = got.double() ** 2
+    blocks = sq.view(nbm, 64, nbn, 64).sum(dim=(1, 3)).reshape(-1)
+    assert torch.all(slots[nbm * nbn:] == -1.0)  # nothing written past the last block
+    rel = (slots[:nbm * nbn].double() - blocks).abs() / blocks.clamp_min(1e-30)
+    assert float(rel.max()) <= 1e-5, float(rel.max())
+
+
+def test_sumsq_ranges_and_plain_sum(ops):
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1_000_003, generator=g).to(DEV)
+    chunks = torch.tensor([[0, 65536], [65536, 1234], [200000, 3], [400004, 70001], [999996, 7]], dtype=torch.int64, device=DEV)
+    out = torch.full((1,), 5.0, device=DEV)
+    part = torch.zeros(4096, device=DEV)
+    ops.sumsq_ranges(x, chunks, 5, out, part)
+    want = sum(float(x[a:a + n].double().pow(2).sum()) for a, n in chunks.tolist())
+    assert abs(float(out) - want) <= 1e-5 * want
+    ops.sumsq_ranges(x, chunks, 5, out, part, accumulate=True)
+    assert abs(float(out) - 2 * want) <= 1e-5 * want
+    ops.sum_f32(x, 1_000_003, out, part)
+    assert abs(float(out) - float(x.double().sum())) <= 1e-3 * float(x.double().abs().sum()) ** 0.5 + 1e-2
+    ops.sum_f32(x[:10], 10, out, part, accumulate=True)
+    assert abs(float(out) - float(x.double().sum()) - float(x[:10].double().sum())) <= 0.1
