@@ -337,7 +337,7 @@ def run_w2v2(model_key, args, world, rank, device, roofline: bool):
     res = dict(engine=eng, shape=shape, B=B, T=T, loss=float(loss), ms_per_step=dt / args.steps * 1e3,
                value=round(float(secs.item()) * args.steps / dt, 2),
                step_tflop=3.0 * fwd_gflop_per_utt(shape, T, Ts) * B / 1e3)
-    if world == 1 and roofline:
+    if world == 1 and roofline and not args.no_fwd_bwd:
         # BASELINE.json words its metric "fwd+bwd"; `value` above is the whole finetune step (clip + AdamW included, the
         # conservative reading).  The same steps without the optimiser, reported beside it, never instead of it.
         trainer.finish()
@@ -427,6 +427,7 @@ def main():
                     help="utterance lengths ~ U[1 s, --seconds] padded to --seconds (the regime of "
                          "R/config/asr_finetuning.yaml:31-32): masked attention / CTC lengths / SpecAugment on valid frames")
     ap.add_argument("--no-also", action="store_true", help="skip the second (24L/1024 = wav2vec2-small) measurement")
+    ap.add_argument("--no-fwd-bwd", action="store_true", help="skip the extra forward+backward-only timing (profile runs)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for 1-GPU debugging of the N>1 logic)")
     ap.add_argument("--check-replicas", action="store_true", help="after the run, verify every rank holds identical parameters")
     ap.add_argument("--one-rank-exchange", action="store_true",

@@ -12,7 +12,7 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parents[1]
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 nsteps = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-cmd = sys.argv[3] if len(sys.argv) > 3 else "python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-also"
+cmd = sys.argv[3] if len(sys.argv) > 3 else "python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-also --no-fwd-bwd"
 
 
 def one(pattern):
@@ -67,7 +67,7 @@ if sq:
         agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     names = ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_MFMA", "SQ_WAIT_ANY",
              "SQ_WAIT_INST_ANY", "GRBM_GUI_ACTIVE"]
-    out_lines = ["# rocprofv3 --pmc " + " ".join(names) + " -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-also",
+    out_lines = ["# rocprofv3 --pmc " + " ".join(names) + " -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-also --no-fwd-bwd",
                  "# per-launch averages over the launches of the run; SQ_*_CYCLES of waves are quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES and",
                  "# GRBM_GUI_ACTIVE are cycles summed over the 8 XCDs (MI355X_MICROARCH.md, cycle constants); mfma_busy_frac =",
                  "# SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs) = share of the kernel's cycles its matrix pipes were busy",
