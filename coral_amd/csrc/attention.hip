@@ -1270,15 +1270,27 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   // all HDPV/32 k-steps and HDPV/16 column blocks are computed: dims >= hd are zero in every LDS image
   bf16x8_t qf[NQ][NKS], dof[NQ][NKS];
   float lse2[NQ], dq_row[NQ];
+  const unsigned short* Oh = a.O + b * a.sob + h * hd;
 #pragma unroll
   for (int j = 0; j < NQ; ++j) {
+    // D = rowsum(dO * O) of the lane's query is taken here, from the dO fragments the kernel holds anyway and the
+    // matching O fragments (each lane group has a quarter of the row), and written for the dK/dV kernel, which runs
+    // after this one: no separate pass over dO and O (attn_bwd_prep_kernel serves the 64-query path only)
+    float dsum = 0.f;
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
       qf[j][ks] = load_rowfrag(Q, a.ldq, qrow[j], ks, lane, hd);
       dof[j][ks] = load_rowfrag(dO, a.lddo, qrow[j], ks, lane, hd);
+      const bf16x8_t of = load_rowfrag(Oh, a.ldo, qrow[j], ks, lane, hd);
+      const u16x8_t x = __builtin_bit_cast(u16x8_t, dof[j][ks]), y = __builtin_bit_cast(u16x8_t, of);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dsum = fmaf(bf2f(x[e]), bf2f(y[e]), dsum);
     }
+    dsum += __shfl_xor(dsum, 16, 64);
+    dsum += __shfl_xor(dsum, 32, 64);
+    dq_row[j] = dsum;
+    if (g == 0 && qi[j] < a.Tq) const_cast<float*>(a.Dq)[((int64_t)b * a.H + h) * a.Tqp + qi[j]] = dsum;
     lse2[j] = a.lse[((int64_t)b * a.H + h) * a.Tqp + qrow[j]] * LOG2E;
-    dq_row[j] = a.Dq[((int64_t)b * a.H + h) * a.Tqp + qrow[j]];
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (these loads are younger than the first tiles)
   f32x4_t acc[NQ][NNB];
@@ -1462,26 +1474,21 @@ extern "C" int ca_attn_bwd(const CaAttnDesc* desc, void* stream) {
   CA_CHECK_ARG((desc->lddo % 8) == 0, "ca_attn_bwd: lddo must be a multiple of 8");
   const AttnArgs a = to_args(*desc);
   hipStream_t s = (hipStream_t)stream;
-  const int64_t groups = (int64_t)desc->B * desc->H * desc->Tq;
-  hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((unsigned)((groups * 16 + 255) / 256)), dim3(256), 0, s,
-                     (const unsigned short*)desc->dO, desc->lddo, desc->sdob, (const unsigned short*)desc->O,
-                     desc->ldo, desc->sob, (float*)desc->Dq, desc->H, desc->Tq, desc->Tqp, desc->hd, desc->B);
-  dim3 gk(attn_grid((desc->Tk + 63) / 64, desc->H, desc->B)), gq(attn_grid((desc->Tq + 63) / 64, desc->H, desc->B)), block(256);
-  const bool drop = desc->dropout_p > 0.f;
   static const int wide = [] { const char* e = getenv("CA_ATTN_WIDE"); return e ? atoi(e) : 1; }();
-  // dK, dV: 64 keys per workgroup (a 128-key, 8-wave variant with a 4-deep ring measured no faster at T = 499 and 5 %
-  // slower at T = 1500: dropped)
-#define CA_DKV(HDPV, DROP) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HDPV, DROP>), gk, block, 4 * 32 * HDPV * 2, s, a)
-  if (desc->hd <= 64) {
-    if (drop) CA_DKV(64, true); else CA_DKV(64, false);
-  } else {
-    if (drop) CA_DKV(128, true); else CA_DKV(128, false);
+  const bool drop = desc->dropout_p > 0.f;
+  const bool dq_wide = wide && desc->Tq >= 100;
+  dim3 gk(attn_grid((desc->Tk + 63) / 64, desc->H, desc->B)), gq(attn_grid((desc->Tq + 63) / 64, desc->H, desc->B)), block(256);
+  // dQ.  128-query workgroups when the query side fills them: that kernel also produces D = rowsum(dO * O) for the
+  // dK/dV kernel behind it.  Otherwise D comes from its own pass first.
+  if (!dq_wide) {
+    const int64_t groups = (int64_t)desc->B * desc->H * desc->Tq;
+    hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((unsigned)((groups * 16 + 255) / 256)), dim3(256), 0, s,
+                       (const unsigned short*)desc->dO, desc->lddo, desc->sdob, (const unsigned short*)desc->O,
+                       desc->ldo, desc->sob, (float*)desc->Dq, desc->H, desc->Tq, desc->Tqp, desc->hd, desc->B);
   }
-#undef CA_DKV
-  // dQ: 128-query workgroups when the query side fills them
 #define CA_DQ(HDPV, DROP)                                                                                          \
   do {                                                                                                             \
-    if (wide && desc->Tq >= 100)                                                                                   \
+    if (dq_wide)                                                                                                   \
       hipLaunchKernelGGL((attn_bwd_dq_wide_kernel<HDPV, DROP, 4, 2>),                                              \
                          dim3(attn_grid((desc->Tq + 127) / 128, desc->H, desc->B)), dim3(256), 2 * 2 * 64 * HDPV * 2, s, a); \
     else                                                                                                           \
@@ -1493,6 +1500,15 @@ extern "C" int ca_attn_bwd(const CaAttnDesc* desc, void* stream) {
     if (drop) CA_DQ(128, true); else CA_DQ(128, false);
   }
 #undef CA_DQ
+  // dK, dV: 64 keys per workgroup (a 128-key, 8-wave variant with a 4-deep ring measured no faster at T = 499 and 5 %
+  // slower at T = 1500: dropped)
+#define CA_DKV(HDPV, DROP) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HDPV, DROP>), gk, block, 4 * 32 * HDPV * 2, s, a)
+  if (desc->hd <= 64) {
+    if (drop) CA_DKV(64, true); else CA_DKV(64, false);
+  } else {
+    if (drop) CA_DKV(128, true); else CA_DKV(128, false);
+  }
+#undef CA_DKV
   CA_CHECK_LAUNCH("ca_attn_bwd");
   return CA_OK;
 }
