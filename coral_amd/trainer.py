@@ -191,6 +191,8 @@ class DataParallelTrainer:
         # per-bucket squared gradient norms, computed on the side stream as the buckets complete
         self.bucket_index = {name: i for i, name in enumerate(st.buckets)}
         self.bucket_sq = torch.zeros(len(st.buckets), dtype=torch.float32, device=st.device)
+        self.shard_norm = os.environ.get("CA_SHARD_NORM", "1") != "0"
+        self._rank = torch.distributed.get_rank(process_group) if self.world > 1 else 0
         self._norms_ready = False
         # N = 1: the squared norm of the gradients that are final early in the backward is taken on the side stream
         # while the rest of the backward runs (one HBM-bound pass beside MFMA-bound GEMMs), see _early_norm
@@ -251,8 +253,21 @@ class DataParallelTrainer:
         return self.engine.norm_plan()
 
     def _bucket_sumsq(self, name: str):
+        """Squared norm of a bucket's (reduced) gradients.  With several ranks every rank holds the same reduced
+        gradients, so each takes the squared norm of its 1/world slice of the bucket only and the slices' sums are
+        added over ranks in optimizer_step (one scalar all-reduce, identical on every rank): 1/world of the bytes."""
         lo, hi = self.engine.store.buckets[name]
         i = self.bucket_index[name]
+        if self.world > 1 and self.shard_norm:
+            per = -(-(hi - lo) // self.world)
+            per = (per + 7) // 8 * 8  # slices start 32-byte aligned
+            a = min(hi, lo + self._rank * per)
+            b = min(hi, a + per)
+            if b > a:
+                ops.sumsq(self.engine.store.g32[a:b], b - a, self.bucket_sq[i:i + 1], self.partial)
+            else:
+                self.bucket_sq[i:i + 1].zero_()
+            return
         ops.sumsq(self.engine.store.g32[lo:hi], hi - lo, self.bucket_sq[i:i + 1], self.partial)
 
     def _bucket_ready(self, name: str):
@@ -308,6 +323,8 @@ class DataParallelTrainer:
             if not self.dist:
                 torch.cuda.current_stream().wait_stream(self.opt_stream)
             self.gnorm_sq.copy_(self.bucket_sq.sum().reshape(1))
+            if self.world > 1 and self.shard_norm:  # add the ranks' slices (the result is the same on every rank)
+                torch.distributed.all_reduce(self.gnorm_sq, op=torch.distributed.ReduceOp.SUM, group=self.sync.pg)
             self._norms_ready = False
         elif self._early_lo is not None:  # the tail's squared norm is already in gnorm_sq (side stream)
             torch.cuda.current_stream().wait_stream(self.opt_stream)
