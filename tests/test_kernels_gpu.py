@@ -420,7 +420,8 @@ def test_misc_reorders(ops):
                                                     (80, 3, 130, 130, False, False), (32, 4, 12, 12, False, True),
                                                     (64, 2, 77, 77, True, False), (64, 2, 40, 300, False, False),
                                                     (64, 4, 1, 1500, False, False), (64, 3, 5, 333, False, True),
-                                                    (128, 1, 200, 200, True, True)])
+                                                    (128, 1, 200, 200, True, True), (64, 3, 130, 333, False, True),
+                                                    (64, 2, 300, 300, True, False), (120, 2, 257, 129, False, False)])
 def test_fused_attention_fwd_bwd(ops, hd, H, Tq, Tk, causal, pad):
     """ca_attn_fwd / ca_attn_bwd against an fp32 torch statement of softmax(scale QK^T + masks) V and
     its autograd gradients; q,k,v live in one fused [B*T, 3d] buffer like the engine's (self-attention)
