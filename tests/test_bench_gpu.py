@@ -40,3 +40,29 @@ def test_bench_refuses_more_ranks_than_devices():
     r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "64"], env=env, capture_output=True, text=True,
                        timeout=300, cwd=str(ROOT))
     assert r.returncode != 0 and "only" in r.stderr   # never a silent 1-GPU run
+
+
+def test_bench_line_of_a_single_rank_and_the_one_rank_rccl_diagnostic():
+    """The N = 1 line: every field the contract names, the forward+backward-only time beside the whole step, the
+    roofline object; and the labelled diagnostic that runs the N > 1 exchange path over an RCCL group of one rank."""
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    base = [sys.executable, str(ROOT / "bench.py"), "--model", "wav2vec2-small", "--steps", "2", "--warmup", "1",
+            "--no-cpu-baseline"]
+    r = subprocess.run(base, env=env, capture_output=True, text=True, timeout=900, cwd=str(ROOT))
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    d = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["rccl_ranks"] == 1 and d["grad_wire"] is None and d["vs_baseline"] is None
+    fb = d["config"]["fwd_bwd"]
+    assert 0 < fb["ms_per_step"] < d["ms_per_step"] and fb["value"] > d["value"]   # the optimiser is inside `value`
+    rf = d["roofline"]
+    assert rf["bound"] == "mfma" and 0 < rf["frac"] < 1 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    r = subprocess.run(base + ["--one-rank-exchange", "--no-fwd-bwd"], env=env, capture_output=True, text=True,
+                       timeout=900, cwd=str(ROOT))
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    e = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    assert "DIAGNOSTIC" in e["config"]["workload"] and e["n_gpus"] == 1 and e["value"] > 0
+    assert abs(e["config"]["loss"] - d["config"]["loss"]) <= 1e-3 * abs(d["config"]["loss"])  # identity exchange
