@@ -1002,7 +1002,11 @@ __global__ __launch_bounds__(512) void ca_gemm_kernel_x(const CaGemmGroup grp) {
   auto kstep = [&](auto st_c, int kt) {
     constexpr int ST = decltype(st_c)::value;
     const bool cs_step = do_colsum && (kt % cs_parts) == tn;  // this K-step belongs to this tile column
-    if (wave >= 4) burst(kt + 1);
+    // waves 4-7 issue their share of tile kt+1 here - or, in the weight-gradient form (both operands MN-major), one
+    // MFMA block later, when their SIMD partners' bursts (issued behind the barrier) are over: 2 685 against 2 802
+    // cycles per K-step there, but 2 840 against 2 590 for the K-major forms (s_memtime stamps, tools/dev_x_stamps.py)
+    constexpr bool LATE_BURST = AL == CA_MNMAJOR && BL == CA_MNMAJOR && !KS;
+    if (!LATE_BURST && wave >= 4) burst(kt + 1);
     // block 0: A(s0, m-half 0) x B(s0); reads A(s0, m-half 1)
     lds_wait(B0);
     lds_wait(A0);
@@ -1018,6 +1022,7 @@ __global__ __launch_bounds__(512) void ca_gemm_kernel_x(const CaGemmGroup grp) {
     X_MM2(0, A0, B0, 3, 0);
     X_MM2(0, A0, B0, 3, 2);
     __builtin_amdgcn_s_setprio(0);
+    if (LATE_BURST && wave >= 4) burst(kt + 1);
     // block 1: A(s0, m-half 1) x B(s0); reads B(s1) and A(s1, m-half 0)
     lds_wait(A1);
     colsum_acc(cs_step, 1, A1);
