@@ -90,10 +90,13 @@ class SelfAttnBlock:
                  dropout_p=hdrop[0], dropout_seed=hdrop[1])
         sv["hin"], sv["klen"], sv["hdrop"] = hin, klen, hdrop
 
-    def backward(self, dh, dhin, sv, sc: Scratch, B, T, defer=None):
+    def backward(self, dh, dhin, sv, sc: Scratch, B, T, defer=None, acc=True, sq=None):
         """dh: grad wrt h_out (kept intact); dhin: output buffer for grad wrt h_in (may alias nothing of sv).
         defer: list collecting the block's weight-gradient problems instead of launching them (the caller launches
-        the whole layer's group once dh and sc.dqkv are no longer needed elsewhere)."""
+        the whole layer's group once dh and sc.dqkv are no longer needed elsewhere).  acc=False: the weight gradients
+        overwrite (first micro-batch of a step, matrices not cleared); sq: {"o": (slots, off), "qkv": ...} where the
+        weight-gradient GEMMs leave their per-tile sums of squares (CaGemmDesc.c_sumsq)."""
+        sq = sq or {}
         st, d = self.st, self.d
         M = B * T
         o, g32, p16 = st.off, st.g32, st.p16
@@ -101,7 +104,8 @@ class SelfAttnBlock:
         # with `defer` the bias gradients travel with the problems (fused into the grouped launch or done by it)
         if defer is None:
             ops.colsum(dy, d, M, d, g32, sc.part, out_off=o(self.attn + "out_proj.bias"))
-        wg = [dict(dY=dy, X=sv["ctx"], M=d, N=d, K=M, lda=d, ldb=d, c_off=o(self.attn + "out_proj.weight"), accumulate=True,
+        wg = [dict(dY=dy, X=sv["ctx"], M=d, N=d, K=M, lda=d, ldb=d, c_off=o(self.attn + "out_proj.weight"), accumulate=acc,
+                   sq=sq.get("o"),
                    **(dict(bias_off=o(self.attn + "out_proj.bias"), part=sc.part, cs_off=3 * d) if defer is not None else {}))]
         ops.gemm(dy, p16, sc.dctx, M=M, N=d, K=d, lda=d, b_layout=MNMAJOR, ldb=d, ldc=d, b_off=o(self.attn + "out_proj.weight"))
         qkv, dqkv = sv["qkv"], sc.dqkv
@@ -111,7 +115,7 @@ class SelfAttnBlock:
         if defer is None:
             ops.colsum(dqkv, 3 * d, M, 3 * d, g32, sc.part, out_off=o(self.qbias))
         wg.append(dict(dY=dqkv, X=sv["x"], M=3 * d, N=d, K=M, lda=3 * d, ldb=d, c_off=o(self.attn + "q_proj.weight"),
-                       accumulate=True,
+                       accumulate=acc, sq=sq.get("qkv"),
                        **(dict(bias_off=o(self.qbias), part=sc.part, cs_off=0) if defer is not None else {})))
         if defer is not None:
             defer.extend(wg)
@@ -219,20 +223,23 @@ class FFNBlock:
                  dropout_seed=hdrop[1])
         sv["hin"], sv["drop"], sv["hdrop"] = hin, (dropout_p, seed), hdrop
 
-    def backward(self, dh, dhin, sv, sc: Scratch, M, defer=None):
+    def backward(self, dh, dhin, sv, sc: Scratch, M, defer=None, acc=True, sq=None):
+        sq = sq or {}
         st, d, f = self.st, self.d, self.f
         o, g32, p16 = st.off, st.g32, st.p16
         p, seed = sv["drop"]
         dy = _masked_grad(dh, sv, sc, M * d, "ffn")
         if defer is None:
             ops.colsum(dy, d, M, d, g32, sc.part, out_off=o(self.fc2 + ".bias"))
-        wg = [dict(dY=dy, X=sv["g"], M=d, N=f, K=M, lda=d, ldb=f, c_off=o(self.fc2 + ".weight"), accumulate=True,
+        wg = [dict(dY=dy, X=sv["g"], M=d, N=f, K=M, lda=d, ldb=f, c_off=o(self.fc2 + ".weight"), accumulate=acc,
+                   sq=sq.get("fc2"),
                    **(dict(bias_off=o(self.fc2 + ".bias"), part=sc.part, cs_off=4 * d + f) if defer is not None else {}))]
         ops.gemm(dy, p16, sc.du, M=M, N=f, K=d, lda=d, b_layout=MNMAJOR, ldb=f, ldc=f, b_off=o(self.fc2 + ".weight"),
                  epilogue=EPI_DGELU, R=sv["u"], ldr=f, dropout_p=p, dropout_seed=seed)
         if defer is None:
             ops.colsum(sc.du, f, M, f, g32, sc.part, out_off=o(self.fc1 + ".bias"))
-        wg.append(dict(dY=sc.du, X=sv["x"], M=f, N=d, K=M, lda=f, ldb=d, c_off=o(self.fc1 + ".weight"), accumulate=True,
+        wg.append(dict(dY=sc.du, X=sv["x"], M=f, N=d, K=M, lda=f, ldb=d, c_off=o(self.fc1 + ".weight"), accumulate=acc,
+                       sq=sq.get("fc1"),
                        **(dict(bias_off=o(self.fc1 + ".bias"), part=sc.part, cs_off=4 * d) if defer is not None else {})))
         if defer is not None:
             defer.extend(wg)

@@ -215,7 +215,7 @@ def wgrad_gemm_group(problems: list, G, colsum_ws=None, colsum_ld=0) -> bool:
         return dict(cs=(colsum_ws, p["cs_off"], colsum_ld)) if fused else dict(bias_off=p.get("bias_off"), part=p.get("part"))
 
     def base(p):
-        return {k: p[k] for k in ("M", "N", "K", "lda", "ldb", "c_off", "accumulate", "sq") if k in p}
+        return {k: p[k] for k in ("M", "N", "K", "lda", "ldb", "c_off", "accumulate", "sq") if p.get(k) is not None or k != "sq"}
 
     for p in solo + fallback:
         wgrad_gemm(p["dY"], p["X"], G, **base(p), **bias_kw(p))

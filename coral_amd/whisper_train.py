@@ -108,8 +108,64 @@ class WhisperTrainEngine(WhisperEngine):
         lo = self.store.off("model.decoder.embed_tokens.weight")
         return lo, lo + self.s.vocab_size * self.s.d_model
 
+    # the six weight matrices of an encoder layer are contiguous (q|k|v, out_proj, fc1, fc2): with matrices=False they
+    # are neither cleared here nor read back by the first micro-batch's weight-gradient GEMMs, which overwrite them
+    def _enc_matrix_range(self, l: int):
+        st = self.store
+        p = f"model.encoder.layers.{l}."
+        lo = st.off(p + "self_attn.q_proj.weight")
+        hi = st.off(p + "fc2.weight") + self.s.d_model * self.s.encoder_ffn_dim
+        return lo, hi
+
+    def _enc_matrices(self, l: int):
+        d, f = self.s.d_model, self.s.encoder_ffn_dim
+        p = f"model.encoder.layers.{l}."
+        return [("qkv", p + "self_attn.q_proj.weight", 3 * d, d), ("o", p + "self_attn.out_proj.weight", d, d),
+                ("fc1", p + "fc1.weight", f, d), ("fc2", p + "fc2.weight", d, f)]
+
     def zero_grad(self, matrices: bool = True):
-        self.store.g32.zero_()
+        st, Le = self.store, self.s.encoder_layers
+        if matrices or self.freeze_base or Le == 0:
+            st.g32.zero_()
+        else:
+            lo0, hi0 = self._enc_matrix_range(0)
+            st.g32[:lo0].zero_()
+            if Le > 1:  # the small tensors behind each layer's matrices: equal size, equal stride
+                lo1, _ = self._enc_matrix_range(1)
+                n = lo1 - hi0
+                st.g32[hi0:hi0 + (Le - 2) * (lo1 - lo0) + n].as_strided((Le - 1, n), (lo1 - lo0, 1)).zero_()
+            _, hil = self._enc_matrix_range(Le - 1)
+            st.g32[hil:].zero_()
+        plan = getattr(self, "_norm_plan", None)
+        if plan is not None:
+            plan["slots"].zero_()
+
+    def norm_plan(self):
+        """Squared gradient norm without a pass over the encoder layers' weight matrices (wav2vec2.norm_plan)."""
+        if self.freeze_base:
+            return None
+        if getattr(self, "_norm_plan", None) is not None:
+            return self._norm_plan
+        st = self.store
+        off, soff, mats = 0, {}, []
+        for l in range(self.s.encoder_layers):
+            for key, name, M, N in self._enc_matrices(l):
+                soff[(l, key)] = off
+                off += ops.sumsq_slots(M, N)
+                mats.append((st.off(name), M * N))
+        if not mats:
+            return None
+        chunks, pos = [], 0
+        for a, n in sorted(mats) + [(st.numel, 0)]:
+            while pos < a:
+                m = min(65536, a - pos)
+                chunks.append((pos, m))
+                pos += m
+            pos = max(pos, a + n)
+        self._norm_plan = dict(slots=torch.zeros(off, dtype=torch.float32, device=self.device), nslots=off, slot_off=soff,
+                               chunks=torch.tensor(chunks, dtype=torch.int64, device=self.device), nchunks=len(chunks),
+                               partial=torch.zeros(max(4096, len(chunks)), dtype=torch.float32, device=self.device))
+        return self._norm_plan
 
     def train(self, mode: bool = True):
         self.training = mode
@@ -353,8 +409,15 @@ class WhisperTrainEngine(WhisperEngine):
         scs, bws = (sc_e, w["sc_e2"]), (w["bias_ws"], w["bias_ws2"])
         wdone, it = {}, 0
         cur = ring[0]
+        plan = self.norm_plan()
+        eacc = not overwrite_matrices  # encoder weight matrices: accumulate, or overwrite in a step's first micro-batch
         for l in reversed(range(s.encoder_layers)):
+            sqd = ({k: (plan["slots"], plan["slot_off"][(l, k)]) for k in ("qkv", "o", "fc1", "fc2")}
+                   if plan is not None else None)
             if not sv["ek"][l]:
+                if overwrite_matrices:  # dropped layer: its (uncleared) matrices get no gradient this step
+                    lo, hi = self._enc_matrix_range(l)
+                    g32[lo:hi].zero_()
                 done(f"enc{l}")
                 continue
             sa, ff = self.enc_blocks[l]
@@ -364,8 +427,8 @@ class WhisperTrainEngine(WhisperEngine):
             sc, bw = scs[it & 1], bws[it & 1]
             cur, other, third = ring[(2 * it) % 6], ring[(2 * it + 1) % 6], ring[(2 * it + 2) % 6]
             wg = []
-            ff.backward(cur, other, sv_f, sc, Me, defer=wg)
-            sa.backward(other, third, sv_a, sc, B, T, defer=wg)
+            ff.backward(cur, other, sv_f, sc, Me, defer=wg, acc=eacc, sq=sqd)
+            sa.backward(other, third, sv_a, sc, B, T, defer=wg, acc=eacc, sq=sqd)
             nb = 5 * d + s.encoder_ffn_dim
 
             def wgrads(wg=wg, bw=bw, l=l):

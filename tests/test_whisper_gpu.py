@@ -187,6 +187,45 @@ def test_whisper_trainer_reduces_loss():
             assert float(eng.store.view(n).abs().sum()) == 0.0
 
 
+def test_whisper_gradient_norm_without_a_pass_over_the_encoder_matrices(monkeypatch):
+    """The trainer's clip norm for the Whisper engine: encoder weight matrices are overwritten by the first
+    micro-batch (not cleared, not read back) and contribute through the weight-gradient GEMMs' per-tile sums of squares;
+    everything else is normed by a pass over its chunks.  Equal to the norm of the gradient buffer at every step, with
+    accumulation micro-batches; and to the run that clears and re-reads everything (CA_FUSED_NORM=0) at the first step."""
+    from coral_amd.trainer import DataParallelTrainer
+    from coral_amd.whisper import WhisperShape
+    from coral_amd.whisper_train import WhisperTrainEngine
+    from oracle import whisper_ref as w
+
+    kw, c = _tiny()
+    g = torch.Generator().manual_seed(5)
+    mbs = [dict(input_features=torch.randn(2, 80, 3000, generator=g) * 0.5, labels=torch.randint(0, 150, (2, 10), generator=g))
+           for _ in range(2)]
+    norms = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("CA_FUSED_NORM", fused)
+        eng = WhisperTrainEngine(WhisperShape(**kw), DEV)
+        eng.load_state_dict(w.synth_params(c))
+        tr = DataParallelTrainer(eng, learning_rate=1e-3, warmup_steps=1, max_steps=30, max_grad_norm=0.05, grad_accum=2,
+                                 overlap_optimizer=False)
+        assert (tr._norm_plan() is not None) == (fused == "1")
+        out = []
+        Le = kw["encoder_layers"]
+        for step in range(3):
+            # in step 1 the second micro-batch drops encoder layer 1, in step 2 the first one does
+            keeps = [[not (step == 2 and l == 1) for l in range(Le)], [not (step == 1 and l == 1) for l in range(Le)]]
+            tr.train_step([dict(mb, enc_keep=k) for mb, k in zip(mbs, keeps)])
+            out.append(tr.grad_norm())
+            torch.cuda.synchronize()
+            direct = float(eng.store.g32.double().pow(2).sum().sqrt())
+            assert abs(out[-1] - direct) <= 1e-5 * direct, (fused, out[-1], direct)
+        norms[fused] = out
+    assert abs(norms["1"][0] - norms["0"][0]) <= 1e-5 * norms["0"][0], norms
+    for n in eng.store.names():
+        if n.endswith("__zero"):
+            assert float(eng.store.view(n, "g32").abs().sum()) == 0.0
+
+
 def test_whisper_layerdrop_matches_oracle():
     """LayerDrop decisions are host-drawn; a dropped layer is the identity in forward and backward and
     its parameters get no gradient."""
