@@ -307,6 +307,7 @@ def run_w2v2(model_key, args, world, rank, device, roofline: bool):
         mb = dict(batch)
         if pipe is not None:  # this step's batch was staged during the previous step; stage the next one now
             mb.update(pipe.get())
+            mb.pop("sample_lengths", None)  # (a hint for the HF-shaped wrapper; the bare engine takes the masks below)
             pipe.submit(pcm)
         if not args.no_specaugment:
             mt, mf = specaugment.sample_masks(B, T, shape.hidden_size, frame_lens, 0.5, 10, 0.5, 64, rng=rng)

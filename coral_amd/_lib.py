@@ -157,6 +157,7 @@ SIGNATURES = {
     "ca_conv_weight_grad_reorder": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
     "ca_sumsq_f32": (C.c_int, [_vp, _i64, _vp, _i32, _vp, _vp]),
     "ca_sumsq_ranges_f32": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _vp, _vp]),
+    "ca_clear_ranges": (C.c_int, [_vp, _vp, _i32, _i64, _vp]),
     "ca_sum_f32": (C.c_int, [_vp, _i64, _vp, _i32, _vp, _vp]),
     "ca_adamw_step": (
         C.c_int,

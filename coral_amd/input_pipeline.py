@@ -52,7 +52,7 @@ class DeviceInputPipeline:
         self.free = [torch.cuda.Event() for _ in range(depth)]  # the compute stream is done with slot i
         self.mel_filters = mel_filters
         self.augment = augment  # coral_amd.augment.DeviceAugment or None (training only, like `augment_audio`)
-        self._queue: list[tuple[int, int, int]] = []  # (slot, rows, longest)
+        self._queue: list[tuple] = []  # (slot, rows, longest, host lengths)
         self._next = 0
 
     def submit(self, audios) -> None:
@@ -78,13 +78,13 @@ class DeviceInputPipeline:
             self.dev[k][:len(audios), :longest].copy_(self.host[k][:len(audios), :longest], non_blocking=True)
             self.dev_len[k].copy_(self.host_len[k], non_blocking=True)
             self.ready[k].record(self.copy_stream)
-        self._queue.append((k, len(audios), longest))
+        self._queue.append((k, len(audios), longest, [int(v) for v in hl[:len(audios)]]))
 
     def get(self) -> dict:
         """Device tensors of the oldest submitted batch (enqueued on the current stream)."""
         if not self._queue:
             raise RuntimeError("nothing submitted")
-        k, rows, longest = self._queue.pop(0)
+        k, rows, longest, host_lengths = self._queue.pop(0)
         cur = torch.cuda.current_stream()
         cur.wait_event(self.ready[k])
         src, src_ld = self.dev[k], self.N
@@ -101,7 +101,9 @@ class DeviceInputPipeline:
             y = torch.empty(rows, n_out, dtype=torch.float32, device=self.device)
             mask = torch.empty(rows, n_out, dtype=torch.int32, device=self.device)
             ops.pcm_prepare(src, self.dev_len[k], y, mask, rows, n_out, src_ld, peak_normalize=peak)
-            out = {"input_values": y, "attention_mask": mask}
+            # (sample_lengths: the valid samples per row as host integers, so that the model wrapper can place its
+            # SpecAugment spans without reading the device mask back)
+            out = {"input_values": y, "attention_mask": mask, "sample_lengths": host_lengths}
         else:
             from .whisper import HOP, N_SAMPLES
 

@@ -3,7 +3,8 @@ R/src/coral/model_setup.py:10-31) re-implemented over the MI355X engine.
 
 `load_model_setup(config)` dispatches on `config.model.type`; the returned object offers the same
 seven loaders with the same meaning.  Instead of `transformers.Trainer` the trainer class is
-`coral_amd.trainer.DataParallelTrainer` (one process per GPU, RCCL gradient all-reduce), and the
+`coral_amd.coral_trainer.CoralTrainer` (Trainer's constructor and `.train()`; underneath one process per GPU, RCCL
+gradient all-reduce, coral_amd/trainer.py), and the
 "training arguments" are a plain dataclass carrying the values `TrainingArguments` would.
 """
 
@@ -22,7 +23,8 @@ import torch
 from .compute_metrics import compute_error_rate_metrics
 from .data_collators import DataCollatorCTCWithPadding
 from .processor import CTCTokenizer, Wav2Vec2Processor, WaveformFeatureExtractor, dump_vocabulary
-from .trainer import DataParallelTrainer, grad_accumulation_steps
+from .coral_trainer import CoralTrainer
+from .trainer import grad_accumulation_steps
 
 logger = logging.getLogger(__package__)
 
@@ -67,6 +69,16 @@ class TrainingArgs:
     dataloader_drop_last: bool = True
     ddp_find_unused_parameters: bool = False
     report_to: list = field(default_factory=list)
+    ignore_data_skip: bool = False
+    # what the device input path needs to know about the examples (the reference applies these per example on the host,
+    # R/src/coral/data.py:254-255,704-747: training = normalise + augment)
+    sampling_rate: int = 16_000
+    max_seconds_per_example: float = 10.0
+    padding: str = "longest"
+    normalise_audio: bool = True
+    augment_audio: bool = True
+    device_input_pipeline: bool = True
+    zero_stage: int = 0   # >0: optimiser state + update sharded over the ranks (the reference's `--zero-stage 2` launch)
 
 
 class ModelSetup(ABC):
@@ -117,7 +129,12 @@ def _training_args(config, learning_rate) -> TrainingArgs:
         save_total_limit=config.save_total_limit, load_best_model_at_end=config.early_stopping,
         metric_for_best_model=metric, greater_is_better=False, seed=config.seed,
         adam_beta1=config.adam_first_momentum, adam_beta2=config.adam_second_momentum,
-        dataloader_num_workers=config.dataloader_num_workers)
+        dataloader_num_workers=config.dataloader_num_workers, ignore_data_skip=bool(config.get("ignore_data_skip", False)),
+        sampling_rate=int(config.model.sampling_rate), max_seconds_per_example=float(config.max_seconds_per_example),
+        padding=config.padding if isinstance(config.padding, str) else "longest",
+        augment_audio=bool(config.get("augment_audio", True)), normalise_audio=bool(config.get("normalise_audio", True)),
+        device_input_pipeline=bool(config.get("device_input_pipeline", True)),
+        zero_stage=int(config.get("zero_stage", 0) or 0))
 
 
 class Wav2Vec2ModelSetup(ModelSetup):
@@ -163,7 +180,7 @@ class Wav2Vec2ModelSetup(ModelSetup):
                                           padding=self.config.padding)
 
     def load_trainer_class(self):
-        return DataParallelTrainer
+        return CoralTrainer
 
     def load_compute_metrics(self):
         return partial(compute_error_rate_metrics, processor=self.processor)

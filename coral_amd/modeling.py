@@ -12,6 +12,7 @@ import numpy as np
 import torch
 
 from . import specaugment
+from .autograd import attach_backward
 from .wav2vec2 import CORAL_W2V2_SHAPES, Wav2Vec2CTCEngine, Wav2Vec2Shape
 
 logger = logging.getLogger(__package__)
@@ -192,15 +193,27 @@ class Wav2Vec2ForCTC:
         return [bool(self._rng.rand() >= self.shape.layerdrop) for _ in range(self.shape.num_hidden_layers)]
 
     def __call__(self, input_values, attention_mask=None, labels=None, mask_time=None, mask_feature=None,
-                 layer_keep=None):
+                 layer_keep=None, sample_lengths=None):
+        """sample_lengths: optional host list of valid samples per row (what `attention_mask.sum(-1)` holds) - given by
+        the device input pipeline, whose masks live on the GPU, so that drawing the SpecAugment spans needs no read-back."""
         B, N = input_values.shape
         if mask_time is None and mask_feature is None and self.training:
             T = self.engine.conv_lengths(N)[-1]
-            flen = [T] * B if attention_mask is None else self.engine.feat_lengths(attention_mask.sum(-1)).tolist()
+            if sample_lengths is not None:
+                flen = [self.engine.conv_lengths(min(int(n), N))[-1] for n in sample_lengths]
+            else:
+                flen = [T] * B if attention_mask is None else self.engine.feat_lengths(attention_mask.sum(-1)).tolist()
             mask_time, mask_feature = self.sample_spec_masks(B, T, flen)
         if layer_keep is None:
             layer_keep = self.sample_layer_keep()
-        return self.engine(input_values, attention_mask, labels, mask_time, mask_feature, layer_keep)
+        out = self.engine(input_values, attention_mask, labels, mask_time, mask_feature, layer_keep)
+        if out.get("loss") is not None:
+            # `out.loss.backward()` runs the engine's backward (coral_amd/autograd.py; $TF/trainer.py:2005,2038)
+            out["loss"] = attach_backward(self, out["loss"])
+        return out
+
+    # forwarded to engine.backward when the backward is started through autograd (`loss.backward()`)
+    backward_kwargs: dict | None = None
 
     def backward(self, **kw):
         return self.engine.backward(**kw)

@@ -158,6 +158,11 @@ def wgrad_gemm(dY, X, G, *, M, N, K, lda, ldb, c_off, accumulate, a_off=0, b_off
     reduce_rows(ws, splits, M * N, M * N, G[c_off:], accumulate=accumulate)
     if sq is not None:
         sumsq(G[c_off:], M * N, sq[0][sq[1]:], ws)  # (ws: free again, >= 4096 floats)
+        # the matrix's other slots may still hold the per-tile partials of a step that took the direct path (K = B*T
+        # changes per batch with padding=longest, and with it _wgrad_splits): the norm is the sum over ALL slots
+        ns = sumsq_slots(M, N)
+        if ns > 1:
+            clear_f32(sq[0], ns - 1, off=sq[1] + 1)
 
 
 def _xtiles(p):
@@ -407,6 +412,33 @@ def conv_weight_reorder(w, wr, Co, Ci, k, w_off=0):
 def conv_weight_grad_reorder(dwr, dw, Co, Ci, k, dw_off=0):
     check(lib().ca_conv_weight_grad_reorder(_p(dwr), _p(dw, dw_off), Co, Ci, k, _stream()),
           "ca_conv_weight_grad_reorder")
+
+
+def clear_f32(x, n, off=0):
+    """x[off : off + n] = 0 (fp32 buffer) as one ca_clear_ranges launch."""
+    clear_ranges(x, [(off, n)])
+
+
+_CLEAR_TABLES: dict = {}
+
+
+def clear_ranges(x, ranges):
+    """Zero the listed (offset, length) ELEMENT ranges of the flat buffer `x` in ONE launch (ca_clear_ranges).  The
+    byte-range table lives on the device, cached per (buffer, ranges): build the list once and pass the same tuple."""
+    elt = _ELT[x.dtype]
+    key = (x.data_ptr(), elt, tuple(ranges))
+    ent = _CLEAR_TABLES.get(key)
+    if ent is None:
+        if len(_CLEAR_TABLES) > 512:
+            _CLEAR_TABLES.clear()
+        rows = [[int(a) * elt, int(n) * elt] for a, n in ranges if n > 0]
+        if any(a % 4 or n % 4 for a, n in rows):
+            raise CoralAmdError("clear_ranges: ranges must be multiples of 4 bytes")
+        ent = (torch.tensor(rows, dtype=torch.int64, device=x.device), len(rows), max(n for _, n in rows)) if rows else None
+        _CLEAR_TABLES[key] = ent
+    if ent is None:
+        return
+    check(lib().ca_clear_ranges(_p(x), _p(ent[0]), ent[1], ent[2], _stream()), "ca_clear_ranges")
 
 
 def sumsq(g, n, out, partial, accumulate=False):

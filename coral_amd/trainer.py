@@ -236,7 +236,8 @@ class DataParallelTrainer:
                 self._done, self._early_lo = {}, None
                 hook = self._early_norm
             eng.backward(loss_scale=1.0 / n, overwrite_matrices=(i == 0), bucket_done=hook)
-            total = out.loss / n if total is None else total + out.loss / n
+            loss = out.loss.detach()  # (the autograd route of coral_amd/autograd.py is not used here)
+            total = loss / n if total is None else total + loss / n
         if self.dist and not self.overlap:
             self.sync.start_all()
         self.sync.finish()
@@ -266,7 +267,7 @@ class DataParallelTrainer:
             if b > a:
                 ops.sumsq(self.engine.store.g32[a:b], b - a, self.bucket_sq[i:i + 1], self.partial)
             else:
-                self.bucket_sq[i:i + 1].zero_()
+                ops.clear_f32(self.bucket_sq, 1, off=i)
             return
         ops.sumsq(self.engine.store.g32[lo:hi], hi - lo, self.bucket_sq[i:i + 1], self.partial)
 

@@ -66,6 +66,31 @@ def _r8(n: int) -> int:
     return (n + 7) // 8 * 8
 
 
+def _arena_build(build, device, default_dtype):
+    """Run `build(z)` twice - z(n, dt=...) first only adds up 256-byte aligned sizes, then hands out views of one
+    zero-filled arena - so that a workspace costs one allocation and one fill."""
+    esz = {torch.bfloat16: 2, torch.float32: 4, torch.uint8: 1, torch.int32: 4}
+    total = [0]
+
+    def measure(n, dt=default_dtype):
+        total[0] += (int(n) * esz[dt] + 255) // 256 * 256
+        return None
+
+    build(measure)
+    arena = torch.zeros(total[0], dtype=torch.uint8, device=device)
+    pos = [0]
+
+    def carve(n, dt=default_dtype):
+        nb = int(n) * esz[dt]
+        v = arena[pos[0]:pos[0] + nb].view(dt)
+        pos[0] += (nb + 255) // 256 * 256
+        return v
+
+    w = build(carve)
+    w["_arena"] = arena
+    return w
+
+
 class ParamStore:
     """Flat fp32 master / fp32 grad / bf16 compute buffers with HF-named views."""
 
@@ -313,24 +338,16 @@ class Wav2Vec2CTCEngine:
         self.clear_small_grads()
 
     def clear_small_grads(self):
-        """Zero everything except the transformer layers' weight matrices (see zero_grad)."""
+        """Zero everything except the transformer layers' weight matrices (see zero_grad): the front and head
+        buckets and every layer's small tensors (LayerNorms, biases), as ONE launch over a cached range table."""
         st = self.store
-        for name in ("front", "head"):
-            lo, hi = st.buckets[name]
-            st.g32[lo:hi].zero_()
-        # the layers' small parameters (LayerNorms, biases) sit at the same offset of equally sized layer buckets:
-        # one strided fill instead of one launch per layer
-        L = self.s.num_hidden_layers
-        lo0 = st.off("wav2vec2.encoder.layers.0.layer_norm.weight")
-        n = st.off("wav2vec2.encoder.layers.0.attention.q_proj.weight") - lo0
-        stride = st.off("wav2vec2.encoder.layers.1.layer_norm.weight") - lo0 if L > 1 else n
-        uniform = all(st.off(f"wav2vec2.encoder.layers.{l}.layer_norm.weight") == lo0 + l * stride for l in range(L))
-        if uniform and L > 1:
-            st.g32[lo0:lo0 + (L - 1) * stride + n].as_strided((L, n), (stride, 1)).zero_()
-        else:
-            for l in range(L):
+        if getattr(self, "_small_ranges", None) is None:
+            rs = [(lo, hi - lo) for lo, hi in (st.buckets[n] for n in ("front", "head"))]
+            for l in range(self.s.num_hidden_layers):
                 lo = st.off(f"wav2vec2.encoder.layers.{l}.layer_norm.weight")
-                st.g32[lo:lo + n].zero_()
+                rs.append((lo, st.off(f"wav2vec2.encoder.layers.{l}.attention.q_proj.weight") - lo))
+            self._small_ranges = tuple(rs)
+        ops.clear_ranges(st.g32, self._small_ranges)
 
     def train(self, mode: bool = True):
         self.training = mode
@@ -392,79 +409,86 @@ class Wav2Vec2CTCEngine:
         G, K = s.num_conv_pos_embedding_groups, s.num_conv_pos_embeddings
         Cg = d // G
         bf, f32 = torch.bfloat16, torch.float32
-        z = lambda *sh, dt=bf: torch.zeros(*sh, dtype=dt, device=dev)  # noqa: E731
-        w = {"B": B, "N": N, "Ts": Ts, "T": T, "M": M, "Tp": Tp}
-        C0 = s.conv_dim[0]
-        w["a"] = [z(B * Ts[i] * s.conv_dim[i]) for i in range(7)]          # conv block outputs
-        w["y"] = [None] + [z(B * Ts[i] * s.conv_dim[i]) for i in range(1, 7)]  # pre-LN conv outputs
-        w["cstats"] = [None] + [z(B * Ts[i] * 2, dt=f32) for i in range(1, 7)]
-        w["fp_stats"] = z(M * 2, dt=f32)
-        w["xln"] = z(M * C0)
-        w["h0"] = z(M * d)
-        w["xg"] = z(B * G * (T + K) * Cg + 8 * Cg)
-        w["pc_pre"] = z(M * d)
-        w["h"] = [z(M * d) for _ in range(L + 1)]      # residual stream entering layer l (h[L] = out)
-        w["x1"] = [z(M * d) for _ in range(L)]
-        w["st1"] = [z(M * 2, dt=f32) for _ in range(L)]
-        w["qkv"] = [z(M * 3 * d) for _ in range(L)]
-        Tqp = (T + 31) // 32 * 32
-        w["Tqp"] = Tqp
-        if self.fused_attention:
-            w["lse"] = [z(B * H * Tqp, dt=f32) for _ in range(L)]
-            w["Dq"] = z(B * H * Tqp, dt=f32)
-        else:
-            w["P"] = [z(B * H * T * Tp) for _ in range(L)]
-        w["ctx"] = [z(M * d) for _ in range(L)]
-        w["h1"] = [z(M * d) for _ in range(L)]
-        w["x2"] = [z(M * d) for _ in range(L)]
-        w["st2"] = [z(M * 2, dt=f32) for _ in range(L)]
-        w["u"] = [z(M * f) for _ in range(L)]
-        w["g"] = [z(M * f) for _ in range(L)]
-        if not self.fused_attention:
-            w["S"] = z(B * H * T * Tp, dt=f32)         # transient scores / dprobs
-        w["hf"] = z(M * d)
-        w["stf"] = z(M * 2, dt=f32)
-        Vp = _r8(s.vocab_size)
-        w["Vp"] = Vp
-        w["logits"] = z(M * Vp, dt=f32)
-        w["dlogits"] = z(M * Vp, dt=f32)
-        w["dlogits16"] = z(M * Vp)
-        w["nll"] = z(B, dt=f32)
-        # backward scratch
-        w["dA"] = z(M * d)
-        w["dB"] = z(M * d)
-        w["dC"] = z(M * d)
-        w["dqkv"] = z(M * 3 * d)
-        # second copies of the buffers the weight gradients read (dY operands): with the weight gradients on their own
-        # stream (backward()) a layer's dY must stay intact while the next layer's data gradients are being written
-        w["dBr"] = [w["dB"], z(M * d), z(M * d)]
-        w["dCr"] = [w["dC"], z(M * d)]
-        w["dqkvr"] = [w["dqkv"], z(M * 3 * d)]
-        if not self.fused_attention:
-            w["dS"] = z(B * H * T * Tp)
-        w["du"] = z(M * f)
-        w["dur"] = [w["du"], z(M * f)]
-        w["dxg"] = z(B * G * (T + K) * Cg + 8 * Cg)
-        w["dwf"] = z(d * K * Cg, dt=f32)
-        # partial column sums of the layer's four dY (fused bias gradients): rows that a problem with fewer than
-        # COLSUM_PARTS tile columns never writes stay zero
-        w["bias_ws"] = z(ops.COLSUM_PARTS * (5 * d + s.intermediate_size), dt=f32)
-        nmax = max(B * Ts[i] * s.conv_kernel[i] * s.conv_dim[i - 1] for i in range(1, 7))
-        w["dcol"] = z(nmax)
-        w["dconv"] = [z(B * Ts[i] * s.conv_dim[i]) for i in range(7)]   # grads wrt conv block outputs
-        w["dy"] = z(max(B * Ts[i] * s.conv_dim[i] for i in range(1, 7)))
-        w["dwr"] = z(max(s.conv_dim[i] * s.conv_kernel[i] * s.conv_dim[i - 1] for i in range(1, 7)), dt=f32)
-        w["dwr_part"] = z(B * max(s.conv_dim[i] * s.conv_kernel[i] * s.conv_dim[i - 1] for i in range(1, 7)), dt=f32)
-        pf = max(
-            ops.layernorm_bwd_partial_floats(B * Ts[1], 512), ops.layernorm_bwd_partial_floats(M, d),
-            ops.colsum_partial_floats(M, max(f, 3 * d)), ops.colsum_partial_floats(B * Ts[1], 512),
-            ops.conv0_bwd_partial_floats(B, N, C0, s.conv_kernel[0], s.conv_stride[0]), 4096)
-        w["partial"] = z(pf, dt=f32)
-        w["partial_w"] = z(pf, dt=f32)  # the weight-gradient stream's own scratch
-        # LayerNorm-backward partials (d gamma | d beta per row block) of a layer's two norms, two layers in flight:
-        # their second-stage reductions run on the weight-gradient stream (backward())
-        w["ln_parts"] = ops.layernorm_bwd_partial_floats(M, d) // (2 * d)
-        w["ln_partial"] = [[z(ops.layernorm_bwd_partial_floats(M, d), dt=f32) for _ in range(2)] for _ in range(2)]
+
+        def build(z):
+            # (run twice: once to measure, once to carve views out of ONE zero-filled arena - a workspace used to
+            # be ~450 separate torch.zeros fills)
+            w = {"B": B, "N": N, "Ts": Ts, "T": T, "M": M, "Tp": Tp}
+            C0 = s.conv_dim[0]
+            w["a"] = [z(B * Ts[i] * s.conv_dim[i]) for i in range(7)]          # conv block outputs
+            w["y"] = [None] + [z(B * Ts[i] * s.conv_dim[i]) for i in range(1, 7)]  # pre-LN conv outputs
+            w["cstats"] = [None] + [z(B * Ts[i] * 2, dt=f32) for i in range(1, 7)]
+            w["fp_stats"] = z(M * 2, dt=f32)
+            w["xln"] = z(M * C0)
+            w["h0"] = z(M * d)
+            w["xg"] = z(B * G * (T + K) * Cg + 8 * Cg)
+            w["pc_pre"] = z(M * d)
+            w["h"] = [z(M * d) for _ in range(L + 1)]      # residual stream entering layer l (h[L] = out)
+            w["x1"] = [z(M * d) for _ in range(L)]
+            w["st1"] = [z(M * 2, dt=f32) for _ in range(L)]
+            w["qkv"] = [z(M * 3 * d) for _ in range(L)]
+            Tqp = (T + 31) // 32 * 32
+            w["Tqp"] = Tqp
+            if self.fused_attention:
+                w["lse"] = [z(B * H * Tqp, dt=f32) for _ in range(L)]
+                w["Dq"] = z(B * H * Tqp, dt=f32)
+            else:
+                w["P"] = [z(B * H * T * Tp) for _ in range(L)]
+            w["ctx"] = [z(M * d) for _ in range(L)]
+            w["h1"] = [z(M * d) for _ in range(L)]
+            w["x2"] = [z(M * d) for _ in range(L)]
+            w["st2"] = [z(M * 2, dt=f32) for _ in range(L)]
+            w["u"] = [z(M * f) for _ in range(L)]
+            w["g"] = [z(M * f) for _ in range(L)]
+            if not self.fused_attention:
+                w["S"] = z(B * H * T * Tp, dt=f32)         # transient scores / dprobs
+            w["hf"] = z(M * d)
+            w["stf"] = z(M * 2, dt=f32)
+            Vp = _r8(s.vocab_size)
+            w["Vp"] = Vp
+            w["logits"] = z(M * Vp, dt=f32)
+            w["dlogits"] = z(M * Vp, dt=f32)
+            w["dlogits16"] = z(M * Vp)
+            w["nll"] = z(B, dt=f32)
+            # backward scratch
+            w["dA"] = z(M * d)
+            w["dB"] = z(M * d)
+            w["dC"] = z(M * d)
+            w["dqkv"] = z(M * 3 * d)
+            # second copies of the buffers the weight gradients read (dY operands): with the weight gradients on their own
+            # stream (backward()) a layer's dY must stay intact while the next layer's data gradients are being written
+            w["dBr"] = [w["dB"], z(M * d), z(M * d)]
+            w["dCr"] = [w["dC"], z(M * d)]
+            w["dqkvr"] = [w["dqkv"], z(M * 3 * d)]
+            if not self.fused_attention:
+                w["dS"] = z(B * H * T * Tp)
+            w["du"] = z(M * f)
+            w["dur"] = [w["du"], z(M * f)]
+            w["dxg"] = z(B * G * (T + K) * Cg + 8 * Cg)
+            w["dwf"] = z(d * K * Cg, dt=f32)
+            # partial column sums of the layer's four dY (fused bias gradients): rows that a problem with fewer than
+            # COLSUM_PARTS tile columns never writes stay zero
+            w["bias_ws"] = z(ops.COLSUM_PARTS * (5 * d + s.intermediate_size), dt=f32)
+            nmax = max(B * Ts[i] * s.conv_kernel[i] * s.conv_dim[i - 1] for i in range(1, 7))
+            w["dcol"] = z(nmax)
+            w["dconv"] = [z(B * Ts[i] * s.conv_dim[i]) for i in range(7)]   # grads wrt conv block outputs
+            w["dy"] = z(max(B * Ts[i] * s.conv_dim[i] for i in range(1, 7)))
+            w["dwr"] = z(max(s.conv_dim[i] * s.conv_kernel[i] * s.conv_dim[i - 1] for i in range(1, 7)), dt=f32)
+            w["dwr_part"] = z(B * max(s.conv_dim[i] * s.conv_kernel[i] * s.conv_dim[i - 1] for i in range(1, 7)), dt=f32)
+            pf = max(
+                ops.layernorm_bwd_partial_floats(B * Ts[1], 512), ops.layernorm_bwd_partial_floats(M, d),
+                ops.colsum_partial_floats(M, max(f, 3 * d)), ops.colsum_partial_floats(B * Ts[1], 512),
+                ops.conv0_bwd_partial_floats(B, N, C0, s.conv_kernel[0], s.conv_stride[0]), 4096)
+            w["partial"] = z(pf, dt=f32)
+            w["partial_w"] = z(pf, dt=f32)  # the weight-gradient stream's own scratch
+            # LayerNorm-backward partials (d gamma | d beta per row block) of a layer's two norms, two layers in flight:
+            # their second-stage reductions run on the weight-gradient stream (backward())
+            w["ln_parts"] = ops.layernorm_bwd_partial_floats(M, d) // (2 * d)
+            w["ln_partial"] = [[z(ops.layernorm_bwd_partial_floats(M, d), dt=f32) for _ in range(2)] for _ in range(2)]
+
+            return w
+
+        w = _arena_build(build, dev, bf)
         self._ws, self._ws_key = w, key
         return w
 
@@ -494,7 +518,9 @@ class Wav2Vec2CTCEngine:
             flen = torch.empty(B, dtype=torch.int32, device=dev)
             ops.frame_lengths(am, s.conv_kernel, s.conv_stride, flen)
         else:
-            flen = torch.full((B,), T, dtype=torch.int32, device=dev)
+            if w.get("flen_full") is None:  # (cached: no fill kernel per step)
+                w["flen_full"] = torch.full((B,), T, dtype=torch.int32, device=dev)
+            flen = w["flen_full"]
         keep = [True] * L if layer_keep is None else list(layer_keep)
         w["flen"] = flen
         self._await("front")
@@ -640,8 +666,10 @@ class Wav2Vec2CTCEngine:
 
         # head: dlogits (fp32) -> bf16 for the MFMA path
         dl = w["dlogits"]
-        if loss_scale != 1.0:
-            dl.mul_(loss_scale)
+        if isinstance(loss_scale, torch.Tensor):  # autograd route: the incoming gradient stays on the device
+            ops.wave_scale(dl, loss_scale.reshape(1).to(torch.float32), dl, 1, M * Vp)
+        elif loss_scale != 1.0:
+            ops.wave_scale(dl, self._scale_scalar(loss_scale), dl, 1, M * Vp)
         ops.cast_f32_bf16(dl, w["dlogits16"], M * Vp)
         d16 = w["dlogits16"]
         ops.gemm(d16, w["hf"], g32, M=V, N=d, K=M, a_layout=MNMAJOR, lda=Vp, b_layout=MNMAJOR, ldb=d,
@@ -697,11 +725,11 @@ class Wav2Vec2CTCEngine:
             if not keep[l]:
                 if overwrite_matrices:  # dropped layer: its matrices get no gradient this step
                     lo = o(f"wav2vec2.encoder.layers.{l}.attention.q_proj.weight")
-                    g32[lo:st.buckets[f"layer{l}"][1]].zero_()
+                    ops.clear_f32(g32, st.buckets[f"layer{l}"][1] - lo, off=lo)
                     if plan is not None:
                         a0 = plan["slot_off"][(l, "qkv")]
                         a1 = plan["slot_off"][(l + 1, "qkv")] if l + 1 < L else plan["nslots"]
-                        plan["slots"][a0:a1].zero_()
+                        ops.clear_f32(plan["slots"], a1 - a0, off=a0)
                 done(f"layer{l}")
                 continue
             pl = f"wav2vec2.encoder.layers.{l}."
@@ -856,6 +884,16 @@ class Wav2Vec2CTCEngine:
                       st.view(p0 + "layer_norm.weight", "g32"), st.view(p0 + "layer_norm.bias", "g32"),
                       part, B, N, s.conv_dim[0], s.conv_kernel[0], s.conv_stride[0], s.layer_norm_eps)
         done("front")
+
+    def _scale_scalar(self, v: float) -> torch.Tensor:
+        """A device scalar holding `v` (cached per value: 1/accum, no fill kernel per step)."""
+        cache = self.__dict__.setdefault("_scalars", {})
+        t = cache.get(v)
+        if t is None:
+            if len(cache) > 64:
+                cache.clear()
+            t = cache[v] = torch.full((1,), float(v), dtype=torch.float32, device=self.device)
+        return t
 
     def _wgrad_stream(self):
         """The weight gradients' stream (None = everything on the current stream; CA_WGRAD_STREAM=0)."""

@@ -16,8 +16,9 @@ import numpy as np
 import torch
 
 from .model_setup import ModelSetup, PreTrainedModelData, _training_args
-from .trainer import DataParallelTrainer
+from .coral_trainer import CoralTrainer
 from . import specaugment
+from .autograd import attach_backward
 from .whisper import CORAL_WHISPER_SHAPES, N_SAMPLES, WhisperEngine, WhisperShape, sinusoid_positions
 from .whisper_train import WhisperTrainEngine
 
@@ -180,8 +181,13 @@ class WhisperForConditionalGeneration:
                 mask_time, mask_feature = self.sample_spec_masks(input_features.shape[0])
             if enc_keep is None and dec_keep is None:
                 enc_keep, dec_keep = self.sample_layer_keep()
-            return self.engine(input_features, labels, mask_time, mask_feature, enc_keep, dec_keep)
+            out = self.engine(input_features, labels, mask_time, mask_feature, enc_keep, dec_keep)
+            if out.get("loss") is not None:  # `out["loss"].backward()` runs the engine's backward (coral_amd/autograd.py)
+                out["loss"] = attach_backward(self, out["loss"])
+            return out
         return self.engine.forward(input_features, labels, decoder_input_ids)
+
+    backward_kwargs: dict | None = None
 
     def backward(self, **kw):
         return self.engine.backward(**kw)
@@ -241,7 +247,7 @@ class WhisperModelSetup(ModelSetup):
         return collate
 
     def load_trainer_class(self):
-        return DataParallelTrainer
+        return CoralTrainer
 
     def load_compute_metrics(self):
         def compute(pred_ids, label_ids):

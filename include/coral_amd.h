@@ -373,6 +373,11 @@ int ca_conv_weight_grad_reorder(const float* dwr, float* dw, int32_t Co, int32_t
  * ---------------------------------------------------------------------------------- */
 int ca_sumsq_f32(const float* g, int64_t n, float* out, int32_t accumulate, float* partial,
                  void* stream);
+/* Zero a list of ranges of one device buffer in ONE launch: the per-step `optimizer.zero_grad()` of
+ * $TF/trainer.py:1796 restricted to what the next backward accumulates into (the weight-matrix gradients are
+ * overwritten by their GEMMs), and the engines' other per-step clears.  ranges_bytes: device array of nranges
+ * (offset, length) pairs in BYTES relative to base, multiples of 4; max_bytes: the longest range (sizes the grid). */
+int ca_clear_ranges(void* base, const int64_t* ranges_bytes, int32_t nranges, int64_t max_bytes, void* stream);
 /* out[0] (+)= sum of g^2 over the listed chunks: chunks = device array of nchunks (offset, length) pairs in floats,
  * offsets multiples of 4; partial: >= nchunks floats.  ca_sum_f32: out[0] (+)= sum x[i] in a fixed order (partial: >= 256
  * floats) - the per-tile partials CaGemmDesc.c_sumsq collects.  Together they are clip_grad_norm_'s squared norm

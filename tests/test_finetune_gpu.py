@@ -8,6 +8,7 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
 
 
 def test_finetune_entry_point_and_roundtrip(tmp_path, monkeypatch):
@@ -31,6 +32,8 @@ def test_finetune_entry_point_and_roundtrip(tmp_path, monkeypatch):
                                    "logging_steps=1", "eval_steps=2"])
     hist = res["history"]
     assert any("loss" in h for h in hist) and any("val_cer" in h for h in hist)
+    # the path a CoRal user runs IS the measured one: the training batches went raw PCM -> device input pipeline
+    assert res["trainer"].pipeline_batches == 2 and res["trainer"]._pipe is not None
     mdir = tmp_path / "smoke"
     assert (mdir / "model.safetensors").exists() and (mdir / "config.json").exists() and (mdir / "vocab.json").exists()
     cfg = json.loads((mdir / "config.json").read_text())
@@ -180,3 +183,149 @@ def test_checkpoints_rotate_and_resume_continues_the_run(tmp_path, monkeypatch):
     # resume_from_checkpoint=true picks the newest checkpoint (step 6 = the end of the run): nothing left to do
     done = finetune_asr_model.main(common + ["model_id=full", "max_steps=6", "resume_from_checkpoint=true"])
     assert done["steps_done"] == 6 and torch.equal(done["model"].engine.store.p32, a)
+
+
+def _tiny_config(tmp_path, monkeypatch, extra=()):
+    import sys
+    from pathlib import Path
+
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1] / "scripts"))
+    from coral_amd import modeling
+    from coral_amd.config import load_config
+
+    monkeypatch.setitem(modeling.HUB_SHAPES, "facebook/wav2vec2-xls-r-300m",
+                        dict(hidden_size=128, num_hidden_layers=2, intermediate_size=256, num_attention_heads=4))
+    return load_config("asr_finetuning", ["model=test-wav2vec2", "datasets=synthetic", f"models_dir={tmp_path}",
+                                          "model_id=t", "max_steps=3", "total_batch_size=2", "per_device_batch_size=2",
+                                          "max_seconds_per_example=2.0", "min_seconds_per_example=1.0", "logging_steps=1",
+                                          "eval_steps=3", "model.freeze_feature_encoder=false", *extra])
+
+
+def test_trainer_class_takes_the_reference_call_verbatim(tmp_path, monkeypatch):
+    """`load_trainer_class()(model=, data_collator=, args=, compute_metrics=, train_dataset=, eval_dataset=,
+    processing_class=, callbacks=)` then `.train(resume_from_checkpoint=)` - the call of R/src/coral/finetune.py:60-79,
+    keyword for keyword, with transformers' own EarlyStoppingCallback class where it is importable.  The training
+    batches must come through the device input pipeline (raw PCM -> GPU normalise / augment / featurise)."""
+    from coral_amd.data import load_data_for_finetuning
+    from coral_amd.model_setup import load_model_setup
+
+    try:
+        from transformers.trainer_callback import EarlyStoppingCallback
+    except Exception:  # noqa: BLE001
+        from coral_amd.coral_trainer import EarlyStoppingCallback
+    config = _tiny_config(tmp_path, monkeypatch, ["early_stopping=true", "early_stopping_patience=5"])
+    model_setup = load_model_setup(config)
+    processor = model_setup.load_processor()
+    model = model_setup.load_model()
+    dataset = load_data_for_finetuning(config, processor)
+    p0 = model.engine.store.p32.clone()
+    trainer = model_setup.load_trainer_class()(
+        model=model,
+        data_collator=model_setup.load_data_collator(),
+        args=model_setup.load_training_arguments(),
+        compute_metrics=model_setup.load_compute_metrics(),
+        train_dataset=dataset["train"],
+        eval_dataset=dataset["val"],
+        processing_class=getattr(processor, "tokenizer"),
+        callbacks=[EarlyStoppingCallback(early_stopping_patience=config.early_stopping_patience)],
+    )
+    out = trainer.train(resume_from_checkpoint=config.resume_from_checkpoint)
+    assert out.global_step == 3 and np.isfinite(out.training_loss)
+    assert trainer.pipeline_batches == 3 and trainer._pipe is not None and trainer._pipe.augment is not None
+    assert not torch.equal(model.engine.store.p32, p0)
+    hist = trainer.state["log_history"]
+    assert [h["step"] for h in hist if "loss" in h] == [1, 2, 3] and any("val_cer" in h for h in hist)
+    m = trainer.evaluate()
+    assert set(m) == {"eval_cer", "eval_wer"} and m["eval_cer"] >= 0.0
+    model.save_pretrained(config.model_dir)
+    assert (tmp_path / "t" / "model.safetensors").exists()
+
+
+def test_loss_backward_drives_the_engine_backward():
+    """`model(**batch)["loss"]` is a scalar with autograd ($TF/trainer.py:2005,2038).  `loss.backward()`
+    fills the same flat gradient buffer, bit for bit, as `engine.backward()`; `(loss / 2).backward()` scales it by
+    exactly 1/2 (the incoming gradient is applied on the device); a second backward through the same graph and a
+    backward after a newer forward raise instead of silently re-running kernels."""
+    from coral_amd.modeling import Wav2Vec2ForCTC
+    from coral_amd.wav2vec2 import Wav2Vec2Shape
+    from oracle import wav2vec2_ref as ref
+
+    kw = dict(hidden_size=128, num_hidden_layers=2, num_attention_heads=4, intermediate_size=256)
+    model = Wav2Vec2ForCTC(Wav2Vec2Shape(**kw), DEV)
+    model.engine.load_state_dict(ref.synth_params(ref.W2V2Config(**kw)))
+    g = torch.Generator().manual_seed(3)
+    waves = [(0.1 * torch.randn(n, generator=g)).numpy() for n in (8000, 6400)]
+    iv, am = ref.zero_mean_unit_var_norm(waves)
+    batch = dict(input_values=torch.from_numpy(iv), attention_mask=torch.from_numpy(am).long(),
+                 labels=torch.randint(0, 42, (2, 6), generator=g))
+    eng = model.engine
+    eng.zero_grad()
+    out = model(**batch)
+    assert out["loss"].requires_grad and out.loss.grad_fn is not None and out[0] is out["loss"]
+    eng.backward()
+    torch.cuda.synchronize()
+    direct = eng.store.g32.clone()
+    assert float(direct.abs().sum()) > 0
+    eng.zero_grad()
+    out = model(**batch)
+    out.loss.backward()
+    torch.cuda.synchronize()
+    assert torch.equal(eng.store.g32, direct)
+    with pytest.raises(RuntimeError):
+        out.loss.backward()
+    eng.zero_grad()
+    (model(**batch)["loss"] / 2).backward()
+    torch.cuda.synchronize()
+    assert torch.equal(eng.store.g32, direct * 0.5)
+    stale = model(**batch)
+    model(**batch)
+    with pytest.raises(RuntimeError):
+        stale.loss.backward()
+    with torch.no_grad():
+        assert not model(**batch).loss.requires_grad
+
+
+def test_checkpoint_on_a_save_only_step_holds_the_finished_update(tmp_path, monkeypatch):
+    """A checkpoint written on a step that does not evaluate must contain the parameters AFTER that step's AdamW (which
+    may still be running bucket by bucket on the optimiser stream when the save starts): same file contents as a run
+    with the optimiser on the main stream (CA_OPT_OVERLAP=0)."""
+    from safetensors.torch import load_file
+
+    import finetune_asr_model  # noqa: F401  (path set up by _tiny_config)
+
+    res = {}
+    for overlap in ("1", "0"):
+        monkeypatch.setenv("CA_OPT_OVERLAP", overlap)
+        cfg = _tiny_config(tmp_path / overlap, monkeypatch, ["save_steps=1", "save_total_limit=5", "eval_steps=100",
+                                                             "model.mask_time_prob=0.0", "model.mask_feature_prob=0.0",
+                                                             "model.activation_dropout=0.0", "model.layerdrop=0.0"])
+        from coral_amd.finetune import finetune
+
+        finetune(cfg)
+        res[overlap] = [load_file(str(tmp_path / overlap / "t" / f"checkpoint-{k}" / "model.safetensors")) for k in (1, 2, 3)]
+    for a, b in zip(res["1"], res["0"]):
+        assert a.keys() == b.keys()
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
+
+
+def test_fused_gradient_norm_when_a_matrix_alternates_between_direct_and_split_k():
+    """A weight gradient whose K = B*T changes per batch can take the direct GEMM in one step (per-tile sums of squares
+    in every slot) and the split-K fallback in the next (the whole sum in slot 0): the other slots must not keep the
+    previous step's partials.  Checked on the op itself: slots after (direct, then split-K) sum to the split-K norm."""
+    from coral_amd import ops
+
+    M, N = 192, 192  # 9 slots of 64 x 64; 4 tiles of 128 -> the split-K rule applies when K divides
+    slots = torch.zeros(ops.sumsq_slots(M, N) + 3, dtype=torch.float32, device=DEV)
+    G = torch.zeros(M * N, dtype=torch.float32, device=DEV)
+    g = torch.Generator(device=DEV).manual_seed(0)
+    for K in (1001, 2048, 1001, 4096):
+        dY = torch.randn(K, M, device=DEV, generator=g).to(torch.bfloat16)
+        X = torch.randn(K, N, device=DEV, generator=g).to(torch.bfloat16)
+        ops.wgrad_gemm(dY, X, G, M=M, N=N, K=K, lda=M, ldb=N, c_off=0, accumulate=False, sq=(slots, 1))
+        torch.cuda.synchronize()
+        want = float(G.double().pow(2).sum())
+        got = float(slots[1:1 + ops.sumsq_slots(M, N)].double().sum())
+        assert abs(got - want) <= 1e-5 * want, (K, ops._wgrad_splits(M, N, K), got, want)
+        assert float(slots[0]) == 0.0 and float(slots[-2:].abs().sum()) == 0.0
+    assert {ops._wgrad_splits(M, N, K) > 1 for K in (1001, 2048)} == {False, True}
