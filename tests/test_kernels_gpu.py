@@ -76,6 +76,19 @@ def test_gemm_256x256_kernel(ops, al, bl, M, N, K):
         ops.lib().ca_gemm_force_kernel(0)
 
 
+@pytest.mark.parametrize("al,bl", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [(1000, 520, 328), (3992, 768, 704), (300, 264, 64), (512, 512, 1024), (700, 300, 200)])
+def test_gemm_256x256_one_wave_per_simd_kernel(ops, al, bl, M, N, K):
+    """Parity of kernel W (256x256 tile, 4 waves x 128x128, forced): ragged tails in both dimensions, a single
+    K-step, a partial last K-step, even and odd K-step counts (the main loop runs in pairs, the rest in the general
+    form)."""
+    ops.lib().ca_gemm_force_kernel(4)
+    try:
+        test_gemm_layouts(ops, al, bl, M, N, K)
+    finally:
+        ops.lib().ca_gemm_force_kernel(0)
+
+
 def test_gemm_epilogues_and_batch(ops):
     M, N, K, Bt = 300, 256, 192, 3
     A, W = bf(rnd(Bt, M, K, seed=3, scale=0.5)), bf(rnd(N, K, seed=4, scale=0.2))
@@ -607,7 +620,7 @@ def test_gemm_random_shapes_all_kernels(ops):
         N = int(rng.randint(1, 90)) * 8
         K = int(rng.randint(1, 60)) * 8
         al, bl = int(rng.randint(0, 2)), int(rng.randint(0, 2))
-        for force in (1, 3):
+        for force in (1, 3, 4):
             ops.lib().ca_gemm_force_kernel(force)
             try:
                 test_gemm_layouts(ops, al, bl, M, N, K)
