@@ -171,22 +171,19 @@ def spawn_ranks(n: int) -> int:
     return subprocess.run(cmd, env=env).returncode
 
 
-def whisper_bench(args, world, rank, device):
-    """Secondary workload (BASELINE.json configs[3]/[4] shapes, bf16): Whisper teacher-forced finetune
-    step on 30 s clips (log-mel on the GPU inside the step) or greedy decoding (--decode)."""
+def whisper_setup_engine(model, device, rank, B):
+    """Random-init Whisper training engine of a CoRal model key + one synthetic batch (0.1*randn clips of
+    7..30 s zero-padded to 30 s, labels U{0..50256} of length U{20..120})."""
     import numpy as np
+    import yaml
 
-    from coral_amd import ops
-    from coral_amd.trainer import DataParallelTrainer
     from coral_amd.whisper import CORAL_WHISPER_SHAPES, N_SAMPLES, WhisperShape
     from coral_amd.whisper_train import WhisperTrainEngine
 
-    shape = WhisperShape(**CORAL_WHISPER_SHAPES[args.model])
+    shape = WhisperShape(**CORAL_WHISPER_SHAPES[model])
     # dropouts of the CoRal model key (config/model/<key>.yaml = R/config/model/<key>.yaml): whisper-medium trains with
     # activation_dropout 0.1, whisper-large-turbo with hidden-state dropout 0.1
-    import yaml
-
-    mcfg = yaml.safe_load((ROOT / "config" / "model" / f"{args.model}.yaml").read_text())
+    mcfg = yaml.safe_load((ROOT / "config" / "model" / f"{model}.yaml").read_text())
     eng = WhisperTrainEngine(shape, device, activation_dropout=float(mcfg.get("activation_dropout", 0.0)),
                              dropout=float(mcfg.get("dropout", 0.0)))
     g = torch.Generator(device=device).manual_seed(4242)
@@ -197,7 +194,6 @@ def whisper_bench(args, world, rank, device):
         elif n.endswith(".bias"):
             v.zero_()
         elif n == "model.encoder.embed_positions.weight":
-            from coral_amd.whisper_setup import WhisperForConditionalGeneration  # noqa: F401
             T, d = shape.max_source_positions, shape.d_model
             inc = np.log(10000.0) / (d // 2 - 1)
             inv = torch.exp(-inc * torch.arange(d // 2, device=device))
@@ -206,29 +202,48 @@ def whisper_bench(args, world, rank, device):
         else:
             v.normal_(0.0, 0.02, generator=g)
     eng.refresh_compute_weights()
-    B = args.batch
     gen = torch.Generator().manual_seed(4242 + rank)
     waves = torch.zeros(B, N_SAMPLES)
     for b in range(B):
         n = int(torch.randint(112_000, N_SAMPLES + 1, (1,), generator=gen))
         waves[b, :n] = 0.1 * torch.randn(n, generator=gen)
-    waves = waves.to(device)
     tl = torch.randint(20, 121, (B,), generator=gen)
     labels = torch.full((B, int(tl.max())), -100, dtype=torch.int64)
     for b in range(B):
         labels[b, :tl[b]] = torch.randint(0, 50257, (int(tl[b]),), generator=gen)
-    trainer = DataParallelTrainer(eng, learning_rate=6e-6, betas=(0.9, 0.98), warmup_steps=1000, max_steps=100_000,
-                                  compress_grads=(args.grad_wire == "bf16"))
+    return eng, shape, waves.to(device), labels
 
-    if args.decode and args.fp8_encoder:
+
+def whisper_decode_bytes_per_token(eng, shape, B) -> float:
+    """Algorithmic HBM bytes of ONE greedy step: every bf16 decoder weight once (the tied
+    proj_out = embed_tokens matrix included) + the cross-attention K|V cache of every decoder layer for every clip."""
+    w = sum(int(torch.tensor(shp).prod()) for n, (_, shp) in eng.store.index.items()
+            if n.startswith("model.decoder.") and not n.endswith("__zero")) * 2
+    kv = shape.decoder_layers * B * shape.max_source_positions * shape.d_model * 2 * 2
+    return float(w + kv)
+
+
+def whisper_measure(model, args, world, rank, device, decode=False, fp8=False, B=None, steps=None, warmup=None):
+    """One Whisper workload: teacher-forced finetune step on 30 s clips (log-mel on the GPU inside the step) or greedy
+    decoding (`decode`).  -> dict(ms_per_step, value, ...) on every rank."""
+    from coral_amd.trainer import DataParallelTrainer
+
+    B = B or args.batch
+    steps = steps or args.steps
+    warmup = args.warmup if warmup is None else warmup
+    eng, shape, waves, labels = whisper_setup_engine(model, device, rank, B)
+    trainer = None if decode else DataParallelTrainer(eng, learning_rate=6e-6, betas=(0.9, 0.98), warmup_steps=1000,
+                                                      max_steps=100_000, compress_grads=(args.grad_wire == "bf16"))
+    if decode and fp8:
         eng.enable_fp8_encoder()
-    if args.fp8_forward and not args.decode:
+    if fp8 and not decode:
         eng.enable_fp8_forward()
+    prefix = [50258, 50285, 50359, 50363]
 
-    def step():
+    def step(new_tokens=args.decode_tokens):
         feats = eng.log_mel(waves)  # front end on the GPU, inside the step
-        if args.decode:
-            return eng.generate(feats, [50258, 50285, 50359, 50363], 4 + args.decode_tokens)
+        if decode:
+            return eng.generate(feats, prefix, 4 + new_tokens)
         return trainer.train_step([dict(input_features=feats, labels=labels)])
 
     def sync():
@@ -236,26 +251,52 @@ def whisper_bench(args, world, rank, device):
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    def timed(n, **kw):
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step(**kw)
+        sync()
+        return (time.perf_counter() - t0) / n
+
+    for _ in range(warmup):
         step()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    sync()
-    dt = time.perf_counter() - t0
+    dt = timed(steps)
+    res = dict(ms_per_step=dt * 1e3, value=world * B * 30.0 / dt, B=B, label_len=int(labels.shape[1]),
+               dropout=eng.dropout, activation_dropout=eng.activation_dropout, engine=eng, shape=shape)
+    if decode:
+        # the per-token time without the log-mel + encoder part: (T(n2 new tokens) - T(n1 new tokens)) / (n2 - n1)
+        n1, n2 = 8, 8 + args.decode_tokens
+        step(new_tokens=n1)
+        t1, t2 = timed(max(2, steps // 2), new_tokens=n1), timed(max(2, steps // 2), new_tokens=n2)
+        per_tok = (t2 - t1) / (n2 - n1)
+        byt = whisper_decode_bytes_per_token(eng, shape, B)
+        res.update(ms_per_token=per_tok * 1e3, bytes_per_token=byt, hbm_frac=byt / per_tok / 8.0e12)
+    if trainer is not None:
+        trainer.finish()
+        torch.cuda.synchronize()
+    return res
+
+
+def whisper_bench(args, world, rank, device):
+    """Secondary workload (BASELINE.json configs[3]/[4] shapes): `--model whisper-*` [--decode] [--fp8-forward]."""
+    fp8 = (args.decode and args.fp8_encoder) or (args.fp8_forward and not args.decode)
+    r = whisper_measure(args.model, args, world, rank, device, decode=args.decode, fp8=fp8)
+    eng, B = r["engine"], r["B"]
     if rank == 0:
-        audio_s = world * B * 30.0 * args.steps
         mode = f"greedy decode, {args.decode_tokens} new tokens" if args.decode else "finetune step fwd+bwd+clip+AdamW, teacher-forced"
+        cfg = {"workload": f"{args.model} {mode}, {B} x 30 s per GPU, log-mel on GPU, dropout {r['dropout']:g} / "
+                           f"activation_dropout {r['activation_dropout']:g}", "global_batch": world * B,
+               "label_len": r["label_len"], "parallelism": f"dp{world}"}
+        if args.decode:
+            cfg.update(ms_per_token=round(r["ms_per_token"], 4), bytes_per_token=int(r["bytes_per_token"]),
+                       hbm_frac_of_8TBps=round(r["hbm_frac"], 4))
         print(json.dumps({
-            "metric": f"audio-seconds/sec ({mode}), {args.model}, 30 s clips", "value": round(audio_s / dt, 2),
+            "metric": f"audio-seconds/sec ({mode}), {args.model}, 30 s clips", "value": round(r["value"], 2),
             "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16 + fp8 e4m3 (encoder q|k|v, fc1 forward)" if ((args.decode and args.fp8_encoder) or (args.fp8_forward and not args.decode)) else "bf16",
-            "data": "synthetic",
-            "config": {"workload": f"{args.model} {mode}, {B} x 30 s per GPU, log-mel on GPU, dropout {eng.dropout:g} / "
-                                   f"activation_dropout {eng.activation_dropout:g}", "global_batch": world * B,
-                       "label_len": int(labels.shape[1]), "parallelism": f"dp{world}"}}), flush=True)
+            "ms_per_step": round(r["ms_per_step"], 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16 + fp8 e4m3 (encoder q|k|v, fc1 forward)" if fp8 else "bf16",
+            "data": "synthetic", "config": cfg}), flush=True)
     if world > 1:
         if args.check_replicas and not args.decode:
             torch.cuda.synchronize()
@@ -287,7 +328,8 @@ def run_w2v2(model_key, args, world, rank, device, roofline: bool):
     eng = Wav2Vec2CTCEngine(shape, device)
     init_random_(eng, 4242)
     trainer = DataParallelTrainer(eng, learning_rate=1e-4, betas=(0.9, 0.98), max_grad_norm=1.0,
-                                  warmup_steps=1000, max_steps=100_000, compress_grads=(args.grad_wire == "bf16"))
+                                  warmup_steps=1000, max_steps=100_000, compress_grads=(args.grad_wire == "bf16"),
+                                  zero_stage=args.zero_stage)
     batch, lens = synth_batch(args.batch, args.seconds, rank, device, ragged=args.ragged)
     B, N = batch["input_values"].shape
     Ts = eng.conv_lengths(N)
@@ -424,10 +466,14 @@ def main():
                     help="dtype of the gradient all-reduce at N>1: fp32 = what the reference's DDP reduces (accelerate "
                          "bf16 autocast keeps fp32 gradients); bf16 = the DDP bf16_compress_hook trade, a separate "
                          "labelled measurement, never the headline")
+    ap.add_argument("--zero-stage", type=int, default=0,
+                    help="N>1: shard the optimiser over the ranks (reduce-scatter of the weight-matrix gradients, AdamW on "
+                         "1/N, all-gather of the bf16 weights) - the reference's `accelerate launch --zero-stage 2` mode "
+                         "(R/makefile:79-84); 0 = replicated DDP semantics (default)")
     ap.add_argument("--ragged", action="store_true",
                     help="utterance lengths ~ U[1 s, --seconds] padded to --seconds (the regime of "
                          "R/config/asr_finetuning.yaml:31-32): masked attention / CTC lengths / SpecAugment on valid frames")
-    ap.add_argument("--no-also", action="store_true", help="skip the second (24L/1024 = wav2vec2-small) measurement")
+    ap.add_argument("--no-also", action="store_true", help="skip the secondary measurements (config.also*)")
     ap.add_argument("--no-fwd-bwd", action="store_true", help="skip the extra forward+backward-only timing (profile runs)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for 1-GPU debugging of the N>1 logic)")
     ap.add_argument("--check-replicas", action="store_true", help="after the run, verify every rank holds identical parameters")
@@ -501,7 +547,8 @@ def main():
                                    f", SpecAugment {'off' if args.no_specaugment else 'on'}, activation_dropout 0.1, "
                                    "layerdrop 0 (multi-GPU rule), fp32 master + AdamW + clip 1.0"
                                    + (", inputs from host int16 PCM through the device input pipeline" if args.from_host_pcm else "")
-                                   + (f", gradient all-reduce ({args.backend}) on {wire}, per-layer buckets overlapped with backward" if world > 1 else "")
+                                   + (f", gradient all-reduce ({args.backend}) on {wire}, per-layer buckets overlapped with backward" if world > 1 and not args.zero_stage else "")
+                                   + (f", sharded optimiser (zero_stage {args.zero_stage}): gradient reduce-scatter ({args.backend}) on {wire} per layer bucket overlapped with backward, AdamW on 1/{world}, bf16 all-gather under the next forward" if world > 1 and args.zero_stage else "")
                                    + (f" [DIAGNOSTIC: N>1 exchange path forced over an RCCL group of one rank, {args.grad_wire} wire]" if args.one_rank_exchange and world == 1 else ""),
                        "global_batch": world * B, "frames_per_utt": T, "parallelism": f"dp{world}",
                        "loss": round(loss_val, 3),
@@ -531,6 +578,43 @@ def main():
                                  "value": r2["value"], "unit": "audio-seconds/sec", "ms_per_step": round(r2["ms_per_step"], 3),
                                  "step_frac_of_peak": round(r2["step_tflop"] / (r2["ms_per_step"] * 1e-3) / MFMA_BF16_DENSE_PEAK_TFLOPS, 4)}
         eng = None
+        # The secondary workloads the round-2 review asked to be driver-visible, each run AFTER (outside) the headline's
+        # timed region, with their own short warm-up: R/makefile:90's production batch (wav2vec2-small, 64 per device),
+        # BASELINE configs[3] (whisper-medium greedy decode: ms per token against its HBM floor) and configs[4]'s
+        # architecture (whisper-large-turbo finetune step, bf16 and with the fp8 forward projections).
+        import copy
+
+        a2 = copy.copy(args)
+        a2.batch, a2.steps, a2.warmup = 64, max(3, args.steps // 2), 2
+        r3 = run_w2v2("wav2vec2-small", a2, world, rank, device, roofline=False)
+        del r3["engine"]
+        out["config"]["also_b64"] = {"workload": "wav2vec2-small (XLS-R-300M), 64 x 10 s per GPU = the reference's production "
+                                                 "per_device_batch_size (R/makefile:90), same step",
+                                     "value": r3["value"], "unit": "audio-seconds/sec", "ms_per_step": round(r3["ms_per_step"], 3),
+                                     "step_frac_of_peak": round(r3["step_tflop"] / (r3["ms_per_step"] * 1e-3) / MFMA_BF16_DENSE_PEAK_TFLOPS, 4)}
+        del r3
+        torch.cuda.empty_cache()
+        dec = {}
+        for Bd in (8, 16, 32):
+            r4 = whisper_measure("whisper-medium", args, world, rank, device, decode=True, B=Bd, steps=3, warmup=1)
+            dec[f"B{Bd}"] = {"ms_per_token": round(r4["ms_per_token"], 4), "bytes_per_token": int(r4["bytes_per_token"]),
+                             "frac_of_8TBps": round(r4["hbm_frac"], 4),
+                             "audio_s_per_s_incl_logmel_encoder": round(r4["value"], 1)}
+            del r4
+            torch.cuda.empty_cache()
+        out["config"]["also_decode"] = dict(workload=f"whisper-medium greedy decode (log-mel + encoder + {args.decode_tokens} "
+                                                     "K|V-cached, graph-replayed decoder steps), 30 s clips; per-token time = "
+                                                     "difference of two generation lengths; bytes = bf16 decoder weights + "
+                                                     "cross K|V cache per step", **dec)
+        tb = {}
+        for fp8 in (False, True):
+            r5 = whisper_measure("whisper-large-turbo", args, world, rank, device, decode=False, fp8=fp8, B=8, steps=4, warmup=2)
+            tb["fp8_forward" if fp8 else "bf16"] = {"ms_per_step": round(r5["ms_per_step"], 3), "value": round(r5["value"], 1)}
+            del r5
+            torch.cuda.empty_cache()
+        out["config"]["also_turbo"] = dict(workload="whisper-large-turbo finetune step (teacher-forced, dropout 0.1), 8 x 30 s, "
+                                                    "log-mel on GPU; fp8_forward = e4m3 forward projections (DESIGN.md 4.4)",
+                                           unit="audio-seconds/sec", **tb)
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

@@ -239,7 +239,7 @@ class CoralTrainer:
         torch.cuda.synchronize()
         self.model.save_pretrained(output_dir or self.args.output_dir)
 
-    def _save_checkpoint(self, step: int) -> Path:
+    def _save_checkpoint(self, step: int, moments=None) -> Path:
         """`checkpoint-<step>/`: the model in HF layout, the optimiser moments and the trainer state
         (Trainer._save_checkpoint + rotation, $TF/trainer.py:3079,3326; `save_total_limit` never deletes the best)."""
         from safetensors.torch import save_file
@@ -251,7 +251,8 @@ class CoralTrainer:
         self.finish()
         torch.cuda.synchronize()
         self.model.save_pretrained(d)
-        save_file(dict(m=self.dp.m.cpu(), v=self.dp.v.cpu()), str(d / "optimizer.safetensors"))
+        m, v = moments if moments is not None else (self.dp.m, self.dp.v)
+        save_file(dict(m=m.cpu(), v=v.cpu()), str(d / "optimizer.safetensors"))
         st = {k: self.state[k] for k in ("epoch", "best_metric", "best_step", "bad_evals")}
         (d / "trainer_state.json").write_text(json.dumps(dict(global_step=step, **st), indent=1))
         limit = self.args.save_total_limit
@@ -284,8 +285,7 @@ class CoralTrainer:
         if hasattr(eng, "refresh_derived"):
             eng.refresh_derived()
         opt = load_file(str(ckpt / "optimizer.safetensors"))
-        self.dp.m.copy_(opt["m"])
-        self.dp.v.copy_(opt["v"])
+        self.dp.load_moments(opt["m"].to(self.dp.m.device), opt["v"].to(self.dp.v.device))
         state = json.loads((ckpt / "trainer_state.json").read_text())
         self.dp.opt_step = int(state["global_step"])
         return state
@@ -381,8 +381,10 @@ class CoralTrainer:
                 stop = self.patience is not None and self.state["bad_evals"] >= self.patience
             save_now = a.save_strategy != "no" and ((step + 1) % a.save_steps == 0 or
                                                     (self.state["best_step"] == step + 1 and a.load_best_model_at_end))
+            # (sharded optimiser: every rank takes part in gathering the master parameters and moments rank 0 writes)
+            moments = self.dp.consolidate() if (save_now and self.dp.zero) else None
             if save_now and self.is_main:
-                d = self._save_checkpoint(step + 1)
+                d = self._save_checkpoint(step + 1, moments)
                 if self.state["best_step"] == step + 1:
                     self.best_dir = d
             if save_now and torch.distributed.is_available() and torch.distributed.is_initialized():
@@ -393,6 +395,8 @@ class CoralTrainer:
                                 self.state["best_step"])
                 break
         self.finish()  # the last optimiser step may still be running on the trainer's side stream
+        if self.dp.zero:
+            self.dp.consolidate()  # the master parameters `model.save_pretrained` reads are complete on every rank again
         torch.cuda.synchronize()
         self.state["global_step"] = step + 1
         if a.load_best_model_at_end and self.state["best_step"] and self.state["best_step"] != step + 1:

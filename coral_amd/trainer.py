@@ -36,6 +36,17 @@ def grad_accumulation_steps(total_batch_size: int, num_devices: int, per_device_
     return max(1, total_batch_size // max(1, num_devices) // per_device_batch_size)
 
 
+class _Handles:
+    """Several asynchronous collectives waited for as one."""
+
+    def __init__(self, hs):
+        self.hs = hs
+
+    def wait(self):
+        for h in self.hs:
+            h.wait()
+
+
 class GradSync:
     """Bucketed gradient all-reduce over a flat fp32 buffer (device-agnostic, so the N>1 logic is
     testable with gloo on CPU).  `start(name)` launches the asynchronous SUM all-reduce of one
@@ -48,13 +59,28 @@ class GradSync:
     the fp32 buffer is refilled from the reduced bf16 values."""
 
     def __init__(self, flat_grad: torch.Tensor, buckets: dict, process_group=None, compress: bool = False,
-                 force: bool = False):
+                 force: bool = False, shard: dict | None = None):
+        """shard: {bucket name: (mlo, hi)} - the part of a bucket that is REDUCE-SCATTERED instead of all-reduced
+        (sharded optimiser, see DataParallelTrainer zero_stage): rank r ends up with the sum over ranks of its slice
+        [mlo + r * per, mlo + (r + 1) * per), per = (hi - mlo) / world, and nothing defined elsewhere in [mlo, hi); the
+        rest of the bucket [lo, mlo) is all-reduced as before."""
         self.g = flat_grad
         self.buckets = buckets
         self.pg = process_group
         self.world = 1
+        self.rank = 0
         if torch.distributed.is_available() and torch.distributed.is_initialized():
             self.world = torch.distributed.get_world_size(process_group)
+            self.rank = torch.distributed.get_rank(process_group)
+        self.shard = dict(shard or {})
+        for name, (mlo, hi) in self.shard.items():
+            lo, bhi = buckets[name]
+            if not (lo <= mlo <= hi == bhi) or (hi - mlo) % (8 * max(1, self.world)):
+                raise ValueError(f"shard range of bucket {name!r} must end the bucket and divide into 32-byte aligned slices")
+        # reduce_scatter_tensor exists on RCCL; the CPU test backend (gloo) has none: there the slice is cut out of an
+        # all-reduce (the same sums; at two ranks the same bits)
+        self._has_rs = (torch.distributed.is_available() and torch.distributed.is_initialized()
+                        and torch.distributed.get_backend(process_group) == "nccl")
         # force (or CA_DP_FORCE=1): run the whole exchange path with a process group of one rank - how the RCCL
         # plumbing (communication stream, asynchronous handles, per-bucket callbacks) is exercised on a 1-GPU box
         force = force or os.environ.get("CA_DP_FORCE", "0") == "1"
@@ -78,12 +104,30 @@ class GradSync:
         else:
             self.g[lo:hi].copy_(self.g16[lo:hi])
 
-    def _launch(self, lo, hi):
+    def slice_of(self, name: str):
+        """This rank's slice (a, b) of bucket `name`'s sharded part."""
+        mlo, hi = self.shard[name]
+        per = (hi - mlo) // self.world
+        return mlo + self.rank * per, mlo + (self.rank + 1) * per
+
+    def _launch(self, lo, hi, name=None):
         buf = self.g
         if self.compress:
             self._to_wire(lo, hi)
             buf = self.g16
-        return torch.distributed.all_reduce(buf[lo:hi], op=torch.distributed.ReduceOp.SUM, group=self.pg, async_op=True)
+        SUM = torch.distributed.ReduceOp.SUM
+        if name is None or name not in self.shard:
+            return torch.distributed.all_reduce(buf[lo:hi], op=SUM, group=self.pg, async_op=True)
+        mlo, _ = self.shard[name]
+        hs = []
+        if mlo > lo:
+            hs.append(torch.distributed.all_reduce(buf[lo:mlo], op=SUM, group=self.pg, async_op=True))
+        a, b = self.slice_of(name)
+        if self._has_rs:  # in place: the output slice sits at input + rank * count, RCCL's in-place form
+            hs.append(torch.distributed.reduce_scatter_tensor(buf[a:b], buf[mlo:hi], op=SUM, group=self.pg, async_op=True))
+        else:
+            hs.append(torch.distributed.all_reduce(buf[mlo:hi], op=SUM, group=self.pg, async_op=True))
+        return _Handles(hs)
 
     def start(self, name: str, post=None):
         """post(name): run on the communication stream as soon as the bucket's reduced gradients are in
@@ -94,7 +138,7 @@ class GradSync:
         self.launched.append(name)
 
         def go():
-            h = self._launch(lo, hi)
+            h = self._launch(lo, hi, name)
             if post is None:
                 return h
             h.wait()  # stream-level wait on a GPU, blocking on the CPU backends
@@ -153,7 +197,15 @@ class DataParallelTrainer:
 
     def __init__(self, engine, learning_rate=1e-4, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.0,
                  max_grad_norm=1.0, warmup_steps=1000, max_steps=100_000, grad_accum=1,
-                 process_group=None, overlap=True, compress_grads=False, overlap_optimizer=True):
+                 process_group=None, overlap=True, compress_grads=False, overlap_optimizer=True, zero_stage=0):
+        """zero_stage > 0 (N > 1): the reference's production launch mode (`accelerate launch --use-deepspeed
+        --zero-stage 2`, R/makefile:79-84,94-99,109-114) in this engine's terms - the weight-matrix part of every layer
+        bucket (> 99 % of the parameters) is REDUCE-SCATTERED instead of all-reduced, each rank keeps AdamW moments for
+        and updates only its 1/N slice, and the bf16 compute copy of the slices is all-gathered bucket by bucket under
+        the next forward.  Per step and rank at XLS-R-2B, N = 8: AdamW traffic 64.8 -> 8.1 GB, wire 2 x 7/8 x 8.64 GB
+        (all-reduce) -> 7/8 x 8.64 GB (reduce-scatter, fp32) + 7/8 x 4.32 GB (all-gather, bf16).  The small tensors of
+        a layer, the front and the head bucket stay replicated.  The update is the same arithmetic on the same sums:
+        parameters equal the replicated trainer's (tests/test_dp_gloo.py, tests/test_dp_gpu.py)."""
         self.model = engine                          # HF-shaped wrapper or the bare engine
         engine = getattr(engine, "engine", engine)  # the kernel-sequencing engine underneath
         self.engine = engine
@@ -163,19 +215,44 @@ class DataParallelTrainer:
         self.grad_accum = grad_accum
         self.opt_step = 0
         st = engine.store
-        self.m = torch.zeros_like(st.p32)
-        self.v = torch.zeros_like(st.p32)
-        self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=st.device)
-        self.partial = torch.zeros(4096, dtype=torch.float32, device=st.device)
-        self.sync = GradSync(st.g32, st.buckets, process_group, compress=compress_grads)
-        self.world = self.sync.world
-        self.dist = self.sync.active  # gradients are exchanged (world > 1, or a forced one-rank group)
-        self.overlap = overlap and self.dist
         if hasattr(engine, "trainable_range"):
             lo, hi = engine.trainable_range()
         else:
             lo, hi = st.buckets["head"] if engine.freeze_base else (0, st.numel)
         self.train_range = (lo, hi)
+        world = 1
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            world = torch.distributed.get_world_size(process_group)
+        zero_stage = int(os.environ.get("CA_ZERO_STAGE", zero_stage) or 0)
+        shard = {}
+        if zero_stage and (world > 1 or os.environ.get("CA_DP_FORCE", "0") == "1") and hasattr(engine, "shard_ranges") \
+                and (lo, hi) == (0, st.numel):
+            shard = {n: r for n, r in engine.shard_ranges().items() if (r[1] - r[0]) % (8 * world) == 0 and r[1] > r[0]}
+        self.sync = GradSync(st.g32, st.buckets, process_group, compress=compress_grads, shard=shard)
+        self.zero = bool(shard) and self.sync.active
+        self.world = self.sync.world
+        self.dist = self.sync.active  # gradients are exchanged (world > 1, or a forced one-rank group)
+        self.overlap = overlap and self.dist
+        # AdamW moments.  Replicated: the parameters' own offsets.  Sharded: a compact buffer holding, bucket by bucket,
+        # the replicated part [lo, mlo) and this rank's slice of the sharded part - 1/N of the state.
+        self._state_off = None
+        if self.zero:
+            self._state_off, n = {}, 0
+            for name, (blo, bhi) in st.buckets.items():
+                if name in shard:
+                    a, b = self.sync.slice_of(name)
+                    self._state_off[name] = (n, n + (shard[name][0] - blo))
+                    n += (shard[name][0] - blo) + (b - a)
+                else:
+                    self._state_off[name] = (n, None)
+                    n += bhi - blo
+            self.m = torch.zeros(n, dtype=torch.float32, device=st.device)
+            self.v = torch.zeros(n, dtype=torch.float32, device=st.device)
+        else:
+            self.m = torch.zeros_like(st.p32)
+            self.v = torch.zeros_like(st.p32)
+        self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=st.device)
+        self.partial = torch.zeros(4096, dtype=torch.float32, device=st.device)
         # AdamW is HBM-bound, the next forward MFMA-bound: run the update bucket by bucket on a side stream
         # and let the next forward wait per bucket (engine._await) instead of for the whole optimiser.
         # (CA_OPT_OVERLAP=0: everything on one stream - the regime the per-kernel profiles are taken in)
@@ -192,7 +269,7 @@ class DataParallelTrainer:
         self.bucket_index = {name: i for i, name in enumerate(st.buckets)}
         self.bucket_sq = torch.zeros(len(st.buckets), dtype=torch.float32, device=st.device)
         self.shard_norm = os.environ.get("CA_SHARD_NORM", "1") != "0"
-        self._rank = torch.distributed.get_rank(process_group) if self.world > 1 else 0
+        self._rank = self.sync.rank
         self._norms_ready = False
         # N = 1: the squared norm of the gradients that are final early in the backward is taken on the side stream
         # while the rest of the backward runs (one HBM-bound pass beside MFMA-bound GEMMs), see _early_norm
@@ -225,7 +302,7 @@ class DataParallelTrainer:
             # Per-bucket norms during the backward pay off where the buckets are being all-reduced anyway (N > 1: the
             # squared norm rides behind each bucket's reduction on the communication stream).  At N = 1 the side-stream
             # kernels only contend with the backward GEMMs for HBM (+20 % on the weight-gradient kernel for 0.2 ms).
-            if last and self.overlap_optimizer and self.dist and self.overlap:
+            if last and self.dist and self.overlap and (self.overlap_optimizer or self.zero):
                 hook = self._bucket_ready
                 self._norms_ready = True
             elif self.dist and last and self.overlap:
@@ -259,7 +336,19 @@ class DataParallelTrainer:
         added over ranks in optimizer_step (one scalar all-reduce, identical on every rank): 1/world of the bytes."""
         lo, hi = self.engine.store.buckets[name]
         i = self.bucket_index[name]
-        if self.world > 1 and self.shard_norm:
+        if self.zero and name in self.sync.shard:
+            # sharded bucket: this rank's slice of the matrices + its 1/world piece of the replicated small tensors
+            g = self.engine.store.g32
+            a, b = self.sync.slice_of(name)
+            ops.sumsq(g[a:b], b - a, self.bucket_sq[i:i + 1], self.partial)
+            mlo = self.sync.shard[name][0]
+            per = (-(-(mlo - lo) // self.world) + 7) // 8 * 8
+            a2 = min(mlo, lo + self._rank * per)
+            b2 = min(mlo, a2 + per)
+            if b2 > a2:
+                ops.sumsq(g[a2:b2], b2 - a2, self.bucket_sq[i:i + 1], self.partial, accumulate=True)
+            return
+        if self.world > 1 and (self.shard_norm or self.zero):
             per = -(-(hi - lo) // self.world)
             per = (per + 7) // 8 * 8  # slices start 32-byte aligned
             a = min(hi, lo + self._rank * per)
@@ -314,6 +403,10 @@ class DataParallelTrainer:
         lr = cosine_lr(self.opt_step, self.lr, self.warmup_steps, self.max_steps)
         self.opt_step += 1
         plan = None if self.dist else self._norm_plan()
+        if self.zero and not self._norms_ready:  # (no per-bucket hooks ran: take the sharded norms here)
+            for name in st.buckets:
+                self._bucket_sumsq(name)
+            self._norms_ready = True
         if plan is not None:
             # N = 1: per-tile sums of squares from the weight-gradient GEMMs' epilogues + one pass over the < 1 % of the
             # buffer that is not a layer weight matrix (instead of reading all 8.6 GB of gradients again: 1.5 ms of
@@ -321,10 +414,10 @@ class DataParallelTrainer:
             ops.sumsq_ranges(st.g32, plan["chunks"], plan["nchunks"], self.gnorm_sq, plan["partial"])
             ops.sum_f32(plan["slots"], plan["nslots"], self.gnorm_sq, self.partial, accumulate=True)
         elif self._norms_ready:  # every bucket's squared norm was produced during the backward
-            if not self.dist:
+            if not self.dist and self.opt_stream is not None:
                 torch.cuda.current_stream().wait_stream(self.opt_stream)
             self.gnorm_sq.copy_(self.bucket_sq.sum().reshape(1))
-            if self.world > 1 and self.shard_norm:  # add the ranks' slices (the result is the same on every rank)
+            if self.world > 1 and (self.shard_norm or self.zero):  # add the ranks' slices (the same result on every rank)
                 torch.distributed.all_reduce(self.gnorm_sq, op=torch.distributed.ReduceOp.SUM, group=self.sync.pg)
             self._norms_ready = False
         elif self._early_lo is not None:  # the tail's squared norm is already in gnorm_sq (side stream)
@@ -334,14 +427,31 @@ class DataParallelTrainer:
         else:
             ops.sumsq(st.g32[lo:hi], n, self.gnorm_sq, self.partial)
 
-        def update(a, b):
-            ops.adamw_step(st.p32[a:b], self.m[a:b], self.v[a:b], st.g32[a:b], st.p16[a:b], b - a, lr,
-                           self.betas[0], self.betas[1], self.eps, self.wd, self.opt_step,
-                           grad_scale=1.0 / self.world, max_norm=self.max_grad_norm, gnorm_sq=self.gnorm_sq)
+        def adam(a, b, so):
+            if b > a:
+                ops.adamw_step(st.p32[a:b], self.m[so:so + b - a], self.v[so:so + b - a], st.g32[a:b], st.p16[a:b], b - a,
+                               lr, self.betas[0], self.betas[1], self.eps, self.wd, self.opt_step,
+                               grad_scale=1.0 / self.world, max_norm=self.max_grad_norm, gnorm_sq=self.gnorm_sq)
+
+        def update(a, b, name=None):
+            if not self.zero:
+                return adam(a, b, a)
+            rep_off, sl_off = self._state_off[name]
+            if sl_off is None:
+                return adam(a, b, rep_off)
+            mlo, bhi = self.sync.shard[name]
+            adam(a, mlo, rep_off)           # replicated small tensors
+            sa, sb = self.sync.slice_of(name)
+            adam(sa, sb, sl_off)            # this rank's slice of the matrices (fp32 master, moments, bf16 copy)
+            self._allgather_bf16(mlo, bhi, sa, sb)
 
         rebucket = getattr(eng, "refresh_bucket", None)  # engines with derived per-bucket weight copies (fp8)
         if not self.overlap_optimizer:
-            update(lo, hi)
+            if self.zero:
+                for name, (a, b) in st.buckets.items():
+                    update(a, b, name)
+            else:
+                update(lo, hi)
             if not eng.freeze_base:
                 eng.refresh_derived()
             if rebucket is not None:
@@ -354,7 +464,7 @@ class DataParallelTrainer:
         with torch.cuda.stream(self.opt_stream):
             order = sorted(st.buckets.items(), key=lambda kv: kv[1][0])
             for name, (a, b) in order:
-                update(a, b)
+                update(a, b, name)
                 if rebucket is not None:
                     rebucket(name)
                 parts = getattr(eng, "derived_parts", None) if name == "front" else None
@@ -380,6 +490,59 @@ class DataParallelTrainer:
             self.opt_done = torch.cuda.Event()
             self.opt_done.record(self.opt_stream)
         eng.weights_ready = events
+
+    def _allgather_bf16(self, mlo, hi, a, b):
+        """Every rank's freshly updated bf16 slice -> the whole [mlo, hi) of the compute copy, on the current stream."""
+        p16, pg = self.engine.store.p16, self.sync.pg
+        if self.sync._has_rs:  # RCCL: in place (the input slice sits at output + rank * count)
+            torch.distributed.all_gather_into_tensor(p16[mlo:hi], p16[a:b], group=pg)
+            return
+        per = b - a
+        outs = [p16[mlo + r * per: mlo + (r + 1) * per] for r in range(self.world)]
+        mine = p16[a:b].clone()
+        torch.distributed.all_gather(outs, mine, group=pg)
+
+    def consolidate(self):
+        """Sharded optimiser: bring the fp32 master parameters of the other ranks' slices up to date on this rank
+        (checkpoints and `save_pretrained` read the master buffer; between steps only the bf16 copy is complete) and
+        return full-size (m, v) moment buffers in the parameters' layout.  A collective: every rank calls it."""
+        st = self.engine.store
+        if not self.zero:
+            return self.m, self.v
+        self.finish()
+        m = torch.zeros_like(st.p32)
+        v = torch.zeros_like(st.p32)
+        for name, (lo, hi) in st.buckets.items():
+            rep_off, sl_off = self._state_off[name]
+            if sl_off is None:
+                m[lo:hi], v[lo:hi] = self.m[rep_off:rep_off + hi - lo], self.v[rep_off:rep_off + hi - lo]
+                continue
+            mlo, _ = self.sync.shard[name]
+            m[lo:mlo], v[lo:mlo] = self.m[rep_off:rep_off + mlo - lo], self.v[rep_off:rep_off + mlo - lo]
+            a, b = self.sync.slice_of(name)
+            m[a:b], v[a:b] = self.m[sl_off:sl_off + b - a], self.v[sl_off:sl_off + b - a]
+            per = b - a
+            for buf in (st.p32, m, v):
+                outs = [buf[mlo + r * per: mlo + (r + 1) * per] for r in range(self.world)]
+                torch.distributed.all_gather(outs, buf[a:b].clone(), group=self.sync.pg)
+        return m, v
+
+    def load_moments(self, m_full, v_full):
+        """Inverse of `consolidate` for resuming: take this rank's part of full-size moment buffers."""
+        if not self.zero:
+            self.m.copy_(m_full)
+            self.v.copy_(v_full)
+            return
+        st = self.engine.store
+        for name, (lo, hi) in st.buckets.items():
+            rep_off, sl_off = self._state_off[name]
+            if sl_off is None:
+                self.m[rep_off:rep_off + hi - lo], self.v[rep_off:rep_off + hi - lo] = m_full[lo:hi], v_full[lo:hi]
+                continue
+            mlo, _ = self.sync.shard[name]
+            self.m[rep_off:rep_off + mlo - lo], self.v[rep_off:rep_off + mlo - lo] = m_full[lo:mlo], v_full[lo:mlo]
+            a, b = self.sync.slice_of(name)
+            self.m[sl_off:sl_off + b - a], self.v[sl_off:sl_off + b - a] = m_full[a:b], v_full[a:b]
 
     def grad_norm(self) -> float:
         """Global gradient norm of the last step (after the DDP mean), host scalar."""

@@ -321,6 +321,15 @@ class Wav2Vec2CTCEngine:
         self._norm_plan = plan
         return plan
 
+    def shard_ranges(self) -> dict:
+        """{layer bucket: (first element of its weight matrices, bucket end)}: the part of every layer bucket a sharded
+        optimiser (trainer.py, zero_stage) may split over the ranks - the forward reads these parameters through the
+        bf16 compute copy only, the small tensors in front of them (LayerNorms, biases: read from the fp32 master) stay
+        replicated."""
+        st = self.store
+        return {f"layer{l}": (st.off(f"wav2vec2.encoder.layers.{l}.attention.q_proj.weight"), st.buckets[f"layer{l}"][1])
+                for l in range(self.s.num_hidden_layers)}
+
     def zero_grad(self, matrices: bool = True):
         """Clear gradients.  matrices=False clears everything except the transformer layers' weight
         matrices (>99 % of the bytes): the next backward(overwrite_matrices=True) writes those

@@ -36,6 +36,7 @@ def build_case():
 
 def main():
     out_dir, wire, steps = Path(sys.argv[1]), sys.argv[2], int(sys.argv[3])
+    zero = int(sys.argv[4]) if len(sys.argv) > 4 else 0
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.cuda.set_device(0)
     torch.distributed.init_process_group("gloo")
@@ -43,16 +44,20 @@ def main():
 
     eng, shard = build_case()
     tr = DataParallelTrainer(eng, learning_rate=1e-3, warmup_steps=0, max_steps=100, max_grad_norm=1.0,
-                             compress_grads=(wire == "bf16"))
-    assert tr.world == world and tr.overlap
+                             compress_grads=(wire == "bf16"), zero_stage=zero)
+    assert tr.world == world and tr.overlap and tr.zero == bool(zero)
+    if zero:  # 1/world of the moments for the layers' matrices
+        assert tr.m.numel() < 0.6 * eng.store.numel
     mb = shard(shard_indices(4, rank, world))
     losses, norms = [], []
     for _ in range(steps):
         losses.append(float(tr.train_step([mb])))
         norms.append(tr.grad_norm())
     tr.finish()
+    m_full, v_full = tr.consolidate()  # (sharded: gathers the master parameters and moments; replicated: a no-op)
     torch.cuda.synchronize()
-    torch.save(dict(losses=losses, norms=norms, p32=eng.store.p32.cpu(), p16=eng.store.p16.float().cpu()),
+    torch.save(dict(losses=losses, norms=norms, p32=eng.store.p32.cpu(), p16=eng.store.p16.float().cpu(), m=m_full.cpu(),
+                    v=v_full.cpu()),
                out_dir / f"rank{rank}.pt")
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()

@@ -63,7 +63,30 @@ def _worker(rank, world, port, q):
     s4.finish()
     ok_post = [n for n, _ in seen] == ["head", "layer1", "layer0", "front"] and torch.equal(g4, want4) and all(
         abs(v - float((want4[buckets[n][0]:buckets[n][1]] ** 2).sum())) <= 1e-3 * v for n, v in seen)
-    q.put((rank, ok_sum, ok_mean, ok_partial, launched == order and ok_bf16 and ok_post, shard_indices(8, rank, world)))
+    # sharded buckets (trainer zero_stage): the matrix part of a layer bucket is reduce-scattered - this rank's slice
+    # holds the sum over ranks, the bucket's small part and the unsharded buckets are all-reduced as before
+    g5 = (torch.arange(200, dtype=torch.float32) * 0.25 + rank).clone()
+    want5 = sum((torch.arange(200, dtype=torch.float32) * 0.25 + r) for r in range(world))
+    shard = {"layer0": (56, 104), "layer1": (120, 168)}
+    s5 = GradSync(g5, buckets, shard=shard)
+    seen5 = []
+    for name in ("head", "layer1", "layer0", "front"):
+        s5.start(name, post=lambda n: seen5.append(n))
+    s5.finish()
+    ok_shard = seen5 == ["head", "layer1", "layer0", "front"]
+    for name, (mlo, hi) in shard.items():
+        a, b = s5.slice_of(name)
+        per = (hi - mlo) // world
+        ok_shard &= (a, b) == (mlo + rank * per, mlo + (rank + 1) * per)
+        ok_shard &= torch.equal(g5[a:b], want5[a:b]) and torch.equal(g5[buckets[name][0]:mlo], want5[buckets[name][0]:mlo])
+    ok_shard &= torch.equal(g5[:40], want5[:40]) and torch.equal(g5[168:], want5[168:])
+    try:
+        GradSync(g5, buckets, shard={"layer0": (57, 104)})
+        ok_shard = False
+    except ValueError:
+        pass
+    q.put((rank, ok_sum, ok_mean, ok_partial, launched == order and ok_bf16 and ok_post and bool(ok_shard),
+           shard_indices(8, rank, world)))
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 

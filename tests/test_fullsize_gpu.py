@@ -156,3 +156,66 @@ def test_full_size_whisper_medium_properties():
     assert same >= 0.9 * sum(len(r) for r in full)
     del eng
     torch.cuda.empty_cache()
+
+
+def test_production_batch_of_64_equals_eight_batches_of_8():
+    """The reference's production geometry (R/makefile:90: `model=wav2vec2-small per_device_batch_size=64`): 64 x 10 s
+    on the XLS-R-300M shape - conv-stack activations of 2.1 GB, i.e. byte offsets beyond 2^31.  Utterances never mix, so
+    the logits of the batch of 64 equal, bit for bit, those of the same utterances run eight at a time; the CTC loss is
+    the sum of the eight losses; and the gradients equal the eight micro-batches accumulated (fp32 summation order
+    differs: 1e-3 of the tensor's scale)."""
+    from coral_amd.wav2vec2 import CORAL_W2V2_SHAPES, Wav2Vec2CTCEngine, Wav2Vec2Shape
+
+    shape = Wav2Vec2Shape(**CORAL_W2V2_SHAPES["wav2vec2-small"])
+    eng = Wav2Vec2CTCEngine(shape, DEV).train()
+    g = torch.Generator(device=DEV).manual_seed(4242)
+    for n in eng.store.names():
+        v = eng.store.view(n)
+        if n.endswith("layer_norm.weight") or n.endswith("original0"):
+            v.fill_(1.0)
+        elif n.endswith(".bias"):
+            v.zero_()
+        else:
+            v.normal_(0.0, 0.02, generator=g)
+    eng.refresh_compute_weights()
+    eng.refresh_derived()
+    gen = torch.Generator().manual_seed(11)
+    B, N = 64, 160_000
+    x = torch.randn(B, N, generator=gen) * 0.1
+    lens = torch.randint(16_000, N + 1, (B,), generator=gen)
+    lens[0] = N
+    am = (torch.arange(N)[None, :] < lens[:, None]).to(torch.int32)
+    x = x * am
+    labels = torch.full((B, 40), -100, dtype=torch.int64)
+    for b in range(B):
+        n = int(torch.randint(5, 41, (1,), generator=gen))
+        labels[b, :n] = torch.randint(0, 42, (n,), generator=gen)
+    names = ["lm_head.weight", "wav2vec2.encoder.layers.23.feed_forward.output_dense.weight",
+             "wav2vec2.encoder.layers.0.attention.q_proj.weight", "wav2vec2.encoder.layers.11.final_layer_norm.bias",
+             "wav2vec2.feature_projection.projection.weight", "wav2vec2.feature_extractor.conv_layers.1.conv.weight",
+             "wav2vec2.feature_extractor.conv_layers.0.conv.weight"]
+    eng.zero_grad()
+    out = eng.forward(x, am, labels)
+    eng.backward()
+    torch.cuda.synchronize()
+    big_logits, big_loss = out.logits.clone(), float(out.loss)
+    big_grads = {n: eng.store.view(n, "g32").clone() for n in names}
+    assert torch.isfinite(big_logits).all() and big_logits.shape == (64, 499, 46)
+    ids, _ = eng.greedy_decode()
+    assert len(ids) == 64
+    eng.zero_grad()
+    loss8 = 0.0
+    for k in range(8):
+        sl = slice(8 * k, 8 * k + 8)
+        o = eng.forward(x[sl], am[sl], labels[sl])
+        eng.backward()
+        torch.cuda.synchronize()
+        assert torch.equal(o.logits, big_logits[sl]), k
+        loss8 += float(o.loss)
+    assert abs(loss8 - big_loss) <= 1e-5 * abs(big_loss)
+    for n in names:
+        a, b = big_grads[n], eng.store.view(n, "g32")
+        scale = float(b.abs().max())
+        assert scale > 0 and float((a - b).abs().max()) <= 2e-3 * scale, (n, float((a - b).abs().max()), scale)
+    del eng
+    torch.cuda.empty_cache()
