@@ -98,6 +98,7 @@ SIGNATURES = {
     "ca_gemm_fp8": (C.c_int, [C.POINTER(CaGemmDesc), _vp]),
     "ca_quantize_fp8": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
     "ca_gemm_force_kernel": (C.c_int, [C.c_int]),
+    "ca_gemm_debug_general_epilogue": (C.c_int, [C.c_int]),
     "ca_prof_begin": (C.c_int, []),
     "ca_prof_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "ca_attn_fwd": (C.c_int, [C.POINTER(CaAttnDesc), _vp]),

@@ -25,6 +25,7 @@
 #define LDS_BYTES (4 * 64 * EPI_PITCH * 4)  // 69632 >= NSTAGE*STAGE_BYTES
 
 __device__ __attribute__((aligned(16))) uint32_t g_ca_zero_page[4];
+__device__ int g_ca_epi_general = 0;  // tests: 1 = every wave tile takes the general epilogue walk (ca_gemm_debug_general_epilogue)
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -406,6 +407,93 @@ __device__ __forceinline__ void epi_load_bias(const CaGemmDesc& d, int lane, int
     }
   }
 }
+// ---- fast epilogue: a 64 x 64 wave tile that lies wholly inside the output, 16-byte aligned rows -------------------
+// The general walk below decides everything per lane and per pass at run time (ragged columns, rows beyond M, which
+// epilogue, unaligned dropout groups, both output types): ~400 vector instructions per pass of 8 elements per lane in
+// the ISA, against ~130 of arithmetic - on the FFN GEMMs the epilogue's instruction count, not the stores' bytes, is
+// what the tile waits for (3.3 VALU per MFMA over the whole kernel).  Interior wave tiles (all but the last row / column
+// of tiles) take this form instead: the epilogue kind, the output type and dropout are template parameters, all
+// predicates are gone, the flat element index of the dropout hash advances by a constant.  Same arithmetic in the same
+// order as the general walk: the results are bit-identical (tests/test_kernels_gpu.py compares ragged and interior tiles
+// of one launch against the same reference).
+template <int EPI, bool F32, bool DROP>
+__device__ __forceinline__ void gemm_epilogue_fast(const CaGemmDesc& d, const float* wt, int lane, int mw, int nb, int z,
+                                                   int64_t zoffC, int64_t zoffR, const float (&bias8)[8], float& ssq) {
+  const int M = d.M, N = d.N;
+  const float alpha = d.alpha;
+  const float keep_scale = DROP ? 1.f / (1.f - d.dropout_p) : 1.f;
+  const int r0 = lane >> 3, c0 = 8 * (lane & 7);
+  constexpr bool NEEDS_R = EPI == CA_EPI_RESIDUAL || EPI == CA_EPI_DGELU;
+  const unsigned short* Rp = NEEDS_R ? (const unsigned short*)d.R + zoffR + nb + (int64_t)(mw + r0) * d.ldr : nullptr;
+  const int64_t rstep = 8 * d.ldr;
+  int64_t coff = zoffC + (int64_t)(mw + r0) * d.ldc + nb;
+  const int64_t cstep = 8 * d.ldc;
+  uint64_t idx = ((uint64_t)z * M + (mw + r0)) * (uint64_t)N + nb;  // multiple of 4: N % 8 == 0, nb % 8 == 0
+  const uint64_t istep = 8ull * (uint64_t)N;
+  u16x8_t r_next = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (NEEDS_R) r_next = *(const u16x8_t*)Rp;
+#pragma unroll 2
+  for (int it = 0; it < 8; ++it) {
+    const u16x8_t r_cur = r_next;
+    if (NEEDS_R && it < 7) r_next = *(const u16x8_t*)(Rp + (it + 1) * rstep);
+    const float* wr = wt + (it * 8 + r0) * EPI_PITCH + c0;
+    const f32x4_t a4 = *(const f32x4_t*)wr, b4 = *(const f32x4_t*)(wr + 4);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (e < 4 ? a4[e] : b4[e - 4]) * alpha + bias8[e];
+    unsigned int keep = 0xFFu;
+    if (DROP) keep = ca_dropout_keep4(d.dropout_seed, idx, d.dropout_p) | (ca_dropout_keep4(d.dropout_seed, idx + 4, d.dropout_p) << 4);
+    float v2[8];
+    if (EPI == CA_EPI_GELU) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float g = gelu_erf(v[e]);
+        if (DROP) g = ((keep >> e) & 1u) ? g * keep_scale : 0.f;
+        v2[e] = g + 0.f;  // (the general walk adds the residual slot, zero here: -0 becomes +0 there too)
+      }
+    } else if (EPI == CA_EPI_RESIDUAL) {
+      if (DROP) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = ((keep >> e) & 1u) ? v[e] * keep_scale : 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += bf2f(r_cur[e]);
+    } else if (EPI == CA_EPI_DGELU) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float dg = dgelu_erf(bf2f(r_cur[e]));
+        if (DROP) dg = ((keep >> e) & 1u) ? dg * keep_scale : 0.f;
+        v[e] *= dg;
+      }
+    }
+    if (F32) {
+      float* C = (float*)d.C + coff;
+      if (d.accumulate) {
+        const f32x4_t c0v = *(const f32x4_t*)C, c1v = *(const f32x4_t*)(C + 4);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += e < 4 ? c0v[e] : c1v[e - 4];
+      }
+      *(f32x4_t*)C = (f32x4_t){v[0], v[1], v[2], v[3]};
+      *(f32x4_t*)(C + 4) = (f32x4_t){v[4], v[5], v[6], v[7]};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ssq = fmaf(v[e], v[e], ssq);
+    } else {
+      u16x8_t o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e]);
+      *(u16x8_t*)((unsigned short*)d.C + coff) = o;
+    }
+    if (EPI == CA_EPI_GELU) {
+      u16x8_t o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = f2bf(v2[e]);
+      *(u16x8_t*)((unsigned short*)d.C2 + coff) = o;
+    }
+    coff += cstep;
+    idx += istep;
+  }
+}
+
 __device__ __forceinline__ void gemm_epilogue(const CaGemmDesc& d, f32x4_t (&acc)[4][4], char* smem,
                                               int wave, int lane, int mw, int nw, int z, int z1,
                                               int z2, const float (*bias_pre)[8] = nullptr) {
@@ -449,6 +537,26 @@ __device__ __forceinline__ void gemm_epilogue(const CaGemmDesc& d, f32x4_t (&acc
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private region: no barrier
   if (nvalid <= 0 && d.c_sumsq == nullptr) return;
   float ssq = 0.f;  // sum of squares of the fp32 values this lane stores (c_sumsq)
+  // interior wave tile (wave-uniform test): the specialised walk above
+  const bool drop_on = d.dropout_p > 0.f;
+  const bool interior = g_ca_epi_general == 0 && mw + 64 <= M && nw + 64 <= N && vec_ok && (N & 7) == 0 && d.C != nullptr &&
+                        (d.out_f32 || !d.accumulate) && (!has_gelu || (epi == CA_EPI_GELU && d.C2 != nullptr && !d.out_f32)) &&
+                        !(d.out_f32 && epi != CA_EPI_NONE) && !(drop_on && epi == CA_EPI_NONE);
+  if (interior) {
+#define EPI_FAST(E, F, D) gemm_epilogue_fast<E, F, D>(d, wt, lane, mw, nb, z, zoffC, zoffR, bias8, ssq)
+    if (d.out_f32) {
+      EPI_FAST(CA_EPI_NONE, true, false);
+    } else if (epi == CA_EPI_NONE) {
+      EPI_FAST(CA_EPI_NONE, false, false);
+    } else if (epi == CA_EPI_GELU) {
+      if (drop_on) EPI_FAST(CA_EPI_GELU, false, true); else EPI_FAST(CA_EPI_GELU, false, false);
+    } else if (epi == CA_EPI_RESIDUAL) {
+      if (drop_on) EPI_FAST(CA_EPI_RESIDUAL, false, true); else EPI_FAST(CA_EPI_RESIDUAL, false, false);
+    } else {
+      if (drop_on) EPI_FAST(CA_EPI_DGELU, false, true); else EPI_FAST(CA_EPI_DGELU, false, false);
+    }
+#undef EPI_FAST
+  } else {
 #pragma unroll 1
   for (int it = 0; it < 8; ++it) {
     const int ml = it * 8 + (lane >> 3);
@@ -565,6 +673,7 @@ __device__ __forceinline__ void gemm_epilogue(const CaGemmDesc& d, f32x4_t (&acc
       }
     }
   }
+  }  // general walk
   if (d.c_sumsq != nullptr) {
     // (every lane of the wave arrives here: fixed butterfly order, the same bits on every run)
 #pragma unroll
@@ -1782,6 +1891,14 @@ extern "C" int ca_prof_end(double* ms, int64_t* count, double* flops) {
   return CA_OK;
 }
 
+extern "C" int ca_gemm_debug_general_epilogue(int on) {
+  const int v = on ? 1 : 0;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_ca_epi_general), &v, sizeof(int)) != hipSuccess) {
+    ca_set_error("ca_gemm_debug_general_epilogue: hipMemcpyToSymbol failed");
+    return CA_ERR_LAUNCH;
+  }
+  return CA_OK;
+}
 static int g_force_kernel = 0;  // 0 auto, 1 force 128x128, 2 force 256x128 (tests / tuning)
 extern "C" int ca_gemm_force_kernel(int which) {
   g_force_kernel = which;

@@ -150,8 +150,12 @@ int ca_gemm_bf16_group(const CaGemmDesc* descs, int32_t count, void* stream);
  * summed kernel milliseconds, launch count, summed algorithmic FLOPs (2*M*N*K*batch).  Not for use
  * inside graph capture. */
 /* Tuning/test hook: 0 = automatic kernel choice, 1 = force the 128x128 kernel, 2 = force the
- * 256x128 pipelined kernel, 3 = force the 256x256 kernel. */
+ * 256x128 pipelined kernel, 3 = force the 256x256 kernel, 4 = force the 256x256 kernel with one wave per SIMD
+ * (4 waves x 128x128; an experiment). */
 int ca_gemm_force_kernel(int which);
+/* Test hook: on != 0 sends every wave tile through the general epilogue walk (interior tiles normally take a
+ * specialised, predicate-free form that must give the same bits). */
+int ca_gemm_debug_general_epilogue(int on);
 int ca_prof_begin(void);
 int ca_prof_end(double* ms, int64_t* count, double* flops);
 

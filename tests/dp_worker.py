@@ -46,8 +46,9 @@ def main():
     tr = DataParallelTrainer(eng, learning_rate=1e-3, warmup_steps=0, max_steps=100, max_grad_norm=1.0,
                              compress_grads=(wire == "bf16"), zero_stage=zero)
     assert tr.world == world and tr.overlap and tr.zero == bool(zero)
-    if zero:  # 1/world of the moments for the layers' matrices
-        assert tr.m.numel() < 0.6 * eng.store.numel
+    if zero:  # the moments: everything replicated except the layers' weight matrices, of which this rank holds 1/world
+        sharded = sum(hi - lo for lo, hi in eng.shard_ranges().values())
+        assert sharded > 0 and tr.m.numel() == eng.store.numel - sharded + sharded // world
     mb = shard(shard_indices(4, rank, world))
     losses, norms = [], []
     for _ in range(steps):

@@ -718,3 +718,58 @@ def test_sumsq_ranges_and_plain_sum(ops):
     assert abs(float(out) - float(x.double().sum())) <= 1e-3 * float(x.double().abs().sum()) ** 0.5 + 1e-2
     ops.sum_f32(x[:10], 10, out, part, accumulate=True)
     assert abs(float(out) - float(x.double().sum()) - float(x[:10].double().sum())) <= 0.1
+
+
+@pytest.mark.parametrize("force", [1, 2, 3, 4])
+def test_gemm_interior_tile_epilogue_is_bit_identical_to_the_general_walk(ops, force):
+    """Interior 64 x 64 wave tiles take a specialised, predicate-free epilogue (gemm.hip, gemm_epilogue_fast); ragged
+    ones the general walk.  Same arithmetic in the same order: with the specialised form switched off
+    (ca_gemm_debug_general_epilogue) every output bit is the same - plain bf16 / bias, bias + GELU + dropout with both
+    outputs, residual (+ dropout), GELU'(R) + dropout, fp32 output written and accumulated with the per-tile sums of
+    squares - on each of the four kernels, at a shape with interior and ragged tiles in both dimensions."""
+    lib = ops.lib()
+    M, N, K = 840, 712, 200
+    g = torch.Generator(device=DEV).manual_seed(5)
+    A = torch.randn(M, K, device=DEV, generator=g).to(torch.bfloat16)
+    B = torch.randn(N, K, device=DEV, generator=g).to(torch.bfloat16)
+    bias = torch.randn(N, device=DEV, generator=g)
+    R = torch.randn(M, N, device=DEV, generator=g).to(torch.bfloat16)
+    kw = dict(M=M, N=N, K=K, lda=K, ldb=K, ldc=N)
+    cases = {
+        "plain": dict(),
+        "bias": dict(bias=bias),
+        "gelu2": dict(bias=bias, epilogue=ops.EPI_GELU, two=True),
+        "gelu2_drop": dict(bias=bias, epilogue=ops.EPI_GELU, two=True, dropout_p=0.1, dropout_seed=11),
+        "residual": dict(bias=bias, epilogue=ops.EPI_RESIDUAL, R=R, ldr=N),
+        "residual_drop": dict(bias=bias, epilogue=ops.EPI_RESIDUAL, R=R, ldr=N, dropout_p=0.2, dropout_seed=3),
+        "dgelu_drop": dict(epilogue=ops.EPI_DGELU, R=R, ldr=N, dropout_p=0.1, dropout_seed=11),
+        "f32": dict(f32=True),
+        "f32_acc": dict(f32=True, accumulate=True),
+    }
+
+    def run(case):
+        c = dict(cases[case])
+        two, f32 = c.pop("two", False), c.pop("f32", False)
+        out = torch.full((M, N), 0.5, dtype=torch.float32 if f32 else torch.bfloat16, device=DEV)
+        out2 = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+        slots = torch.zeros(ops.sumsq_slots(M, N), dtype=torch.float32, device=DEV)
+        extra = dict(C2=out2, c2_off=0) if two else {}
+        if f32:
+            extra.update(c_sumsq=slots, c_sumsq_off=0)
+        ops.gemm(A, B, out, **kw, **c, **extra)
+        torch.cuda.synchronize()
+        return out.clone(), out2.clone(), slots.clone()
+
+    lib.ca_gemm_force_kernel(force)
+    try:
+        for case in cases:
+            lib.ca_gemm_debug_general_epilogue(1)
+            want = run(case)
+            lib.ca_gemm_debug_general_epilogue(0)
+            got = run(case)
+            for a, b in zip(got, want):
+                assert torch.equal(a, b), (force, case)
+            assert float(got[0].float().abs().sum()) > 0
+    finally:
+        lib.ca_gemm_debug_general_epilogue(0)
+        lib.ca_gemm_force_kernel(0)
