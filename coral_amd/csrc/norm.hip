@@ -3,6 +3,7 @@
 // Reference: nn.LayerNorm call sites in $TF/models/wav2vec2/modeling_wav2vec2.py:291-298
 // (conv block LN + GELU), :429-434, :611-654, :791.
 #include "common.h"
+#include <cstdlib>
 
 #define LN_MAXCH 8  // up to 8 chunks of 8 elements per lane -> C <= 4096
 
@@ -20,12 +21,12 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const unsigned short* __res
     const unsigned short* xr = x + row * C;
     float v[NCH][8];
     float s = 0.f;
-    // short rows (greedy decoding: a handful of rows of d <= 1536): gamma / beta are requested together with the row,
-    // so the kernel is one memory round trip instead of two; long-row shapes keep the registers for occupancy
-    f32x4_t gq[NCH <= 3 ? NCH : 1][2], bq[NCH <= 3 ? NCH : 1][2];
-    if (NCH <= 3) {
+    // gamma / beta are requested together with the row, so the kernel is one memory round trip instead of two (rows of
+    // up to 2048 channels: at 3992 rows of d = 1920 a CU holds 16 rows - latency, not occupancy, is what the kernel waits for)
+    f32x4_t gq[NCH <= 4 ? NCH : 1][2], bq[NCH <= 4 ? NCH : 1][2];
+    if (NCH <= 4) {
 #pragma unroll
-      for (int c = 0; c < (NCH <= 3 ? NCH : 1); ++c) {
+      for (int c = 0; c < (NCH <= 4 ? NCH : 1); ++c) {
         const int ch = lane + c * 64;
         if (ch < nchunk) {
           gq[c][0] = *(const f32x4_t*)(gamma + ch * 8);
@@ -74,11 +75,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const unsigned short* __res
       const int ch = lane + c * 64;
       if (ch < nchunk) {
         f32x4_t g0, g1, b0, b1;
-        if (NCH <= 3) {
-          g0 = gq[NCH <= 3 ? c : 0][0];
-          g1 = gq[NCH <= 3 ? c : 0][1];
-          b0 = bq[NCH <= 3 ? c : 0][0];
-          b1 = bq[NCH <= 3 ? c : 0][1];
+        if (NCH <= 4) {
+          g0 = gq[NCH <= 4 ? c : 0][0];
+          g1 = gq[NCH <= 4 ? c : 0][1];
+          b0 = bq[NCH <= 4 ? c : 0][0];
+          b1 = bq[NCH <= 4 ? c : 0][1];
         } else {
           g0 = *(const f32x4_t*)(gamma + ch * 8);
           g1 = *(const f32x4_t*)(gamma + ch * 8 + 4);
@@ -251,7 +252,10 @@ extern "C" int ca_layernorm_fwd_fp8(const void* x, const float* gamma, const flo
 // Enough workgroups to keep ~16 MB of row loads in flight (one wave per row, 2 workgroups per CU at C = 1920
 // because of the LDS reduction buffer); more only lengthens the partial-sum pass.  Measured at XLS-R-2B:
 // 256 -> 29 us, 512 -> 21.5 us, 1024 -> 26.7 us for C = 1920; C = 512 rows prefer 1024.
-static int ln_bwd_grid_max(int C) { return C >= 1024 ? 512 : 1024; }
+static int ln_bwd_grid_max(int C) {
+  static const int wide = [] { const char* e = getenv("CA_LN_BWD_GRID"); return e ? atoi(e) : 512; }();
+  return C >= 1024 ? wide : 1024;
+}
 static int ln_bwd_grid(int64_t rows, int C) {
   int64_t g = (rows + 3) / 4;
   if (g > ln_bwd_grid_max(C)) g = ln_bwd_grid_max(C);
@@ -259,12 +263,12 @@ static int ln_bwd_grid(int64_t rows, int C) {
   return (int)g;
 }
 
-template <int NCH>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(
+template <int NCH, bool ACT>
+__global__ __launch_bounds__(256, 2) void ln_bwd_kernel(
     const unsigned short* __restrict__ dy, const unsigned short* __restrict__ x,
     const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ stats, const unsigned short* __restrict__ dres,
-    unsigned short* __restrict__ dx, float* __restrict__ partial, int64_t rows, int C, int act) {
+    unsigned short* __restrict__ dx, float* __restrict__ partial, int64_t rows, int C) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* red = (float*)smem_raw;  // [4 waves][2][C]
   const int lane = threadIdx.x & 63;
@@ -275,48 +279,92 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
   for (int c = 0; c < NCH; ++c)
 #pragma unroll
     for (int e = 0; e < 8; ++e) dg[c][e] = db[c][e] = 0.f;
-
-  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
-    const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
-    const unsigned short* xr = x + row * C;
-    const unsigned short* dyr = dy + row * C;
-    float xh[NCH][8], dxh[NCH][8];
-    float s1 = 0.f, s2 = 0.f;
+  // gamma (and beta for the GELU form) are re-read per row and phase (7.5 KiB at C = 1920: L1 hits) - holding them
+  // across the rows costs 32 registers that the row pipeline below needs
+  auto load_gamma = [&](int c, float (&g8)[8]) {
+    const int ch = lane + c * 64;
+    if (ch < nchunk) {
+      const f32x4_t g0 = *(const f32x4_t*)(gamma + ch * 8), g1 = *(const f32x4_t*)(gamma + ch * 8 + 4);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) g8[e] = e < 4 ? g0[e] : g1[e - 4];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) g8[e] = 0.f;
+    }
+  };
+  auto load_beta = [&](int c, float (&b8)[8]) {
+    const int ch = lane + c * 64;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) b8[e] = 0.f;
+    if (ACT && ch < nchunk) {
+      const f32x4_t b0 = *(const f32x4_t*)(beta + ch * 8), b1 = *(const f32x4_t*)(beta + ch * 8 + 4);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) b8[e] = e < 4 ? b0[e] : b1[e - 4];
+    }
+  };
+  // A wave walks its rows with the NEXT row's x / dy / residual-gradient chunks and statistics already requested
+  // while it works on the current one (one wave per row and one round trip per phase left the kernel at 47 % of the
+  // achievable HBM rate: latency, not bandwidth; with the rows pipelined a smaller grid keeps the same bytes in flight
+  // and writes a quarter of the partial sums).
+  const int64_t stride = (int64_t)gridDim.x * 4;
+  const u16x8_t zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  u16x8_t cx[NCH], cd[NCH], cr[NCH];
+  float cmean = 0.f, crstd = 0.f;
+  auto request = [&](int64_t row, u16x8_t (&ux)[NCH], u16x8_t (&ud)[NCH], float& mean, float& rstd) {
+    mean = stats[row * 2];
+    rstd = stats[row * 2 + 1];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const int ch = lane + c * 64;
+      ux[c] = ud[c] = zero8;
       if (ch < nchunk) {
-        const u16x8_t ux = *(const u16x8_t*)(xr + ch * 8);
-        const u16x8_t ud = *(const u16x8_t*)(dyr + ch * 8);
-        const f32x4_t g0 = *(const f32x4_t*)(gamma + ch * 8);
-        const f32x4_t g1 = *(const f32x4_t*)(gamma + ch * 8 + 4);
-        f32x4_t b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
-        if (act) {
-          b0 = *(const f32x4_t*)(beta + ch * 8);
-          b1 = *(const f32x4_t*)(beta + ch * 8 + 4);
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float gm = e < 4 ? g0[e] : g1[e - 4];
-          const float h = (bf2f(ux[e]) - mean) * rstd;
-          float du = bf2f(ud[e]);
-          if (act) {
-            const float bt = e < 4 ? b0[e] : b1[e - 4];
-            du *= dgelu_erf(h * gm + bt);
-          }
-          dg[c][e] += du * h;
-          db[c][e] += du;
-          const float d = du * gm;
-          xh[c][e] = h;
-          dxh[c][e] = d;
-          s1 += d;
-          s2 += d * h;
-        }
-      } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) xh[c][e] = dxh[c][e] = 0.f;
+        ux[c] = *(const u16x8_t*)(x + row * C + ch * 8);
+        ud[c] = *(const u16x8_t*)(dy + row * C + ch * 8);
       }
     }
+  };
+  constexpr bool PIPE = NCH <= 4;  // (rows of more than 2048 channels - no model of this path - would spill)
+  int64_t row = (int64_t)blockIdx.x * 4 + wave;
+  if (PIPE && row < rows) request(row, cx, cd, cmean, crstd);
+  while (row < rows) {
+    const int64_t nrow = row + stride;
+    if (!PIPE) request(row, cx, cd, cmean, crstd);
+    // the row's residual gradient: asked for now, used behind the two reductions (it used to be one more exposed
+    // round trip after them)
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int ch = lane + c * 64;
+      cr[c] = zero8;
+      if (dres && ch < nchunk) cr[c] = *(const u16x8_t*)(dres + row * C + ch * 8);
+    }
+    u16x8_t nx[PIPE ? NCH : 1], nd[PIPE ? NCH : 1];
+    float nmean = 0.f, nrstd = 0.f;
+    if constexpr (PIPE) {
+      if (nrow < rows) request(nrow, nx, nd, nmean, nrstd);
+    }
+    float du_[ACT ? NCH : 1][8];  // dy through GELU' (the conv form; the plain form re-reads dy from its registers)
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      float g8[8], b8[8];
+      load_gamma(c, g8);
+      load_beta(c, b8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float h = (bf2f(cx[c][e]) - cmean) * crstd;
+        float du = bf2f(cd[c][e]);
+        if (ACT) {
+          du *= dgelu_erf(h * g8[e] + b8[e]);
+          du_[ACT ? c : 0][e] = du;
+        }
+        dg[c][e] += du * h;
+        db[c][e] += du;
+        const float d = du * g8[e];
+        s1 += d;
+        s2 += d * h;
+      }
+    }
+    // (chunks beyond the row hold zeros and gamma = 0 there: they add nothing)
     const float m1 = wave_sum(s1) / (float)C;
     const float m2 = wave_sum(s2) / (float)C;
     unsigned short* dxr = dx + row * C;
@@ -325,14 +373,27 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
       const int ch = lane + c * 64;
       if (ch < nchunk) {
         u16x8_t o;
-        u16x8_t rs = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (dres) rs = *(const u16x8_t*)(dres + row * C + ch * 8);
+        float g8[8];
+        load_gamma(c, g8);
 #pragma unroll
-        for (int e = 0; e < 8; ++e)
-          o[e] = f2bf(rstd * (dxh[c][e] - m1 - xh[c][e] * m2) + bf2f(rs[e]));
+        for (int e = 0; e < 8; ++e) {
+          const float h = (bf2f(cx[c][e]) - cmean) * crstd;  // recomputed: cheaper than 32 more live registers
+          const float du = ACT ? du_[ACT ? c : 0][e] : bf2f(cd[c][e]);
+          o[e] = f2bf(crstd * (du * g8[e] - m1 - h * m2) + bf2f(cr[c][e]));
+        }
         *(u16x8_t*)(dxr + ch * 8) = o;
       }
     }
+    if constexpr (PIPE) {
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        cx[c] = nx[c];
+        cd[c] = nd[c];
+      }
+      cmean = nmean;
+      crstd = nrstd;
+    }
+    row = nrow;
   }
   // block reduction of the parameter gradients over the 4 waves
 #pragma unroll
@@ -449,10 +510,17 @@ extern "C" int ca_layernorm_bwd(const void* dy, const void* x, const float* gamm
   dim3 grid(g), block(256);
   const size_t lds = (size_t)4 * 2 * C * sizeof(float);
   hipStream_t s = (hipStream_t)stream;
-#define LN_BWD(N)                                                                         \
-  hipLaunchKernelGGL((ln_bwd_kernel<N>), grid, block, lds, s, (const unsigned short*)dy,  \
-                     (const unsigned short*)x, gamma, beta, stats,                        \
-                     (const unsigned short*)dres, (unsigned short*)dx, partial, rows, C, act)
+#define LN_BWD_(N, A)                                                                          \
+  hipLaunchKernelGGL((ln_bwd_kernel<N, A>), grid, block, lds, s, (const unsigned short*)dy,    \
+                     (const unsigned short*)x, gamma, beta, stats,                             \
+                     (const unsigned short*)dres, (unsigned short*)dx, partial, rows, C)
+#define LN_BWD(N)        \
+  do {                   \
+    if (act)             \
+      LN_BWD_(N, true);  \
+    else                 \
+      LN_BWD_(N, false); \
+  } while (0)
   switch (nch) {
     case 1: LN_BWD(1); break;
     case 2: LN_BWD(2); break;
@@ -461,6 +529,7 @@ extern "C" int ca_layernorm_bwd(const void* dy, const void* x, const float* gamm
     default: LN_BWD(8); break;
   }
 #undef LN_BWD
+#undef LN_BWD_
   CA_CHECK_LAUNCH("ca_layernorm_bwd");
   if (dgamma && dbeta == dgamma + C) {  // weight and bias gradients are adjacent in the flat buffer: one launch
     ca_reduce_partials_launch(partial, g, (int64_t)2 * C, 2 * C, dgamma, 1, s);

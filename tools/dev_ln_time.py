@@ -24,4 +24,5 @@ for M, C in ((3992, 1920), (3992, 1024), (12000, 1024), (12000, 1280)):
         return e0.elapsed_time(e1) / n * 1e3
     tf = t(lambda: ops.layernorm_fwd(x, g, b, y, st, M, C))
     tb = t(lambda: ops.layernorm_bwd(dy, x, g, b, st, dres, dx, dg, db, part, M, C))
-    print(f"M{M} C{C}: fwd {tf:.1f} us, bwd (+reduce) {tb:.1f} us")
+    tb2 = t(lambda: ops.layernorm_bwd(dy, x, g, b, st, dres, dx, None, None, part, M, C))  # (the engine's form: partials only)
+    print(f"M{M} C{C}: fwd {tf:.1f} us, bwd (+reduce) {tb:.1f} us, bwd alone {tb2:.1f} us  [CA_LN_BWD_GRID={__import__('os').environ.get('CA_LN_BWD_GRID', '512')}]")
