@@ -128,17 +128,19 @@ class WhisperTrainEngine(WhisperEngine):
         if matrices or self.freeze_base or Le == 0:
             st.g32.zero_()
         else:
-            lo0, hi0 = self._enc_matrix_range(0)
-            st.g32[:lo0].zero_()
-            if Le > 1:  # the small tensors behind each layer's matrices: equal size, equal stride
-                lo1, _ = self._enc_matrix_range(1)
-                n = lo1 - hi0
-                st.g32[hi0:hi0 + (Le - 2) * (lo1 - lo0) + n].as_strided((Le - 1, n), (lo1 - lo0, 1)).zero_()
-            _, hil = self._enc_matrix_range(Le - 1)
-            st.g32[hil:].zero_()
+            # everything except the encoder layers' weight matrices, as ONE launch over a cached range table
+            if getattr(self, "_small_ranges", None) is None:
+                rs, pos = [], 0
+                for l in range(Le):
+                    lo, hi = self._enc_matrix_range(l)
+                    rs.append((pos, lo - pos))
+                    pos = hi
+                rs.append((pos, st.numel - pos))
+                self._small_ranges = tuple(r for r in rs if r[1] > 0)
+            ops.clear_ranges(st.g32, self._small_ranges)
         plan = getattr(self, "_norm_plan", None)
         if plan is not None:
-            plan["slots"].zero_()
+            ops.clear_f32(plan["slots"], plan["nslots"])
 
     def norm_plan(self):
         """Squared gradient norm without a pass over the encoder layers' weight matrices (wav2vec2.norm_plan)."""
@@ -215,7 +217,7 @@ class WhisperTrainEngine(WhisperEngine):
             dec_sv=[(sa.alloc(B, L, dev), ca.alloc(B, L, T, dev), ff.alloc(Md, dev)) for sa, ca, ff in self.dec_blocks],
             logits=_z(Md * _r8(s.vocab_size), dev, f32), dlogits=_z(Md * _r8(s.vocab_size), dev, f32),
             dlogits16=_z(Md * _r8(s.vocab_size), dev),
-            loss_sum=_z(1, dev, f32), count=torch.zeros(1, dtype=torch.int32, device=dev),
+            loss_cnt=_z(2, dev, f32),  # loss_sum (fp32) | count (int32) in adjacent words: cleared by one launch
             sc_e=Scratch(Me, d, s.encoder_ffn_dim, dev), sc_d=Scratch(Md, d, s.decoder_ffn_dim, dev, Mkv=Me),
             # (second scratch / bias workspace and three more gradient buffers: the encoder layers' weight gradients run
             # on a side stream two layers behind the data-gradient chain, see backward())
@@ -325,8 +327,8 @@ class WhisperTrainEngine(WhisperEngine):
                           w["dec_out"], w["dec_st"], Md, d, s.layer_norm_eps)
         V, Vp = s.vocab_size, _r8(s.vocab_size)
         ops.gemm(w["dec_out"], p16, w["logits"], M=Md, N=V, K=d, lda=d, ldb=d, ldc=Vp, b_off=o("model.decoder.embed_tokens.weight"))
-        w["loss_sum"].zero_()
-        w["count"].zero_()
+        ops.clear_ranges(w["loss_cnt"], ((0, 2),))  # loss_sum | count (adjacent 4-byte words): one launch
+        w["loss_sum"], w["count"] = w["loss_cnt"][0:1], w["loss_cnt"][1:2].view(torch.int32)
         lab32 = self._stager.to_device(lab, torch.int32, "lab").view(-1)
         ops.cross_entropy_fwd_bwd(w["logits"], lab32, w["loss_sum"], w["count"], w["dlogits"], Md, V, Vp, -100)
         cnt = w["count"].clamp(min=1).to(torch.float32)
@@ -363,7 +365,7 @@ class WhisperTrainEngine(WhisperEngine):
                           st.view("model.decoder.layer_norm.weight", "g32"), st.view("model.decoder.layer_norm.bias", "g32"),
                           sc_d.part, Md, d)
         cur, other = gb, ga  # cur: gradient wrt the residual stream
-        w["denc32"].zero_()
+        ops.clear_f32(w["denc32"], w["denc32"].numel())
         for l in reversed(range(s.decoder_layers)):
             if not sv["dk"][l]:
                 done(f"dec{l}")
