@@ -1117,6 +1117,203 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a) {
   store_tile16<HDPV>(st, dv, one, dV, a.lddv, k0, a.Tk, hd, lane);
 }
 
+// ---- backward: dK, dV, wide waves (workgroup = 4 waves x KB key blocks of 16 = 64 * KB keys) --------------------------
+// In the kernel above a wave owns 16 keys, so every Q / dO fragment it reads from LDS feeds ONE MFMA: 80 LDS read
+// instructions (48 KiB, the transposed ones with a 2-way bank conflict) per 32 MFMAs and 32-query step - at four
+// workgroups per CU the LDS, not the matrix pipe, sets the pace (768 LDS cycles against 512 MFMA cycles per step).
+// Here a wave owns KB = 2 key blocks: each fragment feeds two MFMAs, a workgroup covers 128 keys, half as many
+// workgroups stream the same Q / dO images.
+template <int HDPV, bool DROP, int KB>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_wide_kernel(const AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NKS = HDPV / 32, NNB = HDPV / 16;
+  constexpr int IMG = 32 * HDPV * 2;
+  char* Qk = smem;         // K-major image of the 32-query tile: S = Q K^T, and (read transposed) dK += dS^T Q
+  char* dOk = smem + IMG;  // K-major image of dO:                dP = dO V^T, and (read transposed) dV += P^T dO
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, r = lane & 15;
+  int tile, h, b;
+  if (!attn_tile_of_block((a.Tk + 64 * KB - 1) / (64 * KB), a.H, a.B, tile, h, b)) return;
+  const int hd = a.hd;
+  const unsigned short* Q = a.Q + b * a.sqb + h * hd;
+  const unsigned short* K = a.K + b * a.skb + h * hd;
+  const unsigned short* V = a.V + b * a.svb + h * hd;
+  const unsigned short* dO = a.dO + b * a.sdob + h * hd;
+  const float* lse = a.lse + ((int64_t)b * a.H + h) * a.Tqp;
+  const float* Dq = a.Dq + ((int64_t)b * a.H + h) * a.Tqp;
+  const int k0 = tile * 64 * KB + wave * 16 * KB;  // block kb: keys k0 + 16 kb + r
+  int kl = a.Tk;
+  if (a.klen) kl = a.klen[b] < kl ? a.klen[b] : kl;
+  // all HDPV/32 k-steps and HDPV/16 column blocks are computed: dims >= hd are zero in every LDS image
+  bf16x8_t kf[KB][NKS], vf[KB][NKS];
+  f32x4_t dk[KB][NNB], dv[KB][NNB];
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) {
+    const int key = k0 + 16 * kb + r;
+    const int krow = key < a.Tk ? key : a.Tk - 1;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      kf[kb][ks] = load_rowfrag(K, a.ldk, krow, ks, lane, hd);
+      vf[kb][ks] = load_rowfrag(V, a.ldv, krow, ks, lane, hd);
+    }
+#pragma unroll
+    for (int nb = 0; nb < NNB; ++nb) dk[kb][nb] = dv[kb][nb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  }
+  const float scale = a.scale;
+  const float c2 = scale * LOG2E;
+  const bool full_keys = (tile * 64 * KB + 64 * KB <= kl) && !a.causal;
+  const int nstep = (a.Tq + 31) / 32;
+  const int s0 = a.causal ? (tile * 64 * KB) / 32 : 0;  // queries before the tile's first key see none of it
+  // Double-buffered: the images and the per-query statistics of step qs+1 are requested right after the barrier
+  // of step qs (one barrier per step: every wave has finished reading the other buffer when it arrives).
+  KImgFast<32, HDPV> qfast, dofast;
+  qfast.init(a.ldq, wave, lane);
+  dofast.init(a.lddo, wave, lane);
+  const int nfast = fast_tiles(a.Tq, 32);
+  auto issue = [&](int qs, int buf) {
+    if (qs < nfast) {
+      qfast.issue(Qk + buf * 2 * IMG, Q + (int64_t)qs * 32 * a.ldq, wave);
+      dofast.issue(dOk + buf * 2 * IMG, dO + (int64_t)qs * 32 * a.lddo, wave);
+    } else {
+      load_kmajor_image<32, HDPV>(Qk + buf * 2 * IMG, Q, a.ldq, qs * 32, a.Tq, hd, wave, lane);
+      load_kmajor_image<32, HDPV>(dOk + buf * 2 * IMG, dO, a.lddo, qs * 32, a.Tq, hd, wave, lane);
+    }
+  };
+  f32x4_t l0, l1, d0, d1;  // statistics of the current step: indices 8g .. 8g+7 are contiguous
+  if (s0 < nstep) {
+    issue(s0, 0);
+    l0 = *(const f32x4_t*)(lse + s0 * 32 + 8 * g);
+    l1 = *(const f32x4_t*)(lse + s0 * 32 + 8 * g + 4);
+    d0 = *(const f32x4_t*)(Dq + s0 * 32 + 8 * g);
+    d1 = *(const f32x4_t*)(Dq + s0 * 32 + 8 * g + 4);
+  }
+  for (int qs = s0; qs < nstep; ++qs) {
+    const int buf = (qs - s0) & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    f32x4_t nl0 = l0, nl1 = l1, nd0 = d0, nd1 = d1;
+    if (qs + 1 < nstep) {
+      issue(qs + 1, buf ^ 1);
+      nl0 = *(const f32x4_t*)(lse + (qs + 1) * 32 + 8 * g);
+      nl1 = *(const f32x4_t*)(lse + (qs + 1) * 32 + 8 * g + 4);
+      nd0 = *(const f32x4_t*)(Dq + (qs + 1) * 32 + 8 * g);
+      nd1 = *(const f32x4_t*)(Dq + (qs + 1) * 32 + 8 * g + 4);
+    }
+    const char* Qi = Qk + buf * 2 * IMG;
+    const char* dOi = dOk + buf * 2 * IMG;
+    const bool full = full_keys && (qs * 32 + 32 <= a.Tq);  // uniform: nothing in this step is masked
+    f32x4_t sacc[KB][2], pacc[KB][2];
+#pragma unroll
+    for (int bb = 0; bb < 2; ++bb) {
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) sacc[kb][bb] = pacc[kb][bb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      const int row = rowperm(bb, r);
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        const bf16x8_t qf = kimg_frag<32>(Qi, row, ks, lane), dof = kimg_frag<32>(dOi, row, ks, lane);
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {  // one fragment read, KB MFMAs
+          sacc[kb][bb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kf[kb][ks], sacc[kb][bb], 0, 0, 0);
+          pacc[kb][bb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dof, vf[kb][ks], pacc[kb][bb], 0, 0, 0);
+        }
+      }
+    }
+    // transposed fragments of the first half of the columns fly while the softmax arithmetic runs
+    constexpr int HB = NNB / 2;
+    bf16x8_t fo[HB], fq[HB];
+#pragma unroll
+    for (int i = 0; i < HB; ++i) {
+      fo[i] = timg_frag_k_async<32>(dOi, 0, i, lane);
+      fq[i] = timg_frag_k_async<32>(Qi, 0, i, lane);
+    }
+    bf16x8_t pf[KB], dsf[KB];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      const int key = k0 + 16 * kb + r;
+      const int krow = key < a.Tk ? key : a.Tk - 1;
+      float p[8], ds[8];
+#pragma unroll
+      for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float ls2 = (bb == 0 ? l0[e] : l1[e]) * LOG2E;
+          const float dq = bb == 0 ? d0[e] : d1[e];
+          float pv = __builtin_amdgcn_exp2f(fmaf(sacc[kb][bb][e], c2, -ls2));
+          float dpv = pacc[kb][bb][e];  // d/dP of the (dropped) probabilities
+          float pdrop = pv;             // the probability as the forward used it against V
+          if constexpr (DROP) {
+            const int qd = qs * 32 + 8 * g + 4 * bb + e;
+            const bool keep = ca_dropout_keep(a.drop_seed, attn_drop_index(a, b, h, qd < a.Tq ? qd : a.Tq - 1, krow), a.drop_p);
+            const float ks = 1.f / (1.f - a.drop_p);
+            dpv = keep ? dpv * ks : 0.f;
+            pdrop = keep ? pv * ks : 0.f;
+          }
+          float dsv = pv * (dpv - dq) * scale;
+          pv = pdrop;
+          if (!full) {  // statistics of padded queries are not initialised: select, never multiply by a mask
+            const int qi = qs * 32 + 8 * g + 4 * bb + e;
+            const bool ok = qi < a.Tq && key < kl && (!a.causal || key <= qi);
+            pv = ok ? pv : 0.f;
+            dsv = ok ? dsv : 0.f;
+          }
+          p[4 * bb + e] = pv;
+          ds[4 * bb + e] = dsv;
+        }
+      pf[kb] = pack8(p);
+      dsf[kb] = pack8(ds);
+    }
+    lds_wait_all();
+#pragma unroll
+    for (int i = 0; i < HB; ++i) {
+      tie(fo[i]);
+      tie(fq[i]);
+    }
+    bf16x8_t go[HB], gq[HB];
+#pragma unroll
+    for (int i = 0; i < HB; ++i) {
+      go[i] = timg_frag_k_async<32>(dOi, 0, HB + i, lane);
+      gq[i] = timg_frag_k_async<32>(Qi, 0, HB + i, lane);
+    }
+#pragma unroll
+    for (int i = 0; i < HB; ++i)
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+        dv[kb][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[kb], fo[i], dv[kb][i], 0, 0, 0);
+        dk[kb][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsf[kb], fq[i], dk[kb][i], 0, 0, 0);
+      }
+    lds_wait_all();
+#pragma unroll
+    for (int i = 0; i < HB; ++i) {
+      tie(go[i]);
+      tie(gq[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < HB; ++i)
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+        dv[kb][HB + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[kb], go[i], dv[kb][HB + i], 0, 0, 0);
+        dk[kb][HB + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsf[kb], gq[i], dk[kb][HB + i], 0, 0, 0);
+      }
+    l0 = nl0;
+    l1 = nl1;
+    d0 = nd0;
+    d1 = nd1;
+  }
+  unsigned short* dK = a.dK + b * a.sdkb + h * hd;
+  unsigned short* dV = a.dV + b * a.sdvb + h * hd;
+  __syncthreads();  // the last step's image reads are done in every wave: the LDS becomes output staging
+  const float one[4] = {1.f, 1.f, 1.f, 1.f};
+  char* st = smem + wave * (attn_stage_bytes(HDPV) / 4);
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) {
+    store_tile16<HDPV>(st, dk[kb], one, dK, a.lddk, k0 + 16 * kb, a.Tk, hd, lane);
+    __builtin_amdgcn_wave_barrier();
+    store_tile16<HDPV>(st, dv[kb], one, dV, a.lddv, k0 + 16 * kb, a.Tk, hd, lane);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // ---- backward: dQ (workgroup = 64 queries, loops over the keys) ------------------------------------------
 template <int HDPV, bool DROP = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_bwd_dq_kernel(const AttnArgs a) {
@@ -1502,7 +1699,18 @@ extern "C" int ca_attn_bwd(const CaAttnDesc* desc, void* stream) {
 #undef CA_DQ
   // dK, dV: 64 keys per workgroup (a 128-key, 8-wave variant with a 4-deep ring measured no faster at T = 499 and 5 %
   // slower at T = 1500: dropped)
-#define CA_DKV(HDPV, DROP) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HDPV, DROP>), gk, block, 4 * 32 * HDPV * 2, s, a)
+  // ... and a wave that owns two key blocks (128 keys per workgroup) halves the LDS fragment reads per MFMA: see
+  // attn_bwd_dkv_wide_kernel.  CA_ATTN_DKV_WIDE=0 keeps the 64-key kernel.
+  static const int dkv_wide_on = [] { const char* e = getenv("CA_ATTN_DKV_WIDE"); return e ? atoi(e) : 1; }();
+  const bool dkv_wide = dkv_wide_on && desc->Tk >= 100;
+#define CA_DKV(HDPV, DROP)                                                                                            \
+  do {                                                                                                               \
+    if (dkv_wide)                                                                                                    \
+      hipLaunchKernelGGL((attn_bwd_dkv_wide_kernel<HDPV, DROP, 2>),                                                  \
+                         dim3(attn_grid((desc->Tk + 127) / 128, desc->H, desc->B)), block, 4 * 32 * HDPV * 2, s, a); \
+    else                                                                                                             \
+      hipLaunchKernelGGL((attn_bwd_dkv_kernel<HDPV, DROP>), gk, block, 4 * 32 * HDPV * 2, s, a);                     \
+  } while (0)
   if (desc->hd <= 64) {
     if (drop) CA_DKV(64, true); else CA_DKV(64, false);
   } else {
