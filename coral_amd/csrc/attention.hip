@@ -1702,7 +1702,11 @@ extern "C" int ca_attn_bwd(const CaAttnDesc* desc, void* stream) {
   // ... and a wave that owns two key blocks (128 keys per workgroup) halves the LDS fragment reads per MFMA: see
   // attn_bwd_dkv_wide_kernel.  CA_ATTN_DKV_WIDE=0 keeps the 64-key kernel.
   static const int dkv_wide_on = [] { const char* e = getenv("CA_ATTN_DKV_WIDE"); return e ? atoi(e) : 1; }();
-  const bool dkv_wide = dkv_wide_on && desc->Tk >= 100;
+  // Measured (tools/exp_dkv.sh, rocprofv3 per-kernel averages): head_dim <= 64 (XLS-R-300M, Whisper) 226 -> 208 us over
+  // the models' shapes (XLS-R-300M backward 72.5 -> 63.1 us per layer, whisper-large-turbo encoder 523 -> 494); at
+  // head_dim 80 / 120 the doubled accumulators (374 registers) leave one wave per SIMD and it LOSES (73.3 -> 83.7 us):
+  // the 64-key kernel stays there.
+  const bool dkv_wide = dkv_wide_on && desc->Tk >= 100 && desc->hd <= 64;
 #define CA_DKV(HDPV, DROP)                                                                                            \
   do {                                                                                                               \
     if (dkv_wide)                                                                                                    \
