@@ -138,13 +138,33 @@ __global__ __launch_bounds__(256) void tap_dot_kernel(const float* __restrict__ 
   }
 }
 
-__global__ void tap_finish_kernel(const float* __restrict__ partial, int nparts, int K,
-                                  float* __restrict__ out, int do_sqrt) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= K) return;
-  float a = 0.f;
-  for (int p = 0; p < nparts; ++p) a += partial[(int64_t)p * K + j];
-  out[j] = do_sqrt ? sqrtf(a) : a;
+// out[j] = (sqrt of) sum_p partial[p][j]: 16 taps x 16 part-lanes per block (256 threads), four independent sums per
+// thread, the 16 lanes of a tap added in a fixed order through LDS (one thread walking all the slabs was a chain of
+// 1024 dependent loads: 235 us).
+__global__ __launch_bounds__(256) void tap_finish_kernel(const float* __restrict__ partial, int nparts, int K,
+                                                         float* __restrict__ out, int do_sqrt) {
+  __shared__ float red[16][17];
+  const int tl = threadIdx.x & 15, pl = threadIdx.x >> 4;
+  const int j = blockIdx.x * 16 + tl;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (j < K) {
+    int p = pl;
+    for (; p + 48 < nparts; p += 64) {
+      a0 += partial[(int64_t)p * K + j];
+      a1 += partial[(int64_t)(p + 16) * K + j];
+      a2 += partial[(int64_t)(p + 32) * K + j];
+      a3 += partial[(int64_t)(p + 48) * K + j];
+    }
+    for (; p < nparts; p += 16) a0 += partial[(int64_t)p * K + j];
+  }
+  red[pl][tl] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (pl == 0 && j < K) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += red[q][tl];
+    out[j] = do_sqrt ? sqrtf(t) : t;
+  }
 }
 
 // one block per (row-set): transposes a [R][K] fp32 panel into [K][R] bf16 with scaling.
@@ -189,7 +209,7 @@ extern "C" int ca_posconv_weight(const float* v, const float* g, void* wf, void*
   const int64_t nrows = (int64_t)d * Cg;
   hipLaunchKernelGGL(tap_dot_kernel, dim3(PCW_SLABS), dim3(256), 0, s, v, v, partial, nrows, K, 0,
                      Cg, d / Cg);
-  hipLaunchKernelGGL(tap_finish_kernel, dim3(1), dim3(256), 0, s, partial, PCW_SLABS, K, norm, 1);
+  hipLaunchKernelGGL(tap_finish_kernel, dim3((K + 15) / 16), dim3(256), 0, s, partial, PCW_SLABS, K, norm, 1);
   const size_t lds = (size_t)Cg * (K + 1) * sizeof(float);
   hipLaunchKernelGGL(posconv_build_kernel, dim3(d), dim3(256), lds, s, v, g, norm,
                      (unsigned short*)wf, Cg, K, 0);
@@ -239,7 +259,7 @@ extern "C" int ca_posconv_weight_bwd(const float* dwf, const float* v, const flo
   float* dot = partial + (int64_t)PCW_SLABS * K;
   hipLaunchKernelGGL(tap_dot_kernel, dim3(PCW_SLABS), dim3(256), 0, s, v, dwf, partial, nrows, K,
                      1, Cg, d / Cg);
-  hipLaunchKernelGGL(tap_finish_kernel, dim3(1), dim3(256), 0, s, partial, PCW_SLABS, K, dot, 0);
+  hipLaunchKernelGGL(tap_finish_kernel, dim3((K + 15) / 16), dim3(256), 0, s, partial, PCW_SLABS, K, dot, 0);
   const size_t lds = (size_t)K * (Cg + 1) * sizeof(float);
   hipLaunchKernelGGL(posconv_wbwd_kernel, dim3(d), dim3(256), lds, s, dwf, v, g, norm, dot, dv,
                      Cg, K);
