@@ -300,7 +300,9 @@ def whisper_bench(args, world, rank, device):
     if world > 1:
         if args.check_replicas and not args.decode:
             torch.cuda.synchronize()
-            p = eng.store.p32
+            # (sharded optimiser: the fp32 master is complete only on the owning rank between steps; the bf16 compute copy,
+            # all-gathered every step, is what every rank must agree on)
+            p = eng.store.p16.float() if args.zero_stage else eng.store.p32
             lo, hi = p.clone(), p.clone()
             torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
             torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
@@ -466,10 +468,11 @@ def main():
                     help="dtype of the gradient all-reduce at N>1: fp32 = what the reference's DDP reduces (accelerate "
                          "bf16 autocast keeps fp32 gradients); bf16 = the DDP bf16_compress_hook trade, a separate "
                          "labelled measurement, never the headline")
-    ap.add_argument("--zero-stage", type=int, default=0,
+    ap.add_argument("--zero-stage", type=int, default=None,
                     help="N>1: shard the optimiser over the ranks (reduce-scatter of the weight-matrix gradients, AdamW on "
-                         "1/N, all-gather of the bf16 weights) - the reference's `accelerate launch --zero-stage 2` mode "
-                         "(R/makefile:79-84); 0 = replicated DDP semantics (default)")
+                         "1/N, all-gather of the bf16 weights) - the reference's production launch `accelerate launch "
+                         "--zero-stage 2` (R/makefile:79-84).  Default: 2 at N>1 (a one-time self-check of the RCCL "
+                         "in-place collectives falls back to replicated DDP if it fails), 0 at N=1; 0 = replicated DDP")
     ap.add_argument("--ragged", action="store_true",
                     help="utterance lengths ~ U[1 s, --seconds] padded to --seconds (the regime of "
                          "R/config/asr_finetuning.yaml:31-32): masked attention / CTC lengths / SpecAugment on valid frames")
@@ -489,6 +492,8 @@ def main():
         raise SystemExit(spawn_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if args.zero_stage is None:
+        args.zero_stage = 2 if world > 1 else 0
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
@@ -622,7 +627,10 @@ def main():
     if world > 1:
         if args.check_replicas:
             # DDP invariant: identical parameters on every rank after identical (averaged) updates
-            p = eng.store.p32
+            # (sharded optimiser: the fp32 master is complete only on the owning rank between steps; the bf16 compute copy,
+            # all-gathered every step, is what every rank must agree on)
+            torch.cuda.synchronize()
+            p = eng.store.p16.float() if args.zero_stage else eng.store.p32
             lo, hi = p.clone(), p.clone()
             torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
             torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)

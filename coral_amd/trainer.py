@@ -230,12 +230,21 @@ class DataParallelTrainer:
             shard = {n: r for n, r in engine.shard_ranges().items() if (r[1] - r[0]) % (8 * world) == 0 and r[1] > r[0]}
         self.sync = GradSync(st.g32, st.buckets, process_group, compress=compress_grads, shard=shard)
         self.zero = bool(shard) and self.sync.active
+        if self.zero and world > 1 and st.p32.is_cuda and not self._collectives_selfcheck(st.device, process_group):
+            # (never silently wrong: a backend whose in-place reduce-scatter / all-gather does not behave as RCCL
+            # documents falls back to the replicated path, and says so)
+            import logging
+
+            logging.getLogger(__package__).warning("sharded optimiser: the collective self-check failed; using replicated DDP")
+            self.sync = GradSync(st.g32, st.buckets, process_group, compress=compress_grads)
+            self.zero = False
         self.world = self.sync.world
         self.dist = self.sync.active  # gradients are exchanged (world > 1, or a forced one-rank group)
         self.overlap = overlap and self.dist
         # AdamW moments.  Replicated: the parameters' own offsets.  Sharded: a compact buffer holding, bucket by bucket,
         # the replicated part [lo, mlo) and this rank's slice of the sharded part - 1/N of the state.
         self._state_off = None
+        self._ag_stream = None
         if self.zero:
             self._state_off, n = {}, 0
             for name, (blo, bhi) in st.buckets.items():
@@ -443,13 +452,23 @@ class DataParallelTrainer:
             adam(a, mlo, rep_off)           # replicated small tensors
             sa, sb = self.sync.slice_of(name)
             adam(sa, sb, sl_off)            # this rank's slice of the matrices (fp32 master, moments, bf16 copy)
-            self._allgather_bf16(mlo, bhi, sa, sb)
+            # the bf16 slices travel on a stream of their own: the AdamW of the next bucket does not wait for this
+            # bucket's all-gather, only the forward's per-bucket wait does (the event below is recorded behind it)
+            cur = torch.cuda.current_stream()
+            if self._ag_stream is None:
+                self._ag_stream = torch.cuda.Stream(device=st.device)
+            self._ag_stream.wait_stream(cur)
+            with torch.cuda.stream(self._ag_stream):
+                self._allgather_bf16(mlo, bhi, sa, sb)
+            return self._ag_stream
 
         rebucket = getattr(eng, "refresh_bucket", None)  # engines with derived per-bucket weight copies (fp8)
         if not self.overlap_optimizer:
             if self.zero:
                 for name, (a, b) in st.buckets.items():
                     update(a, b, name)
+                if self._ag_stream is not None:
+                    torch.cuda.current_stream().wait_stream(self._ag_stream)
             else:
                 update(lo, hi)
             if not eng.freeze_base:
@@ -464,7 +483,9 @@ class DataParallelTrainer:
         with torch.cuda.stream(self.opt_stream):
             order = sorted(st.buckets.items(), key=lambda kv: kv[1][0])
             for name, (a, b) in order:
-                update(a, b, name)
+                gathered_on = update(a, b, name)
+                if gathered_on is not None and rebucket is not None:
+                    self.opt_stream.wait_stream(gathered_on)  # (derived per-bucket copies read the gathered weights)
                 if rebucket is not None:
                     rebucket(name)
                 parts = getattr(eng, "derived_parts", None) if name == "front" else None
@@ -473,7 +494,7 @@ class DataParallelTrainer:
                 if parts:
                     eng.refresh_derived(parts[0])
                 ev = torch.cuda.Event()
-                ev.record(self.opt_stream)
+                ev.record(gathered_on if (gathered_on is not None and rebucket is None) else self.opt_stream)
                 events[name] = ev
                 for part in (parts or ())[1:]:  # later parts of the derived weights get events of their own
                     eng.refresh_derived(part)
@@ -487,9 +508,38 @@ class DataParallelTrainer:
                 # the layers' small tensors) here, under the next forward
                 eng.clear_small_grads()
                 eng._pre_zeroed = True
+            if self._ag_stream is not None:
+                self.opt_stream.wait_stream(self._ag_stream)  # `finish()` = every gather has landed too
             self.opt_done = torch.cuda.Event()
             self.opt_done.record(self.opt_stream)
         eng.weights_ready = events
+
+    @staticmethod
+    def _collectives_selfcheck(device, pg) -> bool:
+        """One-time check, on the real process group, of the two in-place forms the sharded optimiser relies on:
+        reduce_scatter_tensor with the output slice inside the input buffer (at input + rank x count) and
+        all_gather_into_tensor with the input slice inside the output buffer, against a plain all-reduce."""
+        world, rank = torch.distributed.get_world_size(pg), torch.distributed.get_rank(pg)
+        n = 4096
+        base = torch.arange(world * n, dtype=torch.float32, device=device) % 257
+        x = base * (rank + 1)
+        want = base * (world * (world + 1) // 2)
+        try:
+            if torch.distributed.get_backend(pg) == "nccl":
+                buf = x.clone()
+                torch.distributed.reduce_scatter_tensor(buf[rank * n:(rank + 1) * n], buf, group=pg)
+                ok = torch.equal(buf[rank * n:(rank + 1) * n], want[rank * n:(rank + 1) * n])
+                g = torch.zeros(world * n, dtype=torch.bfloat16, device=device)
+                g[rank * n:(rank + 1) * n] = (base[rank * n:(rank + 1) * n]).to(torch.bfloat16)
+                torch.distributed.all_gather_into_tensor(g, g[rank * n:(rank + 1) * n], group=pg)
+                ok = ok and torch.equal(g, base.to(torch.bfloat16))
+            else:
+                ok = True
+            flag = torch.tensor([1.0 if ok else 0.0], device=device)
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN, group=pg)
+            return bool(flag.item() > 0.5)
+        except Exception:  # noqa: BLE001
+            return False
 
     def _allgather_bf16(self, mlo, hi, a, b):
         """Every rank's freshly updated bf16 slice -> the whole [mlo, hi) of the compute copy, on the current stream."""

@@ -15,11 +15,13 @@ pytestmark = pytest.mark.gpu
 ROOT = Path(__file__).resolve().parents[1]
 
 
-def test_bench_spawns_its_ranks_and_reports_them():
+@pytest.mark.parametrize("zero", [None, 0])
+def test_bench_spawns_its_ranks_and_reports_them(zero):
+    """zero = None: the N > 1 default (sharded optimiser, the reference's `--zero-stage 2` launch); 0: replicated DDP."""
     env = dict(os.environ, CA_BENCH_SHARE_GPU="1")
     env.pop("WORLD_SIZE", None)
     cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--backend", "gloo", "--model", "wav2vec2-small",
-           "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--check-replicas"]
+           "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--check-replicas"] + ([] if zero is None else ["--zero-stage", str(zero)])
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=str(ROOT))
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
@@ -29,6 +31,7 @@ def test_bench_spawns_its_ranks_and_reports_them():
     assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["grad_wire"] == "fp32" and d["scaling"] == "weak"
     assert d["config"]["global_batch"] == 16 and d["config"]["parallelism"] == "dp2"
     assert d["value"] > 0 and d["steps"] == 2 and d["warmup"] == 1
+    assert ("sharded optimiser" in d["config"]["workload"]) == (zero is None)
     spread = [x for x in lines if "replica_param_spread" in x]
     assert spread and spread[0]["replica_param_spread"] == 0.0   # DDP invariant: identical replicas
 
