@@ -600,7 +600,7 @@ def main():
         del r3
         torch.cuda.empty_cache()
         dec = {}
-        for Bd in (8, 16):  # (the K|V-cached greedy step runs on the weight-streaming kernel: M = batch <= 16)
+        for Bd in (8, 16, 32):  # (the K|V-cached greedy step runs on the weight-streaming kernel: M = batch <= 32)
             r4 = whisper_measure("whisper-medium", args, world, rank, device, decode=True, B=Bd, steps=3, warmup=1)
             dec[f"B{Bd}"] = {"ms_per_token": round(r4["ms_per_token"], 4), "bytes_per_token": int(r4["bytes_per_token"]),
                              "frac_of_8TBps": round(r4["hbm_frac"], 4),

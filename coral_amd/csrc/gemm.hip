@@ -1747,14 +1747,17 @@ __global__ __launch_bounds__(256) void ca_gemm_kernel_w(const CaGemmDesc d) {
   }
 }
 
-// ---- skinny-M kernel: M <= 16 rows (one decoded token per clip) -------------------------------------
+// ---- skinny-M kernel: M <= 32 rows (one decoded token per clip) -------------------------------------
 // C[m, n] = epilogue(alpha * sum_k A[m, k] W[n, k]): a weight-streaming problem (every weight byte is used once),
 // so there is no LDS staging: each wave owns 16 output columns and a quarter of K, loads its W fragment
-// (16 rows x 64 B) and the matching A fragment straight from global memory into MFMA operands, eight k-steps
+// (16 rows x 64 B) and the matching A fragment(s) straight from global memory into MFMA operands, eight k-steps
 // in flight; the four waves of a workgroup add their partial tiles through LDS and wave 0 runs the epilogue.
-// N/16 workgroups: 64 (N = 1024) to 3242 (the 51865-entry vocabulary).
+// N/16 workgroups: 64 (N = 1024) to 3242 (the 51865-entry vocabulary).  MB = row blocks of 16: a batch of 17..32 clips
+// takes a second A fragment and accumulator against the SAME weight fragment (round 3: the launches and the weight
+// bytes of a decoded token are shared by twice the clips).
+template <int MB>
 __global__ __launch_bounds__(256) void ca_gemm_skinny_kernel(const CaGemmDesc d) {
-  __shared__ float part[4][16 * 16];
+  __shared__ float part[4][MB * 16 * 16];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n0 = blockIdx.x * 16;
@@ -1762,79 +1765,102 @@ __global__ __launch_bounds__(256) void ca_gemm_skinny_kernel(const CaGemmDesc d)
   const __bf16* A = (const __bf16*)d.A;
   const __bf16* W = (const __bf16*)d.B;
   const int nrow = n0 + r < d.N ? n0 + r : d.N - 1;
-  const int mrow = r < d.M ? r : d.M - 1;
   const __bf16* wp = W + (int64_t)nrow * d.ldb + 8 * g;
-  const __bf16* ap = A + (int64_t)mrow * d.lda + 8 * g;
+  const __bf16* ap[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    const int m = 16 * mb + r;
+    ap[mb] = A + (int64_t)(m < d.M ? m : d.M - 1) * d.lda + 8 * g;
+  }
   const int ksteps = (d.K + 31) / 32;
   const int per = (ksteps + 3) / 4;
   const int ks0 = wave * per, ks1 = (ks0 + per < ksteps) ? ks0 + per : ksteps;
-  f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+  f32x4_t acc[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) acc[mb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   const bf16x8_t zero = __builtin_bit_cast(bf16x8_t, (f32x4_t){0.f, 0.f, 0.f, 0.f});
   // The kernel is a short chain of memory round trips behind a ~4 us dependent launch (measured: 4.0 us per launch
   // in a graph at N = K = 1024, +1 us per 24 KB a workgroup streams - the per-CU fill rate - tools/dev_skinny_time.py),
   // so the epilogue's operands (bias, residual, destination row) are asked for up front, beside the first K-steps.
   const int epi = d.epilogue;
-  const bool fin = wave == 0 && r < d.M;  // lanes that finish output row m = r, columns n0 + 4g .. +3
-  float e_bias[4] = {0.f, 0.f, 0.f, 0.f}, e_res[4] = {0.f, 0.f, 0.f, 0.f};
-  int64_t crow = r;
-  if (fin) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int n = n0 + 4 * g + e;
-      if (n < d.N) {
-        if (d.bias) e_bias[e] = d.bias[n];
-        if (epi == CA_EPI_GELU_RESIDUAL || epi == CA_EPI_RESIDUAL)
-          e_res[e] = bf2f(((const unsigned short*)d.R)[(int64_t)r * d.ldr + n]);
-      }
-    }
-    if (d.c_row_index && (d.c_split_n == 0 || n0 >= d.c_split_n)) crow = (int64_t)r * d.c_row_mul + d.c_row_index[r];
-  }
+  const bool wave0 = wave == 0;
+  float e_bias[4] = {0.f, 0.f, 0.f, 0.f}, e_res[MB][4];
+  int64_t crow[MB];
   // c_split_n: columns [c_split_n, N) go to a second output (C_hi, ldc_hi; column index n - c_split_n) and only they
   // take the c_row_index rows - q and the cached K|V rows of a decoded token from one launch.  n0 is a multiple of
   // 16 and so is c_split_n: a workgroup is on one side.
   const bool hi = d.c_split_n > 0 && n0 >= d.c_split_n;
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    const int m = 16 * mb + r;
+    crow[mb] = m;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) e_res[mb][e] = 0.f;
+    if (wave0 && m < d.M) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int n = n0 + 4 * g + e;
+        if (n < d.N) {
+          if (mb == 0 && d.bias) e_bias[e] = d.bias[n];
+          if (epi == CA_EPI_GELU_RESIDUAL || epi == CA_EPI_RESIDUAL)
+            e_res[mb][e] = bf2f(((const unsigned short*)d.R)[(int64_t)m * d.ldr + n]);
+        }
+      }
+      if (d.c_row_index && (d.c_split_n == 0 || hi)) crow[mb] = (int64_t)m * d.c_row_mul + d.c_row_index[m];
+    }
+  }
   void* const Cdst = hi ? d.C_hi : d.C;
   const int64_t ldcd = hi ? d.ldc_hi : d.ldc;
   const int ncol0 = hi ? d.c_split_n : 0;
   for (int ks = ks0; ks < ks1; ks += 8) {
-    bf16x8_t wf[8], af[8];
+    bf16x8_t wf[8], af[MB][8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int k = (ks + u) * 32 + 8 * g;
       const bool ok = ks + u < ks1 && k < d.K;  // K is a multiple of 8 (lda/ldb rule), so a chunk is all-or-nothing
       wf[u] = ok ? *(const bf16x8_t*)(wp + (int64_t)(ks + u) * 32) : zero;
-      af[u] = (ok && r < d.M) ? *(const bf16x8_t*)(ap + (int64_t)(ks + u) * 32) : zero;
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+        af[mb][u] = (ok && 16 * mb + r < d.M) ? *(const bf16x8_t*)(ap[mb] + (int64_t)(ks + u) * 32) : zero;
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u], af[u], acc, 0, 0, 0);
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u], af[mb][u], acc[mb], 0, 0, 0);
   }
   // D[n = 4g + e][m = r]: lane holds 4 consecutive n of row m
 #pragma unroll
-  for (int e = 0; e < 4; ++e) part[wave][r * 16 + 4 * g + e] = acc[e];
-  __syncthreads();
-  if (!fin) return;
+  for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int n = n0 + 4 * g + e;
-    if (n >= d.N) continue;
-    const int i = r * 16 + 4 * g + e;
-    float v = (part[0][i] + part[1][i]) + (part[2][i] + part[3][i]);
-    v = v * d.alpha + e_bias[e];
-    float v2 = 0.f;
-    if (epi == CA_EPI_GELU || epi == CA_EPI_GELU_RESIDUAL) {
-      v2 = gelu_erf(v);
-      if (epi == CA_EPI_GELU_RESIDUAL) v2 += e_res[e];
-    } else if (epi == CA_EPI_RESIDUAL) {
-      v += e_res[e];
+    for (int e = 0; e < 4; ++e) part[wave][mb * 256 + r * 16 + 4 * g + e] = acc[mb][e];
+  __syncthreads();
+  if (!wave0) return;
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    if (16 * mb + r >= d.M) continue;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int n = n0 + 4 * g + e;
+      if (n >= d.N) continue;
+      const int i = mb * 256 + r * 16 + 4 * g + e;
+      float v = (part[0][i] + part[1][i]) + (part[2][i] + part[3][i]);
+      v = v * d.alpha + e_bias[e];
+      float v2 = 0.f;
+      if (epi == CA_EPI_GELU || epi == CA_EPI_GELU_RESIDUAL) {
+        v2 = gelu_erf(v);
+        if (epi == CA_EPI_GELU_RESIDUAL) v2 += e_res[mb][e];
+      } else if (epi == CA_EPI_RESIDUAL) {
+        v += e_res[mb][e];
+      }
+      const int64_t off = crow[mb] * ldcd + (n - ncol0);
+      if (Cdst) {
+        if (d.out_f32)
+          ((float*)Cdst)[off] = d.accumulate ? ((float*)Cdst)[off] + v : v;
+        else
+          ((unsigned short*)Cdst)[off] = f2bf(d.accumulate ? bf2f(((unsigned short*)Cdst)[off]) + v : v);
+      }
+      if ((epi == CA_EPI_GELU || epi == CA_EPI_GELU_RESIDUAL) && d.C2) ((unsigned short*)d.C2)[off] = f2bf(v2);
     }
-    const int64_t off = crow * ldcd + (n - ncol0);
-    if (Cdst) {
-      if (d.out_f32)
-        ((float*)Cdst)[off] = d.accumulate ? ((float*)Cdst)[off] + v : v;
-      else
-        ((unsigned short*)Cdst)[off] = f2bf(d.accumulate ? bf2f(((unsigned short*)Cdst)[off]) + v : v);
-    }
-    if ((epi == CA_EPI_GELU || epi == CA_EPI_GELU_RESIDUAL) && d.C2) ((unsigned short*)d.C2)[off] = f2bf(v2);
   }
 }
 
@@ -2370,17 +2396,20 @@ static int ca_gemm_launch(const CaGemmDesc* desc, void* stream) {
   CA_CHECK_ARG(d.a_layout == CA_KMAJOR || d.a_layout == CA_MNMAJOR, "ca_gemm_bf16: bad a_layout");
   CA_CHECK_ARG(d.b_layout == CA_KMAJOR || d.b_layout == CA_MNMAJOR, "ca_gemm_bf16: bad b_layout");
   // Skinny M (greedy decoding: one token per clip): weight streaming without LDS staging.
-  if (g_force_kernel == 0 && d.M <= 16 && d.a_layout == CA_KMAJOR && d.b_layout == CA_KMAJOR && d.batch1 == 1 &&
+  if (g_force_kernel == 0 && d.M <= 32 && d.a_layout == CA_KMAJOR && d.b_layout == CA_KMAJOR && d.batch1 == 1 &&
       d.batch2 == 1 && d.a_kseg == 0 && d.b_kseg == 0 && d.dropout_p == 0.f && d.epilogue != CA_EPI_DGELU) {
     g_last_kind = 0;
     CA_CHECK_ARG(d.c_split_n == 0 || (d.C_hi && (d.c_split_n % 16) == 0 && d.c_split_n < d.N && d.epilogue == CA_EPI_NONE),
                  "ca_gemm_bf16: c_split_n needs C_hi, a multiple of 16 below N and no epilogue");
-    CA_LAUNCH(ca_gemm_skinny_kernel, dim3((unsigned)((d.N + 15) / 16)), dim3(256), 0, s, d);
+    if (d.M <= 16)
+      CA_LAUNCH(ca_gemm_skinny_kernel<1>, dim3((unsigned)((d.N + 15) / 16)), dim3(256), 0, s, d);
+    else
+      CA_LAUNCH(ca_gemm_skinny_kernel<2>, dim3((unsigned)((d.N + 15) / 16)), dim3(256), 0, s, d);
     CA_CHECK_LAUNCH("ca_gemm_bf16");
     return CA_OK;
   }
   CA_CHECK_ARG(!d.c_row_index && d.c_split_n == 0,
-               "ca_gemm_bf16: c_row_index / c_split_n exist in the skinny form only (M <= 16, K-major operands, un-batched)");
+               "ca_gemm_bf16: c_row_index / c_split_n exist in the skinny form only (M <= 32, K-major operands, un-batched)");
   // Kernel choice: the 256x128 pipelined kernel runs one workgroup per CU, so it needs enough
   // tiles to fill the chip; small or heavily batched problems use the 128x128 kernel.
   const int64_t nb = (int64_t)d.batch1 * d.batch2;

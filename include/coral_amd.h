@@ -102,7 +102,7 @@ typedef struct CaGemmDesc {
    * (ca_reduce_rows_f32).  NULL = off. */
   float* a_colsum;
   int64_t a_colsum_ld;
-  /* Optional, skinny form only (M <= 16, both operands K-major, un-batched: one decoded token per clip,
+  /* Optional, skinny form only (M <= 32, both operands K-major, un-batched: one decoded token per clip,
    * R/src/coral/whisper.py generate path): output row m goes to row m * c_row_mul + c_row_index[m] of C (device-side
    * positions: the new token's K|V rows appended to a cache at a position that is data, not a launch argument).
    * NULL = rows in place. */

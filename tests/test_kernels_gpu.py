@@ -512,9 +512,11 @@ def test_fused_attention_fwd_bwd(ops, hd, H, Tq, Tk, causal, pad):
         assert err < 3e-2 * max(1.0, want.abs().max().item()), (err, want.abs().max().item())
 
 
-@pytest.mark.parametrize("M,N,K", [(8, 1024, 1024), (3, 1000, 4096), (16, 51865, 384), (1, 72, 40)])
+@pytest.mark.parametrize("M,N,K", [(8, 1024, 1024), (3, 1000, 4096), (16, 51865, 384), (1, 72, 40), (32, 1024, 1024), (17, 520, 264),
+                                   (29, 51865, 128)])
 def test_skinny_gemm_matches_torch(ops, M, N, K):
-    """M <= 16 (one decoded token per clip) takes the weight-streaming kernel: bias, GELU (second output),
+    """M <= 32 (one decoded token per clip; 17..32 rows take a second row block against the same weight fragment) takes
+    the weight-streaming kernel: bias, GELU (second output),
     residual, fp32 output with a padded leading dimension (the LM head)."""
     g = torch.Generator().manual_seed(M * 1000 + N)
     A = (torch.randn(M, K, generator=g) * 0.5).to(torch.bfloat16)
@@ -570,7 +572,7 @@ def test_weight_gradient_with_fused_bias_gradient_and_grouped_launch(ops):
             assert (gb - wb).abs().max() <= 2e-3 * max(1.0, float(wb.abs().max())), ("bias", i, fused)
 
 
-@pytest.mark.parametrize("M,N,K", [(8, 1024, 1024), (5, 1000, 1280), (16, 264, 384)])
+@pytest.mark.parametrize("M,N,K", [(8, 1024, 1024), (5, 1000, 1280), (16, 264, 384), (32, 1024, 512), (21, 264, 384)])
 def test_gemm_skinny_row_index(ops, M, N, K):
     """CaGemmDesc.c_row_index (one decoded token per clip): the output rows land at device-side positions of a
     [M, L, N] cache, bit-identical to the plain GEMM's rows; the tiled kernels refuse the option."""
@@ -651,10 +653,11 @@ def test_argmax_masked_first_maximum_and_suppression(ops, V, Vp):
     assert out.cpu().numpy().tolist() == ref.tolist()
 
 
-def test_gemm_skinny_split_output(ops):
+@pytest.mark.parametrize("M", [8, 24])
+def test_gemm_skinny_split_output(ops, M):
     """CaGemmDesc.c_split_n: columns [0, d) to one buffer in place, columns [d, 3d) to the rows of a cache at
     device-side positions - the q projection and the new K|V rows of a decoded token from one launch."""
-    M, d, K, L = 8, 128, 256, 5
+    d, K, L = 128, 256, 5
     x = bf(rnd(M, K, seed=41, scale=0.5)).to(DEV)
     W = bf(rnd(3 * d, K, seed=42, scale=0.1)).to(DEV)
     bias = rnd(3 * d, seed=43).to(DEV)
