@@ -264,7 +264,7 @@ static int ln_bwd_grid(int64_t rows, int C) {
   return (int)g;
 }
 
-template <int NCH, bool ACT>
+template <int NCH, bool ACT, bool DPP>
 __global__ __launch_bounds__(256, 2) void ln_bwd_kernel(
     const unsigned short* __restrict__ dy, const unsigned short* __restrict__ x,
     const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -366,8 +366,10 @@ __global__ __launch_bounds__(256, 2) void ln_bwd_kernel(
       }
     }
     // (chunks beyond the row hold zeros and gamma = 0 there: they add nothing)
-    const float m1 = wave_sum(s1) / (float)C;
-    const float m2 = wave_sum(s2) / (float)C;
+    // (two waves per SIMD here: the DPP + readlane reduction of common.h no longer loses to the shuffle butterfly the way
+    // it did with eight waves hiding the crossbar latency - 19.6 -> 17.5 us at [3992, 1920]; CA_LN_BWD_DPP=0 selects the butterfly)
+    const float m1 = (DPP ? wave_sum_dpp(s1) : wave_sum(s1)) / (float)C;
+    const float m2 = (DPP ? wave_sum_dpp(s2) : wave_sum(s2)) / (float)C;
     unsigned short* dxr = dx + row * C;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
@@ -511,16 +513,19 @@ extern "C" int ca_layernorm_bwd(const void* dy, const void* x, const float* gamm
   dim3 grid(g), block(256);
   const size_t lds = (size_t)4 * 2 * C * sizeof(float);
   hipStream_t s = (hipStream_t)stream;
-#define LN_BWD_(N, A)                                                                          \
-  hipLaunchKernelGGL((ln_bwd_kernel<N, A>), grid, block, lds, s, (const unsigned short*)dy,    \
+#define LN_BWD_(N, A, D)                                                                       \
+  hipLaunchKernelGGL((ln_bwd_kernel<N, A, D>), grid, block, lds, s, (const unsigned short*)dy, \
                      (const unsigned short*)x, gamma, beta, stats,                             \
                      (const unsigned short*)dres, (unsigned short*)dx, partial, rows, C)
-#define LN_BWD(N)        \
-  do {                   \
-    if (act)             \
-      LN_BWD_(N, true);  \
-    else                 \
-      LN_BWD_(N, false); \
+  static const int use_dpp = [] { const char* e = getenv("CA_LN_BWD_DPP"); return e ? atoi(e) : 1; }();
+#define LN_BWD(N)                \
+  do {                           \
+    if (act)                     \
+      LN_BWD_(N, true, true);    \
+    else if (use_dpp)            \
+      LN_BWD_(N, false, true);   \
+    else                         \
+      LN_BWD_(N, false, false);  \
   } while (0)
   switch (nch) {
     case 1: LN_BWD(1); break;
