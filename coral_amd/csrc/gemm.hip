@@ -1204,6 +1204,8 @@ __global__ __launch_bounds__(512) void ca_gemm_kernel_x(const CaGemmGroup grp) {
   asm volatile("" ::: "memory");
 #ifdef X_STAMPS
   const long long stamp_t1 = __builtin_amdgcn_s_memtime();
+  const long long stamp_r1 = __builtin_amdgcn_s_memrealtime();  // 100 MHz: the loop's shader clock = d memtime / d realtime x 100 MHz
+  __builtin_amdgcn_s_waitcnt(0xC07F);
 #endif
   X_RD_B(0, 0, 0, B0[0]); X_RD_B(0, 0, 1, B0[1]); X_RD_B(0, 0, 2, B0[2]); X_RD_B(0, 0, 3, B0[3]);
   X_RD_A(0, 0, 0, A0[0]); X_RD_A(0, 0, 1, A0[1]); X_RD_A(0, 0, 2, A0[2]); X_RD_A(0, 0, 3, A0[3]);
@@ -1218,6 +1220,7 @@ __global__ __launch_bounds__(512) void ca_gemm_kernel_x(const CaGemmGroup grp) {
 #undef X_SB
 #ifdef X_STAMPS
   const long long stamp_t2 = __builtin_amdgcn_s_memtime();
+  const long long stamp_r2 = __builtin_amdgcn_s_memrealtime();
 #endif
   if (AL == CA_MNMAJOR && do_colsum) {
     // a lane's fragment holds k = 8g..8g+7 of a 32-k step: add the four lane groups, then lanes 0-15 own 16 rows
@@ -1256,6 +1259,7 @@ __global__ __launch_bounds__(512) void ca_gemm_kernel_x(const CaGemmGroup grp) {
       o[3] = stamp_dma;
       o[4] = stamp_bar;
       o[5] = nk;
+      o[6] = stamp_r2 - stamp_r1;  // main loop in 100-MHz ticks
     }
   }
 #endif

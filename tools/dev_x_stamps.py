@@ -23,8 +23,11 @@ def stamps():
 
 def report(name, nwg):
     s = stamps()[:nwg].astype(np.float64)
-    pro, loop, epi, dma, bar, nk = [s[:, :, i] for i in range(6)]
+    pro, loop, epi, dma, bar, nk, rt = [s[:, :, i] for i in range(7)]
     nk = nk.mean()
+    ok = rt > 0
+    print(f"      shader clock inside the main loop (d s_memtime / d s_memrealtime x 100 MHz, median over waves): "
+          f"{np.median(loop[ok] / rt[ok]) * 0.1:.2f} GHz")
     print(f"{name}: nk {nk:.0f} | prologue {pro.mean():7.0f} | loop {loop.mean():8.0f} = {loop.mean() / nk:6.0f}/k-step "
           f"(2048 = MFMA floor at 2 waves per SIMD) | dma wait {dma.mean() / nk:5.0f}/k-step  barrier wait {bar.mean() / nk:5.0f}/k-step "
           f"| epilogue {epi.mean():7.0f}   [s_memtime ticks]")
@@ -53,6 +56,10 @@ def run(name, M, N, K, al, bl, out_f32, **extra):
     lib.ca_gemm_force_kernel(0)
 
 
+if len(sys.argv) > 1:  # M N K al bl [out_f32]
+    a = [int(x) for x in sys.argv[1:]]
+    run(" ".join(sys.argv[1:]), a[0], a[1], a[2], a[3], a[4], bool(a[5]) if len(a) > 5 else False)
+    sys.exit(0)
 run("wgrad fc (TN, fp32 out)", 7680, 1920, 3992, 1, 1, True)
 run("fc1 fwd plain (NT)", 3992, 7680, 1920, 0, 0, False)
 run("fc2 dgrad plain (NN)", 3992, 7680, 1920, 0, 1, False)
