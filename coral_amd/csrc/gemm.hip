@@ -494,6 +494,8 @@ __device__ __forceinline__ void gemm_epilogue_fast(const CaGemmDesc& d, const fl
   }
 }
 
+// PARKED: the 64 x 64 staging tile `wave` already holds the accumulators (kernel M: two waves fill one tile)
+template <bool PARKED = false>
 __device__ __forceinline__ void gemm_epilogue(const CaGemmDesc& d, f32x4_t (&acc)[4][4], char* smem,
                                               int wave, int lane, int mw, int nw, int z, int z1,
                                               int z2, const float (*bias_pre)[8] = nullptr) {
@@ -529,12 +531,14 @@ __device__ __forceinline__ void gemm_epilogue(const CaGemmDesc& d, f32x4_t (&acc
   load_r(0, r_next);
 
   float* wt = (float*)smem + wave * (64 * EPI_PITCH);
+  if (!PARKED) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      *(f32x4_t*)(wt + (i * 16 + (lane & 15)) * EPI_PITCH + j * 16 + 4 * (lane >> 4)) = acc[i][j];
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private region: no barrier
+      for (int j = 0; j < 4; ++j)
+        *(f32x4_t*)(wt + (i * 16 + (lane & 15)) * EPI_PITCH + j * 16 + 4 * (lane >> 4)) = acc[i][j];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private region: no barrier
+  }
   if (nvalid <= 0 && d.c_sumsq == nullptr) return;
   float ssq = 0.f;  // sum of squares of the fp32 values this lane stores (c_sumsq)
   // interior wave tile (wave-uniform test): the specialised walk above
@@ -829,6 +833,145 @@ __global__ __launch_bounds__(256) void ca_gemm_kernel(const CaGemmDesc d) {
   __builtin_amdgcn_s_barrier();  // all waves are done with the stages before the epilogue reuses the LDS
   asm volatile("" ::: "memory");
   gemm_epilogue(d, acc, smem, wave, lane, m0 + wm * 64, n0 + wn * 64, z, z1, z2);
+}
+
+// ---- kernel M: 128x128 tile, 8 waves (2x4, 64x32 each), 4 LDS stages, one workgroup per CU --------------------------
+// For grids of at most one 128x128 tile per CU (the N = d GEMMs of the d = 1024 models at M = 3992: 256 tiles; the
+// Whisper decoder's teacher-forced rows: 56-64 tiles).  There kernel S runs a lone wave per SIMD through
+// barrier -> fragment reads -> 32 MFMAs -> ..., 1 400-1 700 cycles per K-step for 512 of MFMA whatever the ring depth
+// (tools/dev_dec_gemm.py), and kernel L's 256x128 tiles use half the CUs.  Here the same tile is shared by two waves
+// per SIMD (64 rows x 32 columns each, 16 MFMAs per K-step and wave): one wave's fragment reads and barrier wait run
+// under the other's MFMAs.  The LDS one workgroup per CU leaves free holds a ring of four stages (LDS-DMA three tiles
+// ahead, counted vmcnt: 4 pieces per wave and tile).  Epilogue: the two waves of a 64x64 quadrant park their halves in
+// one staging tile, the even one walks it through the shared epilogue.
+#define M_NST 4
+#define M_LDS_BYTES (2 * M_NST * TILE_BYTES)  // 131072 >= 4 quadrants * 64*68*4 (69632) of epilogue staging
+template <int N>
+__device__ __forceinline__ void lds_wait_n(bf16x8_t (&f)[N]) {
+  if constexpr (N == 4)
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]));
+  else
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]));
+}
+template <int AL, int BL>
+__global__ __launch_bounds__(512) void ca_gemm_kernel_m(const CaGemmDesc d) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;  // 2 x 4 waves, 64 (M) x 32 (N) each
+  int tm, tn;
+  if (!tile_of_block<8, 8>(blockIdx.x, (d.M + BM - 1) / BM, (d.N + BN - 1) / BN, tm, tn)) return;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int z = blockIdx.z;
+  const int z1 = z / d.batch2, z2 = z % d.batch2;
+  const __bf16* A = (const __bf16*)d.A + z1 * d.sA1 + z2 * d.sA2;
+  const __bf16* B = (const __bf16*)d.B + z1 * d.sB1 + z2 * d.sB2;
+  const int K = d.K;
+  const int nk = (K + BK - 1) / BK;
+
+  KMajorStream<2> la_k, lb_k;
+  MNMajorStream<2, 16> la_f, lb_f;
+  if (AL == CA_KMAJOR) la_k.init(A, d.lda, m0, d.M, wave, lane); else la_f.init(A, d.lda, m0, d.M, wave, lane);
+  if (BL == CA_KMAJOR) lb_k.init(B, d.ldb, n0, d.N, wave, lane); else lb_f.init(B, d.ldb, n0, d.N, wave, lane);
+
+  f32x4_t acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  // LDS: A0 .. A3 | B0 .. B3 (16 KiB each)
+  auto burst = [&](int kt) {  // this wave's share of tile kt: 2 A pieces + 2 B pieces
+    if (kt >= nk) return;
+    char* na = smem + (kt % M_NST) * TILE_BYTES;
+    char* nb = na + M_NST * TILE_BYTES;
+    const bool full = (kt + 1) * BK <= K;  // wave-uniform
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {
+      if (full) {
+        if (AL == CA_KMAJOR) la_k.issue_one(na, wave, part); else la_f.issue_one(na, wave, part);
+        if (BL == CA_KMAJOR) lb_k.issue_one(nb, wave, part); else lb_f.issue_one(nb, wave, part);
+      } else {
+        if (AL == CA_KMAJOR) la_k.issue_one_tail(na, wave, K - kt * BK, part); else la_f.issue_one_tail(na, wave, lane, K - kt * BK, part);
+        if (BL == CA_KMAJOR) lb_k.issue_one_tail(nb, wave, K - kt * BK, part); else lb_f.issue_one_tail(nb, wave, lane, K - kt * BK, part);
+      }
+    }
+    if (AL == CA_KMAJOR) la_k.advance(); else la_f.advance();
+    if (BL == CA_KMAJOR) lb_k.advance(); else lb_f.advance();
+  };
+  auto zero_tail = [&](int kt) {
+    if (kt != nk - 1 || nk * BK == K) return;
+    char* na = smem + (kt % M_NST) * TILE_BYTES;
+    char* nb = na + M_NST * TILE_BYTES;
+    const int krem = K - kt * BK;
+    if (AL == CA_KMAJOR) la_k.zero_fix(na, wave, lane, krem); else la_f.zero_fix(na, wave, lane, krem);
+    if (BL == CA_KMAJOR) lb_k.zero_fix(nb, wave, lane, krem); else lb_f.zero_fix(nb, wave, lane, krem);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
+#pragma unroll
+  for (int p = 0; p < M_NST - 1; ++p) burst(p);
+  for (int kt = 0; kt < nk; ++kt) {
+    // tile kt has landed (this wave's pieces; the barrier covers the others); tiles kt+1, kt+2 may still be in flight
+    if (kt + 2 < nk)
+      asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    else if (kt + 1 < nk)
+      asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    zero_tail(kt);
+    __builtin_amdgcn_s_barrier();  // every wave has consumed tile kt-1: its stage is free
+    asm volatile("" ::: "memory");
+    burst(kt + M_NST - 1);
+
+    const char* ta = smem + (kt % M_NST) * TILE_BYTES;
+    const char* tb = ta + M_NST * TILE_BYTES;
+    auto read_frags = [&](int sh, bf16x8_t (&af)[4], bf16x8_t (&bf)[2]) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        af[i] = (AL == CA_KMAJOR) ? frag_kmajor_async(ta, wm * 64 + i * 16, sh, lane)
+                                  : frag_mnmajor<256>(ta, wm * 64 + i * 16, sh, lane);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        bf[j] = (BL == CA_KMAJOR) ? frag_kmajor_async(tb, wn * 32 + j * 16, sh, lane)
+                                  : frag_mnmajor<256>(tb, wn * 32 + j * 16, sh, lane);
+    };
+    auto mma = [&](bf16x8_t (&af)[4], bf16x8_t (&bf)[2]) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
+    };
+    bf16x8_t a0[4], b0[2], a1[4], b1[2];
+    read_frags(0, a0, b0);
+    lds_wait_n(a0);
+    lds_wait_n(b0);
+    read_frags(1, a1, b1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(a0, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    lds_wait_n(a1);
+    lds_wait_n(b1);
+    mma(a1, b1);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();  // all waves are done with the stages before the epilogue reuses the LDS
+  asm volatile("" ::: "memory");
+  // quadrant (wm, wn >> 1): this wave's 64 x 32 half goes to columns (wn & 1) * 32 of the quadrant's staging tile
+  const int quad = wm * 2 + (wn >> 1);
+  float* wt = (float*)smem + quad * (64 * EPI_PITCH);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      *(f32x4_t*)(wt + (i * 16 + (lane & 15)) * EPI_PITCH + (wn & 1) * 32 + j * 16 + 4 * (lane >> 4)) = acc[i][j];
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  if ((wn & 1) == 0) {
+    f32x4_t none[4][4];
+    gemm_epilogue<true>(d, none, smem, quad, lane, m0 + wm * 64, n0 + (wn >> 1) * 64, z, z1, z2);
+  }
 }
 
 // ---- kernel X: 256x256 tile, 8 waves (2x4, 128x64 each), 2 LDS stages, one workgroup per CU ----------
@@ -2526,6 +2669,26 @@ static int ca_gemm_launch(const CaGemmDesc* desc, void* stream) {
     dim3 block(256);
     const size_t lds = LDS_BYTES;
     const bool ks = d.a_kseg > 0 || d.b_kseg > 0;
+    // at most one tile per CU: kernel M (two waves per SIMD on the same tile; CA_GEMM_M=0 switches it off)
+    static const int m_max = [] { const char* e = getenv("CA_GEMM_M"); return e ? atoi(e) : 256; }();
+    if (!ks && (g_force_kernel == 5 || (g_force_kernel == 0 && (int64_t)ntm * ntn * nb <= m_max && d.K >= 2 * BK))) {
+      static bool mattr = false;
+      if (!mattr) {
+        const void* fs[4] = {(const void*)ca_gemm_kernel_m<0, 0>, (const void*)ca_gemm_kernel_m<0, 1>,
+                             (const void*)ca_gemm_kernel_m<1, 0>, (const void*)ca_gemm_kernel_m<1, 1>};
+        for (int i = 0; i < 4; ++i) hipFuncSetAttribute(fs[i], hipFuncAttributeMaxDynamicSharedMemorySize, M_LDS_BYTES);
+        mattr = true;
+      }
+      const dim3 mblock(512);
+      switch (lay) {
+        case 0: CA_LAUNCH((ca_gemm_kernel_m<0, 0>), grid, mblock, M_LDS_BYTES, s, d); break;
+        case 1: CA_LAUNCH((ca_gemm_kernel_m<0, 1>), grid, mblock, M_LDS_BYTES, s, d); break;
+        case 2: CA_LAUNCH((ca_gemm_kernel_m<1, 0>), grid, mblock, M_LDS_BYTES, s, d); break;
+        default: CA_LAUNCH((ca_gemm_kernel_m<1, 1>), grid, mblock, M_LDS_BYTES, s, d); break;
+      }
+      CA_CHECK_LAUNCH("ca_gemm_bf16");
+      return CA_OK;
+    }
     switch (lay + (ks ? 4 : 0)) {
       case 0: CA_LAUNCH((ca_gemm_kernel<0, 0, false>), grid, block, lds, s, d); break;
       case 1: CA_LAUNCH((ca_gemm_kernel<0, 1, false>), grid, block, lds, s, d); break;

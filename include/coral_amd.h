@@ -151,7 +151,8 @@ int ca_gemm_bf16_group(const CaGemmDesc* descs, int32_t count, void* stream);
  * inside graph capture. */
 /* Tuning/test hook: 0 = automatic kernel choice, 1 = force the 128x128 kernel, 2 = force the
  * 256x128 pipelined kernel, 3 = force the 256x256 kernel, 4 = force the 256x256 kernel with one wave per SIMD
- * (4 waves x 128x128; an experiment). */
+ * (4 waves x 128x128; an experiment), 5 = force the 128x128 tile on 8 waves (kernel M: what the
+ * automatic choice runs when the grid has at most one 128x128 tile per CU). */
 int ca_gemm_force_kernel(int which);
 /* Test hook: on != 0 sends every wave tile through the general epilogue walk (interior tiles normally take a
  * specialised, predicate-free form that must give the same bits). */

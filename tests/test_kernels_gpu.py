@@ -89,6 +89,18 @@ def test_gemm_256x256_one_wave_per_simd_kernel(ops, al, bl, M, N, K):
         ops.lib().ca_gemm_force_kernel(0)
 
 
+@pytest.mark.parametrize("al,bl", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [(1000, 520, 328), (904, 1024, 1024), (300, 264, 64), (130, 40, 200), (700, 300, 136)])
+def test_gemm_128x128_two_waves_per_simd_kernel(ops, al, bl, M, N, K):
+    """Parity of kernel M (128x128 tile shared by 8 waves of 64x32, four-stage ring, forced): ragged tails, a single
+    K-step, fewer K-steps than ring stages, a partial last K-step."""
+    ops.lib().ca_gemm_force_kernel(5)
+    try:
+        test_gemm_layouts(ops, al, bl, M, N, K)
+    finally:
+        ops.lib().ca_gemm_force_kernel(0)
+
+
 def test_gemm_epilogues_and_batch(ops):
     M, N, K, Bt = 300, 256, 192, 3
     A, W = bf(rnd(Bt, M, K, seed=3, scale=0.5)), bf(rnd(N, K, seed=4, scale=0.2))
@@ -622,7 +634,7 @@ def test_gemm_random_shapes_all_kernels(ops):
         N = int(rng.randint(1, 90)) * 8
         K = int(rng.randint(1, 60)) * 8
         al, bl = int(rng.randint(0, 2)), int(rng.randint(0, 2))
-        for force in (1, 3, 4):
+        for force in (1, 3, 4, 5):
             ops.lib().ca_gemm_force_kernel(force)
             try:
                 test_gemm_layouts(ops, al, bl, M, N, K)
@@ -676,7 +688,7 @@ def test_gemm_skinny_split_output(ops, M):
 
 
 @pytest.mark.parametrize("M,N,K,force", [(7680, 1920, 512, 0), (1920, 1920, 512, 0), (296, 200, 256, 0), (520, 392, 192, 1),
-                                         (520, 392, 192, 2), (1000, 1496, 320, 3)])
+                                         (520, 392, 192, 2), (1000, 1496, 320, 3), (520, 392, 192, 5)])
 @pytest.mark.parametrize("accumulate", [False, True])
 def test_gemm_sum_of_squares_partials(ops, M, N, K, force, accumulate):
     """CaGemmDesc.c_sumsq: the weight-gradient form (both operands MN-major, fp32 output) leaves, per 64 x 64 block of
@@ -723,7 +735,7 @@ def test_sumsq_ranges_and_plain_sum(ops):
     assert abs(float(out) - float(x.double().sum()) - float(x[:10].double().sum())) <= 0.1
 
 
-@pytest.mark.parametrize("force", [1, 2, 3, 4])
+@pytest.mark.parametrize("force", [1, 2, 3, 4, 5])
 def test_gemm_interior_tile_epilogue_is_bit_identical_to_the_general_walk(ops, force):
     """Interior 64 x 64 wave tiles take a specialised, predicate-free epilogue (gemm.hip, gemm_epilogue_fast); ragged
     ones the general walk.  Same arithmetic in the same order: with the specialised form switched off

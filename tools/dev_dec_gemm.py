@@ -9,6 +9,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 from coral_amd import ops  # noqa: E402
 
 dev = "cuda:0"
+NAMES = {0: "auto", 1: "S", 2: "L", 3: "X", 5: "M"}
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 904
 
 
@@ -33,11 +34,11 @@ for d, f in ((1024, 4096), (1280, 5120)):
         dX = torch.zeros(M, K, dtype=torch.bfloat16, device=dev)
         dW = torch.zeros(N, K, dtype=torch.float32, device=dev)
         row = f"M{M} N{N:5d} K{K:5d}: "
-        for force in (0, 1, 2, 3):
+        for force in (0, 1, 2, 5):
             ops.lib().ca_gemm_force_kernel(force)
             tf = timeit(lambda: ops.gemm(X, W, Y, M=M, N=N, K=K, a_layout=0, b_layout=0, lda=K, ldb=K, ldc=N))
             td = timeit(lambda: ops.gemm(Y, W, dX, M=M, N=K, K=N, a_layout=0, b_layout=1, lda=N, ldb=K, ldc=K))
             tw = timeit(lambda: ops.gemm(Y, X, dW, M=N, N=K, K=M, a_layout=1, b_layout=1, lda=N, ldb=K, ldc=K, out_f32=True))
-            row += f" [{'auto S L X'.split()[force]}] fwd {tf:5.1f} dgrad {td:5.1f} wgrad {tw:5.1f} |"
+            row += f" [{NAMES[force]}] fwd {tf:5.1f} dgrad {td:5.1f} wgrad {tw:5.1f} |"
         ops.lib().ca_gemm_force_kernel(0)
         print(row, f" weights {N * K * 2 / 1e6:.1f} MB, {2.0 * M * N * K / 1e9:.2f} GFLOP")
