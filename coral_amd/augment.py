@@ -8,9 +8,12 @@ the ranges and filter designs below restate their documented defaults: gain U[-1
 coloured noise with spectral decay f_decay U[-2, 2] (power ~ 1/f^decay); low-pass cutoff 150-7500 Hz,
 high-pass 20-2400 Hz, band-pass/-stop centre 200-4000 Hz with bandwidth fraction 0.5-1.99, all sampled on
 the mel scale; filters are julius-style windowed-sinc low-passes (8 zero crossings, Hann window, edges
-replicated), a high-pass being x - lowpass(x).  The draws happen on the host with a seeded NumPy RNG (one
+replicated), a high-pass being x - lowpass(x), a band-pass lowpass(high) - lowpass(low) at the lower edge's filter
+length, a band-stop x - bandpass(x) (oracle/augment_ref.py restates the chain; parity unpinned: the libraries are absent).
+The draws happen on the host with a seeded NumPy RNG (one
 small H2D copy of the parameter arrays per batch); the arithmetic runs in coral_amd/csrc/augment.hip.
-Being random, this stage has no parity target; tests check each operator against a NumPy restatement.
+Being random, this stage has no golden output; `self.last` records what a call drew so that tests replay it through the
+oracle.
 """
 
 from __future__ import annotations
@@ -23,14 +26,23 @@ from . import ops
 MAX_TAPS = 6401  # high-pass at 20 Hz / 16 kHz: half = int(8 / (20/16000) / 2) = 3200
 
 
-def lowpass_taps(cutoff_hz: float, sample_rate: int, zeros: int = 8) -> np.ndarray:
-    """julius.lowpass_filter design: Hann-windowed sinc, normalised to unit DC gain."""
+def lowpass_taps(cutoff_hz: float, sample_rate: int, zeros: int = 8, half: int | None = None) -> np.ndarray:
+    """julius.LowPassFilters design: sinc under hann_window(2 half + 1, periodic=False), normalised to unit DC gain;
+    half = int(zeros / (cutoff / sample_rate) / 2) unless given."""
     fc = cutoff_hz / sample_rate
-    half = min(int(zeros / fc / 2), (MAX_TAPS - 1) // 2)
+    if half is None:
+        half = int(zeros / fc / 2)
+    half = min(half, (MAX_TAPS - 1) // 2)
     t = np.arange(-half, half + 1, dtype=np.float64)
-    window = 0.5 * (1.0 + np.cos(np.pi * t / (half + 1))) if half > 0 else np.ones(1)
+    window = 0.5 * (1.0 + np.cos(np.pi * t / half)) if half > 0 else np.ones(1)
     h = 2 * fc * window * np.sinc(2 * fc * t)
     return (h / h.sum()).astype(np.float32)
+
+
+def bandpass_taps(low_hz: float, high_hz: float, sample_rate: int, zeros: int = 8) -> np.ndarray:
+    """julius.bandpass_filter as ONE filter: lowpass(high) - lowpass(low), both at the lower cutoff's size."""
+    half = min(int(zeros / (low_hz / sample_rate) / 2), (MAX_TAPS - 1) // 2)
+    return lowpass_taps(high_hz, sample_rate, zeros, half) - lowpass_taps(low_hz, sample_rate, zeros, half)
 
 
 def coloured_taps(f_decay: float, sample_rate: int, n_taps: int = 1025) -> np.ndarray:
@@ -84,8 +96,13 @@ class DeviceAugment:
         rng, sr = self.rng, self.sr
         self._ncall = 0  # (staging keys = position of the transfer inside one call: the same ring every batch)
         cur = x
+        # what was drawn for each example of this call (tests replay it through oracle/augment_ref.py)
+        rec = [dict() for _ in range(B)]
         # Gain(min_gain_in_db=-18, max_gain_in_db=6, p=1)
-        gain = 10.0 ** (rng.uniform(-18.0, 6.0, size=B) / 20.0)
+        gain_db = rng.uniform(-18.0, 6.0, size=B)
+        gain = 10.0 ** (gain_db / 20.0)
+        for b in range(B):
+            rec[b]["gain_db"] = float(gain_db[b])
         nxt = torch.empty_like(x)
         ops.wave_scale(cur, self._dev(gain, torch.float32), nxt, B, N)
         cur = nxt
@@ -94,6 +111,9 @@ class DeviceAugment:
             act = (rng.rand(B) < self.p_background).astype(np.int32)
             snr = rng.uniform(3.0, 30.0, size=B).astype(np.float32)
             off = rng.randint(0, self.noise_bank.numel(), size=B).astype(np.int64)
+            for b in range(B):
+                if act[b]:
+                    rec[b]["background"] = (int(off[b]), float(snr[b]))
             nxt = torch.empty_like(x)
             ops.mix_noise(cur, lengths, self.noise_bank, 0, self.noise_bank.numel(), self._dev(off, torch.int64),
                           self._dev(snr, torch.float32), self._dev(act, torch.int32), nxt, B, N)
@@ -109,6 +129,10 @@ class DeviceAugment:
             taps = np.zeros((B, 1025), dtype=np.float32)
             for b in range(B):
                 taps[b] = coloured_taps(decay[b], sr)
+            for b in range(B):
+                if act[b]:
+                    rec[b]["coloured"] = (float(snr[b]), float(decay[b]))
+            self.last_white = white
             noise = torch.empty_like(white)
             ops.fir_filter(white, None, self._dev(taps, torch.float32), self._dev([1025] * B, torch.int32),
                            self._dev(act, torch.int32), noise, B, N, 1025)
@@ -116,43 +140,37 @@ class DeviceAugment:
             ops.mix_noise(cur, lengths, noise, N, N, None, self._dev(snr, torch.float32), self._dev(act, torch.int32),
                           nxt, B, N)
             cur = nxt
-        # OneOf([BandPass, BandStop, HighPass, LowPass], p=0.2)
+        # OneOf([BandPass, BandStop, HighPass, LowPass], p=0.2): one FIR pass, y (mode 1) or x - y (mode 2)
         act = rng.rand(B) < self.p_filter
         if act.any():
             kind = rng.randint(0, 4, size=B)
-            lp = np.zeros((B, MAX_TAPS), dtype=np.float32)   # first stage: low-pass at the upper edge / the cutoff
-            hp = np.zeros((B, MAX_TAPS), dtype=np.float32)   # second stage of the band filters: high-pass at the lower edge
-            n1 = np.ones(B, dtype=np.int32)
-            n2 = np.ones(B, dtype=np.int32)
-            m1 = np.zeros(B, dtype=np.int32)
-            m2 = np.zeros(B, dtype=np.int32)
-            stop = np.zeros(B, dtype=bool)
+            taps = np.zeros((B, MAX_TAPS), dtype=np.float32)
+            nt = np.ones(B, dtype=np.int32)
+            mode = np.zeros(B, dtype=np.int32)
             for b in range(B):
                 if not act[b]:
                     continue
                 if kind[b] in (0, 1):  # band-pass / band-stop: centre on the mel scale, bandwidth fraction 0.5..1.99
                     centre = _imel(rng.uniform(_mel(200.0), _mel(4000.0)))
                     bw = centre * rng.uniform(0.5, 1.99)
-                    lo, hi = max(centre - bw / 2, 20.0), min(centre + bw / 2, sr / 2 - 100.0)
-                    a, c = lowpass_taps(hi, sr), lowpass_taps(lo, sr)
-                    lp[b, :len(a)], n1[b], m1[b] = a, len(a), 1
-                    hp[b, :len(c)], n2[b], m2[b] = c, len(c), 2
-                    stop[b] = kind[b] == 1
-                elif kind[b] == 2:     # high-pass 20..2400 Hz
-                    a = lowpass_taps(_imel(rng.uniform(_mel(20.0), _mel(2400.0))), sr)
-                    lp[b, :len(a)], n1[b], m1[b] = a, len(a), 2
+                    # (julius would design a 64 001-tap filter for a 1-Hz lower edge: edges below 20 Hz are clamped)
+                    lo, hi = max(centre - bw / 2, 20.0), centre + bw / 2
+                    a = bandpass_taps(lo, hi, sr)
+                    mode[b] = 2 if kind[b] == 1 else 1
+                    rec[b]["filter"] = ("bandstop" if kind[b] == 1 else "bandpass", float(lo), float(hi))
+                elif kind[b] == 2:     # high-pass 20..2400 Hz: x - lowpass(x)
+                    fc = float(_imel(rng.uniform(_mel(20.0), _mel(2400.0))))
+                    a, mode[b] = lowpass_taps(fc, sr), 2
+                    rec[b]["filter"] = ("highpass", fc)
                 else:                  # low-pass 150..7500 Hz
-                    a = lowpass_taps(_imel(rng.uniform(_mel(150.0), _mel(7500.0))), sr)
-                    lp[b, :len(a)], n1[b], m1[b] = a, len(a), 1
-            mt1, mt2 = int(n1.max()) | 1, int(n2.max()) | 1
-            s1 = torch.empty_like(x)
-            ops.fir_filter(cur, lengths, self._dev(lp[:, :mt1], torch.float32), self._dev(n1, torch.int32),
-                           self._dev(m1, torch.int32), s1, B, N, mt1)
-            s2 = torch.empty_like(x)
-            ops.fir_filter(s1, lengths, self._dev(hp[:, :mt2], torch.float32), self._dev(n2, torch.int32),
-                           self._dev(m2, torch.int32), s2, B, N, mt2)
-            if stop.any():  # band-stop = x - band-pass(x)
-                sel = self._dev(stop, torch.bool)[:, None]
-                s2 = torch.where(sel, cur - s2, s2)
-            cur = s2
+                    fc = float(_imel(rng.uniform(_mel(150.0), _mel(7500.0))))
+                    a, mode[b] = lowpass_taps(fc, sr), 1
+                    rec[b]["filter"] = ("lowpass", fc)
+                taps[b, :len(a)], nt[b] = a, len(a)
+            mt = int(nt.max()) | 1
+            out = torch.empty_like(x)
+            ops.fir_filter(cur, lengths, self._dev(taps[:, :mt], torch.float32), self._dev(nt, torch.int32),
+                           self._dev(mode, torch.int32), out, B, N, mt)
+            cur = out
+        self.last = rec
         return cur
