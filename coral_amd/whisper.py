@@ -108,15 +108,17 @@ def whisper_param_list(s: WhisperShape):
     for l in range(s.encoder_layers):
         p, b = f"model.encoder.layers.{l}.", f"enc{l}"
         a = p + "self_attn."
-        out += [(a + n + ".weight", (d, d), b) for n in ("q_proj", "k_proj", "v_proj")]
-        out += [(a + "out_proj.weight", (d, d), b),
-                (p + "fc1.weight", (s.encoder_ffn_dim, d), b), (p + "fc2.weight", (d, s.encoder_ffn_dim), b),
-                (p + "self_attn_layer_norm.weight", (d,), b), (p + "self_attn_layer_norm.bias", (d,), b),
+        # small tensors first, the weight matrices (read through the bf16 compute copy only) at the end of the bucket:
+        # the part a sharded optimiser splits over the ranks (WhisperTrainEngine.shard_ranges, trainer.py zero_stage)
+        out += [(p + "self_attn_layer_norm.weight", (d,), b), (p + "self_attn_layer_norm.bias", (d,), b),
                 (p + "final_layer_norm.weight", (d,), b), (p + "final_layer_norm.bias", (d,), b),
                 # the Linear biases are contiguous (q|k|v, out, fc1, fc2 = 5d + f floats): their gradients are partial
                 # column sums out of the grouped weight-gradient launch, added in one pass (whisper_train.backward)
                 (a + "q_proj.bias", (d,), b), (a + "k_proj.bias__zero", (d,), b), (a + "v_proj.bias", (d,), b),
                 (a + "out_proj.bias", (d,), b), (p + "fc1.bias", (s.encoder_ffn_dim,), b), (p + "fc2.bias", (d,), b)]
+        out += [(a + n + ".weight", (d, d), b) for n in ("q_proj", "k_proj", "v_proj")]
+        out += [(a + "out_proj.weight", (d, d), b),
+                (p + "fc1.weight", (s.encoder_ffn_dim, d), b), (p + "fc2.weight", (d, s.encoder_ffn_dim), b)]
     out += [("model.encoder.layer_norm.weight", (d,), "encf"), ("model.encoder.layer_norm.bias", (d,), "encf"),
             ("model.decoder.embed_tokens.weight", (s.vocab_size, d), "emb"),
             ("model.decoder.embed_positions.weight", (s.max_target_positions, d), "emb")]

@@ -117,6 +117,19 @@ class WhisperTrainEngine(WhisperEngine):
         hi = st.off(p + "fc2.weight") + self.s.d_model * self.s.encoder_ffn_dim
         return lo, hi
 
+    def shard_ranges(self) -> dict:
+        """{encoder-layer bucket: (first element of its weight matrices, bucket end)}: what a sharded optimiser
+        (trainer.py, zero_stage) may split over the ranks - 78 % of whisper-large-turbo's parameters.  The forward reads
+        these matrices through the bf16 compute copy only; the small tensors in front of them, the decoder layers
+        (matrices and biases interleaved) and the embeddings stay replicated."""
+        st = self.store
+        out = {}
+        for l in range(self.s.encoder_layers):
+            lo, hi = self._enc_matrix_range(l)
+            if hi == st.buckets[f"enc{l}"][1]:
+                out[f"enc{l}"] = (lo, hi)
+        return out
+
     def _enc_matrices(self, l: int):
         d, f = self.s.d_model, self.s.encoder_ffn_dim
         p = f"model.encoder.layers.{l}."

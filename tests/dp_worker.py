@@ -34,15 +34,39 @@ def build_case():
     return eng, shard
 
 
+def build_case_whisper():
+    """A 2 + 2-layer Whisper (teacher-forced finetune step) and a global batch of four 30-s feature matrices."""
+    from coral_amd.whisper import WhisperShape
+    from coral_amd.whisper_train import WhisperTrainEngine
+    from oracle import whisper_ref as w  # test infrastructure: the seeded parameters only
+
+    kw = dict(d_model=64, encoder_layers=2, decoder_layers=2, encoder_attention_heads=4, decoder_attention_heads=4,
+              encoder_ffn_dim=128, decoder_ffn_dim=128, num_mel_bins=80, vocab_size=200, max_target_positions=32,
+              pad_token_id=150, decoder_start_token_id=151, eos_token_id=150)
+    eng = WhisperTrainEngine(WhisperShape(**kw), "cuda:0")
+    eng.load_state_dict(w.synth_params(w.WhisperConfig(**kw)))
+    g = torch.Generator().manual_seed(77)
+    feats = torch.randn(4, 80, 3000, generator=g) * 0.5
+    labels = torch.randint(0, 150, (4, 9), generator=g)
+    labels[1, 6:] = -100
+    labels[3, 4:] = -100
+
+    def shard(idx):
+        return dict(input_features=feats[idx], labels=labels[idx])
+
+    return eng, shard
+
+
 def main():
     out_dir, wire, steps = Path(sys.argv[1]), sys.argv[2], int(sys.argv[3])
     zero = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+    kind = sys.argv[5] if len(sys.argv) > 5 else "wav2vec2"
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.cuda.set_device(0)
     torch.distributed.init_process_group("gloo")
     from coral_amd.trainer import DataParallelTrainer, shard_indices
 
-    eng, shard = build_case()
+    eng, shard = build_case_whisper() if kind == "whisper" else build_case()
     tr = DataParallelTrainer(eng, learning_rate=1e-3, warmup_steps=0, max_steps=100, max_grad_norm=1.0,
                              compress_grads=(wire == "bf16"), zero_stage=zero)
     assert tr.world == world and tr.overlap and tr.zero == bool(zero)

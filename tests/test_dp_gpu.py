@@ -17,10 +17,10 @@ pytestmark = pytest.mark.gpu
 ROOT = Path(__file__).resolve().parents[1]
 
 
-def _run_two_ranks(tmp_path, wire, steps=2, zero=0):
+def _run_two_ranks(tmp_path, wire, steps=2, zero=0, kind="wav2vec2"):
     tmp_path.mkdir(parents=True, exist_ok=True)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--nnodes=1", "--nproc-per-node=2",
-           "--local-addr", "127.0.0.1", str(ROOT / "tests" / "dp_worker.py"), str(tmp_path), wire, str(steps), str(zero)]
+           "--local-addr", "127.0.0.1", str(ROOT / "tests" / "dp_worker.py"), str(tmp_path), wire, str(steps), str(zero), kind]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     return [torch.load(tmp_path / f"rank{k}.pt") for k in range(2)]
@@ -99,6 +99,29 @@ def test_sharded_optimizer_equals_the_replicated_trainer(tmp_path, wire):
     else:
         d = (zer[0]["p32"] - rep[0]["p32"]).abs()
         assert float(d.max()) <= 1e-3
+
+
+def test_sharded_optimizer_on_the_whisper_engine(tmp_path):
+    """zero_stage on the Whisper finetune step (configs[4] is whisper-large-turbo under the same `--zero-stage 2`
+    launch): the encoder layers' weight matrices are reduce-scattered and updated on 1/N, decoder / embeddings stay
+    replicated.  Two real ranks, three steps against the replicated trainer: both ranks agree bit for bit, the first
+    loss is identical, parameters and moments agree to the clip factor's last bits."""
+    rep = _run_two_ranks(tmp_path / "rep", "fp32", steps=3, kind="whisper")
+    zer = _run_two_ranks(tmp_path / "zero", "fp32", steps=3, zero=2, kind="whisper")
+    for k in ("p32", "p16", "m", "v"):
+        assert torch.equal(zer[0][k], zer[1][k]), k
+    for r in (0, 1):
+        # (same parameters at the first step; the cross-entropy sums its rows with float atomics, so two runs agree to
+        # the last bits only)
+        assert abs(zer[r]["losses"][0] - rep[r]["losses"][0]) <= 1e-6 * abs(rep[r]["losses"][0])
+        assert all(abs(a - b) <= 1e-3 * abs(b) for a, b in zip(zer[r]["losses"], rep[r]["losses"])), (zer[r]["losses"], rep[r]["losses"])
+    for a, b in zip(zer[0]["norms"], rep[0]["norms"]):
+        assert abs(a - b) <= 1e-5 * b
+    lr = 1e-3
+    d = (zer[0]["p32"] - rep[0]["p32"]).abs()
+    assert float(d.max()) <= 0.1 * lr, float(d.max())
+    assert float((d <= 1e-3 * lr).float().mean()) >= 0.995
+    assert float((zer[0]["m"] - rep[0]["m"]).abs().max()) <= 1e-2 * float(rep[0]["m"].abs().max())
 
 
 def test_rccl_one_rank_group_reproduces_the_plain_trainer(tmp_path):
