@@ -507,9 +507,16 @@ class WhisperTrainEngine(WhisperEngine):
         return self._wstream
 
     def clear_internal_grads_of(self, prefix: str):
-        for n in self.store.names():
-            if n.startswith(prefix) and n.endswith("__zero"):
-                self.store.view(n, "g32").zero_()
+        """The `__zero` slots of one layer, as one launch over a cached range table (called per layer in the backward,
+        before the layer's bucket is handed to the trainer's hook)."""
+        cache = self.__dict__.setdefault("_zero_slot_ranges", {})
+        rs = cache.get(prefix)
+        if rs is None:
+            st = self.store
+            rs = cache[prefix] = tuple((st.off(n), int(st.view(n).numel())) for n in st.names()
+                                       if n.startswith(prefix) and n.endswith("__zero"))
+        if rs:
+            ops.clear_ranges(self.store.g32, rs)
 
     def grad_dict(self):
         return {n: self.store.view(n, "g32") for n in self.exported_names()}
