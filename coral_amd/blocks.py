@@ -28,6 +28,7 @@ class Scratch:
         self.dqkv = _z(M * 3 * d, dev)
         self.du = _z(M * f, dev)
         self.dkv = _z(Mkv * 2 * d, dev) if Mkv else None
+        self.dq = _z(M * d, dev) if Mkv else None  # cross-attention dq: lives until the layer's deferred weight gradients
         # dropout(dh): the gradient entering a sub-layer whose output was dropped (hidden dropout); one buffer per block
         # kind so that a layer's deferred weight gradients can read both
         self.dm = {"attn": _z(M * d, dev), "ffn": _z(M * d, dev), "cross": _z(M * d, dev)}
@@ -51,6 +52,9 @@ class SelfAttnBlock:
     def __init__(self, store, ln: str, attn: str, H: int, d: int, eps: float, causal: bool, qbias: str):
         self.st, self.ln, self.attn, self.H, self.d, self.eps, self.causal = store, ln, attn, H, d, eps, causal
         self.qbias = qbias  # name of the first of the three adjacent bias vectors (q, k, v)
+        # positions of this block's bias gradients in the layer's contiguous bias vector (fused column sums of a
+        # grouped weight-gradient launch); the encoder layout, a decoder layer sets its own
+        self.cs_qkv, self.cs_o = 0, 3 * d
 
     def alloc(self, B, T, dev):
         d, H = self.d, self.H
@@ -106,7 +110,7 @@ class SelfAttnBlock:
             ops.colsum(dy, d, M, d, g32, sc.part, out_off=o(self.attn + "out_proj.bias"))
         wg = [dict(dY=dy, X=sv["ctx"], M=d, N=d, K=M, lda=d, ldb=d, c_off=o(self.attn + "out_proj.weight"), accumulate=acc,
                    sq=sq.get("o"),
-                   **(dict(bias_off=o(self.attn + "out_proj.bias"), part=sc.part, cs_off=3 * d) if defer is not None else {}))]
+                   **(dict(bias_off=o(self.attn + "out_proj.bias"), part=sc.part, cs_off=self.cs_o) if defer is not None else {}))]
         ops.gemm(dy, p16, sc.dctx, M=M, N=d, K=d, lda=d, b_layout=MNMAJOR, ldb=d, ldc=d, b_off=o(self.attn + "out_proj.weight"))
         qkv, dqkv = sv["qkv"], sc.dqkv
         ops.attn_bwd(qkv, qkv, qkv, sv["ctx"], sv["lse"], sc.dctx, sv["Dq"], dqkv, dqkv, dqkv, lddo=d, sdob=T * d, lddq=3 * d,
@@ -116,7 +120,7 @@ class SelfAttnBlock:
             ops.colsum(dqkv, 3 * d, M, 3 * d, g32, sc.part, out_off=o(self.qbias))
         wg.append(dict(dY=dqkv, X=sv["x"], M=3 * d, N=d, K=M, lda=3 * d, ldb=d, c_off=o(self.attn + "q_proj.weight"),
                        accumulate=acc, sq=sq.get("qkv"),
-                       **(dict(bias_off=o(self.qbias), part=sc.part, cs_off=0) if defer is not None else {})))
+                       **(dict(bias_off=o(self.qbias), part=sc.part, cs_off=self.cs_qkv) if defer is not None else {})))
         if defer is not None:
             defer.extend(wg)
         else:
@@ -165,24 +169,34 @@ class CrossAttnBlock:
                  dropout_p=hdrop[0], dropout_seed=hdrop[1])
         sv["hin"], sv["hdrop"] = hin, hdrop
 
-    def backward(self, dh, dhin, sv, sc: Scratch, denc32, B, L, Te):
-        """denc32: fp32 [B*Te, d] accumulator of the gradient wrt the encoder states (+=)."""
+    def backward(self, dh, dhin, sv, sc: Scratch, denc32, B, L, Te, defer=None, cs=(0, 0)):
+        """denc32: fp32 [B*Te, d] accumulator of the gradient wrt the encoder states (+=).  defer: list collecting
+        the two token-side weight-gradient problems (out_proj, q_proj; bias gradients fused at cs = (cs_q, cs_o) of the
+        layer's bias vector) for the layer's grouped launch; the k|v projection's (K = B*Te rows) goes out at once."""
         st, d = self.st, self.d
         M, Mk = B * L, B * Te
         o, g32, p16 = st.off, st.g32, st.p16
         dy = _masked_grad(dh, sv, sc, M * d, "cross")
-        ops.colsum(dy, d, M, d, g32, sc.part, out_off=o(self.attn + "out_proj.bias"))
-        ops.wgrad_gemm(dy, sv["ctx"], g32, M=d, N=d, K=M, lda=d, ldb=d,
-                       c_off=o(self.attn + "out_proj.weight"), accumulate=True)
+        if defer is None:
+            ops.colsum(dy, d, M, d, g32, sc.part, out_off=o(self.attn + "out_proj.bias"))
+            ops.wgrad_gemm(dy, sv["ctx"], g32, M=d, N=d, K=M, lda=d, ldb=d,
+                           c_off=o(self.attn + "out_proj.weight"), accumulate=True)
+        else:
+            defer.append(dict(dY=dy, X=sv["ctx"], M=d, N=d, K=M, lda=d, ldb=d, c_off=o(self.attn + "out_proj.weight"),
+                              accumulate=True, bias_off=o(self.attn + "out_proj.bias"), part=sc.part, cs_off=cs[1]))
         ops.gemm(dy, p16, sc.dctx, M=M, N=d, K=d, lda=d, b_layout=MNMAJOR, ldb=d, ldc=d, b_off=o(self.attn + "out_proj.weight"))
-        dq, dkv = sc.dx, sc.dkv
+        dq, dkv = (sc.dx if defer is None else sc.dq), sc.dkv
         ops.attn_bwd(sv["q"], sv["kv"], sv["kv"], sv["ctx"], sv["lse"], sc.dctx, sv["Dq"], dq, dkv, dkv, lddo=d, sdob=L * d,
                      lddq=d, lddk=2 * d, lddv=2 * d, sdqb=L * d, sdkb=Te * 2 * d, sdvb=Te * 2 * d, dk_off=0, dv_off=d,
                      **self._akw(B, L, Te, sv))
         # q projection
-        ops.colsum(dq, d, M, d, g32, sc.part, out_off=o(self.attn + "q_proj.bias"))
-        ops.wgrad_gemm(dq, sv["x"], g32, M=d, N=d, K=M, lda=d, ldb=d,
-                       c_off=o(self.attn + "q_proj.weight"), accumulate=True)
+        if defer is None:
+            ops.colsum(dq, d, M, d, g32, sc.part, out_off=o(self.attn + "q_proj.bias"))
+            ops.wgrad_gemm(dq, sv["x"], g32, M=d, N=d, K=M, lda=d, ldb=d,
+                           c_off=o(self.attn + "q_proj.weight"), accumulate=True)
+        else:
+            defer.append(dict(dY=dq, X=sv["x"], M=d, N=d, K=M, lda=d, ldb=d, c_off=o(self.attn + "q_proj.weight"),
+                              accumulate=True, bias_off=o(self.attn + "q_proj.bias"), part=sc.part, cs_off=cs[0]))
         ops.gemm(dq, p16, sc.dctx, M=M, N=d, K=d, lda=d, b_layout=MNMAJOR, ldb=d, ldc=d, b_off=o(self.attn + "q_proj.weight"))
         ops.layernorm_bwd(sc.dctx, sv["hin"], st.view(self.ln + ".weight"), None, sv["st"], dh, dhin,
                           st.view(self.ln + ".weight", "g32"), st.view(self.ln + ".bias", "g32"), sc.part, M, d)
@@ -199,6 +213,7 @@ class FFNBlock:
 
     def __init__(self, store, ln: str, fc1: str, fc2: str, d: int, f: int, eps: float):
         self.st, self.ln, self.fc1, self.fc2, self.d, self.f, self.eps = store, ln, fc1, fc2, d, f, eps
+        self.cs_fc1, self.cs_fc2 = 4 * d, 4 * d + f  # (the encoder layer's bias vector; see SelfAttnBlock)
 
     def alloc(self, M, dev):
         return dict(x=_z(M * self.d, dev), st=_z(M * 2, dev, torch.float32), u=_z(M * self.f, dev), g=_z(M * self.f, dev))
@@ -233,14 +248,14 @@ class FFNBlock:
             ops.colsum(dy, d, M, d, g32, sc.part, out_off=o(self.fc2 + ".bias"))
         wg = [dict(dY=dy, X=sv["g"], M=d, N=f, K=M, lda=d, ldb=f, c_off=o(self.fc2 + ".weight"), accumulate=acc,
                    sq=sq.get("fc2"),
-                   **(dict(bias_off=o(self.fc2 + ".bias"), part=sc.part, cs_off=4 * d + f) if defer is not None else {}))]
+                   **(dict(bias_off=o(self.fc2 + ".bias"), part=sc.part, cs_off=self.cs_fc2) if defer is not None else {}))]
         ops.gemm(dy, p16, sc.du, M=M, N=f, K=d, lda=d, b_layout=MNMAJOR, ldb=f, ldc=f, b_off=o(self.fc2 + ".weight"),
                  epilogue=EPI_DGELU, R=sv["u"], ldr=f, dropout_p=p, dropout_seed=seed)
         if defer is None:
             ops.colsum(sc.du, f, M, f, g32, sc.part, out_off=o(self.fc1 + ".bias"))
         wg.append(dict(dY=sc.du, X=sv["x"], M=f, N=d, K=M, lda=f, ldb=d, c_off=o(self.fc1 + ".weight"), accumulate=acc,
                        sq=sq.get("fc1"),
-                       **(dict(bias_off=o(self.fc1 + ".bias"), part=sc.part, cs_off=4 * d) if defer is not None else {})))
+                       **(dict(bias_off=o(self.fc1 + ".bias"), part=sc.part, cs_off=self.cs_fc1) if defer is not None else {})))
         if defer is not None:
             defer.extend(wg)
         else:

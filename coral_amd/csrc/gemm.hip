@@ -983,11 +983,12 @@ __global__ __launch_bounds__(512) void ca_gemm_kernel_m(const CaGemmDesc d) {
 #define XSTAGE (2 * XTILE)
 #define X_LDS_BYTES (8 * 64 * EPI_PITCH * 4)  // 139264 >= 2 stages * 64 KiB
 
-// grp.count > 1: a grouped launch of up to four independent problems of the same operand form
+// grp.count > 1: a grouped launch of up to X_GROUP_MAX independent problems of the same operand form
 // (ca_gemm_bf16_group): block ranges map to problems, each with plain row-major tile numbering.
+#define X_GROUP_MAX 8
 struct CaGemmGroup {
-  CaGemmDesc d[4];
-  int first[4];  // first tile of problem i in the group's tile list (first[0] = 0)
+  CaGemmDesc d[X_GROUP_MAX];
+  int first[X_GROUP_MAX];  // first tile of problem i in the group's tile list (first[0] = 0)
   int count;     // number of problems (0 = plain launch of d[0])
   int total;     // tiles in the group
   // Persistent form (vgrid > gridDim.x): the launch has one workgroup per CU; the workgroups of XCD x (blockIdx & 7)
@@ -1041,9 +1042,9 @@ __global__ __launch_bounds__(512) void ca_gemm_kernel_x(const CaGemmGroup grp) {
     gt = (vb & 7) * (vgrid >> 3) + (vb >> 3);
     live = gt < grp.total;
     if (live) {
-      which = gt >= grp.first[1] ? 1 : 0;
-      if (grp.count > 2 && gt >= grp.first[2]) which = 2;
-      if (grp.count > 3 && gt >= grp.first[3]) which = 3;
+#pragma unroll
+      for (int i = 1; i < X_GROUP_MAX; ++i)
+        if (grp.count > i && gt >= grp.first[i]) which = i;
     }
   }
   const CaGemmDesc d = grp.d[which];
@@ -2452,7 +2453,7 @@ static void x_launch_geometry(CaGemmGroup& g, unsigned vgrid, unsigned nbz, dim3
 }
 
 extern "C" int ca_gemm_bf16_group(const CaGemmDesc* descs, int32_t count, void* stream) {
-  CA_CHECK_ARG(descs && count >= 1 && count <= 4, "ca_gemm_bf16_group: 1..4 problems");
+  CA_CHECK_ARG(descs && count >= 1 && count <= X_GROUP_MAX, "ca_gemm_bf16_group: 1..8 problems");
   CaGemmGroup g;
   int total = 0;
   for (int i = 0; i < count; ++i) {
@@ -2471,7 +2472,7 @@ extern "C" int ca_gemm_bf16_group(const CaGemmDesc* descs, int32_t count, void* 
     total += ((p->M + XBM - 1) / XBM) * ((p->N + XBN - 1) / XBN);
   }
   g.total = total;
-  for (int i = count; i < 4; ++i) {
+  for (int i = count; i < X_GROUP_MAX; ++i) {
     g.d[i] = descs[0];
     g.first[i] = total;
   }

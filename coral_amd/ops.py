@@ -173,34 +173,55 @@ def _fill(t):
     return t / (256.0 * ((t + 255) // 256))
 
 
-def wgrad_plan(problems: list):
-    """-> (solo, groups, fallback): which weight gradients of a layer get their own launch of the 256x256 kernel,
-    which share grouped launches (lists of <= 4) and which fall back to the general path (split-K when tiny)."""
-    solo = [p for p in problems if _fill(_xtiles(p)) >= 0.85 and p["K"] >= 512]
-    rest = [p for p in problems if not (_fill(_xtiles(p)) >= 0.85 and p["K"] >= 512)]
-    groups, fallback = [], []
+GROUP_MAX = 8  # problems per grouped launch (X_GROUP_MAX in gemm.hip)
+
+
+_PLAN_CACHE: dict = {}
+
+
+def _wgrad_plan_idx(shapes: tuple):
+    """wgrad_plan on (M, N, K) triples -> index lists (cached: the plan of a layer is the same every step)."""
     import itertools
 
-    rest = [p for p in rest if p["K"] >= 512] + [p for p in rest if p["K"] < 512]
-    small_k = [p for p in rest if p["K"] < 512]
-    rest = [p for p in rest if p["K"] >= 512]
+    xt = [((m + 255) // 256) * ((n + 255) // 256) for m, n, _ in shapes]
+    big = [i for i, (_, _, k) in enumerate(shapes) if _fill(xt[i]) >= 0.85 and k >= 512]
+    rest = [i for i in range(len(shapes)) if i not in big and shapes[i][2] >= 512]
+    small_k = [i for i in range(len(shapes)) if i not in big and shapes[i][2] < 512]
+    groups = []
+    # all of the under-filled problems together, when that fills >= 60 % of its rounds: one launch (and one pass for the
+    # fused bias gradients) beats the best-filled subset plus stragglers on the split-K path
+    if 1 < len(rest) <= GROUP_MAX and _fill(sum(xt[i] for i in rest)) >= 0.6:
+        groups.append(list(rest))
+        rest = []
     while len(rest) > 1:
-        # the subset (2..4 problems) that fills its rounds of CUs best; stop when nothing reaches 70 %
+        # the subset (2..GROUP_MAX problems) that fills its rounds of CUs best; stop when nothing reaches 70 %
         best, best_fill = None, 0.0
-        for r in range(min(4, len(rest)), 1, -1):
-            for combo in itertools.combinations(range(len(rest)), r):
-                total = sum(_xtiles(rest[i]) for i in combo)
-                alone = sum(_xtiles(rest[i]) / _fill(_xtiles(rest[i])) for i in combo)
+        for r in range(min(GROUP_MAX, len(rest)), 1, -1):
+            for combo in itertools.combinations(rest, r):
+                total = sum(xt[i] for i in combo)
+                alone = sum(xt[i] / _fill(xt[i]) for i in combo)
                 f = _fill(total)
                 if f >= 0.7 and total / f < 0.9 * alone and (f > best_fill + 1e-9 or (abs(f - best_fill) < 1e-9 and best is not None
                                                                                  and len(combo) > len(best))):
                     best, best_fill = combo, f
         if best is None:
             break
-        groups.append([rest[i] for i in best])
-        rest = [p for i, p in enumerate(rest) if i not in best]
-    fallback = rest + small_k
-    return solo, groups, fallback
+        groups.append(list(best))
+        rest = [i for i in rest if i not in best]
+    return big, groups, rest + small_k
+
+
+def wgrad_plan(problems: list):
+    """-> (solo, groups, fallback): which weight gradients of a layer get their own launch of the 256x256 kernel,
+    which share grouped launches (lists of <= GROUP_MAX) and which fall back to the general path (split-K when tiny)."""
+    key = tuple((p["M"], p["N"], p["K"]) for p in problems)
+    plan = _PLAN_CACHE.get(key)
+    if plan is None:
+        if len(_PLAN_CACHE) > 4096:
+            _PLAN_CACHE.clear()
+        plan = _PLAN_CACHE[key] = _wgrad_plan_idx(key)
+    solo, groups, fallback = plan
+    return [problems[i] for i in solo], [[problems[i] for i in g] for g in groups], [problems[i] for i in fallback]
 
 
 def wgrad_gemm_group(problems: list, G, colsum_ws=None, colsum_ld=0) -> bool:

@@ -97,14 +97,6 @@ def whisper_param_list(s: WhisperShape):
            ("model.encoder.conv2.weight", (d, d, 3), "front"), ("model.encoder.conv2.bias", (d,), "front"),
            ("model.encoder.embed_positions.weight", (s.max_source_positions, d), "front")]
 
-    def attn(p, b):
-        o = []
-        for n in ("q_proj", "k_proj", "v_proj"):
-            o.append((p + n + ".weight", (d, d), b))
-        o += [(p + "q_proj.bias", (d,), b), (p + "k_proj.bias__zero", (d,), b), (p + "v_proj.bias", (d,), b),
-              (p + "out_proj.weight", (d, d), b), (p + "out_proj.bias", (d,), b)]
-        return o
-
     for l in range(s.encoder_layers):
         p, b = f"model.encoder.layers.{l}.", f"enc{l}"
         a = p + "self_attn."
@@ -124,11 +116,20 @@ def whisper_param_list(s: WhisperShape):
             ("model.decoder.embed_positions.weight", (s.max_target_positions, d), "emb")]
     for l in range(s.decoder_layers):
         p, b = f"model.decoder.layers.{l}.", f"dec{l}"
-        out += attn(p + "self_attn.", b) + attn(p + "encoder_attn.", b)
+        sa, ca = p + "self_attn.", p + "encoder_attn."
+        # small tensors first (the three norms, then ALL Linear biases as one contiguous vector of 9d + f floats in the
+        # order self q|k|v, self out, cross q, cross k|v, cross out, fc1, fc2: the fused bias gradients of the layer's
+        # grouped weight-gradient launch are added in one pass), the weight matrices at the end of the bucket
         for n in ("self_attn_layer_norm", "encoder_attn_layer_norm", "final_layer_norm"):
             out += [(p + n + ".weight", (d,), b), (p + n + ".bias", (d,), b)]
-        out += [(p + "fc1.weight", (s.decoder_ffn_dim, d), b), (p + "fc1.bias", (s.decoder_ffn_dim,), b),
-                (p + "fc2.weight", (d, s.decoder_ffn_dim), b), (p + "fc2.bias", (d,), b)]
+        out += [(sa + "q_proj.bias", (d,), b), (sa + "k_proj.bias__zero", (d,), b), (sa + "v_proj.bias", (d,), b),
+                (sa + "out_proj.bias", (d,), b),
+                (ca + "q_proj.bias", (d,), b), (ca + "k_proj.bias__zero", (d,), b), (ca + "v_proj.bias", (d,), b),
+                (ca + "out_proj.bias", (d,), b),
+                (p + "fc1.bias", (s.decoder_ffn_dim,), b), (p + "fc2.bias", (d,), b)]
+        for a in (sa, ca):
+            out += [(a + n + ".weight", (d, d), b) for n in ("q_proj", "k_proj", "v_proj", "out_proj")]
+        out += [(p + "fc1.weight", (s.decoder_ffn_dim, d), b), (p + "fc2.weight", (d, s.decoder_ffn_dim), b)]
     out += [("model.decoder.layer_norm.weight", (d,), "decf"), ("model.decoder.layer_norm.bias", (d,), "decf")]
     return out
 

@@ -59,6 +59,9 @@ class WhisperTrainEngine(WhisperEngine):
                               p + "self_attn.q_proj.bias"),
                 CrossAttnBlock(st, p + "encoder_attn_layer_norm", p + "encoder_attn.", s.decoder_attention_heads, d, eps),
                 FFNBlock(st, p + "final_layer_norm", p + "fc1", p + "fc2", d, s.decoder_ffn_dim, eps)))
+            # a decoder layer's bias vector (whisper_param_list): self q|k|v, self out, cross q, cross k|v, cross out, fc1, fc2
+            sa, ca, ff = self.dec_blocks[-1]
+            sa.cs_qkv, sa.cs_o, ca.cs, ff.cs_fc1, ff.cs_fc2 = 0, 3 * d, (4 * d, 7 * d), 8 * d, 8 * d + s.decoder_ffn_dim
         self._tw = None
         self._tw_key = None
         self.zero_mel = torch.zeros(s.num_mel_bins, dtype=torch.bfloat16, device=self.device)
@@ -118,16 +121,18 @@ class WhisperTrainEngine(WhisperEngine):
         return lo, hi
 
     def shard_ranges(self) -> dict:
-        """{encoder-layer bucket: (first element of its weight matrices, bucket end)}: what a sharded optimiser
-        (trainer.py, zero_stage) may split over the ranks - 78 % of whisper-large-turbo's parameters.  The forward reads
-        these matrices through the bf16 compute copy only; the small tensors in front of them, the decoder layers
-        (matrices and biases interleaved) and the embeddings stay replicated."""
+        """{layer bucket: (first element of its weight matrices, bucket end)}: what a sharded optimiser (trainer.py,
+        zero_stage) may split over the ranks - every encoder and decoder layer's matrices (92 % of whisper-large-turbo's
+        parameters).  The forward reads them through the bf16 compute copy only; the small tensors in front of them,
+        the convolutions and the embeddings stay replicated."""
         st = self.store
         out = {}
         for l in range(self.s.encoder_layers):
             lo, hi = self._enc_matrix_range(l)
             if hi == st.buckets[f"enc{l}"][1]:
                 out[f"enc{l}"] = (lo, hi)
+        for l in range(self.s.decoder_layers):  # (a decoder layer: norms and the bias vector, then its ten matrices)
+            out[f"dec{l}"] = (st.off(f"model.decoder.layers.{l}.self_attn.q_proj.weight"), st.buckets[f"dec{l}"][1])
         return out
 
     def _enc_matrices(self, l: int):
@@ -235,7 +240,7 @@ class WhisperTrainEngine(WhisperEngine):
             # (second scratch / bias workspace and three more gradient buffers: the encoder layers' weight gradients run
             # on a side stream two layers behind the data-gradient chain, see backward())
             sc_e2=Scratch(Me, d, s.encoder_ffn_dim, dev),
-            g_e=[_z(Me * d, dev) for _ in range(6)], g_d=[_z(Md * d, dev), _z(Md * d, dev)],
+            g_e=[_z(Me * d, dev) for _ in range(6)], g_d=[_z(Md * d, dev) for _ in range(4)], dec_bias_ws=_z(ops.COLSUM_PARTS * (9 * d + s.decoder_ffn_dim), dev, f32),
             bias_ws=_z(ops.COLSUM_PARTS * (5 * d + s.encoder_ffn_dim), dev, f32),
             bias_ws2=_z(ops.COLSUM_PARTS * (5 * d + s.encoder_ffn_dim), dev, f32), denc32=_z(Me * d, dev, f32), dpre=_z(B * (Tin + 2) * d + 64, dev),
             dcol=_z(Me * 3 * d, dev), dwr_part=_z(B * d * 3 * max(d, s.num_mel_bins), dev, f32),
@@ -372,27 +377,37 @@ class WhisperTrainEngine(WhisperEngine):
         # tied LM head: dE += dlogits^T hf ; dhf = dlogits E
         ops.gemm(dl, w["dec_out"], g32, M=V, N=d, K=Md, a_layout=MNMAJOR, lda=Vp, b_layout=MNMAJOR, ldb=d, ldc=d,
                  c_off=o("model.decoder.embed_tokens.weight"), out_f32=True, accumulate=True)
-        ga, gb = w["g_d"]
+        ga, gb = w["g_d"][:2]
         ops.gemm(dl, p16, ga, M=Md, N=d, K=V, lda=Vp, b_layout=MNMAJOR, ldb=d, ldc=d, b_off=o("model.decoder.embed_tokens.weight"))
         ops.layernorm_bwd(ga, w["dh"][-1], st.view("model.decoder.layer_norm.weight"), None, w["dec_st"], None, gb,
                           st.view("model.decoder.layer_norm.weight", "g32"), st.view("model.decoder.layer_norm.bias", "g32"),
                           sc_d.part, Md, d)
-        cur, other = gb, ga  # cur: gradient wrt the residual stream
         ops.clear_f32(w["denc32"], w["denc32"].numel())
+        # Decoder layers.  The six token-side weight gradients of a layer (K = B*L rows: 16 ... 64 tiles of the 256x256
+        # kernel each, 224 together at whisper-medium) go out as ONE grouped launch at the end of the layer, with their
+        # bias gradients taken from the kernel's A stream and added in one pass (the layer's biases are one vector);
+        # one by one they were split-K launches + reductions + column-sum passes: ~30 launches per layer.  Every dY of
+        # the layer therefore stays alive until then: a ring of four residual-gradient buffers, the blocks' own scratch.
+        ringd, r = w["g_d"], 1  # ringd[1] = gb holds the gradient wrt the last layer's output
+        nbd = 9 * d + s.decoder_ffn_dim
         for l in reversed(range(s.decoder_layers)):
             if not sv["dk"][l]:
                 done(f"dec{l}")
                 continue
             sa, ca, ff = self.dec_blocks[l]
             sv_a, sv_c, sv_f = w["dec_sv"][l]
-            ff.backward(cur, other, sv_f, sc_d, Md)
-            cur, other = other, cur
-            ca.backward(cur, other, sv_c, sc_d, w["denc32"], B, L, T)
-            cur, other = other, cur
-            sa.backward(cur, other, sv_a, sc_d, B, L)
-            cur, other = other, cur
+            g0, g1, g2, g3 = (ringd[(r + i) % 4] for i in range(4))
+            wg = []
+            ff.backward(g0, g1, sv_f, sc_d, Md, defer=wg)
+            ca.backward(g1, g2, sv_c, sc_d, w["denc32"], B, L, T, defer=wg, cs=ca.cs)
+            sa.backward(g2, g3, sv_a, sc_d, B, L, defer=wg)
+            if ops.wgrad_gemm_group(wg, g32, colsum_ws=w["dec_bias_ws"], colsum_ld=nbd):
+                ops.reduce_rows(w["dec_bias_ws"], ops.COLSUM_PARTS, nbd, nbd,
+                                g32[o(f"model.decoder.layers.{l}.self_attn.q_proj.bias"):], accumulate=True)
+            r = (r + 3) % 4
             self.clear_internal_grads_of(f"model.decoder.layers.{l}.")
             done(f"dec{l}")
+        cur = ringd[r]
         done("decf")
         (ep, eseed), (dp, dseed) = sv["embed_drop"]
         if dp > 0.0:  # dropout on the embedded decoder inputs (:763)

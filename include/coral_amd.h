@@ -138,9 +138,10 @@ int ca_gemm_fp8(const CaGemmDesc* desc, void* stream);
  * (round to nearest even, saturating), inv_scale[0] = amax / 448 (the dequantisation factor ca_gemm_fp8 takes).
  * amax_ws: one float of workspace.  n must be a multiple of 8. */
 int ca_quantize_fp8(const void* x_bf16, int64_t n, void* q_fp8, float* inv_scale, float* amax_ws, void* stream);
-/* Up to four independent plain GEMMs of the same operand form (same a_layout / b_layout, un-batched, no epilogue,
+/* Up to eight independent plain GEMMs of the same operand form (same a_layout / b_layout, un-batched, no epilogue,
  * no bias) in one launch of the 256x256 kernel: for problems that under-fill the chip one by one, e.g. the four
- * weight gradients of a transformer layer (each replaces a `torch.mm(dY.T, X)` of autograd's Linear backward). */
+ * weight gradients of an encoder layer or the six token-side ones of a Whisper decoder layer (each replaces a
+ * `torch.mm(dY.T, X)` of autograd's Linear backward). */
 int ca_gemm_bf16_group(const CaGemmDesc* descs, int32_t count, void* stream);
 
 /* Live kernel timing for bench.py's roofline line: between ca_prof_begin() and ca_prof_end()
