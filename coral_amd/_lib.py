@@ -103,6 +103,7 @@ SIGNATURES = {
     "ca_prof_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "ca_attn_fwd": (C.c_int, [C.POINTER(CaAttnDesc), _vp]),
     "ca_attn_bwd": (C.c_int, [C.POINTER(CaAttnDesc), _vp]),
+    "ca_decode_attn_qproj": (C.c_int, [C.POINTER(CaAttnDesc), _vp, _i64, _vp, _vp, _f32, _vp, _i64, _vp, _i32, _vp]),
     "ca_layernorm_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _i32, _vp]),
     "ca_layernorm_fwd_fp8": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp]),
     "ca_layernorm_bwd_partial_floats": (_i64, [_i64, _i32]),

@@ -269,6 +269,15 @@ struct AttnArgs {
   // dropout on the attention probabilities (training): keep decision of (b, h, q, k) from (seed, flat index)
   float drop_p;
   uint64_t drop_seed;
+  // greedy decoding with the query projection inside the kernel (attn_fwd_smallq_kernel<.., true>, ca_decode_attn_qproj):
+  // q[b, h, :] = (LayerNorm(x[b]) Wq[h*hd : (h+1)*hd, :]^T + bq) - one query per clip
+  const unsigned short* qp_x;   // [B, qp_d] residual-stream rows
+  int64_t qp_ldx;
+  const float *qp_gamma, *qp_beta, *qp_bias;
+  const unsigned short* qp_W;   // [H*hd, qp_d] row-major
+  int64_t qp_ldw;
+  int qp_d;
+  float qp_eps;
 };
 // Flat index of probability (b, h, q, key): rows are padded to a multiple of 4 keys so that 4 consecutive keys from a
 // multiple of 4 share one hash (ca_dropout_keep4); the backward kernels regenerate the forward's decisions from it.
@@ -725,7 +734,12 @@ __device__ __forceinline__ void glds16_async(const void* g, char* lds_wave_base)
                : "v"(g), "s"((uint32_t)(uintptr_t)(lptr_t)lds_wave_base)
                : "memory", "m0");
 }
-template <int HDPV>
+// QP (ca_decode_attn_qproj, one query per clip): the wave-0..3 workgroup of (clip, head) first forms its own query -
+// LayerNorm of the clip's residual row (the arithmetic of ln_fwd_kernel, chunk by chunk) and the 64 x d slice of the
+// query projection (the arithmetic of ca_gemm_skinny_kernel: the four waves take a quarter of K each, one MFMA chain
+// per 16 columns, partials added as (p0 + p1) + (p2 + p3), + bias, rounded to bf16) - so the LayerNorm launch, the
+// projection launch and the query's trip through HBM disappear from the per-token chain; bit-identical to them.
+template <int HDPV, bool QP = false>
 __global__ __launch_bounds__(256) void attn_fwd_smallq_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NKS = HDPV / 32, NNB = HDPV / 16;
@@ -737,7 +751,7 @@ __global__ __launch_bounds__(256) void attn_fwd_smallq_kernel(const AttnArgs a) 
   const int g = lane >> 4, r = lane & 15;
   const int h = blockIdx.x % a.H, b = blockIdx.x / a.H;
   const int hd = a.hd;
-  const unsigned short* Q = a.Q + b * a.sqb + h * hd;
+  const unsigned short* Q = QP ? nullptr : a.Q + b * a.sqb + h * hd;
   const unsigned short* K = a.K + b * a.skb + h * hd;
   const unsigned short* V = a.V + b * a.svb + h * hd;
   char* Vring = smem + wave * D * IMG;
@@ -745,8 +759,112 @@ __global__ __launch_bounds__(256) void attn_fwd_smallq_kernel(const AttnArgs a) 
   int kl = a.Tk;
   if (a.klen) kl = a.klen[b] < kl ? a.klen[b] : kl;
   bf16x8_t qf[NKS];
+  if constexpr (QP) {
+    const int C = a.qp_d, nchunk = C >> 3;
+    unsigned short* xs = (unsigned short*)(smem + 4 * D * IMG);  // LayerNorm(x[b]) as bf16 [C <= 2048]
+    float* qpart = (float*)(smem + 4 * D * IMG + 4096);          // [4 waves][64] partial dot products
+    {  // every wave normalises the row (redundantly: no barrier before the statistics); wave 0 publishes it
+      const unsigned short* xr = a.qp_x + (int64_t)b * a.qp_ldx;
+      float v[4][8];
+      float sx = 0.f;
 #pragma unroll
-  for (int ks = 0; ks < NKS; ++ks) qf[ks] = load_rowfrag(Q, a.ldq, qrow, ks, lane, hd);
+      for (int c = 0; c < 4; ++c) {
+        const int ch = lane + c * 64;
+        if (ch < nchunk) {
+          const u16x8_t u = *(const u16x8_t*)(xr + ch * 8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            v[c][e] = bf2f(u[e]);
+            sx += v[c][e];
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[c][e] = 0.f;
+        }
+      }
+      const float mean = wave_sum(sx) / (float)C;
+      float s2 = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int ch = lane + c * 64;
+        if (ch < nchunk) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float dlt = v[c][e] - mean;
+            s2 += dlt * dlt;
+          }
+        }
+      }
+      const float rstd = rsqrtf(wave_sum(s2) / (float)C + a.qp_eps);
+      if (wave == 0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int ch = lane + c * 64;
+          if (ch < nchunk) {
+            const f32x4_t g0 = *(const f32x4_t*)(a.qp_gamma + ch * 8), g1 = *(const f32x4_t*)(a.qp_gamma + ch * 8 + 4);
+            const f32x4_t b0 = *(const f32x4_t*)(a.qp_beta + ch * 8), b1 = *(const f32x4_t*)(a.qp_beta + ch * 8 + 4);
+            u16x8_t o8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              o8[e] = f2bf(ln_apply(v[c][e], mean, rstd, e < 4 ? g0[e] : g1[e - 4], e < 4 ? b0[e] : b1[e - 4]));
+            *(u16x8_t*)(xs + ch * 8) = o8;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // q[h*hd + n] for n < 64: A operand = the weight rows (16 per block), B operand = the normalised row in every lane
+    // row; this wave's quarter of the K-steps, eight at a time, as in the weight-streaming GEMM
+    const int ksteps = (C + 31) / 32, per = (ksteps + 3) / 4;
+    const int ks0 = wave * per, ks1 = (ks0 + per < ksteps) ? ks0 + per : ksteps;
+    const bf16x8_t zero8 = __builtin_bit_cast(bf16x8_t, (f32x4_t){0.f, 0.f, 0.f, 0.f});
+    f32x4_t qa[NNB];
+#pragma unroll
+    for (int nb = 0; nb < NNB; ++nb) qa[nb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    const unsigned short* wrow[NNB];
+#pragma unroll
+    for (int nb = 0; nb < NNB; ++nb) {
+      const int n = 16 * nb + r;
+      wrow[nb] = a.qp_W + (int64_t)(h * hd + (n < hd ? n : hd - 1)) * a.qp_ldw + 8 * g;
+    }
+    for (int ks = ks0; ks < ks1; ks += 8) {
+      bf16x8_t wf[NNB][8], af[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int k = (ks + u) * 32 + 8 * g;
+        const bool ok = ks + u < ks1 && k < C;
+        af[u] = ok ? *(const bf16x8_t*)(xs + k) : zero8;
+#pragma unroll
+        for (int nb = 0; nb < NNB; ++nb) wf[nb][u] = ok ? *(const bf16x8_t*)(wrow[nb] + (int64_t)(ks + u) * 32) : zero8;
+      }
+#pragma unroll
+      for (int nb = 0; nb < NNB; ++nb)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) qa[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nb][u], af[u], qa[nb], 0, 0, 0);
+    }
+    if (r == 0) {
+#pragma unroll
+      for (int nb = 0; nb < NNB; ++nb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) qpart[wave * 64 + 16 * nb + 4 * g + e] = qa[nb][e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      float qv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int n = 32 * ks + 8 * g + j;
+        float t = (qpart[n] + qpart[64 + n]) + (qpart[128 + n] + qpart[192 + n]);
+        t = t * 1.0f + (n < hd ? a.qp_bias[h * hd + n] : 0.f);
+        qv[j] = n < hd ? bf2f(f2bf(t)) : 0.f;  // (the bf16 the projection would have stored)
+      }
+      qf[ks] = pack8(qv);
+    }
+  } else {
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) qf[ks] = load_rowfrag(Q, a.ldq, qrow, ks, lane, hd);
+  }
   const int ntile = (kl + 63) / 64;
   const int nw = ntile > wave ? (ntile - wave + 3) / 4 : 0;  // this wave's tiles: kt = wave + 4 j
   const float c2 = a.scale * LOG2E;
@@ -1613,6 +1731,8 @@ static AttnArgs to_args(const CaAttnDesc& d) {
   a.dQ = (unsigned short*)d.dQ; a.dK = (unsigned short*)d.dK; a.dV = (unsigned short*)d.dV;
   a.lddq = d.lddq; a.lddk = d.lddk; a.lddv = d.lddv; a.sdqb = d.sdqb; a.sdkb = d.sdkb; a.sdvb = d.sdvb;
   a.drop_p = d.dropout_p; a.drop_seed = d.dropout_seed;
+  a.qp_x = nullptr; a.qp_ldx = 0; a.qp_gamma = a.qp_beta = a.qp_bias = nullptr; a.qp_W = nullptr; a.qp_ldw = 0; a.qp_d = 0;
+  a.qp_eps = 0.f;
   return a;
 }
 
@@ -1662,6 +1782,40 @@ extern "C" int ca_attn_fwd(const CaAttnDesc* desc, void* stream) {
   else
     hipLaunchKernelGGL((attn_fwd_kernel<128>), grid, block, 2 * 64 * 128 * 2, s, a);
   CA_CHECK_LAUNCH("ca_attn_fwd");
+  return CA_OK;
+}
+
+// Greedy decoding: LayerNorm + query projection + single-query attention over a K|V cache in one launch per layer.
+extern "C" int ca_decode_attn_qproj(const CaAttnDesc* desc, const void* x, int64_t ldx, const float* ln_gamma,
+                                    const float* ln_beta, float ln_eps, const void* Wq, int64_t ldw, const float* bq,
+                                    int32_t d_model, void* stream) {
+  CA_CHECK_ARG(desc && x && ln_gamma && ln_beta && Wq && bq, "ca_decode_attn_qproj: null pointer");
+  CA_CHECK_ARG(desc->K && desc->V && desc->O && desc->B > 0 && desc->H > 0 && desc->Tk > 0, "ca_decode_attn_qproj: bad descriptor");
+  CA_CHECK_ARG(desc->Tq == 1 && desc->hd <= 64 && (desc->hd % 8) == 0 && !desc->causal && desc->dropout_p == 0.f,
+               "ca_decode_attn_qproj: one query per clip, head_dim <= 64, no mask, no dropout");
+  CA_CHECK_ARG(d_model >= 64 && d_model <= 2048 && (d_model % 8) == 0 && (ldx % 8) == 0 && (ldw % 8) == 0 &&
+                   ((uintptr_t)x % 16) == 0 && ((uintptr_t)Wq % 16) == 0 && ((uintptr_t)ln_gamma % 16) == 0 &&
+                   ((uintptr_t)ln_beta % 16) == 0,
+               "ca_decode_attn_qproj: d_model in [64, 2048], multiples of 8, 16-byte aligned operands");
+  CA_CHECK_ARG((desc->ldk % 8) == 0 && (desc->ldv % 8) == 0, "ca_decode_attn_qproj: ldk / ldv must be multiples of 8");
+  AttnArgs a = to_args(*desc);
+  a.qp_x = (const unsigned short*)x;
+  a.qp_ldx = ldx;
+  a.qp_gamma = ln_gamma;
+  a.qp_beta = ln_beta;
+  a.qp_eps = ln_eps;
+  a.qp_W = (const unsigned short*)Wq;
+  a.qp_ldw = ldw;
+  a.qp_bias = bq;
+  a.qp_d = d_model;
+  constexpr int LDS = 4 * 3 * 64 * 64 * 2 + 4096 + 1024;  // the V rings + the normalised row + the partial products
+  static bool attr = false;
+  if (!attr) {
+    hipFuncSetAttribute((const void*)attn_fwd_smallq_kernel<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr = true;
+  }
+  hipLaunchKernelGGL((attn_fwd_smallq_kernel<64, true>), dim3((unsigned)(desc->B * desc->H)), dim3(256), LDS, (hipStream_t)stream, a);
+  CA_CHECK_LAUNCH("ca_decode_attn_qproj");
   return CA_OK;
 }
 

@@ -552,6 +552,14 @@ def attn_fwd(Q, K, V, O, lse, **kw):
     check(lib().ca_attn_fwd(C.byref(d), _stream()), "ca_attn_fwd")
 
 
+def decode_attn_qproj(x, gamma, beta, W, bias, K, V, O, *, d_model, eps, ldx, ldw, w_off=0, bias_off=0, **kw):
+    """Greedy decoding, one token per clip: LayerNorm(x) -> query projection (W rows w_off.., bias) -> single-query
+    attention over the K|V cache, one launch (ca_decode_attn_qproj); kw as for attn_fwd with Tq = 1 (no Q)."""
+    d = _attn_desc(None, K, V, O, None, Tq=1, Tqp=32, ldq=0, sqb=0, **kw)
+    check(lib().ca_decode_attn_qproj(C.byref(d), _p(x), ldx, _p(gamma), _p(beta), eps, _p(W, w_off), ldw, _p(bias, bias_off),
+                                     d_model, _stream()), "ca_decode_attn_qproj")
+
+
 def attn_bwd(Q, K, V, O, lse, dO, Dq, dQ, dK, dV, *, lddo, sdob, lddq, lddk, lddv, sdqb, sdkb, sdvb, do_off=0,
              dq_off=0, dk_off=0, dv_off=0, **kw):
     d = _attn_desc(Q, K, V, O, lse, **kw)

@@ -518,6 +518,9 @@ class WhisperEngine:
         d, f, H, Te = s.d_model, s.decoder_ffn_dim, s.decoder_attention_heads, s.max_source_positions
         hd = d // H
         w = self._decoder_ws(B, 1)
+        import os
+
+        fused = os.environ.get("CA_DECODE_FUSED", "1") != "0" and hd <= 64 and d <= 2048
         ops.embed_tokens(p16[o("model.decoder.embed_tokens.weight"):], p16[o("model.decoder.embed_positions.weight"):],
                          g["tok"], g["pos"], w["h"][0], B, d)
         h0, h1 = w["h"][0], w["h"][1]
@@ -537,13 +540,23 @@ class WhisperEngine:
                          svb=Lmax * 2 * d, sob=d, k_off=0, v_off=d, klen=g["klen"])
             ops.gemm(w["ctx"], p16, h1, M=B, N=d, K=d, lda=d, ldb=d, ldc=d, b_off=o(p + "self_attn.out_proj.weight"),
                      bias=p32, bias_off=o(p + "self_attn.out_proj.bias"), epilogue=EPI_RESIDUAL, R=h0, ldr=d)
-            ops.layernorm_fwd(h1, st.view(p + "encoder_attn_layer_norm.weight"), st.view(p + "encoder_attn_layer_norm.bias"),
-                              w["x"], None, B, d, s.layer_norm_eps)
-            ops.gemm(w["x"], p16, w["q"], M=B, N=d, K=d, lda=d, ldb=d, ldc=d, b_off=o(p + "encoder_attn.q_proj.weight"),
-                     bias=p32, bias_off=o(p + "encoder_attn.q_proj.bias"))
-            ops.attn_fwd(w["q"], g["cross"][l], g["cross"][l], w["ctx"], self._lse(B * H * 32), B=B, H=H, Tq=1, Tk=Te,
-                         hd=hd, Tqp=32, scale=hd ** -0.5, ldq=d, ldk=2 * d, ldv=2 * d, ldo=d, sqb=d, skb=Te * 2 * d,
-                         svb=Te * 2 * d, sob=d, k_off=0, v_off=d)
+            if fused:
+                # LayerNorm + query projection + attention over the cached encoder K|V: one launch (bit-identical to
+                # the three below; CA_DECODE_FUSED=0 keeps them)
+                ops.decode_attn_qproj(h1, st.view(p + "encoder_attn_layer_norm.weight"), st.view(p + "encoder_attn_layer_norm.bias"),
+                                      p16, p32, g["cross"][l], g["cross"][l], w["ctx"], d_model=d, eps=s.layer_norm_eps,
+                                      ldx=d, ldw=d, w_off=o(p + "encoder_attn.q_proj.weight"),
+                                      bias_off=o(p + "encoder_attn.q_proj.bias"), B=B, H=H, Tk=Te, hd=hd,
+                                      scale=hd ** -0.5, ldk=2 * d, ldv=2 * d, ldo=d, skb=Te * 2 * d, svb=Te * 2 * d,
+                                      sob=d, k_off=0, v_off=d)
+            else:
+                ops.layernorm_fwd(h1, st.view(p + "encoder_attn_layer_norm.weight"), st.view(p + "encoder_attn_layer_norm.bias"),
+                                  w["x"], None, B, d, s.layer_norm_eps)
+                ops.gemm(w["x"], p16, w["q"], M=B, N=d, K=d, lda=d, ldb=d, ldc=d, b_off=o(p + "encoder_attn.q_proj.weight"),
+                         bias=p32, bias_off=o(p + "encoder_attn.q_proj.bias"))
+                ops.attn_fwd(w["q"], g["cross"][l], g["cross"][l], w["ctx"], self._lse(B * H * 32), B=B, H=H, Tq=1, Tk=Te,
+                             hd=hd, Tqp=32, scale=hd ** -0.5, ldq=d, ldk=2 * d, ldv=2 * d, ldo=d, sqb=d, skb=Te * 2 * d,
+                             svb=Te * 2 * d, sob=d, k_off=0, v_off=d)
             ops.gemm(w["ctx"], p16, h0, M=B, N=d, K=d, lda=d, ldb=d, ldc=d, b_off=o(p + "encoder_attn.out_proj.weight"),
                      bias=p32, bias_off=o(p + "encoder_attn.out_proj.bias"), epilogue=EPI_RESIDUAL, R=h1, ldr=d)
             self._ffn(w, h0, h1, p, B, d, f)

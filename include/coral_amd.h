@@ -312,6 +312,15 @@ typedef struct CaAttnDesc {
 } CaAttnDesc;
 int ca_attn_fwd(const CaAttnDesc* desc, void* stream);
 int ca_attn_bwd(const CaAttnDesc* desc, void* stream);
+/* Greedy decoding, one new token per clip: the pre-attention LayerNorm, the query projection and the single-query
+ * attention over a K|V cache in ONE launch - what `WhisperDecoderLayer` does between the residual stream and the
+ * attention output for its cross-attention ($TF/models/whisper/modeling_whisper.py:476-486: encoder_attn_layer_norm,
+ * q_proj, attention over the cached encoder K|V).  x bf16 [B, d_model] (row stride ldx); Wq bf16 [H*hd, d_model]
+ * row-major (row stride ldw), bq fp32; desc: K / V / O / klen / strides / B / H / Tk / hd / scale as for ca_attn_fwd
+ * with Tq = 1 (Q is not read).  Bit-identical to ca_layernorm_fwd + ca_gemm_bf16 + ca_attn_fwd on the same inputs. */
+int ca_decode_attn_qproj(const CaAttnDesc* desc, const void* x, int64_t ldx, const float* ln_gamma,
+                         const float* ln_beta, float ln_eps, const void* Wq, int64_t ldw, const float* bq,
+                         int32_t d_model, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * CTC head: log_softmax(fp32) + CTC loss (+ gradient wrt logits) + greedy decode.

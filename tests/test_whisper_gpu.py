@@ -323,6 +323,52 @@ def test_whisper_cached_decode_matches_full_recompute(golden_dir):
     assert long_g == long_a
 
 
+@pytest.mark.parametrize("d,H,Tk,B", [(1024, 16, 1500, 8), (1280, 20, 1500, 3), (384, 6, 200, 2), (512, 8, 77, 5)])
+def test_decode_attention_with_the_query_projection_inside_is_bit_identical(d, H, Tk, B):
+    """ca_decode_attn_qproj (greedy decoding: LayerNorm + q projection + single-query attention over the cached
+    encoder K|V in one launch) against the three launches it replaces, on the same inputs: every output bit."""
+    from coral_amd import ops
+
+    hd = d // H
+    g = torch.Generator(device=DEV).manual_seed(d + Tk)
+    x = torch.randn(B, d, device=DEV, generator=g).to(torch.bfloat16)
+    gamma = 1.0 + 0.1 * torch.randn(d, device=DEV, generator=g)
+    beta = 0.1 * torch.randn(d, device=DEV, generator=g)
+    W = (0.05 * torch.randn(d, d, device=DEV, generator=g)).to(torch.bfloat16)
+    bias = 0.1 * torch.randn(d, device=DEV, generator=g)
+    kv = torch.randn(B, Tk, 2 * d, device=DEV, generator=g).to(torch.bfloat16)
+    klen = torch.tensor([Tk, max(1, Tk - 37), 1, Tk // 2, Tk, 64, 65, Tk][:B], dtype=torch.int32, device=DEV)
+    akw = dict(B=B, H=H, Tk=Tk, hd=hd, scale=hd ** -0.5, ldk=2 * d, ldv=2 * d, ldo=d, skb=Tk * 2 * d, svb=Tk * 2 * d,
+               sob=d, k_off=0, v_off=d)
+    for kl in (None, klen):
+        xn, q = torch.empty_like(x), torch.empty_like(x)
+        want, got = torch.zeros(B, d, dtype=torch.bfloat16, device=DEV), torch.ones(B, d, dtype=torch.bfloat16, device=DEV)
+        ops.layernorm_fwd(x, gamma, beta, xn, None, B, d, 1e-5)
+        ops.gemm(xn, W, q, M=B, N=d, K=d, lda=d, ldb=d, ldc=d, bias=bias)
+        ops.attn_fwd(q, kv, kv, want, torch.empty(B * H * 32, device=DEV), Tq=1, Tqp=32, ldq=d, sqb=d, klen=kl, **akw)
+        ops.decode_attn_qproj(x, gamma, beta, W, bias, kv, kv, got, d_model=d, eps=1e-5, ldx=d, ldw=d, klen=kl, **akw)
+        torch.cuda.synchronize()
+        assert torch.isfinite(want.float()).all() and float(want.float().abs().sum()) > 0
+        assert torch.equal(got, want), (d, H, Tk, float((got.float() - want.float()).abs().max()))
+
+
+def test_whisper_generate_is_the_same_with_and_without_the_fused_decode_launches(monkeypatch):
+    """The graph-replayed token step with ca_decode_attn_qproj (default) and with the three launches it replaces
+    (CA_DECODE_FUSED=0): the same ids, token for token."""
+    from coral_amd.whisper import WhisperEngine, WhisperShape
+    from oracle import whisper_ref as w
+
+    kw, c = _tiny()
+    eng = WhisperEngine(WhisperShape(**kw), DEV)
+    eng.load_state_dict(w.synth_params(c))
+    feats = torch.randn(3, 80, 3000, generator=torch.Generator().manual_seed(12)) * 0.5
+    monkeypatch.setenv("CA_DECODE_FUSED", "1")
+    a = eng.generate(feats, [151, 3, 4, 5], 40, use_graph=True)
+    monkeypatch.setenv("CA_DECODE_FUSED", "0")
+    b = eng.generate(feats, [151, 3, 4, 5], 40, use_graph=True)
+    assert a == b
+
+
 def test_whisper_large_turbo_shape_training_step_vs_oracle():
     """BASELINE configs[4]'s architecture (whisper-large-v3-turbo: d 1280, 20 heads, 128 mel bins, 51866 tokens)
     at reduced depth (2 + 2 layers), bf16: teacher-forced loss and a few gradients against autograd on the oracle.
