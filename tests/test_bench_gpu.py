@@ -36,6 +36,25 @@ def test_bench_spawns_its_ranks_and_reports_them(zero):
     assert spread and spread[0]["replica_param_spread"] == 0.0   # DDP invariant: identical replicas
 
 
+def test_two_ranks_at_the_full_xlsr_2b_shape_with_the_sharded_optimizer():
+    """BASELINE configs[2]'s model (wav2vec2-large = XLS-R-2B, 8 x 10 s per rank) on two ranks with the N > 1 default
+    (reduce-scatter of the 48 layers' 44 M-element matrix parts, AdamW on 1/2, bf16 all-gather): the real bucket
+    sizes, offsets and slice alignments; after three steps both ranks hold the same bf16 compute copy bit for bit.
+    (Two processes share the one GPU over gloo: ~82 GB of device memory, ~40 s.)"""
+    env = dict(os.environ, CA_BENCH_SHARE_GPU="1")
+    env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline", "--no-also", "--no-fwd-bwd", "--check-replicas"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500, cwd=str(ROOT))
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    d = [x for x in lines if "metric" in x][0]
+    assert d["n_gpus"] == 2 and "sharded optimiser" in d["config"]["workload"] and "wav2vec2-large" in d["metric"]
+    assert d["config"]["loss"] > 0 and d["config"]["loss"] == d["config"]["loss"]  # finite
+    spread = [x for x in lines if "replica_param_spread" in x]
+    assert spread and spread[0]["replica_param_spread"] == 0.0
+
+
 def test_bench_refuses_more_ranks_than_devices():
     env = dict(os.environ)
     env.pop("WORLD_SIZE", None)
