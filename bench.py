@@ -233,7 +233,8 @@ def whisper_measure(model, args, world, rank, device, decode=False, fp8=False, B
     warmup = args.warmup if warmup is None else warmup
     eng, shape, waves, labels = whisper_setup_engine(model, device, rank, B)
     trainer = None if decode else DataParallelTrainer(eng, learning_rate=6e-6, betas=(0.9, 0.98), warmup_steps=1000,
-                                                      max_steps=100_000, compress_grads=(args.grad_wire == "bf16"))
+                                                      max_steps=100_000, compress_grads=(args.grad_wire == "bf16"),
+                                                      zero_stage=args.zero_stage or 0)
     if decode and fp8:
         eng.enable_fp8_encoder()
     if fp8 and not decode:
@@ -286,7 +287,9 @@ def whisper_bench(args, world, rank, device):
     if rank == 0:
         mode = f"greedy decode, {args.decode_tokens} new tokens" if args.decode else "finetune step fwd+bwd+clip+AdamW, teacher-forced"
         cfg = {"workload": f"{args.model} {mode}, {B} x 30 s per GPU, log-mel on GPU, dropout {r['dropout']:g} / "
-                           f"activation_dropout {r['activation_dropout']:g}", "global_batch": world * B,
+                           f"activation_dropout {r['activation_dropout']:g}"
+                           + (f", sharded optimiser (zero_stage {args.zero_stage}) over {args.backend}" if world > 1 and args.zero_stage
+                              and not args.decode else ""), "global_batch": world * B,
                "label_len": r["label_len"], "parallelism": f"dp{world}"}
         if args.decode:
             cfg.update(ms_per_token=round(r["ms_per_token"], 4), bytes_per_token=int(r["bytes_per_token"]),
