@@ -93,6 +93,11 @@ def gemm(A, B, Cout, **kw):
 _SPLITK_WS: dict = {}
 # tests (and CA_FUSE_BIAS=0) flip this to compare the fused bias gradient with the separate column-sum pass
 FUSE_BIAS_GRAD = os.environ.get("CA_FUSE_BIAS", "1") == "1"
+# A layer with a weight gradient on the fallback path: the others still take their bias gradients from the 256x256
+# kernel when the token count is at least this (measured, interleaved on one box: whisper-large-turbo, 12 000 rows,
+# 86.1 -> 84.7 ms - four column-sum passes over 12 000 x 1280 ... 5120 per layer disappear; XLS-R-1B, 3 992 rows,
+# 46.4 -> 47.4 ms - there the passes are short and hide on the side stream, the fused sums slow the grouped launch)
+FUSE_BIAS_PARTIAL_MIN_K = int(os.environ.get("CA_FUSE_BIAS_PARTIAL_MIN_K", "8192"))
 
 
 def gemm_fp8(A8, B8, Cout, *, a_scale=None, b_scale=None, a_row_scale=None, **kw):
@@ -177,6 +182,7 @@ GROUP_MAX = 8  # problems per grouped launch (X_GROUP_MAX in gemm.hip)
 
 
 _PLAN_CACHE: dict = {}
+_CS_DIRTY: dict = {}  # per bias workspace: the (offset, length) slices that hold fused partial column sums
 
 
 def _wgrad_plan_idx(shapes: tuple):
@@ -230,12 +236,17 @@ def wgrad_gemm_group(problems: list, G, colsum_ws=None, colsum_ld=0) -> bool:
     together they fill >= 70 % of a round of CUs and beat separate launches; well-filled ones keep their own launch.
     Measured: XLS-R-300M step 25.7 -> 23.6 ms, XLS-R-2B 92.0 -> 89.4 ms; Whisper blocks (128 tiles) stay on split-K.
 
-    Bias gradients: when every problem is served by the 256x256 kernel and `colsum_ws` is given, each launch leaves
-    COLSUM_PARTS rows of partial column sums at colsum_ws[p * colsum_ld + cs_off + m] and the function returns True
-    (the caller adds the rows with one reduce_rows); otherwise they are separate column-sum passes into
-    G[bias_off:] and the function returns False."""
+    Bias gradients: when `colsum_ws` is given and at least one problem is served by the 256x256 kernel, each of those
+    launches leaves COLSUM_PARTS rows of partial column sums at colsum_ws[p * colsum_ld + cs_off + m], the others put
+    theirs into row 0, and the function returns True (the caller adds the rows with one reduce_rows); otherwise they
+    are separate column-sum passes into G[bias_off:] and the function returns False."""
     solo, groups, fallback = wgrad_plan(problems)
-    fused = FUSE_BIAS_GRAD and colsum_ws is not None and not fallback and all("cs_off" in p for p in problems)
+    # Fused bias gradients need the 256x256 kernel: problems on the fallback path (split-K / smaller tiles) take a
+    # separate column-sum pass instead - into row 0 of their slice of the workspace, so that the caller's ONE reduction
+    # over the layer's bias vector still covers them (rows 1.. of the slice are cleared if an earlier step, with another
+    # token count and plan, left fused partials there).
+    fused = (FUSE_BIAS_GRAD and colsum_ws is not None and bool(solo or groups) and all("cs_off" in p for p in problems)
+             and (not fallback or min(p["K"] for p in problems) >= FUSE_BIAS_PARTIAL_MIN_K))
 
     def bias_kw(p):
         return dict(cs=(colsum_ws, p["cs_off"], colsum_ld)) if fused else dict(bias_off=p.get("bias_off"), part=p.get("part"))
@@ -243,8 +254,21 @@ def wgrad_gemm_group(problems: list, G, colsum_ws=None, colsum_ld=0) -> bool:
     def base(p):
         return {k: p[k] for k in ("M", "N", "K", "lda", "ldb", "c_off", "accumulate", "sq") if p.get(k) is not None or k != "sq"}
 
-    for p in solo + fallback:
+    dirty = _CS_DIRTY.setdefault(colsum_ws.data_ptr(), set()) if fused else None
+    for p in solo:
         wgrad_gemm(p["dY"], p["X"], G, **base(p), **bias_kw(p))
+        if fused:
+            dirty.add((p["cs_off"], p["M"]))
+    for p in fallback:
+        if fused:
+            key = (p["cs_off"], p["M"])
+            if key in dirty:
+                clear_ranges(colsum_ws, tuple((r * colsum_ld + p["cs_off"], p["M"]) for r in range(1, COLSUM_PARTS)))
+                dirty.discard(key)
+            colsum(p["dY"], p["lda"], p["K"], p["M"], colsum_ws, p["part"], accumulate=False, out_off=p["cs_off"])
+            wgrad_gemm(p["dY"], p["X"], G, **base(p))
+        else:
+            wgrad_gemm(p["dY"], p["X"], G, **base(p), **bias_kw(p))
     for chunk in groups:
         arr = (CaGemmDesc * len(chunk))()
         for i, p in enumerate(chunk):
@@ -257,6 +281,8 @@ def wgrad_gemm_group(problems: list, G, colsum_ws=None, colsum_ld=0) -> bool:
                                 b_layout=MNMAJOR, ldb=p["ldb"], ldc=p["N"], c_off=p["c_off"], out_f32=True,
                                 accumulate=p["accumulate"], **kw)
         check(lib().ca_gemm_bf16_group(arr, len(chunk), _stream()), "ca_gemm_bf16_group")
+        if fused:
+            dirty.update((p["cs_off"], p["M"]) for p in chunk)
     return fused
 
 
