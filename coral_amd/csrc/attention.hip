@@ -1129,7 +1129,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a) {
     d0 = *(const f32x4_t*)(Dq + s0 * 32 + 8 * g);
     d1 = *(const f32x4_t*)(Dq + s0 * 32 + 8 * g + 4);
   }
-  for (int qs = s0; qs < nstep; ++qs) {
+  // One 32-query step; FULL (compile time): nothing in the step is masked - no per-element compare / select.  As a
+  // run-time flag inside the element loop the masks became ~30 small basic blocks per step: in-kernel stamps put the
+  // softmax / dS section at 1 630 cycles of a 3 430-cycle step (tools/dev_dkv_stamps.py), against 553 + 655 for the 32 MFMAs.
+  auto step = [&](auto full_c, int qs) __attribute__((always_inline)) {
+    constexpr bool FULL = decltype(full_c)::value;
     const int buf = (qs - s0) & 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -1143,7 +1147,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a) {
     }
     const char* Qi = Qk + buf * 2 * IMG;
     const char* dOi = dOk + buf * 2 * IMG;
-    const bool full = full_keys && (qs * 32 + 32 <= a.Tq);  // uniform: nothing in this step is masked
     f32x4_t sacc[2], pacc[2];
 #pragma unroll
     for (int bb = 0; bb < 2; ++bb) {
@@ -1182,7 +1185,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a) {
         }
         float dsv = pv * (dpv - dq) * scale;
         pv = pdrop;
-        if (!full) {  // statistics of padded queries are not initialised: select, never multiply by a mask
+        if constexpr (!FULL) {  // statistics of padded queries are not initialised: select, never multiply by a mask
           const int qi = qs * 32 + 8 * g + 4 * bb + e;
           const bool ok = qi < a.Tq && key < kl && (!a.causal || key <= qi);
           pv = ok ? pv : 0.f;
@@ -1224,7 +1227,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a) {
     l1 = nl1;
     d0 = nd0;
     d1 = nd1;
-  }
+  };
+  int nfull = full_keys ? a.Tq / 32 : s0;  // steps [s0, nfull) see whole 32-query blocks of valid queries and keys
+  nfull = nfull < s0 ? s0 : nfull;
+  for (int qs = s0; qs < nfull; ++qs) step(std::true_type{}, qs);
+  for (int qs = nfull; qs < nstep; ++qs) step(std::false_type{}, qs);
   unsigned short* dK = a.dK + b * a.sdkb + h * hd;
   unsigned short* dV = a.dV + b * a.sdvb + h * hd;
   __syncthreads();  // the last step's image reads are done in every wave: the LDS becomes output staging
@@ -1306,7 +1313,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_wide_kernel(const AttnArgs a
     d0 = *(const f32x4_t*)(Dq + s0 * 32 + 8 * g);
     d1 = *(const f32x4_t*)(Dq + s0 * 32 + 8 * g + 4);
   }
-  for (int qs = s0; qs < nstep; ++qs) {
+  // One 32-query step; FULL (compile time): nothing in the step is masked - no per-element compare / select.  As a
+  // run-time flag inside the element loop the masks became ~30 small basic blocks per step: in-kernel stamps put the
+  // softmax / dS section at 1 630 cycles of a 3 430-cycle step (tools/dev_dkv_stamps.py), against 553 + 655 for the 32 MFMAs.
+  auto step = [&](auto full_c, int qs) __attribute__((always_inline)) {
+    constexpr bool FULL = decltype(full_c)::value;
     const int buf = (qs - s0) & 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -1320,7 +1331,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_wide_kernel(const AttnArgs a
     }
     const char* Qi = Qk + buf * 2 * IMG;
     const char* dOi = dOk + buf * 2 * IMG;
-    const bool full = full_keys && (qs * 32 + 32 <= a.Tq);  // uniform: nothing in this step is masked
     f32x4_t sacc[KB][2], pacc[KB][2];
 #pragma unroll
     for (int bb = 0; bb < 2; ++bb) {
@@ -1369,7 +1379,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_wide_kernel(const AttnArgs a
           }
           float dsv = pv * (dpv - dq) * scale;
           pv = pdrop;
-          if (!full) {  // statistics of padded queries are not initialised: select, never multiply by a mask
+          if constexpr (!FULL) {  // statistics of padded queries are not initialised: select, never multiply by a mask
             const int qi = qs * 32 + 8 * g + 4 * bb + e;
             const bool ok = qi < a.Tq && key < kl && (!a.causal || key <= qi);
             pv = ok ? pv : 0.f;
@@ -1417,7 +1427,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_wide_kernel(const AttnArgs a
     l1 = nl1;
     d0 = nd0;
     d1 = nd1;
-  }
+  };
+  int nfull = full_keys ? a.Tq / 32 : s0;  // steps [s0, nfull) see whole 32-query blocks of valid queries and keys
+  nfull = nfull < s0 ? s0 : nfull;
+  for (int qs = s0; qs < nfull; ++qs) step(std::true_type{}, qs);
+  for (int qs = nfull; qs < nstep; ++qs) step(std::false_type{}, qs);
   unsigned short* dK = a.dK + b * a.sdkb + h * hd;
   unsigned short* dV = a.dV + b * a.sdvb + h * hd;
   __syncthreads();  // the last step's image reads are done in every wave: the LDS becomes output staging
