@@ -931,8 +931,11 @@ __global__ __launch_bounds__(256) void attn_fwd_smallq_kernel(const AttnArgs a) 
       }
       sc[blk] = acc;
     }
-    const bool full = kt * 64 + 64 <= kl;
-    if (!full) {
+    // (tiles wholly inside the valid keys: a body of their own without compare / select - a run-time flag inside the
+    // element loops becomes control flow per element)
+    auto rest = [&](auto full_c) __attribute__((always_inline)) {
+    constexpr bool FULL = decltype(full_c)::value;
+    if constexpr (!FULL) {
 #pragma unroll
       for (int blk = 0; blk < 4; ++blk)
 #pragma unroll
@@ -956,7 +959,7 @@ __global__ __launch_bounds__(256) void attn_fwd_smallq_kernel(const AttnArgs a) 
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         float pv = __builtin_amdgcn_exp2f(fmaf(sc[blk][e], c2, -m_new));
-        if (!full) pv = sc[blk][e] > 0.5f * NEG_BIG ? pv : 0.f;
+        if constexpr (!FULL) pv = sc[blk][e] > 0.5f * NEG_BIG ? pv : 0.f;
         p[4 * blk + e] = pv;
         sum += pv;  // the normaliser is the sum of ALL probabilities: dropout acts on the normalised ones
       }
@@ -983,6 +986,11 @@ __global__ __launch_bounds__(256) void attn_fwd_smallq_kernel(const AttnArgs a) 
         o[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, vf[s][nb], o[nb], 0, 0, 0);
       }
     }
+    };
+    if (kt * 64 + 64 <= kl)
+      rest(std::true_type{});
+    else
+      rest(std::false_type{});
     if (j + D < nw) issue(slot_c, j + D);  // slot S is free again: its registers and its LDS image have been consumed
   };
   if (nw > 0) issue(std::integral_constant<int, 0>{}, 0);
