@@ -1191,7 +1191,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a) {
           dpv = keep ? dpv * ks : 0.f;
           pdrop = keep ? pv * ks : 0.f;
         }
-        float dsv = pv * (dpv - dq) * scale;
+        float dsv = pv * (dpv - dq);  // (x scale: once, when dK is stored)
         pv = pdrop;
         if constexpr (!FULL) {  // statistics of padded queries are not initialised: select, never multiply by a mask
           const int qi = qs * 32 + 8 * g + 4 * bb + e;
@@ -1245,7 +1245,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a) {
   __syncthreads();  // the last step's image reads are done in every wave: the LDS becomes output staging
   const float one[4] = {1.f, 1.f, 1.f, 1.f};
   char* st = smem + wave * (attn_stage_bytes(HDPV) / 4);
-  store_tile16<HDPV>(st, dk, one, dK, a.lddk, k0, a.Tk, hd, lane);
+  const float sc4[4] = {scale, scale, scale, scale};  // dS was formed without the softmax scale
+  store_tile16<HDPV>(st, dk, sc4, dK, a.lddk, k0, a.Tk, hd, lane);
   __builtin_amdgcn_wave_barrier();
   store_tile16<HDPV>(st, dv, one, dV, a.lddv, k0, a.Tk, hd, lane);
 }
@@ -1385,7 +1386,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_wide_kernel(const AttnArgs a
             dpv = keep ? dpv * ks : 0.f;
             pdrop = keep ? pv * ks : 0.f;
           }
-          float dsv = pv * (dpv - dq) * scale;
+          float dsv = pv * (dpv - dq);  // (x scale: once, when dK is stored)
           pv = pdrop;
           if constexpr (!FULL) {  // statistics of padded queries are not initialised: select, never multiply by a mask
             const int qi = qs * 32 + 8 * g + 4 * bb + e;
@@ -1444,10 +1445,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_wide_kernel(const AttnArgs a
   unsigned short* dV = a.dV + b * a.sdvb + h * hd;
   __syncthreads();  // the last step's image reads are done in every wave: the LDS becomes output staging
   const float one[4] = {1.f, 1.f, 1.f, 1.f};
+  const float sc4[4] = {scale, scale, scale, scale};  // dS was formed without the softmax scale
   char* st = smem + wave * (attn_stage_bytes(HDPV) / 4);
 #pragma unroll
   for (int kb = 0; kb < KB; ++kb) {
-    store_tile16<HDPV>(st, dk[kb], one, dK, a.lddk, k0 + 16 * kb, a.Tk, hd, lane);
+    store_tile16<HDPV>(st, dk[kb], sc4, dK, a.lddk, k0 + 16 * kb, a.Tk, hd, lane);
     __builtin_amdgcn_wave_barrier();
     store_tile16<HDPV>(st, dv[kb], one, dV, a.lddv, k0 + 16 * kb, a.Tk, hd, lane);
     __builtin_amdgcn_wave_barrier();
@@ -1531,7 +1533,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float dpv = DROP ? (((keep >> e) & 1u) ? pacc[e] * kscale : 0.f) : pacc[e];
-          float dsv = __builtin_amdgcn_exp2f(fmaf(sacc[e], c2, -lse2)) * (dpv - dq_row) * scale;
+          float dsv = __builtin_amdgcn_exp2f(fmaf(sacc[e], c2, -lse2)) * (dpv - dq_row);  // (x scale: when dQ is stored)
           if (!full) {
             const int key = kt * 64 + 32 * s + 8 * g + 4 * bb + e;
             const bool ok = key < kl && (!a.causal || key <= qi);
@@ -1548,9 +1550,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     __syncthreads();
   }
   unsigned short* dQ = a.dQ + b * a.sdqb + h * hd;
-  const float one[4] = {1.f, 1.f, 1.f, 1.f};
+  const float sc4[4] = {scale, scale, scale, scale};  // dS was formed without the softmax scale
   // (every loop iteration ended with a workgroup barrier: the images are free)
-  store_tile16<HDPV>(smem + wave * (attn_stage_bytes(HDPV) / 4), acc, one, dQ, a.lddq, q0, a.Tq, hd, lane);
+  store_tile16<HDPV>(smem + wave * (attn_stage_bytes(HDPV) / 4), acc, sc4, dQ, a.lddq, q0, a.Tq, hd, lane);
 }
 
 // ---- backward: dQ, wide workgroups (same reasoning and ring as attn_fwd_wide_kernel) -----------------------------------
@@ -1668,7 +1670,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const float dpv = DROP ? (((keep >> e) & 1u) ? pacc[j][e] * kscale : 0.f) : pacc[j][e];
-            float dsv = __builtin_amdgcn_exp2f(fmaf(sacc[j][e], c2, -lse2[j])) * (dpv - dq_row[j]) * scale;
+            float dsv = __builtin_amdgcn_exp2f(fmaf(sacc[j][e], c2, -lse2[j])) * (dpv - dq_row[j]);  // (x scale: when dQ is stored)
             if constexpr (!FULL) {
               const int key = kt * 64 + 32 * s + 8 * g + 4 * bb + e;
               const bool ok = key < kl && (!a.causal || key <= qi[j]);
@@ -1723,12 +1725,12 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   run(std::false_type{}, nfull, ntile);
   __syncthreads();  // every wave is done with the images: the LDS becomes output staging
   unsigned short* dQ = a.dQ + b * a.sdqb + h * hd;
-  const float one[4] = {1.f, 1.f, 1.f, 1.f};
+  const float sc4[4] = {scale, scale, scale, scale};  // dS was formed without the softmax scale
   char* st = smem + wave * (16 * (HDPV * 2 + 16));
 #pragma unroll
   for (int j = 0; j < NQ; ++j) {
     if (j) __builtin_amdgcn_wave_barrier();
-    store_tile16<HDPV>(st, acc[j], one, dQ, a.lddq, q0 + 16 * j, a.Tq, hd, lane);
+    store_tile16<HDPV>(st, acc[j], sc4, dQ, a.lddq, q0 + 16 * j, a.Tq, hd, lane);
   }
 }
 
