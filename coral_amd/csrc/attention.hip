@@ -579,35 +579,37 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             sc[j][blk][e] = ok ? sc[j][blk][e] : NEG_BIG;
           }
       }
-      // scores in log2 units first: the products are canonical values, so the maximum below compiles to plain
-      // v_max3_f32 (fmaxf straight on MFMA outputs makes the compiler canonicalise every operand: v_max x, x), and a
-      // probability is one subtraction and one v_exp_f32.  (A hand-written v_max3_f32 on the accumulators is not an
-      // option: the hazard recogniser does not see inline asm, and the MFMA -> VALU read then returns stale registers.)
-      float t[16];
-#pragma unroll
-      for (int blk = 0; blk < 4; ++blk)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) t[4 * blk + e] = sc[j][blk][e] * c2;
-      float tmax = fmaxf(fmaxf(t[0], t[1]), t[2]);
-#pragma unroll
-      for (int i = 3; i < 15; i += 2) tmax = fmaxf(fmaxf(tmax, t[i]), t[i + 1]);
-      tmax = fmaxf(tmax, t[15]);
-      tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-      const float m_new = fmaxf(m[j], tmax);
-      const float alpha = __builtin_amdgcn_exp2f(m[j] - m_new);
       float p[16];
-      float sum = 0.f;
-#pragma unroll
-      for (int blk = 0; blk < 4; ++blk)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float pv = __builtin_amdgcn_exp2f(t[4 * blk + e] - m_new);
-          if constexpr (!FULL) pv = sc[j][blk][e] > 0.5f * NEG_BIG ? pv : 0.f;
-          p[4 * blk + e] = pv;
-          sum += pv;  // the normaliser is the sum of ALL probabilities: dropout acts on the normalised ones
-        }
+      float alpha;
+      float m_new;
       if constexpr (DROP) {
+        // scores in log2 units first: the products are canonical values, so the maximum below compiles to plain
+        // v_max3_f32 (fmaxf straight on MFMA outputs makes the compiler canonicalise every operand: v_max x, x), and a
+        // probability is one subtraction and one v_exp_f32.  (A hand-written v_max3_f32 on the accumulators is not an
+        // option: the hazard recogniser does not see inline asm, and the MFMA -> VALU read then returns stale registers.)
+        float t[16];
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) t[4 * blk + e] = sc[j][blk][e] * c2;
+        float tmax = fmaxf(fmaxf(t[0], t[1]), t[2]);
+#pragma unroll
+        for (int i = 3; i < 15; i += 2) tmax = fmaxf(fmaxf(tmax, t[i]), t[i + 1]);
+        tmax = fmaxf(tmax, t[15]);
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        m_new = fmaxf(m[j], tmax);
+        alpha = __builtin_amdgcn_exp2f(m[j] - m_new);
+        float sum = 0.f;
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float pv = __builtin_amdgcn_exp2f(t[4 * blk + e] - m_new);
+            if constexpr (!FULL) pv = sc[j][blk][e] > 0.5f * NEG_BIG ? pv : 0.f;
+            p[4 * blk + e] = pv;
+            sum += pv;  // the normaliser is the sum of ALL probabilities: dropout acts on the normalised ones
+          }
         const float ks = 1.f / (1.f - a.drop_p);
 #pragma unroll
         for (int blk = 0; blk < 4; ++blk) {
@@ -616,8 +618,35 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
           for (int e = 0; e < 4; ++e) p[4 * blk + e] = ((keep >> e) & 1u) ? p[4 * blk + e] * ks : 0.f;
         }
+        l[j] = fmaf(l[j], alpha, sum);
+      } else {
+        // The kernels are bound by vector-instruction issue (~250 per tile and wave against 32 MFMAs), so
+        // the softmax is kept short: the maximum of the RAW scores (median of (x, y, +inf) = max without the
+        // canonicalising move the compiler puts in front of fmaxf on MFMA outputs), scale and shift as ONE fma in front
+        // of the exponential.  (The row sums as one more column of the P V product - P . 1 on the matrix pipe instead
+        // of an addition per probability - were measured too: 4.5 % faster at T = 1500, but sums of bf16-rounded
+        // probabilities took the 24-layer logits from 3.7e-2 to 5.2e-2 of the fp32 reference; the fp32 sums stay.)
+        const float inf = __builtin_inff();
+        float tmax = __builtin_amdgcn_fmed3f(sc[j][0][0], sc[j][0][1], inf);
+#pragma unroll
+        for (int i = 2; i < 16; ++i) tmax = __builtin_amdgcn_fmed3f(tmax, sc[j][i >> 2][i & 3], inf);
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        m_new = fmaxf(m[j], tmax * c2);
+        alpha = __builtin_amdgcn_exp2f(m[j] - m_new);
+        const float nm = -m_new;
+        float sum = 0.f;
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float pv = __builtin_amdgcn_exp2f(fmaf(sc[j][blk][e], c2, nm));
+            if constexpr (!FULL) pv = sc[j][blk][e] > 0.5f * NEG_BIG ? pv : 0.f;
+            p[4 * blk + e] = pv;
+            sum += pv;
+          }
+        l[j] = fmaf(l[j], alpha, sum);
       }
-      l[j] = fmaf(l[j], alpha, sum);
       if (__builtin_amdgcn_ballot_w64(m_new > m[j]) != 0) {  // some query of this block moved its maximum
         float ar[4];
 #pragma unroll
