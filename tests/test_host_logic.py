@@ -190,3 +190,28 @@ def test_param_store_layout_is_bucketed_and_aligned():
     i = names.index("wav2vec2.encoder.layers.0.attention.q_proj.weight")
     assert names[i + 1].endswith("k_proj.weight") and names[i + 2].endswith("v_proj.weight")
     assert _r8(46) == 48
+
+
+def test_weight_gradient_launch_plans_of_the_model_shapes():
+    """ops.wgrad_plan (host logic of the grouped weight-gradient launches): which problems of a layer get their own
+    launch of the 256x256 kernel, which share one, which stay on the split-K path - at the shapes the engines run."""
+    from coral_amd import ops
+
+    def plan(shapes):
+        solo, groups, fb = ops.wgrad_plan([dict(M=m, N=n, K=k) for m, n, k in shapes])
+        return len(solo), sorted(len(g) for g in groups), len(fb)
+
+    def enc(d, f, rows):
+        return [(3 * d, d, rows), (d, d, rows), (f, d, rows), (d, f, rows)]
+
+    def dec(d, f, rows):
+        return [(3 * d, d, rows), (d, d, rows), (d, d, rows), (d, d, rows), (f, d, rows), (d, f, rows)]
+
+    assert plan(enc(1920, 7680, 3992)) == (2, [2], 0)       # XLS-R-2B: fc1 / fc2 alone (240 tiles each), q|k|v + out together
+    assert plan(enc(1024, 4096, 3992)) == (0, [4], 0)       # XLS-R-300M: one launch of 192 tiles
+    assert plan(enc(1280, 5120, 3992)) == (0, [3], 1)       # XLS-R-1B: 200 tiles together, one matrix on the 256x128 kernel
+    assert plan(dec(1024, 4096, 904)) == (0, [6], 0)        # whisper-medium decoder layer: six problems, 224 tiles, one launch
+    assert plan(dec(1280, 5120, 904)) == (0, [6], 0)        # whisper-large-turbo decoder layer: 350 tiles, one launch
+    assert plan(enc(768, 3072, 1000)) == (0, [], 4)         # nothing fills the chip: the general path
+    assert plan([(1024, 1024, 200)] * 3) == (0, [], 3)      # short contraction: never grouped
+    assert ops.GROUP_MAX == 8
