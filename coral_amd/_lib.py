@@ -73,6 +73,12 @@ class CaGemmDesc(C.Structure):
     ]
 
 
+class CaReduceDesc(C.Structure):
+    """include/coral_amd.h: CaReduceDesc (one reduction of ca_reduce_rows_multi)."""
+    _fields_ = [("partial", C.c_void_p), ("out", C.c_void_p), ("stride", C.c_int64), ("nparts", C.c_int32),
+                ("n", C.c_int32), ("accumulate", C.c_int32)]
+
+
 class CaAttnDesc(C.Structure):
     """Mirror of `CaAttnDesc` in include/coral_amd.h."""
 
@@ -116,6 +122,7 @@ SIGNATURES = {
     "ca_dgelu_mul": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
     "ca_dropout_bf16": (C.c_int, [_vp, _vp, _i64, _f32, _u64, _vp]),
     "ca_reduce_rows_f32": (C.c_int, [_vp, _i32, _i64, _i32, _vp, _i32, _vp]),
+    "ca_reduce_rows_multi": (C.c_int, [C.POINTER(CaReduceDesc), _i32, _vp]),
     "ca_wave_normalize": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _f32, _vp]),
     "ca_frame_lengths": (C.c_int, [_vp, _i32, _i64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _i32, _vp, _vp]),
     "ca_wave_scale": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _vp]),

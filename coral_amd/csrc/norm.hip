@@ -663,6 +663,65 @@ extern "C" int ca_dropout_bf16(const void* x, void* y, int64_t n, float p, uint6
   return CA_OK;
 }
 
+// Up to CA_REDUCE_MAX independent reductions of the reduce_partials_kernel form in ONE launch: the second stages of a
+// layer's backward (fused bias-gradient partials, the d gamma | d beta partials of its two norms) were three launches of
+// ~5 us each per layer.  Same arithmetic per reduction as ca_reduce_rows_f32's many-parts form (bit-identical).
+struct ReduceMulti {
+  CaReduceDesc d[CA_REDUCE_MAX];
+  int first[CA_REDUCE_MAX + 1];  // first block of reduction i
+  int count;
+};
+__global__ __launch_bounds__(1024) void reduce_partials_multi_kernel(const ReduceMulti m) {
+  __shared__ float red[16][64];
+  int which = 0;
+#pragma unroll
+  for (int i = 1; i < CA_REDUCE_MAX; ++i)
+    if (i < m.count && (int)blockIdx.x >= m.first[i]) which = i;
+  const CaReduceDesc d = m.d[which];
+  const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
+  const int i = ((int)blockIdx.x - m.first[which]) * 64 + cl;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (i < d.n) {
+    int p = pl;
+    for (; p + 48 < d.nparts; p += 64) {
+      a0 += d.partial[(int64_t)p * d.stride + i];
+      a1 += d.partial[(int64_t)(p + 16) * d.stride + i];
+      a2 += d.partial[(int64_t)(p + 32) * d.stride + i];
+      a3 += d.partial[(int64_t)(p + 48) * d.stride + i];
+    }
+    for (; p < d.nparts; p += 16) a0 += d.partial[(int64_t)p * d.stride + i];
+  }
+  red[pl][cl] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (pl == 0 && i < d.n) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += red[q][cl];
+    d.out[i] = d.accumulate ? d.out[i] + t : t;
+  }
+}
+extern "C" int ca_reduce_rows_multi(const CaReduceDesc* descs, int32_t count, void* stream) {
+  CA_CHECK_ARG(descs && count >= 1 && count <= CA_REDUCE_MAX, "ca_reduce_rows_multi: 1..%d reductions", CA_REDUCE_MAX);
+  ReduceMulti m;
+  int blocks = 0;
+  for (int i = 0; i < count; ++i) {
+    CA_CHECK_ARG(descs[i].partial && descs[i].out && descs[i].nparts > 0 && descs[i].n > 0 && descs[i].stride >= descs[i].n,
+                 "ca_reduce_rows_multi: bad reduction %d", i);
+    m.d[i] = descs[i];
+    m.first[i] = blocks;
+    blocks += (descs[i].n + 63) / 64;
+  }
+  for (int i = count; i < CA_REDUCE_MAX; ++i) {
+    m.d[i] = descs[0];
+    m.first[i] = blocks;
+  }
+  m.first[CA_REDUCE_MAX] = blocks;
+  m.count = count;
+  hipLaunchKernelGGL(reduce_partials_multi_kernel, dim3(blocks), dim3(1024), 0, (hipStream_t)stream, m);
+  CA_CHECK_LAUNCH("ca_reduce_rows_multi");
+  return CA_OK;
+}
+
 // out[i] (+)= sum_p partial[p*stride + i]: public form of the partial-sum reduction
 extern "C" int ca_reduce_rows_f32(const float* partial, int32_t nparts, int64_t stride, int32_t n, float* out,
                                   int32_t accumulate, void* stream) {

@@ -321,6 +321,18 @@ def reduce_rows(partial, nparts, stride, n, out, accumulate=False):
           "ca_reduce_rows_f32")
 
 
+def reduce_rows_multi(items):
+    """Up to 4 reductions `out[i] (+)= sum_p partial[p * stride + i]` in one launch (ca_reduce_rows_multi):
+    items = [(partial, nparts, stride, n, out, accumulate), ...]."""
+    from ._lib import CaReduceDesc
+
+    arr = (CaReduceDesc * len(items))()
+    for k, (partial, nparts, stride, n, out, accumulate) in enumerate(items):
+        arr[k].partial, arr[k].out = _p(partial), _p(out)
+        arr[k].stride, arr[k].nparts, arr[k].n, arr[k].accumulate = stride, nparts, n, int(accumulate)
+    check(lib().ca_reduce_rows_multi(arr, len(items), _stream()), "ca_reduce_rows_multi")
+
+
 def dgelu_mul(dy, u, out, n):
     check(lib().ca_dgelu_mul(_p(dy), _p(u), _p(out), n, _stream()), "ca_dgelu_mul")
 

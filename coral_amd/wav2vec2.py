@@ -767,14 +767,9 @@ class Wav2Vec2CTCEngine:
             # LN2: dh1 = dh + LN'(dx2)
             # (with the side stream, the d gamma | d beta partials of the layer's two norms are reduced there: two
             # tiny dependent launches less per layer on the critical stream)
-            lnp = w["ln_partial"][it & 1] if ws is not None else None
-            if ws is None:
-                ops.layernorm_bwd(other, w["h1"][l], st.view(pl + "final_layer_norm.weight"), None, w["st2"][l],
-                                  dh, dh1, st.view(pl + "final_layer_norm.weight", "g32"),
-                                  st.view(pl + "final_layer_norm.bias", "g32"), part, M, d)
-            else:
-                ops.layernorm_bwd(other, w["h1"][l], st.view(pl + "final_layer_norm.weight"), None, w["st2"][l],
-                                  dh, dh1, None, None, lnp[0], M, d)
+            lnp = w["ln_partial"][it & 1]
+            ops.layernorm_bwd(other, w["h1"][l], st.view(pl + "final_layer_norm.weight"), None, w["st2"][l],
+                              dh, dh1, None, None, lnp[0], M, d)
             # out_proj: h1 = h + Wo ctx + bo
             wg.append(dict(dY=dh1, X=w["ctx"][l], M=d, N=d, K=M, lda=d, ldb=d, part=w["partial_w"],
                            c_off=o(pl + "attention.out_proj.weight"), accumulate=lacc,
@@ -789,25 +784,32 @@ class Wav2Vec2CTCEngine:
 
             # the layer's weight gradients (one grouped launch plan: 240 + 240 + 184 + 64 tiles at XLS-R-2B) and the
             # reduction of their fused bias-gradient partials
-            def wgrads(wg=wg, pl=pl):
-                if ops.wgrad_gemm_group(wg, g32, colsum_ws=w["bias_ws"], colsum_ld=nb):
-                    ops.reduce_rows(w["bias_ws"], ops.COLSUM_PARTS, nb, nb, g32[o(pl + "attention.q_proj.bias"):],
-                                    accumulate=True)
+            bias_fused = [False]
+
+            def wgrads(wg=wg, pl=pl, bias_fused=bias_fused):
+                bias_fused[0] = ops.wgrad_gemm_group(wg, g32, colsum_ws=w["bias_ws"], colsum_ld=nb)
 
             on_side(mark(), wgrads)
             dx1 = other
             ops.gemm(dqkv, p16, dx1, M=M, N=d, K=3 * d, lda=3 * d, b_layout=MNMAJOR, ldb=d, ldc=d,
                      b_off=o(pl + "attention.q_proj.weight"))
             # LN1: dh_in = dh1 + LN'(dx1)
-            if ws is None:
-                ops.layernorm_bwd(dx1, hin, st.view(pl + "layer_norm.weight"), None, w["st1"][l], dh1, dh_next,
-                                  st.view(pl + "layer_norm.weight", "g32"), st.view(pl + "layer_norm.bias", "g32"),
-                                  part, M, d)
-            else:
-                ops.layernorm_bwd(dx1, hin, st.view(pl + "layer_norm.weight"), None, w["st1"][l], dh1, dh_next,
-                                  None, None, lnp[1], M, d)
+            ops.layernorm_bwd(dx1, hin, st.view(pl + "layer_norm.weight"), None, w["st1"][l], dh1, dh_next,
+                              None, None, lnp[1], M, d)
             dh = dh_next
+
+            # the layer's second stages in ONE launch: the fused bias-gradient partials of the weight-gradient kernels
+            # and the d gamma | d beta partials of its two norms (weight and bias gradients of a norm are adjacent in the
+            # flat buffer)
+            def second_stage(pl=pl, lnp=lnp, bias_fused=bias_fused):
+                items = [(lnp[0], w["ln_parts"], 2 * d, 2 * d, g32[o(pl + "final_layer_norm.weight"):], True),
+                         (lnp[1], w["ln_parts"], 2 * d, 2 * d, g32[o(pl + "layer_norm.weight"):], True)]
+                if bias_fused[0]:
+                    items.append((w["bias_ws"], ops.COLSUM_PARTS, nb, nb, g32[o(pl + "attention.q_proj.bias"):], True))
+                ops.reduce_rows_multi(items)
+
             if ws is None:
+                second_stage()
                 done(f"layer{l}")
             else:
                 # the bucket is complete once the side stream has passed both its own launches and the main stream's
@@ -816,11 +818,7 @@ class Wav2Vec2CTCEngine:
                 ev = mark()
                 ws.wait_event(ev)
                 with torch.cuda.stream(ws):
-                    # (weight and bias gradients of a norm are adjacent in the flat buffer: one reduction each)
-                    ops.reduce_rows(lnp[0], w["ln_parts"], 2 * d, 2 * d, g32[o(pl + "final_layer_norm.weight"):],
-                                    accumulate=True)
-                    ops.reduce_rows(lnp[1], w["ln_parts"], 2 * d, 2 * d, g32[o(pl + "layer_norm.weight"):],
-                                    accumulate=True)
+                    second_stage()
                     wd = torch.cuda.Event()
                     wd.record(ws)
                     wdone[it] = wd

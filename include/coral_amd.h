@@ -194,6 +194,16 @@ int ca_colsum_bf16(const void* x, int64_t ld, int64_t rows, int32_t N, const uin
 /* out[i] (+)= sum_{p<nparts} partial[p*stride + i], i < n  (fp32; split-batch weight gradients) */
 int ca_reduce_rows_f32(const float* partial, int32_t nparts, int64_t stride, int32_t n, float* out,
                        int32_t accumulate, void* stream);
+/* Up to CA_REDUCE_MAX such reductions (the many-parts form: nparts rows of partial sums, n <= a few thousand columns)
+ * in one launch - the second stages of one layer's backward.  Bit-identical to ca_reduce_rows_f32 per reduction. */
+#define CA_REDUCE_MAX 4
+typedef struct CaReduceDesc {
+  const float* partial;
+  float* out;
+  int64_t stride;
+  int32_t nparts, n, accumulate;
+} CaReduceDesc;
+int ca_reduce_rows_multi(const CaReduceDesc* descs, int32_t count, void* stream);
 /* out = dy * gelu_erf'(u), bf16 elementwise (backward of the pos-conv GELU, :374). */
 int ca_dgelu_mul(const void* dy, const void* u, void* out, int64_t n, void* stream);
 /* y = x * keep / (1 - p), keep of element i from (seed, i): hidden-state dropout as its own pass and the mask the

@@ -788,3 +788,25 @@ def test_gemm_interior_tile_epilogue_is_bit_identical_to_the_general_walk(ops, f
     finally:
         lib.ca_gemm_debug_general_epilogue(0)
         lib.ca_gemm_force_kernel(0)
+
+
+def test_grouped_second_stage_reductions_are_bit_identical(ops):
+    """ca_reduce_rows_multi: a layer's second-stage reductions (different partial counts, strides, widths, accumulate
+    or overwrite) in one launch, against ca_reduce_rows_f32 one by one: every bit."""
+    g = torch.Generator(device=DEV).manual_seed(77)
+    specs = [(512, 3840, 3840, True), (8, 17280, 17280, True), (500, 2048 + 64, 2048, False), (3, 40, 33, True)]
+    parts = [torch.randn(np_, stride, device=DEV, generator=g) for np_, stride, _, _ in specs]
+    base = [torch.randn(n, device=DEV, generator=g) for _, _, n, _ in specs]
+    want = [b.clone() for b in base]
+    got = [b.clone() for b in base]
+    for (np_, stride, n, acc), p, o in zip(specs, parts, want):
+        ops.reduce_rows(p, np_, stride, n, o, accumulate=acc)
+    ops.reduce_rows_multi([(p, np_, stride, n, o, acc) for (np_, stride, n, acc), p, o in zip(specs, parts, got)])
+    torch.cuda.synchronize()
+    for a, b, (np_, stride, n, acc), p, b0 in zip(got, want, specs, parts, base):
+        assert torch.equal(a, b)
+        ref = p[:, :n].double().sum(0) + (b0.double() if acc else 0)
+        assert (a.double() - ref).abs().max() <= 1e-3
+    ops.reduce_rows_multi([(parts[3], 3, 40, 33, got[3], False)])
+    torch.cuda.synchronize()
+    assert (got[3].double() - parts[3][:, :33].double().sum(0)).abs().max() <= 1e-5
