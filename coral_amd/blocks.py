@@ -46,6 +46,17 @@ def _masked_grad(dh, sv, sc: "Scratch", n, kind):
     return sc.dm[kind]
 
 
+def _ln_bwd(st, ln, dx, sv, dh, dhin, sc: "Scratch", M, d, ln_part, pending):
+    """The pre-norm's backward: dhin = dh + LN'(dx).  d gamma | d beta (adjacent in the flat buffer) either reduced right
+    away, or left as partials in `ln_part` with the reduction appended to `pending`."""
+    if pending is None:
+        ops.layernorm_bwd(dx, sv["hin"], st.view(ln + ".weight"), None, sv["st"], dh, dhin,
+                          st.view(ln + ".weight", "g32"), st.view(ln + ".bias", "g32"), sc.part, M, d)
+        return
+    ops.layernorm_bwd(dx, sv["hin"], st.view(ln + ".weight"), None, sv["st"], dh, dhin, None, None, ln_part, M, d)
+    pending.append((ln_part, ops.layernorm_bwd_partial_floats(M, d) // (2 * d), 2 * d, 2 * d, st.g32[st.off(ln + ".weight"):], True))
+
+
 class SelfAttnBlock:
     """h_out = h_in + out_proj(attn(q, k, v)),  q|k|v = LN(h_in) Wqkv^T + bqkv."""
 
@@ -94,8 +105,10 @@ class SelfAttnBlock:
                  dropout_p=hdrop[0], dropout_seed=hdrop[1])
         sv["hin"], sv["klen"], sv["hdrop"] = hin, klen, hdrop
 
-    def backward(self, dh, dhin, sv, sc: Scratch, B, T, defer=None, acc=True, sq=None):
+    def backward(self, dh, dhin, sv, sc: Scratch, B, T, defer=None, acc=True, sq=None, ln_part=None, pending=None):
         """dh: grad wrt h_out (kept intact); dhin: output buffer for grad wrt h_in (may alias nothing of sv).
+        ln_part / pending: leave the norm's d gamma | d beta partials in `ln_part` and append their second-stage
+        reduction to `pending` (the caller runs a layer's reductions as one launch, ops.reduce_rows_multi).
         defer: list collecting the block's weight-gradient problems instead of launching them (the caller launches
         the whole layer's group once dh and sc.dqkv are no longer needed elsewhere).  acc=False: the weight gradients
         overwrite (first micro-batch of a step, matrices not cleared); sq: {"o": (slots, off), "qkv": ...} where the
@@ -126,8 +139,7 @@ class SelfAttnBlock:
         else:
             ops.wgrad_gemm_group(wg, g32)  # both weight gradients of the block in one grouped launch
         ops.gemm(dqkv, p16, sc.dx, M=M, N=d, K=3 * d, lda=3 * d, b_layout=MNMAJOR, ldb=d, ldc=d, b_off=o(self.attn + "q_proj.weight"))
-        ops.layernorm_bwd(sc.dx, sv["hin"], st.view(self.ln + ".weight"), None, sv["st"], dh, dhin,
-                          st.view(self.ln + ".weight", "g32"), st.view(self.ln + ".bias", "g32"), sc.part, M, d)
+        _ln_bwd(st, self.ln, sc.dx, sv, dh, dhin, sc, M, d, ln_part, pending)
 
 
 class CrossAttnBlock:
@@ -169,7 +181,7 @@ class CrossAttnBlock:
                  dropout_p=hdrop[0], dropout_seed=hdrop[1])
         sv["hin"], sv["hdrop"] = hin, hdrop
 
-    def backward(self, dh, dhin, sv, sc: Scratch, denc32, B, L, Te, defer=None, cs=(0, 0)):
+    def backward(self, dh, dhin, sv, sc: Scratch, denc32, B, L, Te, defer=None, cs=(0, 0), ln_part=None, pending=None):
         """denc32: fp32 [B*Te, d] accumulator of the gradient wrt the encoder states (+=).  defer: list collecting
         the two token-side weight-gradient problems (out_proj, q_proj; bias gradients fused at cs = (cs_q, cs_o) of the
         layer's bias vector) for the layer's grouped launch; the k|v projection's (K = B*Te rows) goes out at once."""
@@ -198,8 +210,7 @@ class CrossAttnBlock:
             defer.append(dict(dY=dq, X=sv["x"], M=d, N=d, K=M, lda=d, ldb=d, c_off=o(self.attn + "q_proj.weight"),
                               accumulate=True, bias_off=o(self.attn + "q_proj.bias"), part=sc.part, cs_off=cs[0]))
         ops.gemm(dq, p16, sc.dctx, M=M, N=d, K=d, lda=d, b_layout=MNMAJOR, ldb=d, ldc=d, b_off=o(self.attn + "q_proj.weight"))
-        ops.layernorm_bwd(sc.dctx, sv["hin"], st.view(self.ln + ".weight"), None, sv["st"], dh, dhin,
-                          st.view(self.ln + ".weight", "g32"), st.view(self.ln + ".bias", "g32"), sc.part, M, d)
+        _ln_bwd(st, self.ln, sc.dctx, sv, dh, dhin, sc, M, d, ln_part, pending)
         # k|v projection of the encoder states
         ops.colsum(dkv, 2 * d, Mk, 2 * d, g32, sc.part, out_off=o(self.attn + "k_proj.bias__zero"))
         ops.wgrad_gemm(dkv, sv["enc"], g32, M=2 * d, N=d, K=Mk, lda=2 * d, ldb=d,
@@ -238,7 +249,7 @@ class FFNBlock:
                  dropout_seed=hdrop[1])
         sv["hin"], sv["drop"], sv["hdrop"] = hin, (dropout_p, seed), hdrop
 
-    def backward(self, dh, dhin, sv, sc: Scratch, M, defer=None, acc=True, sq=None):
+    def backward(self, dh, dhin, sv, sc: Scratch, M, defer=None, acc=True, sq=None, ln_part=None, pending=None):
         sq = sq or {}
         st, d, f = self.st, self.d, self.f
         o, g32, p16 = st.off, st.g32, st.p16
@@ -261,5 +272,4 @@ class FFNBlock:
         else:
             ops.wgrad_gemm_group(wg, g32)
         ops.gemm(sc.du, p16, sc.dx, M=M, N=d, K=f, lda=f, b_layout=MNMAJOR, ldb=d, ldc=d, b_off=o(self.fc1 + ".weight"))
-        ops.layernorm_bwd(sc.dx, sv["hin"], st.view(self.ln + ".weight"), None, sv["st"], dh, dhin,
-                          st.view(self.ln + ".weight", "g32"), st.view(self.ln + ".bias", "g32"), sc.part, M, d)
+        _ln_bwd(st, self.ln, sc.dx, sv, dh, dhin, sc, M, d, ln_part, pending)

@@ -241,6 +241,10 @@ class WhisperTrainEngine(WhisperEngine):
             # on a side stream two layers behind the data-gradient chain, see backward())
             sc_e2=Scratch(Me, d, s.encoder_ffn_dim, dev),
             g_e=[_z(Me * d, dev) for _ in range(6)], g_d=[_z(Md * d, dev) for _ in range(4)], dec_bias_ws=_z(ops.COLSUM_PARTS * (9 * d + s.decoder_ffn_dim), dev, f32),
+            # d gamma | d beta partials of a layer's norms until the layer's one second-stage launch (encoder: two sets, its
+            # weight-gradient stream runs a layer behind)
+            ln_part_e=[[_z(ops.layernorm_bwd_partial_floats(Me, d), dev, f32) for _ in range(2)] for _ in range(2)],
+            ln_part_d=[_z(ops.layernorm_bwd_partial_floats(Md, d), dev, f32) for _ in range(3)],
             bias_ws=_z(ops.COLSUM_PARTS * (5 * d + s.encoder_ffn_dim), dev, f32),
             bias_ws2=_z(ops.COLSUM_PARTS * (5 * d + s.encoder_ffn_dim), dev, f32), denc32=_z(Me * d, dev, f32), dpre=_z(B * (Tin + 2) * d + 64, dev),
             dcol=_z(Me * 3 * d, dev), dwr_part=_z(B * d * 3 * max(d, s.num_mel_bins), dev, f32),
@@ -397,13 +401,15 @@ class WhisperTrainEngine(WhisperEngine):
             sa, ca, ff = self.dec_blocks[l]
             sv_a, sv_c, sv_f = w["dec_sv"][l]
             g0, g1, g2, g3 = (ringd[(r + i) % 4] for i in range(4))
-            wg = []
-            ff.backward(g0, g1, sv_f, sc_d, Md, defer=wg)
-            ca.backward(g1, g2, sv_c, sc_d, w["denc32"], B, L, T, defer=wg, cs=ca.cs)
-            sa.backward(g2, g3, sv_a, sc_d, B, L, defer=wg)
+            wg, second = [], []
+            lpd = w["ln_part_d"]
+            ff.backward(g0, g1, sv_f, sc_d, Md, defer=wg, ln_part=lpd[0], pending=second)
+            ca.backward(g1, g2, sv_c, sc_d, w["denc32"], B, L, T, defer=wg, cs=ca.cs, ln_part=lpd[1], pending=second)
+            sa.backward(g2, g3, sv_a, sc_d, B, L, defer=wg, ln_part=lpd[2], pending=second)
             if ops.wgrad_gemm_group(wg, g32, colsum_ws=w["dec_bias_ws"], colsum_ld=nbd):
-                ops.reduce_rows(w["dec_bias_ws"], ops.COLSUM_PARTS, nbd, nbd,
-                                g32[o(f"model.decoder.layers.{l}.self_attn.q_proj.bias"):], accumulate=True)
+                second.append((w["dec_bias_ws"], ops.COLSUM_PARTS, nbd, nbd,
+                               g32[o(f"model.decoder.layers.{l}.self_attn.q_proj.bias"):], True))
+            ops.reduce_rows_multi(second)  # the layer's second stages (three norms + the bias vector): one launch
             r = (r + 3) % 4
             self.clear_internal_grads_of(f"model.decoder.layers.{l}.")
             done(f"dec{l}")
@@ -456,15 +462,17 @@ class WhisperTrainEngine(WhisperEngine):
                 main.wait_event(wdone.pop(it - 2))
             sc, bw = scs[it & 1], bws[it & 1]
             cur, other, third = ring[(2 * it) % 6], ring[(2 * it + 1) % 6], ring[(2 * it + 2) % 6]
-            wg = []
-            ff.backward(cur, other, sv_f, sc, Me, defer=wg, acc=eacc, sq=sqd)
-            sa.backward(other, third, sv_a, sc, B, T, defer=wg, acc=eacc, sq=sqd)
+            wg, second = [], []
+            lpe = w["ln_part_e"][it & 1]
+            ff.backward(cur, other, sv_f, sc, Me, defer=wg, acc=eacc, sq=sqd, ln_part=lpe[0], pending=second)
+            sa.backward(other, third, sv_a, sc, B, T, defer=wg, acc=eacc, sq=sqd, ln_part=lpe[1], pending=second)
             nb = 5 * d + s.encoder_ffn_dim
 
-            def wgrads(wg=wg, bw=bw, l=l):
+            def wgrads(wg=wg, bw=bw, l=l, second=second):
                 if ops.wgrad_gemm_group(wg, g32, colsum_ws=bw, colsum_ld=nb):
-                    ops.reduce_rows(bw, ops.COLSUM_PARTS, nb, nb,
-                                    g32[o(f"model.encoder.layers.{l}.self_attn.q_proj.bias"):], accumulate=True)
+                    second.append((bw, ops.COLSUM_PARTS, nb, nb,
+                                   g32[o(f"model.encoder.layers.{l}.self_attn.q_proj.bias"):], True))
+                ops.reduce_rows_multi(second)  # both norms' d gamma | d beta and the bias vector: one launch
                 self.clear_internal_grads_of(f"model.encoder.layers.{l}.")
 
             if wside is None:
