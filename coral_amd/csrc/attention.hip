@@ -1359,14 +1359,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_wide_kernel(const AttnArgs a
     const int buf = (qs - s0) & 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    f32x4_t nl0 = l0, nl1 = l1, nd0 = d0, nd1 = d1;
-    if (qs + 1 < nstep) {
-      issue(qs + 1, buf ^ 1);
-      nl0 = *(const f32x4_t*)(lse + (qs + 1) * 32 + 8 * g);
-      nl1 = *(const f32x4_t*)(lse + (qs + 1) * 32 + 8 * g + 4);
-      nd0 = *(const f32x4_t*)(Dq + (qs + 1) * 32 + 8 * g);
-      nd1 = *(const f32x4_t*)(Dq + (qs + 1) * 32 + 8 * g + 4);
-    }
+    if (qs + 1 < nstep) issue(qs + 1, buf ^ 1);
+    // (this step's statistics: asked for here, used behind the S | dP products - no second set of registers for the next step's)
+    l0 = *(const f32x4_t*)(lse + qs * 32 + 8 * g);
+    l1 = *(const f32x4_t*)(lse + qs * 32 + 8 * g + 4);
+    d0 = *(const f32x4_t*)(Dq + qs * 32 + 8 * g);
+    d1 = *(const f32x4_t*)(Dq + qs * 32 + 8 * g + 4);
     const char* Qi = Qk + buf * 2 * IMG;
     const char* dOi = dOk + buf * 2 * IMG;
     f32x4_t sacc[KB][2], pacc[KB][2];
@@ -1461,10 +1459,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_wide_kernel(const AttnArgs a
         dv[kb][HB + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[kb], go[i], dv[kb][HB + i], 0, 0, 0);
         dk[kb][HB + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsf[kb], gq[i], dk[kb][HB + i], 0, 0, 0);
       }
-    l0 = nl0;
-    l1 = nl1;
-    d0 = nd0;
-    d1 = nd1;
   };
   int nfull = full_keys ? a.Tq / 32 : s0;  // steps [s0, nfull) see whole 32-query blocks of valid queries and keys
   nfull = nfull < s0 ? s0 : nfull;
