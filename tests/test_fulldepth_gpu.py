@@ -124,6 +124,59 @@ def test_xlsr2b_one_utterance_forward_backward_against_the_oracle():
     torch.cuda.empty_cache()
 
 
+def test_xlsr1b_one_utterance_forward_backward_against_the_oracle():
+    """CoRal's `model=wav2vec2-medium` (XLS-R-1B: 48 layers, d 1280, head_dim 80 - the third head size of the attention
+    kernels, 16 heads x 80 padded to 128 lanes) at full depth on one ragged 7 s utterance: logits, CTC loss, greedy ids
+    and a few gradients against the oracle."""
+    from coral_amd.wav2vec2 import CORAL_W2V2_SHAPES, Wav2Vec2CTCEngine, Wav2Vec2Shape
+    from oracle import wav2vec2_ref as ref
+
+    cfg = ref.W2V2Config(**ref.CORAL_SHAPES["wav2vec2-medium"])
+    P = ref.synth_params(cfg)
+    g = torch.Generator().manual_seed(1280)
+    x = (0.1 * torch.randn(112_000, generator=g)).clamp(-1, 1)
+    iv, am = ref.zero_mean_unit_var_norm([(x / x.abs().max()).numpy()])
+    iv, am = torch.from_numpy(iv), torch.from_numpy(am).long()
+    labels = torch.randint(0, 42, (1, 64), generator=g)
+    eng = Wav2Vec2CTCEngine(Wav2Vec2Shape(**CORAL_W2V2_SHAPES["wav2vec2-medium"]), DEV)
+    eng.load_state_dict(P)
+    eng.zero_grad()
+    out = eng(iv, am, labels)
+    eng.backward()
+    torch.cuda.synchronize()
+    logits = out.logits.float().cpu()
+    names = ["lm_head.weight", "wav2vec2.encoder.layers.47.attention.out_proj.weight",
+             "wav2vec2.encoder.layers.20.attention.k_proj.weight", "wav2vec2.encoder.layers.0.feed_forward.output_dense.weight",
+             "wav2vec2.feature_projection.projection.weight"]
+    Pr = dict(P)
+    for n in names:
+        Pr[n] = P[n].clone().requires_grad_(True)
+    loss_ref, logits_ref, _ = ref.forward_loss(iv, am, labels, Pr, cfg)
+    loss_ref.backward()
+    logits_ref = logits_ref.detach()
+    err = float((logits - logits_ref).abs().max())
+    cos = _cos(logits, logits_ref)
+    rel = abs(float(out.loss) - float(loss_ref)) / abs(float(loss_ref))
+    print(f"\nXLS-R-1B (48 L, d 1280, hd 80), 1 x 7 s: logits max-abs err {err:.4f} (mean |logit| "
+          f"{float(logits_ref.abs().mean()):.3f}), cosine {cos:.6f}, CTC loss rel {rel:.2e}")
+    assert torch.isfinite(logits).all()
+    assert err <= 8e-2 and cos >= 0.999, (err, cos)
+    assert rel <= 2e-3, rel
+    ids, _ = eng.greedy_decode()
+    assert ids == ref.greedy_ctc_ids(logits.numpy(), cfg.pad_token_id)
+    top2 = logits_ref.topk(2, dim=-1).values
+    decided = (top2[..., 0] - top2[..., 1]) > 2 * err
+    assert (logits.argmax(-1)[decided] == logits_ref.argmax(-1)[decided]).all()
+    gd = eng.grad_dict()
+    for n in names:
+        a, b = gd[n].float().cpu(), Pr[n].grad
+        ratio, c = float(a.norm() / b.norm()), _cos(a, b)
+        print(f"  grad {n}: norm ratio {ratio:.4f}, cosine {c:.5f}")
+        assert 0.95 <= ratio <= 1.05 and c >= 0.97, (n, ratio, c)
+    del eng
+    torch.cuda.empty_cache()
+
+
 def test_whisper_medium_full_depth_one_clip_against_the_oracle():
     from coral_amd.whisper import CORAL_WHISPER_SHAPES, WhisperEngine, WhisperShape
     from oracle import whisper_ref as w
