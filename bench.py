@@ -223,6 +223,34 @@ def whisper_decode_bytes_per_token(eng, shape, B) -> float:
     return float(w + kv)
 
 
+def check_replicas(eng, trainer, rank, extra=None):
+    """DDP invariant after the run: every rank holds identical parameters AND identical optimiser state.  With the
+    sharded optimiser the fp32 master and the moments of a slice live on the owning rank between steps, so they are
+    gathered first (`consolidate()`, a collective); the bf16 compute copy - what the forward reads, all-gathered every
+    step - must agree as it stands, and must be the bf16 rounding of the gathered master."""
+    torch.cuda.synchronize()
+    st = eng.store
+    m, v = trainer.consolidate() if trainer is not None else (None, None)
+    spreads = {}
+    for name, t in (("p32", st.p32), ("p16", st.p16.float()), ("m", m), ("v", v)):
+        if t is None:
+            continue
+        lo, hi = t.clone(), t.clone()
+        torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
+        torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
+        spreads[name] = float((hi - lo).abs().max())
+        del lo, hi
+    if trainer is not None and getattr(trainer, "zero", False):
+        # the sharded ranges of the compute copy against the gathered master (catches a stale or misplaced slice)
+        worst = 0.0
+        for name, (mlo, bhi) in trainer.sync.shard.items():
+            worst = max(worst, float((st.p32[mlo:bhi].to(torch.bfloat16).float() - st.p16[mlo:bhi].float()).abs().max()))
+        spreads["p16_vs_master"] = worst
+    if rank == 0:
+        print(json.dumps({"replica_param_spread": spreads["p32"], "replica_spreads": spreads, **(extra or {})}), flush=True)
+    assert all(x == 0.0 for x in spreads.values()), f"replicas diverged: {spreads}"
+
+
 def whisper_measure(model, args, world, rank, device, decode=False, fp8=False, B=None, steps=None, warmup=None):
     """One Whisper workload: teacher-forced finetune step on 30 s clips (log-mel on the GPU inside the step) or greedy
     decoding (`decode`).  -> dict(ms_per_step, value, ...) on every rank."""
@@ -264,7 +292,7 @@ def whisper_measure(model, args, world, rank, device, decode=False, fp8=False, B
         step()
     dt = timed(steps)
     res = dict(ms_per_step=dt * 1e3, value=world * B * 30.0 / dt, B=B, label_len=int(labels.shape[1]),
-               dropout=eng.dropout, activation_dropout=eng.activation_dropout, engine=eng, shape=shape)
+               dropout=eng.dropout, activation_dropout=eng.activation_dropout, engine=eng, shape=shape, trainer=trainer)
     if decode:
         # the per-token time without the log-mel + encoder part: (T(n2 new tokens) - T(n1 new tokens)) / (n2 - n1)
         n1, n2 = 8, 8 + args.decode_tokens
@@ -302,17 +330,7 @@ def whisper_bench(args, world, rank, device):
             "data": "synthetic", "config": cfg}), flush=True)
     if world > 1:
         if args.check_replicas and not args.decode:
-            torch.cuda.synchronize()
-            # (sharded optimiser: the fp32 master is complete only on the owning rank between steps; the bf16 compute copy,
-            # all-gathered every step, is what every rank must agree on)
-            p = eng.store.p16.float() if args.zero_stage else eng.store.p32
-            lo, hi = p.clone(), p.clone()
-            torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
-            torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
-            spread = float((hi - lo).abs().max())
-            if rank == 0:
-                print(json.dumps({"replica_param_spread": spread}), flush=True)
-            assert spread == 0.0, f"replicas diverged: {spread}"
+            check_replicas(eng, r["trainer"], rank)
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 
@@ -382,7 +400,7 @@ def run_w2v2(model_key, args, world, rank, device, roofline: bool):
     secs = torch.tensor([float(lens.sum()) / 16000.0], dtype=torch.float64, device=device)  # real (unpadded) audio
     if world > 1:
         torch.distributed.all_reduce(secs)
-    res = dict(engine=eng, shape=shape, B=B, T=T, loss=float(loss), ms_per_step=dt / args.steps * 1e3,
+    res = dict(engine=eng, trainer=trainer, shape=shape, B=B, T=T, loss=float(loss), ms_per_step=dt / args.steps * 1e3,
                value=round(float(secs.item()) * args.steps / dt, 2),
                step_tflop=3.0 * fwd_gflop_per_utt(shape, T, Ts) * B / 1e3)
     if world == 1 and roofline and not args.no_fwd_bwd:
@@ -443,7 +461,8 @@ def run_w2v2(model_key, args, world, rank, device, roofline: bool):
                           f"{r['flops'] / (r['ms'] * 1e-3) / 1e12:7.1f} TFLOP/s", file=sys.stderr)
     trainer.finish()
     torch.cuda.synchronize()
-    res["trainer"] = None
+    if world == 1:
+        res["trainer"] = None  # (N = 1: nothing to check afterwards; the moments' memory goes back before the next workload)
     return res
 
 
@@ -524,7 +543,7 @@ def main():
         return whisper_bench(args, world, rank, device)
 
     res = run_w2v2(args.model, args, world, rank, device, roofline=True)
-    eng, loss_val = res.pop("engine"), res["loss"]
+    eng, loss_val, trainer_ = res.pop("engine"), res["loss"], res.pop("trainer")
     if rank == 0:
         shape, B, T = res["shape"], res["B"], res["T"]
         dom, prof = res["dom"], res["prof"]
@@ -547,7 +566,8 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(step_ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
             "data": "synthetic",
-            "rccl_ranks": torch.distributed.get_world_size() if world > 1 else 1,
+            "rccl_ranks": torch.distributed.get_world_size() if (world > 1 and args.backend == "nccl") else 1,
+            "backend": (args.backend if world > 1 else None), "ranks": world,
             "grad_wire": args.grad_wire if world > 1 else None,
             "config": {"workload": f"{args.model} (XLS-R shape d={shape.hidden_size} L={shape.num_hidden_layers} "
                                    f"ffn={shape.intermediate_size}) CTC finetune, {B} x {args.seconds:g} s per GPU"
@@ -630,17 +650,8 @@ def main():
     if world > 1:
         if args.check_replicas:
             # DDP invariant: identical parameters on every rank after identical (averaged) updates
-            # (sharded optimiser: the fp32 master is complete only on the owning rank between steps; the bf16 compute copy,
-            # all-gathered every step, is what every rank must agree on)
-            torch.cuda.synchronize()
-            p = eng.store.p16.float() if args.zero_stage else eng.store.p32
-            lo, hi = p.clone(), p.clone()
-            torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
-            torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
-            spread = float((hi - lo).abs().max())
-            if rank == 0:
-                print(json.dumps({"replica_param_spread": spread, "loss_rank0": loss_val}), flush=True)
-            assert spread == 0.0, f"replicas diverged: {spread}"
+            # (parameters, bf16 compute copy and AdamW moments; the sharded optimiser's slices are gathered first)
+            check_replicas(eng, trainer_, rank, extra={"loss_rank0": loss_val})
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
     elif torch.distributed.is_initialized():  # --one-rank-exchange

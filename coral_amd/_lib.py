@@ -111,6 +111,11 @@ SIGNATURES = {
     "ca_attn_bwd": (C.c_int, [C.POINTER(CaAttnDesc), _vp]),
     "ca_decode_attn_qproj": (C.c_int, [C.POINTER(CaAttnDesc), _vp, _i64, _vp, _vp, _f32, _vp, _i64, _vp, _i32, _vp]),
     "ca_layernorm_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _i32, _vp]),
+    "ca_layernorm_fwd_ex": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _i32, _i32, _i32, _vp]),
+    "ca_layernorm_bwd_ex": (
+        C.c_int,
+        [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp],
+    ),
     "ca_layernorm_fwd_fp8": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp]),
     "ca_layernorm_bwd_partial_floats": (_i64, [_i64, _i32]),
     "ca_layernorm_bwd": (
@@ -181,6 +186,17 @@ SIGNATURES = {
     "ca_argmax_masked": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i64, _vp]),
     "ca_embed_tokens": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
     "ca_embed_tokens_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
+    "ca_comm_unique_id": (C.c_int, [_vp]),
+    "ca_comm_init": (C.c_int, [C.POINTER(_vp), _vp, _i32, _i32]),
+    "ca_comm_destroy": (C.c_int, [_vp]),
+    "ca_comm_stream": (_vp, [_vp]),
+    "ca_comm_rank": (C.c_int, [_vp]),
+    "ca_comm_world": (C.c_int, [_vp]),
+    "ca_comm_after": (C.c_int, [_vp, _vp]),
+    "ca_comm_before": (C.c_int, [_vp, _vp]),
+    "ca_allreduce_bucket": (C.c_int, [_vp, _vp, _i64, _i32]),
+    "ca_reduce_scatter_bucket": (C.c_int, [_vp, _vp, _i64, _i32]),
+    "ca_allgather_bucket": (C.c_int, [_vp, _vp, _i64, _i32]),
 }
 
 _lib = None

@@ -170,16 +170,18 @@ class CoralTrainer:
 
             aug = DeviceAugment(self.engine.device, sr, seed=int(getattr(a, "seed", 4242)) + 17 * int(os.getenv("RANK", "0") or 0),
                                 background_noises=getattr(a, "background_noises", None))
+        # the reference's augmentation chain itself starts with PeakNormalization(p=1) (R/src/coral/data.py:709-711):
+        # augmented training audio is peak-normalised also when normalise_audio is off
+        peak = bool(getattr(a, "normalise_audio", True)) or aug is not None
         if self.is_seq2seq:
             from .whisper import N_SAMPLES
 
             return DeviceInputPipeline(self.engine.device, B, N_SAMPLES, kind="whisper", dtype=np.float32,
-                                       peak_normalize=bool(getattr(a, "normalise_audio", True)),
-                                       mel_filters=self.engine.mel_filters, augment=aug)
+                                       peak_normalize=peak, mel_filters=self.engine.mel_filters, augment=aug)
         n_max = int(sr * float(getattr(a, "max_seconds_per_example", 10.0)))
         return DeviceInputPipeline(self.engine.device, B, n_max, kind="wav2vec2", dtype=np.float32,
                                    padding=getattr(a, "padding", "longest") or "longest",
-                                   peak_normalize=bool(getattr(a, "normalise_audio", True)), augment=aug)
+                                   peak_normalize=peak, augment=aug)
 
     def _pull(self, B: int):
         """B examples of the training stream, or None when the pass ran dry on some rank (`dataloader_drop_last`)."""
@@ -235,9 +237,42 @@ class CoralTrainer:
 
     # ---- checkpoints ----------------------------------------------------------------------------------------------
     def save_model(self, output_dir=None):
+        """`Trainer.save_model`.  With the sharded optimiser this is a COLLECTIVE: between steps the fp32 master of the
+        other ranks' slices is stale on this rank (only the bf16 copy is all-gathered), so every rank must call it - the
+        masters are gathered first (`DataParallelTrainer.consolidate`), then the main process writes."""
         self.finish()
+        if self.dp.zero:
+            self.dp.consolidate()
         torch.cuda.synchronize()
-        self.model.save_pretrained(output_dir or self.args.output_dir)
+        if self.is_main or not self.dp.zero:
+            self.model.save_pretrained(output_dir or self.args.output_dir)
+
+    def _moment_layout(self) -> str:
+        """Fingerprint of the flat parameter layout the moment buffers follow: (name, offset, shape) of every tensor.
+        `optimizer.safetensors` holds m and v as raw flat buffers; a file written under another layout has the same
+        length and would attach moments to the wrong parameters."""
+        import hashlib
+
+        idx = self.engine.store.index
+        text = ";".join(f"{n}@{off}:{'x'.join(map(str, shp))}" for n, (off, shp) in idx.items())
+        return hashlib.sha256(text.encode()).hexdigest()[:32]
+
+    def _rng_state(self) -> dict:
+        """Host RNG streams the training step draws from: SpecAugment spans and LayerDrop decisions (the wav2vec2
+        wrapper's own RandomState; np.random / torch's CPU generator for Whisper, as in HF) - Trainer keeps them in
+        rng_state.pth so that a resumed run continues the interrupted one's mask sequence ($TF/trainer.py _save_rng_state)."""
+        st = dict(numpy=np.random.get_state(), torch_cpu=torch.get_rng_state())
+        rng = getattr(self.model, "_rng", None)
+        if isinstance(rng, np.random.RandomState):
+            st["wrapper"] = rng.get_state()
+        return st
+
+    def _set_rng_state(self, st: dict):
+        np.random.set_state(st["numpy"])
+        torch.set_rng_state(st["torch_cpu"])
+        rng = getattr(self.model, "_rng", None)
+        if "wrapper" in st and isinstance(rng, np.random.RandomState):
+            rng.set_state(st["wrapper"])
 
     def _save_checkpoint(self, step: int, moments=None) -> Path:
         """`checkpoint-<step>/`: the model in HF layout, the optimiser moments and the trainer state
@@ -252,7 +287,8 @@ class CoralTrainer:
         torch.cuda.synchronize()
         self.model.save_pretrained(d)
         m, v = moments if moments is not None else (self.dp.m, self.dp.v)
-        save_file(dict(m=m.cpu(), v=v.cpu()), str(d / "optimizer.safetensors"))
+        save_file(dict(m=m.cpu(), v=v.cpu()), str(d / "optimizer.safetensors"), metadata={"layout": self._moment_layout()})
+        torch.save(self._rng_state(), str(d / f"rng_state_{int(os.getenv('RANK', '0') or 0)}.pth"))
         st = {k: self.state[k] for k in ("epoch", "best_metric", "best_step", "bad_evals")}
         (d / "trainer_state.json").write_text(json.dumps(dict(global_step=step, **st), indent=1))
         limit = self.args.save_total_limit
@@ -284,8 +320,24 @@ class CoralTrainer:
                 raise KeyError(f"{ckpt}: checkpoint lacks {rep['missing']}")
         if hasattr(eng, "refresh_derived"):
             eng.refresh_derived()
-        opt = load_file(str(ckpt / "optimizer.safetensors"))
-        self.dp.load_moments(opt["m"].to(self.dp.m.device), opt["v"].to(self.dp.v.device))
+        from safetensors import safe_open
+
+        with safe_open(str(ckpt / "optimizer.safetensors"), "pt") as f:
+            layout = (f.metadata() or {}).get("layout")
+        if layout is not None and layout != self._moment_layout():
+            raise ValueError(f"{ckpt}/optimizer.safetensors was written under another flat parameter layout "
+                             f"({layout} != {self._moment_layout()}): its AdamW moments would land on the wrong parameters")
+        if layout is None:
+            # (a file from before the layout tag: its order cannot be verified - restart the moments rather than risk
+            # attaching them to other parameters)
+            logger.warning("%s/optimizer.safetensors carries no layout tag: AdamW moments restart from zero", ckpt)
+            self.dp.m.zero_()
+            self.dp.v.zero_()
+        else:
+            opt = load_file(str(ckpt / "optimizer.safetensors"))
+            self.dp.load_moments(opt["m"].to(self.dp.m.device), opt["v"].to(self.dp.v.device))
+        rng_file = ckpt / f"rng_state_{int(os.getenv('RANK', '0') or 0)}.pth"
+        self._resumed_rng = torch.load(str(rng_file), weights_only=False) if rng_file.exists() else None
         state = json.loads((ckpt / "trainer_state.json").read_text())
         self.dp.opt_step = int(state["global_step"])
         return state
@@ -351,6 +403,10 @@ class CoralTrainer:
             # augmentation draws then fall exactly where they fell in the first run
             for _ in range(start_step * accum):
                 self.next_micro_batch()
+        if start_step and getattr(self, "_resumed_rng", None) is not None:
+            # the SpecAugment / LayerDrop streams continue where the interrupted run left them (HF restores rng_state.pth)
+            self._set_rng_state(self._resumed_rng)
+            self._resumed_rng = None
         t0 = time.time()
         step = start_step - 1
         loss_sum, loss_n = 0.0, 0

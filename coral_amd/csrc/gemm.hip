@@ -1646,255 +1646,6 @@ __global__ __launch_bounds__(512) void ca_gemm_kernel_l(const CaGemmDesc d) {
   gemm_epilogue(d, acc, smem, wave, lane, m0 + wm * 64, n0 + wn * 64, z, z1, z2, &lbias);
 }
 
-// ---- kernel W: 256x256 tile, 4 waves (2x2, 128x128 each), ONE wave per SIMD, 2 LDS stages -------------------------
-// The structure DESIGN.md §6a named as the remaining lever for kernel X: each wave owns a 128 x 128 output block (256
-// accumulator registers of the 512 a lone wave of a SIMD may hold), so a K-step reads 128 KiB of fragments from LDS per
-// CU instead of X's 192 KiB, no two waves share a matrix pipe, and the one barrier per K-step joins 4 waves, not 8.
-// Per K-step and wave: 128 MFMAs in two halves (k-half 0, k-half 1); the 16 fragment reads of the next half go out
-// one per group of 4 MFMAs; the barrier sits between the halves (tile kt+1 has landed, every wave is done reading tile
-// kt); behind it the wave issues its 16 LDS-DMA pieces of tile kt+2 into the freed stage, again one per 4 MFMAs, so the
-// pieces have the whole following half to land.  LDS: A0 | A1 | B0 | B1 as in kernel X.
-template <int AL, int BL>
-__global__ __launch_bounds__(256) void ca_gemm_kernel_w(const CaGemmDesc d) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  int tm, tn;
-  if (!tile_of_block<4, 8>(blockIdx.x, (d.M + XBM - 1) / XBM, (d.N + XBN - 1) / XBN, tm, tn)) return;
-  const int m0 = tm * XBM, n0 = tn * XBN;
-  const int z = blockIdx.z;
-  const int z1 = z / d.batch2, z2 = z % d.batch2;
-  const __bf16* A = (const __bf16*)d.A + z1 * d.sA1 + z2 * d.sA2;
-  const __bf16* B = (const __bf16*)d.B + z1 * d.sB1 + z2 * d.sB2;
-  const int K = d.K;
-  const int nk = (K + BK - 1) / BK;
-
-  KMajorStream<8> la_k, lb_k;
-  MNMajorStream<8, 32> la_f, lb_f;
-  if (AL == CA_KMAJOR)
-    la_k.init(A, d.lda, m0, d.M, wave, lane);
-  else
-    la_f.init(A, d.lda, m0, d.M, wave, lane);
-  if (BL == CA_KMAJOR)
-    lb_k.init(B, d.ldb, n0, d.N, wave, lane);
-  else
-    lb_f.init(B, d.ldb, n0, d.N, wave, lane);
-
-  f32x4_t acc[8][8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-
-  // piece P (0..7: A, 8..15: B) of this wave's share of tile kt.  FULL: the caller guarantees kt < nk and a whole
-  // K-step (the main loop: no condition, no predicate), else the general form
-  auto piece = [&](auto p_c, auto full_c, int kt) {
-    constexpr int P = decltype(p_c)::value;
-    constexpr bool FULL = decltype(full_c)::value;
-    if (!FULL && kt >= nk) return;
-    char* na = smem + (kt & 1) * XTILE;
-    char* nb = na + 2 * XTILE;
-    const bool full = FULL || (kt + 1) * BK <= K;  // wave-uniform
-    if (P < 8) {
-      if (AL == CA_KMAJOR) {
-        if (full) la_k.issue_one(na, wave, P); else la_k.issue_one_tail(na, wave, K - kt * BK, P);
-        if (P == 7) la_k.advance();
-      } else {
-        if (full) la_f.issue_one(na, wave, P); else la_f.issue_one_tail(na, wave, lane, K - kt * BK, P);
-        if (P == 7) la_f.advance();
-      }
-    } else {
-      if (BL == CA_KMAJOR) {
-        if (full) lb_k.issue_one(nb, wave, P - 8); else lb_k.issue_one_tail(nb, wave, K - kt * BK, P - 8);
-        if (P == 15) lb_k.advance();
-      } else {
-        if (full) lb_f.issue_one(nb, wave, P - 8); else lb_f.issue_one_tail(nb, wave, lane, K - kt * BK, P - 8);
-        if (P == 15) lb_f.advance();
-      }
-    }
-  };
-  auto burst_all = [&](int kt) {
-#define W_PG(N) piece(std::integral_constant<int, N>{}, std::false_type{}, kt)
-    W_PG(0); W_PG(8); W_PG(1); W_PG(9); W_PG(2); W_PG(10); W_PG(3); W_PG(11);
-    W_PG(4); W_PG(12); W_PG(5); W_PG(13); W_PG(6); W_PG(14); W_PG(7); W_PG(15);
-#undef W_PG
-  };
-  auto zero_tail = [&](int kt) {
-    if (kt != nk - 1 || nk * BK == K) return;
-    char* na = smem + (kt & 1) * XTILE;
-    char* nb = na + 2 * XTILE;
-    const int krem = K - kt * BK;
-    if (AL == CA_KMAJOR) la_k.zero_fix(na, wave, lane, krem); else la_f.zero_fix(na, wave, lane, krem);
-    if (BL == CA_KMAJOR) lb_k.zero_fix(nb, wave, lane, krem); else lb_f.zero_fix(nb, wave, lane, krem);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  };
-  const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
-  uint32_t abase[8], bbase[8];  // K-major: [0], [1] = k-half 0, 1; MN-major: one per fragment
-  if (AL == CA_KMAJOR) {
-    const int r = wm * 128 + (lane & 15);
-#pragma unroll
-    for (int sh = 0; sh < 2; ++sh) abase[sh] = lds0 + r * 128 + (((4 * sh + (lane >> 4)) ^ ((r >> 1) & 7)) * 16);
-  } else {
-    const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
-    const int swz = q | ((g & 1) << 2);
-#pragma unroll
-    for (int f = 0; f < 8; ++f) {
-      const int c = ((((wm * 128 + f * 16) >> 3) + (pp >> 1)) ^ (swz << 1));
-      abase[f] = lds0 + (8 * g + q) * 512 + c * 16 + (pp & 1) * 8;
-    }
-  }
-  if (BL == CA_KMAJOR) {
-    const int r = wn * 128 + (lane & 15);
-#pragma unroll
-    for (int sh = 0; sh < 2; ++sh)
-      bbase[sh] = lds0 + 2 * XTILE + r * 128 + (((4 * sh + (lane >> 4)) ^ ((r >> 1) & 7)) * 16);
-  } else {
-    const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
-    const int swz = q | ((g & 1) << 2);
-#pragma unroll
-    for (int f = 0; f < 8; ++f) {
-      const int c = ((((wn * 128 + f * 16) >> 3) + (pp >> 1)) ^ (swz << 1));
-      bbase[f] = lds0 + 2 * XTILE + (8 * g + q) * 512 + c * 16 + (pp & 1) * 8;
-    }
-  }
-  bf16x8_t A0[8], A1[8], B0[8], B1[8];
-#define W_RD_A(ST, SH, F, dst)                                                            \
-  do {                                                                                    \
-    if (AL == CA_KMAJOR)                                                                  \
-      dst = lds_read_b128<(ST) * XTILE + (F) * 2048>(abase[SH]);                          \
-    else                                                                                  \
-      dst = lds_read_tr<(ST) * XTILE + (SH) * 16384, 2048>(abase[F]);                     \
-  } while (0)
-#define W_RD_B(ST, SH, F, dst)                                                            \
-  do {                                                                                    \
-    if (BL == CA_KMAJOR)                                                                  \
-      dst = lds_read_b128<(ST) * XTILE + (F) * 2048>(bbase[SH]);                          \
-    else                                                                                  \
-      dst = lds_read_tr<(ST) * XTILE + (SH) * 16384, 2048>(bbase[F]);                     \
-  } while (0)
-#define W_SB __builtin_amdgcn_sched_barrier(0)
-  // The MFMAs are inline asm with the accumulator tied to an AGPR ("+a", in place): with all 256 AGPRs holding
-  // accumulators hipcc's own allocation of the builtin copied accumulators around and spilled them inside the loop.
-  // (Hazards the compiler cannot see inside an asm string: an accumulator is touched again 64 MFMAs later, and the
-  // first read of the accumulators after the loop sits behind a barrier and an explicit s_nop.)
-  // (fragment rows 0..6 accumulate in AGPRs, row 7 in arch VGPRs: with all 256 AGPRs pinned the allocator has no
-  // temporary for the loop's copies and sends accumulators through scratch memory)
-#define W_MM1(AF, BF, I, J)                                                                                        \
-  do {                                                                                                             \
-    if constexpr ((I) < 7)                                                                                         \
-      asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[I][J]) : "v"(BF[J]), "v"(AF[I]));          \
-    else                                                                                                           \
-      asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[I][J]) : "v"(BF[J]), "v"(AF[I]));          \
-  } while (0)
-#define W_MM4(AF, BF, I, J)       \
-  do {                            \
-    W_MM1(AF, BF, I, J);          \
-    W_MM1(AF, BF, I, (J) + 1);    \
-    W_MM1(AF, BF, I, (J) + 2);    \
-    W_MM1(AF, BF, I, (J) + 3);    \
-    W_SB;                         \
-  } while (0)
-  auto wait8 = [&](bf16x8_t (&f)[8]) {
-    asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]));
-  };
-#define W_P(N) piece(std::integral_constant<int, N>{}, full_c, kt + 2)
-  auto kstep = [&](auto st_c, auto full_c, int kt) {
-    constexpr int ST = decltype(st_c)::value;
-    constexpr bool FULL = decltype(full_c)::value;
-    // half 0: k-half 0 of tile kt; reads k-half 1 (same stage)
-    wait8(B0);
-    wait8(A0);
-    W_SB;
-    W_MM4(A0, B0, 0, 0); W_RD_B(ST, 1, 0, B1[0]); W_SB;
-    W_MM4(A0, B0, 0, 4); W_RD_B(ST, 1, 1, B1[1]); W_SB;
-    W_MM4(A0, B0, 1, 0); W_RD_B(ST, 1, 2, B1[2]); W_SB;
-    W_MM4(A0, B0, 1, 4); W_RD_B(ST, 1, 3, B1[3]); W_SB;
-    W_MM4(A0, B0, 2, 0); W_RD_B(ST, 1, 4, B1[4]); W_SB;
-    W_MM4(A0, B0, 2, 4); W_RD_B(ST, 1, 5, B1[5]); W_SB;
-    W_MM4(A0, B0, 3, 0); W_RD_B(ST, 1, 6, B1[6]); W_SB;
-    W_MM4(A0, B0, 3, 4); W_RD_B(ST, 1, 7, B1[7]); W_SB;
-    W_MM4(A0, B0, 4, 0); W_RD_A(ST, 1, 0, A1[0]); W_SB;
-    W_MM4(A0, B0, 4, 4); W_RD_A(ST, 1, 1, A1[1]); W_SB;
-    W_MM4(A0, B0, 5, 0); W_RD_A(ST, 1, 2, A1[2]); W_SB;
-    W_MM4(A0, B0, 5, 4); W_RD_A(ST, 1, 3, A1[3]); W_SB;
-    W_MM4(A0, B0, 6, 0); W_RD_A(ST, 1, 4, A1[4]); W_SB;
-    W_MM4(A0, B0, 6, 4); W_RD_A(ST, 1, 5, A1[5]); W_SB;
-    W_MM4(A0, B0, 7, 0); W_RD_A(ST, 1, 6, A1[6]); W_SB;
-    W_MM4(A0, B0, 7, 4); W_RD_A(ST, 1, 7, A1[7]); W_SB;
-    wait8(B1);
-    wait8(A1);  // the last fragment reads of tile kt have returned
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of tile kt+1 has landed
-    if (!FULL) zero_tail(kt + 1);
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    W_SB;
-    // half 1: k-half 1 of tile kt; reads k-half 0 of tile kt+1 (stage 1 - ST; harmless stale data after the last tile);
-    // LDS-DMA of tile kt+2 into stage ST, which every wave has finished reading
-    W_MM4(A1, B1, 0, 0); W_RD_B(1 - ST, 0, 0, B0[0]); W_P(0); W_SB;
-    W_MM4(A1, B1, 0, 4); W_RD_B(1 - ST, 0, 1, B0[1]); W_P(8); W_SB;
-    W_MM4(A1, B1, 1, 0); W_RD_B(1 - ST, 0, 2, B0[2]); W_P(1); W_SB;
-    W_MM4(A1, B1, 1, 4); W_RD_B(1 - ST, 0, 3, B0[3]); W_P(9); W_SB;
-    W_MM4(A1, B1, 2, 0); W_RD_B(1 - ST, 0, 4, B0[4]); W_P(2); W_SB;
-    W_MM4(A1, B1, 2, 4); W_RD_B(1 - ST, 0, 5, B0[5]); W_P(10); W_SB;
-    W_MM4(A1, B1, 3, 0); W_RD_B(1 - ST, 0, 6, B0[6]); W_P(3); W_SB;
-    W_MM4(A1, B1, 3, 4); W_RD_B(1 - ST, 0, 7, B0[7]); W_P(11); W_SB;
-    W_MM4(A1, B1, 4, 0); W_RD_A(1 - ST, 0, 0, A0[0]); W_P(4); W_SB;
-    W_MM4(A1, B1, 4, 4); W_RD_A(1 - ST, 0, 1, A0[1]); W_P(12); W_SB;
-    W_MM4(A1, B1, 5, 0); W_RD_A(1 - ST, 0, 2, A0[2]); W_P(5); W_SB;
-    W_MM4(A1, B1, 5, 4); W_RD_A(1 - ST, 0, 3, A0[3]); W_P(13); W_SB;
-    W_MM4(A1, B1, 6, 0); W_RD_A(1 - ST, 0, 4, A0[4]); W_P(6); W_SB;
-    W_MM4(A1, B1, 6, 4); W_RD_A(1 - ST, 0, 5, A0[5]); W_P(14); W_SB;
-    W_MM4(A1, B1, 7, 0); W_RD_A(1 - ST, 0, 6, A0[6]); W_P(7); W_SB;
-    W_MM4(A1, B1, 7, 4); W_RD_A(1 - ST, 0, 7, A0[7]); W_P(15); W_SB;
-  };
-  burst_all(0);
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  zero_tail(0);
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  W_RD_B(0, 0, 0, B0[0]); W_RD_B(0, 0, 1, B0[1]); W_RD_B(0, 0, 2, B0[2]); W_RD_B(0, 0, 3, B0[3]);
-  W_RD_B(0, 0, 4, B0[4]); W_RD_B(0, 0, 5, B0[5]); W_RD_B(0, 0, 6, B0[6]); W_RD_B(0, 0, 7, B0[7]);
-  W_RD_A(0, 0, 0, A0[0]); W_RD_A(0, 0, 1, A0[1]); W_RD_A(0, 0, 2, A0[2]); W_RD_A(0, 0, 3, A0[3]);
-  W_RD_A(0, 0, 4, A0[4]); W_RD_A(0, 0, 5, A0[5]); W_RD_A(0, 0, 6, A0[6]); W_RD_A(0, 0, 7, A0[7]);
-  burst_all(1);
-  // main loop: pairs of K-steps whose prefetched tiles (kt + 2, kt + 3) are whole K-steps - no condition anywhere;
-  // the last K-steps (and a partial one) run the general form
-  const int nfull = K / BK;
-  int kt = 0;
-  for (; kt + 3 < nfull; kt += 2) {
-    kstep(std::integral_constant<int, 0>{}, std::true_type{}, kt);
-    kstep(std::integral_constant<int, 1>{}, std::true_type{}, kt + 1);
-  }
-  for (; kt < nk; kt += 2) {
-    kstep(std::integral_constant<int, 0>{}, std::false_type{}, kt);
-    if (kt + 1 < nk) kstep(std::integral_constant<int, 1>{}, std::false_type{}, kt + 1);
-  }
-#undef W_P
-#undef W_RD_A
-#undef W_RD_B
-#undef W_MM4
-#undef W_MM1
-#undef W_SB
-  asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_waitcnt lgkmcnt(0) vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  // four 64 x 64 quadrants through the shared epilogue (each wave re-uses its own staging region)
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int ih = q >> 1, jh = q & 1;
-    f32x4_t quad[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) quad[i][j] = acc[ih * 4 + i][jh * 4 + j];
-    gemm_epilogue(d, quad, smem, wave, lane, m0 + wm * 128 + ih * 64, n0 + wn * 128 + jh * 64, z, z1, z2);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // staging reads done before it is overwritten
-  }
-}
-
 // ---- skinny-M kernel: M <= 32 rows (one decoded token per clip) -------------------------------------
 // C[m, n] = epilogue(alpha * sum_k A[m, k] W[n, k]): a weight-streaming problem (every weight byte is used once),
 // so there is no LDS staging: each wave owns 16 output columns and a quarter of K, loads its W fragment
@@ -2595,26 +2346,6 @@ static int ca_gemm_launch(const CaGemmDesc* desc, void* stream) {
     use_x = 0;
   }
   g_last_kind = use_x ? 2 : (use_l ? 1 : 0);
-  static const int prefer_w = [] { const char* e = getenv("CA_GEMM_W"); return e ? atoi(e) : 0; }();
-  if ((g_force_kernel == 4 || (prefer_w && use_x)) && d.a_kseg == 0 && d.b_kseg == 0 && !d.a_colsum) {
-    static bool wattr = false;
-    if (!wattr) {
-      const void* fs[4] = {(const void*)ca_gemm_kernel_w<0, 0>, (const void*)ca_gemm_kernel_w<0, 1>,
-                           (const void*)ca_gemm_kernel_w<1, 0>, (const void*)ca_gemm_kernel_w<1, 1>};
-      for (int i = 0; i < 4; ++i) hipFuncSetAttribute(fs[i], hipFuncAttributeMaxDynamicSharedMemorySize, X_LDS_BYTES);
-      wattr = true;
-    }
-    g_last_kind = 2;
-    dim3 grid(tile_grid<4, 8>(xtm, xtn), 1, (unsigned)nb), block(256);
-    switch (lay) {
-      case 0: CA_LAUNCH((ca_gemm_kernel_w<0, 0>), grid, block, X_LDS_BYTES, s, d); break;
-      case 1: CA_LAUNCH((ca_gemm_kernel_w<0, 1>), grid, block, X_LDS_BYTES, s, d); break;
-      case 2: CA_LAUNCH((ca_gemm_kernel_w<1, 0>), grid, block, X_LDS_BYTES, s, d); break;
-      default: CA_LAUNCH((ca_gemm_kernel_w<1, 1>), grid, block, X_LDS_BYTES, s, d); break;
-    }
-    CA_CHECK_LAUNCH("ca_gemm_bf16");
-    return CA_OK;
-  }
   if (use_x) {
     static bool xattr = false;
     const bool ks = d.a_kseg > 0 || d.b_kseg > 0;

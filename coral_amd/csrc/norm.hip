@@ -7,18 +7,44 @@
 
 #define LN_MAXCH 8  // up to 8 chunks of 8 elements per lane -> C <= 4096
 
-template <int NCH>
-__global__ __launch_bounds__(256) void ln_fwd_kernel(const unsigned short* __restrict__ x,
+// A lane's chunk of 8 consecutive row elements, bf16 (one 16-byte load) or fp32 (two): the conv stack's pre-norm
+// tensors and the last conv block's output stay fp32 (ca_layernorm_fwd_ex / ca_layernorm_bwd_ex), as they do under
+// the reference's autocast, where nn.LayerNorm and the GELU behind it run in fp32
+// ($TF/models/wav2vec2/modeling_wav2vec2.py:291-298,429-434).
+template <bool F32>
+struct LnRow;
+template <>
+struct LnRow<false> {
+  typedef u16x8_t V;
+  static __device__ __forceinline__ V load(const void* base, int64_t idx) {
+    return *(const u16x8_t*)((const unsigned short*)base + idx);
+  }
+  static __device__ __forceinline__ V zero() { return (u16x8_t){0, 0, 0, 0, 0, 0, 0, 0}; }
+  static __device__ __forceinline__ float at(const V& v, int e) { return bf2f(v[e]); }
+};
+typedef __attribute__((ext_vector_type(8))) float f32x8_t;
+template <>
+struct LnRow<true> {
+  typedef f32x8_t V;
+  static __device__ __forceinline__ V load(const void* base, int64_t idx) {
+    const f32x4_t a = *(const f32x4_t*)((const float*)base + idx), b = *(const f32x4_t*)((const float*)base + idx + 4);
+    return (f32x8_t){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  }
+  static __device__ __forceinline__ V zero() { return (f32x8_t){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; }
+  static __device__ __forceinline__ float at(const V& v, int e) { return v[e]; }
+};
+
+template <int NCH, bool XF32 = false, bool YF32 = false>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const void* __restrict__ x,
                                                      const float* __restrict__ gamma,
                                                      const float* __restrict__ beta,
-                                                     unsigned short* __restrict__ y,
+                                                     void* __restrict__ y,
                                                      float* __restrict__ stats, int64_t rows,
                                                      int C, float eps, int act) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int nchunk = C >> 3;
   for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
-    const unsigned short* xr = x + row * C;
     float v[NCH][8];
     float s = 0.f;
     // short rows (greedy decoding: a handful of rows of d <= 1536): gamma / beta are requested together with the row,
@@ -41,10 +67,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const unsigned short* __res
     for (int c = 0; c < NCH; ++c) {
       const int ch = lane + c * 64;
       if (ch < nchunk) {
-        const u16x8_t u = *(const u16x8_t*)(xr + ch * 8);
+        const typename LnRow<XF32>::V u = LnRow<XF32>::load(x, row * C + ch * 8);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          v[c][e] = bf2f(u[e]);
+          v[c][e] = LnRow<XF32>::at(u, e);
           s += v[c][e];
         }
       } else {
@@ -70,7 +96,6 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const unsigned short* __res
       stats[row * 2] = mean;
       stats[row * 2 + 1] = rstd;
     }
-    unsigned short* yr = y + row * C;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const int ch = lane + c * 64;
@@ -87,16 +112,25 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const unsigned short* __res
           b0 = *(const f32x4_t*)(beta + ch * 8);
           b1 = *(const f32x4_t*)(beta + ch * 8 + 4);
         }
-        u16x8_t o;
+        float o32[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const float gm = e < 4 ? g0[e] : g1[e - 4];
           const float bt = e < 4 ? b0[e] : b1[e - 4];
           float u = ln_apply(v[c][e], mean, rstd, gm, bt);
           if (act) u = gelu_erf(u);
-          o[e] = f2bf(u);
+          o32[e] = u;
         }
-        *(u16x8_t*)(yr + ch * 8) = o;
+        if (YF32) {
+          float* yr = (float*)y + row * C + ch * 8;
+          *(f32x4_t*)yr = (f32x4_t){o32[0], o32[1], o32[2], o32[3]};
+          *(f32x4_t*)(yr + 4) = (f32x4_t){o32[4], o32[5], o32[6], o32[7]};
+        } else {
+          u16x8_t o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = f2bf(o32[e]);
+          *(u16x8_t*)((unsigned short*)y + row * C + ch * 8) = o;
+        }
       }
     }
   }
@@ -109,28 +143,43 @@ static int ln_grid(int64_t rows) {
   return (int)g;
 }
 
-extern "C" int ca_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y,
-                                float* stats, int64_t rows, int32_t C, float eps, int32_t act,
-                                void* stream) {
+extern "C" int ca_layernorm_fwd_ex(const void* x, const float* gamma, const float* beta, void* y,
+                                   float* stats, int64_t rows, int32_t C, float eps, int32_t act,
+                                   int32_t x_f32, int32_t y_f32, void* stream) {
   CA_CHECK_ARG(x && gamma && beta && y, "ca_layernorm_fwd: null pointer");
   CA_CHECK_ARG(rows > 0 && C > 0 && (C % 8) == 0 && C <= LN_MAXCH * 512,
                "ca_layernorm_fwd: C=%d must be a multiple of 8 and <= %d", C, LN_MAXCH * 512);
+  CA_CHECK_ARG((!x_f32 && !y_f32) || C <= 1024, "ca_layernorm_fwd_ex: fp32 rows are served up to C = 1024 (C=%d)", C);
   const int nch = (C / 8 + 63) / 64;
   dim3 grid(ln_grid(rows)), block(256);
   hipStream_t s = (hipStream_t)stream;
-#define LN_FWD(N)                                                                            \
-  hipLaunchKernelGGL((ln_fwd_kernel<N>), grid, block, 0, s, (const unsigned short*)x, gamma, \
-                     beta, (unsigned short*)y, stats, rows, C, eps, act)
+#define LN_FWD_(N, XF, YF) \
+  hipLaunchKernelGGL((ln_fwd_kernel<N, XF, YF>), grid, block, 0, s, x, gamma, beta, y, stats, rows, C, eps, act)
+#define LN_FWD_T(N)                                \
+  do {                                             \
+    if (x_f32 && y_f32) LN_FWD_(N, true, true);    \
+    else if (x_f32) LN_FWD_(N, true, false);       \
+    else if (y_f32) LN_FWD_(N, false, true);       \
+    else LN_FWD_(N, false, false);                 \
+  } while (0)
+#define LN_FWD(N) LN_FWD_(N, false, false)
   switch (nch) {
-    case 1: LN_FWD(1); break;
-    case 2: LN_FWD(2); break;
+    case 1: LN_FWD_T(1); break;
+    case 2: LN_FWD_T(2); break;
     case 3: LN_FWD(3); break;
     case 4: LN_FWD(4); break;
     default: LN_FWD(8); break;
   }
 #undef LN_FWD
+#undef LN_FWD_T
+#undef LN_FWD_
   CA_CHECK_LAUNCH("ca_layernorm_fwd");
   return CA_OK;
+}
+extern "C" int ca_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y,
+                                float* stats, int64_t rows, int32_t C, float eps, int32_t act,
+                                void* stream) {
+  return ca_layernorm_fwd_ex(x, gamma, beta, y, stats, rows, C, eps, act, 0, 0, stream);
 }
 
 // ---- forward with the output also quantised to fp8, one scale per row -------------------------------------------
@@ -264,9 +313,9 @@ static int ln_bwd_grid(int64_t rows, int C) {
   return (int)g;
 }
 
-template <int NCH, bool ACT, bool DPP>
+template <int NCH, bool ACT, bool DPP, bool XF32 = false>
 __global__ __launch_bounds__(256, 2) void ln_bwd_kernel(
-    const unsigned short* __restrict__ dy, const unsigned short* __restrict__ x,
+    const unsigned short* __restrict__ dy, const void* __restrict__ x,
     const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ stats, const unsigned short* __restrict__ dres,
     unsigned short* __restrict__ dx, float* __restrict__ partial, int64_t rows, int C) {
@@ -309,17 +358,21 @@ __global__ __launch_bounds__(256, 2) void ln_bwd_kernel(
   // and writes a quarter of the partial sums).
   const int64_t stride = (int64_t)gridDim.x * 4;
   const u16x8_t zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-  u16x8_t cx[NCH], cd[NCH], cr[NCH];
+  typedef LnRow<XF32> XR;
+  typedef typename XR::V xv_t;
+  xv_t cx[NCH];
+  u16x8_t cd[NCH], cr[NCH];
   float cmean = 0.f, crstd = 0.f;
-  auto request = [&](int64_t row, u16x8_t (&ux)[NCH], u16x8_t (&ud)[NCH], float& mean, float& rstd) {
+  auto request = [&](int64_t row, xv_t (&ux)[NCH], u16x8_t (&ud)[NCH], float& mean, float& rstd) {
     mean = stats[row * 2];
     rstd = stats[row * 2 + 1];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const int ch = lane + c * 64;
-      ux[c] = ud[c] = zero8;
+      ux[c] = XR::zero();
+      ud[c] = zero8;
       if (ch < nchunk) {
-        ux[c] = *(const u16x8_t*)(x + row * C + ch * 8);
+        ux[c] = XR::load(x, row * C + ch * 8);
         ud[c] = *(const u16x8_t*)(dy + row * C + ch * 8);
       }
     }
@@ -338,7 +391,8 @@ __global__ __launch_bounds__(256, 2) void ln_bwd_kernel(
       cr[c] = zero8;
       if (dres && ch < nchunk) cr[c] = *(const u16x8_t*)(dres + row * C + ch * 8);
     }
-    u16x8_t nx[PIPE ? NCH : 1], nd[PIPE ? NCH : 1];
+    xv_t nx[PIPE ? NCH : 1];
+    u16x8_t nd[PIPE ? NCH : 1];
     float nmean = 0.f, nrstd = 0.f;
     if constexpr (PIPE) {
       if (nrow < rows) request(nrow, nx, nd, nmean, nrstd);
@@ -352,7 +406,7 @@ __global__ __launch_bounds__(256, 2) void ln_bwd_kernel(
       load_beta(c, b8);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const float h = (bf2f(cx[c][e]) - cmean) * crstd;
+        const float h = (XR::at(cx[c], e) - cmean) * crstd;
         float du = bf2f(cd[c][e]);
         if (ACT) {
           du *= dgelu_erf(h * g8[e] + b8[e]);
@@ -380,7 +434,7 @@ __global__ __launch_bounds__(256, 2) void ln_bwd_kernel(
         load_gamma(c, g8);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const float h = (bf2f(cx[c][e]) - cmean) * crstd;  // recomputed: cheaper than 32 more live registers
+          const float h = (XR::at(cx[c], e) - cmean) * crstd;  // recomputed: cheaper than 32 more live registers
           const float du = ACT ? du_[ACT ? c : 0][e] : bf2f(cd[c][e]);
           o[e] = f2bf(crstd * (du * g8[e] - m1 - h * m2) + bf2f(cr[c][e]));
         }
@@ -500,11 +554,12 @@ extern "C" int64_t ca_layernorm_bwd_partial_floats(int64_t rows, int32_t C) {
   return (int64_t)ln_bwd_grid(rows, C) * 2 * C;
 }
 
-extern "C" int ca_layernorm_bwd(const void* dy, const void* x, const float* gamma,
-                                const float* beta, const float* stats, const void* dres,
-                                void* dx, float* dgamma, float* dbeta, float* partial,
-                                int64_t rows, int32_t C, int32_t act, void* stream) {
+extern "C" int ca_layernorm_bwd_ex(const void* dy, const void* x, const float* gamma,
+                                   const float* beta, const float* stats, const void* dres,
+                                   void* dx, float* dgamma, float* dbeta, float* partial,
+                                   int64_t rows, int32_t C, int32_t act, int32_t x_f32, void* stream) {
   CA_CHECK_ARG(dy && x && gamma && stats && dx && partial, "ca_layernorm_bwd: null pointer");
+  CA_CHECK_ARG(!x_f32 || C <= 1024, "ca_layernorm_bwd_ex: fp32 rows are served up to C = 1024 (C=%d)", C);
   CA_CHECK_ARG(!act || beta, "ca_layernorm_bwd: act needs beta");
   CA_CHECK_ARG(rows > 0 && C > 0 && (C % 8) == 0 && C <= LN_MAXCH * 512,
                "ca_layernorm_bwd: bad C=%d", C);
@@ -513,10 +568,17 @@ extern "C" int ca_layernorm_bwd(const void* dy, const void* x, const float* gamm
   dim3 grid(g), block(256);
   const size_t lds = (size_t)4 * 2 * C * sizeof(float);
   hipStream_t s = (hipStream_t)stream;
-#define LN_BWD_(N, A, D)                                                                       \
-  hipLaunchKernelGGL((ln_bwd_kernel<N, A, D>), grid, block, lds, s, (const unsigned short*)dy, \
-                     (const unsigned short*)x, gamma, beta, stats,                             \
-                     (const unsigned short*)dres, (unsigned short*)dx, partial, rows, C)
+#define LN_BWD_(N, A, D)                                                                              \
+  do {                                                                                                \
+    if (x_f32 && N <= 2)                                                                              \
+      hipLaunchKernelGGL((ln_bwd_kernel<(N <= 2 ? N : 1), A, D, true>), grid, block, lds, s,          \
+                         (const unsigned short*)dy, x, gamma, beta, stats, (const unsigned short*)dres, \
+                         (unsigned short*)dx, partial, rows, C);                                      \
+    else                                                                                              \
+      hipLaunchKernelGGL((ln_bwd_kernel<N, A, D, false>), grid, block, lds, s,                        \
+                         (const unsigned short*)dy, x, gamma, beta, stats, (const unsigned short*)dres, \
+                         (unsigned short*)dx, partial, rows, C);                                      \
+  } while (0)
   static const int use_dpp = [] { const char* e = getenv("CA_LN_BWD_DPP"); return e ? atoi(e) : 1; }();
 #define LN_BWD(N)                \
   do {                           \
@@ -545,6 +607,12 @@ extern "C" int ca_layernorm_bwd(const void* dy, const void* x, const float* gamm
   }
   CA_CHECK_LAUNCH("ca_layernorm_bwd(reduce)");
   return CA_OK;
+}
+extern "C" int ca_layernorm_bwd(const void* dy, const void* x, const float* gamma,
+                                const float* beta, const float* stats, const void* dres,
+                                void* dx, float* dgamma, float* dbeta, float* partial,
+                                int64_t rows, int32_t C, int32_t act, void* stream) {
+  return ca_layernorm_bwd_ex(dy, x, gamma, beta, stats, dres, dx, dgamma, dbeta, partial, rows, C, act, 0, stream);
 }
 
 // ---- column sums (bias gradients) ---------------------------------------------------------

@@ -287,6 +287,12 @@ def wgrad_gemm_group(problems: list, G, colsum_ws=None, colsum_ld=0) -> bool:
 
 
 def layernorm_fwd(x, gamma, beta, y, stats, rows, Cn, eps=1e-5, act=0, x_off=0, y_off=0):
+    """LayerNorm (+ GELU with act=1) over rows; fp32 tensors on either side select the fp32 forms (C <= 1024)."""
+    xf, yf = x.dtype == torch.float32, y.dtype == torch.float32
+    if xf or yf:
+        check(lib().ca_layernorm_fwd_ex(_p(x, x_off), _p(gamma), _p(beta), _p(y, y_off), _p(stats), rows, Cn, eps, act,
+                                        int(xf), int(yf), _stream()), "ca_layernorm_fwd_ex")
+        return
     check(lib().ca_layernorm_fwd(_p(x, x_off), _p(gamma), _p(beta), _p(y, y_off), _p(stats), rows,
                                  Cn, eps, act, _stream()), "ca_layernorm_fwd")
 
@@ -302,6 +308,10 @@ def layernorm_bwd_partial_floats(rows, Cn):
 
 
 def layernorm_bwd(dy, x, gamma, beta, stats, dres, dx, dgamma, dbeta, partial, rows, Cn, act=0):
+    if x.dtype == torch.float32:  # the saved input was kept in fp32 (layernorm_fwd's fp32 form)
+        check(lib().ca_layernorm_bwd_ex(_p(dy), _p(x), _p(gamma), _p(beta), _p(stats), _p(dres), _p(dx), _p(dgamma),
+                                        _p(dbeta), _p(partial), rows, Cn, act, 1, _stream()), "ca_layernorm_bwd_ex")
+        return
     check(lib().ca_layernorm_bwd(_p(dy), _p(x), _p(gamma), _p(beta), _p(stats), _p(dres), _p(dx),
                                  _p(dgamma), _p(dbeta), _p(partial), rows, Cn, act, _stream()),
           "ca_layernorm_bwd")
@@ -488,7 +498,11 @@ def clear_ranges(x, ranges):
     key = (x.data_ptr(), elt, tuple(ranges))
     ent = _CLEAR_TABLES.get(key)
     if ent is None:
-        if len(_CLEAR_TABLES) > 512:
+        if len(_CLEAR_TABLES) > 4096:
+            # The tables are read by launches on side streams the caching allocator knows nothing about (weight-gradient,
+            # optimiser, communication): a table must not be freed - and its memory handed to the next H2D copy - while
+            # a queued ca_clear_ranges may still read it.  Retire the cache only with the device idle.
+            torch.cuda.synchronize()
             _CLEAR_TABLES.clear()
         rows = [[int(a) * elt, int(n) * elt] for a, n in ranges if n > 0]
         if any(a % 4 or n % 4 for a, n in rows):

@@ -47,6 +47,65 @@ class _Handles:
             h.wait()
 
 
+class _Done:
+    """Handle of a collective that is ordered by the communication stream itself (the C-ABI path)."""
+
+    def wait(self):
+        pass
+
+
+class CommContext:
+    """One RCCL communicator + its communication stream behind the C ABI (include/coral_amd.h: ca_comm_*).  The
+    rendezvous - handing rank 0's 128-byte unique id to every rank - rides on the torch.distributed group that launched
+    the ranks; every collective afterwards is a ca_* call enqueued on the context's own HIP stream."""
+
+    def __init__(self, device, process_group=None):
+        import ctypes as C
+
+        lib = ops.lib()
+        dist = torch.distributed
+        self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        buf = C.create_string_buffer(128)
+        if self.rank == 0:
+            ops.check(lib.ca_comm_unique_id(buf), "ca_comm_unique_id")
+        ident = [bytes(buf.raw)]
+        if self.world > 1:
+            src = dist.get_global_rank(process_group, 0) if process_group is not None else 0
+            dist.broadcast_object_list(ident, src=src, group=process_group)
+        with torch.cuda.device(device):
+            ctx = C.c_void_p()
+            ops.check(lib.ca_comm_init(C.byref(ctx), ident[0], self.rank, self.world), "ca_comm_init")
+        self.ctx = ctx
+        self.lib = lib
+        self.stream = torch.cuda.ExternalStream(lib.ca_comm_stream(ctx), device=device)
+
+    @staticmethod
+    def _dt(t):
+        return {torch.float32: 0, torch.bfloat16: 1}[t.dtype]
+
+    def after_current(self):
+        """The communication stream waits for what is enqueued on torch's current stream."""
+        ops.check(self.lib.ca_comm_after(self.ctx, torch.cuda.current_stream().cuda_stream), "ca_comm_after")
+
+    def before_current(self):
+        """torch's current stream waits for the collectives enqueued so far."""
+        ops.check(self.lib.ca_comm_before(self.ctx, torch.cuda.current_stream().cuda_stream), "ca_comm_before")
+
+    def all_reduce(self, t):
+        ops.check(self.lib.ca_allreduce_bucket(self.ctx, t.data_ptr(), t.numel(), self._dt(t)), "ca_allreduce_bucket")
+
+    def reduce_scatter(self, t):
+        """In place over t (world equal slices): this rank's slice ends with the sum over ranks."""
+        ops.check(self.lib.ca_reduce_scatter_bucket(self.ctx, t.data_ptr(), t.numel() // self.world, self._dt(t)),
+                  "ca_reduce_scatter_bucket")
+
+    def all_gather(self, t):
+        """In place over t: every rank's slice -> all of t on every rank."""
+        ops.check(self.lib.ca_allgather_bucket(self.ctx, t.data_ptr(), t.numel() // self.world, self._dt(t)),
+                  "ca_allgather_bucket")
+
+
 class GradSync:
     """Bucketed gradient all-reduce over a flat fp32 buffer (device-agnostic, so the N>1 logic is
     testable with gloo on CPU).  `start(name)` launches the asynchronous SUM all-reduce of one
@@ -86,7 +145,16 @@ class GradSync:
         force = force or os.environ.get("CA_DP_FORCE", "0") == "1"
         self.active = self.world > 1 or (force and torch.distributed.is_available() and torch.distributed.is_initialized())
         self.on_gpu = flat_grad.is_cuda
-        self.comm_stream = torch.cuda.Stream(device=flat_grad.device) if (self.on_gpu and self.active) else None
+        # RCCL ranks exchange through the C ABI (ca_allreduce_bucket / ca_reduce_scatter_bucket on the context's own
+        # stream: include/coral_amd.h); torch.distributed collectives remain for the gloo CPU tests (CA_COMM_CAPI=0
+        # forces them on RCCL too: the A/B switch)
+        self.capi = None
+        if self.active and self.on_gpu and self._has_rs and os.environ.get("CA_COMM_CAPI", "1") != "0":
+            self.capi = CommContext(flat_grad.device, process_group)
+        if self.capi is not None:
+            self.comm_stream = self.capi.stream
+        else:
+            self.comm_stream = torch.cuda.Stream(device=flat_grad.device) if (self.on_gpu and self.active) else None
         self.compress = compress and self.active
         self.g16 = torch.empty_like(flat_grad, dtype=torch.bfloat16) if self.compress else None
         self._pending = []
@@ -116,6 +184,15 @@ class GradSync:
             self._to_wire(lo, hi)
             buf = self.g16
         SUM = torch.distributed.ReduceOp.SUM
+        if self.capi is not None:  # (called with the communication stream current: ordered by the stream itself)
+            if name is None or name not in self.shard:
+                self.capi.all_reduce(buf[lo:hi])
+            else:
+                mlo, _ = self.shard[name]
+                if mlo > lo:
+                    self.capi.all_reduce(buf[lo:mlo])
+                self.capi.reduce_scatter(buf[mlo:hi])
+            return _Done()
         if name is None or name not in self.shard:
             return torch.distributed.all_reduce(buf[lo:hi], op=SUM, group=self.pg, async_op=True)
         mlo, _ = self.shard[name]
@@ -148,7 +225,10 @@ class GradSync:
             return None
 
         if self.comm_stream is not None:
-            self.comm_stream.wait_stream(torch.cuda.current_stream())  # the bucket's grads are enqueued
+            if self.capi is not None:
+                self.capi.after_current()  # (ca_comm_after: the bucket's grads are enqueued)
+            else:
+                self.comm_stream.wait_stream(torch.cuda.current_stream())  # the bucket's grads are enqueued
             with torch.cuda.stream(self.comm_stream):
                 h = go()
         else:
@@ -171,7 +251,10 @@ class GradSync:
         if self.comm_stream is not None:
             with torch.cuda.stream(self.comm_stream):
                 drain()
-            torch.cuda.current_stream().wait_stream(self.comm_stream)
+            if self.capi is not None:
+                self.capi.before_current()
+            else:
+                torch.cuda.current_stream().wait_stream(self.comm_stream)
         else:
             drain()
         self._pending.clear()
@@ -230,7 +313,7 @@ class DataParallelTrainer:
             shard = {n: r for n, r in engine.shard_ranges().items() if (r[1] - r[0]) % (8 * world) == 0 and r[1] > r[0]}
         self.sync = GradSync(st.g32, st.buckets, process_group, compress=compress_grads, shard=shard)
         self.zero = bool(shard) and self.sync.active
-        if self.zero and world > 1 and st.p32.is_cuda and not self._collectives_selfcheck(st.device, process_group):
+        if self.zero and world > 1 and st.p32.is_cuda and not self._collectives_selfcheck(st.device, process_group, self.sync.capi):
             # (never silently wrong: a backend whose in-place reduce-scatter / all-gather does not behave as RCCL
             # documents falls back to the replicated path, and says so)
             import logging
@@ -245,6 +328,7 @@ class DataParallelTrainer:
         # the replicated part [lo, mlo) and this rank's slice of the sharded part - 1/N of the state.
         self._state_off = None
         self._ag_stream = None
+        self._ag_comm = None
         if self.zero:
             self._state_off, n = {}, 0
             for name, (blo, bhi) in st.buckets.items():
@@ -427,7 +511,12 @@ class DataParallelTrainer:
                 torch.cuda.current_stream().wait_stream(self.opt_stream)
             self.gnorm_sq.copy_(self.bucket_sq.sum().reshape(1))
             if self.world > 1 and (self.shard_norm or self.zero):  # add the ranks' slices (the same result on every rank)
-                torch.distributed.all_reduce(self.gnorm_sq, op=torch.distributed.ReduceOp.SUM, group=self.sync.pg)
+                if self.sync.capi is not None:
+                    self.sync.capi.after_current()
+                    self.sync.capi.all_reduce(self.gnorm_sq)
+                    self.sync.capi.before_current()
+                else:
+                    torch.distributed.all_reduce(self.gnorm_sq, op=torch.distributed.ReduceOp.SUM, group=self.sync.pg)
             self._norms_ready = False
         elif self._early_lo is not None:  # the tail's squared norm is already in gnorm_sq (side stream)
             torch.cuda.current_stream().wait_stream(self.opt_stream)
@@ -456,7 +545,11 @@ class DataParallelTrainer:
             # bucket's all-gather, only the forward's per-bucket wait does (the event below is recorded behind it)
             cur = torch.cuda.current_stream()
             if self._ag_stream is None:
-                self._ag_stream = torch.cuda.Stream(device=st.device)
+                if self.sync.capi is not None:  # a second communicator: gathers do not queue behind reduce-scatters
+                    self._ag_comm = CommContext(st.device, self.sync.pg)
+                    self._ag_stream = self._ag_comm.stream
+                else:
+                    self._ag_stream = torch.cuda.Stream(device=st.device)
             self._ag_stream.wait_stream(cur)
             with torch.cuda.stream(self._ag_stream):
                 self._allgather_bf16(mlo, bhi, sa, sb)
@@ -515,35 +608,61 @@ class DataParallelTrainer:
         eng.weights_ready = events
 
     @staticmethod
-    def _collectives_selfcheck(device, pg) -> bool:
+    def _collectives_selfcheck(device, pg, capi=None) -> bool:
         """One-time check, on the real process group, of the two in-place forms the sharded optimiser relies on:
-        reduce_scatter_tensor with the output slice inside the input buffer (at input + rank x count) and
-        all_gather_into_tensor with the input slice inside the output buffer, against a plain all-reduce."""
+        reduce-scatter with the output slice inside the input buffer (at input + rank x count) and all-gather with the
+        input slice inside the output buffer, against their defining sums - through the C ABI's ca_* collectives when
+        `capi` (a CommContext) is given, else torch.distributed's."""
         world, rank = torch.distributed.get_world_size(pg), torch.distributed.get_rank(pg)
         n = 4096
         base = torch.arange(world * n, dtype=torch.float32, device=device) % 257
         x = base * (rank + 1)
         want = base * (world * (world + 1) // 2)
-        try:
-            if torch.distributed.get_backend(pg) == "nccl":
+        ok = True
+        if capi is not None or torch.distributed.get_backend(pg) == "nccl":
+            # each collective under its own guard: a rank whose call raises records a failure and still joins the flag
+            # reduction below, so the other ranks fall back with it instead of waiting for it
+            try:
                 buf = x.clone()
-                torch.distributed.reduce_scatter_tensor(buf[rank * n:(rank + 1) * n], buf, group=pg)
+                if capi is not None:
+                    capi.after_current()
+                    capi.reduce_scatter(buf)
+                    capi.before_current()
+                else:
+                    torch.distributed.reduce_scatter_tensor(buf[rank * n:(rank + 1) * n], buf, group=pg)
                 ok = torch.equal(buf[rank * n:(rank + 1) * n], want[rank * n:(rank + 1) * n])
+            except Exception:  # noqa: BLE001
+                ok = False
+            try:
                 g = torch.zeros(world * n, dtype=torch.bfloat16, device=device)
                 g[rank * n:(rank + 1) * n] = (base[rank * n:(rank + 1) * n]).to(torch.bfloat16)
-                torch.distributed.all_gather_into_tensor(g, g[rank * n:(rank + 1) * n], group=pg)
+                if capi is not None:
+                    capi.after_current()
+                    capi.all_gather(g)
+                    capi.before_current()
+                else:
+                    torch.distributed.all_gather_into_tensor(g, g[rank * n:(rank + 1) * n], group=pg)
                 ok = ok and torch.equal(g, base.to(torch.bfloat16))
+            except Exception:  # noqa: BLE001
+                ok = False
+        try:
+            bad = torch.tensor([0.0 if ok else 1.0], device=device)  # failures, summed over the ranks
+            if capi is not None:
+                capi.after_current()
+                capi.all_reduce(bad)
+                capi.before_current()
             else:
-                ok = True
-            flag = torch.tensor([1.0 if ok else 0.0], device=device)
-            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN, group=pg)
-            return bool(flag.item() > 0.5)
+                torch.distributed.all_reduce(bad, op=torch.distributed.ReduceOp.SUM, group=pg)
+            return bool(bad.item() < 0.5)
         except Exception:  # noqa: BLE001
             return False
 
     def _allgather_bf16(self, mlo, hi, a, b):
         """Every rank's freshly updated bf16 slice -> the whole [mlo, hi) of the compute copy, on the current stream."""
         p16, pg = self.engine.store.p16, self.sync.pg
+        if getattr(self, "_ag_comm", None) is not None:  # C ABI (ca_allgather_bucket, in place, on the gather context's stream)
+            self._ag_comm.all_gather(p16[mlo:hi])
+            return
         if self.sync._has_rs:  # RCCL: in place (the input slice sits at output + rank * count)
             torch.distributed.all_gather_into_tensor(p16[mlo:hi], p16[a:b], group=pg)
             return

@@ -19,6 +19,7 @@ HBM layout
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass
 
 import torch
@@ -64,6 +65,13 @@ CORAL_W2V2_SHAPES = {
 
 def _r8(n: int) -> int:
     return (n + 7) // 8 * 8
+
+
+# The conv stack's pre-norm tensors (outputs of the conv GEMMs 1..6) and the last conv block's output stay fp32, as under
+# the reference's autocast, where nn.LayerNorm and the GELU behind it run in fp32
+# ($TF/models/wav2vec2/modeling_wav2vec2.py:291-298,429-434): 0.5 GB more at B = 8 and seven bf16 roundings less in front
+# of the transformer.  CA_CONV_F32=0 restores the bf16 tensors (A/B measurements only).
+CONV_F32 = os.environ.get("CA_CONV_F32", "1") == "1"
 
 
 def _arena_build(build, device, default_dtype):
@@ -424,8 +432,9 @@ class Wav2Vec2CTCEngine:
             # be ~450 separate torch.zeros fills)
             w = {"B": B, "N": N, "Ts": Ts, "T": T, "M": M, "Tp": Tp}
             C0 = s.conv_dim[0]
-            w["a"] = [z(B * Ts[i] * s.conv_dim[i]) for i in range(7)]          # conv block outputs
-            w["y"] = [None] + [z(B * Ts[i] * s.conv_dim[i]) for i in range(1, 7)]  # pre-LN conv outputs
+            cdt = f32 if CONV_F32 else bf
+            w["a"] = [z(B * Ts[i] * s.conv_dim[i], dt=cdt if i == 6 else bf) for i in range(7)]  # conv block outputs
+            w["y"] = [None] + [z(B * Ts[i] * s.conv_dim[i], dt=cdt) for i in range(1, 7)]  # pre-LN conv outputs
             w["cstats"] = [None] + [z(B * Ts[i] * 2, dt=f32) for i in range(1, 7)]
             w["fp_stats"] = z(M * 2, dt=f32)
             w["xln"] = z(M * C0)

@@ -414,10 +414,11 @@ class WhisperEngine:
         Vp = _r8(V)
         if last_only:
             rows = w["hf"].view(B, L, d)[:, -1, :].contiguous()
-            logits = torch.zeros(B, Vp, dtype=torch.float32, device=dev)
+            # (torch.empty: the GEMM writes all V columns, the Vp - V pad columns are never read - no fill kernel per call)
+            logits = torch.empty(B, Vp, dtype=torch.float32, device=dev)
             ops.gemm(rows, p16, logits, M=B, N=V, K=d, lda=d, ldb=d, ldc=Vp, b_off=o("model.decoder.embed_tokens.weight"))
             return logits.view(B, 1, Vp)[:, :, :V]
-        logits = torch.zeros(M, Vp, dtype=torch.float32, device=dev)
+        logits = torch.empty(M, Vp, dtype=torch.float32, device=dev)
         ops.gemm(w["hf"], p16, logits, M=M, N=V, K=d, lda=d, ldb=d, ldc=Vp, b_off=o("model.decoder.embed_tokens.weight"))
         self._last_logits = logits
         return logits.view(B, L, Vp)[:, :, :V]
@@ -487,7 +488,7 @@ class WhisperEngine:
                           w["hf"], None, M, d, s.layer_norm_eps)
         V, Vp = s.vocab_size, _r8(s.vocab_size)
         rows = w["hf"].view(B, n, d)[:, -1, :].contiguous()
-        logits = torch.zeros(B, Vp, dtype=torch.float32, device=dev)
+        logits = torch.empty(B, Vp, dtype=torch.float32, device=dev)
         ops.gemm(rows, p16, logits, M=B, N=V, K=d, lda=d, ldb=d, ldc=Vp, b_off=o("model.decoder.embed_tokens.weight"))
         cache["pos"] = Lk
         return logits[:, :V]

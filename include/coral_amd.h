@@ -150,16 +150,19 @@ int ca_gemm_bf16_group(const CaGemmDesc* descs, int32_t count, void* stream);
  * ca_gemm_kernel, 1 = ca_gemm_kernel_l, 2 = ca_gemm_kernel_x; segmented = a_kseg or b_kseg set):
  * summed kernel milliseconds, launch count, summed algorithmic FLOPs (2*M*N*K*batch).  Not for use
  * inside graph capture. */
-/* Tuning/test hook: 0 = automatic kernel choice, 1 = force the 128x128 kernel, 2 = force the
- * 256x128 pipelined kernel, 3 = force the 256x256 kernel, 4 = force the 256x256 kernel with one wave per SIMD
- * (4 waves x 128x128; an experiment), 5 = force the 128x128 tile on 8 waves (kernel M: what the
- * automatic choice runs when the grid has at most one 128x128 tile per CU). */
-int ca_gemm_force_kernel(int which);
-/* Test hook: on != 0 sends every wave tile through the general epilogue walk (interior tiles normally take a
- * specialised, predicate-free form that must give the same bits). */
-int ca_gemm_debug_general_epilogue(int on);
 int ca_prof_begin(void);
 int ca_prof_end(double* ms, int64_t* count, double* flops);
+
+/* ---- CA_DEBUG_API: test and tuning hooks.  Not part of the product interface - no host code of the path calls them;
+ * tests/ and tools/ do, to run every tile shape through the same parity cases. ---------------------------------------
+ * ca_gemm_force_kernel: 0 = automatic kernel choice, 1 = force the 128x128 kernel, 2 = force the 256x128 pipelined
+ * kernel, 3 = force the 256x256 kernel, 5 = force the 128x128 tile on 8 waves (kernel M: what the automatic choice runs
+ * when the grid has at most one 128x128 tile per CU).  (4 was the one-wave-per-SIMD experiment of round 3, DESIGN.md
+ * 4.1: measured, not adopted, removed.)
+ * ca_gemm_debug_general_epilogue: on != 0 sends every wave tile through the general epilogue walk (interior tiles
+ * normally take a specialised, predicate-free form that must give the same bits). */
+int ca_gemm_force_kernel(int which);
+int ca_gemm_debug_general_epilogue(int on);
 
 /* ------------------------------------------------------------------------------------
  * LayerNorm over the channel axis.  $TF/models/wav2vec2/modeling_wav2vec2.py:429-434,
@@ -170,6 +173,13 @@ int ca_prof_end(double* ms, int64_t* count, double* flops);
 int ca_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y,
                      float* stats, int64_t rows, int32_t C, float eps, int32_t act,
                      void* stream);
+/* The same with fp32 rows on either side (x_f32: x is fp32 [rows, C]; y_f32: y is fp32), C <= 1024: the conv stack's
+ * pre-norm tensors and the last conv block's output, which the reference's autocast keeps in fp32 as well (nn.LayerNorm
+ * and the GELU behind it run in fp32 there: $TF/models/wav2vec2/modeling_wav2vec2.py:291-298,429-434) - seven bf16
+ * roundings less in front of the transformer. */
+int ca_layernorm_fwd_ex(const void* x, const float* gamma, const float* beta, void* y,
+                        float* stats, int64_t rows, int32_t C, float eps, int32_t act,
+                        int32_t x_f32, int32_t y_f32, void* stream);
 /* The same LayerNorm with the output also quantised to OCP fp8 e4m3, one scale per row (taken by the wave that holds
  * the row, no extra pass): q[row] = e4m3(y[row] * 448 / amax(y[row])), row_scale[row] = amax / 448 for
  * CaGemmDesc.a_row_scale.  y (bf16) and stats ([rows][2] mean, rstd for ca_layernorm_bwd) may be NULL.  C must be a
@@ -184,6 +194,12 @@ int ca_layernorm_bwd(const void* dy, const void* x, const float* gamma, const fl
                      const float* stats, const void* dres, void* dx, float* dgamma,
                      float* dbeta, float* partial, int64_t rows, int32_t C, int32_t act,
                      void* stream);
+
+/* x_f32 != 0: the saved input x is fp32 (see ca_layernorm_fwd_ex); dy, dres and dx stay bf16. */
+int ca_layernorm_bwd_ex(const void* dy, const void* x, const float* gamma, const float* beta,
+                        const float* stats, const void* dres, void* dx, float* dgamma,
+                        float* dbeta, float* partial, int64_t rows, int32_t C, int32_t act,
+                        int32_t x_f32, void* stream);
 
 /* column sums: out[n] (+)= sum_m x[m*ld + n]  (bias gradients). x bf16, out fp32.
  * rowmask uint8 [rows] or NULL: only rows with a non-zero mask byte are summed (gradient of
@@ -444,6 +460,43 @@ int ca_embed_tokens(const void* table, const void* pos, const int32_t* ids,
 /* its backward: dtable[ids[r],:] += dy[r,:], dpos[pos_ids[r],:] += dy[r,:]  (fp32 tables, bf16 dy) */
 int ca_embed_tokens_bwd(const void* dy, const int32_t* ids, const int32_t* pos_ids, float* dtable,
                         float* dpos, int64_t rows, int32_t C, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Data-parallel exchange: bucket collectives over RCCL (xGMI), one context per rank.  Replaces what the reference gets
+ * from accelerate's DDP wrapper / DeepSpeed ZeRO-2 under `Trainer` (accelerate/accelerator.py:1892 prepare_model ->
+ * DistributedDataParallel, :2053 backward; launch lines R/makefile:79-84): a SUM all-reduce per gradient bucket
+ * overlapped with the backward, or - sharded optimiser - a reduce-scatter of the gradients and an all-gather of the
+ * updated bf16 weights.  (`cm_allreduce_bucket(ctx, ...)`.)
+ *
+ * A context owns an RCCL communicator and ONE HIP stream on which all of its collectives are enqueued, in call order;
+ * nothing here synchronises the host.  Rendezvous is the caller's: rank 0 calls ca_comm_unique_id and hands the 128
+ * bytes to every rank (any channel), then every rank calls ca_comm_init with the device it computes on current.
+ * RCCL is bound at run time on the first ca_comm_* call (CA_ERR_UNSUPPORTED when librccl.so.1 cannot be found); the
+ * rest of the library does not depend on it.
+ *   ca_comm_after(ctx, producer):  the communication stream waits for the work enqueued so far on `producer`
+ *                                  (the bucket's gradients are complete);
+ *   ca_comm_before(ctx, consumer): `consumer` waits for the collectives enqueued so far (the optimiser may read).
+ * Buffers are DEVICE pointers; all three collectives work IN PLACE:
+ *   ca_allreduce_bucket:      buf[0:n] <- sum over ranks;
+ *   ca_reduce_scatter_bucket: rank r ends with the sum over ranks of buf[r * n_per_rank : (r + 1) * n_per_rank] in
+ *                             that slice (the other slices are left undefined);
+ *   ca_allgather_bucket:      buf[r * n_per_rank : (r + 1) * n_per_rank] of every rank r -> all of buf on every rank.
+ * ---------------------------------------------------------------------------------- */
+#define CA_COMM_ID_BYTES 128
+#define CA_COMM_F32 0
+#define CA_COMM_BF16 1
+typedef struct CaComm CaComm;
+int ca_comm_unique_id(void* id128_h);
+int ca_comm_init(CaComm** ctx, const void* id128_h, int32_t rank, int32_t world);
+int ca_comm_destroy(CaComm* ctx);
+void* ca_comm_stream(CaComm* ctx); /* the context's hipStream_t */
+int ca_comm_rank(CaComm* ctx);
+int ca_comm_world(CaComm* ctx);
+int ca_comm_after(CaComm* ctx, void* producer_stream);
+int ca_comm_before(CaComm* ctx, void* consumer_stream);
+int ca_allreduce_bucket(CaComm* ctx, void* buf, int64_t n, int32_t dtype);
+int ca_reduce_scatter_bucket(CaComm* ctx, void* buf, int64_t n_per_rank, int32_t dtype);
+int ca_allgather_bucket(CaComm* ctx, void* buf, int64_t n_per_rank, int32_t dtype);
 
 #ifdef __cplusplus
 }

@@ -14,16 +14,24 @@ sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
 
 
-def run(forced, wire, steps, zero=0):
+def run(forced, wire, steps, zero=0, clip=1e9):
+    """clip = the trainer's max_grad_norm.  The default (1e9: the clip coefficient is exactly 1) makes the comparison
+    independent of the last bits of the gradient norm, which the plain trainer sums from the weight-gradient kernels'
+    per-tile partials and the exchange path per bucket: one ulp of the norm moves every parameter by one ulp, a few of
+    the 4.8 M bf16 copies then round the other way, and two steps later nothing is bit-identical any more."""
     import dp_worker
 
     from coral_amd.trainer import DataParallelTrainer
 
     os.environ["CA_DP_FORCE"] = "1" if forced else "0"
     eng, shard = dp_worker.build_case()
-    tr = DataParallelTrainer(eng, learning_rate=1e-3, warmup_steps=0, max_steps=100, max_grad_norm=1.0,
+    tr = DataParallelTrainer(eng, learning_rate=1e-3, warmup_steps=0, max_steps=100, max_grad_norm=clip,
                              compress_grads=(wire == "bf16"), zero_stage=zero)
     assert tr.dist == forced and tr.overlap == forced and tr.world == 1 and tr.zero == bool(zero)
+    # RCCL ranks exchange through the C ABI's ca_* collectives (include/coral_amd.h), CA_COMM_CAPI=0 = torch.distributed's
+    assert (tr.sync.capi is not None) == (forced and os.environ.get("CA_COMM_CAPI", "1") != "0")
+    if zero and forced:
+        assert tr._collectives_selfcheck(eng.store.device, None, tr.sync.capi)
     mb = shard([0, 1, 2, 3])
     losses, norms = [], []
     for _ in range(steps):
@@ -44,6 +52,14 @@ def main():
     res = {"plain": run(False, "fp32", steps), "fp32": run(True, "fp32", steps), "bf16": run(True, "bf16", steps),
            # the sharded optimiser's RCCL calls (in-place reduce_scatter_tensor / all_gather_into_tensor) over one rank
            "zero": run(True, "fp32", steps, zero=2)}
+    # with the clip active (max_grad_norm 1.0, the reference's value): ONE step, compared to the norm's rounding
+    res["plain_clip"] = run(False, "fp32", 1, clip=1.0)
+    res["fp32_clip"] = run(True, "fp32", 1, clip=1.0)
+    res["zero_clip"] = run(True, "fp32", 1, zero=2, clip=1.0)
+    # the same exchange through torch.distributed's own RCCL calls (the A/B switch)
+    os.environ["CA_COMM_CAPI"] = "0"
+    res["fp32_torch"] = run(True, "fp32", steps)
+    os.environ.pop("CA_COMM_CAPI")
     torch.save(res, out)
     torch.distributed.destroy_process_group()
 

@@ -28,12 +28,16 @@ def test_bench_spawns_its_ranks_and_reports_them(zero):
     main = [d for d in lines if "metric" in d]
     assert len(main) == 1, r.stdout[-1500:]              # rank 0 prints ONE line
     d = main[0]
-    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["grad_wire"] == "fp32" and d["scaling"] == "weak"
+    assert d["n_gpus"] == 2 and d["ranks"] == 2 and d["backend"] == "gloo" and d["grad_wire"] == "fp32" and d["scaling"] == "weak"
+    assert d["rccl_ranks"] == 1  # (no RCCL rank ran: the field counts ranks of backend "nccl" only)
     assert d["config"]["global_batch"] == 16 and d["config"]["parallelism"] == "dp2"
     assert d["value"] > 0 and d["steps"] == 2 and d["warmup"] == 1
     assert ("sharded optimiser" in d["config"]["workload"]) == (zero is None)
     spread = [x for x in lines if "replica_param_spread" in x]
     assert spread and spread[0]["replica_param_spread"] == 0.0   # DDP invariant: identical replicas
+    sp = spread[0]["replica_spreads"]  # parameters, bf16 copy AND the AdamW moments (gathered first under the sharded optimiser)
+    assert set(sp) >= {"p32", "p16", "m", "v"} and all(x == 0.0 for x in sp.values()), sp
+    assert ("p16_vs_master" in sp) == (zero is None)
 
 
 def test_two_ranks_at_the_full_xlsr_2b_shape_with_the_sharded_optimizer():

@@ -137,17 +137,57 @@ def test_rccl_one_rank_group_reproduces_the_plain_trainer(tmp_path):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     res = torch.load(out)
     plain, f32, b16 = res["plain"], res["fp32"], res["bf16"]
-    # the sharded optimiser over the same one-rank group (RCCL's in-place reduce-scatter and all-gather are identities)
-    # (equal up to the last bits of the clip factor: the squared norm is summed over other partials)
-    assert float((plain["p32"] - res["zero"]["p32"]).abs().max()) <= 1e-7
-    assert float((plain["p16"] != res["zero"]["p16"]).float().mean()) <= 1e-4
-    assert all(abs(a - b) <= 1e-6 * abs(a) for a, b in zip(plain["losses"], res["zero"]["losses"]))
-    # fp32 wire: the identity exchange changes nothing, bit for bit
-    assert torch.equal(plain["p32"], f32["p32"]) and plain["losses"] == f32["losses"]
-    assert all(abs(a - b) <= 1e-6 * a for a, b in zip(plain["norms"], f32["norms"]))  # (norm: per-bucket sums vs one pass)
+    # Without the clip (see the worker: the comparison must not hang on the last bit of the gradient norm) the identity
+    # exchange changes nothing, bit for bit: fp32 wire through the C ABI's ca_* collectives (the default on RCCL) and
+    # through torch.distributed's, and the sharded optimiser over the same one-rank group (RCCL's in-place
+    # reduce-scatter and all-gather are identities)
+    for k in ("fp32", "fp32_torch", "zero"):
+        assert torch.equal(plain["p32"], res[k]["p32"]) and torch.equal(plain["p16"], res[k]["p16"]), k
+        assert plain["losses"] == res[k]["losses"], k
+        assert all(abs(a - b) <= 1e-6 * a for a, b in zip(plain["norms"], res[k]["norms"])), k  # (per-bucket sums vs one pass)
+    # with the clip (max_grad_norm 1.0): one step, parameters equal to the rounding of the clip coefficient
+    pc = res["plain_clip"]
+    for k in ("fp32_clip", "zero_clip"):
+        assert pc["losses"] == res[k]["losses"] and abs(pc["norms"][0] - res[k]["norms"][0]) <= 1e-6 * pc["norms"][0]
+        assert float((pc["p32"] - res[k]["p32"]).abs().max()) <= 1e-7, k
+        assert float((pc["p16"] != res[k]["p16"]).float().mean()) <= 1e-4, k
+    assert float((pc["p32"] - plain["p32"]).abs().max()) > 0  # (the clip did act: norm ~ 950)
     # bf16 wire: one rounding of the gradients to 8 bits
     lr = 1e-3
     assert plain["losses"][0] == b16["losses"][0]
     assert abs(plain["norms"][0] - b16["norms"][0]) <= 2e-3 * plain["norms"][0]
     d = (plain["p32"] - b16["p32"]).abs()
     assert float(d.max()) <= 4 * lr and float((d <= 0.05 * lr).float().mean()) >= 0.9
+
+
+def test_comm_context_collectives_through_the_c_abi():
+    """ca_comm_* (include/coral_amd.h) on a context of ONE rank: unique id -> init -> the three in-place collectives on
+    the context's own stream, ordered against torch's stream by ca_comm_after / ca_comm_before.  Over one rank a SUM
+    all-reduce, a reduce-scatter and an all-gather are identities: the buffers must come back unchanged - and the work
+    enqueued after ca_comm_before must see them."""
+    import ctypes as C
+
+    from coral_amd import ops
+
+    lib = ops.lib()
+    ident = C.create_string_buffer(128)
+    assert lib.ca_comm_unique_id(ident) == 0, lib.ca_last_error()
+    assert any(ident.raw)  # RCCL filled it
+    ctx = C.c_void_p()
+    torch.cuda.set_device(0)
+    assert lib.ca_comm_init(C.byref(ctx), ident, 0, 1) == 0, lib.ca_last_error()
+    assert lib.ca_comm_rank(ctx) == 0 and lib.ca_comm_world(ctx) == 1 and lib.ca_comm_stream(ctx)
+    x = torch.randn(1 << 20, device="cuda:0")
+    h = x.to(torch.bfloat16)
+    want, want_h = x.clone(), h.clone()
+    cur = torch.cuda.current_stream().cuda_stream
+    assert lib.ca_comm_after(ctx, cur) == 0
+    assert lib.ca_allreduce_bucket(ctx, x.data_ptr(), x.numel(), 0) == 0, lib.ca_last_error()
+    assert lib.ca_reduce_scatter_bucket(ctx, x.data_ptr(), x.numel(), 0) == 0, lib.ca_last_error()
+    assert lib.ca_allgather_bucket(ctx, h.data_ptr(), h.numel(), 1) == 0, lib.ca_last_error()
+    assert lib.ca_comm_before(ctx, cur) == 0
+    y = x * 2  # enqueued on torch's stream behind the collectives
+    torch.cuda.synchronize()
+    assert torch.equal(x, want) and torch.equal(h, want_h) and torch.equal(y, want * 2)
+    assert lib.ca_allreduce_bucket(ctx, x.data_ptr(), 0, 0) != 0 and lib.ca_allreduce_bucket(ctx, x.data_ptr(), 8, 7) != 0  # argument checks
+    assert lib.ca_comm_destroy(ctx) == 0

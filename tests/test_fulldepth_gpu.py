@@ -11,6 +11,8 @@ themselves (tests/test_fullsize_gpu.py keeps the batch-of-8 property checks).
               ($TF/models/wav2vec2/modeling_wav2vec2.py:1667-1728)
   configs[3]  whisper-medium: encoder states, 8 teacher-forced logits rows, 16 greedy tokens under the tie margin
               ($TF/models/whisper/modeling_whisper.py:994-1099, generation_whisper.py:383)
+  default     whisper-large (R/config/asr_finetuning.yaml:1-11: the reference's default model key), 32 + 32 layers: the
+              same three comparisons on one clip, and its training step at the reference's batch of 64 (R/makefile:109-137)
   configs[4]  whisper-large-turbo, 32 + 4 layers, 2 clips: bf16 engine loss vs the oracle, and the fp8-forward step
               (`enable_fp8_forward`) vs the bf16 engine - fp8 has no reference oracle: its stated
               tolerance is against the build's own bf16 path
@@ -84,7 +86,22 @@ def test_xlsr2b_one_utterance_forward_backward_against_the_oracle():
     assert torch.isfinite(logits).all()
     assert err <= 8e-2, err
     assert cos >= 0.999, cos
-    assert rel <= 2e-3, rel  # (north star: 1e-3; measured 1.3e-3 on ONE utterance through 48 bf16 layers - DESIGN.md §2)
+    # The loss of ONE utterance through 48 layers is first-order sensitive to the time-mean of the logit error (a
+    # per-class offset common to all frames, driven by the weights' own bf16 rounding): DESIGN.md 2 "why 1e-3 per
+    # utterance is not a property of a bf16 path".  With ONLY the weights rounded to bf16 and every activation in fp32
+    # the oracle itself moves by 2.7e-4 ... 1.3e-3 on these five utterances (tools/dev_bf16_emulation.py), the
+    # reference's own bf16 path (HF autocast) by 9e-6 ... 1.3e-3 (tests/golden/w2v2_cfg2_bf16_noise.npz).  Asserted:
+    # 2e-3 per utterance here (3e-3 on the ragged ones), the north star's 1e-3 on the BATCH loss below, and a noise level
+    # of the logits no higher than the reference's own bf16 path.
+    assert rel <= 2e-3, rel
+    from pathlib import Path
+
+    hf = dict(np.load(Path(__file__).parent / "golden" / "w2v2_cfg2_bf16_noise.npz"))
+    assert float(np.abs(hf["logits_fp32"] - logits_ref.numpy()).max()) <= 1e-4  # the fixture is this utterance, these weights
+    rms = float((logits - logits_ref).double().norm() / logits_ref.double().norm())
+    print(f"  logits relative RMS error {rms:.4e}; the reference's own bf16 path (HF autocast vs HF fp32): {float(hf['rel_logits']):.4e}, "
+          f"its CTC loss {float(hf['loss_bf16']):.4f} (rel {abs(float(hf['loss_bf16']) - float(hf['loss_fp32'])) / float(hf['loss_fp32']):.2e})")
+    assert rms <= 1.05 * float(hf["rel_logits"]), (rms, float(hf["rel_logits"]))
     ids, _ = eng.greedy_decode()
     assert ids == ref.greedy_ctc_ids(logits.numpy(), cfg.pad_token_id)  # bit-exact on the engine's fp32 logits
     top2 = logits_ref.topk(2, dim=-1).values
@@ -117,9 +134,15 @@ def test_xlsr2b_one_utterance_forward_backward_against_the_oracle():
     per = [abs(float(a) - float(b)) / float(b) for a, b in zip(out4["nll"].cpu(), nll4)]
     tot_e, tot_r = float(out.loss) + float(out4.loss), float(loss_ref) + float(loss4)
     rel5 = abs(tot_e - tot_r) / tot_r
+    assert float(np.abs(hf["nll4_fp32"] - nll4.numpy()).max()) <= 2e-3  # (the fixture's four utterances are these four)
+    hf_per = [abs(float(a) - float(b)) / float(b) for a, b in zip(hf["nll4_bf16"], hf["nll4_fp32"])]
+    hf5 = abs(float(hf["loss_bf16"]) + float(hf["nll4_bf16"].sum()) - float(hf["loss_fp32"]) - float(hf["nll4_fp32"].sum())) / \
+        (float(hf["loss_fp32"]) + float(hf["nll4_fp32"].sum()))
     print("  four more utterances (ragged): per-utterance CTC rel err " + ", ".join(f"{x:.2e}" for x in per) +
-          f"; the five together {tot_e:.3f} vs {tot_r:.3f} (rel {rel5:.2e})")
-    assert max(per) <= 3e-3 and rel5 <= 2e-3
+          f"; the five together {tot_e:.3f} vs {tot_r:.3f} (rel {rel5:.2e})\n  the reference's own bf16 path on the same four: " +
+          ", ".join(f"{x:.2e}" for x in hf_per) + f"; its five together {hf5:.2e}")
+    assert max(per) <= 3e-3
+    assert rel5 <= 1e-3, rel5  # the batch loss - what a training step back-propagates - inside the north-star bound
     del eng
     torch.cuda.empty_cache()
 
@@ -177,14 +200,16 @@ def test_xlsr1b_one_utterance_forward_backward_against_the_oracle():
     torch.cuda.empty_cache()
 
 
-def test_whisper_medium_full_depth_one_clip_against_the_oracle():
+def _whisper_full_depth_one_clip(key: str, prefix: list, seed: int):
+    """One 30 s clip at the full architecture of CoRal model key `key` against the oracle: encoder states, 8
+    teacher-forced logits rows + CE loss, 16 greedy tokens under the tie-margin policy."""
     from coral_amd.whisper import CORAL_WHISPER_SHAPES, WhisperEngine, WhisperShape
     from oracle import whisper_ref as w
 
-    kw = dict(CORAL_WHISPER_SHAPES["whisper-medium"])
+    kw = dict(CORAL_WHISPER_SHAPES[key])
     c = w.WhisperConfig(**kw)
     P = w.synth_params(c)
-    g = torch.Generator().manual_seed(21)
+    g = torch.Generator().manual_seed(seed)
     wave = (0.1 * torch.randn(16_000 * 11, generator=g)).numpy()
     feats = torch.from_numpy(w.log_mel(w.pad_or_trim(wave), c.num_mel_bins))[None]
     labels = torch.randint(0, 50257, (1, 8), generator=g)
@@ -200,14 +225,13 @@ def test_whisper_medium_full_depth_one_clip_against_the_oracle():
     logits = out["logits"].float().cpu()
     e_log, c_log = float((logits - logits_ref).abs().max()), _cos(logits, logits_ref)
     rel = abs(float(out["loss"]) - float(loss_ref)) / abs(float(loss_ref))
-    print(f"\nwhisper-medium (24 + 24 L), 1 x 30 s: encoder states max-abs err {e_enc:.4f} (mean |x| "
-          f"{float(enc_ref.abs().mean()):.3f}, max |x| {float(enc_ref.abs().max()):.1f}), cosine {c_enc:.6f}; 8 teacher-forced "
-          f"logits rows max-abs err {e_log:.4f}, cosine {c_log:.6f}; CE loss rel {rel:.2e}")
+    print(f"\n{key} ({c.encoder_layers} + {c.decoder_layers} L, d {c.d_model}, {c.num_mel_bins} mels), 1 x 30 s: encoder states "
+          f"max-abs err {e_enc:.4f} (mean |x| {float(enc_ref.abs().mean()):.3f}, max |x| {float(enc_ref.abs().max()):.1f}), "
+          f"cosine {c_enc:.6f}; 8 teacher-forced logits rows max-abs err {e_log:.4f}, cosine {c_log:.6f}; CE loss rel {rel:.2e}")
     assert c_enc >= 0.999 and e_enc <= 2.5e-1  # (the encoder output carries a few large-magnitude channels)
     assert e_log <= 8e-2 and c_log >= 0.999
-    assert rel <= 2e-3, rel
+    assert rel <= 1e-3, rel  # the north-star bound
     # 16 greedy tokens: CoRal's evaluation call (forced Danish transcribe prefix, begin-suppress set)
-    prefix = [50258, 50285, 50359, 50363]
     bs = [220, c.eos_token_id]
     ids = eng.generate(feats, prefix, len(prefix) + 16, suppress_tokens=None, begin_suppress_tokens=bs)
     with torch.no_grad():
@@ -219,8 +243,84 @@ def test_whisper_medium_full_depth_one_clip_against_the_oracle():
             return lg
 
         check_greedy_rows(rows, ids, want, len(prefix), accept=max(3e-2, 1.5 * e_log), forced=max(6e-2, 3 * e_log),
-                          label="whisper-medium")
+                          label=key)
     del eng
+    torch.cuda.empty_cache()
+
+
+def test_whisper_medium_full_depth_one_clip_against_the_oracle():
+    _whisper_full_depth_one_clip("whisper-medium", [50258, 50285, 50359, 50363], seed=21)
+
+
+def test_whisper_large_the_reference_default_model_full_depth_against_the_oracle():
+    """`model=whisper-large` is the reference's DEFAULT (R/config/asr_finetuning.yaml:1-11; R/config/model/whisper-large.yaml:
+    openai/whisper-large-v3): 32 + 32 layers, d 1280, 20 heads, 128 mel bins, vocabulary 51 866 - the one CoRal key whose
+    decoder is as deep as its encoder.  (large-v3's prefix ids: the task / timestamp tokens sit one higher than in the
+    older vocabularies.)"""
+    from coral_amd.whisper import CORAL_WHISPER_SHAPES
+
+    kw = CORAL_WHISPER_SHAPES["whisper-large"]
+    assert (kw["encoder_layers"], kw["decoder_layers"], kw["num_mel_bins"], kw["vocab_size"]) == (32, 32, 128, 51866)
+    _whisper_full_depth_one_clip("whisper-large", [50258, 50285, 50360, 50364], seed=22)
+
+
+def test_whisper_large_training_step_at_the_reference_batch_of_64():
+    """The reference trains its default model at per_device_batch_size = 64 (R/makefile:109-137) WITH gradient
+    checkpointing (R/config/asr_finetuning.yaml:73): 80-GB devices cannot keep 32 + 32 layers x 64 clips x 1500 frames of
+    activations.  This engine keeps every activation resident - the test runs that step at full size,
+    measures what it holds (printed: the peak device memory of forward + backward, parameters and gradients included) and
+    checks the batch through size-independent properties: the loss of the 64 clips equals the token-weighted mean of the
+    eight 8-clip losses (clips never mix), gradients are finite and the encoder / decoder ends both received them."""
+    from coral_amd.whisper import CORAL_WHISPER_SHAPES, WhisperShape
+    from coral_amd.whisper_train import WhisperTrainEngine
+
+    torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats()
+    kw = dict(CORAL_WHISPER_SHAPES["whisper-large"])
+    eng = WhisperTrainEngine(WhisperShape(**kw), DEV)
+    g = torch.Generator(device=DEV).manual_seed(64)
+    for n in eng.store.names():
+        v = eng.store.view(n)
+        if n.endswith("layer_norm.weight"):
+            v.fill_(1.0)
+        elif n.endswith(".bias") or n.endswith("__zero"):
+            v.zero_()
+        else:
+            v.normal_(0.0, 0.02, generator=g)
+    eng.refresh_compute_weights()
+    eng.train(False)  # (dropout off: the 8-clip runs must see the arithmetic of the 64-clip run)
+    gen = torch.Generator().manual_seed(65)
+    B, L = 64, 48
+    feats = torch.randn(B, 128, 3000, generator=gen) * 0.5
+    labels = torch.randint(0, 50257, (B, L), generator=gen)
+    for b in range(B):
+        labels[b, int(torch.randint(16, L + 1, (1,), generator=gen)):] = -100
+    eng.zero_grad()
+    out = eng.forward_train(feats, labels)
+    eng.backward()
+    torch.cuda.synchronize()
+    peak = torch.cuda.max_memory_allocated() / 2 ** 30
+    loss64 = float(out["loss"])
+    g32 = eng.store.g32
+    assert np.isfinite(loss64) and bool(torch.isfinite(g32).all())
+    gd = eng.grad_dict()
+    for n in ("model.encoder.conv1.weight", "model.encoder.layers.0.self_attn.q_proj.weight",
+              "model.decoder.layers.31.fc2.weight", "model.decoder.embed_tokens.weight"):
+        assert float(gd[n].abs().max()) > 0.0, n
+    tot, cnt = 0.0, 0
+    for i in range(0, B, 8):
+        o8 = eng.forward_train(feats[i:i + 8], labels[i:i + 8])
+        n8 = int((labels[i:i + 8] >= 0).sum())
+        tot += float(o8["loss"]) * n8
+        cnt += n8
+    rel = abs(tot / cnt - loss64) / loss64
+    nparam = eng.store.numel
+    print(f"\nwhisper-large (32 + 32 L), training step at B = 64 x 30 s, {L} label positions: peak device memory "
+          f"{peak:.1f} GiB of 288 (parameters: {nparam / 1e9:.2f} B = {nparam * 10 / 2 ** 30:.1f} GiB of fp32 master + "
+          f"gradient + bf16 copy), loss {loss64:.5f}, eight 8-clip batches give {tot / cnt:.5f} (rel {rel:.1e})")
+    assert rel <= 2e-5, rel
+    assert peak < 270.0
+    del eng, out, gd, g32
     torch.cuda.empty_cache()
 
 
