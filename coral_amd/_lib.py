@@ -70,6 +70,7 @@ class CaGemmDesc(C.Structure):
         ("b_scale", C.c_void_p),
         ("a_row_scale", C.c_void_p),
         ("c_sumsq", C.c_void_p),
+        ("c_stream_out", C.c_int32),
     ]
 
 

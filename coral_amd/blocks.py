@@ -238,12 +238,12 @@ class FFNBlock:
                                   stats=sv["st"])
             ops.gemm_fp8(x8, p8, sv["u"], C2=sv["g"], a_row_scale=rs, b_scale=scale, M=M, N=f, K=d, lda=d, ldb=d, ldc=f,
                          b_off=st.off(self.fc1 + ".weight"), bias=st.p32, bias_off=st.off(self.fc1 + ".bias"),
-                         epilogue=EPI_GELU, dropout_p=dropout_p, dropout_seed=seed)
+                         epilogue=EPI_GELU, dropout_p=dropout_p, dropout_seed=seed, stream_out=ops.STREAM_U)
         else:
             ops.layernorm_fwd(hin, st.view(self.ln + ".weight"), st.view(self.ln + ".bias"), sv["x"], sv["st"], M, d, self.eps)
             ops.gemm(sv["x"], st.p16, sv["u"], C2=sv["g"], M=M, N=f, K=d, lda=d, ldb=d, ldc=f, b_off=st.off(self.fc1 + ".weight"),
                      bias=st.p32, bias_off=st.off(self.fc1 + ".bias"), epilogue=EPI_GELU, dropout_p=dropout_p,
-                     dropout_seed=seed)
+                     dropout_seed=seed, stream_out=ops.STREAM_U)
         ops.gemm(sv["g"], st.p16, hout, M=M, N=d, K=f, lda=f, ldb=f, ldc=d, b_off=st.off(self.fc2 + ".weight"), bias=st.p32,
                  bias_off=st.off(self.fc2 + ".bias"), epilogue=EPI_RESIDUAL, R=hin, ldr=d, dropout_p=hdrop[0],
                  dropout_seed=hdrop[1])

@@ -467,11 +467,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 // kernel; 256 queries x 8 waves x 4 pairs (one workgroup per CU) measured the same or slower, so only the former is
 // instantiated.
 template <int N>
+using IC = std::integral_constant<int, N>;
+template <int N>
 __device__ __forceinline__ void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
-template <int HDPV, bool DROP, int NW, int NST>
-__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_fwd_wide_kernel(const AttnArgs a) {
+// WPE = workgroups (waves per SIMD) the register budget is held to.  Round 4: the kernel is bound by vector-instruction
+// issue with both waves of a SIMD stalled ~35 % of the time (LDS fragment reads, the per-tile barrier, MFMA results), and
+// a THIRD resident wave hides most of that: the head_dim <= 64 form holds 154 registers (512 / 3 = 170), so it runs three
+// workgroups per CU - whisper-medium encoder forward 136 -> 124 us per layer, whisper-large-turbo 166 -> 148
+// (tools/exp_attn_env.sh, interleaved).  Measured and dropped on the way: forming the scores of tile kt + 1 under the
+// softmax of tile kt inside one wave (a third image pair and a second score set, 230 registers: 5 % SLOWER - the
+// co-resident waves already overlap the two pipes, what is short is issue slots), and four waves per SIMD at 128
+// registers (27 spilled dwords: 183 us).
+template <int HDPV, bool DROP, int NW, int NST, int WPE = 2>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void attn_fwd_wide_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NQ = 2, NKS = HDPV / 32, NNB = HDPV / 16;
   constexpr int IMG = 64 * HDPV * 2, PAIR = 2 * IMG;  // a tile = K-major image of the keys + MN-major image of the values
@@ -549,13 +559,12 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
       voff[nb] = (uint32_t)(uintptr_t)(lptr_t)smem + IMG + (8 * g + q4) * (HDPV * 2) + c * 16 + (p4 & 1) * 8;
     }
   }
-  auto tile_body = [&](auto full_c, int kt, int stage) __attribute__((always_inline)) {
-    constexpr bool FULL = decltype(full_c)::value;
+  // transposed scores of the 64 keys of the tile in image pair `stage`: block (s, bb) holds keys 32 s + 8 g + 4 bb +
+  // {0..3} of query qi
+  auto qk_tile = [&](int stage, f32x4_t (&sc)[NQ][4], auto b0_c, auto b1_c) __attribute__((always_inline)) {
     const char* Kimg = smem + stage * PAIR;
-    // transposed scores of the 64 keys: block (s, bb) holds keys 32 s + 8 g + 4 bb + {0..3} of query qi
-    f32x4_t sc[NQ][4];
 #pragma unroll
-    for (int blk = 0; blk < 4; ++blk) {
+    for (int blk = decltype(b0_c)::value; blk < decltype(b1_c)::value; ++blk) {
       const int row = 32 * (blk >> 1) + rowperm(blk & 1, r);
 #pragma unroll
       for (int j = 0; j < NQ; ++j) sc[j][blk] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
@@ -566,9 +575,13 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         for (int j = 0; j < NQ; ++j) sc[j][blk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr, qf[j][ks], sc[j][blk], 0, 0, 0);
       }
     }
-    bf16x8_t pf[NQ][2];
-#pragma unroll
-    for (int j = 0; j < NQ; ++j) {
+  };
+  // softmax of the tile's scores (consumed) and the P V product into o
+  // softmax of query block j of the tile's scores (consumed): probabilities as the packed A operands pf[j][0..1]
+  auto soft_one = [&](auto full_c, int kt, f32x4_t (&sc)[NQ][4], auto j_c, bf16x8_t (&pf)[NQ][2]) __attribute__((always_inline)) {
+    constexpr bool FULL = decltype(full_c)::value;
+    constexpr int j = decltype(j_c)::value;
+    {
       if constexpr (!FULL) {
 #pragma unroll
         for (int blk = 0; blk < 4; ++blk)
@@ -665,6 +678,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         pf[j][s] = pack8(ps);
       }
     }
+  };
+  // the P V product of the tile in image pair `stage` into o
+  auto pv_tile = [&](int stage, bf16x8_t (&pf)[NQ][2]) __attribute__((always_inline)) {
     // value fragments in batches of four column blocks; the next batch is in flight while the current one is used
     // (inline-asm reads: the builtin would be ordered behind the LDS-DMA of the tiles in flight)
     constexpr int NBATCH = 2 * NNB / 4, PITCH = HDPV * 2;
@@ -704,27 +720,38 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
       step(std::integral_constant<int, 3>{}, fb, fa);
     }
   };
-  // tile kt lives in image pair kt % NST; tiles kt + 1 .. kt + NST - 2 stay in flight across the wait for tile kt, and
-  // the request for tile kt + NST - 1 goes out right after the barrier that frees its pair (one barrier per tile)
-  int stage = 0;
-  auto run = [&](auto full_c, int kt0, int kt1) __attribute__((always_inline)) {
-    for (int kt = kt0; kt < kt1; ++kt) {
-      const int ahead = ntile - 1 - kt;
-      if (NST >= 4 && ahead >= 2)
-        wait_vm<2 * DPT>();
-      else if (NST >= 3 && ahead >= 1)
-        wait_vm<DPT>();
-      else
-        wait_vm<0>();
-      __syncthreads();
-      if (kt + NST - 1 < ntile) issue(kt + NST - 1, stage == 0 ? NST - 1 : stage - 1);
-      tile_body(full_c, kt, stage);
-      stage = stage + 1 == NST ? 0 : stage + 1;
-    }
+  auto soft_pv = [&](auto full_c, int kt, int stage, f32x4_t (&sc)[NQ][4]) __attribute__((always_inline)) {
+    bf16x8_t pf[NQ][2];
+    soft_one(full_c, kt, sc, std::integral_constant<int, 0>{}, pf);
+    soft_one(full_c, kt, sc, std::integral_constant<int, 1>{}, pf);
+    static_assert(NQ == 2, "two query blocks per wave");
+    pv_tile(stage, pf);
   };
   const int nfull = a.causal ? 0 : (kl / 64 < ntile ? kl / 64 : ntile);
-  run(std::true_type{}, 0, nfull);
-  run(std::false_type{}, nfull, ntile);
+  int stage = 0;
+  {
+    // tile kt lives in image pair kt % NST; tiles kt + 1 .. kt + NST - 2 stay in flight across the wait for tile kt, and
+    // the request for tile kt + NST - 1 goes out right after the barrier that frees its pair (one barrier per tile)
+    auto run = [&](auto full_c, int kt0, int kt1) __attribute__((always_inline)) {
+      for (int kt = kt0; kt < kt1; ++kt) {
+        const int ahead = ntile - 1 - kt;
+        if (NST >= 4 && ahead >= 2)
+          wait_vm<2 * DPT>();
+        else if (NST >= 3 && ahead >= 1)
+          wait_vm<DPT>();
+        else
+          wait_vm<0>();
+        __syncthreads();
+        if (kt + NST - 1 < ntile) issue(kt + NST - 1, stage == 0 ? NST - 1 : stage - 1);
+        f32x4_t sc[NQ][4];
+        qk_tile(stage, sc, IC<0>{}, IC<4>{});
+        soft_pv(full_c, kt, stage, sc);
+        stage = stage + 1 == NST ? 0 : stage + 1;
+      }
+    };
+    run(std::true_type{}, 0, nfull);
+    run(std::false_type{}, nfull, ntile);
+  }
   __syncthreads();  // every wave is done with the images: the LDS becomes output staging
   unsigned short* O = a.O + b * a.sob + h * hd;
   char* st = smem + wave * (16 * (HDPV * 2 + 16));
@@ -1286,8 +1313,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a) {
 // workgroups per CU the LDS, not the matrix pipe, sets the pace (768 LDS cycles against 512 MFMA cycles per step).
 // Here a wave owns KB = 2 key blocks: each fragment feeds two MFMAs, a workgroup covers 128 keys, half as many
 // workgroups stream the same Q / dO images.
-template <int HDPV, bool DROP, int KB>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_wide_kernel(const AttnArgs a) {
+template <int HDPV, bool DROP, int KB, int WPE = 2>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void attn_bwd_dkv_wide_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NKS = HDPV / 32, NNB = HDPV / 16;
   constexpr int IMG = 32 * HDPV * 2;
@@ -1581,8 +1608,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 // ---- backward: dQ, wide workgroups (same reasoning and ring as attn_fwd_wide_kernel) -----------------------------------
 // NW waves x 32 queries; per 64-key tile a K-major image of K (S^T = K Q^T and, read transposed, dQ += dS K) and one of
 // V (dP^T = V dO^T): every fragment read feeds the MFMAs of both 16-query blocks of the wave.
-template <int HDPV, bool DROP, int NW, int NST>
-__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_dq_wide_kernel(const AttnArgs a) {
+template <int HDPV, bool DROP, int NW, int NST, int WPE = 2>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void attn_bwd_dq_wide_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NQ = 2, NKS = HDPV / 32, NNB = HDPV / 16;
   constexpr int IMG = 64 * HDPV * 2, PAIR = 2 * IMG;
@@ -1796,6 +1823,14 @@ extern "C" int ca_attn_fwd(const CaAttnDesc* desc, void* stream) {
 #define CA_FWD_WIDE(HDPV, DROP)                                                                                   \
   hipLaunchKernelGGL((attn_fwd_wide_kernel<HDPV, DROP, 4, 2>), dim3(attn_grid((desc->Tq + 127) / 128, desc->H, desc->B)), \
                      dim3(256), 2 * 2 * 64 * HDPV * 2, s, a)
+    // head_dim <= 64 without dropout: three workgroups per CU (see the kernel's header); CA_ATTN_WPE3=0 keeps two (A/B)
+    static const int wpe3 = [] { const char* e = getenv("CA_ATTN_WPE3"); return e ? atoi(e) : 1; }();
+    if (desc->hd <= 64 && wpe3 && !drop) {
+      hipLaunchKernelGGL((attn_fwd_wide_kernel<64, false, 4, 2, 3>), dim3(attn_grid((desc->Tq + 127) / 128, desc->H, desc->B)),
+                         dim3(256), 2 * 2 * 64 * 64 * 2, s, a);
+      CA_CHECK_LAUNCH("ca_attn_fwd");
+      return CA_OK;
+    }
     if (desc->hd <= 64) {
       if (drop) CA_FWD_WIDE(64, true); else CA_FWD_WIDE(64, false);
     } else {
@@ -1884,6 +1919,11 @@ extern "C" int ca_attn_bwd(const CaAttnDesc* desc, void* stream) {
                        (const unsigned short*)desc->dO, desc->lddo, desc->sdob, (const unsigned short*)desc->O,
                        desc->ldo, desc->sob, (float*)desc->Dq, desc->H, desc->Tq, desc->Tqp, desc->hd, desc->B);
   }
+  static const int dq_wpe3 = [] { const char* e = getenv("CA_ATTN_DQ_WPE3"); return e ? atoi(e) : 1; }();
+  if (dq_wide && dq_wpe3 && desc->hd <= 64 && !drop) {
+    hipLaunchKernelGGL((attn_bwd_dq_wide_kernel<64, false, 4, 2, 3>), dim3(attn_grid((desc->Tq + 127) / 128, desc->H, desc->B)),
+                       dim3(256), 2 * 2 * 64 * 64 * 2, s, a);
+  } else
 #define CA_DQ(HDPV, DROP)                                                                                          \
   do {                                                                                                             \
     if (dq_wide)                                                                                                   \
@@ -1908,6 +1948,11 @@ extern "C" int ca_attn_bwd(const CaAttnDesc* desc, void* stream) {
   // head_dim 80 / 120 the doubled accumulators (374 registers) leave one wave per SIMD and it LOSES (73.3 -> 83.7 us):
   // the 64-key kernel stays there.
   const bool dkv_wide = dkv_wide_on && desc->Tk >= 100 && desc->hd <= 64;
+  static const int dkv_wpe3 = [] { const char* e = getenv("CA_ATTN_DKV_WPE3"); return e ? atoi(e) : 0; }();
+  if (dkv_wide && dkv_wpe3 && desc->hd <= 64 && !drop) {
+    hipLaunchKernelGGL((attn_bwd_dkv_wide_kernel<64, false, 2, 3>), dim3(attn_grid((desc->Tk + 127) / 128, desc->H, desc->B)),
+                       block, 4 * 32 * 64 * 2, s, a);
+  } else
 #define CA_DKV(HDPV, DROP)                                                                                            \
   do {                                                                                                               \
     if (dkv_wide)                                                                                                    \

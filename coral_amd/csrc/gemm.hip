@@ -473,15 +473,23 @@ __device__ __forceinline__ void gemm_epilogue_fast(const CaGemmDesc& d, const fl
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += e < 4 ? c0v[e] : c1v[e - 4];
       }
-      *(f32x4_t*)C = (f32x4_t){v[0], v[1], v[2], v[3]};
-      *(f32x4_t*)(C + 4) = (f32x4_t){v[4], v[5], v[6], v[7]};
+      if (d.c_stream_out) {
+        __builtin_nontemporal_store((f32x4_t){v[0], v[1], v[2], v[3]}, (f32x4_t*)C);
+        __builtin_nontemporal_store((f32x4_t){v[4], v[5], v[6], v[7]}, (f32x4_t*)(C + 4));
+      } else {
+        *(f32x4_t*)C = (f32x4_t){v[0], v[1], v[2], v[3]};
+        *(f32x4_t*)(C + 4) = (f32x4_t){v[4], v[5], v[6], v[7]};
+      }
 #pragma unroll
       for (int e = 0; e < 8; ++e) ssq = fmaf(v[e], v[e], ssq);
     } else {
       u16x8_t o;
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e]);
-      *(u16x8_t*)((unsigned short*)d.C + coff) = o;
+      if (d.c_stream_out)
+        __builtin_nontemporal_store(o, (u16x8_t*)((unsigned short*)d.C + coff));
+      else
+        *(u16x8_t*)((unsigned short*)d.C + coff) = o;
     }
     if (EPI == CA_EPI_GELU) {
       u16x8_t o;

@@ -44,8 +44,9 @@ def _gemm_desc(A, B, Cout, *, M, N, K, lda, ldb, ldc, a_layout=KMAJOR, b_layout=
          sA=(0, 0), sB=(0, 0), sC=(0, 0), sR=(0, 0), sBias=(0, 0), a_kseg=0, a_kseg_stride=0, b_kseg=0,
          b_kseg_stride=0, dropout_p=0.0, dropout_seed=0, a_colsum=None, a_colsum_off=0,
          a_colsum_ld=0, c_row_index=None, c_row_mul=0, c_split_n=0, C_hi=None, c_hi_off=0, ldc_hi=0,
-         c_sumsq=None, c_sumsq_off=0):
+         c_sumsq=None, c_sumsq_off=0, stream_out=False):
     d = CaGemmDesc()
+    d.c_stream_out = int(stream_out)
     if c_sumsq is not None:
         d.c_sumsq = _p(c_sumsq, c_sumsq_off)
     if c_split_n:
@@ -115,6 +116,10 @@ def quantize_fp8(x, q, inv_scale, amax_ws, n=None):
 
 
 COLSUM_PARTS = 8  # rows of the fused bias-gradient partials (CaGemmDesc.a_colsum)
+# CaGemmDesc.c_stream_out for outputs that are not read again soon: the FFN pre-activation (kept for the backward) and the
+# weight gradients (read by the optimiser a backward later).  CA_STREAM_U=0 / CA_STREAM_WGRAD=0: default-policy stores (A/B)
+STREAM_U = os.environ.get("CA_STREAM_U", "1") == "1"
+STREAM_WGRAD = os.environ.get("CA_STREAM_WGRAD", "1") == "1"
 
 
 def _wgrad_splits(M, N, K):
@@ -151,7 +156,7 @@ def wgrad_gemm(dY, X, G, *, M, N, K, lda, ldb, c_off, accumulate, a_off=0, b_off
         if sq is not None:
             kw.update(c_sumsq=sq[0], c_sumsq_off=sq[1])
         gemm(dY, X, G, M=M, N=N, K=K, a_layout=MNMAJOR, lda=lda, b_layout=MNMAJOR, ldb=ldb, ldc=N, c_off=c_off,
-             a_off=a_off, b_off=b_off, out_f32=True, accumulate=accumulate, **kw)
+             a_off=a_off, b_off=b_off, out_f32=True, accumulate=accumulate, stream_out=STREAM_WGRAD, **kw)
         return
     ws = _SPLITK_WS.get(G.device)
     if ws is None or ws.numel() < splits * M * N:
@@ -279,7 +284,7 @@ def wgrad_gemm_group(problems: list, G, colsum_ws=None, colsum_ld=0) -> bool:
                 kw.update(c_sumsq=p["sq"][0], c_sumsq_off=p["sq"][1])
             arr[i] = _gemm_desc(p["dY"], p["X"], G, M=p["M"], N=p["N"], K=p["K"], a_layout=MNMAJOR, lda=p["lda"],
                                 b_layout=MNMAJOR, ldb=p["ldb"], ldc=p["N"], c_off=p["c_off"], out_f32=True,
-                                accumulate=p["accumulate"], **kw)
+                                accumulate=p["accumulate"], stream_out=STREAM_WGRAD, **kw)
         check(lib().ca_gemm_bf16_group(arr, len(chunk), _stream()), "ca_gemm_bf16_group")
         if fused:
             dirty.update((p["cs_off"], p["M"]) for p in chunk)

@@ -605,7 +605,7 @@ class Wav2Vec2CTCEngine:
             ops.gemm(w["x2"][l], p16, w["u"][l], C2=w["g"][l], M=M, N=f, K=d, lda=d, ldb=d, ldc=f,
                      b_off=o(pl + "feed_forward.intermediate_dense.weight"), bias=p32,
                      bias_off=o(pl + "feed_forward.intermediate_dense.bias"), epilogue=EPI_GELU,
-                     dropout_p=drop_p, dropout_seed=self.step_seed * 1000 + l)
+                     dropout_p=drop_p, dropout_seed=self.step_seed * 1000 + l, stream_out=ops.STREAM_U)
             ops.gemm(w["g"][l], p16, hout, M=M, N=d, K=f, lda=f, ldb=f, ldc=d,
                      b_off=o(pl + "feed_forward.output_dense.weight"), bias=p32,
                      bias_off=o(pl + "feed_forward.output_dense.bias"), epilogue=EPI_RESIDUAL,

@@ -149,7 +149,7 @@ def test_rccl_one_rank_group_reproduces_the_plain_trainer(tmp_path):
     pc = res["plain_clip"]
     for k in ("fp32_clip", "zero_clip"):
         assert pc["losses"] == res[k]["losses"] and abs(pc["norms"][0] - res[k]["norms"][0]) <= 1e-6 * pc["norms"][0]
-        assert float((pc["p32"] - res[k]["p32"]).abs().max()) <= 1e-7, k
+        assert float((pc["p32"] - res[k]["p32"]).abs().max()) <= 5e-7, k  # (one ulp of a parameter near 1 is 1.2e-7)
         assert float((pc["p16"] != res[k]["p16"]).float().mean()) <= 1e-4, k
     assert float((pc["p32"] - plain["p32"]).abs().max()) > 0  # (the clip did act: norm ~ 950)
     # bf16 wire: one rounding of the gradients to 8 bits
