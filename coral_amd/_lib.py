@@ -71,6 +71,9 @@ class CaGemmDesc(C.Structure):
         ("a_row_scale", C.c_void_p),
         ("c_sumsq", C.c_void_p),
         ("c_stream_out", C.c_int32),
+        ("C8", C.c_void_p),
+        ("c8_scale", C.c_void_p),
+        ("c8_amax", C.c_void_p),
     ]
 
 
@@ -104,6 +107,8 @@ SIGNATURES = {
     "ca_gemm_bf16": (C.c_int, [C.POINTER(CaGemmDesc), _vp]),
     "ca_gemm_fp8": (C.c_int, [C.POINTER(CaGemmDesc), _vp]),
     "ca_quantize_fp8": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
+    "ca_quantize_fp8_delayed": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
+    "ca_fp8_amax_rotate": (C.c_int, [_vp, _vp, _vp, _i32, _f32, _vp]),
     "ca_gemm_force_kernel": (C.c_int, [C.c_int]),
     "ca_gemm_debug_general_epilogue": (C.c_int, [C.c_int]),
     "ca_prof_begin": (C.c_int, []),

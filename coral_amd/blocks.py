@@ -232,21 +232,29 @@ class FFNBlock:
     def forward(self, hin, hout, sv, M, dropout_p=0.0, seed=0, hdrop=(0.0, 0)):
         st, d, f = self.st, self.d, self.f
         fp8 = getattr(self, "fp8", None)
+        fc2_8 = getattr(self, "fp8_fc2", None) if fp8 is not None else None
         if fp8 is not None:
             p8, scale, x8, rs = fp8
             ops.layernorm_fwd_fp8(hin, st.view(self.ln + ".weight"), st.view(self.ln + ".bias"), sv["x"], x8, rs, M, d, self.eps,
                                   stats=sv["st"])
+            # (fc2 on the fp8 path: the GELU output also leaves fc1's epilogue as e4m3, delayed per-tensor scale)
+            c8 = dict(C8=fc2_8[0], c8_scale=fc2_8[1], c8_amax=fc2_8[3]) if fc2_8 is not None else {}
             ops.gemm_fp8(x8, p8, sv["u"], C2=sv["g"], a_row_scale=rs, b_scale=scale, M=M, N=f, K=d, lda=d, ldb=d, ldc=f,
                          b_off=st.off(self.fc1 + ".weight"), bias=st.p32, bias_off=st.off(self.fc1 + ".bias"),
-                         epilogue=EPI_GELU, dropout_p=dropout_p, dropout_seed=seed, stream_out=ops.STREAM_U)
+                         epilogue=EPI_GELU, dropout_p=dropout_p, dropout_seed=seed, stream_out=ops.STREAM_U, **c8)
         else:
             ops.layernorm_fwd(hin, st.view(self.ln + ".weight"), st.view(self.ln + ".bias"), sv["x"], sv["st"], M, d, self.eps)
             ops.gemm(sv["x"], st.p16, sv["u"], C2=sv["g"], M=M, N=f, K=d, lda=d, ldb=d, ldc=f, b_off=st.off(self.fc1 + ".weight"),
                      bias=st.p32, bias_off=st.off(self.fc1 + ".bias"), epilogue=EPI_GELU, dropout_p=dropout_p,
                      dropout_seed=seed, stream_out=ops.STREAM_U)
-        ops.gemm(sv["g"], st.p16, hout, M=M, N=d, K=f, lda=f, ldb=f, ldc=d, b_off=st.off(self.fc2 + ".weight"), bias=st.p32,
-                 bias_off=st.off(self.fc2 + ".bias"), epilogue=EPI_RESIDUAL, R=hin, ldr=d, dropout_p=hdrop[0],
-                 dropout_seed=hdrop[1])
+        if fc2_8 is not None:
+            ops.gemm_fp8(fc2_8[0], fp8[0], hout, a_scale=fc2_8[2], b_scale=fc2_8[4], M=M, N=d, K=f, lda=f, ldb=f, ldc=d,
+                         b_off=st.off(self.fc2 + ".weight"), bias=st.p32, bias_off=st.off(self.fc2 + ".bias"),
+                         epilogue=EPI_RESIDUAL, R=hin, ldr=d, dropout_p=hdrop[0], dropout_seed=hdrop[1])
+        else:
+            ops.gemm(sv["g"], st.p16, hout, M=M, N=d, K=f, lda=f, ldb=f, ldc=d, b_off=st.off(self.fc2 + ".weight"), bias=st.p32,
+                     bias_off=st.off(self.fc2 + ".bias"), epilogue=EPI_RESIDUAL, R=hin, ldr=d, dropout_p=hdrop[0],
+                     dropout_seed=hdrop[1])
         sv["hin"], sv["drop"], sv["hdrop"] = hin, (dropout_p, seed), hdrop
 
     def backward(self, dh, dhin, sv, sc: Scratch, M, defer=None, acc=True, sq=None, ln_part=None, pending=None):

@@ -407,6 +407,22 @@ __device__ __forceinline__ void epi_load_bias(const CaGemmDesc& d, int lane, int
     }
   }
 }
+// CaGemmDesc.C8: eight consecutive activations as e4m3 with the delayed per-tensor scale; the lane's running max|v|
+__device__ __forceinline__ void ca_store_fp8x8(unsigned char* dst, const float (&v)[8], float scale, float& amx) {
+  float t[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    amx = fmaxf(amx, fabsf(v[e]));
+    t[e] = fminf(fmaxf(v[e] * scale, -448.0f), 448.0f);
+  }
+  unsigned int w0 = 0, w1 = 0;
+  w0 = __builtin_amdgcn_cvt_pk_fp8_f32(t[0], t[1], w0, false);
+  w0 = __builtin_amdgcn_cvt_pk_fp8_f32(t[2], t[3], w0, true);
+  w1 = __builtin_amdgcn_cvt_pk_fp8_f32(t[4], t[5], w1, false);
+  w1 = __builtin_amdgcn_cvt_pk_fp8_f32(t[6], t[7], w1, true);
+  *(uint2*)dst = make_uint2(w0, w1);
+}
+
 // ---- fast epilogue: a 64 x 64 wave tile that lies wholly inside the output, 16-byte aligned rows -------------------
 // The general walk below decides everything per lane and per pass at run time (ragged columns, rows beyond M, which
 // epilogue, unaligned dropout groups, both output types): ~400 vector instructions per pass of 8 elements per lane in
@@ -418,7 +434,8 @@ __device__ __forceinline__ void epi_load_bias(const CaGemmDesc& d, int lane, int
 // of one launch against the same reference).
 template <int EPI, bool F32, bool DROP>
 __device__ __forceinline__ void gemm_epilogue_fast(const CaGemmDesc& d, const float* wt, int lane, int mw, int nb, int z,
-                                                   int64_t zoffC, int64_t zoffR, const float (&bias8)[8], float& ssq) {
+                                                   int64_t zoffC, int64_t zoffR, const float (&bias8)[8], float& ssq,
+                                                   float& amx) {
   const int M = d.M, N = d.N;
   const float alpha = d.alpha;
   const float keep_scale = DROP ? 1.f / (1.f - d.dropout_p) : 1.f;
@@ -432,6 +449,8 @@ __device__ __forceinline__ void gemm_epilogue_fast(const CaGemmDesc& d, const fl
   const uint64_t istep = 8ull * (uint64_t)N;
   u16x8_t r_next = {0, 0, 0, 0, 0, 0, 0, 0};
   if (NEEDS_R) r_next = *(const u16x8_t*)Rp;
+  const bool c8_on = EPI == CA_EPI_GELU && d.C8 != nullptr;  // (wave-uniform)
+  const float s8 = c8_on ? d.c8_scale[0] : 1.f;
 #pragma unroll 2
   for (int it = 0; it < 8; ++it) {
     const u16x8_t r_cur = r_next;
@@ -496,6 +515,7 @@ __device__ __forceinline__ void gemm_epilogue_fast(const CaGemmDesc& d, const fl
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] = f2bf(v2[e]);
       *(u16x8_t*)((unsigned short*)d.C2 + coff) = o;
+      if (c8_on) ca_store_fp8x8((unsigned char*)d.C8 + coff, v2, s8, amx);
     }
     coff += cstep;
     idx += istep;
@@ -547,15 +567,18 @@ __device__ __forceinline__ void gemm_epilogue(const CaGemmDesc& d, f32x4_t (&acc
         *(f32x4_t*)(wt + (i * 16 + (lane & 15)) * EPI_PITCH + j * 16 + 4 * (lane >> 4)) = acc[i][j];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private region: no barrier
   }
-  if (nvalid <= 0 && d.c_sumsq == nullptr) return;
+  const bool c8_on = d.C8 != nullptr && epi == CA_EPI_GELU;
+  if (nvalid <= 0 && d.c_sumsq == nullptr && !c8_on) return;
   float ssq = 0.f;  // sum of squares of the fp32 values this lane stores (c_sumsq)
+  float amx = 0.f;  // max |gelu| this lane stores (C8)
+  const float s8 = c8_on ? d.c8_scale[0] : 1.f;
   // interior wave tile (wave-uniform test): the specialised walk above
   const bool drop_on = d.dropout_p > 0.f;
   const bool interior = g_ca_epi_general == 0 && mw + 64 <= M && nw + 64 <= N && vec_ok && (N & 7) == 0 && d.C != nullptr &&
                         (d.out_f32 || !d.accumulate) && (!has_gelu || (epi == CA_EPI_GELU && d.C2 != nullptr && !d.out_f32)) &&
                         !(d.out_f32 && epi != CA_EPI_NONE) && !(drop_on && epi == CA_EPI_NONE);
   if (interior) {
-#define EPI_FAST(E, F, D) gemm_epilogue_fast<E, F, D>(d, wt, lane, mw, nb, z, zoffC, zoffR, bias8, ssq)
+#define EPI_FAST(E, F, D) gemm_epilogue_fast<E, F, D>(d, wt, lane, mw, nb, z, zoffC, zoffR, bias8, ssq, amx)
     if (d.out_f32) {
       EPI_FAST(CA_EPI_NONE, true, false);
     } else if (epi == CA_EPI_NONE) {
@@ -684,6 +707,20 @@ __device__ __forceinline__ void gemm_epilogue(const CaGemmDesc& d, f32x4_t (&acc
           if (e < nvalid) C2[e] = f2bf(v2[e]);
       }
     }
+    if (c8_on) {
+      unsigned char* C8 = (unsigned char*)d.C8 + coff;
+      if (full) {
+        ca_store_fp8x8(C8, v2, s8, amx);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (e < nvalid) {
+            amx = fmaxf(amx, fabsf(v2[e]));
+            const float t = fminf(fmaxf(v2[e] * s8, -448.0f), 448.0f);
+            C8[e] = (unsigned char)(__builtin_amdgcn_cvt_pk_fp8_f32(t, 0.f, 0u, false) & 0xffu);
+          }
+      }
+    }
   }
   }  // general walk
   if (d.c_sumsq != nullptr) {
@@ -691,6 +728,14 @@ __device__ __forceinline__ void gemm_epilogue(const CaGemmDesc& d, f32x4_t (&acc
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) ssq += __shfl_xor(ssq, o, 64);
     if (lane == 0 && mw < M && nw < N) d.c_sumsq[(int64_t)(mw >> 6) * ((N + 63) >> 6) + (nw >> 6)] = ssq;
+  }
+  if (c8_on && d.c8_amax != nullptr) {
+    // (every lane of the wave arrives here; a maximum does not depend on the order: the same bits on every run)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amx = fmaxf(amx, __shfl_xor(amx, o, 64));
+    // (spread over the accumulator's words: the 15 000 wave tiles of a 12 000 x 5 120 output on one address took 200 us)
+    if (lane == 0 && amx > 0.f)
+      atomicMax((unsigned int*)d.c8_amax + (((mw >> 6) * 7 + (nw >> 6)) & (CA_FP8_AMAX_SLOTS - 1)), __float_as_uint(amx));
   }
 }
 
@@ -2150,6 +2195,9 @@ extern "C" int ca_gemm_fp8(const CaGemmDesc* desc, void* stream) {
   CA_CHECK_ARG(desc != nullptr, "ca_gemm_fp8: null descriptor");
   const CaGemmDesc& d = *desc;
   CA_CHECK_ARG(d.A && d.B && (d.C || d.C2) && d.M > 0 && d.N > 0 && d.K > 0, "ca_gemm_fp8: bad argument");
+  CA_CHECK_ARG(d.C8 == nullptr || (d.epilogue == CA_EPI_GELU && d.c8_scale != nullptr && (d.ldc % 8) == 0 &&
+                                   ((uintptr_t)d.C8 % 8) == 0),
+               "ca_gemm_fp8: C8 needs CA_EPI_GELU, a scale and 8-byte aligned rows");
   CA_CHECK_ARG(d.a_layout == CA_KMAJOR && d.b_layout == CA_KMAJOR && d.batch1 == 1 && d.batch2 == 1 && d.a_kseg == 0 &&
                    d.b_kseg == 0 && !d.a_colsum && !d.c_row_index,
                "ca_gemm_fp8: K-major operands, un-batched, plain rows only");
@@ -2291,6 +2339,9 @@ static int ca_gemm_launch(const CaGemmDesc* desc, void* stream) {
   if (d.epilogue == CA_EPI_RESIDUAL || d.epilogue == CA_EPI_DGELU || d.epilogue == CA_EPI_GELU_RESIDUAL)
     CA_CHECK_ARG(d.R != nullptr, "ca_gemm_bf16: epilogue needs R");
   CA_CHECK_ARG(d.dropout_p >= 0.f && d.dropout_p < 1.f, "ca_gemm_bf16: bad dropout_p");
+  CA_CHECK_ARG(d.C8 == nullptr || (d.epilogue == CA_EPI_GELU && d.c8_scale != nullptr && d.batch1 == 1 && d.batch2 == 1 &&
+                                   (d.ldc % 8) == 0 && ((uintptr_t)d.C8 % 8) == 0 && d.M > 32),
+               "ca_gemm_bf16: C8 needs CA_EPI_GELU, a scale, an un-batched problem and 8-byte aligned rows");
   if (d.a_colsum)
     CA_CHECK_ARG(d.a_layout == CA_MNMAJOR && d.b_layout == CA_MNMAJOR && d.batch1 == 1 && d.batch2 == 1 && d.a_kseg == 0,
                  "ca_gemm_bf16: a_colsum needs the un-batched weight-gradient form");

@@ -18,7 +18,8 @@ from ._lib import (CaAttnDesc, EPI_DGELU, EPI_GELU, EPI_GELU_RESIDUAL, EPI_NONE,
 __all__ = ["KMAJOR", "MNMAJOR", "EPI_NONE", "EPI_GELU", "EPI_RESIDUAL", "EPI_DGELU",
            "EPI_GELU_RESIDUAL", "CoralAmdError"]
 
-_ELT = {torch.bfloat16: 2, torch.float32: 4, torch.int32: 4, torch.uint8: 1, torch.int64: 8, torch.int16: 2}
+_ELT = {torch.bfloat16: 2, torch.float32: 4, torch.int32: 4, torch.uint8: 1, torch.int64: 8, torch.int16: 2,
+        torch.uint32: 4}
 
 
 def _stream() -> int:
@@ -44,9 +45,11 @@ def _gemm_desc(A, B, Cout, *, M, N, K, lda, ldb, ldc, a_layout=KMAJOR, b_layout=
          sA=(0, 0), sB=(0, 0), sC=(0, 0), sR=(0, 0), sBias=(0, 0), a_kseg=0, a_kseg_stride=0, b_kseg=0,
          b_kseg_stride=0, dropout_p=0.0, dropout_seed=0, a_colsum=None, a_colsum_off=0,
          a_colsum_ld=0, c_row_index=None, c_row_mul=0, c_split_n=0, C_hi=None, c_hi_off=0, ldc_hi=0,
-         c_sumsq=None, c_sumsq_off=0, stream_out=False):
+         c_sumsq=None, c_sumsq_off=0, stream_out=False, C8=None, c8_scale=None, c8_amax=None):
     d = CaGemmDesc()
     d.c_stream_out = int(stream_out)
+    if C8 is not None:  # third output of CA_EPI_GELU: the activation as e4m3 with a delayed per-tensor scale
+        d.C8, d.c8_scale, d.c8_amax = _p(C8), _p(c8_scale), _p(c8_amax)
     if c_sumsq is not None:
         d.c_sumsq = _p(c_sumsq, c_sumsq_off)
     if c_split_n:
@@ -107,6 +110,20 @@ def gemm_fp8(A8, B8, Cout, *, a_scale=None, b_scale=None, a_row_scale=None, **kw
     d = _gemm_desc(A8, B8, Cout, **kw)
     d.a_scale, d.b_scale, d.a_row_scale = _p(a_scale), _p(b_scale), _p(a_row_scale)
     check(lib().ca_gemm_fp8(C.byref(d), _stream()), "ca_gemm_fp8")
+
+
+FP8_AMAX_SLOTS = 64  # CA_FP8_AMAX_SLOTS: words per amax accumulator
+
+
+def quantize_fp8_delayed(x, q, scale, amax_next, n=None):
+    """One-pass quantisation with last step's scale (device scalar); this step's amax accumulates into amax_next."""
+    check(lib().ca_quantize_fp8_delayed(_p(x), x.numel() if n is None else n, _p(q), _p(scale), _p(amax_next), _stream()),
+          "ca_quantize_fp8_delayed")
+
+
+def fp8_amax_rotate(amax_next, scale, inv_scale, count, margin=1.0):
+    """amax words accumulated since the last rotation -> scales of the next step (zero words keep their old scale)."""
+    check(lib().ca_fp8_amax_rotate(_p(amax_next), _p(scale), _p(inv_scale), count, float(margin), _stream()), "ca_fp8_amax_rotate")
 
 
 def quantize_fp8(x, q, inv_scale, amax_ws, n=None):

@@ -69,38 +69,71 @@ class WhisperTrainEngine(WhisperEngine):
     # ---- fp8 forward projections (BASELINE.json configs[4]) ------------------------------------------
     _fp8_train = None
 
-    def enable_fp8_forward(self, on: bool = True):
-        """Training: the encoder's q|k|v and fc1 forward projections on the fp8 matrix instruction - e4m3 copies of
-        those weights (one scale per matrix, re-quantised after every optimiser step: refresh_bucket) and LayerNorm
-        outputs quantised per row by the LayerNorm kernel itself.  The backward is unchanged (bf16 weights and saved
-        bf16 activations, i.e. straight-through gradients)."""
+    def enable_fp8_forward(self, on: bool = True, ffn2: bool | None = None):
+        """Training: encoder forward projections on the fp8 matrix instruction (BASELINE configs[4]: "fp8 weights").
+        q|k|v and fc1 take their inputs from LayerNorm kernels that quantise per row in the same pass; fc2 (`ffn2`, on by
+        default; CA_FP8_FC2=0 switches it off) takes the GELU output as e4m3 straight from fc1's epilogue
+        (CaGemmDesc.C8) with a DELAYED per-tensor scale - the scale of step t from the amax of step t - 1, the fp8
+        training recipe - so no quantisation pass exists anywhere in the forward.  The e4m3 weight copies are refreshed
+        per bucket behind AdamW (refresh_bucket) in ONE pass each, also with delayed scales (ca_quantize_fp8_delayed; a
+        weight matrix moves by ~1e-4 of its range per step), and all scales turn over in one launch per step
+        (ca_fp8_amax_rotate).  out_proj stays bf16 (8 % of the forward FLOPs; its input comes out of the attention
+        kernel).  The backward is unchanged (bf16 weights and saved bf16 activations: straight-through gradients)."""
+        import os
+
         if not on:
             self._fp8_train = None
             for sa, ff in self.enc_blocks:
                 sa.fp8 = ff.fp8 = None
             return
-        st, dev = self.store, self.device
-        self._fp8_train = dict(p8=torch.zeros(st.numel, dtype=torch.uint8, device=dev),
-                               scales=torch.zeros(2 * self.s.encoder_layers, dtype=torch.float32, device=dev),
-                               ws=torch.zeros(1, dtype=torch.float32, device=dev), x8=None, rs=None)
+        st, dev, L = self.store, self.device, self.s.encoder_layers
+        if ffn2 is None:
+            ffn2 = os.environ.get("CA_FP8_FC2", "1") == "1"
+        nw = 3 * L  # weight tensors: q|k|v, fc1, fc2 per layer; then one activation (the GELU output) per layer
+        f8 = dict(p8=torch.zeros(st.numel, dtype=torch.uint8, device=dev), nw=nw, ffn2=ffn2,
+                  amax=torch.zeros((nw + L) * ops.FP8_AMAX_SLOTS, dtype=torch.int32, device=dev),
+                  scale=torch.ones(nw + L, dtype=torch.float32, device=dev),
+                  inv=torch.ones(nw + L, dtype=torch.float32, device=dev), x8=None, rs=None, g8=None)
+        # activations: a first guess (amax 8, margin 2) until the first step has measured them
+        f8["scale"][nw:] = 448.0 / 16.0
+        f8["inv"][nw:] = 16.0 / 448.0
+        self._fp8_train = f8
         self._tw_key = None  # the workspace hands the blocks their staging buffers
-        self.refresh_fp8()
+        self.refresh_fp8()                                   # (scale 1: measures every matrix's amax)
+        ops.fp8_amax_rotate(f8["amax"], f8["scale"], f8["inv"], nw, margin=1.0)
+        self.refresh_fp8()                                   # the real copies
+        ops.fp8_amax_rotate(f8["amax"], f8["scale"], f8["inv"], nw, margin=1.0)
+
+    def _fp8_weights(self, l: int):
+        s = self.s
+        d, f = s.d_model, s.encoder_ffn_dim
+        p = f"model.encoder.layers.{l}."
+        return ((p + "self_attn.q_proj.weight", 3 * d * d), (p + "fc1.weight", f * d), (p + "fc2.weight", f * d))
 
     def refresh_fp8(self, layer: int | None = None):
         f8 = self._fp8_train
         if f8 is None:
             return
-        s, st = self.s, self.store
-        d, f = s.d_model, s.encoder_ffn_dim
-        for l in (range(s.encoder_layers) if layer is None else (layer,)):
-            p = f"model.encoder.layers.{l}."
-            for k, (name, n) in enumerate(((p + "self_attn.q_proj.weight", 3 * d * d), (p + "fc1.weight", f * d))):
-                off = st.off(name)
-                ops.quantize_fp8(st.p16[off:off + n], f8["p8"][off:off + n], f8["scales"][2 * l + k:2 * l + k + 1], f8["ws"], n=n)
+        st = self.store
+        for l in (range(self.s.encoder_layers) if layer is None else (layer,)):
+            for k, (name, n) in enumerate(self._fp8_weights(l)):
+                if k == 2 and not f8["ffn2"]:
+                    continue
+                off, i = st.off(name), 3 * l + k
+                ops.quantize_fp8_delayed(st.p16[off:off + n], f8["p8"][off:off + n], f8["scale"][i:i + 1],
+                                         f8["amax"][i * ops.FP8_AMAX_SLOTS:], n=n)
 
     def refresh_bucket(self, name: str):
-        """Trainer hook: bucket `name` has just been updated (on the trainer's optimiser stream)."""
-        if self._fp8_train is not None and name.startswith("enc") and name[3:].isdigit():
+        """Trainer hook: bucket `name` has just been updated (on the trainer's optimiser stream).  The first bucket of a
+        step turns the amax words of the previous step into this step's scales."""
+        f8 = self._fp8_train
+        if f8 is None:
+            return
+        if name == next(iter(self.store.buckets)):
+            nw, L = f8["nw"], self.s.encoder_layers
+            ops.fp8_amax_rotate(f8["amax"], f8["scale"], f8["inv"], nw, margin=1.0)
+            ops.fp8_amax_rotate(f8["amax"][nw * ops.FP8_AMAX_SLOTS:], f8["scale"][nw:], f8["inv"][nw:], L, margin=2.0)
+        if name.startswith("enc") and name[3:].isdigit():
             self.refresh_fp8(int(name[3:]))
 
     def trainable_range(self):
@@ -254,9 +287,15 @@ class WhisperTrainEngine(WhisperEngine):
             Me = B * s.max_source_positions
             f8["x8"] = torch.zeros(Me * s.d_model, dtype=torch.uint8, device=dev)
             f8["rs"] = torch.zeros(Me, dtype=torch.float32, device=dev)
+            f8["g8"] = torch.zeros(Me * s.encoder_ffn_dim, dtype=torch.uint8, device=dev) if f8["ffn2"] else None
+            nw = f8["nw"]
             for l, (sa, ff) in enumerate(self.enc_blocks):
-                sa.fp8 = (f8["p8"], f8["scales"][2 * l:2 * l + 1], f8["x8"], f8["rs"])
-                ff.fp8 = (f8["p8"], f8["scales"][2 * l + 1:2 * l + 2], f8["x8"], f8["rs"])
+                sa.fp8 = (f8["p8"], f8["inv"][3 * l:3 * l + 1], f8["x8"], f8["rs"])
+                ff.fp8 = (f8["p8"], f8["inv"][3 * l + 1:3 * l + 2], f8["x8"], f8["rs"])
+                # fc2: (fp8 GELU output, its scale / dequantisation factor / amax word, fc2's dequantisation factor)
+                ff.fp8_fc2 = ((f8["g8"], f8["scale"][nw + l:nw + l + 1], f8["inv"][nw + l:nw + l + 1],
+                               f8["amax"][(nw + l) * ops.FP8_AMAX_SLOTS:],
+                               f8["inv"][3 * l + 2:3 * l + 3]) if f8["ffn2"] else None)
         self._tw, self._tw_key = w, key
         return w
 

@@ -131,6 +131,14 @@ typedef struct CaGemmDesc {
    * displace the operands of the next GEMMs from the L2s / Infinity Cache (measured: -0.5 ms of the 73-ms XLS-R-2B step
    * for the pre-activation alone).  Results are unchanged.  C2 always takes the default policy. */
   int32_t c_stream_out;
+  /* Optional, CA_EPI_GELU only: a third output C8[m * ldc + n] = e4m3(clamp(gelu(v) * c8_scale[0])) - the activation
+   * (after dropout) as the fp8 A operand of the NEXT projection (ca_gemm_fp8 with a_scale = the matching inv_scale),
+   * written by the tile that computes it: no quantisation pass.  c8_scale is a device scalar from the previous step's
+   * amax (ca_fp8_amax_rotate); max|gelu(v)| of this launch is accumulated into the CA_FP8_AMAX_SLOTS words at c8_amax.
+   * NULL = off. */
+  void* C8;
+  const float* c8_scale;
+  uint32_t* c8_amax;
 } CaGemmDesc;
 
 int ca_gemm_bf16(const CaGemmDesc* desc, void* stream);
@@ -143,6 +151,17 @@ int ca_gemm_fp8(const CaGemmDesc* desc, void* stream);
  * (round to nearest even, saturating), inv_scale[0] = amax / 448 (the dequantisation factor ca_gemm_fp8 takes).
  * amax_ws: one float of workspace.  n must be a multiple of 8. */
 int ca_quantize_fp8(const void* x_bf16, int64_t n, void* q_fp8, float* inv_scale, float* amax_ws, void* stream);
+/* Delayed scaling (the fp8 training recipe: the scale of step t comes from the amax of step t - 1): ONE pass that
+ * quantises x with the device scalar scale[0] (q = e4m3(clamp(x * scale)), saturating) and accumulates max|x| into
+ * amax_next[0 .. CA_FP8_AMAX_SLOTS) (bits of non-negative floats; atomic max, order-independent).  ca_fp8_amax_rotate then turns `count`
+ * accumulated amax accumulators (CA_FP8_AMAX_SLOTS words each) into the next step's scales: scale[i] = 448 / (margin * amax), inv_scale[i] =
+ * margin * amax / 448 (what ca_gemm_fp8 takes as a_scale / b_scale), amax_next[i] = 0; a zero word keeps the old scale.
+ * The same scale / amax pair serves activations produced by a GEMM epilogue (CaGemmDesc.C8). */
+#define CA_FP8_AMAX_SLOTS 64 /* an amax accumulator is this many words (the writers spread their atomics over them:
+                              * atomics on one address serialise); the tensor's amax is the maximum over the words */
+int ca_quantize_fp8_delayed(const void* x_bf16, int64_t n, void* q_fp8, const float* scale, uint32_t* amax_next,
+                            void* stream);
+int ca_fp8_amax_rotate(uint32_t* amax_next, float* scale, float* inv_scale, int32_t count, float margin, void* stream);
 /* Up to eight independent plain GEMMs of the same operand form (same a_layout / b_layout, un-batched, no epilogue,
  * no bias) in one launch of the 256x256 kernel: for problems that under-fill the chip one by one, e.g. the four
  * weight gradients of an encoder layer or the six token-side ones of a Whisper decoder layer (each replaces a

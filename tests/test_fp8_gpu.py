@@ -227,7 +227,80 @@ def test_whisper_training_with_fp8_forward_projections():
     tr.finish()
     torch.cuda.synchronize()
     assert np.isfinite(losses).all() and losses[-1] < 0.7 * losses[1], losses
-    assert not torch.equal(p8_before, eng._fp8_train["p8"])  # re-quantised after the optimiser steps
+    f8 = eng._fp8_train
+    assert not torch.equal(p8_before, f8["p8"])  # re-quantised after the optimiser steps
+    # delayed scaling: the GELU outputs' scales left their first guess (448 / 16) for measured ones, the weights' scales
+    # follow the weights, and fc2 ran on the fp8 path (its e4m3 copy exists)
+    nw = f8["nw"]
+    assert f8["ffn2"] and bool((f8["scale"][nw:] != 28.0).all()) and bool((f8["scale"][:nw] > 1.0).all())
+    off = eng.store.off("model.encoder.layers.1.fc2.weight")
+    assert int(f8["p8"][off:off + 64 * 128].count_nonzero()) > 0
+
+
+def test_delayed_quantiser_and_amax_rotation(ops):
+    """ca_quantize_fp8_delayed: ONE pass with last step's scale, bit-exact against torch's e4m3 cast of x * scale
+    (saturating), this step's amax left in the amax word; ca_fp8_amax_rotate turns it into scale / inv_scale with the
+    margin and clears the word; a word that was not written keeps its old scale."""
+    x = rnd(777, 264, seed=3, scale=0.3).to(torch.bfloat16)
+    xd = x.to(DEV)
+    q = torch.zeros(x.shape, dtype=torch.uint8, device=DEV)
+    S = ops.FP8_AMAX_SLOTS
+    amax = torch.zeros(2 * S, dtype=torch.int32, device=DEV)  # an accumulator = S words, the amax their maximum
+    scale = torch.tensor([100.0, 7.0], device=DEV)   # too large on purpose: values beyond 448 / 100 saturate
+    inv = torch.tensor([0.01, 1.0 / 7.0], device=DEV)
+    ops.quantize_fp8_delayed(xd, q, scale[0:1], amax)
+    want = (x.float() * 100.0).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).view(torch.uint8)
+    assert torch.equal(q.cpu(), want)
+    am = float(x.float().abs().max())
+    assert amax[:S].view(torch.float32).max().item() == am and int(amax[S:].abs().sum()) == 0
+    ops.fp8_amax_rotate(amax, scale, inv, 2, margin=2.0)
+    torch.cuda.synchronize()
+    assert abs(scale[0].item() - 448.0 / (2 * am)) <= 1e-6 * 448.0 / am and abs(inv[0].item() - 2 * am / 448.0) <= 1e-7
+    assert scale[1].item() == 7.0 and int(amax.abs().sum()) == 0  # untouched accumulator: old scale kept; used one cleared
+    ops.quantize_fp8_delayed(xd, q, scale[0:1], amax)  # second pass, now inside the range
+    s = scale[0].item()
+    assert torch.equal(q.cpu(), (x.float() * s).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).view(torch.uint8))
+
+
+@pytest.mark.parametrize("force", [1, 3])
+@pytest.mark.parametrize("fp8_in", [False, True])
+def test_gelu_epilogue_third_output_in_fp8(ops, force, fp8_in):
+    """CaGemmDesc.C8: the GELU output of a projection also as e4m3 with a given per-tensor scale, from the tile that
+    computes it (bf16 and fp8 input GEMM, 128 x 128 and 256 x 256 kernels, interior and ragged tiles, with dropout): the
+    bytes are the e4m3 cast of the kernel's own fp32 GELU value times the scale - checked against the bf16 second output
+    to one e4m3 step - and the amax word holds max |GELU|."""
+    from coral_amd.ops import EPI_GELU
+
+    M, N, K = 1000, 520, 256
+    a = rnd(M, K, seed=1, scale=0.5).to(torch.bfloat16)
+    w = rnd(N, K, seed=2, scale=0.2).to(torch.bfloat16)
+    bias = rnd(N, seed=3, scale=0.1)
+    u = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+    g = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+    g8 = torch.zeros(M, N, dtype=torch.uint8, device=DEV)
+    sc = torch.tensor([37.0], device=DEV)
+    amax = torch.zeros(ops.FP8_AMAX_SLOTS, dtype=torch.int32, device=DEV)
+    kw = dict(C2=g, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=bias.to(DEV), epilogue=EPI_GELU, dropout_p=0.1, dropout_seed=11,
+              C8=g8, c8_scale=sc, c8_amax=amax)
+    ops.lib().ca_gemm_force_kernel(force)
+    try:
+        if fp8_in:
+            qa, ia = quantize_dev(ops, a.to(DEV))
+            qw, iw = quantize_dev(ops, w.to(DEV))
+            ops.gemm_fp8(qa, qw, u, a_scale=ia, b_scale=iw, **kw)
+        else:
+            ops.gemm(a.to(DEV), w.to(DEV), u, **kw)
+    finally:
+        ops.lib().ca_gemm_force_kernel(0)
+    torch.cuda.synchronize()
+    gf = g.float().cpu()
+    got = g8.cpu().view(torch.float8_e4m3fn).float() / 37.0
+    # e4m3 carries 3 mantissa bits: within one step (2^-3 relative, 2^-9 absolute after the scale) of the bf16 output
+    tol = gf.abs() * 0.0625 + gf.abs() * 0.008 + 2.0 ** -9 / 37.0 * 2
+    assert bool(((got - gf).abs() <= tol).all()), float(((got - gf).abs() - tol).max())
+    assert float((got == 0).float().mean()) < 0.2  # dropout zeros + tiny values only
+    am = amax.view(torch.float32).max().item()
+    assert abs(am - float(gf.abs().max())) <= 0.01 * am  # (fp32 value vs its bf16 rounding)
 
 
 def test_gemm_fp8_random_shapes(ops):
