@@ -645,6 +645,13 @@ def main():
                                                     "log-mel on GPU; fp8_forward = encoder q|k|v, fc1, fc2 forward projections with e4m3 weights and activations "
                                                     "(DESIGN.md 4.4)",
                                            unit="audio-seconds/sec", **tb)
+        # the reference's DEFAULT model key (R/config/asr_finetuning.yaml:1-11: model=whisper-large = large-v3, 32 + 32 layers)
+        r6 = whisper_measure("whisper-large", args, world, rank, device, decode=False, fp8=False, B=8, steps=4, warmup=2)
+        out["config"]["also_large"] = dict(workload="whisper-large (the reference's default model key: large-v3, 32 + 32 layers, 128 mels) "
+                                                    "finetune step (teacher-forced, activation_dropout 0.1), 8 x 30 s, log-mel on GPU",
+                                           unit="audio-seconds/sec", ms_per_step=round(r6["ms_per_step"], 3), value=round(r6["value"], 1))
+        del r6
+        torch.cuda.empty_cache()
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

@@ -150,7 +150,7 @@ class GradSync:
         # forces them on RCCL too: the A/B switch)
         self.capi = None
         if self.active and self.on_gpu and self._has_rs and os.environ.get("CA_COMM_CAPI", "1") != "0":
-            self.capi = CommContext(flat_grad.device, process_group)
+            self.capi = self._make_capi(flat_grad.device, process_group)
         if self.capi is not None:
             self.comm_stream = self.capi.stream
         else:
@@ -159,6 +159,38 @@ class GradSync:
         self.g16 = torch.empty_like(flat_grad, dtype=torch.bfloat16) if self.compress else None
         self._pending = []
         self.launched: list[str] = []
+
+    @staticmethod
+    def _make_capi(device, pg):
+        """A CommContext all ranks agree on, or None (every rank then uses torch.distributed's collectives).  The context
+        is created and, with more than one rank, checked once against torch.distributed on a small buffer; the ranks
+        exchange their verdicts, so that one rank's failure moves ALL of them to the fallback - never a mixed group."""
+        import logging
+
+        dist = torch.distributed
+        world = dist.get_world_size(pg)
+        ctx, ok = None, True
+        try:
+            ctx = CommContext(device, pg)
+            if world > 1:
+                x = (torch.arange(4096, dtype=torch.float32, device=device) % 61) * (dist.get_rank(pg) + 1)
+                want = x.clone()
+                dist.all_reduce(want, group=pg)
+                ctx.after_current()
+                ctx.all_reduce(x)
+                ctx.before_current()
+                ok = bool(torch.equal(x, want))
+        except Exception as e:  # noqa: BLE001
+            logging.getLogger(__package__).warning("C-ABI collectives unavailable (%s)", e)
+            ok = False
+        if world > 1:
+            flag = torch.tensor([1.0 if ok else 0.0], device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=pg)
+            ok = bool(flag.item() > 0.5)
+        if not ok:
+            logging.getLogger(__package__).warning("gradient exchange falls back to torch.distributed's RCCL collectives")
+            return None
+        return ctx
 
     def _to_wire(self, lo, hi):
         if self.on_gpu:
@@ -546,10 +578,8 @@ class DataParallelTrainer:
             cur = torch.cuda.current_stream()
             if self._ag_stream is None:
                 if self.sync.capi is not None:  # a second communicator: gathers do not queue behind reduce-scatters
-                    self._ag_comm = CommContext(st.device, self.sync.pg)
-                    self._ag_stream = self._ag_comm.stream
-                else:
-                    self._ag_stream = torch.cuda.Stream(device=st.device)
+                    self._ag_comm = GradSync._make_capi(st.device, self.sync.pg)
+                self._ag_stream = self._ag_comm.stream if self._ag_comm is not None else torch.cuda.Stream(device=st.device)
             self._ag_stream.wait_stream(cur)
             with torch.cuda.stream(self._ag_stream):
                 self._allgather_bf16(mlo, bhi, sa, sb)
