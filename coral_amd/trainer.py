@@ -577,8 +577,10 @@ class DataParallelTrainer:
             # bucket's all-gather, only the forward's per-bucket wait does (the event below is recorded behind it)
             cur = torch.cuda.current_stream()
             if self._ag_stream is None:
-                if self.sync.capi is not None:  # a second communicator: gathers do not queue behind reduce-scatters
-                    self._ag_comm = GradSync._make_capi(st.device, self.sync.pg)
+                # C ABI: the gathers ride on the exchange context's own stream - ONE communicator per rank, so no two
+                # collectives of this trainer are ever in flight in an order that could differ between ranks (by the
+                # time the optimiser runs, the step's reduce-scatters have been waited for: nothing queues in front)
+                self._ag_comm = self.sync.capi
                 self._ag_stream = self._ag_comm.stream if self._ag_comm is not None else torch.cuda.Stream(device=st.device)
             self._ag_stream.wait_stream(cur)
             with torch.cuda.stream(self._ag_stream):
