@@ -90,7 +90,8 @@ class CaAttnDesc(C.Structure):
                 + [(n, C.c_int64) for n in ("ldq", "ldk", "ldv", "ldo", "lddo", "lddq", "lddk", "lddv",
                                              "sqb", "skb", "svb", "sob", "sdob", "sdqb", "sdkb", "sdvb")]
                 + [(n, C.c_int32) for n in ("B", "H", "Tq", "Tk", "hd", "Tqp", "causal")]
-                + [("scale", C.c_float), ("dropout_p", C.c_float), ("dropout_seed", C.c_uint64)])
+                + [("scale", C.c_float), ("dropout_p", C.c_float), ("dropout_seed", C.c_uint64)]
+                + [("O8", C.c_void_p), ("o8_scale", C.c_void_p), ("o8_amax", C.c_void_p)])
 
 
 KMAJOR, MNMAJOR = 0, 1
@@ -109,6 +110,8 @@ SIGNATURES = {
     "ca_quantize_fp8": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
     "ca_quantize_fp8_delayed": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
     "ca_fp8_amax_rotate": (C.c_int, [_vp, _vp, _vp, _i32, _f32, _vp]),
+    "ca_dropout_rows_fp8": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _u64, _vp]),
+    "ca_quantize_fp8_transposed": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp]),
     "ca_gemm_force_kernel": (C.c_int, [C.c_int]),
     "ca_gemm_debug_general_epilogue": (C.c_int, [C.c_int]),
     "ca_prof_begin": (C.c_int, []),

@@ -46,6 +46,15 @@ def _masked_grad(dh, sv, sc: "Scratch", n, kind):
     return sc.dm[kind]
 
 
+def _masked_grad_fp8(dh, sv, sc: "Scratch", M, d, kind, fb):
+    """_masked_grad on the fp8 path: the same bf16 dropout(dh) (or dh itself) for the weight gradient, and in the same pass
+    the rows as e4m3 with one scale per row (fb = (p8t, w_off, dy8, row_scale, inv_w)) - the A operand of the sub-layer's
+    data gradient through ca_gemm_fp8 against the transposed e4m3 weight copy."""
+    p, seed = sv.get("hdrop", (0.0, 0))
+    ops.dropout_rows_fp8(dh, sc.dm[kind] if p > 0.0 else None, fb[2], fb[3], M, d, p, seed)
+    return sc.dm[kind] if p > 0.0 else dh
+
+
 def _ln_bwd(st, ln, dx, sv, dh, dhin, sc: "Scratch", M, d, ln_part, pending):
     """The pre-norm's backward: dhin = dh + LN'(dx).  d gamma | d beta (adjacent in the flat buffer) either reduced right
     away, or left as partials in `ln_part` with the reduction appended to `pending`."""
@@ -99,10 +108,20 @@ class SelfAttnBlock:
             ops.layernorm_fwd(hin, st.view(self.ln + ".weight"), st.view(self.ln + ".bias"), sv["x"], sv["st"], M, d, self.eps)
             ops.gemm(sv["x"], st.p16, sv["qkv"], M=M, N=3 * d, K=d, lda=d, ldb=d, ldc=3 * d,
                      b_off=st.off(self.attn + "q_proj.weight"), bias=st.p32, bias_off=st.off(self.qbias))
-        ops.attn_fwd(sv["qkv"], sv["qkv"], sv["qkv"], sv["ctx"], sv["lse"], **self._akw(B, T, sv, klen))
-        ops.gemm(sv["ctx"], st.p16, hout, M=M, N=d, K=d, lda=d, ldb=d, ldc=d, b_off=st.off(self.attn + "out_proj.weight"),
-                 bias=st.p32, bias_off=st.off(self.attn + "out_proj.bias"), epilogue=EPI_RESIDUAL, R=hin, ldr=d,
-                 dropout_p=hdrop[0], dropout_seed=hdrop[1])
+        o8 = getattr(self, "fp8_out", None) if (fp8 is not None and T >= 100 and adrop[0] == 0.0) else None
+        if o8 is not None:
+            # out_proj on the fp8 path: the attention kernel's output stage also writes the context as e4m3 (delayed
+            # per-tensor scale, CaAttnDesc.O8)
+            ops.attn_fwd(sv["qkv"], sv["qkv"], sv["qkv"], sv["ctx"], sv["lse"], O8=o8[0], o8_scale=o8[1], o8_amax=o8[3],
+                         **self._akw(B, T, sv, klen))
+            ops.gemm_fp8(o8[0], fp8[0], hout, a_scale=o8[2], b_scale=o8[4], M=M, N=d, K=d, lda=d, ldb=d, ldc=d,
+                         b_off=st.off(self.attn + "out_proj.weight"), bias=st.p32, bias_off=st.off(self.attn + "out_proj.bias"),
+                         epilogue=EPI_RESIDUAL, R=hin, ldr=d, dropout_p=hdrop[0], dropout_seed=hdrop[1])
+        else:
+            ops.attn_fwd(sv["qkv"], sv["qkv"], sv["qkv"], sv["ctx"], sv["lse"], **self._akw(B, T, sv, klen))
+            ops.gemm(sv["ctx"], st.p16, hout, M=M, N=d, K=d, lda=d, ldb=d, ldc=d, b_off=st.off(self.attn + "out_proj.weight"),
+                     bias=st.p32, bias_off=st.off(self.attn + "out_proj.bias"), epilogue=EPI_RESIDUAL, R=hin, ldr=d,
+                     dropout_p=hdrop[0], dropout_seed=hdrop[1])
         sv["hin"], sv["klen"], sv["hdrop"] = hin, klen, hdrop
 
     def backward(self, dh, dhin, sv, sc: Scratch, B, T, defer=None, acc=True, sq=None, ln_part=None, pending=None):
@@ -117,14 +136,18 @@ class SelfAttnBlock:
         st, d = self.st, self.d
         M = B * T
         o, g32, p16 = st.off, st.g32, st.p16
-        dy = _masked_grad(dh, sv, sc, M * d, "attn")
+        fb = getattr(self, "fp8_bwd", None) if getattr(self, "fp8", None) is not None else None
+        dy = _masked_grad(dh, sv, sc, M * d, "attn") if fb is None else _masked_grad_fp8(dh, sv, sc, M, d, "attn", fb)
         # with `defer` the bias gradients travel with the problems (fused into the grouped launch or done by it)
         if defer is None:
             ops.colsum(dy, d, M, d, g32, sc.part, out_off=o(self.attn + "out_proj.bias"))
         wg = [dict(dY=dy, X=sv["ctx"], M=d, N=d, K=M, lda=d, ldb=d, c_off=o(self.attn + "out_proj.weight"), accumulate=acc,
                    sq=sq.get("o"),
                    **(dict(bias_off=o(self.attn + "out_proj.bias"), part=sc.part, cs_off=self.cs_o) if defer is not None else {}))]
-        ops.gemm(dy, p16, sc.dctx, M=M, N=d, K=d, lda=d, b_layout=MNMAJOR, ldb=d, ldc=d, b_off=o(self.attn + "out_proj.weight"))
+        if fb is not None:  # data gradient of out_proj on the fp8 path: e4m3 dY (row scales) x transposed e4m3 weights
+            ops.gemm_fp8(fb[2], fb[0], sc.dctx, a_row_scale=fb[3], b_scale=fb[4], M=M, N=d, K=d, lda=d, ldb=d, ldc=d, b_off=fb[1])
+        else:
+            ops.gemm(dy, p16, sc.dctx, M=M, N=d, K=d, lda=d, b_layout=MNMAJOR, ldb=d, ldc=d, b_off=o(self.attn + "out_proj.weight"))
         qkv, dqkv = sv["qkv"], sc.dqkv
         ops.attn_bwd(qkv, qkv, qkv, sv["ctx"], sv["lse"], sc.dctx, sv["Dq"], dqkv, dqkv, dqkv, lddo=d, sdob=T * d, lddq=3 * d,
                      lddk=3 * d, lddv=3 * d, sdqb=T * 3 * d, sdkb=T * 3 * d, sdvb=T * 3 * d, dq_off=0, dk_off=d, dv_off=2 * d,
@@ -262,14 +285,19 @@ class FFNBlock:
         st, d, f = self.st, self.d, self.f
         o, g32, p16 = st.off, st.g32, st.p16
         p, seed = sv["drop"]
-        dy = _masked_grad(dh, sv, sc, M * d, "ffn")
+        fb = getattr(self, "fp8_bwd", None) if getattr(self, "fp8", None) is not None else None
+        dy = _masked_grad(dh, sv, sc, M * d, "ffn") if fb is None else _masked_grad_fp8(dh, sv, sc, M, d, "ffn", fb)
         if defer is None:
             ops.colsum(dy, d, M, d, g32, sc.part, out_off=o(self.fc2 + ".bias"))
         wg = [dict(dY=dy, X=sv["g"], M=d, N=f, K=M, lda=d, ldb=f, c_off=o(self.fc2 + ".weight"), accumulate=acc,
                    sq=sq.get("fc2"),
                    **(dict(bias_off=o(self.fc2 + ".bias"), part=sc.part, cs_off=self.cs_fc2) if defer is not None else {}))]
-        ops.gemm(dy, p16, sc.du, M=M, N=f, K=d, lda=d, b_layout=MNMAJOR, ldb=f, ldc=f, b_off=o(self.fc2 + ".weight"),
-                 epilogue=EPI_DGELU, R=sv["u"], ldr=f, dropout_p=p, dropout_seed=seed)
+        if fb is not None:  # fc2's data gradient on the fp8 path (GELU' epilogue as on the bf16 path)
+            ops.gemm_fp8(fb[2], fb[0], sc.du, a_row_scale=fb[3], b_scale=fb[4], M=M, N=f, K=d, lda=d, ldb=d, ldc=f, b_off=fb[1],
+                         epilogue=EPI_DGELU, R=sv["u"], ldr=f, dropout_p=p, dropout_seed=seed)
+        else:
+            ops.gemm(dy, p16, sc.du, M=M, N=f, K=d, lda=d, b_layout=MNMAJOR, ldb=f, ldc=f, b_off=o(self.fc2 + ".weight"),
+                     epilogue=EPI_DGELU, R=sv["u"], ldr=f, dropout_p=p, dropout_seed=seed)
         if defer is None:
             ops.colsum(sc.du, f, M, f, g32, sc.part, out_off=o(self.fc1 + ".bias"))
         wg.append(dict(dY=sc.du, X=sv["x"], M=f, N=d, K=M, lda=f, ldb=d, c_off=o(self.fc1 + ".weight"), accumulate=acc,

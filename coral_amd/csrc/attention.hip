@@ -211,9 +211,12 @@ __device__ __forceinline__ int fast_tiles(int n, int rows_per_tile) { return (n 
 // o[nb][e] is element (row 4g + e, column 16 nb + r) of the wave's 16-row tile.  Stored straight from the registers
 // that is one 2-byte store per lane and element (32 branches + stores per lane for 128 columns, 32-byte segments);
 // through LDS the tile goes out as whole 16-byte chunks of rows.
+// dst8 (optional): the same rows also as e4m3 bytes of the bf16-rounded values times scale8 (delayed per-tensor scale,
+// CaAttnDesc.O8) with the lane's running max |value| in amx.
 template <int HDPV>
 __device__ __forceinline__ void store_tile16(char* st, const f32x4_t (&o)[HDPV / 16], const float (&rs)[4],
-                                             unsigned short* dst, int64_t ld, int row0, int nrows, int hd, int lane) {
+                                             unsigned short* dst, int64_t ld, int row0, int nrows, int hd, int lane,
+                                             unsigned char* dst8 = nullptr, float scale8 = 1.f, float* amx = nullptr) {
   constexpr int PITCH = HDPV * 2 + 16;  // bytes: consecutive rows start 4 banks apart
   const int g = lane >> 4, r = lane & 15;
 #pragma unroll
@@ -228,7 +231,25 @@ __device__ __forceinline__ void store_tile16(char* st, const f32x4_t (&o)[HDPV /
     const int idx = i * 64 + lane;
     const int row = idx / CPR, ch = idx % CPR;
     const int q = row0 + row;
-    if (q < nrows && ch * 8 < hd) *(u16x8_t*)(dst + (int64_t)q * ld + ch * 8) = *(const u16x8_t*)(st + row * PITCH + ch * 16);
+    if (q < nrows && ch * 8 < hd) {
+      const u16x8_t v = *(const u16x8_t*)(st + row * PITCH + ch * 16);
+      *(u16x8_t*)(dst + (int64_t)q * ld + ch * 8) = v;
+      if (dst8) {  // (wave-uniform)
+        float t[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float f = bf2f(v[e]);
+          *amx = fmaxf(*amx, fabsf(f));
+          t[e] = fminf(fmaxf(f * scale8, -448.0f), 448.0f);
+        }
+        unsigned int w0 = 0, w1 = 0;
+        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(t[0], t[1], w0, false);
+        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(t[2], t[3], w0, true);
+        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(t[4], t[5], w1, false);
+        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(t[6], t[7], w1, true);
+        *(uint2*)(dst8 + (int64_t)q * ld + ch * 8) = make_uint2(w0, w1);
+      }
+    }
   }
 }
 constexpr int attn_stage_bytes(int hdpv) { return 4 * 16 * (hdpv * 2 + 16); }
@@ -256,6 +277,9 @@ struct AttnArgs {
   int64_t ldq, ldk, ldv, sqb, skb, svb;  // row strides and per-batch strides (elements)
   unsigned short* O;                     // forward output / backward: saved O is not needed (Dq given)
   int64_t ldo, sob;
+  unsigned char* O8;                     // forward, wide kernels: the output also as e4m3 (CaAttnDesc.O8) or null
+  const float* o8_scale;
+  unsigned int* o8_amax;
   float* lse;                            // [B, H, Tqp]
   const int32_t* klen;                   // [B] or null
   int B, H, Tq, Tk, hd, Tqp, causal;
@@ -754,6 +778,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
   }
   __syncthreads();  // every wave is done with the images: the LDS becomes output staging
   unsigned short* O = a.O + b * a.sob + h * hd;
+  unsigned char* O8 = a.O8 ? a.O8 + b * a.sob + h * hd : nullptr;
+  const float s8 = a.O8 ? a.o8_scale[0] : 1.f;
+  float amx = 0.f;
   char* st = smem + wave * (16 * (HDPV * 2 + 16));
 #pragma unroll
   for (int j = 0; j < NQ; ++j) {
@@ -768,7 +795,11 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
 #pragma unroll
     for (int e = 0; e < 4; ++e) ir[e] = __shfl(inv, 4 * g + e, 64);
     if (j) __builtin_amdgcn_wave_barrier();
-    store_tile16<HDPV>(st, o[j], ir, O, a.ldo, q0 + 16 * j, a.Tq, hd, lane);
+    store_tile16<HDPV>(st, o[j], ir, O, a.ldo, q0 + 16 * j, a.Tq, hd, lane, O8, s8, &amx);
+  }
+  if (a.O8 && a.o8_amax) {  // (every lane arrives; a maximum does not depend on the order)
+    amx = wave_max(amx);
+    if (lane == 0 && amx > 0.f) atomicMax(a.o8_amax + (blockIdx.x & (CA_FP8_AMAX_SLOTS - 1)), __float_as_uint(amx));
   }
 }
 
@@ -1799,6 +1830,7 @@ static AttnArgs to_args(const CaAttnDesc& d) {
   a.Q = (const unsigned short*)d.Q; a.K = (const unsigned short*)d.K; a.V = (const unsigned short*)d.V;
   a.ldq = d.ldq; a.ldk = d.ldk; a.ldv = d.ldv; a.sqb = d.sqb; a.skb = d.skb; a.svb = d.svb;
   a.O = (unsigned short*)d.O; a.ldo = d.ldo; a.sob = d.sob;
+  a.O8 = (unsigned char*)d.O8; a.o8_scale = d.o8_scale; a.o8_amax = (unsigned int*)d.o8_amax;
   a.lse = d.lse; a.klen = d.klen; a.B = d.B; a.H = d.H; a.Tq = d.Tq; a.Tk = d.Tk; a.hd = d.hd; a.Tqp = d.Tqp;
   a.causal = d.causal; a.scale = d.scale;
   a.dO = (const unsigned short*)d.dO; a.lddo = d.lddo; a.sdob = d.sdob; a.Dq = d.Dq;
@@ -1813,6 +1845,10 @@ static AttnArgs to_args(const CaAttnDesc& d) {
 extern "C" int ca_attn_fwd(const CaAttnDesc* desc, void* stream) {
   if (int rc = attn_check(desc, "ca_attn_fwd")) return rc;
   CA_CHECK_ARG(desc->O != nullptr, "ca_attn_fwd: null output");
+  static const int wide_on = [] { const char* e = getenv("CA_ATTN_WIDE"); return e ? atoi(e) : 1; }();
+  CA_CHECK_ARG(desc->O8 == nullptr || (desc->o8_scale != nullptr && desc->Tq >= 100 && wide_on && (desc->ldo % 8) == 0 &&
+                                       ((uintptr_t)desc->O8 % 8) == 0),
+               "ca_attn_fwd: O8 needs a scale, >= 100 queries per head (the wide kernels) and 8-byte aligned rows");
   const AttnArgs a = to_args(*desc);
   dim3 grid(attn_grid((desc->Tq + 63) / 64, desc->H, desc->B)), block(256);
   hipStream_t s = (hipStream_t)stream;

@@ -139,3 +139,146 @@ extern "C" int ca_fp8_amax_rotate(uint32_t* amax_next, float* scale, float* inv_
   CA_CHECK_LAUNCH("ca_fp8_amax_rotate");
   return CA_OK;
 }
+
+// ---- data gradients on the fp8 path ---------------------------------------------------------------------------------
+// dX = dY W needs (a) dY as e4m3 and (b) W with the contraction index contiguous, i.e. a TRANSPOSED e4m3 copy.
+// (a) The gradient entering a sub-layer already goes through one elementwise pass when the sub-layer's output was dropped
+// (hidden-state dropout: dY = dropout(dH) with the forward's mask, ca_dropout_bf16); this is that pass as a row-per-wave
+// kernel that also leaves the row as e4m3 with its own scale (the wave holds the whole row, as in ca_layernorm_fwd_fp8).
+// p = 0: a plain per-row quantiser (y may be NULL).
+template <int NCH>
+__global__ __launch_bounds__(256) void dropout_rows_fp8_kernel(const unsigned short* __restrict__ x,
+                                                               unsigned short* __restrict__ y, unsigned int* __restrict__ q,
+                                                               float* __restrict__ row_scale, int64_t rows, int C, float p,
+                                                               uint64_t seed) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int nchunk = C >> 3;
+  const float ks = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+    float v[NCH][8];
+    float am = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int ch = lane + c * 64;
+      if (ch < nchunk) {
+        const int64_t i = row * C + ch * 8;
+        const u16x8_t u = *(const u16x8_t*)(x + i);
+        unsigned int keep = 0xFFu;
+        if (p > 0.f) keep = ca_dropout_keep4(seed, (uint64_t)i, p) | (ca_dropout_keep4(seed, (uint64_t)i + 4, p) << 4);
+        u16x8_t o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          // (the bf16 value ca_dropout_bf16 would have written: the weight gradient reads that one)
+          o[e] = ((keep >> e) & 1u) ? (p > 0.f ? f2bf(bf2f(u[e]) * ks) : u[e]) : (unsigned short)0;
+          v[c][e] = bf2f(o[e]);
+          am = fmaxf(am, fabsf(v[c][e]));
+        }
+        if (y) *(u16x8_t*)(y + i) = o;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[c][e] = 0.f;
+      }
+    }
+    am = wave_max(am);
+    const float scale = am > 0.f ? FP8_MAX / am : 1.f;
+    if (lane == 0) row_scale[row] = am > 0.f ? am / FP8_MAX : 1.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int ch = lane + c * 64;
+      if (ch < nchunk) {
+        float t[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t[e] = fminf(fmaxf(v[c][e] * scale, -FP8_MAX), FP8_MAX);
+        unsigned int w0 = 0, w1 = 0;
+        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(t[0], t[1], w0, false);
+        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(t[2], t[3], w0, true);
+        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(t[4], t[5], w1, false);
+        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(t[6], t[7], w1, true);
+        q[(row * C + ch * 8) / 4] = w0;
+        q[(row * C + ch * 8) / 4 + 1] = w1;
+      }
+    }
+  }
+}
+
+extern "C" int ca_dropout_rows_fp8(const void* x, void* y, void* q_fp8, float* row_scale, int64_t rows, int32_t C, float p,
+                                   uint64_t seed, void* stream) {
+  CA_CHECK_ARG(x && q_fp8 && row_scale && rows > 0 && C > 0 && (C % 16) == 0 && C <= 4096,
+               "ca_dropout_rows_fp8: C=%d must be a multiple of 16 and <= 4096", C);
+  CA_CHECK_ARG(p >= 0.f && p < 1.f && (p == 0.f || y != nullptr), "ca_dropout_rows_fp8: bad p (p > 0 needs y)");
+  const int nch = (C / 8 + 63) / 64;
+  int64_t g = (rows + 3) / 4;
+  if (g > 4096) g = 4096;
+  hipStream_t s = (hipStream_t)stream;
+#define DRF(N)                                                                                                   \
+  hipLaunchKernelGGL((dropout_rows_fp8_kernel<N>), dim3((unsigned)g), dim3(256), 0, s, (const unsigned short*)x, \
+                     (unsigned short*)y, (unsigned int*)q_fp8, row_scale, rows, C, p, seed)
+  switch (nch) {
+    case 1: DRF(1); break;
+    case 2: DRF(2); break;
+    case 3: DRF(3); break;
+    case 4: DRF(4); break;
+    default: DRF(8); break;
+  }
+#undef DRF
+  CA_CHECK_LAUNCH("ca_dropout_rows_fp8");
+  return CA_OK;
+}
+
+// (b) q_t[c][r] = e4m3(clamp(x[r][c] * scale[0])): the transposed e4m3 copy of a [rows, cols] bf16 matrix, 64 x 64 tiles
+// through LDS (16-byte reads along the rows of x, 8-byte stores along the rows of q_t).  Uses the scale of the matrix's
+// own (untransposed) copy: no amax of its own.
+__global__ __launch_bounds__(256) void fp8_cast_transposed_kernel(const unsigned short* __restrict__ x, int rows, int cols,
+                                                                  const float* __restrict__ scale_p,
+                                                                  unsigned char* __restrict__ qt) {
+  __shared__ unsigned char tile[64][64 + 8];  // tile[c][r]
+  const float scale = scale_p[0];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  {  // thread -> (row of the tile, 16 consecutive columns)
+    const int r = threadIdx.x >> 2, cq = (threadIdx.x & 3) * 16;
+    if (r0 + r < rows) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int c = cq + 8 * h;
+        if (c0 + c < cols) {  // cols % 8 == 0: a chunk is all-or-nothing
+          const u16x8_t u = *(const u16x8_t*)(x + (int64_t)(r0 + r) * cols + c0 + c);
+#pragma unroll
+          for (int e = 0; e < 8; e += 2) {
+            const float a = fminf(fmaxf(bf2f(u[e]) * scale, -FP8_MAX), FP8_MAX);
+            const float b = fminf(fmaxf(bf2f(u[e + 1]) * scale, -FP8_MAX), FP8_MAX);
+            const unsigned int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0u, false);
+            tile[c + e][r] = (unsigned char)(w & 0xffu);
+            tile[c + e + 1][r] = (unsigned char)((w >> 8) & 0xffu);
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  {  // thread -> (column of x = row of q_t, 16 consecutive rows of x)
+    const int c = threadIdx.x >> 2, rq = (threadIdx.x & 3) * 16;
+    if (c0 + c < cols) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int r = rq + 8 * h;
+        if (r0 + r + 8 <= rows) {
+          *(uint2*)(qt + (int64_t)(c0 + c) * rows + r0 + r) = *(const uint2*)&tile[c][r];
+        } else {
+          for (int e = 0; e < 8; ++e)
+            if (r0 + r + e < rows) qt[(int64_t)(c0 + c) * rows + r0 + r + e] = tile[c][r + e];
+        }
+      }
+    }
+  }
+}
+extern "C" int ca_quantize_fp8_transposed(const void* x_bf16, int32_t rows, int32_t cols, void* q_fp8_t, const float* scale,
+                                          void* stream) {
+  CA_CHECK_ARG(x_bf16 && q_fp8_t && scale && rows > 0 && cols > 0 && (rows % 8) == 0 && (cols % 8) == 0 &&
+                   ((uintptr_t)q_fp8_t % 8) == 0,
+               "ca_quantize_fp8_transposed: rows and cols must be multiples of 8");
+  hipLaunchKernelGGL(fp8_cast_transposed_kernel, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0, (hipStream_t)stream,
+                     (const unsigned short*)x_bf16, rows, cols, scale, (unsigned char*)q_fp8_t);
+  CA_CHECK_LAUNCH("ca_quantize_fp8_transposed");
+  return CA_OK;
+}

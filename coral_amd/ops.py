@@ -126,6 +126,18 @@ def fp8_amax_rotate(amax_next, scale, inv_scale, count, margin=1.0):
     check(lib().ca_fp8_amax_rotate(_p(amax_next), _p(scale), _p(inv_scale), count, float(margin), _stream()), "ca_fp8_amax_rotate")
 
 
+def dropout_rows_fp8(x, y, q, row_scale, rows, Cn, p, seed):
+    """y = dropout(x) (ca_dropout_bf16's mask; y None when p == 0) and the rows of y as e4m3 with one scale per row."""
+    check(lib().ca_dropout_rows_fp8(_p(x), _p(y), _p(q), _p(row_scale), rows, Cn, float(p), int(seed), _stream()),
+          "ca_dropout_rows_fp8")
+
+
+def quantize_fp8_transposed(x, rows, cols, qt, scale, x_off=0, qt_off=0):
+    """qt [cols, rows] = e4m3(x [rows, cols] * scale): the transposed e4m3 copy of a weight matrix."""
+    check(lib().ca_quantize_fp8_transposed(_p(x, x_off), rows, cols, _p(qt, qt_off), _p(scale), _stream()),
+          "ca_quantize_fp8_transposed")
+
+
 def quantize_fp8(x, q, inv_scale, amax_ws, n=None):
     """bf16 tensor -> e4m3 bytes (uint8 tensor q) + inv_scale (1 float on the device)."""
     check(lib().ca_quantize_fp8(_p(x), x.numel() if n is None else n, _p(q), _p(inv_scale), _p(amax_ws), _stream()),
@@ -609,8 +621,11 @@ def prof_end():
 
 
 def _attn_desc(Q, K, V, O, lse, *, B, H, Tq, Tk, hd, Tqp, scale, ldq, ldk, ldv, ldo, sqb, skb, svb, sob,
-               q_off=0, k_off=0, v_off=0, o_off=0, klen=None, causal=False, dropout_p=0.0, dropout_seed=0):
+               q_off=0, k_off=0, v_off=0, o_off=0, klen=None, causal=False, dropout_p=0.0, dropout_seed=0,
+               O8=None, o8_scale=None, o8_amax=None):
     d = CaAttnDesc()
+    if O8 is not None:  # the output also as e4m3 (delayed per-tensor scale): the fp8 operand of the out-projection
+        d.O8, d.o8_scale, d.o8_amax = _p(O8, o_off), _p(o8_scale), _p(o8_amax)
     d.Q, d.K, d.V, d.O = _p(Q, q_off), _p(K, k_off), _p(V, v_off), _p(O, o_off)
     d.lse, d.klen = _p(lse), _p(klen)
     d.ldq, d.ldk, d.ldv, d.ldo = ldq, ldk, ldv, ldo

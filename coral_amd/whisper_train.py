@@ -73,27 +73,39 @@ class WhisperTrainEngine(WhisperEngine):
         """Training: encoder forward projections on the fp8 matrix instruction (BASELINE configs[4]: "fp8 weights").
         q|k|v and fc1 take their inputs from LayerNorm kernels that quantise per row in the same pass; fc2 (`ffn2`, on by
         default; CA_FP8_FC2=0 switches it off) takes the GELU output as e4m3 straight from fc1's epilogue
-        (CaGemmDesc.C8) with a DELAYED per-tensor scale - the scale of step t from the amax of step t - 1, the fp8
-        training recipe - so no quantisation pass exists anywhere in the forward.  The e4m3 weight copies are refreshed
+        (CaGemmDesc.C8) and out_proj (CA_FP8_OUT=0 off) the attention output as e4m3 straight from the attention kernel's
+        output stage (CaAttnDesc.O8), both with a DELAYED per-tensor scale - the scale of step t from the amax of step
+        t - 1, the fp8 training recipe - so no quantisation pass exists anywhere in the forward.  The e4m3 weight copies are refreshed
         per bucket behind AdamW (refresh_bucket) in ONE pass each, also with delayed scales (ca_quantize_fp8_delayed; a
         weight matrix moves by ~1e-4 of its range per step), and all scales turn over in one launch per step
-        (ca_fp8_amax_rotate).  out_proj stays bf16 (8 % of the forward FLOPs; its input comes out of the attention
-        kernel).  The backward is unchanged (bf16 weights and saved bf16 activations: straight-through gradients)."""
+        (ca_fp8_amax_rotate).  Backward (CA_FP8_DGRAD=0 off): the data gradients of fc2 and out_proj - the two whose
+        incoming gradient passes through an elementwise pass anyway (hidden-state dropout) - run on the fp8 instruction
+        too: that pass also leaves dY as e4m3 with row scales (ca_dropout_rows_fp8), the weights have transposed e4m3
+        copies (ca_quantize_fp8_transposed).  Everything else of the backward is bf16: weight gradients from the saved
+        bf16 activations, the other data gradients from bf16 weights (straight-through)."""
         import os
 
         if not on:
             self._fp8_train = None
             for sa, ff in self.enc_blocks:
                 sa.fp8 = ff.fp8 = None
+                sa.fp8_bwd = ff.fp8_bwd = None
             return
         st, dev, L = self.store, self.device, self.s.encoder_layers
         if ffn2 is None:
             ffn2 = os.environ.get("CA_FP8_FC2", "1") == "1"
-        nw = 3 * L  # weight tensors: q|k|v, fc1, fc2 per layer; then one activation (the GELU output) per layer
-        f8 = dict(p8=torch.zeros(st.numel, dtype=torch.uint8, device=dev), nw=nw, ffn2=ffn2,
-                  amax=torch.zeros((nw + L) * ops.FP8_AMAX_SLOTS, dtype=torch.int32, device=dev),
-                  scale=torch.ones(nw + L, dtype=torch.float32, device=dev),
-                  inv=torch.ones(nw + L, dtype=torch.float32, device=dev), x8=None, rs=None, g8=None)
+        out8 = os.environ.get("CA_FP8_OUT", "1") == "1"
+        dgrad = os.environ.get("CA_FP8_DGRAD", "1") == "1" and ffn2 and out8
+        d_, f_ = self.s.d_model, self.s.encoder_ffn_dim
+        nw = 4 * L  # weight tensors: q|k|v, out, fc1, fc2 per layer; then two activations per layer: GELU output, attention output
+        na = 2 * L
+        f8 = dict(p8=torch.zeros(st.numel, dtype=torch.uint8, device=dev), nw=nw, na=na, ffn2=ffn2, out8=out8,
+                  amax=torch.zeros((nw + na) * ops.FP8_AMAX_SLOTS, dtype=torch.int32, device=dev),
+                  scale=torch.ones(nw + na, dtype=torch.float32, device=dev),
+                  inv=torch.ones(nw + na, dtype=torch.float32, device=dev), x8=None, rs=None, g8=None, c8=None,
+                  dgrad=dgrad, dy8=None, drs=None,
+                  # transposed e4m3 copies for the data gradients: per layer fc2^T [f, d] then out_proj^T [d, d]
+                  p8t=torch.zeros(L * (f_ * d_ + d_ * d_), dtype=torch.uint8, device=dev) if dgrad else None)
         # activations: a first guess (amax 8, margin 2) until the first step has measured them
         f8["scale"][nw:] = 448.0 / 16.0
         f8["inv"][nw:] = 16.0 / 448.0
@@ -108,7 +120,8 @@ class WhisperTrainEngine(WhisperEngine):
         s = self.s
         d, f = s.d_model, s.encoder_ffn_dim
         p = f"model.encoder.layers.{l}."
-        return ((p + "self_attn.q_proj.weight", 3 * d * d), (p + "fc1.weight", f * d), (p + "fc2.weight", f * d))
+        return ((p + "self_attn.q_proj.weight", 3 * d * d), (p + "self_attn.out_proj.weight", d * d), (p + "fc1.weight", f * d),
+                (p + "fc2.weight", f * d))
 
     def refresh_fp8(self, layer: int | None = None):
         f8 = self._fp8_train
@@ -117,11 +130,18 @@ class WhisperTrainEngine(WhisperEngine):
         st = self.store
         for l in (range(self.s.encoder_layers) if layer is None else (layer,)):
             for k, (name, n) in enumerate(self._fp8_weights(l)):
-                if k == 2 and not f8["ffn2"]:
+                if (k == 3 and not f8["ffn2"]) or (k == 1 and not f8["out8"]):
                     continue
-                off, i = st.off(name), 3 * l + k
+                off, i = st.off(name), 4 * l + k
                 ops.quantize_fp8_delayed(st.p16[off:off + n], f8["p8"][off:off + n], f8["scale"][i:i + 1],
                                          f8["amax"][i * ops.FP8_AMAX_SLOTS:], n=n)
+                if f8["dgrad"] and k in (1, 3):  # the transposed copy, same scale
+                    d, f = self.s.d_model, self.s.encoder_ffn_dim
+                    base = l * (f * d + d * d)
+                    if k == 3:
+                        ops.quantize_fp8_transposed(st.p16, d, f, f8["p8t"], f8["scale"][i:i + 1], x_off=off, qt_off=base)
+                    else:
+                        ops.quantize_fp8_transposed(st.p16, d, d, f8["p8t"], f8["scale"][i:i + 1], x_off=off, qt_off=base + f * d)
 
     def refresh_bucket(self, name: str):
         """Trainer hook: bucket `name` has just been updated (on the trainer's optimiser stream).  The first bucket of a
@@ -130,9 +150,9 @@ class WhisperTrainEngine(WhisperEngine):
         if f8 is None:
             return
         if name == next(iter(self.store.buckets)):
-            nw, L = f8["nw"], self.s.encoder_layers
+            nw, na = f8["nw"], f8["na"]
             ops.fp8_amax_rotate(f8["amax"], f8["scale"], f8["inv"], nw, margin=1.0)
-            ops.fp8_amax_rotate(f8["amax"][nw * ops.FP8_AMAX_SLOTS:], f8["scale"][nw:], f8["inv"][nw:], L, margin=2.0)
+            ops.fp8_amax_rotate(f8["amax"][nw * ops.FP8_AMAX_SLOTS:], f8["scale"][nw:], f8["inv"][nw:], na, margin=2.0)
         if name.startswith("enc") and name[3:].isdigit():
             self.refresh_fp8(int(name[3:]))
 
@@ -288,14 +308,25 @@ class WhisperTrainEngine(WhisperEngine):
             f8["x8"] = torch.zeros(Me * s.d_model, dtype=torch.uint8, device=dev)
             f8["rs"] = torch.zeros(Me, dtype=torch.float32, device=dev)
             f8["g8"] = torch.zeros(Me * s.encoder_ffn_dim, dtype=torch.uint8, device=dev) if f8["ffn2"] else None
-            nw = f8["nw"]
+            f8["c8"] = torch.zeros(Me * s.d_model, dtype=torch.uint8, device=dev) if f8["out8"] else None
+            f8["dy8"] = torch.zeros(Me * s.d_model, dtype=torch.uint8, device=dev) if f8["dgrad"] else None
+            f8["drs"] = torch.zeros(Me, dtype=torch.float32, device=dev) if f8["dgrad"] else None
+            nw, S = f8["nw"], ops.FP8_AMAX_SLOTS
+
+            def act(i, buf, w):  # (e4m3 activation, its scale / dequantisation factor / amax accumulator, the weight's factor)
+                return (buf, f8["scale"][nw + i:nw + i + 1], f8["inv"][nw + i:nw + i + 1], f8["amax"][(nw + i) * S:], f8["inv"][w:w + 1])
+
             for l, (sa, ff) in enumerate(self.enc_blocks):
-                sa.fp8 = (f8["p8"], f8["inv"][3 * l:3 * l + 1], f8["x8"], f8["rs"])
-                ff.fp8 = (f8["p8"], f8["inv"][3 * l + 1:3 * l + 2], f8["x8"], f8["rs"])
-                # fc2: (fp8 GELU output, its scale / dequantisation factor / amax word, fc2's dequantisation factor)
-                ff.fp8_fc2 = ((f8["g8"], f8["scale"][nw + l:nw + l + 1], f8["inv"][nw + l:nw + l + 1],
-                               f8["amax"][(nw + l) * ops.FP8_AMAX_SLOTS:],
-                               f8["inv"][3 * l + 2:3 * l + 3]) if f8["ffn2"] else None)
+                sa.fp8 = (f8["p8"], f8["inv"][4 * l:4 * l + 1], f8["x8"], f8["rs"])
+                ff.fp8 = (f8["p8"], f8["inv"][4 * l + 2:4 * l + 3], f8["x8"], f8["rs"])
+                ff.fp8_fc2 = act(2 * l, f8["g8"], 4 * l + 3) if f8["ffn2"] else None       # fc2 <- GELU output
+                sa.fp8_out = act(2 * l + 1, f8["c8"], 4 * l + 1) if f8["out8"] else None  # out_proj <- attention output
+                if f8["dgrad"]:  # (transposed weights, offset, e4m3 dY, its row scales, the weight's dequantisation factor)
+                    base = l * (s.encoder_ffn_dim * s.d_model + s.d_model * s.d_model)
+                    ff.fp8_bwd = (f8["p8t"], base, f8["dy8"], f8["drs"], f8["inv"][4 * l + 3:4 * l + 4])
+                    sa.fp8_bwd = (f8["p8t"], base + s.encoder_ffn_dim * s.d_model, f8["dy8"], f8["drs"], f8["inv"][4 * l + 1:4 * l + 2])
+                else:
+                    ff.fp8_bwd = sa.fp8_bwd = None
         self._tw, self._tw_key = w, key
         return w
 

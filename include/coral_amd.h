@@ -162,6 +162,17 @@ int ca_quantize_fp8(const void* x_bf16, int64_t n, void* q_fp8, float* inv_scale
 int ca_quantize_fp8_delayed(const void* x_bf16, int64_t n, void* q_fp8, const float* scale, uint32_t* amax_next,
                             void* stream);
 int ca_fp8_amax_rotate(uint32_t* amax_next, float* scale, float* inv_scale, int32_t count, float margin, void* stream);
+/* Data gradients on the fp8 path (dX = dY W through ca_gemm_fp8: A = dY as e4m3 with row scales, B = W transposed):
+ * ca_dropout_rows_fp8: y = dropout(x) exactly as ca_dropout_bf16 (mask of element i from (seed, i), i = row * C + col;
+ *   p = 0: no mask, y may be NULL) and, in the same pass, q[row] = e4m3(y[row] * 448 / amax(y[row])), row_scale[row] =
+ *   amax / 448 (CaGemmDesc.a_row_scale) - the gradient entering a sub-layer whose output went through hidden-state
+ *   dropout ($TF/models/whisper/modeling_whisper.py:398,406) as the fp8 operand of that sub-layer's data gradient.
+ * ca_quantize_fp8_transposed: q_t [cols, rows] = e4m3(clamp(x [rows, cols] * scale[0])) - the transposed e4m3 copy of a
+ *   weight matrix, quantised with the scale of its untransposed copy (ca_quantize_fp8_delayed). */
+int ca_dropout_rows_fp8(const void* x, void* y, void* q_fp8, float* row_scale, int64_t rows, int32_t C, float p,
+                        uint64_t seed, void* stream);
+int ca_quantize_fp8_transposed(const void* x_bf16, int32_t rows, int32_t cols, void* q_fp8_t, const float* scale,
+                               void* stream);
 /* Up to eight independent plain GEMMs of the same operand form (same a_layout / b_layout, un-batched, no epilogue,
  * no bias) in one launch of the 256x256 kernel: for problems that under-fill the chip one by one, e.g. the four
  * weight gradients of an encoder layer or the six token-side ones of a Whisper decoder layer (each replaces a
@@ -359,6 +370,14 @@ typedef struct CaAttnDesc {
    * (b, h, q, k) from a hash of (seed, flat index); forward and backward must be given the same p and seed. 0 = off. */
   float dropout_p;
   uint64_t dropout_seed;
+  /* Optional, forward with at least 100 queries per head: the output also as OCP e4m3, O8[same element offsets as O] =
+   * e4m3(clamp(bf16(O) * o8_scale[0])) - the fp8 A operand of the out-projection (ca_gemm_fp8, a_scale = the matching
+   * inv_scale) written by the attention kernel's output stage, no quantisation pass.  o8_scale: device scalar from the
+   * previous step's amax (delayed scaling, ca_fp8_amax_rotate); this launch's max |O| goes to the CA_FP8_AMAX_SLOTS words
+   * at o8_amax.  NULL = off. */
+  void* O8;
+  const float* o8_scale;
+  uint32_t* o8_amax;
 } CaAttnDesc;
 int ca_attn_fwd(const CaAttnDesc* desc, void* stream);
 int ca_attn_bwd(const CaAttnDesc* desc, void* stream);

@@ -232,9 +232,11 @@ def test_whisper_training_with_fp8_forward_projections():
     # delayed scaling: the GELU outputs' scales left their first guess (448 / 16) for measured ones, the weights' scales
     # follow the weights, and fc2 ran on the fp8 path (its e4m3 copy exists)
     nw = f8["nw"]
-    assert f8["ffn2"] and bool((f8["scale"][nw:] != 28.0).all()) and bool((f8["scale"][:nw] > 1.0).all())
-    off = eng.store.off("model.encoder.layers.1.fc2.weight")
-    assert int(f8["p8"][off:off + 64 * 128].count_nonzero()) > 0
+    assert f8["ffn2"] and f8["out8"] and f8["dgrad"] and bool((f8["scale"][nw:] != 28.0).all()) and bool((f8["scale"][:nw] > 1.0).all())
+    assert int(f8["p8t"].count_nonzero()) > 0 and int(f8["dy8"].count_nonzero()) > 0  # the fp8 data gradients ran
+    for name, n in (("fc2", 64 * 128), ("self_attn.out_proj", 64 * 64)):
+        off = eng.store.off(f"model.encoder.layers.1.{name}.weight")
+        assert int(f8["p8"][off:off + n].count_nonzero()) > 0
 
 
 def test_delayed_quantiser_and_amax_rotation(ops):
@@ -301,6 +303,72 @@ def test_gelu_epilogue_third_output_in_fp8(ops, force, fp8_in):
     assert float((got == 0).float().mean()) < 0.2  # dropout zeros + tiny values only
     am = amax.view(torch.float32).max().item()
     assert abs(am - float(gf.abs().max())) <= 0.01 * am  # (fp32 value vs its bf16 rounding)
+
+
+@pytest.mark.parametrize("hd,H,T", [(64, 4, 333), (16, 4, 1500), (120, 2, 260)])
+def test_attention_output_also_in_fp8(ops, hd, H, T):
+    """CaAttnDesc.O8: the forward's output stage also writes the context as e4m3 of the bf16 output times a given scale -
+    bit-exact against torch's e4m3 cast of the kernel's own bf16 output (saturating), max |O| in the amax accumulator,
+    the bf16 output itself unchanged by the option."""
+    B, d = 2, H * hd
+    qkv = rnd(B, T, 3 * d, seed=4, scale=1.0).to(torch.bfloat16).to(DEV)
+    Tqp = (T + 31) // 32 * 32
+    lse = torch.zeros(B, H, Tqp, device=DEV)
+    kw = dict(B=B, H=H, Tq=T, Tk=T, hd=hd, Tqp=Tqp, scale=hd ** -0.5, ldo=d, sob=T * d, ldq=3 * d, ldk=3 * d, ldv=3 * d,
+              sqb=T * 3 * d, skb=T * 3 * d, svb=T * 3 * d, q_off=0, k_off=d, v_off=2 * d)
+    O0 = torch.zeros(B, T, d, dtype=torch.bfloat16, device=DEV)
+    ops.attn_fwd(qkv, qkv, qkv, O0, lse, **kw)
+    O1 = torch.zeros_like(O0)
+    O8 = torch.zeros(B, T, d, dtype=torch.uint8, device=DEV)
+    sc = torch.tensor([300.0], device=DEV)  # (large on purpose: the biggest outputs saturate at 448)
+    amax = torch.zeros(ops.FP8_AMAX_SLOTS, dtype=torch.int32, device=DEV)
+    ops.attn_fwd(qkv, qkv, qkv, O1, lse, O8=O8, o8_scale=sc, o8_amax=amax, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(O0, O1)
+    want = (O1.float().cpu() * 300.0).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).view(torch.uint8)
+    assert torch.equal(O8.cpu(), want)
+    assert amax.view(torch.float32).max().item() == float(O1.float().abs().max())
+
+
+@pytest.mark.parametrize("rows,C,p", [(333, 1280, 0.1), (1000, 64, 0.0), (77, 4096, 0.25)])
+def test_row_quantising_dropout_and_transposed_weight_copy(ops, rows, C, p):
+    """The two producers of the fp8 data gradients.  ca_dropout_rows_fp8: the bf16 output is ca_dropout_bf16's bit for
+    bit (the weight gradient reads it), the e4m3 rows and row scales are the per-row quantisation of exactly that
+    output.  ca_quantize_fp8_transposed: the transposed e4m3 copy of a matrix with a given scale, bit-exact."""
+    x = rnd(rows, C, seed=8, scale=3.0).to(torch.bfloat16)
+    x[5] = 0.0  # an all-zero row: scale 1
+    xd = x.to(DEV)
+    y0 = torch.zeros_like(xd)
+    if p > 0:
+        ops.dropout(xd, y0, rows * C, p, 1234)
+    else:
+        y0.copy_(xd)
+    y1 = torch.zeros_like(xd)
+    q = torch.zeros(rows, C, dtype=torch.uint8, device=DEV)
+    rs = torch.zeros(rows, dtype=torch.float32, device=DEV)
+    ops.dropout_rows_fp8(xd, y1 if p > 0 else None, q, rs, rows, C, p, 1234)
+    torch.cuda.synchronize()
+    if p > 0:
+        assert torch.equal(y0, y1)
+        assert 0.5 * p < float((y1 == 0).float().mean()) < 1.5 * p + 0.01
+    yf = y0.float().cpu()
+    am = yf.abs().amax(dim=1)
+    want_rs = torch.where(am > 0, am / 448.0, torch.ones_like(am))
+    assert torch.allclose(rs.cpu(), want_rs, rtol=1e-6, atol=0)
+    sc = torch.where(am > 0, 448.0 / am, torch.ones_like(am))
+    want = (yf * sc[:, None]).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).view(torch.uint8)
+    # (the device forms 448 / amax with its fast division: the scale may differ in the last bit, which moves a value that
+    # sits on an e4m3 rounding boundary to the neighbouring code - rare, and never further than one code)
+    qa, qb = q.cpu().view(torch.float8_e4m3fn).float(), want.view(torch.float8_e4m3fn).float()
+    assert float((qa != qb).float().mean()) <= 5e-3
+    assert bool(((qa - qb).abs() <= 0.13 * qb.abs() + 2.0 ** -9).all())
+    # transposed copy (rows x C matrix -> C x rows)
+    if rows % 8 == 0:
+        qt = torch.zeros(C, rows, dtype=torch.uint8, device=DEV)
+        s1 = torch.tensor([41.0], device=DEV)
+        ops.quantize_fp8_transposed(xd, rows, C, qt, s1)
+        want_t = (x.float() * 41.0).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).view(torch.uint8).t().contiguous()
+        assert torch.equal(qt.cpu(), want_t)
 
 
 def test_gemm_fp8_random_shapes(ops):
