@@ -327,7 +327,7 @@ def whisper_bench(args, world, rank, device):
             "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(r["ms_per_step"], 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": ("bf16 + fp8 e4m3 (encoder q|k|v, fc1 forward)" if args.decode else
-                                          "bf16 + fp8 e4m3 forward (encoder q|k|v, fc1, fc2: e4m3 weights and activations, delayed scaling)") if fp8 else "bf16",
+                                          "bf16 + fp8 e4m3 (encoder q|k|v, out, fc1, fc2 forward and the data gradients of fc2 / out: e4m3 weights and activations, delayed scaling)") if fp8 else "bf16",
             "data": "synthetic", "config": cfg}), flush=True)
     if world > 1:
         if args.check_replicas and not args.decode:
@@ -484,7 +484,7 @@ def main():
     ap.add_argument("--decode", action="store_true", help="whisper models: time greedy decoding instead of training")
     ap.add_argument("--decode-tokens", type=int, default=32)
     ap.add_argument("--fp8-forward", action="store_true",
-                    help="whisper finetune step: encoder q|k|v, fc1 and fc2 forward projections in fp8 (DESIGN.md 4.4)")
+                    help="whisper finetune step: encoder forward projections and the fc2 / out_proj data gradients in fp8 (DESIGN.md 4.4)")
     ap.add_argument("--fp8-encoder", action="store_true",
                     help="whisper --decode: encoder q|k|v and fc1 projections with fp8 weights (DESIGN.md 4.4)")
     ap.add_argument("--grad-wire", default="fp32", choices=["bf16", "fp32"],
@@ -642,8 +642,8 @@ def main():
             del r5
             torch.cuda.empty_cache()
         out["config"]["also_turbo"] = dict(workload="whisper-large-turbo finetune step (teacher-forced, dropout 0.1), 8 x 30 s, "
-                                                    "log-mel on GPU; fp8_forward = encoder q|k|v, fc1, fc2 forward projections with e4m3 weights and activations "
-                                                    "(DESIGN.md 4.4)",
+                                                    "log-mel on GPU; fp8_forward = all encoder forward projections + the data gradients of fc2 / out_proj with "
+                                                    "e4m3 weights and activations (DESIGN.md 4.4)",
                                            unit="audio-seconds/sec", **tb)
         # the reference's DEFAULT model key (R/config/asr_finetuning.yaml:1-11: model=whisper-large = large-v3, 32 + 32 layers)
         r6 = whisper_measure("whisper-large", args, world, rank, device, decode=False, fp8=False, B=8, steps=4, warmup=2)
