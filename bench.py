@@ -327,7 +327,7 @@ def whisper_bench(args, world, rank, device):
             "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(r["ms_per_step"], 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": ("bf16 + fp8 e4m3 (encoder q|k|v, fc1 forward)" if args.decode else
-                                          "bf16 + fp8 e4m3 (encoder q|k|v, out, fc1, fc2 forward and the data gradients of fc2 / out: e4m3 weights and activations, delayed scaling)") if fp8 else "bf16",
+                                          "bf16 + fp8 e4m3 (encoder q|k|v, out, fc1, fc2 forward and the data gradients of fc2 / out / fc1: e4m3 weights and activations, delayed scaling)") if fp8 else "bf16",
             "data": "synthetic", "config": cfg}), flush=True)
     if world > 1:
         if args.check_replicas and not args.decode:
@@ -642,7 +642,7 @@ def main():
             del r5
             torch.cuda.empty_cache()
         out["config"]["also_turbo"] = dict(workload="whisper-large-turbo finetune step (teacher-forced, dropout 0.1), 8 x 30 s, "
-                                                    "log-mel on GPU; fp8_forward = all encoder forward projections + the data gradients of fc2 / out_proj with "
+                                                    "log-mel on GPU; fp8_forward = all encoder forward projections + the data gradients of fc2 / out_proj / fc1 with "
                                                     "e4m3 weights and activations (DESIGN.md 4.4)",
                                            unit="audio-seconds/sec", **tb)
         # the reference's DEFAULT model key (R/config/asr_finetuning.yaml:1-11: model=whisper-large = large-v3, 32 + 32 layers)

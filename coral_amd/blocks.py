@@ -292,9 +292,12 @@ class FFNBlock:
         wg = [dict(dY=dy, X=sv["g"], M=d, N=f, K=M, lda=d, ldb=f, c_off=o(self.fc2 + ".weight"), accumulate=acc,
                    sq=sq.get("fc2"),
                    **(dict(bias_off=o(self.fc2 + ".bias"), part=sc.part, cs_off=self.cs_fc2) if defer is not None else {}))]
+        du8 = getattr(self, "fp8_du", None) if fb is not None else None
         if fb is not None:  # fc2's data gradient on the fp8 path (GELU' epilogue as on the bf16 path)
+            # (fc1's data gradient on it too: dU also leaves this epilogue as e4m3, delayed per-tensor scale - CaGemmDesc.C8)
+            c8 = dict(C8=du8["buf"], c8_scale=du8["scale"], c8_amax=du8["amax"]) if du8 is not None else {}
             ops.gemm_fp8(fb[2], fb[0], sc.du, a_row_scale=fb[3], b_scale=fb[4], M=M, N=f, K=d, lda=d, ldb=d, ldc=f, b_off=fb[1],
-                         epilogue=EPI_DGELU, R=sv["u"], ldr=f, dropout_p=p, dropout_seed=seed)
+                         epilogue=EPI_DGELU, R=sv["u"], ldr=f, dropout_p=p, dropout_seed=seed, **c8)
         else:
             ops.gemm(dy, p16, sc.du, M=M, N=f, K=d, lda=d, b_layout=MNMAJOR, ldb=f, ldc=f, b_off=o(self.fc2 + ".weight"),
                      epilogue=EPI_DGELU, R=sv["u"], ldr=f, dropout_p=p, dropout_seed=seed)
@@ -307,5 +310,11 @@ class FFNBlock:
             defer.extend(wg)
         else:
             ops.wgrad_gemm_group(wg, g32)
-        ops.gemm(sc.du, p16, sc.dx, M=M, N=d, K=f, lda=f, b_layout=MNMAJOR, ldb=d, ldc=d, b_off=o(self.fc1 + ".weight"))
+        if du8 is not None and du8["ready"][0]:
+            # dX = dU W1 through ca_gemm_fp8: e4m3 dU x the transposed e4m3 copy of W1 (the scale of dU comes from the
+            # previous step's amax; until one backward has measured it the bf16 GEMM below runs)
+            ops.gemm_fp8(du8["buf"], fb[0], sc.dx, a_scale=du8["inv"], b_scale=du8["inv_w"], M=M, N=d, K=f, lda=f, ldb=f, ldc=d,
+                         b_off=du8["w_off"])
+        else:
+            ops.gemm(sc.du, p16, sc.dx, M=M, N=d, K=f, lda=f, b_layout=MNMAJOR, ldb=d, ldc=d, b_off=o(self.fc1 + ".weight"))
         _ln_bwd(st, self.ln, sc.dx, sv, dh, dhin, sc, M, d, ln_part, pending)

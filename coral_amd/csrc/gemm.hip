@@ -449,7 +449,7 @@ __device__ __forceinline__ void gemm_epilogue_fast(const CaGemmDesc& d, const fl
   const uint64_t istep = 8ull * (uint64_t)N;
   u16x8_t r_next = {0, 0, 0, 0, 0, 0, 0, 0};
   if (NEEDS_R) r_next = *(const u16x8_t*)Rp;
-  const bool c8_on = EPI == CA_EPI_GELU && d.C8 != nullptr;  // (wave-uniform)
+  const bool c8_on = (EPI == CA_EPI_GELU || EPI == CA_EPI_DGELU) && d.C8 != nullptr;  // (wave-uniform)
   const float s8 = c8_on ? d.c8_scale[0] : 1.f;
 #pragma unroll 2
   for (int it = 0; it < 8; ++it) {
@@ -509,6 +509,7 @@ __device__ __forceinline__ void gemm_epilogue_fast(const CaGemmDesc& d, const fl
         __builtin_nontemporal_store(o, (u16x8_t*)((unsigned short*)d.C + coff));
       else
         *(u16x8_t*)((unsigned short*)d.C + coff) = o;
+      if (EPI == CA_EPI_DGELU && c8_on) ca_store_fp8x8((unsigned char*)d.C8 + coff, v, s8, amx);
     }
     if (EPI == CA_EPI_GELU) {
       u16x8_t o;
@@ -567,7 +568,7 @@ __device__ __forceinline__ void gemm_epilogue(const CaGemmDesc& d, f32x4_t (&acc
         *(f32x4_t*)(wt + (i * 16 + (lane & 15)) * EPI_PITCH + j * 16 + 4 * (lane >> 4)) = acc[i][j];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private region: no barrier
   }
-  const bool c8_on = d.C8 != nullptr && epi == CA_EPI_GELU;
+  const bool c8_on = d.C8 != nullptr && (epi == CA_EPI_GELU || epi == CA_EPI_DGELU);
   if (nvalid <= 0 && d.c_sumsq == nullptr && !c8_on) return;
   float ssq = 0.f;  // sum of squares of the fp32 values this lane stores (c_sumsq)
   float amx = 0.f;  // max |gelu| this lane stores (C8)
@@ -709,14 +710,17 @@ __device__ __forceinline__ void gemm_epilogue(const CaGemmDesc& d, f32x4_t (&acc
     }
     if (c8_on) {
       unsigned char* C8 = (unsigned char*)d.C8 + coff;
+      float w8[8];  // the activation (GELU) or the gradient (GELU') this tile just formed
+#pragma unroll
+      for (int e = 0; e < 8; ++e) w8[e] = epi == CA_EPI_GELU ? v2[e] : v[e];
       if (full) {
-        ca_store_fp8x8(C8, v2, s8, amx);
+        ca_store_fp8x8(C8, w8, s8, amx);
       } else {
 #pragma unroll
         for (int e = 0; e < 8; ++e)
           if (e < nvalid) {
-            amx = fmaxf(amx, fabsf(v2[e]));
-            const float t = fminf(fmaxf(v2[e] * s8, -448.0f), 448.0f);
+            amx = fmaxf(amx, fabsf(w8[e]));
+            const float t = fminf(fmaxf(w8[e] * s8, -448.0f), 448.0f);
             C8[e] = (unsigned char)(__builtin_amdgcn_cvt_pk_fp8_f32(t, 0.f, 0u, false) & 0xffu);
           }
       }
@@ -2195,9 +2199,9 @@ extern "C" int ca_gemm_fp8(const CaGemmDesc* desc, void* stream) {
   CA_CHECK_ARG(desc != nullptr, "ca_gemm_fp8: null descriptor");
   const CaGemmDesc& d = *desc;
   CA_CHECK_ARG(d.A && d.B && (d.C || d.C2) && d.M > 0 && d.N > 0 && d.K > 0, "ca_gemm_fp8: bad argument");
-  CA_CHECK_ARG(d.C8 == nullptr || (d.epilogue == CA_EPI_GELU && d.c8_scale != nullptr && (d.ldc % 8) == 0 &&
+  CA_CHECK_ARG(d.C8 == nullptr || ((d.epilogue == CA_EPI_GELU || d.epilogue == CA_EPI_DGELU) && d.c8_scale != nullptr && (d.ldc % 8) == 0 &&
                                    ((uintptr_t)d.C8 % 8) == 0),
-               "ca_gemm_fp8: C8 needs CA_EPI_GELU, a scale and 8-byte aligned rows");
+               "ca_gemm_fp8: C8 needs CA_EPI_GELU / CA_EPI_DGELU, a scale and 8-byte aligned rows");
   CA_CHECK_ARG(d.a_layout == CA_KMAJOR && d.b_layout == CA_KMAJOR && d.batch1 == 1 && d.batch2 == 1 && d.a_kseg == 0 &&
                    d.b_kseg == 0 && !d.a_colsum && !d.c_row_index,
                "ca_gemm_fp8: K-major operands, un-batched, plain rows only");
@@ -2339,9 +2343,9 @@ static int ca_gemm_launch(const CaGemmDesc* desc, void* stream) {
   if (d.epilogue == CA_EPI_RESIDUAL || d.epilogue == CA_EPI_DGELU || d.epilogue == CA_EPI_GELU_RESIDUAL)
     CA_CHECK_ARG(d.R != nullptr, "ca_gemm_bf16: epilogue needs R");
   CA_CHECK_ARG(d.dropout_p >= 0.f && d.dropout_p < 1.f, "ca_gemm_bf16: bad dropout_p");
-  CA_CHECK_ARG(d.C8 == nullptr || (d.epilogue == CA_EPI_GELU && d.c8_scale != nullptr && d.batch1 == 1 && d.batch2 == 1 &&
+  CA_CHECK_ARG(d.C8 == nullptr || ((d.epilogue == CA_EPI_GELU || d.epilogue == CA_EPI_DGELU) && d.c8_scale != nullptr && d.batch1 == 1 && d.batch2 == 1 &&
                                    (d.ldc % 8) == 0 && ((uintptr_t)d.C8 % 8) == 0 && d.M > 32),
-               "ca_gemm_bf16: C8 needs CA_EPI_GELU, a scale, an un-batched problem and 8-byte aligned rows");
+               "ca_gemm_bf16: C8 needs CA_EPI_GELU / CA_EPI_DGELU, a scale, an un-batched problem and 8-byte aligned rows");
   if (d.a_colsum)
     CA_CHECK_ARG(d.a_layout == CA_MNMAJOR && d.b_layout == CA_MNMAJOR && d.batch1 == 1 && d.batch2 == 1 && d.a_kseg == 0,
                  "ca_gemm_bf16: a_colsum needs the un-batched weight-gradient form");

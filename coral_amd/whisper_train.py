@@ -98,14 +98,15 @@ class WhisperTrainEngine(WhisperEngine):
         dgrad = os.environ.get("CA_FP8_DGRAD", "1") == "1" and ffn2 and out8
         d_, f_ = self.s.d_model, self.s.encoder_ffn_dim
         nw = 4 * L  # weight tensors: q|k|v, out, fc1, fc2 per layer; then two activations per layer: GELU output, attention output
-        na = 2 * L
+        na = 3 * L  # per layer: GELU output, attention output (forward), dU = the gradient entering fc1 (backward)
         f8 = dict(p8=torch.zeros(st.numel, dtype=torch.uint8, device=dev), nw=nw, na=na, ffn2=ffn2, out8=out8,
                   amax=torch.zeros((nw + na) * ops.FP8_AMAX_SLOTS, dtype=torch.int32, device=dev),
                   scale=torch.ones(nw + na, dtype=torch.float32, device=dev),
                   inv=torch.ones(nw + na, dtype=torch.float32, device=dev), x8=None, rs=None, g8=None, c8=None,
-                  dgrad=dgrad, dy8=None, drs=None,
-                  # transposed e4m3 copies for the data gradients: per layer fc2^T [f, d] then out_proj^T [d, d]
-                  p8t=torch.zeros(L * (f_ * d_ + d_ * d_), dtype=torch.uint8, device=dev) if dgrad else None)
+                  dgrad=dgrad, dy8=None, drs=None, du8=None, du_ready=[False], bwd_seen=False,
+                  dgrad_fc1=dgrad and os.environ.get("CA_FP8_DGRAD_FC1", "1") == "1",
+                  # transposed e4m3 copies for the data gradients: per layer fc2^T [f, d], out_proj^T [d, d], fc1^T [d, f]
+                  p8t=torch.zeros(L * (2 * f_ * d_ + d_ * d_), dtype=torch.uint8, device=dev) if dgrad else None)
         # activations: a first guess (amax 8, margin 2) until the first step has measured them
         f8["scale"][nw:] = 448.0 / 16.0
         f8["inv"][nw:] = 16.0 / 448.0
@@ -135,13 +136,15 @@ class WhisperTrainEngine(WhisperEngine):
                 off, i = st.off(name), 4 * l + k
                 ops.quantize_fp8_delayed(st.p16[off:off + n], f8["p8"][off:off + n], f8["scale"][i:i + 1],
                                          f8["amax"][i * ops.FP8_AMAX_SLOTS:], n=n)
-                if f8["dgrad"] and k in (1, 3):  # the transposed copy, same scale
+                if f8["dgrad"] and k in (1, 2, 3):  # the transposed copy, same scale
                     d, f = self.s.d_model, self.s.encoder_ffn_dim
-                    base = l * (f * d + d * d)
-                    if k == 3:
+                    base = l * (2 * f * d + d * d)
+                    if k == 3:    # fc2 [d, f] -> [f, d]
                         ops.quantize_fp8_transposed(st.p16, d, f, f8["p8t"], f8["scale"][i:i + 1], x_off=off, qt_off=base)
-                    else:
+                    elif k == 1:  # out_proj [d, d]
                         ops.quantize_fp8_transposed(st.p16, d, d, f8["p8t"], f8["scale"][i:i + 1], x_off=off, qt_off=base + f * d)
+                    elif f8["dgrad_fc1"]:  # fc1 [f, d] -> [d, f]
+                        ops.quantize_fp8_transposed(st.p16, f, d, f8["p8t"], f8["scale"][i:i + 1], x_off=off, qt_off=base + f * d + d * d)
 
     def refresh_bucket(self, name: str):
         """Trainer hook: bucket `name` has just been updated (on the trainer's optimiser stream).  The first bucket of a
@@ -150,9 +153,13 @@ class WhisperTrainEngine(WhisperEngine):
         if f8 is None:
             return
         if name == next(iter(self.store.buckets)):
-            nw, na = f8["nw"], f8["na"]
+            nw, L = f8["nw"], self.s.encoder_layers
+            S = ops.FP8_AMAX_SLOTS
             ops.fp8_amax_rotate(f8["amax"], f8["scale"], f8["inv"], nw, margin=1.0)
-            ops.fp8_amax_rotate(f8["amax"][nw * ops.FP8_AMAX_SLOTS:], f8["scale"][nw:], f8["inv"][nw:], na, margin=2.0)
+            ops.fp8_amax_rotate(f8["amax"][nw * S:], f8["scale"][nw:], f8["inv"][nw:], 2 * L, margin=2.0)  # activations
+            ops.fp8_amax_rotate(f8["amax"][(nw + 2 * L) * S:], f8["scale"][nw + 2 * L:], f8["inv"][nw + 2 * L:], L, margin=4.0)  # gradients
+            if f8["bwd_seen"]:
+                f8["du_ready"][0] = True  # the gradients' scales now come from a measured backward
         if name.startswith("enc") and name[3:].isdigit():
             self.refresh_fp8(int(name[3:]))
 
@@ -311,6 +318,7 @@ class WhisperTrainEngine(WhisperEngine):
             f8["c8"] = torch.zeros(Me * s.d_model, dtype=torch.uint8, device=dev) if f8["out8"] else None
             f8["dy8"] = torch.zeros(Me * s.d_model, dtype=torch.uint8, device=dev) if f8["dgrad"] else None
             f8["drs"] = torch.zeros(Me, dtype=torch.float32, device=dev) if f8["dgrad"] else None
+            f8["du8"] = torch.zeros(Me * s.encoder_ffn_dim, dtype=torch.uint8, device=dev) if f8["dgrad_fc1"] else None
             nw, S = f8["nw"], ops.FP8_AMAX_SLOTS
 
             def act(i, buf, w):  # (e4m3 activation, its scale / dequantisation factor / amax accumulator, the weight's factor)
@@ -321,10 +329,16 @@ class WhisperTrainEngine(WhisperEngine):
                 ff.fp8 = (f8["p8"], f8["inv"][4 * l + 2:4 * l + 3], f8["x8"], f8["rs"])
                 ff.fp8_fc2 = act(2 * l, f8["g8"], 4 * l + 3) if f8["ffn2"] else None       # fc2 <- GELU output
                 sa.fp8_out = act(2 * l + 1, f8["c8"], 4 * l + 1) if f8["out8"] else None  # out_proj <- attention output
+                ff.fp8_du = None
                 if f8["dgrad"]:  # (transposed weights, offset, e4m3 dY, its row scales, the weight's dequantisation factor)
-                    base = l * (s.encoder_ffn_dim * s.d_model + s.d_model * s.d_model)
+                    fd, dd = s.encoder_ffn_dim * s.d_model, s.d_model * s.d_model
+                    base = l * (2 * fd + dd)
                     ff.fp8_bwd = (f8["p8t"], base, f8["dy8"], f8["drs"], f8["inv"][4 * l + 3:4 * l + 4])
-                    sa.fp8_bwd = (f8["p8t"], base + s.encoder_ffn_dim * s.d_model, f8["dy8"], f8["drs"], f8["inv"][4 * l + 1:4 * l + 2])
+                    sa.fp8_bwd = (f8["p8t"], base + fd, f8["dy8"], f8["drs"], f8["inv"][4 * l + 1:4 * l + 2])
+                    if f8["dgrad_fc1"]:
+                        i = nw + 2 * len(self.enc_blocks) + l
+                        ff.fp8_du = dict(buf=f8["du8"], scale=f8["scale"][i:i + 1], inv=f8["inv"][i:i + 1], amax=f8["amax"][i * S:],
+                                         inv_w=f8["inv"][4 * l + 2:4 * l + 3], w_off=base + fd + dd, ready=f8["du_ready"])
                 else:
                     ff.fp8_bwd = sa.fp8_bwd = None
         self._tw, self._tw_key = w, key
@@ -438,6 +452,8 @@ class WhisperTrainEngine(WhisperEngine):
         s, st = self.s, self.store
         w, B, L = sv["w"], sv["B"], sv["L"]
         p16, g32, o = st.p16, st.g32, st.off
+        if self._fp8_train is not None:
+            self._fp8_train["bwd_seen"] = True  # (this backward measures the amax of the gradients entering fc1)
         T, d = s.max_source_positions, s.d_model
         Tin = 2 * T
         Me, Md = B * T, B * L

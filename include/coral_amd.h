@@ -131,9 +131,10 @@ typedef struct CaGemmDesc {
    * displace the operands of the next GEMMs from the L2s / Infinity Cache (measured: -0.5 ms of the 73-ms XLS-R-2B step
    * for the pre-activation alone).  Results are unchanged.  C2 always takes the default policy. */
   int32_t c_stream_out;
-  /* Optional, CA_EPI_GELU only: a third output C8[m * ldc + n] = e4m3(clamp(gelu(v) * c8_scale[0])) - the activation
-   * (after dropout) as the fp8 A operand of the NEXT projection (ca_gemm_fp8 with a_scale = the matching inv_scale),
-   * written by the tile that computes it: no quantisation pass.  c8_scale is a device scalar from the previous step's
+  /* Optional, CA_EPI_GELU / CA_EPI_DGELU: one more output C8[m * ldc + n] = e4m3(clamp(w * c8_scale[0])), w = gelu(v)
+   * (after dropout; CA_EPI_GELU) or the gradient v * gelu'(R) (CA_EPI_DGELU) - the fp8 A operand of the NEXT projection
+   * / data gradient (ca_gemm_fp8 with a_scale = the matching inv_scale), written by the tile that computes it: no
+   * quantisation pass.  c8_scale is a device scalar from the previous step's
    * amax (ca_fp8_amax_rotate); max|gelu(v)| of this launch is accumulated into the CA_FP8_AMAX_SLOTS words at c8_amax.
    * NULL = off. */
   void* C8;

@@ -218,6 +218,21 @@ def test_whisper_training_with_fp8_forward_projections():
     cos = torch.nn.functional.cosine_similarity(g0.flatten(), g1.flatten(), dim=0).item()
     assert cos > 0.98, cos
     assert not torch.equal(g0, g1)  # the fp8 path really ran
+    # The gradient entering fc1 joins the fp8 path only once a backward has measured its amax (delayed scaling): turn the
+    # scales over as the trainer does after a step (same weights: the e4m3 copies come out the same), run the step again
+    # - now with every fp8 piece active - and hold its gradients against the bf16 step's as well
+    assert not eng._fp8_train["du_ready"][0]
+    eng.refresh_bucket(next(iter(eng.store.buckets)))
+    assert eng._fp8_train["du_ready"][0]
+    eng.zero_grad()
+    out = eng(**batch)
+    eng.backward()
+    torch.cuda.synchronize()
+    g2 = eng.store.g32
+    cos2 = torch.nn.functional.cosine_similarity(g0.flatten(), g2.flatten(), dim=0).item()
+    print(f"fp8 step vs bf16 step: gradient cosine {cos:.5f} (first step), {cos2:.5f} (all pieces, e4m3 gradient into fc1)")
+    assert abs(float(out.loss) - l0) <= 0.02 * abs(l0) and cos2 > 0.97, cos2
+    assert not torch.equal(g1, g2)
     eng = WhisperTrainEngine(WhisperShape(**kw), DEV)
     eng.load_state_dict(w.synth_params(c))
     eng.enable_fp8_forward()
@@ -234,6 +249,7 @@ def test_whisper_training_with_fp8_forward_projections():
     nw = f8["nw"]
     assert f8["ffn2"] and f8["out8"] and f8["dgrad"] and bool((f8["scale"][nw:] != 28.0).all()) and bool((f8["scale"][:nw] > 1.0).all())
     assert int(f8["p8t"].count_nonzero()) > 0 and int(f8["dy8"].count_nonzero()) > 0  # the fp8 data gradients ran
+    assert f8["dgrad_fc1"] and f8["du_ready"][0] and int(f8["du8"].count_nonzero()) > 0  # ... fc1's too, after the first step
     for name, n in (("fc2", 64 * 128), ("self_attn.out_proj", 64 * 64)):
         off = eng.store.off(f"model.encoder.layers.1.{name}.weight")
         assert int(f8["p8"][off:off + n].count_nonzero()) > 0
@@ -266,12 +282,14 @@ def test_delayed_quantiser_and_amax_rotation(ops):
 
 @pytest.mark.parametrize("force", [1, 3])
 @pytest.mark.parametrize("fp8_in", [False, True])
-def test_gelu_epilogue_third_output_in_fp8(ops, force, fp8_in):
-    """CaGemmDesc.C8: the GELU output of a projection also as e4m3 with a given per-tensor scale, from the tile that
-    computes it (bf16 and fp8 input GEMM, 128 x 128 and 256 x 256 kernels, interior and ragged tiles, with dropout): the
-    bytes are the e4m3 cast of the kernel's own fp32 GELU value times the scale - checked against the bf16 second output
-    to one e4m3 step - and the amax word holds max |GELU|."""
-    from coral_amd.ops import EPI_GELU
+@pytest.mark.parametrize("grad", [False, True])
+def test_gelu_epilogue_third_output_in_fp8(ops, force, fp8_in, grad):
+    """CaGemmDesc.C8: the GELU output of a projection (grad = False, CA_EPI_GELU) or the gradient v * GELU'(R) of a data
+    gradient (grad = True, CA_EPI_DGELU) also as e4m3 with a given per-tensor scale, from the tile that computes it (bf16
+    and fp8 input GEMM, 128 x 128 and 256 x 256 kernels, interior and ragged tiles, with dropout): the bytes are the e4m3
+    cast of the kernel's own fp32 value times the scale - checked against the bf16 output to one e4m3 step - and the amax
+    accumulator holds max |value|."""
+    from coral_amd.ops import EPI_DGELU, EPI_GELU
 
     M, N, K = 1000, 520, 256
     a = rnd(M, K, seed=1, scale=0.5).to(torch.bfloat16)
@@ -282,8 +300,14 @@ def test_gelu_epilogue_third_output_in_fp8(ops, force, fp8_in):
     g8 = torch.zeros(M, N, dtype=torch.uint8, device=DEV)
     sc = torch.tensor([37.0], device=DEV)
     amax = torch.zeros(ops.FP8_AMAX_SLOTS, dtype=torch.int32, device=DEV)
-    kw = dict(C2=g, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=bias.to(DEV), epilogue=EPI_GELU, dropout_p=0.1, dropout_seed=11,
-              C8=g8, c8_scale=sc, c8_amax=amax)
+    kw = dict(M=M, N=N, K=K, lda=K, ldb=K, ldc=N, dropout_p=0.1, dropout_seed=11, C8=g8, c8_scale=sc, c8_amax=amax)
+    if grad:
+        R = rnd(M, N, seed=5, scale=1.5).to(torch.bfloat16).to(DEV)
+        kw.update(epilogue=EPI_DGELU, R=R, ldr=N)
+        out = u  # the gradient is the first output
+    else:
+        kw.update(C2=g, bias=bias.to(DEV), epilogue=EPI_GELU)
+        out = g
     ops.lib().ca_gemm_force_kernel(force)
     try:
         if fp8_in:
@@ -295,7 +319,7 @@ def test_gelu_epilogue_third_output_in_fp8(ops, force, fp8_in):
     finally:
         ops.lib().ca_gemm_force_kernel(0)
     torch.cuda.synchronize()
-    gf = g.float().cpu()
+    gf = out.float().cpu()
     got = g8.cpu().view(torch.float8_e4m3fn).float() / 37.0
     # e4m3 carries 3 mantissa bits: within one step (2^-3 relative, 2^-9 absolute after the scale) of the bf16 output
     tol = gf.abs() * 0.0625 + gf.abs() * 0.008 + 2.0 ** -9 / 37.0 * 2
