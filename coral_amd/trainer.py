@@ -154,7 +154,7 @@ class GradSync:
         if self.capi is not None:
             self.comm_stream = self.capi.stream
         else:
-            self.comm_stream = torch.cuda.Stream(device=flat_grad.device) if (self.on_gpu and self.active) else None
+            self.comm_stream = ops.side_stream(flat_grad.device, "exchange") if (self.on_gpu and self.active) else None
         self.compress = compress and self.active
         self.g16 = torch.empty_like(flat_grad, dtype=torch.bfloat16) if self.compress else None
         self._pending = []
@@ -388,7 +388,7 @@ class DataParallelTrainer:
         if self.overlap_optimizer:
             # the HBM-bound update only fills what the MFMA-bound forward leaves free: lowest queue priority
             prio = int(os.environ.get("CA_OPT_PRIO", "0"))
-            self.opt_stream = torch.cuda.Stream(device=st.device, priority=prio)
+            self.opt_stream = ops.side_stream(st.device, "optimizer", prio)
         self.opt_done = None
         # per-bucket squared gradient norms, computed on the side stream as the buckets complete
         self.bucket_index = {name: i for i, name in enumerate(st.buckets)}
@@ -581,7 +581,7 @@ class DataParallelTrainer:
                 # collectives of this trainer are ever in flight in an order that could differ between ranks (by the
                 # time the optimiser runs, the step's reduce-scatters have been waited for: nothing queues in front)
                 self._ag_comm = self.sync.capi
-                self._ag_stream = self._ag_comm.stream if self._ag_comm is not None else torch.cuda.Stream(device=st.device)
+                self._ag_stream = self._ag_comm.stream if self._ag_comm is not None else ops.side_stream(st.device, "gather")
             self._ag_stream.wait_stream(cur)
             with torch.cuda.stream(self._ag_stream):
                 self._allgather_bf16(mlo, bhi, sa, sb)

@@ -918,7 +918,7 @@ class Wav2Vec2CTCEngine:
         if os.environ.get("CA_WGRAD_STREAM", "1") == "0":
             return None
         if getattr(self, "_wstream", None) is None:
-            self._wstream = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("CA_WGRAD_PRIO", "0")))
+            self._wstream = ops.side_stream(self.device, "wgrad", int(os.environ.get("CA_WGRAD_PRIO", "0")))
         return self._wstream
 
     def _attention_bwd(self, w, l, dctx, B, T, Tp, H, hd, d, scale, dqkv=None):

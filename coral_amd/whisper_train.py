@@ -612,7 +612,7 @@ class WhisperTrainEngine(WhisperEngine):
         if os.environ.get("CA_WGRAD_STREAM", "1") == "0":
             return None
         if getattr(self, "_wstream", None) is None:
-            self._wstream = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("CA_WGRAD_PRIO", "0")))
+            self._wstream = ops.side_stream(self.device, "wgrad", int(os.environ.get("CA_WGRAD_PRIO", "0")))
         return self._wstream
 
     def clear_internal_grads_of(self, prefix: str):

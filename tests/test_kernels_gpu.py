@@ -834,3 +834,14 @@ def test_grouped_second_stage_reductions_are_bit_identical(ops):
     ops.reduce_rows_multi([(parts[3], 3, 40, 33, got[3], False)])
     torch.cuda.synchronize()
     assert (got[3].double() - parts[3][:, :33].double().sum(0)).abs().max() <= 1e-5
+
+
+def test_side_streams_are_one_per_role_and_process(ops, monkeypatch):
+    """Every engine of a process gets the SAME weight-gradient / optimiser stream (the stream -> hardware-queue assignment,
+    hence the overlap, must not depend on how many engines were built before); CA_SHARED_STREAMS=0 is the A/B switch."""
+    a, b = ops.side_stream("cuda:0", "wgrad"), ops.side_stream(torch.device("cuda", 0), "wgrad")
+    assert a is b and a.cuda_stream != torch.cuda.default_stream().cuda_stream
+    assert ops.side_stream("cuda:0", "optimizer") is not a
+    assert ops.side_stream("cuda:0", "wgrad", -1) is not a
+    monkeypatch.setenv("CA_SHARED_STREAMS", "0")
+    assert ops.side_stream("cuda:0", "wgrad") is not a
