@@ -21,7 +21,9 @@ import sys
 import time
 from pathlib import Path
 
-import torch
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")  # before the HIP runtime initialises (see coral_amd/__init__.py)
+
+import torch  # noqa: E402
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))

@@ -74,6 +74,9 @@ class CaGemmDesc(C.Structure):
         ("C8", C.c_void_p),
         ("c8_scale", C.c_void_p),
         ("c8_amax", C.c_void_p),
+        ("a_ln_gamma", C.c_void_p),
+        ("a_ln_beta", C.c_void_p),
+        ("a_ln_eps", C.c_float),
     ]
 
 

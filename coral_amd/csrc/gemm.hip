@@ -1711,9 +1711,23 @@ __global__ __launch_bounds__(512) void ca_gemm_kernel_l(const CaGemmDesc d) {
 // N/16 workgroups: 64 (N = 1024) to 3242 (the 51865-entry vocabulary).  MB = row blocks of 16: a batch of 17..32 clips
 // takes a second A fragment and accumulator against the SAME weight fragment (round 3: the launches and the weight
 // bytes of a decoded token are shared by twice the clips).
-template <int MB>
+// LN (CaGemmDesc.a_ln_gamma): the A rows are LayerNorm(A rows), formed by every workgroup in its prologue (the
+// arithmetic of ln_fwd_kernel, chunk by chunk: a wave per row, the normalised row rounded to bf16 as the LayerNorm
+// launch would have stored it) into an LDS image the MFMA operand loads then read - the LayerNorm launch in front of
+// the q|k|v and fc1 projections of a decoded token (4.9 us each from dispatch to completion, a quarter of them a
+// memory round trip) disappears from the per-token chain; bit-identical to the two launches.  The first eight weight
+// fragments of every wave (all of them at K = 1024) are asked for BEFORE the prologue, so the statistics run under
+// the weight fetch.
+#define SKINNY_LN_PAD 32  // bf16 elements between LDS rows beyond K: 64 B, lanes r and r + 1 then sit 16 banks apart
+// NCH: 64-lane rounds of 8-element chunks a row takes (K <= 512 NCH), 0 = no LayerNorm prologue
+template <int MB, int NCH = 0>
 __global__ __launch_bounds__(256) void ca_gemm_skinny_kernel(const CaGemmDesc d) {
-  __shared__ float part[4][MB * 16 * 16];
+  constexpr bool LN = NCH > 0;
+  constexpr int NC = LN ? NCH : 1;
+  extern __shared__ __attribute__((aligned(16))) char sk_smem[];
+  float(*part)[MB * 16 * 16] = (float(*)[MB * 16 * 16]) sk_smem;
+  unsigned short* const xs = (unsigned short*)(sk_smem + 4 * MB * 256 * sizeof(float));  // LN only: [16 MB][K + pad]
+  const int xpitch = d.K + SKINNY_LN_PAD;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n0 = blockIdx.x * 16;
@@ -1768,16 +1782,96 @@ __global__ __launch_bounds__(256) void ca_gemm_skinny_kernel(const CaGemmDesc d)
   void* const Cdst = hi ? d.C_hi : d.C;
   const int64_t ldcd = hi ? d.ldc_hi : d.ldc;
   const int ncol0 = hi ? d.c_split_n : 0;
+  bf16x8_t wf0[8];  // LN: the first iteration's weight fragments, in flight across the prologue
+  if constexpr (LN) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int k = (ks0 + u) * 32 + 8 * g;
+      wf0[u] = (ks0 + u < ks1 && k < d.K) ? *(const bf16x8_t*)(wp + (int64_t)(ks0 + u) * 32) : zero;
+    }
+    // rows wave, wave + 4, ...: all of a wave's rows are asked for before the first statistic (one round trip)
+    constexpr int RW = MB * 4;
+    const int C = d.K, nchunk = C >> 3;
+    const unsigned short* xr = (const unsigned short*)d.A;
+    u16x8_t raw[RW][NC];
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+      const int row = wave + 4 * i;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const int ch = lane + c * 64;
+        raw[i][c] = (row < d.M && ch < nchunk) ? *(const u16x8_t*)(xr + (int64_t)row * d.lda + ch * 8)
+                                               : (u16x8_t){0, 0, 0, 0, 0, 0, 0, 0};
+      }
+    }
+    f32x4_t gq[NC][2], bq[NC][2];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int ch = lane + c * 64;
+      if (ch < nchunk) {
+        gq[c][0] = *(const f32x4_t*)(d.a_ln_gamma + ch * 8);
+        gq[c][1] = *(const f32x4_t*)(d.a_ln_gamma + ch * 8 + 4);
+        bq[c][0] = *(const f32x4_t*)(d.a_ln_beta + ch * 8);
+        bq[c][1] = *(const f32x4_t*)(d.a_ln_beta + ch * 8 + 4);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+      const int row = wave + 4 * i;
+      if (row >= d.M) break;  // (wave-uniform)
+      float sx = 0.f;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        if (lane + c * 64 < nchunk) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) sx += bf2f(raw[i][c][e]);
+        }
+      }
+      const float mean = wave_sum(sx) / (float)C;
+      float s2 = 0.f;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        if (lane + c * 64 < nchunk) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float dlt = bf2f(raw[i][c][e]) - mean;
+            s2 += dlt * dlt;
+          }
+        }
+      }
+      const float rstd = rsqrtf(wave_sum(s2) / (float)C + d.a_ln_eps);
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const int ch = lane + c * 64;
+        if (ch < nchunk) {
+          u16x8_t o8;
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            o8[e] = f2bf(ln_apply(bf2f(raw[i][c][e]), mean, rstd, e < 4 ? gq[c][0][e] : gq[c][1][e - 4],
+                                  e < 4 ? bq[c][0][e] : bq[c][1][e - 4]));
+          *(u16x8_t*)(xs + (int64_t)row * xpitch + ch * 8) = o8;
+        }
+      }
+    }
+    __syncthreads();
+  }
   for (int ks = ks0; ks < ks1; ks += 8) {
     bf16x8_t wf[8], af[MB][8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int k = (ks + u) * 32 + 8 * g;
       const bool ok = ks + u < ks1 && k < d.K;  // K is a multiple of 8 (lda/ldb rule), so a chunk is all-or-nothing
-      wf[u] = ok ? *(const bf16x8_t*)(wp + (int64_t)(ks + u) * 32) : zero;
+      if constexpr (LN) {
+        wf[u] = ks == ks0 ? wf0[u] : (ok ? *(const bf16x8_t*)(wp + (int64_t)(ks + u) * 32) : zero);
 #pragma unroll
-      for (int mb = 0; mb < MB; ++mb)
-        af[mb][u] = (ok && 16 * mb + r < d.M) ? *(const bf16x8_t*)(ap[mb] + (int64_t)(ks + u) * 32) : zero;
+        for (int mb = 0; mb < MB; ++mb)
+          af[mb][u] = (ok && 16 * mb + r < d.M) ? *(const bf16x8_t*)(xs + (int64_t)(16 * mb + r) * xpitch + k) : zero;
+      } else {
+        wf[u] = ok ? *(const bf16x8_t*)(wp + (int64_t)(ks + u) * 32) : zero;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+          af[mb][u] = (ok && 16 * mb + r < d.M) ? *(const bf16x8_t*)(ap[mb] + (int64_t)(ks + u) * 32) : zero;
+      }
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u)
@@ -2363,13 +2457,39 @@ static int ca_gemm_launch(const CaGemmDesc* desc, void* stream) {
     g_last_kind = 0;
     CA_CHECK_ARG(d.c_split_n == 0 || (d.C_hi && (d.c_split_n % 16) == 0 && d.c_split_n < d.N && d.epilogue == CA_EPI_NONE),
                  "ca_gemm_bf16: c_split_n needs C_hi, a multiple of 16 below N and no epilogue");
-    if (d.M <= 16)
-      CA_LAUNCH(ca_gemm_skinny_kernel<1>, dim3((unsigned)((d.N + 15) / 16)), dim3(256), 0, s, d);
-    else
-      CA_LAUNCH(ca_gemm_skinny_kernel<2>, dim3((unsigned)((d.N + 15) / 16)), dim3(256), 0, s, d);
+    const unsigned grid = (unsigned)((d.N + 15) / 16);
+    if (d.a_ln_gamma) {
+      CA_CHECK_ARG(d.a_ln_beta && d.K <= 2048 && ((uintptr_t)d.a_ln_gamma % 16) == 0 && ((uintptr_t)d.a_ln_beta % 16) == 0,
+                   "ca_gemm_bf16: a_ln_gamma needs a_ln_beta, K <= 2048 and 16-byte aligned vectors");
+      const int mb = d.M <= 16 ? 1 : 2;
+      const int nch = (d.K + 511) / 512 <= 2 ? 2 : (d.K + 511) / 512;
+      const size_t lds = (size_t)4 * mb * 256 * sizeof(float) + (size_t)16 * mb * (d.K + SKINNY_LN_PAD) * 2;
+#define SKINNY_LN(MBV, NCHV)                                                                                         \
+  do {                                                                                                               \
+    static bool attr_ln = false;                                                                                     \
+    if (!attr_ln) {                                                                                                  \
+      hipFuncSetAttribute((const void*)ca_gemm_skinny_kernel<MBV, NCHV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                          160 * 1024);                                                                               \
+      attr_ln = true;                                                                                                \
+    }                                                                                                                \
+    CA_LAUNCH((ca_gemm_skinny_kernel<MBV, NCHV>), dim3(grid), dim3(256), lds, s, d);                                 \
+  } while (0)
+      if (mb == 1 && nch == 2) SKINNY_LN(1, 2);
+      else if (mb == 1 && nch == 3) SKINNY_LN(1, 3);
+      else if (mb == 1) SKINNY_LN(1, 4);
+      else if (nch == 2) SKINNY_LN(2, 2);
+      else if (nch == 3) SKINNY_LN(2, 3);
+      else SKINNY_LN(2, 4);
+#undef SKINNY_LN
+    } else if (d.M <= 16) {
+      CA_LAUNCH((ca_gemm_skinny_kernel<1, 0>), dim3(grid), dim3(256), 4 * 256 * sizeof(float), s, d);
+    } else {
+      CA_LAUNCH((ca_gemm_skinny_kernel<2, 0>), dim3(grid), dim3(256), 8 * 256 * sizeof(float), s, d);
+    }
     CA_CHECK_LAUNCH("ca_gemm_bf16");
     return CA_OK;
   }
+  CA_CHECK_ARG(!d.a_ln_gamma, "ca_gemm_bf16: a_ln_gamma exists in the skinny form only (M <= 32, K-major operands, un-batched)");
   CA_CHECK_ARG(!d.c_row_index && d.c_split_n == 0,
                "ca_gemm_bf16: c_row_index / c_split_n exist in the skinny form only (M <= 32, K-major operands, un-batched)");
   // Kernel choice: the 256x128 pipelined kernel runs one workgroup per CU, so it needs enough

@@ -65,8 +65,10 @@ def _gemm_desc(A, B, Cout, *, M, N, K, lda, ldb, ldc, a_layout=KMAJOR, b_layout=
          sA=(0, 0), sB=(0, 0), sC=(0, 0), sR=(0, 0), sBias=(0, 0), a_kseg=0, a_kseg_stride=0, b_kseg=0,
          b_kseg_stride=0, dropout_p=0.0, dropout_seed=0, a_colsum=None, a_colsum_off=0,
          a_colsum_ld=0, c_row_index=None, c_row_mul=0, c_split_n=0, C_hi=None, c_hi_off=0, ldc_hi=0,
-         c_sumsq=None, c_sumsq_off=0, stream_out=False, C8=None, c8_scale=None, c8_amax=None):
+         c_sumsq=None, c_sumsq_off=0, stream_out=False, C8=None, c8_scale=None, c8_amax=None, a_ln=None):
     d = CaGemmDesc()
+    if a_ln is not None:  # (gamma, beta, eps): A = LayerNorm(A rows) inside the skinny kernel's prologue
+        d.a_ln_gamma, d.a_ln_beta, d.a_ln_eps = _p(a_ln[0]), _p(a_ln[1]), float(a_ln[2])
     d.c_stream_out = int(stream_out)
     if C8 is not None:  # third output of CA_EPI_GELU: the activation as e4m3 with a delayed per-tensor scale
         d.C8, d.c8_scale, d.c8_amax = _p(C8), _p(c8_scale), _p(c8_amax)

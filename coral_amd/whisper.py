@@ -20,6 +20,7 @@ once per clip (a KV-cached single-token step and the Whisper backward are the ne
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass
 
 import numpy as np
@@ -50,6 +51,10 @@ class WhisperShape:
 
 
 # CoRal model keys -> architectures (R/config/model/whisper-*.yaml:3-5; public config.json values)
+# A decoded token's self-attention and FFN LayerNorms inside the following projection's prologue (CA_DECODE_LN_FUSED=0:
+# their own launches - the A/B switch; the results are bit-identical)
+LN_IN_GEMM = os.environ.get("CA_DECODE_LN_FUSED", "1") != "0"
+
 CORAL_WHISPER_SHAPES = {
     "whisper-xxsmall": dict(d_model=384, encoder_layers=4, decoder_layers=4, encoder_attention_heads=6,
                             decoder_attention_heads=6, encoder_ffn_dim=1536, decoder_ffn_dim=1536),
@@ -224,10 +229,16 @@ class WhisperEngine:
     def _ffn(self, w, h_in, h_out, p, M, d, f):
         st, p32, p16 = self.store, self.store.p32, self.store.p16
         o = st.off
-        ops.layernorm_fwd(h_in, st.view(p + "final_layer_norm.weight"), st.view(p + "final_layer_norm.bias"),
-                          w["x"], None, M, d, self.s.layer_norm_eps)
-        ops.gemm(w["x"], p16, None, C2=w["g"], M=M, N=f, K=d, lda=d, ldb=d, ldc=f, b_off=o(p + "fc1.weight"),
-                 bias=p32, bias_off=o(p + "fc1.bias"), epilogue=EPI_GELU)
+        if M <= 32 and d <= 2048 and LN_IN_GEMM:
+            # a decoded token: the LayerNorm runs in the projection's prologue (CaGemmDesc.a_ln_gamma, bit-identical)
+            ops.gemm(h_in, p16, None, C2=w["g"], M=M, N=f, K=d, lda=d, ldb=d, ldc=f, b_off=o(p + "fc1.weight"),
+                     bias=p32, bias_off=o(p + "fc1.bias"), epilogue=EPI_GELU,
+                     a_ln=(st.view(p + "final_layer_norm.weight"), st.view(p + "final_layer_norm.bias"), self.s.layer_norm_eps))
+        else:
+            ops.layernorm_fwd(h_in, st.view(p + "final_layer_norm.weight"), st.view(p + "final_layer_norm.bias"),
+                              w["x"], None, M, d, self.s.layer_norm_eps)
+            ops.gemm(w["x"], p16, None, C2=w["g"], M=M, N=f, K=d, lda=d, ldb=d, ldc=f, b_off=o(p + "fc1.weight"),
+                     bias=p32, bias_off=o(p + "fc1.bias"), epilogue=EPI_GELU)
         ops.gemm(w["g"], p16, h_out, M=M, N=d, K=f, lda=f, ldb=f, ldc=d, b_off=o(p + "fc2.weight"), bias=p32,
                  bias_off=o(p + "fc2.bias"), epilogue=EPI_RESIDUAL, R=h_in, ldr=d)
 
@@ -528,14 +539,20 @@ class WhisperEngine:
         for l in range(s.decoder_layers):
             p = f"model.decoder.layers.{l}."
             ckv = cache["kv"][l]
-            ops.layernorm_fwd(h0, st.view(p + "self_attn_layer_norm.weight"), st.view(p + "self_attn_layer_norm.bias"),
-                              w["x"], None, B, d, s.layer_norm_eps)
+            ln_in = LN_IN_GEMM and B <= 32 and d <= 2048
+            if not ln_in:
+                ops.layernorm_fwd(h0, st.view(p + "self_attn_layer_norm.weight"), st.view(p + "self_attn_layer_norm.bias"),
+                                  w["x"], None, B, d, s.layer_norm_eps)
             # q and the new K|V rows from one launch over the adjacent q|k|v weights: q to its buffer, K|V straight
             # into the cache at the device-side position (CaGemmDesc.c_split_n / c_row_index: the position is data,
-            # not a launch argument, so the launch sequence can be replayed as a graph)
-            ops.gemm(w["x"], p16, w["q"], M=B, N=3 * d, K=d, lda=d, ldb=d, ldc=d, b_off=o(p + "self_attn.q_proj.weight"),
+            # not a launch argument, so the launch sequence can be replayed as a graph); the LayerNorm in front of it
+            # in the same launch's prologue (CaGemmDesc.a_ln_gamma)
+            ops.gemm(h0 if ln_in else w["x"], p16, w["q"], M=B, N=3 * d, K=d, lda=d, ldb=d, ldc=d,
+                     b_off=o(p + "self_attn.q_proj.weight"),
                      bias=p32, bias_off=o(p + "self_attn.q_proj.bias"), c_split_n=d, C_hi=ckv, ldc_hi=2 * d,
-                     c_row_index=g["pos"], c_row_mul=Lmax)
+                     c_row_index=g["pos"], c_row_mul=Lmax,
+                     a_ln=(st.view(p + "self_attn_layer_norm.weight"), st.view(p + "self_attn_layer_norm.bias"),
+                           s.layer_norm_eps) if ln_in else None)
             ops.attn_fwd(w["q"], ckv, ckv, w["ctx"], self._lse(B * H * 32), B=B, H=H, Tq=1, Tk=Lmax, hd=hd, Tqp=32,
                          scale=hd ** -0.5, ldq=d, ldk=2 * d, ldv=2 * d, ldo=d, sqb=d, skb=Lmax * 2 * d,
                          svb=Lmax * 2 * d, sob=d, k_off=0, v_off=d, klen=g["klen"])

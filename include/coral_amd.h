@@ -140,6 +140,14 @@ typedef struct CaGemmDesc {
   void* C8;
   const float* c8_scale;
   uint32_t* c8_amax;
+  /* Optional, skinny form only (M <= 32, both operands K-major, un-batched; K <= 2048): the A operand is
+   * LayerNorm(A rows) over the K elements of each row with these fp32 [K] vectors, formed in every workgroup's prologue
+   * and rounded to bf16 exactly as ca_layernorm_fwd would have stored it (bit-identical to the two launches): the
+   * LayerNorm in front of the q|k|v and fc1 projections of a decoded token ($TF/models/whisper/modeling_whisper.py:
+   * 459-460,497-498 on the R/src/coral/whisper.py generate path) costs no launch of its own.  NULL = off. */
+  const float* a_ln_gamma;
+  const float* a_ln_beta;
+  float a_ln_eps;
 } CaGemmDesc;
 
 int ca_gemm_bf16(const CaGemmDesc* desc, void* stream);

@@ -845,3 +845,46 @@ def test_side_streams_are_one_per_role_and_process(ops, monkeypatch):
     assert ops.side_stream("cuda:0", "wgrad", -1) is not a
     monkeypatch.setenv("CA_SHARED_STREAMS", "0")
     assert ops.side_stream("cuda:0", "wgrad") is not a
+
+
+@pytest.mark.parametrize("M,N,K", [(8, 3072, 1024), (16, 4096, 1024), (1, 72, 40), (5, 1000, 384), (24, 1280, 1280), (32, 5120, 1280),
+                                   (16, 136, 2048)])
+def test_skinny_gemm_with_layernorm_prologue_is_bit_identical_to_two_launches(ops, M, N, K):
+    """CaGemmDesc.a_ln_gamma: LayerNorm(A rows) inside the weight-streaming kernel's prologue = ca_layernorm_fwd followed by
+    the same GEMM, bit for bit (plain, GELU second output, the q | K|V split with device-side row positions); rows of A
+    may be further apart than K (lda)."""
+    g = torch.Generator().manual_seed(M * 1000 + N + K)
+    lda = K + 16
+    A = (torch.randn(M, lda, generator=g) * 1.5 + 0.3).to(torch.bfloat16).to(DEV)
+    W = (torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16).to(DEV)
+    bias, gamma, beta = torch.randn(N, generator=g).to(DEV), (torch.rand(K, generator=g) + 0.5).to(DEV), torch.randn(K, generator=g).to(DEV)
+    x = torch.zeros(M, K, dtype=torch.bfloat16, device=DEV)
+    Ac = A[:, :K].contiguous()
+    ops.layernorm_fwd(Ac, gamma, beta, x, None, M, K, 1e-5)
+    ref = torch.nn.functional.layer_norm(Ac.float(), (K,), gamma, beta, 1e-5)
+    assert (x.float() - ref).abs().max() <= 2e-2 * max(1.0, float(ref.abs().max()))
+    ln = (gamma, beta, 1e-5)
+    for kw in (dict(), dict(epilogue=ops.EPI_GELU)):
+        outs = []
+        for fused in (False, True):
+            c = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+            dst = dict(Cout=None, C2=c) if kw else dict(Cout=c)
+            ops.gemm(A if fused else x, W, dst.pop("Cout"), M=M, N=N, K=K, lda=lda if fused else K, ldb=K, ldc=N, bias=bias,
+                     a_ln=ln if fused else None, **dst, **kw)
+            outs.append(c)
+        assert torch.equal(outs[0], outs[1]) and float(outs[0].float().abs().max()) > 0
+    if N % 48 == 0:  # q | K|V: columns [N/3, N) go to a cache row picked on the device
+        d3, Lmax = N // 3, 7
+        pos = torch.arange(M, dtype=torch.int32, device=DEV) % Lmax
+        outs = []
+        for fused in (False, True):
+            q = torch.zeros(M, d3, dtype=torch.bfloat16, device=DEV)
+            kv = torch.zeros(M * Lmax, 2 * d3, dtype=torch.bfloat16, device=DEV)
+            ops.gemm(A if fused else x, W, q, M=M, N=N, K=K, lda=lda if fused else K, ldb=K, ldc=d3, bias=bias, c_split_n=d3,
+                     C_hi=kv, ldc_hi=2 * d3, c_row_index=pos, c_row_mul=Lmax, a_ln=ln if fused else None)
+            outs.append((q, kv))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    if M == 16:  # the prologue exists in the skinny form only
+        big = torch.zeros(64, N, dtype=torch.bfloat16, device=DEV)
+        with pytest.raises(Exception, match="skinny form only"):
+            ops.gemm(torch.zeros(64, K, dtype=torch.bfloat16, device=DEV), W, big, M=64, N=N, K=K, lda=K, ldb=K, ldc=N, a_ln=ln)
