@@ -585,18 +585,26 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
     if (p16) p16[i] = f2bf(pi);
   }
 }
-extern "C" int ca_adamw_step(float* p, float* m, float* v, const float* g, void* p16, int64_t n,
-                             float lr, float beta1, float beta2, float eps, float weight_decay,
-                             int32_t step, float grad_scale, float max_norm,
-                             const float* gnorm_sq, void* stream) {
-  CA_CHECK_ARG(p && m && v && g && n > 0 && step >= 1, "ca_adamw_step: bad argument");
+// max_blocks > 0 caps the grid.  With one 256-thread workgroup per CU (max_blocks = the CU count) a wave of the update
+// (60 registers) fits into what the forward GEMMs leave of a SIMD's register file (ca_gemm_kernel_x<0,0>: 2 x 224 of 512,
+// ca_gemm_kernel_l: 2 x 160), so the HBM-bound update runs UNDER the next step's forward instead of alternating with it:
+// a full-occupancy update holds every register of the CUs, the GEMM's workgroups wait for its waves to drain and the next
+// bucket's update for the GEMM's (measured with events on both streams, XLS-R-2B: update 13.0 ms, the forward beside it
+// 31.0 instead of 20.9; capped: update 17.0 ms, forward 28.7, step 72.9 -> 70.7 ms).  What remains is the HBM queue
+// itself: the forward loses ~8.4 ms to the update's 64.8 GB whatever the update's pace (128 threads per CU: update
+// 28 ms, forward 29.5; eight requests in flight per lane instead of four: no better) - tools/dev_opt_timeline.py.
+extern "C" int ca_adamw_step_ex(float* p, float* m, float* v, const float* g, void* p16, int64_t n,
+                                float lr, float beta1, float beta2, float eps, float weight_decay,
+                                int32_t step, float grad_scale, float max_norm,
+                                const float* gnorm_sq, int32_t max_blocks, void* stream) {
+  CA_CHECK_ARG(p && m && v && g && n > 0 && step >= 1 && max_blocks >= 0, "ca_adamw_step: bad argument");
   const float bc1 = 1.f - powf(beta1, (float)step);
   const float bc2 = 1.f - powf(beta2, (float)step);
-  // CA_ADAMW_BLOCKS caps the grid (tuning knob): a smaller grid leaves CU slots and HBM bandwidth to the forward
-  // GEMMs this update overlaps with (trainer.py runs it bucket by bucket on a side stream)
-  static const int cap = [] { const char* e = getenv("CA_ADAMW_BLOCKS"); return e ? atoi(e) : 0; }();
+  // CA_ADAMW_BLOCKS caps the grid of every call (tuning knob)
+  static const int cap_env = [] { const char* e = getenv("CA_ADAMW_BLOCKS"); return e ? atoi(e) : 0; }();
   static const int vec = [] { const char* e = getenv("CA_ADAMW_VEC"); return e ? atoi(e) : 1; }();
   static const int nt = [] { const char* e = getenv("CA_ADAMW_NT"); return e ? atoi(e) : 1; }();
+  const int cap = cap_env > 0 ? cap_env : max_blocks;
   int grid = ew_grid(n, vec ? 4 : 1);
   if (cap > 0 && grid > cap) grid = cap;
   if (nt)
@@ -609,6 +617,13 @@ extern "C" int ca_adamw_step(float* p, float* m, float* v, const float* g, void*
                        max_norm, gnorm_sq, vec);
   CA_CHECK_LAUNCH("ca_adamw_step");
   return CA_OK;
+}
+extern "C" int ca_adamw_step(float* p, float* m, float* v, const float* g, void* p16, int64_t n,
+                             float lr, float beta1, float beta2, float eps, float weight_decay,
+                             int32_t step, float grad_scale, float max_norm,
+                             const float* gnorm_sq, void* stream) {
+  return ca_adamw_step_ex(p, m, v, g, p16, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, max_norm, gnorm_sq, 0,
+                          stream);
 }
 
 // ---- token + position embedding gather ----------------------------------------------------------

@@ -586,9 +586,11 @@ def sum_f32(x, n, out, partial, accumulate=False):
 
 
 def adamw_step(p, m, v, g, p16, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0,
-               max_norm=0.0, gnorm_sq=None):
-    check(lib().ca_adamw_step(_p(p), _p(m), _p(v), _p(g), _p(p16), n, lr, beta1, beta2, eps,
-                              weight_decay, step, grad_scale, max_norm, _p(gnorm_sq), _stream()),
+               max_norm=0.0, gnorm_sq=None, max_blocks=0):
+    """AdamW with the clip coefficient folded in; max_blocks > 0 caps the grid (ca_adamw_step_ex: the CU count makes
+    it a background kernel that runs under the next forward's GEMMs)."""
+    check(lib().ca_adamw_step_ex(_p(p), _p(m), _p(v), _p(g), _p(p16), n, lr, beta1, beta2, eps,
+                                 weight_decay, step, grad_scale, max_norm, _p(gnorm_sq), int(max_blocks), _stream()),
           "ca_adamw_step")
 
 

@@ -390,6 +390,12 @@ class DataParallelTrainer:
             prio = int(os.environ.get("CA_OPT_PRIO", "0"))
             self.opt_stream = ops.side_stream(st.device, "optimizer", prio)
         self.opt_done = None
+        # ... and as a BACKGROUND kernel: one workgroup per CU, whose waves fit beside the forward GEMMs' in the register
+        # file, so the two really run at the same time (ca_adamw_step_ex; CA_OPT_BG_BLOCKS=0: full grid - the A/B switch)
+        self.bg_blocks = 0
+        if self.overlap_optimizer:
+            bg = os.environ.get("CA_OPT_BG_BLOCKS")
+            self.bg_blocks = int(bg) if bg is not None else torch.cuda.get_device_properties(st.device).multi_processor_count
         # per-bucket squared gradient norms, computed on the side stream as the buckets complete
         self.bucket_index = {name: i for i, name in enumerate(st.buckets)}
         self.bucket_sq = torch.zeros(len(st.buckets), dtype=torch.float32, device=st.device)
@@ -561,7 +567,8 @@ class DataParallelTrainer:
             if b > a:
                 ops.adamw_step(st.p32[a:b], self.m[so:so + b - a], self.v[so:so + b - a], st.g32[a:b], st.p16[a:b], b - a,
                                lr, self.betas[0], self.betas[1], self.eps, self.wd, self.opt_step,
-                               grad_scale=1.0 / self.world, max_norm=self.max_grad_norm, gnorm_sq=self.gnorm_sq)
+                               grad_scale=1.0 / self.world, max_norm=self.max_grad_norm, gnorm_sq=self.gnorm_sq,
+                               max_blocks=self.bg_blocks if getattr(self.engine, "background_optimizer", True) else 0)
 
         def update(a, b, name=None):
             if not self.zero:

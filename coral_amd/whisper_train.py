@@ -85,6 +85,9 @@ class WhisperTrainEngine(WhisperEngine):
         bf16 activations, the other data gradients from bf16 weights (straight-through)."""
         import os
 
+        # the fp8 kernels leave no registers for a co-resident optimiser wave (253 of 256 per lane, two waves per SIMD):
+        # the per-bucket AdamW + re-quantisation chain runs at full width there (trainer.py: ca_adamw_step_ex)
+        self.background_optimizer = not on
         if not on:
             self._fp8_train = None
             for sa, ff in self.enc_blocks:

@@ -482,6 +482,14 @@ int ca_adamw_step(float* p, float* m, float* v, const float* g, void* p16, int64
                   float lr, float beta1, float beta2, float eps, float weight_decay,
                   int32_t step, float grad_scale, float max_norm, const float* gnorm_sq,
                   void* stream);
+/* The same update with the grid capped at max_blocks 256-thread workgroups (0 = no cap).  One workgroup per CU lets the
+ * update run UNDER the next step's forward GEMMs (its waves fit into the registers they leave free) instead of
+ * alternating with them - what the trainer passes for the per-bucket updates it overlaps with the forward
+ * (coral_amd/trainer.py; $TF/trainer.py:1796 optimizer.step has no such notion: the result is the same bits). */
+int ca_adamw_step_ex(float* p, float* m, float* v, const float* g, void* p16, int64_t n,
+                     float lr, float beta1, float beta2, float eps, float weight_decay,
+                     int32_t step, float grad_scale, float max_norm, const float* gnorm_sq,
+                     int32_t max_blocks, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Whisper log-mel front end.  $TF/models/whisper/feature_extraction_whisper.py:135-168
