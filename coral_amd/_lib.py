@@ -94,7 +94,8 @@ class CaAttnDesc(C.Structure):
                                              "sqb", "skb", "svb", "sob", "sdob", "sdqb", "sdkb", "sdvb")]
                 + [(n, C.c_int32) for n in ("B", "H", "Tq", "Tk", "hd", "Tqp", "causal")]
                 + [("scale", C.c_float), ("dropout_p", C.c_float), ("dropout_seed", C.c_uint64)]
-                + [("O8", C.c_void_p), ("o8_scale", C.c_void_p), ("o8_amax", C.c_void_p)])
+                + [("O8", C.c_void_p), ("o8_scale", C.c_void_p), ("o8_amax", C.c_void_p),
+                   ("split_ws", C.c_void_p), ("split_ws_bytes", C.c_int64)])
 
 
 KMAJOR, MNMAJOR = 0, 1

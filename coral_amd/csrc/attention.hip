@@ -293,6 +293,11 @@ struct AttnArgs {
   // dropout on the attention probabilities (training): keep decision of (b, h, q, k) from (seed, flat index)
   float drop_p;
   uint64_t drop_seed;
+  // small-query kernel only: the keys of one (clip, head) dealt to nsplit workgroups (CaAttnDesc.split_ws): partial
+  // (max, normaliser, unnormalised output) slabs + one arrival counter per (clip, head); nsplit <= 1 = off
+  int nsplit;
+  float* split_slab;        // [B * H][nsplit][16][SPLIT_ROW]
+  unsigned int* split_cnt;  // [B * H], zero between launches
   // greedy decoding with the query projection inside the kernel (attn_fwd_smallq_kernel<.., true>, ca_decode_attn_qproj):
   // q[b, h, :] = (LayerNorm(x[b]) Wq[h*hd : (h+1)*hd, :]^T + bq) - one query per clip
   const unsigned short* qp_x;   // [B, qp_d] residual-stream rows
@@ -826,6 +831,7 @@ __device__ __forceinline__ void glds16_async(const void* g, char* lds_wave_base)
 // query projection (the arithmetic of ca_gemm_skinny_kernel: the four waves take a quarter of K each, one MFMA chain
 // per 16 columns, partials added as (p0 + p1) + (p2 + p3), + bias, rounded to bf16) - so the LayerNorm launch, the
 // projection launch and the query's trip through HBM disappear from the per-token chain; bit-identical to them.
+#define SPLIT_ROW 66  // floats per query of a partial slab: m, l, 64 output columns
 template <int HDPV, bool QP = false>
 __global__ __launch_bounds__(256) void attn_fwd_smallq_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -836,7 +842,14 @@ __global__ __launch_bounds__(256) void attn_fwd_smallq_kernel(const AttnArgs a) 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, r = lane & 15;
-  const int h = blockIdx.x % a.H, b = blockIdx.x / a.H;
+  // Key split (a.nsplit > 1): nsplit workgroups per (clip, head) - with B x H below the CU count (8 clips x 16 heads on
+  // 256 CUs) half the chip would idle while each workgroup streams its 384 KB of cross-attention K|V at what ONE CU takes
+  // in.  The tiles are dealt to 4 x nsplit "waves"; each workgroup leaves its (m, l, O) partial in a slab and the last
+  // one to arrive (one counter per clip and head; release / acquire at agent scope around it) merges them in slab order.
+  const int ns = a.nsplit > 1 ? a.nsplit : 1;
+  const int bh = blockIdx.x / ns, sp = blockIdx.x - bh * ns;
+  const int h = bh % a.H, b = bh / a.H;
+  const int vw = sp * 4 + wave, nvw = 4 * ns;  // this wave's place among the waves that share the keys
   const int hd = a.hd;
   const unsigned short* Q = QP ? nullptr : a.Q + b * a.sqb + h * hd;
   const unsigned short* K = a.K + b * a.skb + h * hd;
@@ -953,7 +966,7 @@ __global__ __launch_bounds__(256) void attn_fwd_smallq_kernel(const AttnArgs a) 
     for (int ks = 0; ks < NKS; ++ks) qf[ks] = load_rowfrag(Q, a.ldq, qrow, ks, lane, hd);
   }
   const int ntile = (kl + 63) / 64;
-  const int nw = ntile > wave ? (ntile - wave + 3) / 4 : 0;  // this wave's tiles: kt = wave + 4 j
+  const int nw = ntile > vw ? (ntile - vw + nvw - 1) / nvw : 0;  // this wave's tiles: kt = vw + nvw j
   const float c2 = a.scale * LOG2E;
   float m = NEG_BIG, l = 0.f;
   f32x4_t o[NNB];
@@ -964,7 +977,7 @@ __global__ __launch_bounds__(256) void attn_fwd_smallq_kernel(const AttnArgs a) 
   // 8 K-fragment loads + 8 LDS-DMA pieces of V for tile j of this wave, into slot S
   auto issue = [&](auto slot_c, int j) {
     constexpr int S = decltype(slot_c)::value;
-    const int kt = wave + 4 * j;
+    const int kt = vw + nvw * j;
 #pragma unroll
     for (int blk = 0; blk < 4; ++blk) {
       int key = kt * 64 + 32 * (blk >> 1) + rowperm(blk & 1, r);
@@ -991,7 +1004,7 @@ __global__ __launch_bounds__(256) void attn_fwd_smallq_kernel(const AttnArgs a) 
   };
   auto step = [&](auto slot_c, int j) {
     constexpr int S = decltype(slot_c)::value;
-    const int kt = wave + 4 * j;
+    const int kt = vw + nvw * j;
     const int rem = nw - 1 - j;  // younger tiles already issued (at most D - 1)
     if (rem >= 2)
       asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
@@ -1106,6 +1119,77 @@ __global__ __launch_bounds__(256) void attn_fwd_smallq_kernel(const AttnArgs a) 
   __syncthreads();
   if (wave != 0) return;
   unsigned short* O = a.O + b * a.sob + h * hd;
+  if (ns > 1) {
+    // this workgroup's partial: per query (m, l) and the unnormalised output row
+    float* slab = a.split_slab + ((int64_t)bh * ns + sp) * (16 * SPLIT_ROW);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int q = 4 * g + e;
+      float M = cm[q];
+#pragma unroll
+      for (int w = 1; w < 4; ++w) M = fmaxf(M, cm[w * 16 + q]);
+      float L = 0.f, wgt[4];
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        wgt[w] = __builtin_amdgcn_exp2f(cm[w * 16 + q] - M);
+        L = fmaf(cl[w * 16 + q], wgt[w], L);
+      }
+      if (q < a.Tq) {
+        if (r == 0) {
+          slab[q * SPLIT_ROW] = M;
+          slab[q * SPLIT_ROW + 1] = L;
+        }
+#pragma unroll
+        for (int nb = 0; nb < NNB; ++nb) {
+          float v = 0.f;
+#pragma unroll
+          for (int w = 0; w < 4; ++w) v = fmaf(co[(w * 16 + q) * HDPV + 16 * nb + r], wgt[w], v);
+          slab[q * SPLIT_ROW + 2 + 16 * nb + r] = v;
+        }
+      }
+    }
+    // publish (plain stores -> drained -> agent-scope release -> ticket); the workgroup that draws the last ticket
+    // acquires and merges.  Nobody waits for anybody: no residency assumption.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned ticket = 0;
+    if (lane == 0) ticket = __hip_atomic_fetch_add(a.split_cnt + bh, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ticket = __builtin_amdgcn_readfirstlane(ticket);
+    if (ticket != (unsigned)(ns - 1)) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const float* base = a.split_slab + (int64_t)bh * ns * (16 * SPLIT_ROW);
+    // lane = output column; every slab value of a query is asked for before the first is used (one round trip per
+    // query - a decoded token has one query per clip - instead of one per slab and value)
+    for (int q = 0; q < a.Tq; ++q) {
+      float Mt[CA_ATTN_SPLIT_MAX], Lt[CA_ATTN_SPLIT_MAX], ot[CA_ATTN_SPLIT_MAX];
+#pragma unroll
+      for (int t = 0; t < CA_ATTN_SPLIT_MAX; ++t) {
+        const float* row = base + ((t < ns ? t : 0) * 16 + q) * SPLIT_ROW;
+        Mt[t] = row[0];
+        Lt[t] = row[1];
+        ot[t] = row[2 + lane];
+      }
+      float M = NEG_BIG;
+#pragma unroll
+      for (int t = 0; t < CA_ATTN_SPLIT_MAX; ++t) M = fmaxf(M, t < ns ? Mt[t] : NEG_BIG);
+      float L = 0.f, v = 0.f;
+#pragma unroll
+      for (int t = 0; t < CA_ATTN_SPLIT_MAX; ++t) {
+        const float wt = t < ns ? __builtin_amdgcn_exp2f(Mt[t] - M) : 0.f;
+        L = fmaf(Lt[t], wt, L);
+        v = fmaf(ot[t], wt, v);
+      }
+      const float inv = L > 0.f ? 1.0f / L : 0.f;
+      if (lane < hd) O[(int64_t)q * a.ldo + lane] = f2bf(v * inv);
+      if (lane == 0 && a.lse)
+        a.lse[((int64_t)b * a.H + h) * a.Tqp + q] = L > 0.f ? (M + __builtin_amdgcn_logf(L)) * 0.69314718055994530942f
+                                                            : __builtin_inff();
+    }
+    if (lane == 0) __hip_atomic_store(a.split_cnt + bh, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next launch
+    return;
+  }
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int q = 4 * g + e;
@@ -1839,7 +1923,34 @@ static AttnArgs to_args(const CaAttnDesc& d) {
   a.drop_p = d.dropout_p; a.drop_seed = d.dropout_seed;
   a.qp_x = nullptr; a.qp_ldx = 0; a.qp_gamma = a.qp_beta = a.qp_bias = nullptr; a.qp_W = nullptr; a.qp_ldw = 0; a.qp_d = 0;
   a.qp_eps = 0.f;
+  a.nsplit = 1; a.split_slab = nullptr; a.split_cnt = nullptr;
   return a;
+}
+
+// Key split of the small-query kernel: on when the caller lent a workspace, the keys are many and (clips x heads) leaves
+// at least half of the CUs without a workgroup.  Sets a.nsplit / the slab and counter pointers; returns the grid size.
+static int smallq_split(const CaAttnDesc& d, AttnArgs& a, unsigned& grid) {
+  const int bh = d.B * d.H;
+  grid = (unsigned)bh;
+  a.nsplit = 1;
+  if (!d.split_ws || d.Tk < 1024) return CA_OK;
+  static const int ncu = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n > 0 ? n : 256;
+  }();
+  static const int cap = [] { const char* e = getenv("CA_ATTN_SPLIT"); return e ? atoi(e) : CA_ATTN_SPLIT_MAX; }();
+  int ns = ncu / bh;
+  ns = ns > CA_ATTN_SPLIT_MAX ? CA_ATTN_SPLIT_MAX : ns;
+  ns = ns > cap ? cap : ns;
+  if (ns < 2) return CA_OK;
+  CA_CHECK_ARG(d.split_ws_bytes >= CA_ATTN_SPLIT_WS_BYTES(d.B, d.H) && ((uintptr_t)d.split_ws % 16) == 0,
+               "attention: split_ws needs CA_ATTN_SPLIT_WS_BYTES(B, H) bytes, 16-byte aligned");
+  a.nsplit = ns;
+  a.split_cnt = (unsigned int*)d.split_ws;
+  a.split_slab = (float*)((char*)d.split_ws + ((size_t)bh * 4 + 255) / 256 * 256);
+  grid = (unsigned)(bh * ns);
+  return CA_OK;
 }
 
 extern "C" int ca_attn_fwd(const CaAttnDesc* desc, void* stream) {
@@ -1891,7 +2002,10 @@ extern "C" int ca_attn_fwd(const CaAttnDesc* desc, void* stream) {
       hipFuncSetAttribute((const void*)attn_fwd_smallq_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, SMALLQ_LDS);
       attr = true;
     }
-    hipLaunchKernelGGL((attn_fwd_smallq_kernel<64>), dim3((unsigned)(desc->B * desc->H)), block, SMALLQ_LDS, s, a);
+    AttnArgs as = a;
+    unsigned sgrid;
+    if (int rc = smallq_split(*desc, as, sgrid)) return rc;
+    hipLaunchKernelGGL((attn_fwd_smallq_kernel<64>), dim3(sgrid), block, SMALLQ_LDS, s, as);
     CA_CHECK_LAUNCH("ca_attn_fwd");
     return CA_OK;
   }
@@ -1932,7 +2046,9 @@ extern "C" int ca_decode_attn_qproj(const CaAttnDesc* desc, const void* x, int64
     hipFuncSetAttribute((const void*)attn_fwd_smallq_kernel<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr = true;
   }
-  hipLaunchKernelGGL((attn_fwd_smallq_kernel<64, true>), dim3((unsigned)(desc->B * desc->H)), dim3(256), LDS, (hipStream_t)stream, a);
+  unsigned sgrid;
+  if (int rc = smallq_split(*desc, a, sgrid)) return rc;
+  hipLaunchKernelGGL((attn_fwd_smallq_kernel<64, true>), dim3(sgrid), dim3(256), LDS, (hipStream_t)stream, a);
   CA_CHECK_LAUNCH("ca_decode_attn_qproj");
   return CA_OK;
 }

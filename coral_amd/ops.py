@@ -646,8 +646,10 @@ def prof_end():
 
 def _attn_desc(Q, K, V, O, lse, *, B, H, Tq, Tk, hd, Tqp, scale, ldq, ldk, ldv, ldo, sqb, skb, svb, sob,
                q_off=0, k_off=0, v_off=0, o_off=0, klen=None, causal=False, dropout_p=0.0, dropout_seed=0,
-               O8=None, o8_scale=None, o8_amax=None):
+               O8=None, o8_scale=None, o8_amax=None, split_ws=None):
     d = CaAttnDesc()
+    if split_ws is not None:  # key split of the small-query kernel (attn_split_workspace)
+        d.split_ws, d.split_ws_bytes = _p(split_ws), split_ws.numel() * _ELT[split_ws.dtype]
     if O8 is not None:  # the output also as e4m3 (delayed per-tensor scale): the fp8 operand of the out-projection
         d.O8, d.o8_scale, d.o8_amax = _p(O8, o_off), _p(o8_scale), _p(o8_amax)
     d.Q, d.K, d.V, d.O = _p(Q, q_off), _p(K, k_off), _p(V, v_off), _p(O, o_off)
@@ -657,6 +659,16 @@ def _attn_desc(Q, K, V, O, lse, *, B, H, Tq, Tk, hd, Tqp, scale, ldq, ldk, ldv, 
     d.B, d.H, d.Tq, d.Tk, d.hd, d.Tqp, d.causal, d.scale = B, H, Tq, Tk, hd, Tqp, int(causal), scale
     d.dropout_p, d.dropout_seed = float(dropout_p), int(dropout_seed)
     return d
+
+
+ATTN_SPLIT_MAX = 4  # CA_ATTN_SPLIT_MAX
+
+
+def attn_split_workspace(B, H, device):
+    """Zero-filled workspace of CA_ATTN_SPLIT_WS_BYTES(B, H) bytes for `split_ws=` of attn_fwd / decode_attn_qproj (Tq <= 16):
+    the keys of one (clip, head) may then be dealt to several workgroups.  One launch at a time per workspace."""
+    nbytes = (B * H * 4 + 255) // 256 * 256 + B * H * ATTN_SPLIT_MAX * 16 * 66 * 4
+    return torch.zeros(nbytes // 4, dtype=torch.float32, device=device)
 
 
 def attn_fwd(Q, K, V, O, lse, **kw):

@@ -371,6 +371,9 @@ class WhisperEngine:
         z = lambda n, dt=torch.bfloat16: torch.zeros(n, dtype=dt, device=dev)  # noqa: E731
         w = dict(h=[z(B * L * d), z(B * L * d)], x=z(B * L * d), qkv=z(B * L * 3 * d), q=z(B * L * d), ctx=z(B * L * d),
                  g=z(B * L * f), hf=z(B * L * d))
+        # one decoded token per clip: the cross-attention may deal a (clip, head)'s 1500 keys to several workgroups
+        # (CaAttnDesc.split_ws; it decides by B x H against the CU count)
+        w["split"] = ops.attn_split_workspace(B, H, dev) if L == 1 else None
         self._dec_ws[key] = w
         return w
 
@@ -566,7 +569,7 @@ class WhisperEngine:
                                       ldx=d, ldw=d, w_off=o(p + "encoder_attn.q_proj.weight"),
                                       bias_off=o(p + "encoder_attn.q_proj.bias"), B=B, H=H, Tk=Te, hd=hd,
                                       scale=hd ** -0.5, ldk=2 * d, ldv=2 * d, ldo=d, skb=Te * 2 * d, svb=Te * 2 * d,
-                                      sob=d, k_off=0, v_off=d)
+                                      sob=d, k_off=0, v_off=d, split_ws=w["split"])
             else:
                 ops.layernorm_fwd(h1, st.view(p + "encoder_attn_layer_norm.weight"), st.view(p + "encoder_attn_layer_norm.bias"),
                                   w["x"], None, B, d, s.layer_norm_eps)
@@ -574,7 +577,7 @@ class WhisperEngine:
                          bias=p32, bias_off=o(p + "encoder_attn.q_proj.bias"))
                 ops.attn_fwd(w["q"], g["cross"][l], g["cross"][l], w["ctx"], self._lse(B * H * 32), B=B, H=H, Tq=1, Tk=Te,
                              hd=hd, Tqp=32, scale=hd ** -0.5, ldq=d, ldk=2 * d, ldv=2 * d, ldo=d, sqb=d, skb=Te * 2 * d,
-                             svb=Te * 2 * d, sob=d, k_off=0, v_off=d)
+                             svb=Te * 2 * d, sob=d, k_off=0, v_off=d, split_ws=w["split"])
             ops.gemm(w["ctx"], p16, h0, M=B, N=d, K=d, lda=d, ldb=d, ldc=d, b_off=o(p + "encoder_attn.out_proj.weight"),
                      bias=p32, bias_off=o(p + "encoder_attn.out_proj.bias"), epilogue=EPI_RESIDUAL, R=h1, ldr=d)
             self._ffn(w, h0, h1, p, B, d, f)

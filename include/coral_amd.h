@@ -387,7 +387,18 @@ typedef struct CaAttnDesc {
   void* O8;
   const float* o8_scale;
   uint32_t* o8_amax;
+  /* Optional, forward with Tq <= 16 and head_dim <= 64 (greedy decoding, ca_attn_fwd and ca_decode_attn_qproj): a
+   * workspace of CA_ATTN_SPLIT_WS_BYTES(B, H) bytes, zero-filled ONCE by the caller (the kernels leave its counters at
+   * zero), lets the keys of one (clip, head) be dealt to up to CA_ATTN_SPLIT_MAX workgroups when B x H workgroups would
+   * leave half of the CUs idle and Tk >= 1024 (the 1500 cross-attention keys of $TF/models/whisper/modeling_whisper.py:
+   * 312-335 at the evaluation batch sizes of R/config/evaluation.yaml); partial results are merged in a fixed order by
+   * the workgroup that finishes last.  One launch at a time per workspace.  NULL = one workgroup per (clip, head). */
+  void* split_ws;
+  int64_t split_ws_bytes;
 } CaAttnDesc;
+#define CA_ATTN_SPLIT_MAX 4
+#define CA_ATTN_SPLIT_WS_BYTES(B, H) \
+  ((((int64_t)(B) * (H) * 4 + 255) / 256 * 256) + (int64_t)(B) * (H) * CA_ATTN_SPLIT_MAX * 16 * 66 * 4)
 int ca_attn_fwd(const CaAttnDesc* desc, void* stream);
 int ca_attn_bwd(const CaAttnDesc* desc, void* stream);
 /* Greedy decoding, one new token per clip: the pre-attention LayerNorm, the query projection and the single-query

@@ -352,6 +352,62 @@ def test_decode_attention_with_the_query_projection_inside_is_bit_identical(d, H
         assert torch.equal(got, want), (d, H, Tk, float((got.float() - want.float()).abs().max()))
 
 
+@pytest.mark.parametrize("d,H,Tk,B,Tq", [(1024, 16, 1500, 8, 1), (1024, 16, 1500, 2, 1), (1280, 20, 1500, 3, 1), (512, 8, 1100, 5, 7),
+                                         (1024, 16, 1500, 16, 1)])
+def test_decode_attention_with_the_keys_dealt_to_several_workgroups(d, H, Tk, B, Tq):
+    """CaAttnDesc.split_ws: the keys of one (clip, head) dealt to 2-4 workgroups whose partials the last one to finish
+    merges - against fp32 torch and against the one-workgroup launch (same values up to the merge order), the fused
+    q-projection form bit-identical to the unfused one under the same split, the counters back at zero after every
+    launch (the same workspace serves 30 launches in a row), and no split where B x H already fills the chip."""
+    from coral_amd import ops
+
+    hd = d // H
+    g = torch.Generator(device=DEV).manual_seed(d + Tk + B)
+    x = torch.randn(B, d, device=DEV, generator=g).to(torch.bfloat16)
+    gamma, beta = 1.0 + 0.1 * torch.randn(d, device=DEV, generator=g), 0.1 * torch.randn(d, device=DEV, generator=g)
+    W = (0.05 * torch.randn(d, d, device=DEV, generator=g)).to(torch.bfloat16)
+    bias = 0.1 * torch.randn(d, device=DEV, generator=g)
+    kv = torch.randn(B, Tk, 2 * d, device=DEV, generator=g).to(torch.bfloat16)
+    q = torch.randn(B, Tq, d, device=DEV, generator=g).to(torch.bfloat16)
+    klen = torch.tensor([Tk, max(1, Tk - 37), 1, Tk // 2, Tk, 64, 65, Tk] * 2, dtype=torch.int32, device=DEV)[:B]
+    ws = ops.attn_split_workspace(B, H, DEV)
+    akw = dict(B=B, H=H, Tk=Tk, hd=hd, scale=hd ** -0.5, ldk=2 * d, ldv=2 * d, ldo=d, skb=Tk * 2 * d, svb=Tk * 2 * d, k_off=0, v_off=d)
+    nb = (B * H * 4 + 255) // 256 * 256 // 4  # the counters' words
+    for kl in (None, klen):
+        one, many = (torch.zeros(B, Tq, d, dtype=torch.bfloat16, device=DEV) for _ in range(2))
+        lse1, lse2 = torch.zeros(B * H * 32, device=DEV), torch.zeros(B * H * 32, device=DEV)
+        common = dict(Tq=Tq, Tqp=32, ldq=d, sqb=Tq * d, sob=Tq * d, klen=kl, **akw)
+        ops.attn_fwd(q, kv, kv, one, lse1, **common)
+        for _ in range(30):
+            ops.attn_fwd(q, kv, kv, many, lse2, split_ws=ws, **common)
+        torch.cuda.synchronize()
+        assert int(ws[:nb].view(torch.int32).abs().sum()) == 0
+        K, V = kv[..., :d].float().view(B, Tk, H, hd).transpose(1, 2), kv[..., d:].float().view(B, Tk, H, hd).transpose(1, 2)
+        sc = (q.float().view(B, Tq, H, hd).transpose(1, 2) @ K.transpose(-1, -2)) * hd ** -0.5
+        if kl is not None:
+            sc = sc.masked_fill(torch.arange(Tk, device=DEV)[None, None, None, :] >= kl[:, None, None, None], float("-inf"))
+        ref = (torch.softmax(sc, -1) @ V).transpose(1, 2).reshape(B, Tq, d)
+        assert (many.float() - ref).abs().max() < 2e-2
+        assert (many.float() - one.float()).abs().max() <= 4e-3  # (bf16 outputs of the same fp32 sums in another order)
+        assert (lse2 - lse1).abs().max() < 1e-4
+        if B * H * 2 > 256:  # nothing to deal: the very same launch
+            assert torch.equal(many, one)
+        if Tq == 1:
+            xn, qp = torch.empty_like(x), torch.empty_like(x)
+            want, got = torch.zeros(B, d, dtype=torch.bfloat16, device=DEV), torch.ones(B, d, dtype=torch.bfloat16, device=DEV)
+            ops.layernorm_fwd(x, gamma, beta, xn, None, B, d, 1e-5)
+            ops.gemm(xn, W, qp, M=B, N=d, K=d, lda=d, ldb=d, ldc=d, bias=bias)
+            ops.attn_fwd(qp, kv, kv, want, lse1, Tq=1, Tqp=32, ldq=d, sqb=d, sob=d, klen=kl, split_ws=ws, **akw)
+            ops.decode_attn_qproj(x, gamma, beta, W, bias, kv, kv, got, d_model=d, eps=1e-5, ldx=d, ldw=d, sob=d, klen=kl,
+                                  split_ws=ws, **akw)
+            torch.cuda.synchronize()
+            assert torch.equal(got, want)
+            assert int(ws[:nb].view(torch.int32).abs().sum()) == 0
+    if B * H * 2 <= 256:
+        with pytest.raises(Exception, match="split_ws"):
+            ops.attn_fwd(q, kv, kv, many, lse2, split_ws=ws[:64], **common)
+
+
 def test_whisper_generate_is_the_same_with_and_without_the_fused_decode_launches(monkeypatch):
     """The graph-replayed token step with ca_decode_attn_qproj (default) and with the three launches it replaces
     (CA_DECODE_FUSED=0): the same ids, token for token."""
