@@ -464,6 +464,7 @@ def run_w2v2(model_key, args, world, rank, device, roofline: bool):
                           f"{r['flops'] / (r['ms'] * 1e-3) / 1e12:7.1f} TFLOP/s", file=sys.stderr)
     trainer.finish()
     torch.cuda.synchronize()
+    res["bg_blocks"] = int(getattr(trainer, "bg_blocks", 0) or 0)
     if world == 1:
         res["trainer"] = None  # (N = 1: nothing to check afterwards; the moments' memory goes back before the next workload)
     return res
@@ -582,6 +583,10 @@ def main():
                                    + (f", sharded optimiser (zero_stage {args.zero_stage}): gradient reduce-scatter ({args.backend}) on {wire} per layer bucket overlapped with backward, AdamW on 1/{world}, bf16 all-gather under the next forward" if world > 1 and args.zero_stage else "")
                                    + (f" [DIAGNOSTIC: N>1 exchange path forced over an RCCL group of one rank, {args.grad_wire} wire]" if args.one_rank_exchange and world == 1 else ""),
                        "global_batch": world * B, "frames_per_utt": T, "parallelism": f"dp{world}",
+                       # what the runtime was told: kernel arguments in device memory; AdamW's grid cap
+                       # under the next forward (workgroups; 0 = full grid)
+                       "runtime": {"HIP_FORCE_DEV_KERNARG": os.environ.get("HIP_FORCE_DEV_KERNARG"),
+                                   "optimizer_background_blocks": res.get("bg_blocks")},
                        "loss": round(loss_val, 3),
                        **({"fwd_bwd": dict(res["fwd_bwd"], frac_of_peak=round(
                            res["step_tflop"] / (res["fwd_bwd"]["ms_per_step"] * 1e-3) / MFMA_BF16_DENSE_PEAK_TFLOPS, 4))}
