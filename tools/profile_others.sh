@@ -4,6 +4,8 @@
 TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 export CA_WGRAD_STREAM=0 CA_OPT_OVERLAP=0
+# (bench.py sets this itself, but a profiler that initialises the runtime first would read the environment before it does)
+export HIP_FORCE_DEV_KERNARG=1
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${TAG}small_stats -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-also --no-fwd-bwd --model wav2vec2-small > gpurun_out/prof_${TAG}small_bench.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${TAG}whisper_stats -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-also --no-fwd-bwd --model whisper-medium > gpurun_out/prof_${TAG}whisper_bench.log 2>&1
 find gpurun_out -name "*kernel_trace.csv" -delete

@@ -10,6 +10,8 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 # per-kernel durations and counters need serialised kernels: weight gradients and the optimiser back on the main stream
 # (see bench.py)
 export CA_WGRAD_STREAM=0 CA_OPT_OVERLAP=0
+# (bench.py sets this itself, but a profiler that initialises the runtime first would read the environment before it does)
+export HIP_FORCE_DEV_KERNARG=1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/prof_${TAG}_sq -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-also --no-fwd-bwd > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${TAG}_decode_stats -- python bench.py --model whisper-medium --decode --steps 4 --warmup 2 > gpurun_out/prof_${TAG}_decode.log 2>&1
 tail -1 gpurun_out/prof_${TAG}_decode.log | cut -c1-300
