@@ -215,3 +215,23 @@ def test_weight_gradient_launch_plans_of_the_model_shapes():
     assert plan(enc(768, 3072, 1000)) == (0, [], 4)         # nothing fills the chip: the general path
     assert plan([(1024, 1024, 200)] * 3) == (0, [], 3)      # short contraction: never grouped
     assert ops.GROUP_MAX == 8
+
+
+def test_import_asks_for_kernel_arguments_in_device_memory():
+    """`import coral_amd` sets HIP_FORCE_DEV_KERNARG=1 unless the environment already says otherwise (the HIP runtime
+    reads it when it initialises: INTEGRATION.md), in a fresh interpreter."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = str(Path(__file__).resolve().parents[1])
+    code = "import os, coral_amd; print(os.environ.get('HIP_FORCE_DEV_KERNARG'))"
+    for preset, want in ((None, "1"), ("0", "0")):
+        env = {k: v for k, v in os.environ.items() if k != "HIP_FORCE_DEV_KERNARG"}
+        if preset is not None:
+            env["HIP_FORCE_DEV_KERNARG"] = preset
+        env["PYTHONPATH"] = root
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stderr[-400:]
+        assert out.stdout.strip().splitlines()[-1] == want

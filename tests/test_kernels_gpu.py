@@ -426,6 +426,15 @@ def test_optimizer_kernels(ops):
         ops.adamw_step(pd, m, v, gd, p16, pad, 1e-3, 0.9, 0.98, 1e-8, 0.01, step, 1.0, 1.0, nsq)
     assert (pd[:n].cpu() - pr.detach()).abs().max() < 2e-6
     assert (p16[:n].float().cpu() - pr.detach()).abs().max() < 2e-2
+    # the grid cap of ca_adamw_step_ex (the background form the trainer runs under the next forward): the same bits
+    outs = []
+    for blocks in (0, 1, 37, 256):
+        q, qm, qv, q16 = pd.clone(), m.clone(), v.clone(), p16.clone()
+        ops.adamw_step(q, qm, qv, gd, q16, pad, 1e-3, 0.9, 0.98, 1e-8, 0.01, 4, 1.0, 1.0, nsq, max_blocks=blocks)
+        outs.append((q, qm, qv, q16))
+    for o in outs[1:]:
+        assert all(torch.equal(a, b) for a, b in zip(o, outs[0]))
+    assert not torch.equal(outs[0][0], pd)
 
 
 def test_misc_reorders(ops):
