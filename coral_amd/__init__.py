@@ -7,7 +7,7 @@ this package is the Python host side mirroring the reference's ModelSetup bounda
 import os as _os
 
 # Kernel arguments in device memory instead of host memory: the first instruction of every kernel is a scalar load of its
-# argument block, and a training step is ~1 800 dependent launches - with the block in host memory each of them starts
+# argument block, and a training step is ~1 000 dependent launches - with the block in host memory each of them starts
 # with a PCIe round trip.  Measured on the XLS-R-2B step (same box, interleaved): 77.4 / 78.8 -> 75.3 / 75.7 ms.  The HIP
 # runtime reads the variable when it initialises (the first HIP call of the process), so this has to run before any
 # torch.cuda use: import coral_amd first, or export it in the job's environment.  An explicit

@@ -50,11 +50,11 @@ class WhisperShape:
     layer_norm_eps: float = 1e-5
 
 
-# CoRal model keys -> architectures (R/config/model/whisper-*.yaml:3-5; public config.json values)
 # A decoded token's self-attention and FFN LayerNorms inside the following projection's prologue (CA_DECODE_LN_FUSED=0:
 # their own launches - the A/B switch; the results are bit-identical)
 LN_IN_GEMM = os.environ.get("CA_DECODE_LN_FUSED", "1") != "0"
 
+# CoRal model keys -> architectures (R/config/model/whisper-*.yaml:3-5; public config.json values)
 CORAL_WHISPER_SHAPES = {
     "whisper-xxsmall": dict(d_model=384, encoder_layers=4, decoder_layers=4, encoder_attention_heads=6,
                             decoder_attention_heads=6, encoder_ffn_dim=1536, decoder_ffn_dim=1536),
