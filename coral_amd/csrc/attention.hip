@@ -30,6 +30,30 @@ __device__ __forceinline__ void glds16a(const void* g, char* lds_wave_base) {
 // ---- LDS images -----------------------------------------------------------------------------------
 // K-major image: [HDPV/64 chunks][ROWS][64 dims], 128-B rows, 16-B chunk index XOR ((row>>1)&7).
 // NW = number of waves that share the load (4 = the whole workgroup, 1 = a wave-private image)
+// Chunk swizzle of the K-major images: the 16-byte chunk c of row r sits at position c ^ kswz(r) of its 128-byte row.
+// Row bits 1, 3 and 4 are the ones that vary among the lanes of one LDS pass of the two read patterns: the operand-row
+// reads (ds_read_b128, rows 8 (r >> 2) + 4 bb + (r & 3) of a 32-row block: 16 lanes = 8 even + 8 odd rows) need three
+// distinct bits over the even rows, the transposed reads (ds_read_b64_tr_b16, rows 8 g + q of a lane group: 32 lanes =
+// 4 even rows, each lane pair reading a chunk PAIR) need distinct bits 1-2 over row bits (1, 3).  The round-1 swizzle
+// (r >> 1) & 7 used row bits 1-3 and left both patterns with two-way bank conflicts (SQ_LDS_BANK_CONFLICT = 49 % of
+// SQ_LDS_IDX_ACTIVE in the dQ and dK|dV kernels, tools/exp_attn_pmc.sh); LDS-DMA writes are linear and do not care.
+// MN-major images ([rows][HDPV dims], read only transposed): XOR value of the chunk index of row kr.  A 32-lane pass of
+// ds_read_b64_tr_b16 covers rows 8 g + q (q = 0..3, g in {0, 1}) of a 32-row block, each lane pair a chunk PAIR: the
+// four even rows need four distinct values of bits 1-2 (and bit 3 where a row has 16 chunks).  With 8 chunks per row
+// (head_dim <= 64) the round-1 form (2 q | 8 (g & 1)) & 7 lost the g bit: two-way conflicts on every value-fragment read
+// of the forward kernels (SQ_LDS_BANK_CONFLICT 37 % of SQ_LDS_IDX_ACTIVE).
+template <int PC>
+__device__ __forceinline__ int mnswz(int kr) {
+#ifndef CA_KSWZ_OLD
+  if (PC == 8) return (((kr >> 1) & 1) << 1) | (((kr >> 3) & 1) << 2);
+#endif
+  return ((((kr & 3) | (((kr >> 3) & 1) << 2))) << 1) & (PC - 1);
+}
+#ifndef CA_KSWZ_OLD
+__device__ __forceinline__ int kswz(int r) { return ((r >> 4) & 1) | (((r >> 1) & 1) << 1) | (((r >> 3) & 1) << 2); }
+#else
+__device__ __forceinline__ int kswz(int r) { return (r >> 1) & 7; }
+#endif
 template <int ROWS, int HDPV, int NW = 4>
 __device__ __forceinline__ void load_kmajor_image(char* lds, const unsigned short* base, int64_t ld,
                                                   int row0, int nrows, int hd, int wave, int lane) {
@@ -41,7 +65,7 @@ __device__ __forceinline__ void load_kmajor_image(char* lds, const unsigned shor
     for (int i = 0; i < IPW; ++i) {
       const int inst = wave * IPW + i;
       const int r = inst * 8 + (lane >> 3);
-      const int cc = (lane & 7) ^ ((r >> 1) & 7);
+      const int cc = (lane & 7) ^ kswz(r);
       const int dim = c * 64 + cc * 8;
       int row = row0 + r;
       row = row < nrows ? row : nrows - 1;
@@ -60,8 +84,7 @@ __device__ __forceinline__ void load_mnmajor_image(char* lds, const unsigned sho
   for (int i = 0; i < IPW; ++i) {
     const int inst = wave * IPW + i;
     const int kr = inst * RPI + lane / PC;
-    const int swz = (kr & 3) | (((kr >> 3) & 1) << 2);
-    const int c = (lane % PC) ^ ((swz << 1) & (PC - 1));
+    const int c = (lane % PC) ^ mnswz<PC>(kr);
     const int dim = c * 8;
     const int row = row0 + kr;
     const void* src = (row < nrows && dim < hd) ? (const void*)(base + (int64_t)row * ld + dim)
@@ -71,7 +94,7 @@ __device__ __forceinline__ void load_mnmajor_image(char* lds, const unsigned sho
 }
 template <int ROWS>
 __device__ __forceinline__ bf16x8_t kimg_frag(const char* img, int row, int ks, int lane) {
-  const int cc = (4 * (ks & 1) + (lane >> 4)) ^ ((row >> 1) & 7);
+  const int cc = (4 * (ks & 1) + (lane >> 4)) ^ kswz(row);
   return *(const bf16x8_t*)(img + (ks >> 1) * ROWS * 128 + row * 128 + cc * 16);
 }
 // rows 32*s + 8g + {0..7} of the image x 16 columns starting at 16*nb, transposed into a B operand
@@ -81,8 +104,7 @@ __device__ __forceinline__ bf16x8_t timg_frag(const char* img, int s, int nb, in
   constexpr int PITCH = HDPV * 2;
   const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
   const int kr = 32 * s + 8 * g + q;
-  const int swz = q | ((g & 1) << 2);
-  const int c = ((2 * nb) + (p >> 1)) ^ ((swz << 1) & (PC - 1));
+  const int c = ((2 * nb) + (p >> 1)) ^ mnswz<PC>(kr);
   const char* a0 = img + kr * PITCH + c * 16 + (p & 1) * 8;
   s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(lptr_t)a0);
   s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
@@ -100,8 +122,8 @@ __device__ __forceinline__ bf16x8_t timg_frag_k(const char* img, int s, int nb, 
   const int r0 = 32 * s + 8 * g + q, r1 = r0 + 4;
   const int c = 2 * (nb & 3) + (p >> 1);
   const char* base = img + (nb >> 2) * ROWS * 128 + (p & 1) * 8;
-  const char* a0 = base + r0 * 128 + ((c ^ ((r0 >> 1) & 7)) * 16);
-  const char* a1 = base + r1 * 128 + ((c ^ ((r1 >> 1) & 7)) * 16);
+  const char* a0 = base + r0 * 128 + ((c ^ kswz(r0)) * 16);
+  const char* a1 = base + r1 * 128 + ((c ^ kswz(r1)) * 16);
   s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(lptr_t)a0);
   s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(lptr_t)a1);
   s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -123,7 +145,7 @@ __device__ __forceinline__ bf16x8_t timg_frag_k_async(const char* img, int s, in
   const int r0 = 32 * s + 8 * g + q, r1 = r0 + 4;
   const int c = 2 * (nb & 3) + (p >> 1);
   const char* base = img + (nb >> 2) * ROWS * 128 + (p & 1) * 8;
-  return tr_pair_async(base + r0 * 128 + ((c ^ ((r0 >> 1) & 7)) * 16), base + r1 * 128 + ((c ^ ((r1 >> 1) & 7)) * 16));
+  return tr_pair_async(base + r0 * 128 + ((c ^ kswz(r0)) * 16), base + r1 * 128 + ((c ^ kswz(r1)) * 16));
 }
 template <int HDPV>
 __device__ __forceinline__ bf16x8_t timg_frag_async(const char* img, int s, int nb, int lane) {
@@ -131,8 +153,7 @@ __device__ __forceinline__ bf16x8_t timg_frag_async(const char* img, int s, int 
   constexpr int PITCH = HDPV * 2;
   const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
   const int kr = 32 * s + 8 * g + q;
-  const int swz = q | ((g & 1) << 2);
-  const int c = ((2 * nb) + (p >> 1)) ^ ((swz << 1) & (PC - 1));
+  const int c = ((2 * nb) + (p >> 1)) ^ mnswz<PC>(kr);
   const char* a0 = img + kr * PITCH + c * 16 + (p & 1) * 8;
   return tr_pair_async(a0, a0 + 4 * PITCH);
 }
@@ -170,7 +191,7 @@ struct KImgFast {
 #pragma unroll
       for (int i = 0; i < IPW; ++i) {
         const int r = (wave * IPW + i) * 8 + (lane >> 3);
-        const int cc = (lane & 7) ^ ((r >> 1) & 7);
+        const int cc = (lane & 7) ^ kswz(r);
         off[c * IPW + i] = (uint32_t)((r * ld + c * 64 + cc * 8) * 2);
       }
   }
@@ -192,8 +213,7 @@ struct MnImgFast {
 #pragma unroll
     for (int i = 0; i < IPW; ++i) {
       const int kr = (wave * IPW + i) * RPI + lane / PC;
-      const int swz = (kr & 3) | (((kr >> 3) & 1) << 2);
-      const int c = (lane % PC) ^ ((swz << 1) & (PC - 1));
+      const int c = (lane % PC) ^ mnswz<PC>(kr);
       off[i] = (uint32_t)((kr * ld + c * 8) * 2);
     }
   }
@@ -581,10 +601,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
   {
     constexpr int PC = HDPV / 8;
     const int q4 = (lane & 15) >> 2, p4 = lane & 3;
-    const int swz = q4 | ((g & 1) << 2);
 #pragma unroll
     for (int nb = 0; nb < NNB; ++nb) {
-      const int c = ((2 * nb) + (p4 >> 1)) ^ ((swz << 1) & (PC - 1));
+      const int c = ((2 * nb) + (p4 >> 1)) ^ mnswz<PC>(8 * g + q4);
       voff[nb] = (uint32_t)(uintptr_t)(lptr_t)smem + IMG + (8 * g + q4) * (HDPV * 2) + c * 16 + (p4 & 1) * 8;
     }
   }
@@ -993,8 +1012,7 @@ __global__ __launch_bounds__(256) void attn_fwd_smallq_kernel(const AttnArgs a) 
 #pragma unroll
     for (int i = 0; i < 64 * HDPV * 2 / 1024; ++i) {
       const int kr = i * RPI + lane / PC;
-      const int swz = (kr & 3) | (((kr >> 3) & 1) << 2);
-      const int c = (lane % PC) ^ ((swz << 1) & (PC - 1));
+      const int c = (lane % PC) ^ mnswz<PC>(kr);
       const int dim = c * 8;
       const int row = kt * 64 + kr;
       const void* src = (row < a.Tk && dim < hd) ? (const void*)(V + (int64_t)row * a.ldv + dim)
