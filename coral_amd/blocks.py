@@ -204,10 +204,12 @@ class CrossAttnBlock:
                  dropout_p=hdrop[0], dropout_seed=hdrop[1])
         sv["hin"], sv["hdrop"] = hin, hdrop
 
-    def backward(self, dh, dhin, sv, sc: Scratch, denc32, B, L, Te, defer=None, cs=(0, 0), ln_part=None, pending=None):
+    def backward(self, dh, dhin, sv, sc: Scratch, denc32, B, L, Te, defer=None, cs=(0, 0), ln_part=None, pending=None,
+                 acc=True):
         """denc32: fp32 [B*Te, d] accumulator of the gradient wrt the encoder states (+=).  defer: list collecting
         the two token-side weight-gradient problems (out_proj, q_proj; bias gradients fused at cs = (cs_q, cs_o) of the
-        layer's bias vector) for the layer's grouped launch; the k|v projection's (K = B*Te rows) goes out at once."""
+        layer's bias vector) for the layer's grouped launch; the k|v projection's (K = B*Te rows) goes out at once.
+        acc=False: the three weight gradients overwrite their (uncleared) slots instead of adding to them."""
         st, d = self.st, self.d
         M, Mk = B * L, B * Te
         o, g32, p16 = st.off, st.g32, st.p16
@@ -215,10 +217,10 @@ class CrossAttnBlock:
         if defer is None:
             ops.colsum(dy, d, M, d, g32, sc.part, out_off=o(self.attn + "out_proj.bias"))
             ops.wgrad_gemm(dy, sv["ctx"], g32, M=d, N=d, K=M, lda=d, ldb=d,
-                           c_off=o(self.attn + "out_proj.weight"), accumulate=True)
+                           c_off=o(self.attn + "out_proj.weight"), accumulate=acc)
         else:
             defer.append(dict(dY=dy, X=sv["ctx"], M=d, N=d, K=M, lda=d, ldb=d, c_off=o(self.attn + "out_proj.weight"),
-                              accumulate=True, bias_off=o(self.attn + "out_proj.bias"), part=sc.part, cs_off=cs[1]))
+                              accumulate=acc, bias_off=o(self.attn + "out_proj.bias"), part=sc.part, cs_off=cs[1]))
         ops.gemm(dy, p16, sc.dctx, M=M, N=d, K=d, lda=d, b_layout=MNMAJOR, ldb=d, ldc=d, b_off=o(self.attn + "out_proj.weight"))
         dq, dkv = (sc.dx if defer is None else sc.dq), sc.dkv
         ops.attn_bwd(sv["q"], sv["kv"], sv["kv"], sv["ctx"], sv["lse"], sc.dctx, sv["Dq"], dq, dkv, dkv, lddo=d, sdob=L * d,
@@ -228,16 +230,16 @@ class CrossAttnBlock:
         if defer is None:
             ops.colsum(dq, d, M, d, g32, sc.part, out_off=o(self.attn + "q_proj.bias"))
             ops.wgrad_gemm(dq, sv["x"], g32, M=d, N=d, K=M, lda=d, ldb=d,
-                           c_off=o(self.attn + "q_proj.weight"), accumulate=True)
+                           c_off=o(self.attn + "q_proj.weight"), accumulate=acc)
         else:
             defer.append(dict(dY=dq, X=sv["x"], M=d, N=d, K=M, lda=d, ldb=d, c_off=o(self.attn + "q_proj.weight"),
-                              accumulate=True, bias_off=o(self.attn + "q_proj.bias"), part=sc.part, cs_off=cs[0]))
+                              accumulate=acc, bias_off=o(self.attn + "q_proj.bias"), part=sc.part, cs_off=cs[0]))
         ops.gemm(dq, p16, sc.dctx, M=M, N=d, K=d, lda=d, b_layout=MNMAJOR, ldb=d, ldc=d, b_off=o(self.attn + "q_proj.weight"))
         _ln_bwd(st, self.ln, sc.dctx, sv, dh, dhin, sc, M, d, ln_part, pending)
         # k|v projection of the encoder states
         ops.colsum(dkv, 2 * d, Mk, 2 * d, g32, sc.part, out_off=o(self.attn + "k_proj.bias__zero"))
         ops.wgrad_gemm(dkv, sv["enc"], g32, M=2 * d, N=d, K=Mk, lda=2 * d, ldb=d,
-                       c_off=o(self.attn + "k_proj.weight"), accumulate=True)
+                       c_off=o(self.attn + "k_proj.weight"), accumulate=acc)
         ops.gemm(dkv, p16, denc32, M=Mk, N=d, K=2 * d, lda=2 * d, b_layout=MNMAJOR, ldb=d, ldc=d,
                  b_off=o(self.attn + "k_proj.weight"), out_f32=True, accumulate=True)
 

@@ -548,8 +548,9 @@ _CLEAR_TABLES: dict = {}
 
 
 def clear_ranges(x, ranges):
-    """Zero the listed (offset, length) ELEMENT ranges of the flat buffer `x` in ONE launch (ca_clear_ranges).  The
-    byte-range table lives on the device, cached per (buffer, ranges): build the list once and pass the same tuple."""
+    """Zero the listed (offset, length) ELEMENT ranges of the flat buffer `x` in one ca_clear_ranges launch (two when
+    ranges of at least and under 1 MB are mixed).  The byte-range tables live on the device, cached per (buffer, ranges):
+    build the list once and pass the same tuple."""
     elt = _ELT[x.dtype]
     key = (x.data_ptr(), elt, tuple(ranges))
     ent = _CLEAR_TABLES.get(key)
@@ -563,11 +564,16 @@ def clear_ranges(x, ranges):
         rows = [[int(a) * elt, int(n) * elt] for a, n in ranges if n > 0]
         if any(a % 4 or n % 4 for a, n in rows):
             raise CoralAmdError("clear_ranges: ranges must be multiples of 4 bytes")
-        ent = (torch.tensor(rows, dtype=torch.int64, device=x.device), len(rows), max(n for _, n in rows)) if rows else None
+        # The launch is a (blocks per range) x (ranges) grid sized by the LONGEST range: one 200-MB embedding gradient
+        # among 600 bias-sized ranges made it 600 K workgroups, nearly all of them idle (194 us for what HBM does in
+        # 45).  Long and short ranges therefore go out as two launches.
+        big = [r for r in rows if r[1] >= (1 << 20)]
+        small = [r for r in rows if r[1] < (1 << 20)]
+        ent = tuple((torch.tensor(part, dtype=torch.int64, device=x.device), len(part), max(n for _, n in part))
+                    for part in (big, small) if part)
         _CLEAR_TABLES[key] = ent
-    if ent is None:
-        return
-    check(lib().ca_clear_ranges(_p(x), _p(ent[0]), ent[1], ent[2], _stream()), "ca_clear_ranges")
+    for table, count, longest in ent:
+        check(lib().ca_clear_ranges(_p(x), _p(table), count, longest, _stream()), "ca_clear_ranges")
 
 
 def sumsq(g, n, out, partial, accumulate=False):

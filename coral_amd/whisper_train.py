@@ -183,6 +183,11 @@ class WhisperTrainEngine(WhisperEngine):
         hi = st.off(p + "fc2.weight") + self.s.d_model * self.s.encoder_ffn_dim
         return lo, hi
 
+    # ... and so are the ten of a decoder layer (self q|k|v|out, cross q|k|v|out, fc1, fc2), at the end of its bucket
+    def _dec_matrix_range(self, l: int):
+        st = self.store
+        return st.off(f"model.decoder.layers.{l}.self_attn.q_proj.weight"), st.buckets[f"dec{l}"][1]
+
     def shard_ranges(self) -> dict:
         """{layer bucket: (first element of its weight matrices, bucket end)}: what a sharded optimiser (trainer.py,
         zero_stage) may split over the ranks - every encoder and decoder layer's matrices (92 % of whisper-large-turbo's
@@ -209,11 +214,13 @@ class WhisperTrainEngine(WhisperEngine):
         if matrices or self.freeze_base or Le == 0:
             st.g32.zero_()
         else:
-            # everything except the encoder layers' weight matrices, as ONE launch over a cached range table
+            # everything except the encoder AND decoder layers' weight matrices (each gets exactly one weight gradient per
+            # backward, which overwrites in the step's first micro-batch: at whisper-medium the decoder's 1.6 GB were
+            # cleared here and then read back by the accumulating epilogues), over a cached range table
             if getattr(self, "_small_ranges", None) is None:
                 rs, pos = [], 0
-                for l in range(Le):
-                    lo, hi = self._enc_matrix_range(l)
+                spans = [self._enc_matrix_range(l) for l in range(Le)] + [self._dec_matrix_range(l) for l in range(self.s.decoder_layers)]
+                for lo, hi in sorted(spans):
                     rs.append((pos, lo - pos))
                     pos = hi
                 rs.append((pos, st.numel - pos))
@@ -483,8 +490,12 @@ class WhisperTrainEngine(WhisperEngine):
         # the layer therefore stays alive until then: a ring of four residual-gradient buffers, the blocks' own scratch.
         ringd, r = w["g_d"], 1  # ringd[1] = gb holds the gradient wrt the last layer's output
         nbd = 9 * d + s.decoder_ffn_dim
+        dacc = not overwrite_matrices  # decoder weight matrices: accumulate, or overwrite in a step's first micro-batch
         for l in reversed(range(s.decoder_layers)):
             if not sv["dk"][l]:
+                if overwrite_matrices:  # dropped layer: its (uncleared) matrices get no gradient this step
+                    lo, hi = self._dec_matrix_range(l)
+                    g32[lo:hi].zero_()
                 done(f"dec{l}")
                 continue
             sa, ca, ff = self.dec_blocks[l]
@@ -492,9 +503,9 @@ class WhisperTrainEngine(WhisperEngine):
             g0, g1, g2, g3 = (ringd[(r + i) % 4] for i in range(4))
             wg, second = [], []
             lpd = w["ln_part_d"]
-            ff.backward(g0, g1, sv_f, sc_d, Md, defer=wg, ln_part=lpd[0], pending=second)
-            ca.backward(g1, g2, sv_c, sc_d, w["denc32"], B, L, T, defer=wg, cs=ca.cs, ln_part=lpd[1], pending=second)
-            sa.backward(g2, g3, sv_a, sc_d, B, L, defer=wg, ln_part=lpd[2], pending=second)
+            ff.backward(g0, g1, sv_f, sc_d, Md, defer=wg, acc=dacc, ln_part=lpd[0], pending=second)
+            ca.backward(g1, g2, sv_c, sc_d, w["denc32"], B, L, T, defer=wg, cs=ca.cs, ln_part=lpd[1], pending=second, acc=dacc)
+            sa.backward(g2, g3, sv_a, sc_d, B, L, defer=wg, acc=dacc, ln_part=lpd[2], pending=second)
             if ops.wgrad_gemm_group(wg, g32, colsum_ws=w["dec_bias_ws"], colsum_ld=nbd):
                 second.append((w["dec_bias_ws"], ops.COLSUM_PARTS, nbd, nbd,
                                g32[o(f"model.decoder.layers.{l}.self_attn.q_proj.bias"):], True))

@@ -613,3 +613,42 @@ def test_whisper_attention_dropout_matches_oracle_with_the_same_masks():
         if not (cos >= 0.99 and 0.94 <= ratio <= 1.06):
             bad.append((name, round(cos, 4), round(ratio, 4)))
     assert not bad, bad
+
+
+def test_whisper_first_micro_batch_overwrites_every_layer_matrix_gradient():
+    """Trainer's contract (zero_grad(matrices=False) + backward(overwrite_matrices=True) for a step's first micro-batch):
+    the encoder AND decoder layers' weight matrices are neither cleared nor read back - their weight-gradient GEMMs
+    overwrite - and the result equals zero-everything-then-accumulate bit for bit, also with a dropped encoder layer and a
+    dropped decoder layer (their stale slots are cleared) and when a second micro-batch then accumulates."""
+    from coral_amd.whisper import WhisperShape
+    from coral_amd.whisper_train import WhisperTrainEngine
+    from oracle import whisper_ref as w
+
+    kw, c = _tiny()
+    g = torch.Generator().manual_seed(5)
+    feats = torch.randn(2, 80, 3000, generator=g) * 0.5
+    labels = torch.randint(0, 200, (2, 6), generator=g)
+    nl_e, nl_d = kw["encoder_layers"], kw["decoder_layers"]
+    keep = dict(enc_keep=[True] * (nl_e - 1) + [False], dec_keep=[False] + [True] * (nl_d - 1))
+    grads = {}
+    for mode in ("accumulate", "overwrite"):
+        eng = WhisperTrainEngine(WhisperShape(**kw), DEV)
+        eng.load_state_dict(w.synth_params(c))
+        for step, kws in enumerate((dict(), keep)):
+            if mode == "accumulate":
+                eng.zero_grad()
+            else:
+                lo_hi = [eng._enc_matrix_range(l) for l in range(eng.s.encoder_layers)] + [eng._dec_matrix_range(l) for l in range(eng.s.decoder_layers)]
+                for lo, hi in lo_hi:  # stale values where nothing is cleared: an overwrite must not see them
+                    eng.store.g32[lo:hi].fill_(1e3 * (step + 1))
+                eng.zero_grad(matrices=False)
+            eng.forward_train(feats, labels, **kws)
+            eng.backward(loss_scale=0.5, overwrite_matrices=(mode == "overwrite"))
+            eng.forward_train(feats.flip(0), labels.flip(0), **kws)  # second micro-batch: accumulates in both modes
+            eng.backward(loss_scale=0.5, overwrite_matrices=False)
+            torch.cuda.synchronize()
+            grads[(mode, step)] = eng.store.g32.clone()
+    for step in (0, 1):
+        a, b = grads[("accumulate", step)], grads[("overwrite", step)]
+        assert torch.isfinite(a).all() and float(a.abs().max()) > 0 and float(a.abs().max()) < 1e2
+        assert torch.equal(a, b), float((a - b).abs().max())
