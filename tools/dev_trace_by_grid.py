@@ -20,5 +20,5 @@ for r in rows:
     a[1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
 tot = sum(a[1] for a in agg.values())
 print(f"{len(rows)} launches, {tot / 1e3:.2f} ms of kernel time")
-for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1])[:30]:
+for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1])[:60]:
     print(f"{a[1] / tot * 100:5.1f}%  {a[0]:6d} x {a[1] / a[0]:8.2f} us  grid {k[1]:>8s} wg {k[2]:>4s}  {k[0]}")
