@@ -306,6 +306,8 @@ def whisper_measure(model, args, world, rank, device, decode=False, fp8=False, B
     if trainer is not None:
         trainer.finish()
         torch.cuda.synchronize()
+        if world == 1:
+            trainer.close()
     return res
 
 
@@ -466,6 +468,7 @@ def run_w2v2(model_key, args, world, rank, device, roofline: bool):
     torch.cuda.synchronize()
     res["bg_blocks"] = int(getattr(trainer, "bg_blocks", 0) or 0)
     if world == 1:
+        trainer.close()  # (the C-ABI communicator of a --one-rank-exchange run goes back with it)
         res["trainer"] = None  # (N = 1: nothing to check afterwards; the moments' memory goes back before the next workload)
     return res
 

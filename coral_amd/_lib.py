@@ -118,6 +118,8 @@ SIGNATURES = {
     "ca_quantize_fp8_transposed": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp]),
     "ca_gemm_force_kernel": (C.c_int, [C.c_int]),
     "ca_gemm_debug_general_epilogue": (C.c_int, [C.c_int]),
+    "ca_debug_cu_hog": (C.c_int, [_i32, _i32, _i32, C.c_double, _vp]),
+    "ca_gemm_set_compute_cus": (C.c_int, [C.c_int]),
     "ca_prof_begin": (C.c_int, []),
     "ca_prof_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "ca_attn_fwd": (C.c_int, [C.POINTER(CaAttnDesc), _vp]),
@@ -206,6 +208,7 @@ SIGNATURES = {
     "ca_comm_unique_id": (C.c_int, [_vp]),
     "ca_comm_init": (C.c_int, [C.POINTER(_vp), _vp, _i32, _i32]),
     "ca_comm_destroy": (C.c_int, [_vp]),
+    "ca_comm_abort": (C.c_int, [_vp]),
     "ca_comm_stream": (_vp, [_vp]),
     "ca_comm_rank": (C.c_int, [_vp]),
     "ca_comm_world": (C.c_int, [_vp]),

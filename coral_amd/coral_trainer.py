@@ -109,7 +109,11 @@ class CoralTrainer:
         self.dp = DataParallelTrainer(
             model, learning_rate=a.learning_rate, betas=(a.adam_beta1, a.adam_beta2), max_grad_norm=a.max_grad_norm,
             warmup_steps=a.warmup_steps, max_steps=a.max_steps, grad_accum=a.gradient_accumulation_steps,
-            process_group=process_group, compress_grads=compress_grads, **kw)
+            process_group=process_group, compress_grads=compress_grads,
+            # the reference's Trainer (transformers 5.x) does not divide these models' losses by the accumulation count
+            # (DataParallelTrainer.accum_loss; pinned by tests/golden/trainer_traj.npz); `accumulation_loss="mean"`
+            # in the training arguments restores the textbook scaling
+            accum_loss=getattr(a, "accumulation_loss", "sum"), **kw)
         self.engine = self.dp.engine
         self.is_seq2seq = hasattr(model, "generate")
         self.is_main = os.getenv("RANK", "0") == "0"
@@ -274,6 +278,13 @@ class CoralTrainer:
         if "wrapper" in st and isinstance(rng, np.random.RandomState):
             rng.set_state(st["wrapper"])
 
+    def _save_rng_state(self, d: Path):
+        """`rng_state_<rank>.pth`, written by EVERY rank (HF's per-process `_save_rng_state`, $TF/trainer.py:3166-3201):
+        the main rank writes its file with the checkpoint, the others after the barrier behind it (`train()`), when
+        the directory exists - a resumed N-rank run continues each rank's own SpecAugment / LayerDrop sequence."""
+        d.mkdir(parents=True, exist_ok=True)
+        torch.save(self._rng_state(), str(d / f"rng_state_{int(os.getenv('RANK', '0') or 0)}.pth"))
+
     def _save_checkpoint(self, step: int, moments=None) -> Path:
         """`checkpoint-<step>/`: the model in HF layout, the optimiser moments and the trainer state
         (Trainer._save_checkpoint + rotation, $TF/trainer.py:3079,3326; `save_total_limit` never deletes the best)."""
@@ -288,7 +299,7 @@ class CoralTrainer:
         self.model.save_pretrained(d)
         m, v = moments if moments is not None else (self.dp.m, self.dp.v)
         save_file(dict(m=m.cpu(), v=v.cpu()), str(d / "optimizer.safetensors"), metadata={"layout": self._moment_layout()})
-        torch.save(self._rng_state(), str(d / f"rng_state_{int(os.getenv('RANK', '0') or 0)}.pth"))
+        self._save_rng_state(d)
         st = {k: self.state[k] for k in ("epoch", "best_metric", "best_step", "bad_evals")}
         (d / "trainer_state.json").write_text(json.dumps(dict(global_step=step, **st), indent=1))
         limit = self.args.save_total_limit
@@ -330,6 +341,10 @@ class CoralTrainer:
         if layout is None:
             # (a file from before the layout tag: its order cannot be verified - restart the moments rather than risk
             # attaching them to other parameters)
+            if not getattr(self.args, "restart_untagged_moments", False):
+                raise ValueError(f"{ckpt}/optimizer.safetensors carries no layout tag (written before round 4): its AdamW "
+                                 "moments cannot be matched to the parameters.  Delete the file or pass "
+                                 "`restart_untagged_moments=True` in the training arguments to restart them from zero")
             logger.warning("%s/optimizer.safetensors carries no layout tag: AdamW moments restart from zero", ckpt)
             self.dp.m.zero_()
             self.dp.v.zero_()
@@ -417,7 +432,11 @@ class CoralTrainer:
             if (step + 1) % a.logging_steps == 0 or step == start_step:
                 lv = float(loss)
                 loss_sum, loss_n = loss_sum + lv, loss_n + 1
-                hist.append(dict(step=step + 1, loss=lv, lr=self.dp.lr, epoch=self.state["epoch"], elapsed=time.time() - t0))
+                # (as Trainer logs them: the loss over the step's micro-batches, the gradient norm BEFORE clipping and
+                # the learning rate the update just taken used, $TF/trainer.py `_maybe_log_save_evaluate`)
+                hist.append(dict(step=step + 1, loss=lv, grad_norm=float(self.dp.grad_norm()),
+                                 learning_rate=float(getattr(self.dp, "last_lr", self.dp.lr)), lr=self.dp.lr,
+                                 epoch=self.state["epoch"], elapsed=time.time() - t0))
                 if self.is_main:
                     logger.info("step %d loss %.4f", step + 1, lv)
             stop = False
@@ -444,7 +463,12 @@ class CoralTrainer:
                 if self.state["best_step"] == step + 1:
                     self.best_dir = d
             if save_now and torch.distributed.is_available() and torch.distributed.is_initialized():
-                torch.distributed.barrier()
+                torch.distributed.barrier()  # the main rank's directory exists (and survived the rotation)
+                if not self.is_main:
+                    self._save_rng_state(Path(a.output_dir) / f"checkpoint-{step + 1}")
+                    torch.distributed.barrier()  # nobody resumes or rotates before every rank's file is there
+                else:
+                    torch.distributed.barrier()
             if stop:
                 if self.is_main:
                     logger.info("early stopping at step %d (best %.4f at step %s)", step + 1, self.state["best_metric"],

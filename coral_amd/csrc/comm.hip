@@ -24,6 +24,7 @@ struct Rccl {
   ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;  // optional: ca_comm_abort falls back to CommDestroy without it
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*ReduceScatter)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
@@ -59,6 +60,7 @@ int rccl_load() {
   CA_SYM(AllGather, "ncclAllGather");
   CA_SYM(GetErrorString, "ncclGetErrorString");
 #undef CA_SYM
+  g_rccl.CommAbort = (decltype(g_rccl.CommAbort))dlsym(h, "ncclCommAbort");
   g_rccl.handle = h;
   return CA_OK;
 }
@@ -113,7 +115,11 @@ extern "C" int ca_comm_init(CaComm** out, const void* id128, int32_t rank, int32
   CaComm* c = new CaComm();
   c->rank = rank;
   c->world = world;
-  CA_HIP(hipGetDevice(&c->device), "ca_comm_init");
+  if (hipGetDevice(&c->device) != hipSuccess) {
+    delete c;
+    ca_set_error("ca_comm_init: no current device");
+    return CA_ERR_LAUNCH;
+  }
   ncclUniqueId id;
   memcpy(&id, id128, sizeof(id));
   ncclResult_t r = g_rccl.CommInitRank(&c->comm, world, id, rank);
@@ -122,8 +128,18 @@ extern "C" int ca_comm_init(CaComm** out, const void* id128, int32_t rank, int32
     delete c;
     return CA_ERR_LAUNCH;
   }
-  CA_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "ca_comm_init(stream)");
-  CA_HIP(hipEventCreateWithFlags(&c->ev, hipEventDisableTiming), "ca_comm_init(event)");
+  // (a failure from here on gives the communicator and the context back: nothing of a half-built context survives)
+  hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) {
+    e = hipEventCreateWithFlags(&c->ev, hipEventDisableTiming);
+    if (e != hipSuccess) hipStreamDestroy(c->stream);
+  }
+  if (e != hipSuccess) {
+    ca_set_error("ca_comm_init: %s", hipGetErrorString(e));
+    g_rccl.CommDestroy(c->comm);
+    delete c;
+    return CA_ERR_LAUNCH;
+  }
   *out = c;
   return CA_OK;
 }
@@ -132,6 +148,21 @@ extern "C" int ca_comm_destroy(CaComm* c) {
   if (!c) return CA_OK;
   hipStreamSynchronize(c->stream);
   if (g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+  hipEventDestroy(c->ev);
+  hipStreamDestroy(c->stream);
+  delete c;
+  return CA_OK;
+}
+
+// Tear a context down WITHOUT waiting for its stream: for a communicator whose peers never joined a collective (its
+// kernel would spin for ever; ncclCommAbort ends it).  The rendezvous fallback of the host side uses it.
+extern "C" int ca_comm_abort(CaComm* c) {
+  if (!c) return CA_OK;
+  if (g_rccl.CommAbort)
+    g_rccl.CommAbort(c->comm);
+  else if (g_rccl.CommDestroy)
+    g_rccl.CommDestroy(c->comm);
+  hipStreamSynchronize(c->stream);  // (the aborted kernels have left the stream)
   hipEventDestroy(c->ev);
   hipStreamDestroy(c->stream);
   delete c;

@@ -48,27 +48,41 @@ __device__ __forceinline__ unsigned short f2bf(float f) {
 // (Abramowitz & Stegun 7.1.26, |error| <= 1.5e-7 on erf).  Phi(x) is taken from the complementary
 // form on the negative side, so there is no 1 + erf cancellation: against the float64 value this
 // rounds to the same bf16 more often than torch's own fp32 GELU does (tools/dev notes in DESIGN.md §4.4).
-// ~14 VALU ops instead of ~50; the exp(-x^2/2) is shared with the derivative's pdf term.
+// Round 5: the FFN epilogues are bound by vector-instruction issue (24 VALU per element for GELU + dropout, two
+// waves per SIMD), so the evaluation is written for instruction count:
+//   * he = 0.5 erfc(|x| / sqrt 2) with the 0.5 folded into the coefficients (an exact scaling) and the two constant
+//     factors in front of exp2 folded into one (w = |x| sqrt(log2(e) / 2), exp(-x^2/2) = exp2(-w^2));
+//   * gelu(x) = max(x, 0) - |x| he (one fma; for x >= 0: x - x he = x (1 - he), for x < 0: x he) instead of forming
+//     Phi(x) with a compare and a select and multiplying;
+//   * |x| is clamped to 14 inside the erfc part (he underflows to 0 beyond), so an infinite x stays infinite.
+// 9 VALU slots per element with packed fp32 arithmetic instead of 14; the exp(-x^2/2) is shared with the derivative.
+__device__ __forceinline__ void ca_half_erfc(float x, float& he, float& e, float& ax) {
+  ax = fminf(fabsf(x), 14.0f);
+  const float w = ax * 0.84932180028801904272f;  // sqrt(log2(e) / 2)
+  e = __builtin_amdgcn_exp2f(-w * w);            // exp(-x^2/2)
+  const float t = __builtin_amdgcn_rcpf(fmaf(ax, 0.23164189f, 1.0f));  // 0.3275911 / sqrt 2
+  float poly = fmaf(t, 0.5f * 1.061405429f, 0.5f * -1.453152027f);
+  poly = fmaf(t, poly, 0.5f * 1.421413741f);
+  poly = fmaf(t, poly, 0.5f * -0.284496736f);
+  poly = fmaf(t, poly, 0.5f * 0.254829592f);
+  he = t * poly * e;
+}
 __device__ __forceinline__ void ca_gauss_cdf_pdf(float x, float& cdf, float& e) {
-  const float u = fabsf(x) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, u, 1.0f));
-  float poly = fmaf(t, 1.061405429f, -1.453152027f);
-  poly = fmaf(t, poly, 1.421413741f);
-  poly = fmaf(t, poly, -0.284496736f);
-  poly = fmaf(t, poly, 0.254829592f);
-  e = __expf(-u * u);  // exp(-x^2/2)
-  const float half_erfc = 0.5f * t * poly * e;
-  cdf = x >= 0.f ? 1.0f - half_erfc : half_erfc;
+  float he, ax;
+  ca_half_erfc(x, he, e, ax);
+  cdf = x >= 0.f ? 1.0f - he : he;
 }
 __device__ __forceinline__ float gelu_erf(float x) {
-  float cdf, e;
-  ca_gauss_cdf_pdf(x, cdf, e);
-  return x * cdf;
+  float he, e, ax;
+  ca_half_erfc(x, he, e, ax);
+  return fmaf(-ax, he, fmaxf(x, 0.f));
 }
 __device__ __forceinline__ float dgelu_erf(float x) {
-  float cdf, e;
-  ca_gauss_cdf_pdf(x, cdf, e);
-  return fmaf(x * 0.39894228040143267794f, e, cdf);
+  float he, e, ax;
+  ca_half_erfc(x, he, e, ax);
+  const float cdf = x >= 0.f ? 1.0f - he : he;
+  // x pdf(x) with the clamped |x| (beyond 14 the term is below 1e-40): an infinite x gives 1 or 0, not inf * 0
+  return fmaf(__builtin_copysignf(ax, x) * 0.39894228040143267794f, e, cdf);
 }
 
 // ---- 64-lane wavefront reductions ----
@@ -146,6 +160,15 @@ __device__ __forceinline__ unsigned int ca_dropout_keep4(uint64_t seed, uint64_t
   unsigned int w0, w1;
   ca_dropout_words(seed, idx4 >> 2, w0, w1);
   const unsigned int thr = ca_dropout_threshold(p);
+  return ((w0 & 0xFFFFu) >= thr ? 1u : 0u) | ((w0 >> 16) >= thr ? 2u : 0u) | ((w1 & 0xFFFFu) >= thr ? 4u : 0u) |
+         ((w1 >> 16) >= thr ? 8u : 0u);
+}
+// ca_dropout_keep4 with the hash input split by the caller: s_eff = seed word ^ (high group word * 0x85EBCA6B),
+// group_lo = low 32 bits of (flat element index / 4) - for callers that walk a range in which the high word is constant
+__device__ __forceinline__ unsigned int ca_dropout_keep4_lo(unsigned int s_eff, unsigned int group_lo, unsigned int thr) {
+  const unsigned int w0 = ca_mix32(group_lo ^ s_eff);
+  unsigned int w1 = w0 * 0xC2B2AE35u;
+  w1 ^= w1 >> 15;
   return ((w0 & 0xFFFFu) >= thr ? 1u : 0u) | ((w0 >> 16) >= thr ? 2u : 0u) | ((w1 & 0xFFFFu) >= thr ? 4u : 0u) |
          ((w1 >> 16) >= thr ? 8u : 0u);
 }

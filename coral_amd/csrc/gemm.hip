@@ -432,10 +432,53 @@ __device__ __forceinline__ void ca_store_fp8x8(unsigned char* dst, const float (
 // predicates are gone, the flat element index of the dropout hash advances by a constant.  Same arithmetic in the same
 // order as the general walk: the results are bit-identical (tests/test_kernels_gpu.py compares ragged and interior tiles
 // of one launch against the same reference).
-template <int EPI, bool F32, bool DROP>
+// ---- slab staging (kernel X, round 5) ---------------------------------------------------------------------------
+// The classic staging parks a wave's whole 64 x 64 fp32 tile (17 KB, 139 KB for the 8 waves of kernel X: every byte of
+// the operand stages), so nothing of the next tile can be in flight while a tile leaves.  Slab staging parks 16 rows
+// at a time in a 4-KiB region per wave that lies BEHIND the two operand stages (128 KiB + 8 x 4 KiB = all 160 KiB of
+// LDS), walks them in the same two passes of 8 rows x 64 columns per lane group as before (same lane -> element
+// assignment, same order: bit-identical outputs and sums of squares) and lets kernel X request the next tile's first
+// K-step before the epilogue starts.  The 16 x 64 slab has no row padding: 16-byte chunk c of row r sits at chunk
+// c ^ r, which is conflict-free for the parked fragments (8 consecutive rows of one chunk column per ds_write_b128
+// group) and for the row-major reads (the hardware's 16-lane ds_read_b128 groups cover 16 different chunks).
+// Which 16 rows are parked is a run-time choice in a rolled loop - made by a wave-uniform switch over register
+// copies, because a run-time index into the accumulator array would send it through scratch memory.
+#define SLAB_BYTES 4096
+__device__ __forceinline__ void slab_park(const f32x4_t (&acc)[4][4], int i4, float* slab, int lane) {
+  const int r = lane & 15, g = lane >> 4;
+  float* row = slab + r * 64;
+  float* p0 = row + ((g ^ r) << 2);
+  float* p1 = row + (((4 + g) ^ r) << 2);
+  float* p2 = row + (((8 + g) ^ r) << 2);
+  float* p3 = row + (((12 + g) ^ r) << 2);
+  // the stores sit INSIDE the cases: straight from the accumulator registers, no copies (the asm statements keep the
+  // cases as branches: as selects they would cost 3 x 16 v_cndmask per slab)
+#define SLAB_CASE(I)                 \
+  asm volatile("; slab rows " #I);   \
+  *(f32x4_t*)p0 = acc[I][0];         \
+  *(f32x4_t*)p1 = acc[I][1];         \
+  *(f32x4_t*)p2 = acc[I][2];         \
+  *(f32x4_t*)p3 = acc[I][3];
+  switch (i4) {
+    case 0: SLAB_CASE(0) break;
+    case 1: SLAB_CASE(1) break;
+    case 2: SLAB_CASE(2) break;
+    default: SLAB_CASE(3) break;
+  }
+#undef SLAB_CASE
+}
+// the 8 consecutive columns 8 (lane & 7) .. of row p * 8 + (lane >> 3) of the parked slab
+__device__ __forceinline__ void slab_read(const float* slab, int p, int lane, f32x4_t& a4, f32x4_t& b4) {
+  const int r = p * 8 + (lane >> 3), c = 2 * (lane & 7);
+  const float* row = slab + r * 64;
+  a4 = *(const f32x4_t*)(row + ((c ^ r) << 2));
+  b4 = *(const f32x4_t*)(row + (((c + 1) ^ r) << 2));
+}
+
+template <int EPI, bool F32, bool DROP, bool SLAB = false>
 __device__ __forceinline__ void gemm_epilogue_fast(const CaGemmDesc& d, const float* wt, int lane, int mw, int nb, int z,
                                                    int64_t zoffC, int64_t zoffR, const float (&bias8)[8], float& ssq,
-                                                   float& amx) {
+                                                   float& amx, const f32x4_t (*acc)[4][4] = nullptr) {
   const int M = d.M, N = d.N;
   const float alpha = d.alpha;
   const float keep_scale = DROP ? 1.f / (1.f - d.dropout_p) : 1.f;
@@ -451,17 +494,52 @@ __device__ __forceinline__ void gemm_epilogue_fast(const CaGemmDesc& d, const fl
   if (NEEDS_R) r_next = *(const u16x8_t*)Rp;
   const bool c8_on = (EPI == CA_EPI_GELU || EPI == CA_EPI_DGELU) && d.C8 != nullptr;  // (wave-uniform)
   const float s8 = c8_on ? d.c8_scale[0] : 1.f;
+  // dropout: the hash takes the group index (flat element index / 4) as two 32-bit words.  Where the wave tile does
+  // not cross a multiple of 2^34 elements (wave-uniform test) the high word is a constant folded into the seed word
+  // and the low word advances by a 32-bit add per pass - the same bits as ca_dropout_keep4 on the 64-bit index.
+  // (the caller sends a wave tile that does cross such a multiple through the general walk: epi_drop32_ok)
+  unsigned int dg = 0, ds_eff = 0, dthr = 0;
+  if (DROP) {
+    const uint64_t ilo = ((uint64_t)z * M + mw) * (uint64_t)N;
+    const unsigned int sd = (unsigned int)d.dropout_seed * 0x9E3779B9u + (unsigned int)(d.dropout_seed >> 32);
+    ds_eff = sd ^ ((unsigned int)(ilo >> 34) * 0x85EBCA6Bu);
+    dg = (unsigned int)(idx >> 2);
+    dthr = ca_dropout_threshold(d.dropout_p);
+  }
+  const unsigned int dgstep = (unsigned int)(istep >> 2);
+  if (SLAB) slab_park(*acc, 0, const_cast<float*>(wt), lane);
+#pragma unroll 1
+  for (int i4 = 0; i4 < (SLAB ? 4 : 1); ++i4) {
+  // slab i4's 16 rows go to registers first, then the next 16 rows are parked (LDS operations of a wave execute in
+  // order: the reads see the old slab) - the stores complete under this slab's arithmetic
+  f32x4_t sa[2], sb[2];
+  if (SLAB) {
+    slab_read(wt, 0, lane, sa[0], sb[0]);
+    slab_read(wt, 1, lane, sa[1], sb[1]);
+    if (i4 < 3) slab_park(*acc, i4 + 1, const_cast<float*>(wt), lane);
+  }
 #pragma unroll 2
-  for (int it = 0; it < 8; ++it) {
+  for (int itl = 0; itl < (SLAB ? 2 : 8); ++itl) {
+    const int it = SLAB ? 2 * i4 + itl : itl;
     const u16x8_t r_cur = r_next;
     if (NEEDS_R && it < 7) r_next = *(const u16x8_t*)(Rp + (it + 1) * rstep);
-    const float* wr = wt + (it * 8 + r0) * EPI_PITCH + c0;
-    const f32x4_t a4 = *(const f32x4_t*)wr, b4 = *(const f32x4_t*)(wr + 4);
+    f32x4_t a4, b4;
+    if (SLAB) {
+      a4 = sa[itl];
+      b4 = sb[itl];
+    } else {
+      const float* wr = wt + (it * 8 + r0) * EPI_PITCH + c0;
+      a4 = *(const f32x4_t*)wr;
+      b4 = *(const f32x4_t*)(wr + 4);
+    }
     float v[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = (e < 4 ? a4[e] : b4[e - 4]) * alpha + bias8[e];
     unsigned int keep = 0xFFu;
-    if (DROP) keep = ca_dropout_keep4(d.dropout_seed, idx, d.dropout_p) | (ca_dropout_keep4(d.dropout_seed, idx + 4, d.dropout_p) << 4);
+    if (DROP) {
+      keep = ca_dropout_keep4_lo(ds_eff, dg, dthr) | (ca_dropout_keep4_lo(ds_eff, dg + 1, dthr) << 4);
+      dg += dgstep;
+    }
     float v2[8];
     if (EPI == CA_EPI_GELU) {
 #pragma unroll
@@ -519,12 +597,13 @@ __device__ __forceinline__ void gemm_epilogue_fast(const CaGemmDesc& d, const fl
       if (c8_on) ca_store_fp8x8((unsigned char*)d.C8 + coff, v2, s8, amx);
     }
     coff += cstep;
-    idx += istep;
   }
+  }  // slabs
 }
 
 // PARKED: the 64 x 64 staging tile `wave` already holds the accumulators (kernel M: two waves fill one tile)
-template <bool PARKED = false>
+// SLAB: `smem` is the wave's own 4-KiB slab (see slab_park); the 64 x 64 tile goes through it 16 rows at a time
+template <bool PARKED = false, bool SLAB = false>
 __device__ __forceinline__ void gemm_epilogue(const CaGemmDesc& d, f32x4_t (&acc)[4][4], char* smem,
                                               int wave, int lane, int mw, int nw, int z, int z1,
                                               int z2, const float (*bias_pre)[8] = nullptr) {
@@ -559,8 +638,8 @@ __device__ __forceinline__ void gemm_epilogue(const CaGemmDesc& d, f32x4_t (&acc
   u16x8_t r_next = {0, 0, 0, 0, 0, 0, 0, 0};
   load_r(0, r_next);
 
-  float* wt = (float*)smem + wave * (64 * EPI_PITCH);
-  if (!PARKED) {
+  float* wt = SLAB ? (float*)smem : (float*)smem + wave * (64 * EPI_PITCH);
+  if (!PARKED && !SLAB) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -569,17 +648,20 @@ __device__ __forceinline__ void gemm_epilogue(const CaGemmDesc& d, f32x4_t (&acc
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private region: no barrier
   }
   const bool c8_on = d.C8 != nullptr && (epi == CA_EPI_GELU || epi == CA_EPI_DGELU);
-  if (nvalid <= 0 && d.c_sumsq == nullptr && !c8_on) return;
+  // (slab staging: every lane keeps parking its share of the rows inside the walk, also one without valid columns)
+  if (!SLAB && nvalid <= 0 && d.c_sumsq == nullptr && !c8_on) return;
   float ssq = 0.f;  // sum of squares of the fp32 values this lane stores (c_sumsq)
   float amx = 0.f;  // max |gelu| this lane stores (C8)
   const float s8 = c8_on ? d.c8_scale[0] : 1.f;
   // interior wave tile (wave-uniform test): the specialised walk above
   const bool drop_on = d.dropout_p > 0.f;
-  const bool interior = g_ca_epi_general == 0 && mw + 64 <= M && nw + 64 <= N && vec_ok && (N & 7) == 0 && d.C != nullptr &&
+  // (dropout in the specialised walk: the 64 rows' flat element indices share their bits from 34 up)
+  const bool drop32_ok = !drop_on || ((((uint64_t)z * M + mw) * (uint64_t)N) >> 34) == ((((uint64_t)z * M + mw + 64) * (uint64_t)N) >> 34);
+  const bool interior = g_ca_epi_general == 0 && mw + 64 <= M && nw + 64 <= N && vec_ok && (N & 7) == 0 && d.C != nullptr && drop32_ok &&
                         (d.out_f32 || !d.accumulate) && (!has_gelu || (epi == CA_EPI_GELU && d.C2 != nullptr && !d.out_f32)) &&
                         !(d.out_f32 && epi != CA_EPI_NONE) && !(drop_on && epi == CA_EPI_NONE);
   if (interior) {
-#define EPI_FAST(E, F, D) gemm_epilogue_fast<E, F, D>(d, wt, lane, mw, nb, z, zoffC, zoffR, bias8, ssq, amx)
+#define EPI_FAST(E, F, D) gemm_epilogue_fast<E, F, D, SLAB>(d, wt, lane, mw, nb, z, zoffC, zoffR, bias8, ssq, amx, &acc)
     if (d.out_f32) {
       EPI_FAST(CA_EPI_NONE, true, false);
     } else if (epi == CA_EPI_NONE) {
@@ -595,13 +677,19 @@ __device__ __forceinline__ void gemm_epilogue(const CaGemmDesc& d, f32x4_t (&acc
   } else {
 #pragma unroll 1
   for (int it = 0; it < 8; ++it) {
+    if (SLAB && (it & 1) == 0) slab_park(acc, it >> 1, wt, lane);  // (before any `continue`: every lane parks its rows)
     const int ml = it * 8 + (lane >> 3);
     const int m = mw + ml;
     const u16x8_t r_cur = r_next;
     load_r(it + 1, r_next);
     if (m >= M || nvalid <= 0) continue;
-    const f32x4_t a4 = *(const f32x4_t*)(wt + ml * EPI_PITCH + 8 * (lane & 7));
-    const f32x4_t b4 = *(const f32x4_t*)(wt + ml * EPI_PITCH + 8 * (lane & 7) + 4);
+    f32x4_t a4, b4;
+    if (SLAB) {
+      slab_read(wt, it & 1, lane, a4, b4);
+    } else {
+      a4 = *(const f32x4_t*)(wt + ml * EPI_PITCH + 8 * (lane & 7));
+      b4 = *(const f32x4_t*)(wt + ml * EPI_PITCH + 8 * (lane & 7) + 4);
+    }
     float v[8], v2[8], r[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -1038,7 +1126,17 @@ __global__ __launch_bounds__(512) void ca_gemm_kernel_m(const CaGemmDesc d) {
 #define XBN 256
 #define XTILE (XBM * BK * 2)  // 32 KiB per operand tile
 #define XSTAGE (2 * XTILE)
-#define X_LDS_BYTES (8 * 64 * EPI_PITCH * 4)  // 139264 >= 2 stages * 64 KiB
+#define X_LDS_BYTES (8 * 64 * EPI_PITCH * 4)  // 139264 >= 2 stages * 64 KiB (classic staging: the fp8 256x256 kernel)
+#define X_SLAB_BASE (2 * XSTAGE)             // bf16 kernel X: 8 epilogue slabs of 4 KiB behind the two stages
+#define X_SLAB_LDS (X_SLAB_BASE + 8 * SLAB_BYTES)  // 163840 = all 160 KiB of a CU's LDS
+#ifndef CA_X_SLAB
+// 1: slab staging + the next tile's first K-step requested under the epilogue.  Built and measured in round 5 (same box,
+// interleaved, profiles/r05_gemm_shapes.txt): 3 % SLOWER on the plain FFN launch and equal on the GELU launches in its
+// first form, 20 % slower with the slab's reads hoisted above the next park - the epilogue of a 256 x 256 tile is bound
+// by the 128-256 KB every CU stores at the same moment (12.5 B/clk per CU = the chip's HBM write rate), not by its LDS
+// staging or by the prologue the early request hides.  The default stays the classic staging; -DCA_X_SLAB=1 builds it.
+#define CA_X_SLAB 0
+#endif
 
 // grp.count > 1: a grouped launch of up to X_GROUP_MAX independent problems of the same operand form
 // (ca_gemm_bf16_group): block ranges map to problems, each with plain row-major tile numbering.
@@ -1053,6 +1151,12 @@ struct CaGemmGroup {
   // workgroups become free, through one counter per XCD (cnt[x], zero between launches: the last pull resets it).
   int vgrid;      // blocks of the virtual grid (= gridDim.x in the one-tile-per-workgroup form)
   unsigned* cnt;  // 8 counters, or null
+  // Persistent form beside another resident kernel (an RCCL ring kernel during the backward of an N > 1 run): some of the
+  // launch's workgroups only start when others have EXITED - i.e. after every dynamic block is taken - and a static
+  // first block would then cost one whole tile time at the end of the launch.  dyn_first: every block, the first
+  // included, comes from the counter; a workgroup that finds it exhausted exits at once (ca_gemm_set_compute_cus).
+  int dyn_first;
+  int stagger_ticks;  // experiment (CA_X_STAGGER_US): every second workgroup of an XCD starts this many 100-MHz ticks late
 };
 // counter slots for persistent launches: launches that may be in flight together (two streams) use different slots
 #define X_CNT_SLOTS 64
@@ -1081,18 +1185,54 @@ __global__ __launch_bounds__(512) void ca_gemm_kernel_x(const CaGemmGroup grp) {
   const int npx = ((int)gridDim.x - xcd + 7) >> 3;  // workgroups of this XCD in the launch
   const int nvx = (vgrid - xcd + 7) >> 3;           // virtual blocks of this XCD
   const int ndyn = nvx > npx ? nvx - npx : 0;       // ... handed out dynamically
-  volatile unsigned* nextw = (volatile unsigned*)(smem + X_LDS_BYTES);  // two words, alternating per iteration
+  // LDS: A0 | A1 | B0 | B1 (the two operand stages, 128 KiB), then one 4-KiB epilogue slab per wave (slab_park).
+  // The word pair that carries the next block's index sits at the head of wave 0's slab: thread 0 writes it at the
+  // start of a tile (its own wave's previous epilogue is over by program order), every wave reads it behind the main
+  // loop - at least one K-step barrier after the write - and in FRONT of the barrier that ends the tile's LDS reads;
+  // only behind that barrier does wave 0's epilogue overwrite it.
+  constexpr bool XSLAB = CA_X_SLAB != 0;
+  volatile unsigned* nextw = (volatile unsigned*)(smem + (XSLAB ? X_SLAB_BASE : X_LDS_BYTES));  // two words, alternating per iteration
+  char* const slab = smem + X_SLAB_BASE + wave * SLAB_BYTES;
+  // Loader state lives outside the tile loop: with one problem per launch (the same descriptor for every tile) the
+  // NEXT tile's loaders are set up and its first K-step is requested behind the barrier that ends this tile's LDS
+  // reads, i.e. under this tile's epilogue (`pre`) - the operand stages are free by then, the epilogue only touches
+  // the slabs.  K-major operands and plain MN-major ones stream through a scalar base (KMajorStream / MNMajorStream);
+  // MN-major operands with segmented rows (KS) keep the per-lane pointer walk.
+  KMajorStream<4> la_k, lb_k;
+  MNMajorStream<4, 32> la_f, lb_f;
+  MNMajorLoader<4, 32, KS> la_m, lb_m;
+  bool pre = false;
+  int pre_tm = 0, pre_tn = 0;
+  if (grp.stagger_ticks > 0 && (((int)blockIdx.x >> 3) & 1)) {
+    // (experiment: would the launch gain if the CUs' epilogues - 128-256 KB of stores each - did not coincide?)
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)grp.stagger_ticks) __builtin_amdgcn_s_sleep(8);
+  }
   int vb = (int)blockIdx.x;
+  int dbase = npx, dcount = ndyn;  // dynamic blocks of this XCD: local indices dbase .. dbase + dcount - 1
+  if (grp.cnt != nullptr && grp.dyn_first) {
+    dbase = 0;
+    dcount = nvx;
+    if (tid == 0) {
+      const unsigned i = __hip_atomic_fetch_add(&grp.cnt[xcd], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (i == (unsigned)(dcount + npx - 1)) __hip_atomic_store(&grp.cnt[xcd], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      nextw[1] = i;  // (the word of odd iterations: rewritten at the start of iteration 1, K-step barriers after this read)
+    }
+    __syncthreads();
+    const unsigned i = (unsigned)__builtin_amdgcn_readfirstlane((int)nextw[1]);
+    vb = i < (unsigned)dcount ? xcd + 8 * (int)i : vgrid;
+  }
   for (int iter = 0; vb < vgrid; ++iter) {
+  int vb_next = vgrid;
   if (grp.cnt != nullptr && tid == 0) {
     // this workgroup's NEXT block (the answer is read after the tile): relaxed device-scope counter
     const unsigned i = __hip_atomic_fetch_add(&grp.cnt[xcd], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (i == (unsigned)(ndyn + npx - 1)) __hip_atomic_store(&grp.cnt[xcd], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (i == (unsigned)(dcount + npx - 1)) __hip_atomic_store(&grp.cnt[xcd], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     nextw[iter & 1] = i;
   }
   bool live = true;
   int which = 0, gt = 0;
-  if (grp.count > 1) {
+  if (!pre && grp.count > 1) {
     // grouped launch: the group's tiles form one list (problem after problem, each in run order) and XCD x
     // (= block & 7) takes the x-th run of ceil(total / 8) of them: every XCD gets the same number of tiles
     // whatever the shapes, and a run covers a compact band of one or two problems.
@@ -1105,8 +1245,8 @@ __global__ __launch_bounds__(512) void ca_gemm_kernel_x(const CaGemmGroup grp) {
     }
   }
   const CaGemmDesc d = grp.d[which];
-  int tm = 0, tn = 0;
-  if (live) {
+  int tm = pre_tm, tn = pre_tn;
+  if (live && !pre) {
     if (grp.count > 1)
       run_tile(gt - grp.first[which], (d.M + XBM - 1) / XBM, (d.N + XBN - 1) / XBN, tm, tn);
     else
@@ -1119,23 +1259,21 @@ __global__ __launch_bounds__(512) void ca_gemm_kernel_x(const CaGemmGroup grp) {
   const __bf16* A = (const __bf16*)d.A + z1 * d.sA1 + z2 * d.sA2;
   const __bf16* B = (const __bf16*)d.B + z1 * d.sB1 + z2 * d.sB2;
 
-  // K-major operands and plain MN-major ones stream through a scalar base (KMajorStream / MNMajorStream); MN-major
-  // operands with segmented rows (KS) keep the per-lane pointer walk
-  KMajorStream<4> la_k, lb_k;
-  MNMajorStream<4, 32> la_f, lb_f;
-  MNMajorLoader<4, 32, KS> la_m, lb_m;
-  if (AL == CA_KMAJOR)
-    la_k.init(A, d.lda, m0, d.M, wave, lane);
-  else if (KS)
-    la_m.init(A, d.lda, d.a_kseg, d.a_kseg_stride, m0, d.M, wave, lane);
-  else
-    la_f.init(A, d.lda, m0, d.M, wave, lane);
-  if (BL == CA_KMAJOR)
-    lb_k.init(B, d.ldb, n0, d.N, wave, lane);
-  else if (KS)
-    lb_m.init(B, d.ldb, d.b_kseg, d.b_kseg_stride, n0, d.N, wave, lane);
-  else
-    lb_f.init(B, d.ldb, n0, d.N, wave, lane);
+  auto init_loaders = [&](int row0, int col0) {
+    if (AL == CA_KMAJOR)
+      la_k.init(A, d.lda, row0, d.M, wave, lane);
+    else if (KS)
+      la_m.init(A, d.lda, d.a_kseg, d.a_kseg_stride, row0, d.M, wave, lane);
+    else
+      la_f.init(A, d.lda, row0, d.M, wave, lane);
+    if (BL == CA_KMAJOR)
+      lb_k.init(B, d.ldb, col0, d.N, wave, lane);
+    else if (KS)
+      lb_m.init(B, d.ldb, d.b_kseg, d.b_kseg_stride, col0, d.N, wave, lane);
+    else
+      lb_f.init(B, d.ldb, col0, d.N, wave, lane);
+  };
+  if (!pre) init_loaders(m0, n0);
 
   f32x4_t acc[8][4];
 #pragma unroll
@@ -1398,7 +1536,7 @@ __global__ __launch_bounds__(512) void ca_gemm_kernel_x(const CaGemmGroup grp) {
 #ifdef X_STAMPS
   const long long stamp_t0 = __builtin_amdgcn_s_memtime();
 #endif
-  burst(0);
+  if (!pre) burst(0);  // (else: requested under the previous tile's epilogue)
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   zero_tail(0);
   __builtin_amdgcn_s_barrier();
@@ -1434,10 +1572,31 @@ __global__ __launch_bounds__(512) void ca_gemm_kernel_x(const CaGemmGroup grp) {
       if (lane < 16 && m < d.M) d.a_colsum[(int64_t)tn * d.a_colsum_ld + m] = s;  // this tile column's share
     }
   }
+  // this workgroup's next block (thread 0 wrote the word at the start of the tile, K-step barriers ago; it is read in
+  // front of the barrier below, behind which wave 0's epilogue may overwrite it)
+  unsigned nxt = 0;
+  if (grp.cnt != nullptr) nxt = (unsigned)__builtin_amdgcn_readfirstlane((int)nextw[iter & 1]);  // wave-uniform by construction
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_s_barrier();  // every wave has read the last K-step: the operand stages are free
   asm volatile("" ::: "memory");
-  // two 64-row halves through the shared epilogue (each wave re-uses its own staging region)
+  pre = false;
+  if (grp.cnt != nullptr) {
+    vb_next = nxt < (unsigned)dcount ? xcd + 8 * (dbase + (int)nxt) : vgrid;
+    if constexpr (!KS && XSLAB) {
+      if (grp.count <= 1 && vb_next < vgrid) {
+        // one problem per launch: the next tile's first K-step goes out now and lands under this tile's epilogue
+        int tmn = 0, tnn = 0;
+        if (tile_of_block_g<4, 8>(vb_next, vgrid, (d.M + XBM - 1) / XBM, (d.N + XBN - 1) / XBN, tmn, tnn)) {
+          init_loaders(tmn * XBM, tnn * XBN);
+          burst(0);
+          pre = true;
+          pre_tm = tmn;
+          pre_tn = tnn;
+        }
+      }
+    }
+  }
+  // two 64-row halves through the shared epilogue, 16 rows at a time through the wave's slab
 #pragma unroll
   for (int ih = 0; ih < 2; ++ih) {
     f32x4_t half[4][4];
@@ -1445,8 +1604,15 @@ __global__ __launch_bounds__(512) void ca_gemm_kernel_x(const CaGemmGroup grp) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) half[i][j] = acc[ih * 4 + i][j];
-    gemm_epilogue(d, half, smem, wave, lane, m0 + wm * 128 + ih * 64, n0 + wn * 64, z, z1, z2, KS ? nullptr : &xbias);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // staging reads done before it is overwritten
+    if constexpr (XSLAB) {
+      gemm_epilogue<false, true>(d, half, slab, wave, lane, m0 + wm * 128 + ih * 64, n0 + wn * 64, z, z1, z2, KS ? nullptr : &xbias);
+    } else {
+      gemm_epilogue(d, half, smem, wave, lane, m0 + wm * 128 + ih * 64, n0 + wn * 64, z, z1, z2, KS ? nullptr : &xbias);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // staging reads done before it is overwritten
+    }
+  }
+  if constexpr (!XSLAB) {
+    if (grp.cnt != nullptr) __syncthreads();  // every wave is done with the staging area before the next tile lands in it
   }
 #ifdef X_STAMPS
   {
@@ -1465,10 +1631,15 @@ __global__ __launch_bounds__(512) void ca_gemm_kernel_x(const CaGemmGroup grp) {
   }
 #endif
   }  // live
+  else if (grp.cnt != nullptr) {
+    // a padding block of the virtual grid: no K-step barrier separates thread 0's write from the reads
+    pre = false;
+    __syncthreads();
+    const unsigned i = (unsigned)__builtin_amdgcn_readfirstlane((int)nextw[iter & 1]);
+    vb_next = i < (unsigned)dcount ? xcd + 8 * (dbase + (int)i) : vgrid;
+  }
   if (grp.cnt == nullptr) break;
-  __syncthreads();  // every wave is done with the staging area; the next block's index is in LDS
-  const unsigned i = (unsigned)__builtin_amdgcn_readfirstlane((int)nextw[iter & 1]);  // wave-uniform by construction
-  vb = i < (unsigned)ndyn ? xcd + 8 * (npx + (int)i) : vgrid;
+  vb = vb_next;
   }  // persistent tile loop
 }
 
@@ -2336,17 +2507,38 @@ extern "C" int ca_gemm_fp8(const CaGemmDesc* desc, void* stream) {
 // and plain (no epilogue, no bias).
 // Launch geometry of kernel X.  Default: persistent workgroups (one per CU) with dynamic tile pulls whenever the tile
 // grid is larger than the chip and un-batched; CA_X_PERSIST=0 restores one workgroup per tile.
-#define X_LAUNCH_LDS (X_LDS_BYTES + 64)
-static void x_launch_geometry(CaGemmGroup& g, unsigned vgrid, unsigned nbz, dim3& grid) {
-  static const int persist = [] { const char* e = getenv("CA_X_PERSIST"); return e ? atoi(e) : 1; }();
+#define X_LAUNCH_LDS (CA_X_SLAB ? X_SLAB_LDS : X_LDS_BYTES + 64)
+// CUs the compute kernels may count on (ca_gemm_set_compute_cus): 0 = all of them.  Set by the trainer of an N > 1 run,
+// where a collective's kernel holds some CUs for most of the backward: persistent launches are sized to the rest and
+// hand out every tile dynamically (CaGemmGroup.dyn_first), and the kernel-choice rule counts rounds on the rest.
+static int g_compute_cus = 0;
+extern "C" int ca_gemm_set_compute_cus(int n) {
+  g_compute_cus = n > 0 ? n : 0;
+  return CA_OK;
+}
+static unsigned x_device_cus() {
   static const unsigned ncu = [] {
     int dev = 0, n = 256;
     if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
     return (unsigned)(n >= 8 ? (n / 8) * 8 : 8);
   }();
+  return ncu;
+}
+static unsigned x_compute_cus() {
+  const unsigned ncu = x_device_cus();
+  if (g_compute_cus <= 0) return ncu;
+  const unsigned c = (unsigned)(g_compute_cus >= 8 ? (g_compute_cus / 8) * 8 : 8);
+  return c < ncu ? c : ncu;
+}
+static void x_launch_geometry(CaGemmGroup& g, unsigned vgrid, unsigned nbz, dim3& grid) {
+  static const int persist = [] { const char* e = getenv("CA_X_PERSIST"); return e ? atoi(e) : 1; }();
+  const unsigned ncu = x_compute_cus();
   static unsigned seq = 0;
   g.vgrid = (int)vgrid;
   g.cnt = nullptr;
+  g.dyn_first = g_compute_cus > 0 ? 1 : 0;
+  static const int stagger = [] { const char* e = getenv("CA_X_STAGGER_US"); return e ? (int)(atof(e) * 100.0) : 0; }();
+  g.stagger_ticks = stagger;
   grid = dim3(vgrid, 1, nbz);
   if (persist && nbz == 1 && vgrid > ncu) {
     unsigned* base = nullptr;
@@ -2510,8 +2702,9 @@ static int ca_gemm_launch(const CaGemmDesc* desc, void* stream) {
   // Kernel X (256x256): only where it fills the chip -- at least ~0.7 tiles per CU in its last round.
   const int xtm = (d.M + XBM - 1) / XBM, xtn = (d.N + XBN - 1) / XBN;
   const int64_t xt = (int64_t)xtm * xtn * nb;
-  const double xwaves = (double)xt / 256.0;
-  const double xeff = xwaves / (double)((xt + 255) / 256);                       // last-wave occupancy
+  const int64_t cus = (int64_t)x_compute_cus();  // (256 on MI355X; fewer beside a resident collective: ca_gemm_set_compute_cus)
+  const double xwaves = (double)xt / (double)cus;
+  const double xeff = xwaves / (double)((xt + cus - 1) / cus);                   // last-wave occupancy
   const double xfill = ((double)d.M * d.N) / ((double)xtm * XBM * (double)xtn * XBN);  // tile padding waste
   // The MN-major x MN-major (weight-gradient) form gains most from the 256x256 tile (1.0 PFLOP/s against 0.63
   // for S inside the training step), so it switches at a lower fill than the other forms.
@@ -2523,7 +2716,7 @@ static int ca_gemm_launch(const CaGemmDesc* desc, void* stream) {
   static const int l_over_x = [] { const char* e = getenv("CA_GEMM_L_OVER_X"); return e ? atoi(e) : 0; }();
   static const int l_min = [] { const char* e = getenv("CA_GEMM_L_MIN"); return e ? atoi(e) : 100; }();
   if (prefer_l && g_force_kernel == 0 && d.a_kseg == 0 && d.b_kseg == 0 && d.K >= 512 && tiles_l >= l_min &&
-      (tiles_l <= 256 * prefer_l || (use_x && l_over_x)) && !d.a_colsum &&
+      (tiles_l <= cus * prefer_l || (use_x && l_over_x)) && !d.a_colsum &&
       (!use_x || (l_over_x == 1 && !tn) || l_over_x == 2 || (l_over_x == 3 && lay == 0))) {
     use_l = 1;
     use_x = 0;

@@ -79,6 +79,11 @@ class TrainingArgs:
     augment_audio: bool = True
     device_input_pipeline: bool = True
     zero_stage: int = 0   # >0: optimiser state + update sharded over the ranks (the reference's `--zero-stage 2` launch)
+    # "sum": the micro-batches of an optimiser step are NOT scaled by 1 / gradient_accumulation_steps - what the
+    # reference's transformers.Trainer (>= 4.46; pinned 5.5.0) does for Wav2Vec2ForCTC / WhisperForConditionalGeneration
+    # (their forwards accept **kwargs, $TF/trainer.py:496-505,1952-1954); "mean": the textbook scaling
+    accumulation_loss: str = "sum"
+    restart_untagged_moments: bool = False  # resume from an optimizer.safetensors without a layout tag: restart m, v from zero
 
 
 class ModelSetup(ABC):

@@ -59,26 +59,41 @@ class CommContext:
     rendezvous - handing rank 0's 128-byte unique id to every rank - rides on the torch.distributed group that launched
     the ranks; every collective afterwards is a ca_* call enqueued on the context's own HIP stream."""
 
-    def __init__(self, device, process_group=None):
+    def __init__(self, device, ident: bytes, rank: int, world: int):
+        """`ident`: rank 0's 128-byte unique id (`new_unique_id()`), handed to every rank by the caller."""
         import ctypes as C
 
         lib = ops.lib()
-        dist = torch.distributed
-        self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
-        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
-        buf = C.create_string_buffer(128)
-        if self.rank == 0:
-            ops.check(lib.ca_comm_unique_id(buf), "ca_comm_unique_id")
-        ident = [bytes(buf.raw)]
-        if self.world > 1:
-            src = dist.get_global_rank(process_group, 0) if process_group is not None else 0
-            dist.broadcast_object_list(ident, src=src, group=process_group)
+        self.rank, self.world = rank, world
+        self.ctx = None
         with torch.cuda.device(device):
             ctx = C.c_void_p()
-            ops.check(lib.ca_comm_init(C.byref(ctx), ident[0], self.rank, self.world), "ca_comm_init")
+            ops.check(lib.ca_comm_init(C.byref(ctx), ident, rank, world), "ca_comm_init")
         self.ctx = ctx
         self.lib = lib
         self.stream = torch.cuda.ExternalStream(lib.ca_comm_stream(ctx), device=device)
+
+    @staticmethod
+    def new_unique_id() -> bytes:
+        """Binds RCCL through the C ABI (ca_comm_unique_id) and returns a fresh id; raises where it cannot."""
+        import ctypes as C
+
+        buf = C.create_string_buffer(128)
+        ops.check(ops.lib().ca_comm_unique_id(buf), "ca_comm_unique_id")
+        return bytes(buf.raw)
+
+    def close(self, abort: bool = False):
+        """Give the communicator and its stream back (ca_comm_destroy: waits for the stream first; `abort`:
+        ca_comm_abort, for a context whose peers never joined a collective)."""
+        ctx, self.ctx = self.ctx, None
+        if ctx is not None:
+            (self.lib.ca_comm_abort if abort else self.lib.ca_comm_destroy)(ctx)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001  (interpreter shutdown: the library may be gone)
+            pass
 
     @staticmethod
     def _dt(t):
@@ -168,28 +183,65 @@ class GradSync:
         import logging
 
         dist = torch.distributed
-        world = dist.get_world_size(pg)
-        ctx, ok = None, True
-        try:
-            ctx = CommContext(device, pg)
-            if world > 1:
-                x = (torch.arange(4096, dtype=torch.float32, device=device) % 61) * (dist.get_rank(pg) + 1)
-                want = x.clone()
-                dist.all_reduce(want, group=pg)
-                ctx.after_current()
-                ctx.all_reduce(x)
-                ctx.before_current()
-                ok = bool(torch.equal(x, want))
-        except Exception as e:  # noqa: BLE001
-            logging.getLogger(__package__).warning("C-ABI collectives unavailable (%s)", e)
-            ok = False
-        if world > 1:
+        world, rank = dist.get_world_size(pg), dist.get_rank(pg)
+        log = logging.getLogger(__package__)
+
+        def agree(ok: bool) -> bool:
+            """True only if EVERY rank says so - exchanged over torch.distributed's own communicator on the current
+            stream, which at no point of this function waits for the context under test."""
+            if world == 1:
+                return ok
             flag = torch.tensor([1.0 if ok else 0.0], device=device)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=pg)
-            ok = bool(flag.item() > 0.5)
-        if not ok:
-            logging.getLogger(__package__).warning("gradient exchange falls back to torch.distributed's RCCL collectives")
+            return bool(flag.item() > 0.5)
+
+        def fallback(ctx=None, abort=False):
+            if ctx is not None:
+                ctx.close(abort=abort)
+            log.warning("gradient exchange falls back to torch.distributed's RCCL collectives")
             return None
+
+        # 1. every rank binds RCCL through the C ABI (its own throw-away id proves it); rank 0's id is the one used.
+        #    The broadcast happens WHATEVER rank 0 found - its id or a None sentinel - so no rank is left waiting in it.
+        ident, ok = None, True
+        try:
+            ident = CommContext.new_unique_id()
+        except Exception as e:  # noqa: BLE001
+            log.warning("C-ABI collectives unavailable (%s)", e)
+            ok = False
+        box = [ident]
+        if world > 1:
+            src = dist.get_global_rank(pg, 0) if pg is not None else 0
+            dist.broadcast_object_list(box, src=src, group=pg)
+        if not agree(ok and box[0] is not None):
+            return fallback()
+        # 2. the communicator (collective: every rank passed step 1, so every rank calls it)
+        ctx = None
+        try:
+            ctx = CommContext(device, box[0], rank, world)
+        except Exception as e:  # noqa: BLE001
+            log.warning("C-ABI communicator not created (%s)", e)
+            ok = False
+        if not agree(ok):
+            return fallback(ctx, abort=True)
+        # 3. one all-reduce against torch.distributed's.  The verdict on the ENQUEUE is exchanged before anything
+        #    waits for the context's stream: a rank that could not enqueue leaves its peers' kernels spinning, and
+        #    those are aborted, not waited for.
+        if world > 1:
+            x = (torch.arange(4096, dtype=torch.float32, device=device) % 61) * (rank + 1)
+            want = x.clone()
+            dist.all_reduce(want, group=pg)
+            try:
+                ctx.after_current()
+                ctx.all_reduce(x)
+            except Exception as e:  # noqa: BLE001
+                log.warning("C-ABI all-reduce not enqueued (%s)", e)
+                ok = False
+            if not agree(ok):
+                return fallback(ctx, abort=True)
+            ctx.before_current()
+            if not agree(bool(torch.equal(x, want))):
+                return fallback(ctx)
         return ctx
 
     def _to_wire(self, lo, hi):
@@ -292,6 +344,12 @@ class GradSync:
         self._pending.clear()
         self.launched.clear()
 
+    def close(self, abort: bool = False):
+        """Give the C-ABI communicator (and its stream) back; `abort`: without waiting for its stream."""
+        if self.capi is not None:
+            self.capi.close(abort=abort)
+            self.capi = None
+
     def scale_(self):
         """DDP-mean semantics for host-side consumers: g /= world."""
         if self.world > 1:
@@ -312,7 +370,8 @@ class DataParallelTrainer:
 
     def __init__(self, engine, learning_rate=1e-4, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.0,
                  max_grad_norm=1.0, warmup_steps=1000, max_steps=100_000, grad_accum=1,
-                 process_group=None, overlap=True, compress_grads=False, overlap_optimizer=True, zero_stage=0):
+                 process_group=None, overlap=True, compress_grads=False, overlap_optimizer=True, zero_stage=0,
+                 accum_loss: str = "mean"):
         """zero_stage > 0 (N > 1): the reference's production launch mode (`accelerate launch --use-deepspeed
         --zero-stage 2`, R/makefile:79-84,94-99,109-114) in this engine's terms - the weight-matrix part of every layer
         bucket (> 99 % of the parameters) is REDUCE-SCATTERED instead of all-reduced, each rank keeps AdamW moments for
@@ -328,6 +387,15 @@ class DataParallelTrainer:
         self.max_grad_norm = max_grad_norm
         self.warmup_steps, self.max_steps = warmup_steps, max_steps
         self.grad_accum = grad_accum
+        # How the micro-batches of one optimiser step combine.  "mean": loss and gradients of each micro-batch scaled by
+        # 1 / grad_accum (Trainer.training_step for a model WITHOUT **kwargs in its forward, $TF/trainer.py:1952-1954).
+        # "sum": no scaling - what transformers >= 4.46 (the reference pins 5.5.0) does for Wav2Vec2ForCTC and
+        # WhisperForConditionalGeneration, whose forwards take **kwargs (`model_accepts_loss_kwargs`) while their own
+        # losses ignore `num_items_in_batch`: the logged loss is the SUM over the micro-batches and so is the gradient
+        # the clip sees (tools/gen_goldens.py trainer_traj pins it; CoralTrainer's default).
+        if accum_loss not in ("mean", "sum"):
+            raise ValueError(f"accum_loss must be 'mean' or 'sum', not {accum_loss!r}")
+        self.accum_loss = accum_loss
         self.opt_step = 0
         st = engine.store
         if hasattr(engine, "trainable_range"):
@@ -351,10 +419,18 @@ class DataParallelTrainer:
             import logging
 
             logging.getLogger(__package__).warning("sharded optimiser: the collective self-check failed; using replicated DDP")
+            self.sync.close(abort=True)  # (a rank that could not enqueue leaves its peers' kernels spinning)
             self.sync = GradSync(st.g32, st.buckets, process_group, compress=compress_grads)
             self.zero = False
         self.world = self.sync.world
         self.dist = self.sync.active  # gradients are exchanged (world > 1, or a forced one-rank group)
+        if self.dist and st.p32.is_cuda:
+            # A collective's kernel holds CUs for most of the backward: the persistent GEMM launches hand out every tile
+            # dynamically (a workgroup that only starts once others have exited finds nothing left and exits) and, with
+            # CA_COMPUTE_CUS=<n>, size themselves and the tile-shape rule to n CUs (include/coral_amd.h:
+            # ca_gemm_set_compute_cus; measured beside an emulated ring kernel: tools/r05_hog_gemm.py)
+            ncu = torch.cuda.get_device_properties(st.device).multi_processor_count
+            ops.lib().ca_gemm_set_compute_cus(int(os.environ.get("CA_COMPUTE_CUS", ncu)))
         self.overlap = overlap and self.dist
         # AdamW moments.  Replicated: the parameters' own offsets.  Sharded: a compact buffer holding, bucket by bucket,
         # the replicated part [lo, mlo) and this rank's slice of the sharded part - 1/N of the state.
@@ -412,8 +488,8 @@ class DataParallelTrainer:
     # ---- one optimiser step ----------------------------------------------------------------------
     def train_step(self, micro_batches) -> float | torch.Tensor:
         """micro_batches: list (len = grad_accum) of dicts with input_values / attention_mask /
-        labels (+ optional mask_time / mask_feature / layer_keep).  Returns the summed loss
-        tensor (device) of this rank, scaled as Trainer does (1/grad_accum)."""
+        labels (+ optional mask_time / mask_feature / layer_keep).  Returns the loss tensor (device) of this rank
+        over the micro-batches, combined as `accum_loss` says (see __init__)."""
         eng = self.engine
         self.model.train()
         total = None
@@ -443,9 +519,10 @@ class DataParallelTrainer:
             elif not self.dist and last and self.overlap_optimizer and self.early_fraction > 0:
                 self._done, self._early_lo = {}, None
                 hook = self._early_norm
-            eng.backward(loss_scale=1.0 / n, overwrite_matrices=(i == 0), bucket_done=hook)
+            scale = 1.0 / n if self.accum_loss == "mean" else 1.0
+            eng.backward(loss_scale=scale, overwrite_matrices=(i == 0), bucket_done=hook)
             loss = out.loss.detach()  # (the autograd route of coral_amd/autograd.py is not used here)
-            total = loss / n if total is None else total + loss / n
+            total = loss * scale if total is None else total + loss * scale
         if self.dist and not self.overlap:
             self.sync.start_all()
         self.sync.finish()
@@ -527,11 +604,21 @@ class DataParallelTrainer:
             torch.cuda.current_stream().wait_event(self.opt_done)
             self.opt_done = None
 
+    def close(self):
+        """Teardown: wait for the optimiser, give the C-ABI communicator and its stream back (one RCCL communicator per
+        trainer otherwise stays behind - bench workloads and tests build several per process)."""
+        self.finish()
+        if torch.cuda.is_available() and self.engine.store.p32.is_cuda:
+            torch.cuda.synchronize()
+        self._ag_comm = None
+        self.sync.close()
+
     def optimizer_step(self):
         eng, st = self.engine, self.engine.store
         lo, hi = self.train_range
         n = hi - lo
         lr = cosine_lr(self.opt_step, self.lr, self.warmup_steps, self.max_steps)
+        self.last_lr = lr  # the rate THIS update uses (what Trainer logs as `learning_rate` for the step)
         self.opt_step += 1
         plan = None if self.dist else self._norm_plan()
         if self.zero and not self._norms_ready:  # (no per-bucket hooks ran: take the sharded norms here)
@@ -652,47 +739,62 @@ class DataParallelTrainer:
         reduce-scatter with the output slice inside the input buffer (at input + rank x count) and all-gather with the
         input slice inside the output buffer, against their defining sums - through the C ABI's ca_* collectives when
         `capi` (a CommContext) is given, else torch.distributed's."""
-        world, rank = torch.distributed.get_world_size(pg), torch.distributed.get_rank(pg)
+        dist = torch.distributed
+        world, rank = dist.get_world_size(pg), dist.get_rank(pg)
         n = 4096
         base = torch.arange(world * n, dtype=torch.float32, device=device) % 257
         x = base * (rank + 1)
         want = base * (world * (world + 1) // 2)
-        ok = True
-        if capi is not None or torch.distributed.get_backend(pg) == "nccl":
-            # each collective under its own guard: a rank whose call raises records a failure and still joins the flag
-            # reduction below, so the other ranks fall back with it instead of waiting for it
-            try:
-                buf = x.clone()
-                if capi is not None:
-                    capi.after_current()
-                    capi.reduce_scatter(buf)
-                    capi.before_current()
-                else:
-                    torch.distributed.reduce_scatter_tensor(buf[rank * n:(rank + 1) * n], buf, group=pg)
-                ok = torch.equal(buf[rank * n:(rank + 1) * n], want[rank * n:(rank + 1) * n])
-            except Exception:  # noqa: BLE001
-                ok = False
-            try:
-                g = torch.zeros(world * n, dtype=torch.bfloat16, device=device)
-                g[rank * n:(rank + 1) * n] = (base[rank * n:(rank + 1) * n]).to(torch.bfloat16)
-                if capi is not None:
-                    capi.after_current()
-                    capi.all_gather(g)
-                    capi.before_current()
-                else:
-                    torch.distributed.all_gather_into_tensor(g, g[rank * n:(rank + 1) * n], group=pg)
-                ok = ok and torch.equal(g, base.to(torch.bfloat16))
-            except Exception:  # noqa: BLE001
-                ok = False
-        try:
-            bad = torch.tensor([0.0 if ok else 1.0], device=device)  # failures, summed over the ranks
-            if capi is not None:
-                capi.after_current()
-                capi.all_reduce(bad)
+
+        def agree(ok: bool) -> bool:
+            """Every rank's verdict, over torch.distributed's own communicator (never the context under test)."""
+            flag = torch.tensor([1.0 if ok else 0.0], device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=pg)
+            return bool(flag.item() > 0.5)
+
+        if capi is None and dist.get_backend(pg) != "nccl":
+            return True  # (gloo: GradSync cuts the slices out of all-reduces, nothing in place to check)
+        if capi is not None:
+            # C ABI: enqueue under a guard, agree that EVERY rank enqueued, only then wait for the context's stream (a
+            # rank whose ca_* call raised has enqueued nothing: its peers' kernels would spin, and so would a verdict
+            # exchanged behind them)
+            for which in ("reduce_scatter", "all_gather"):
+                ok = True
+                try:
+                    if which == "reduce_scatter":
+                        buf = x.clone()
+                        capi.after_current()
+                        capi.reduce_scatter(buf)
+                    else:
+                        buf = torch.zeros(world * n, dtype=torch.bfloat16, device=device)
+                        buf[rank * n:(rank + 1) * n] = (base[rank * n:(rank + 1) * n]).to(torch.bfloat16)
+                        capi.after_current()
+                        capi.all_gather(buf)
+                except Exception:  # noqa: BLE001
+                    ok = False
+                if not agree(ok):
+                    return False  # (the caller rebuilds GradSync without the sharded path; the context is left to abort)
                 capi.before_current()
-            else:
-                torch.distributed.all_reduce(bad, op=torch.distributed.ReduceOp.SUM, group=pg)
-            return bool(bad.item() < 0.5)
+                if which == "reduce_scatter":
+                    good = torch.equal(buf[rank * n:(rank + 1) * n], want[rank * n:(rank + 1) * n])
+                else:
+                    good = torch.equal(buf, base.to(torch.bfloat16))
+                if not agree(bool(good)):
+                    return False
+            return True
+        ok = True
+        try:
+            buf = x.clone()
+            dist.reduce_scatter_tensor(buf[rank * n:(rank + 1) * n], buf, group=pg)
+            ok = torch.equal(buf[rank * n:(rank + 1) * n], want[rank * n:(rank + 1) * n])
+            g = torch.zeros(world * n, dtype=torch.bfloat16, device=device)
+            g[rank * n:(rank + 1) * n] = (base[rank * n:(rank + 1) * n]).to(torch.bfloat16)
+            dist.all_gather_into_tensor(g, g[rank * n:(rank + 1) * n], group=pg)
+            ok = ok and torch.equal(g, base.to(torch.bfloat16))
+        except Exception:  # noqa: BLE001
+            ok = False
+        try:
+            return agree(bool(ok))
         except Exception:  # noqa: BLE001
             return False
 

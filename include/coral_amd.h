@@ -207,6 +207,17 @@ int ca_prof_end(double* ms, int64_t* count, double* flops);
  * normally take a specialised, predicate-free form that must give the same bits). */
 int ca_gemm_force_kernel(int which);
 int ca_gemm_debug_general_epilogue(int on);
+/* ca_debug_cu_hog: `blocks` idle workgroups (`threads` threads, `lds_bytes` of LDS each) resident for `ms` milliseconds on
+ * `stream` - a stand-in for the ring kernel of a collective that holds CUs during the backward of an N > 1 run
+ * (accelerate/accelerator.py:1892,2053), so that its effect on the GEMM launches can be measured on one GPU. */
+int ca_debug_cu_hog(int32_t blocks, int32_t threads, int32_t lds_bytes, double ms, void* stream);
+
+/* CUs the compute kernels may count on: 0 (default) = the whole chip.  With n > 0 - what the trainer of an N > 1 run
+ * sets, because the gradient exchange's kernel occupies CUs for most of the backward - persistent GEMM launches use at
+ * most n workgroups (rounded down to a multiple of 8) and hand out EVERY tile through their counters (a workgroup that
+ * only starts when others have exited finds the counter exhausted and exits, instead of running a statically assigned
+ * tile at the end of the launch), and the tile-shape choice counts rounds on n CUs.  Results never depend on it. */
+int ca_gemm_set_compute_cus(int n);
 
 /* ------------------------------------------------------------------------------------
  * LayerNorm over the channel axis.  $TF/models/wav2vec2/modeling_wav2vec2.py:429-434,
@@ -559,7 +570,9 @@ int ca_embed_tokens_bwd(const void* dy, const int32_t* ids, const int32_t* pos_i
 typedef struct CaComm CaComm;
 int ca_comm_unique_id(void* id128_h);
 int ca_comm_init(CaComm** ctx, const void* id128_h, int32_t rank, int32_t world);
-int ca_comm_destroy(CaComm* ctx);
+int ca_comm_destroy(CaComm* ctx); /* waits for the context's stream, then frees communicator, stream and context */
+int ca_comm_abort(CaComm* ctx);   /* the same WITHOUT waiting (ncclCommAbort): for a context whose peers never joined a
+                                   * collective - the rendezvous fallback of the host side (coral_amd/trainer.py) */
 void* ca_comm_stream(CaComm* ctx); /* the context's hipStream_t */
 int ca_comm_rank(CaComm* ctx);
 int ca_comm_world(CaComm* ctx);

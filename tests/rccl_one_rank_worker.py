@@ -40,8 +40,11 @@ def run(forced, wire, steps, zero=0, clip=1e9):
     tr.finish()
     tr.consolidate()
     torch.cuda.synchronize()
-    return dict(losses=losses, norms=norms, p32=eng.store.p32.cpu(), p16=eng.store.p16.float().cpu(),
-                launched=list(tr.sync.buckets))
+    out = dict(losses=losses, norms=norms, p32=eng.store.p32.cpu(), p16=eng.store.p16.float().cpu(),
+               launched=list(tr.sync.buckets))
+    tr.close()  # the communicator and its stream go back (eight trainers are built in this process)
+    assert tr.sync.capi is None
+    return out
 
 
 def main():

@@ -147,6 +147,88 @@ def test_xlsr2b_one_utterance_forward_backward_against_the_oracle():
     torch.cuda.empty_cache()
 
 
+def test_xlsr2b_bench_batch_ctc_loss_against_the_oracle():
+    """configs[1] on configs[1]'s OWN batch: the 8 x 10 s synthetic batch `bench.py` times (same generator, same labels),
+    forward only, against the fp32 oracle on the host cores: the BATCH CTC loss - what the step back-propagates - within
+    the north star's 1e-3; per utterance within the 3e-3 the bf16 weights alone account for."""
+    import sys
+    from pathlib import Path
+
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+    import bench
+    from coral_amd.wav2vec2 import CORAL_W2V2_SHAPES, Wav2Vec2CTCEngine, Wav2Vec2Shape
+    from oracle import wav2vec2_ref as ref
+
+    cfg = ref.W2V2Config(**ref.CORAL_SHAPES["wav2vec2-large"])
+    P = ref.synth_params(cfg)
+    batch, lens = bench.synth_batch(8, 10.0, 0, DEV)
+    eng = Wav2Vec2CTCEngine(Wav2Vec2Shape(**CORAL_W2V2_SHAPES["wav2vec2-large"]), DEV)
+    eng.load_state_dict(P)
+    out = eng(batch["input_values"], batch["attention_mask"], batch["labels"])
+    torch.cuda.synchronize()
+    nll = out["nll"].float().cpu()
+    loss = float(out.loss)
+    logits = out.logits.float().cpu()
+    del eng
+    torch.cuda.empty_cache()
+    t1 = time.time()
+    iv, am, lab = batch["input_values"].float().cpu(), batch["attention_mask"].long().cpu(), batch["labels"].long().cpu()
+    nll_ref, logit_rows = [], []
+    with torch.no_grad():
+        for b0 in range(0, 8, 2):  # (two utterances at a time: bounded host memory)
+            _, lg, n_ = ref.forward_loss(iv[b0:b0 + 2], am[b0:b0 + 2], lab[b0:b0 + 2], P, cfg)
+            nll_ref.append(n_)
+            logit_rows.append(lg)
+    nll_ref = torch.cat(nll_ref)
+    logits_ref = torch.cat(logit_rows)
+    t_ref = time.time() - t1
+    per = [abs(float(a) - float(b)) / float(b) for a, b in zip(nll, nll_ref)]
+    rel = abs(loss - float(nll_ref.sum())) / float(nll_ref.sum())
+    err = float((logits - logits_ref).abs().max())
+    print(f"\nXLS-R-2B on the bench batch (8 x 10 s): batch CTC loss {loss:.3f} vs {float(nll_ref.sum()):.3f} (rel {rel:.2e}); "
+          "per utterance " + ", ".join(f"{x:.2e}" for x in per) + f"; logits max-abs err {err:.4f}, cosine "
+          f"{_cos(logits, logits_ref):.6f}; oracle forward {t_ref:.0f} s")
+    assert rel <= 1e-3, rel
+    assert max(per) <= 3e-3, per
+    assert err <= 8e-2 and _cos(logits, logits_ref) >= 0.999
+
+
+def test_xlsr1b_batch_of_four_ctc_loss_against_the_oracle():
+    """XLS-R-1B (CoRal's wav2vec2-medium) on a batch of four ragged utterances, forward only: the batch CTC loss within
+    1e-3 of the oracle's (the single-utterance test below keeps 2e-3 for one utterance)."""
+    from coral_amd.wav2vec2 import CORAL_W2V2_SHAPES, Wav2Vec2CTCEngine, Wav2Vec2Shape
+    from oracle import wav2vec2_ref as ref
+
+    cfg = ref.W2V2Config(**ref.CORAL_SHAPES["wav2vec2-medium"])
+    P = ref.synth_params(cfg)
+    g = torch.Generator().manual_seed(1281)
+    lens = [160_000, 124_800, 96_000, 143_360]
+    waves = []
+    for n in lens:
+        w_ = (0.1 * torch.randn(n, generator=g)).clamp(-1, 1)
+        waves.append((w_ / w_.abs().max()).numpy())
+    iv, am = ref.zero_mean_unit_var_norm(waves)
+    iv, am = torch.from_numpy(iv), torch.from_numpy(am).long()
+    lab = torch.full((4, 100), -100, dtype=torch.int64)
+    for b, L in enumerate((100, 72, 51, 88)):
+        lab[b, :L] = torch.randint(0, 42, (L,), generator=g)
+    eng = Wav2Vec2CTCEngine(Wav2Vec2Shape(**CORAL_W2V2_SHAPES["wav2vec2-medium"]), DEV)
+    eng.load_state_dict(P)
+    out = eng(iv, am, lab)
+    torch.cuda.synchronize()
+    nll, loss = out["nll"].float().cpu(), float(out.loss)
+    del eng
+    torch.cuda.empty_cache()
+    with torch.no_grad():
+        loss_ref, _, nll_ref = ref.forward_loss(iv, am, lab, P, cfg)
+    per = [abs(float(a) - float(b)) / float(b) for a, b in zip(nll, nll_ref)]
+    rel = abs(loss - float(loss_ref)) / float(loss_ref)
+    print(f"\nXLS-R-1B, 4 ragged utterances: batch CTC loss {loss:.3f} vs {float(loss_ref):.3f} (rel {rel:.2e}); per utterance "
+          + ", ".join(f"{x:.2e}" for x in per))
+    assert rel <= 1e-3, rel
+    assert max(per) <= 3e-3, per
+
+
 def test_xlsr1b_one_utterance_forward_backward_against_the_oracle():
     """CoRal's `model=wav2vec2-medium` (XLS-R-1B: 48 layers, d 1280, head_dim 80 - the third head size of the attention
     kernels, 16 heads x 80 padded to 128 lanes) at full depth on one ragged 7 s utterance: logits, CTC loss, greedy ids

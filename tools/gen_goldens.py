@@ -11,7 +11,7 @@ Weights: no checkpoints exist offline, so every parameter is overwritten with
 oracle.wav2vec2_ref.synth_params (name-keyed seeded values) — the tests regenerate the same
 weights instead of storing them.
 
-usage: python tools/gen_goldens.py [w2v2_tiny ctc featext tokenizer w2v2_cfg1 logmel whisper_tiny whisper_mid hf_ckpt]
+usage: python tools/gen_goldens.py [w2v2_tiny ctc featext tokenizer w2v2_cfg1 logmel whisper_tiny whisper_mid hf_ckpt trainer_traj]
 """
 
 from __future__ import annotations
@@ -553,6 +553,145 @@ def gen_hf_ckpt():
                         labels=wl.numpy(), feats_seed=np.array(5))
     for dd in ("hf_ckpt_w2v2", "hf_ckpt_w2v2_pretrain", "hf_ckpt_whisper"):
         print(dd, {f.name: f.stat().st_size for f in (GOLD / dd).iterdir()})
+
+
+def _trajectory(model, examples, collate, B, accum, steps, lr, warmup, watch):
+    """Drive `transformers.Trainer` - the reference's own loop (R/src/coral/finetune.py:60-79; the optimiser, schedule
+    and clipping of R/src/coral/wav2vec2.py:156-251 / whisper.py) - over a fixed example stream on the CPU in fp32 and
+    return what it logged per optimiser step plus the watched parameters afterwards."""
+    from torch.utils.data import IterableDataset
+    from transformers import Trainer, TrainerCallback, TrainingArguments
+
+    class Stream(IterableDataset):  # (an IterableDataset, as the reference streams: Trainer does not shuffle it)
+        def __iter__(self):
+            return iter(examples)
+
+    logs = []
+
+    class Rec(TrainerCallback):
+        def on_log(self, args, state, control, logs=None, **kw):
+            if logs and "loss" in logs:
+                logs_ = dict(logs)
+                logs_["step"] = state.global_step
+                logs.update({})
+                rec.append(logs_)
+
+    rec = logs
+    with tempfile.TemporaryDirectory() as td:
+        args = TrainingArguments(
+            output_dir=td, per_device_train_batch_size=B, gradient_accumulation_steps=accum, max_steps=steps,
+            learning_rate=lr, warmup_steps=warmup, lr_scheduler_type="cosine", adam_beta1=0.9, adam_beta2=0.98,
+            adam_epsilon=1e-8, weight_decay=0.0, max_grad_norm=1.0, logging_steps=1, logging_first_step=True,
+            save_strategy="no", report_to=[], use_cpu=True, seed=4242, dataloader_num_workers=0,
+            remove_unused_columns=False, disable_tqdm=True, logging_nan_inf_filter=False)
+        tr = Trainer(model=model, args=args, data_collator=collate, train_dataset=Stream(), callbacks=[Rec()])
+        accepts = bool(tr.model_accepts_loss_kwargs)
+        tr.train()
+    sd = dict(model.named_parameters())
+    out = {"loss": np.array([r["loss"] for r in rec], dtype=np.float64),
+           "grad_norm": np.array([r["grad_norm"] for r in rec], dtype=np.float64),
+           "lr_logged": np.array([r["learning_rate"] for r in rec], dtype=np.float64),
+           "step": np.array([r["step"] for r in rec]), "model_accepts_loss_kwargs": np.array(accepts)}
+    for name in watch:
+        out["final:" + name] = sd[name].detach().numpy().copy()
+    return out
+
+
+def gen_trainer_traj():
+    """Per-step loss / gradient norm / learning rate and the final head weights of SIX optimiser steps of
+    `transformers.Trainer` (gradient_accumulation_steps 2, max_grad_norm 1.0, cosine schedule with 2 warm-up steps,
+    AdamW 0.9 / 0.98, dropout 0, fp32 CPU) on the tiny wav2vec2 and the tiny Whisper: the pin of SURVEY.md row A11 -
+    accumulation scaling, clipping, warm-up and AdamW TOGETHER ($TF/trainer.py:1892-1963,1778-1796)."""
+    from transformers import WhisperConfig, WhisperForConditionalGeneration
+
+    from oracle import whisper_ref as wref
+
+    out = {}
+    # ---- wav2vec2 (CTC) -------------------------------------------------------------------------------------
+    cfg = ref.W2V2Config(hidden_size=128, num_hidden_layers=2, num_attention_heads=4, intermediate_size=256)
+    B, accum, steps = 3, 2, 6
+    g = torch.Generator().manual_seed(1234)
+    lens = [int(x) for x in torch.randint(2400, 4001, (B * accum * steps,), generator=g)]
+    lab_lens = [int(x) for x in torch.randint(2, 6, (B * accum * steps,), generator=g)]
+    waves, labels = synth_batch(len(lens), 4000, lens, lab_lens, seed=77)
+    examples = []
+    for w, lab, L in zip(waves, labels, lab_lens):
+        iv, _ = ref.zero_mean_unit_var_norm([w])
+        examples.append({"input_values": iv[0].astype(np.float32), "labels": [int(t) for t in lab[:L]]})
+
+    def collate_ctc(feats):  # DataCollatorCTCWithPadding, padding="longest" (R/src/coral/data_collators.py:62-95)
+        n = max(len(f["input_values"]) for f in feats)
+        iv = torch.zeros(len(feats), n)
+        am = torch.zeros(len(feats), n, dtype=torch.long)
+        Lm = max(len(f["labels"]) for f in feats)
+        lab = torch.full((len(feats), Lm), -100, dtype=torch.long)
+        for i, f in enumerate(feats):
+            k = len(f["input_values"])
+            iv[i, :k] = torch.from_numpy(f["input_values"])
+            am[i, :k] = 1
+            lab[i, :len(f["labels"])] = torch.tensor(f["labels"])
+        return {"input_values": iv, "attention_mask": am, "labels": lab}
+
+    model = hf_w2v2(cfg)
+    watch = ["lm_head.weight", "lm_head.bias", "wav2vec2.encoder.layers.1.feed_forward.output_dense.weight",
+             "wav2vec2.feature_extractor.conv_layers.0.conv.weight",
+             "wav2vec2.encoder.pos_conv_embed.conv.parametrizations.weight.original0"]
+    t = _trajectory(model, examples, collate_ctc, B, accum, steps, 2e-3, 2, watch)
+    out.update({"w2v2:" + k: v for k, v in t.items()})
+    out["w2v2:lens"] = np.array(lens)
+    out["w2v2:lab_lens"] = np.array(lab_lens)
+    out["w2v2:labels"] = labels.numpy()
+    out["w2v2:hparams"] = np.array([B, accum, steps, 2e-3, 2])
+    print("trainer_traj w2v2: accepts_loss_kwargs", t["model_accepts_loss_kwargs"], "loss", t["loss"], "gnorm", t["grad_norm"],
+          "lr", t["lr_logged"])
+    # ---- Whisper (teacher-forced CE) ------------------------------------------------------------------------
+    c = wref.WhisperConfig(d_model=64, encoder_layers=2, decoder_layers=2, encoder_attention_heads=4,
+                           decoder_attention_heads=4, encoder_ffn_dim=128, decoder_ffn_dim=128, num_mel_bins=80,
+                           vocab_size=200, max_target_positions=64, pad_token_id=150, decoder_start_token_id=151,
+                           eos_token_id=150)
+    hc = WhisperConfig(d_model=c.d_model, encoder_layers=2, decoder_layers=2, encoder_attention_heads=4,
+                       decoder_attention_heads=4, encoder_ffn_dim=128, decoder_ffn_dim=128, num_mel_bins=80,
+                       vocab_size=200, max_source_positions=1500, max_target_positions=64, pad_token_id=150,
+                       bos_token_id=150, eos_token_id=150, decoder_start_token_id=151, dropout=0.0,
+                       attention_dropout=0.0, activation_dropout=0.0, encoder_layerdrop=0.0, decoder_layerdrop=0.0,
+                       apply_spec_augment=False, attn_implementation="eager", suppress_tokens=[],
+                       begin_suppress_tokens=[], use_cache=False)
+    wm = WhisperForConditionalGeneration(hc)
+    P = wref.synth_params(c)
+    sd = wm.state_dict()
+    with torch.no_grad():
+        for k, v in P.items():
+            sd[k].copy_(v)
+    wm.train()
+    Bw = 2
+    nw = Bw * accum * steps
+    g = torch.Generator().manual_seed(4321)
+    feats = (torch.randn(nw, 80, 3000, generator=g) * 0.5).to(torch.float16)  # (fp16 keeps the fixture small; exact in fp32)
+    wl = [int(x) for x in torch.randint(4, 10, (nw,), generator=g)]
+    wlab = torch.full((nw, 9), -100, dtype=torch.long)
+    for i, L in enumerate(wl):
+        wlab[i, :L] = torch.randint(0, 150, (L,), generator=g)
+    wex = [{"input_features": feats[i].float().numpy(), "labels": [int(t) for t in wlab[i, :wl[i]]]} for i in range(nw)]
+
+    def collate_s2s(fs):  # DataCollatorSpeechSeq2SeqWithPadding (R/src/coral/data_collators.py:145-187), no BOS to cut
+        Lm = max(len(f["labels"]) for f in fs)
+        lab = torch.full((len(fs), Lm), -100, dtype=torch.long)
+        for i, f in enumerate(fs):
+            lab[i, :len(f["labels"])] = torch.tensor(f["labels"])
+        return {"input_features": torch.stack([torch.from_numpy(f["input_features"]) for f in fs]), "labels": lab}
+
+    wwatch = ["model.decoder.embed_tokens.weight", "model.decoder.layers.1.fc1.weight", "model.encoder.conv1.weight",
+              "model.decoder.embed_positions.weight"]
+    t = _trajectory(wm, wex, collate_s2s, Bw, accum, steps, 2e-3, 2, wwatch)
+    out.update({"whisper:" + k: v for k, v in t.items()})
+    out["whisper:feats_seed"] = np.array(4321)
+    out["whisper:lab_lens"] = np.array(wl)
+    out["whisper:labels"] = wlab.numpy()
+    out["whisper:hparams"] = np.array([Bw, accum, steps, 2e-3, 2])
+    print("trainer_traj whisper: accepts_loss_kwargs", t["model_accepts_loss_kwargs"], "loss", t["loss"], "gnorm", t["grad_norm"],
+          "lr", t["lr_logged"])
+    np.savez_compressed(GOLD / "trainer_traj.npz", **out)
+    print("trainer_traj.npz", (GOLD / "trainer_traj.npz").stat().st_size, "bytes")
 
 
 if __name__ == "__main__":
