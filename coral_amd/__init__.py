@@ -12,6 +12,17 @@ import os as _os
 # runtime reads the variable when it initialises (the first HIP call of the process), so this has to run before any
 # torch.cuda use: import coral_amd first, or export it in the job's environment.  An explicit
 # setting in the environment wins.
-_os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+if "HIP_FORCE_DEV_KERNARG" not in _os.environ:
+    _os.environ["HIP_FORCE_DEV_KERNARG"] = "1"
+    import sys as _sys
+
+    _torch = _sys.modules.get("torch")
+    if _torch is not None and getattr(_torch, "cuda", None) is not None and _torch.cuda.is_initialized():
+        # too late for this process: the runtime read its environment when the caller first touched torch.cuda
+        import warnings as _warnings
+
+        _warnings.warn("coral_amd was imported after torch.cuda was initialised and HIP_FORCE_DEV_KERNARG was not in the "
+                       "environment: kernel arguments stay in host memory (about 2 ms per XLS-R-2B step slower).  Import "
+                       "coral_amd first, or export HIP_FORCE_DEV_KERNARG=1 (INTEGRATION.md).", RuntimeWarning, stacklevel=2)
 
 __version__ = "0.1.0"

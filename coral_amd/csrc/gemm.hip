@@ -1891,9 +1891,16 @@ __global__ __launch_bounds__(512) void ca_gemm_kernel_l(const CaGemmDesc d) {
 // the weight fetch.
 #define SKINNY_LN_PAD 32  // bf16 elements between LDS rows beyond K: 64 B, lanes r and r + 1 then sit 16 banks apart
 // NCH: 64-lane rounds of 8-element chunks a row takes (K <= 512 NCH), 0 = no LayerNorm prologue
-template <int MB, int NCH = 0>
+// Round 5: 33 .. 128 rows (an evaluation run decodes more clips per step than 32 - R/config/evaluation.yaml:20,
+// R/src/coral/evaluate.py:56-60) run the SAME 32-row kernel on a two-dimensional grid: blockIdx.y picks the block of 32
+// rows.  A workgroup then streams 64 KB of A per 1024 k beside its 32 KB of weights, as at 32 rows (four row blocks in one
+// workgroup measured 17.7 us per launch at 64 rows against 8 at 32: the A rows, re-read by every workgroup, were 4/5 of
+// its bytes); the weight fragment is read by the 2 - 4 workgroups of a column block, once from HBM and then from L2.
+template <int MB, int NCH = 0, int U = 8>
 __global__ __launch_bounds__(256) void ca_gemm_skinny_kernel(const CaGemmDesc d) {
   constexpr bool LN = NCH > 0;
+  static_assert(!LN || U == 8, "the LayerNorm prologue keeps eight weight fragments in flight");
+  const int mrow0 = (int)blockIdx.y * 16 * MB;  // first row of this workgroup's row block
   constexpr int NC = LN ? NCH : 1;
   extern __shared__ __attribute__((aligned(16))) char sk_smem[];
   float(*part)[MB * 16 * 16] = (float(*)[MB * 16 * 16]) sk_smem;
@@ -1910,7 +1917,7 @@ __global__ __launch_bounds__(256) void ca_gemm_skinny_kernel(const CaGemmDesc d)
   const __bf16* ap[MB];
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
-    const int m = 16 * mb + r;
+    const int m = mrow0 + 16 * mb + r;
     ap[mb] = A + (int64_t)(m < d.M ? m : d.M - 1) * d.lda + 8 * g;
   }
   const int ksteps = (d.K + 31) / 32;
@@ -1933,7 +1940,7 @@ __global__ __launch_bounds__(256) void ca_gemm_skinny_kernel(const CaGemmDesc d)
   const bool hi = d.c_split_n > 0 && n0 >= d.c_split_n;
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
-    const int m = 16 * mb + r;
+    const int m = mrow0 + 16 * mb + r;
     crow[mb] = m;
 #pragma unroll
     for (int e = 0; e < 4; ++e) e_res[mb][e] = 0.f;
@@ -1967,7 +1974,7 @@ __global__ __launch_bounds__(256) void ca_gemm_skinny_kernel(const CaGemmDesc d)
     u16x8_t raw[RW][NC];
 #pragma unroll
     for (int i = 0; i < RW; ++i) {
-      const int row = wave + 4 * i;
+      const int row = mrow0 + wave + 4 * i;
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
         const int ch = lane + c * 64;
@@ -1988,7 +1995,8 @@ __global__ __launch_bounds__(256) void ca_gemm_skinny_kernel(const CaGemmDesc d)
     }
 #pragma unroll
     for (int i = 0; i < RW; ++i) {
-      const int row = wave + 4 * i;
+      const int lrow = wave + 4 * i;  // row of the LDS image; global row mrow0 + lrow
+      const int row = mrow0 + lrow;
       if (row >= d.M) break;  // (wave-uniform)
       float sx = 0.f;
 #pragma unroll
@@ -2020,32 +2028,32 @@ __global__ __launch_bounds__(256) void ca_gemm_skinny_kernel(const CaGemmDesc d)
           for (int e = 0; e < 8; ++e)
             o8[e] = f2bf(ln_apply(bf2f(raw[i][c][e]), mean, rstd, e < 4 ? gq[c][0][e] : gq[c][1][e - 4],
                                   e < 4 ? bq[c][0][e] : bq[c][1][e - 4]));
-          *(u16x8_t*)(xs + (int64_t)row * xpitch + ch * 8) = o8;
+          *(u16x8_t*)(xs + (int64_t)lrow * xpitch + ch * 8) = o8;
         }
       }
     }
     __syncthreads();
   }
-  for (int ks = ks0; ks < ks1; ks += 8) {
-    bf16x8_t wf[8], af[MB][8];
+  for (int ks = ks0; ks < ks1; ks += U) {
+    bf16x8_t wf[U], af[MB][U];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < U; ++u) {
       const int k = (ks + u) * 32 + 8 * g;
       const bool ok = ks + u < ks1 && k < d.K;  // K is a multiple of 8 (lda/ldb rule), so a chunk is all-or-nothing
       if constexpr (LN) {
         wf[u] = ks == ks0 ? wf0[u] : (ok ? *(const bf16x8_t*)(wp + (int64_t)(ks + u) * 32) : zero);
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
-          af[mb][u] = (ok && 16 * mb + r < d.M) ? *(const bf16x8_t*)(xs + (int64_t)(16 * mb + r) * xpitch + k) : zero;
+          af[mb][u] = (ok && mrow0 + 16 * mb + r < d.M) ? *(const bf16x8_t*)(xs + (int64_t)(16 * mb + r) * xpitch + k) : zero;
       } else {
         wf[u] = ok ? *(const bf16x8_t*)(wp + (int64_t)(ks + u) * 32) : zero;
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
-          af[mb][u] = (ok && 16 * mb + r < d.M) ? *(const bf16x8_t*)(ap[mb] + (int64_t)(ks + u) * 32) : zero;
+          af[mb][u] = (ok && mrow0 + 16 * mb + r < d.M) ? *(const bf16x8_t*)(ap[mb] + (int64_t)(ks + u) * 32) : zero;
       }
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u)
+    for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u], af[mb][u], acc[mb], 0, 0, 0);
   }
@@ -2058,7 +2066,7 @@ __global__ __launch_bounds__(256) void ca_gemm_skinny_kernel(const CaGemmDesc d)
   if (!wave0) return;
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
-    if (16 * mb + r >= d.M) continue;
+    if (mrow0 + 16 * mb + r >= d.M) continue;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int n = n0 + 4 * g + e;
@@ -2644,16 +2652,21 @@ static int ca_gemm_launch(const CaGemmDesc* desc, void* stream) {
   CA_CHECK_ARG(d.a_layout == CA_KMAJOR || d.a_layout == CA_MNMAJOR, "ca_gemm_bf16: bad a_layout");
   CA_CHECK_ARG(d.b_layout == CA_KMAJOR || d.b_layout == CA_MNMAJOR, "ca_gemm_bf16: bad b_layout");
   // Skinny M (greedy decoding: one token per clip): weight streaming without LDS staging.
-  if (g_force_kernel == 0 && d.M <= 32 && d.a_layout == CA_KMAJOR && d.b_layout == CA_KMAJOR && d.batch1 == 1 &&
+  // (33 .. 128 rows take it when the caller asks for what only this form has - the K|V-cache row scatter of a decoded
+  // token - or when the problem is too narrow to give the tiled kernels a grid: N < 8192 means <= 64 tiles of 128 x 128)
+  const bool skinny_wide = d.M > 32 && d.M <= 128 && d.C8 == nullptr && d.c_sumsq == nullptr &&
+                           (d.a_ln_gamma || d.c_row_index || d.c_split_n > 0 || d.N <= 8192 || d.M <= 64);
+  if (g_force_kernel == 0 && (d.M <= 32 || skinny_wide) && d.a_layout == CA_KMAJOR && d.b_layout == CA_KMAJOR && d.batch1 == 1 &&
       d.batch2 == 1 && d.a_kseg == 0 && d.b_kseg == 0 && d.dropout_p == 0.f && d.epilogue != CA_EPI_DGELU) {
     g_last_kind = 0;
     CA_CHECK_ARG(d.c_split_n == 0 || (d.C_hi && (d.c_split_n % 16) == 0 && d.c_split_n < d.N && d.epilogue == CA_EPI_NONE),
                  "ca_gemm_bf16: c_split_n needs C_hi, a multiple of 16 below N and no epilogue");
-    const unsigned grid = (unsigned)((d.N + 15) / 16);
+    const unsigned gy = d.M <= 32 ? 1u : (unsigned)((d.M + 31) / 32);  // row blocks of 32 (blockIdx.y)
+    const dim3 grid((unsigned)((d.N + 15) / 16), gy);
     if (d.a_ln_gamma) {
       CA_CHECK_ARG(d.a_ln_beta && d.K <= 2048 && ((uintptr_t)d.a_ln_gamma % 16) == 0 && ((uintptr_t)d.a_ln_beta % 16) == 0,
                    "ca_gemm_bf16: a_ln_gamma needs a_ln_beta, K <= 2048 and 16-byte aligned vectors");
-      const int mb = d.M <= 16 ? 1 : 2;
+      const int mb = d.M <= 16 ? 1 : 2;  // (33 .. 128 rows: 32-row blocks over blockIdx.y)
       const int nch = (d.K + 511) / 512 <= 2 ? 2 : (d.K + 511) / 512;
       const size_t lds = (size_t)4 * mb * 256 * sizeof(float) + (size_t)16 * mb * (d.K + SKINNY_LN_PAD) * 2;
 #define SKINNY_LN(MBV, NCHV)                                                                                         \
@@ -2664,7 +2677,7 @@ static int ca_gemm_launch(const CaGemmDesc* desc, void* stream) {
                           160 * 1024);                                                                               \
       attr_ln = true;                                                                                                \
     }                                                                                                                \
-    CA_LAUNCH((ca_gemm_skinny_kernel<MBV, NCHV>), dim3(grid), dim3(256), lds, s, d);                                 \
+    CA_LAUNCH((ca_gemm_skinny_kernel<MBV, NCHV>), grid, dim3(256), lds, s, d);                                       \
   } while (0)
       if (mb == 1 && nch == 2) SKINNY_LN(1, 2);
       else if (mb == 1 && nch == 3) SKINNY_LN(1, 3);
@@ -2674,16 +2687,16 @@ static int ca_gemm_launch(const CaGemmDesc* desc, void* stream) {
       else SKINNY_LN(2, 4);
 #undef SKINNY_LN
     } else if (d.M <= 16) {
-      CA_LAUNCH((ca_gemm_skinny_kernel<1, 0>), dim3(grid), dim3(256), 4 * 256 * sizeof(float), s, d);
+      CA_LAUNCH((ca_gemm_skinny_kernel<1, 0>), grid, dim3(256), 4 * 256 * sizeof(float), s, d);
     } else {
-      CA_LAUNCH((ca_gemm_skinny_kernel<2, 0>), dim3(grid), dim3(256), 8 * 256 * sizeof(float), s, d);
+      CA_LAUNCH((ca_gemm_skinny_kernel<2, 0>), grid, dim3(256), 8 * 256 * sizeof(float), s, d);
     }
     CA_CHECK_LAUNCH("ca_gemm_bf16");
     return CA_OK;
   }
-  CA_CHECK_ARG(!d.a_ln_gamma, "ca_gemm_bf16: a_ln_gamma exists in the skinny form only (M <= 32, K-major operands, un-batched)");
+  CA_CHECK_ARG(!d.a_ln_gamma, "ca_gemm_bf16: a_ln_gamma exists in the skinny form only (M <= 128, K-major operands, un-batched)");
   CA_CHECK_ARG(!d.c_row_index && d.c_split_n == 0,
-               "ca_gemm_bf16: c_row_index / c_split_n exist in the skinny form only (M <= 32, K-major operands, un-batched)");
+               "ca_gemm_bf16: c_row_index / c_split_n exist in the skinny form only (M <= 128, K-major operands, un-batched)");
   // Kernel choice: the 256x128 pipelined kernel runs one workgroup per CU, so it needs enough
   // tiles to fill the chip; small or heavily batched problems use the 128x128 kernel.
   const int64_t nb = (int64_t)d.batch1 * d.batch2;

@@ -229,7 +229,7 @@ class WhisperEngine:
     def _ffn(self, w, h_in, h_out, p, M, d, f):
         st, p32, p16 = self.store, self.store.p32, self.store.p16
         o = st.off
-        if M <= 32 and d <= 2048 and LN_IN_GEMM:
+        if M <= 128 and d <= 2048 and LN_IN_GEMM:
             # a decoded token: the LayerNorm runs in the projection's prologue (CaGemmDesc.a_ln_gamma, bit-identical)
             ops.gemm(h_in, p16, None, C2=w["g"], M=M, N=f, K=d, lda=d, ldb=d, ldc=f, b_off=o(p + "fc1.weight"),
                      bias=p32, bias_off=o(p + "fc1.bias"), epilogue=EPI_GELU,
@@ -542,7 +542,7 @@ class WhisperEngine:
         for l in range(s.decoder_layers):
             p = f"model.decoder.layers.{l}."
             ckv = cache["kv"][l]
-            ln_in = LN_IN_GEMM and B <= 32 and d <= 2048
+            ln_in = LN_IN_GEMM and B <= 128 and d <= 2048
             if not ln_in:
                 ops.layernorm_fwd(h0, st.view(p + "self_attn_layer_norm.weight"), st.view(p + "self_attn_layer_norm.bias"),
                                   w["x"], None, B, d, s.layer_norm_eps)

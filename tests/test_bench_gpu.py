@@ -15,9 +15,11 @@ pytestmark = pytest.mark.gpu
 ROOT = Path(__file__).resolve().parents[1]
 
 
-@pytest.mark.parametrize("zero", [None, 0])
+@pytest.mark.parametrize("zero", [None, 0, 2])
 def test_bench_spawns_its_ranks_and_reports_them(zero):
-    """zero = None: the N > 1 default (sharded optimiser, the reference's `--zero-stage 2` launch); 0: replicated DDP."""
+    """zero = None: the N > 1 default - the headline is BASELINE configs[2]'s replicated DDP (gradient all-reduce) and the
+    sharded optimiser (the reference's `--zero-stage 2` launch) follows in the same run as config.also_zero2; 0 / 2: one
+    of them alone."""
     env = dict(os.environ, CA_BENCH_SHARE_GPU="1")
     env.pop("WORLD_SIZE", None)
     cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--backend", "gloo", "--model", "wav2vec2-small",
@@ -32,12 +34,19 @@ def test_bench_spawns_its_ranks_and_reports_them(zero):
     assert d["rccl_ranks"] == 1  # (no RCCL rank ran: the field counts ranks of backend "nccl" only)
     assert d["config"]["global_batch"] == 16 and d["config"]["parallelism"] == "dp2"
     assert d["value"] > 0 and d["steps"] == 2 and d["warmup"] == 1
-    assert ("sharded optimiser" in d["config"]["workload"]) == (zero is None)
+    assert ("sharded optimiser" in d["config"]["workload"]) == (zero == 2)
+    assert ("gradient all-reduce" in d["config"]["workload"]) == (zero != 2)
+    z2 = d["config"].get("also_zero2")
+    assert (z2 is not None) == (zero is None)
+    if z2 is not None:
+        assert z2["value"] > 0 and z2["zero_stage_in_effect"] == 2
     spread = [x for x in lines if "replica_param_spread" in x]
-    assert spread and spread[0]["replica_param_spread"] == 0.0   # DDP invariant: identical replicas
-    sp = spread[0]["replica_spreads"]  # parameters, bf16 copy AND the AdamW moments (gathered first under the sharded optimiser)
-    assert set(sp) >= {"p32", "p16", "m", "v"} and all(x == 0.0 for x in sp.values()), sp
-    assert ("p16_vs_master" in sp) == (zero is None)
+    assert len(spread) == (2 if zero is None else 1)
+    for sp_line in spread:  # DDP invariant: identical replicas - parameters, bf16 copy AND the AdamW moments
+        assert sp_line["replica_param_spread"] == 0.0
+        sp = sp_line["replica_spreads"]
+        assert set(sp) >= {"p32", "p16", "m", "v"} and all(x == 0.0 for x in sp.values()), sp
+    assert ("p16_vs_master" in spread[-1]["replica_spreads"]) == (zero != 0)
 
 
 def test_two_ranks_at_the_full_xlsr_2b_shape_with_the_sharded_optimizer():
@@ -48,7 +57,7 @@ def test_two_ranks_at_the_full_xlsr_2b_shape_with_the_sharded_optimizer():
     env = dict(os.environ, CA_BENCH_SHARE_GPU="1")
     env.pop("WORLD_SIZE", None)
     cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1",
-           "--no-cpu-baseline", "--no-also", "--no-fwd-bwd", "--check-replicas"]
+           "--no-cpu-baseline", "--no-also", "--no-fwd-bwd", "--check-replicas", "--zero-stage", "2"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500, cwd=str(ROOT))
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]

@@ -106,6 +106,59 @@ def test_bucketed_allreduce_world2_gloo():
     assert res[0][5] == [0, 1, 2, 3] and res[1][5] == [4, 5, 6, 7]  # disjoint, covering shards
 
 
+def _rng_worker(rank, world, port, tmp, q):
+    """Two ranks write `rng_state_<rank>.pth` into one checkpoint directory the way CoralTrainer.train does (the main rank
+    with the checkpoint, the others behind the barrier) and read their OWN file back: the resumed SpecAugment / LayerDrop
+    streams continue per rank (HF's per-process `_save_rng_state`), not rank 0's on every rank."""
+    import types
+    from pathlib import Path
+
+    import numpy as np
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    from coral_amd.coral_trainer import CoralTrainer
+
+    tr = CoralTrainer.__new__(CoralTrainer)  # (the host-side checkpoint logic only: no engine, no GPU)
+    tr.model = types.SimpleNamespace(_rng=np.random.RandomState(4242 + 17 * rank))
+    tr.is_main = rank == 0
+    np.random.seed(100 + rank)
+    torch.manual_seed(200 + rank)
+    tr.model._rng.rand(5 + rank)  # the ranks' streams have advanced differently
+    d = Path(tmp) / "checkpoint-3"
+    if tr.is_main:
+        tr._save_rng_state(d)
+    torch.distributed.barrier()
+    if not tr.is_main:
+        tr._save_rng_state(d)
+    torch.distributed.barrier()
+    mine = d / f"rng_state_{rank}.pth"
+    ok = mine.exists() and len(list(d.glob("rng_state_*.pth"))) == world
+    want = tr.model._rng.rand(3).tolist()  # what the uninterrupted run would draw next
+    st = torch.load(str(mine), weights_only=False)
+    tr.model._rng.rand(7)  # (the "interrupted" process went on; a resume rewinds to the saved state)
+    tr._set_rng_state(st)
+    got = tr.model._rng.rand(3).tolist()
+    q.put((rank, bool(ok), got == want, want))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_every_rank_saves_and_restores_its_own_rng_state(tmp_path):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rng_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] and r[2] for r in res), res
+    assert res[0][3] != res[1][3]  # two different streams were saved, not rank 0's twice
+
+
 def test_schedule_and_accumulation():
     from coral_amd.trainer import cosine_lr, grad_accumulation_steps, shard_indices
 

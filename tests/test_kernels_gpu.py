@@ -558,10 +558,12 @@ def test_fused_attention_fwd_bwd(ops, hd, H, Tq, Tk, causal, pad):
 
 
 @pytest.mark.parametrize("M,N,K", [(8, 1024, 1024), (3, 1000, 4096), (16, 51865, 384), (1, 72, 40), (32, 1024, 1024), (17, 520, 264),
-                                   (29, 51865, 128)])
+                                   (29, 51865, 128), (64, 1024, 1024), (48, 520, 264), (128, 1024, 1280), (100, 4096, 1024),
+                                   (64, 51865, 128), (33, 72, 40)])
 def test_skinny_gemm_matches_torch(ops, M, N, K):
     """M <= 32 (one decoded token per clip; 17..32 rows take a second row block against the same weight fragment) takes
-    the weight-streaming kernel: bias, GELU (second output),
+    the weight-streaming kernel, and so do 33 .. 128 rows (round 5: four / eight row blocks - evaluation batches of 64 and
+    128 clips): bias, GELU (second output),
     residual, fp32 output with a padded leading dimension (the LM head)."""
     g = torch.Generator().manual_seed(M * 1000 + N)
     A = (torch.randn(M, K, generator=g) * 0.5).to(torch.bfloat16)
@@ -617,7 +619,8 @@ def test_weight_gradient_with_fused_bias_gradient_and_grouped_launch(ops):
             assert (gb - wb).abs().max() <= 2e-3 * max(1.0, float(wb.abs().max())), ("bias", i, fused)
 
 
-@pytest.mark.parametrize("M,N,K", [(8, 1024, 1024), (5, 1000, 1280), (16, 264, 384), (32, 1024, 512), (21, 264, 384)])
+@pytest.mark.parametrize("M,N,K", [(8, 1024, 1024), (5, 1000, 1280), (16, 264, 384), (32, 1024, 512), (21, 264, 384),
+                                   (64, 1024, 512), (100, 264, 384), (128, 1024, 1024)])
 def test_gemm_skinny_row_index(ops, M, N, K):
     """CaGemmDesc.c_row_index (one decoded token per clip): the output rows land at device-side positions of a
     [M, L, N] cache, bit-identical to the plain GEMM's rows; the tiled kernels refuse the option."""
@@ -638,9 +641,9 @@ def test_gemm_skinny_row_index(ops, M, N, K):
     want_cache[torch.arange(M, device=DEV), pos.long()] = ref
     assert torch.equal(cache, want_cache)
     with pytest.raises(Exception):
-        big = torch.zeros(64 * L, Np, dtype=torch.bfloat16, device=DEV)
-        ops.gemm(torch.zeros(64, K, dtype=torch.bfloat16, device=DEV), W, big, M=64, N=N, K=K, lda=K, ldb=K, ldc=Np,
-                 c_row_index=torch.zeros(64, dtype=torch.int32, device=DEV), c_row_mul=L)
+        big = torch.zeros(160 * L, Np, dtype=torch.bfloat16, device=DEV)
+        ops.gemm(torch.zeros(160, K, dtype=torch.bfloat16, device=DEV), W, big, M=160, N=N, K=K, lda=K, ldb=K, ldc=Np,
+                 c_row_index=torch.zeros(160, dtype=torch.int32, device=DEV), c_row_mul=L)
 
 
 def test_frame_lengths(ops):
@@ -698,7 +701,7 @@ def test_argmax_masked_first_maximum_and_suppression(ops, V, Vp):
     assert out.cpu().numpy().tolist() == ref.tolist()
 
 
-@pytest.mark.parametrize("M", [8, 24])
+@pytest.mark.parametrize("M", [8, 24, 64, 100])
 def test_gemm_skinny_split_output(ops, M):
     """CaGemmDesc.c_split_n: columns [0, d) to one buffer in place, columns [d, 3d) to the rows of a cache at
     device-side positions - the q projection and the new K|V rows of a decoded token from one launch."""
@@ -857,7 +860,7 @@ def test_side_streams_are_one_per_role_and_process(ops, monkeypatch):
 
 
 @pytest.mark.parametrize("M,N,K", [(8, 3072, 1024), (16, 4096, 1024), (1, 72, 40), (5, 1000, 384), (24, 1280, 1280), (32, 5120, 1280),
-                                   (16, 136, 2048)])
+                                   (16, 136, 2048), (64, 3072, 1024), (100, 1280, 1280), (128, 4096, 1024)])
 def test_skinny_gemm_with_layernorm_prologue_is_bit_identical_to_two_launches(ops, M, N, K):
     """CaGemmDesc.a_ln_gamma: LayerNorm(A rows) inside the weight-streaming kernel's prologue = ca_layernorm_fwd followed by
     the same GEMM, bit for bit (plain, GELU second output, the q | K|V split with device-side row positions); rows of A
@@ -893,7 +896,7 @@ def test_skinny_gemm_with_layernorm_prologue_is_bit_identical_to_two_launches(op
                      C_hi=kv, ldc_hi=2 * d3, c_row_index=pos, c_row_mul=Lmax, a_ln=ln if fused else None)
             outs.append((q, kv))
         assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
-    if M == 16:  # the prologue exists in the skinny form only
-        big = torch.zeros(64, N, dtype=torch.bfloat16, device=DEV)
+    if M == 16:  # the prologue exists in the skinny form only (up to 128 rows)
+        big = torch.zeros(160, N, dtype=torch.bfloat16, device=DEV)
         with pytest.raises(Exception, match="skinny form only"):
-            ops.gemm(torch.zeros(64, K, dtype=torch.bfloat16, device=DEV), W, big, M=64, N=N, K=K, lda=K, ldb=K, ldc=N, a_ln=ln)
+            ops.gemm(torch.zeros(160, K, dtype=torch.bfloat16, device=DEV), W, big, M=160, N=N, K=K, lda=K, ldb=K, ldc=N, a_ln=ln)

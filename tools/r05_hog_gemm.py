@@ -49,25 +49,29 @@ def chain(which):
 
 
 def timed(which):
+    main = torch.cuda.current_stream()
     chain(which)  # warm-up
-    torch.cuda.synchronize()
+    main.synchronize()  # (this stream only: a device-wide synchronise would wait for the hog to leave)
     best = 1e9
     for _ in range(args.iters):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         chain(which)
         e1.record()
-        torch.cuda.synchronize()
+        main.synchronize()
         best = min(best, e0.elapsed_time(e1))
     return best * 1e3 / args.layers  # us per layer
 
 
-def with_hog(n, which, ms=400.0):
+def with_hog(n, which, ms=600.0):
     """The same timing with n hog workgroups resident: started first, given a moment to occupy their CUs."""
     with torch.cuda.stream(side):
         ops.check(lib.ca_debug_cu_hog(n, 256, 96 * 1024, ms, side.cuda_stream), "ca_debug_cu_hog")
     time.sleep(0.02)
+    t0 = time.time()
     t = timed(which)
+    took = time.time() - t0
+    assert took < ms * 1e-3 * 0.9, f"the hog ({ms} ms) left before the measurement ended ({took * 1e3:.0f} ms)"
     side.synchronize()
     return t
 
