@@ -77,6 +77,7 @@ class CaGemmDesc(C.Structure):
         ("a_ln_gamma", C.c_void_p),
         ("a_ln_beta", C.c_void_p),
         ("a_ln_eps", C.c_float),
+        ("xcd_balanced", C.c_int32),
     ]
 
 

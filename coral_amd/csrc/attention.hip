@@ -36,7 +36,7 @@ __device__ __forceinline__ void glds16a(const void* g, char* lds_wave_base) {
 // group holds 16 rows of two lane groups g) and transposed reads (ds_read_b64_tr_b16 of rows 8 g + q, two 32-lane
 // groups, each lane pair a chunk pair).  kswz = (r0, r0 ^ r1, r3) is one of the XOR-linear maps of the row bits for
 // which a bank simulation of every read of a step, with the hardware's lane groups, finds no conflict at all
-// (tools/dev_lds_swizzle.py); the round-1 map (r >> 1) & 7 cost an extra LDS cycle on every read of either kind
+// (tools/archive/dev_lds_swizzle.py); the round-1 map (r >> 1) & 7 cost an extra LDS cycle on every read of either kind
 // (SQ_LDS_BANK_CONFLICT = 49 % of SQ_LDS_IDX_ACTIVE in dQ and dK|dV).  LDS-DMA writes are linear and do not care.
 // MN-major images ([rows][HDPV dims], read only transposed): XOR value of the chunk index of row kr.  A 32-lane group of
 // ds_read_b64_tr_b16 covers rows 8 g + q (q = 0..3, g in {0, 1}) of a 32-row block, each lane pair a chunk PAIR: the
@@ -526,7 +526,7 @@ __device__ __forceinline__ void wait_vm() {
 // issue with both waves of a SIMD stalled ~35 % of the time (LDS fragment reads, the per-tile barrier, MFMA results), and
 // a THIRD resident wave hides most of that: the head_dim <= 64 form holds 154 registers (512 / 3 = 170), so it runs three
 // workgroups per CU - whisper-medium encoder forward 136 -> 124 us per layer, whisper-large-turbo 166 -> 148
-// (tools/exp_attn_env.sh, interleaved).  Measured and dropped on the way: forming the scores of tile kt + 1 under the
+// (tools/archive/exp_attn_env.sh, interleaved).  Measured and dropped on the way: forming the scores of tile kt + 1 under the
 // softmax of tile kt inside one wave (a third image pair and a second score set, 230 registers: 5 % SLOWER - the
 // co-resident waves already overlap the two pipes, what is short is issue slots), and four waves per SIMD at 128
 // registers (27 spilled dwords: 183 us).
@@ -852,12 +852,17 @@ __device__ __forceinline__ void glds16_async(const void* g, char* lds_wave_base)
 // per 16 columns, partials added as (p0 + p1) + (p2 + p3), + bias, rounded to bf16) - so the LayerNorm launch, the
 // projection launch and the query's trip through HBM disappear from the per-token chain; bit-identical to them.
 #define SPLIT_ROW 66  // floats per query of a partial slab: m, l, 64 output columns
-template <int HDPV, bool QP = false>
+// DT: tiles in flight per wave = slots of its V ring.  3 (96 KiB of LDS: one workgroup per CU) where clips x heads is
+// at most about two per CU; 2 (64 KiB: two workgroups per CU) for larger batches (round 5: an evaluation batch of 64
+// clips x 16 heads is 1024 workgroups - with one per CU they ran in four rounds, each paying its LayerNorm + query
+// projection prologue in front of its K|V stream; with two per CU one workgroup's prologue runs under the other's stream).
+template <int HDPV, bool QP = false, int DT = 3>
 __global__ __launch_bounds__(256) void attn_fwd_smallq_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NKS = HDPV / 32, NNB = HDPV / 16;
   constexpr int IMG = 64 * HDPV * 2;
-  constexpr int D = 3;  // tiles in flight per wave
+  constexpr int D = DT;  // tiles in flight per wave
+  static_assert(D == 2 || D == 3, "two or three tiles in flight");
   static_assert(HDPV == 64, "16 vector-memory operations per tile are assumed by the counted waits");
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1025,9 +1030,9 @@ __global__ __launch_bounds__(256) void attn_fwd_smallq_kernel(const AttnArgs a) 
     constexpr int S = decltype(slot_c)::value;
     const int kt = vw + nvw * j;
     const int rem = nw - 1 - j;  // younger tiles already issued (at most D - 1)
-    if (rem >= 2)
+    if (D > 2 && rem >= 2)
       asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-    else if (rem == 1)
+    else if (rem >= 1)
       asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     else
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1114,11 +1119,15 @@ __global__ __launch_bounds__(256) void attn_fwd_smallq_kernel(const AttnArgs a) 
   };
   if (nw > 0) issue(std::integral_constant<int, 0>{}, 0);
   if (nw > 1) issue(std::integral_constant<int, 1>{}, 1);
-  if (nw > 2) issue(std::integral_constant<int, 2>{}, 2);
+  if constexpr (D > 2) {
+    if (nw > 2) issue(std::integral_constant<int, 2>{}, 2);
+  }
   for (int j = 0; j < nw; j += D) {
     step(std::integral_constant<int, 0>{}, j);
     if (j + 1 < nw) step(std::integral_constant<int, 1>{}, j + 1);
-    if (j + 2 < nw) step(std::integral_constant<int, 2>{}, j + 2);
+    if constexpr (D > 2) {
+      if (j + 2 < nw) step(std::integral_constant<int, 2>{}, j + 2);
+    }
   }
   // merge the four waves: (m, l) per query and the output rows, through LDS (the images are dead now)
   l += __shfl_xor(l, 16, 64);
@@ -1329,7 +1338,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a) {
   }
   // One 32-query step; FULL (compile time): nothing in the step is masked - no per-element compare / select.  As a
   // run-time flag inside the element loop the masks became ~30 small basic blocks per step: in-kernel stamps put the
-  // softmax / dS section at 1 630 cycles of a 3 430-cycle step (tools/dev_dkv_stamps.py), against 553 + 655 for the 32 MFMAs.
+  // softmax / dS section at 1 630 cycles of a 3 430-cycle step (tools/archive/dev_dkv_stamps.py), against 553 + 655 for the 32 MFMAs.
   auto step = [&](auto full_c, int qs) __attribute__((always_inline)) {
     constexpr bool FULL = decltype(full_c)::value;
     const int buf = (qs - s0) & 1;
@@ -1514,7 +1523,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
   }
   // One 32-query step; FULL (compile time): nothing in the step is masked - no per-element compare / select.  As a
   // run-time flag inside the element loop the masks became ~30 small basic blocks per step: in-kernel stamps put the
-  // softmax / dS section at 1 630 cycles of a 3 430-cycle step (tools/dev_dkv_stamps.py), against 553 + 655 for the 32 MFMAs.
+  // softmax / dS section at 1 630 cycles of a 3 430-cycle step (tools/archive/dev_dkv_stamps.py), against 553 + 655 for the 32 MFMAs.
   auto step = [&](auto full_c, int qs) __attribute__((always_inline)) {
     constexpr bool FULL = decltype(full_c)::value;
     const int buf = (qs - s0) & 1;
@@ -1948,6 +1957,18 @@ static AttnArgs to_args(const CaAttnDesc& d) {
 
 // Key split of the small-query kernel: on when the caller lent a workspace, the keys are many and (clips x heads) leaves
 // at least half of the CUs without a workgroup.  Sets a.nsplit / the slab and counter pointers; returns the grid size.
+// grids from which the single-query kernels run two workgroups per CU (rings of two tiles): more than 1.5 workgroups per
+// CU (CA_SMALLQ_2PERCU: the grid size; 0 = never)
+static unsigned smallq_two_per_cu() {
+  static const unsigned thr = [] {
+    const char* e = getenv("CA_SMALLQ_2PERCU");
+    if (e) return (unsigned)(atoi(e) > 0 ? atoi(e) : 0x7fffffff);
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return (unsigned)(n + n / 2);
+  }();
+  return thr;
+}
 static int smallq_split(const CaAttnDesc& d, AttnArgs& a, unsigned& grid) {
   const int bh = d.B * d.H;
   grid = (unsigned)bh;
@@ -2016,15 +2037,20 @@ extern "C" int ca_attn_fwd(const CaAttnDesc* desc, void* stream) {
   }
   if (desc->Tq <= 16 && desc->hd <= 64 && !desc->causal) {  // greedy decoding: the waves split the keys
     constexpr int SMALLQ_LDS = 4 * 3 * 64 * 64 * 2;  // four waves x ring of three 8-KiB V images
+    constexpr int SMALLQ_LDS2 = 4 * 2 * 64 * 64 * 2;  // ... of two: two workgroups per CU (large batches)
     static bool attr = false;
     if (!attr) {
       hipFuncSetAttribute((const void*)attn_fwd_smallq_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, SMALLQ_LDS);
+      hipFuncSetAttribute((const void*)attn_fwd_smallq_kernel<64, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, SMALLQ_LDS2);
       attr = true;
     }
     AttnArgs as = a;
     unsigned sgrid;
     if (int rc = smallq_split(*desc, as, sgrid)) return rc;
-    hipLaunchKernelGGL((attn_fwd_smallq_kernel<64>), dim3(sgrid), block, SMALLQ_LDS, s, as);
+    if (sgrid >= smallq_two_per_cu())
+      hipLaunchKernelGGL((attn_fwd_smallq_kernel<64, false, 2>), dim3(sgrid), block, SMALLQ_LDS2, s, as);
+    else
+      hipLaunchKernelGGL((attn_fwd_smallq_kernel<64>), dim3(sgrid), block, SMALLQ_LDS, s, as);
     CA_CHECK_LAUNCH("ca_attn_fwd");
     return CA_OK;
   }
@@ -2060,14 +2086,19 @@ extern "C" int ca_decode_attn_qproj(const CaAttnDesc* desc, const void* x, int64
   a.qp_bias = bq;
   a.qp_d = d_model;
   constexpr int LDS = 4 * 3 * 64 * 64 * 2 + 4096 + 1024;  // the V rings + the normalised row + the partial products
+  constexpr int LDS2 = 4 * 2 * 64 * 64 * 2 + 4096 + 1024;  // rings of two: two workgroups per CU (large batches)
   static bool attr = false;
   if (!attr) {
     hipFuncSetAttribute((const void*)attn_fwd_smallq_kernel<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipFuncSetAttribute((const void*)attn_fwd_smallq_kernel<64, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
     attr = true;
   }
   unsigned sgrid;
   if (int rc = smallq_split(*desc, a, sgrid)) return rc;
-  hipLaunchKernelGGL((attn_fwd_smallq_kernel<64, true>), dim3(sgrid), dim3(256), LDS, (hipStream_t)stream, a);
+  if (sgrid >= smallq_two_per_cu())
+    hipLaunchKernelGGL((attn_fwd_smallq_kernel<64, true, 2>), dim3(sgrid), dim3(256), LDS2, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL((attn_fwd_smallq_kernel<64, true>), dim3(sgrid), dim3(256), LDS, (hipStream_t)stream, a);
   CA_CHECK_LAUNCH("ca_decode_attn_qproj");
   return CA_OK;
 }
@@ -2114,7 +2145,7 @@ extern "C" int ca_attn_bwd(const CaAttnDesc* desc, void* stream) {
   // ... and a wave that owns two key blocks (128 keys per workgroup) halves the LDS fragment reads per MFMA: see
   // attn_bwd_dkv_wide_kernel.  CA_ATTN_DKV_WIDE=0 keeps the 64-key kernel.
   static const int dkv_wide_on = [] { const char* e = getenv("CA_ATTN_DKV_WIDE"); return e ? atoi(e) : 1; }();
-  // Measured (tools/exp_dkv.sh, rocprofv3 per-kernel averages): head_dim <= 64 (XLS-R-300M, Whisper) 226 -> 208 us over
+  // Measured (tools/archive/exp_dkv.sh, rocprofv3 per-kernel averages): head_dim <= 64 (XLS-R-300M, Whisper) 226 -> 208 us over
   // the models' shapes (XLS-R-300M backward 72.5 -> 63.1 us per layer, whisper-large-turbo encoder 523 -> 494); at
   // head_dim 80 / 120 the doubled accumulators (374 registers) leave one wave per SIMD and it LOSES (73.3 -> 83.7 us):
   // the 64-key kernel stays there.

@@ -320,18 +320,21 @@ __device__ __forceinline__ void run_tile(int l, int ntm, int ntn, int& tm, int& 
 }
 // The rectangular split leaves XCDs unevenly loaded when the grid does not divide (5 x 5 tiles: 6, 6, 3, 0, 4, 4, 2,
 // 0 per XCD): where it would pad by more than a quarter, each XCD takes a run of ceil(T / 8) consecutive tiles.
-__host__ __device__ __forceinline__ bool xcd_use_runs(int ntm, int ntn, int hb, int wb) {
-  return 8 * hb * wb * 4 > ntm * ntn * 5;
+// bal (CaGemmDesc.xcd_balanced, set by the library beside a resident collective): always runs - every XCD gets
+// ceil(T / 8) tiles.  The rectangular split may hand one XCD exactly its 32 CUs' worth of a 240-tile grid (32, 32, ...,
+// 24, 24): with two CUs of an XCD held by another kernel that XCD runs a second round and the launch takes twice as long.
+__host__ __device__ __forceinline__ bool xcd_use_runs(int ntm, int ntn, int hb, int wb, bool bal = false) {
+  return bal || 8 * hb * wb * 4 > ntm * ntn * 5;
 }
-__host__ __device__ __forceinline__ int xcd_grid(int ntm, int ntn) {
+__host__ __device__ __forceinline__ int xcd_grid(int ntm, int ntn, bool bal = false) {
   if (ntm * ntn <= 8) return ntm * ntn;  // a handful of tiles (batched attention-sized problems): plain numbering
   int hb, wb;
   xcd_split(ntm, ntn, hb, wb);
-  if (xcd_use_runs(ntm, ntn, hb, wb)) return 8 * ((ntm * ntn + 7) / 8);
+  if (xcd_use_runs(ntm, ntn, hb, wb, bal)) return 8 * ((ntm * ntn + 7) / 8);
   return 8 * hb * wb;
 }
 // tile of block `bid` under that split (false = padding block)
-__device__ __forceinline__ bool xcd_tile(int bid, int ntm, int ntn, int& tm, int& tn) {
+__device__ __forceinline__ bool xcd_tile(int bid, int ntm, int ntn, int& tm, int& tn, bool bal = false) {
   if (ntm * ntn <= 8) {
     tm = bid / ntn;
     tn = bid % ntn;
@@ -341,7 +344,7 @@ __device__ __forceinline__ bool xcd_tile(int bid, int ntm, int ntn, int& tm, int
   const int bm = xcd_split(ntm, ntn, hb, wb);
   const int bn = 8 / bm;
   const int x = bid & 7, idx = bid >> 3;
-  if (xcd_use_runs(ntm, ntn, hb, wb)) {
+  if (xcd_use_runs(ntm, ntn, hb, wb, bal)) {
     const int l = x * ((ntm * ntn + 7) / 8) + idx;
     run_tile(l, ntm, ntn, tm, tn);
     return l < ntm * ntn;
@@ -352,19 +355,19 @@ __device__ __forceinline__ bool xcd_tile(int bid, int ntm, int ntn, int& tm, int
   return tm < ntm && tn < ntn;
 }
 template <int SBM, int SBN>
-__device__ __forceinline__ bool tile_of_block_g(int bid, int grid, int ntm, int ntn, int& tm, int& tn);
+__device__ __forceinline__ bool tile_of_block_g(int bid, int grid, int ntm, int ntn, int& tm, int& tn, bool bal = false);
 template <int SBM, int SBN>
-__device__ __forceinline__ bool tile_of_block(int bid, int ntm, int ntn, int& tm, int& tn) {
-  return tile_of_block_g<SBM, SBN>(bid, (int)gridDim.x, ntm, ntn, tm, tn);
+__device__ __forceinline__ bool tile_of_block(int bid, int ntm, int ntn, int& tm, int& tn, bool bal = false) {
+  return tile_of_block_g<SBM, SBN>(bid, (int)gridDim.x, ntm, ntn, tm, tn, bal);
 }
 // the same with the size of the (virtual) grid given: persistent workgroups walk a grid larger than the launch
 template <int SBM, int SBN>
-__device__ __forceinline__ bool tile_of_block_g(int bid, int grid, int ntm, int ntn, int& tm, int& tn) {
-  if (grid == xcd_grid(ntm, ntn)) {
+__device__ __forceinline__ bool tile_of_block_g(int bid, int grid, int ntm, int ntn, int& tm, int& tn, bool bal) {
+  if (grid == xcd_grid(ntm, ntn, bal)) {
     // small problem (fewer than 4 super-blocks per XCD): one rectangular block of tiles per XCD, so an L2 only
     // streams the operand bands of its block.  (Plain round-robin numbering gave each XCD one tile COLUMN: all of
     // A streamed into every L2, 8x the bytes in the PMC counters.)
-    return xcd_tile(bid, ntm, ntn, tm, tn);
+    return xcd_tile(bid, ntm, ntn, tm, tn, bal);
   }
   const int x = bid & 7, i = bid >> 3;
   const int per = SBM * SBN;
@@ -376,8 +379,8 @@ __device__ __forceinline__ bool tile_of_block_g(int bid, int grid, int ntm, int 
   return tm < ntm && tn < ntn;
 }
 template <int SBM, int SBN>
-static inline unsigned tile_grid(int ntm, int ntn) {
-  if (ntm * ntn < 4 * 8 * SBM * SBN) return (unsigned)xcd_grid(ntm, ntn);  // fewer than 4 super-blocks per XCD
+static inline unsigned tile_grid(int ntm, int ntn, bool bal = false) {
+  if (ntm * ntn < 4 * 8 * SBM * SBN) return (unsigned)xcd_grid(ntm, ntn, bal);  // fewer than 4 super-blocks per XCD
   const int nsb = ((ntm + SBM - 1) / SBM) * ((ntn + SBN - 1) / SBN);
   return (unsigned)(((nsb + 7) / 8) * 8 * SBM * SBN);
 }
@@ -840,7 +843,7 @@ __global__ __launch_bounds__(256) void ca_gemm_kernel(const CaGemmDesc d) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   int tm, tn;
-  if (!tile_of_block<8, 8>(blockIdx.x, (d.M + BM - 1) / BM, (d.N + BN - 1) / BN, tm, tn)) return;
+  if (!tile_of_block<8, 8>(blockIdx.x, (d.M + BM - 1) / BM, (d.N + BN - 1) / BN, tm, tn, d.xcd_balanced != 0)) return;
   const int m0 = tm * BM, n0 = tn * BN;
   const int z = blockIdx.z;
   const int z1 = z / d.batch2, z2 = z % d.batch2;
@@ -984,7 +987,7 @@ __global__ __launch_bounds__(256) void ca_gemm_kernel(const CaGemmDesc d) {
 // For grids of at most one 128x128 tile per CU (the N = d GEMMs of the d = 1024 models at M = 3992: 256 tiles; the
 // Whisper decoder's teacher-forced rows: 56-64 tiles).  There kernel S runs a lone wave per SIMD through
 // barrier -> fragment reads -> 32 MFMAs -> ..., 1 400-1 700 cycles per K-step for 512 of MFMA whatever the ring depth
-// (tools/dev_dec_gemm.py), and kernel L's 256x128 tiles use half the CUs.  Here the same tile is shared by two waves
+// (tools/archive/dev_dec_gemm.py), and kernel L's 256x128 tiles use half the CUs.  Here the same tile is shared by two waves
 // per SIMD (64 rows x 32 columns each, 16 MFMAs per K-step and wave): one wave's fragment reads and barrier wait run
 // under the other's MFMAs.  The LDS one workgroup per CU leaves free holds a ring of four stages (LDS-DMA three tiles
 // ahead, counted vmcnt: 4 pieces per wave and tile).  Epilogue: the two waves of a 64x64 quadrant park their halves in
@@ -1006,7 +1009,7 @@ __global__ __launch_bounds__(512) void ca_gemm_kernel_m(const CaGemmDesc d) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;  // 2 x 4 waves, 64 (M) x 32 (N) each
   int tm, tn;
-  if (!tile_of_block<8, 8>(blockIdx.x, (d.M + BM - 1) / BM, (d.N + BN - 1) / BN, tm, tn)) return;
+  if (!tile_of_block<8, 8>(blockIdx.x, (d.M + BM - 1) / BM, (d.N + BN - 1) / BN, tm, tn, d.xcd_balanced != 0)) return;
   const int m0 = tm * BM, n0 = tn * BN;
   const int z = blockIdx.z;
   const int z1 = z / d.batch2, z2 = z % d.batch2;
@@ -1250,7 +1253,7 @@ __global__ __launch_bounds__(512) void ca_gemm_kernel_x(const CaGemmGroup grp) {
     if (grp.count > 1)
       run_tile(gt - grp.first[which], (d.M + XBM - 1) / XBM, (d.N + XBN - 1) / XBN, tm, tn);
     else
-      live = tile_of_block_g<4, 8>(vb, vgrid, (d.M + XBM - 1) / XBM, (d.N + XBN - 1) / XBN, tm, tn);
+      live = tile_of_block_g<4, 8>(vb, vgrid, (d.M + XBM - 1) / XBM, (d.N + XBN - 1) / XBN, tm, tn, d.xcd_balanced != 0);
   }
   if (live) {
   const int m0 = tm * XBM, n0 = tn * XBN;
@@ -1452,7 +1455,7 @@ __global__ __launch_bounds__(512) void ca_gemm_kernel_x(const CaGemmGroup grp) {
     const bool cs_step = do_colsum && (kt % cs_parts) == tn;  // this K-step belongs to this tile column
     // waves 4-7 issue their share of tile kt+1 here - or, in the weight-gradient form (both operands MN-major), one
     // MFMA block later, when their SIMD partners' bursts (issued behind the barrier) are over: 2 685 against 2 802
-    // cycles per K-step there, but 2 840 against 2 590 for the K-major forms (s_memtime stamps, tools/dev_x_stamps.py)
+    // cycles per K-step there, but 2 840 against 2 590 for the K-major forms (s_memtime stamps, tools/archive/dev_x_stamps.py)
     constexpr bool LATE_BURST = AL == CA_MNMAJOR && BL == CA_MNMAJOR && !KS;
     if (!LATE_BURST && wave >= 4) burst(kt + 1);
     // block 0: A(s0, m-half 0) x B(s0); reads A(s0, m-half 1)
@@ -1586,7 +1589,7 @@ __global__ __launch_bounds__(512) void ca_gemm_kernel_x(const CaGemmGroup grp) {
       if (grp.count <= 1 && vb_next < vgrid) {
         // one problem per launch: the next tile's first K-step goes out now and lands under this tile's epilogue
         int tmn = 0, tnn = 0;
-        if (tile_of_block_g<4, 8>(vb_next, vgrid, (d.M + XBM - 1) / XBM, (d.N + XBN - 1) / XBN, tmn, tnn)) {
+        if (tile_of_block_g<4, 8>(vb_next, vgrid, (d.M + XBM - 1) / XBM, (d.N + XBN - 1) / XBN, tmn, tnn, d.xcd_balanced != 0)) {
           init_loaders(tmn * XBM, tnn * XBN);
           burst(0);
           pre = true;
@@ -1669,7 +1672,7 @@ __global__ __launch_bounds__(512) void ca_gemm_kernel_l(const CaGemmDesc d) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;  // 4 x 2 waves, 64x64 each
   int tm, tn;
-  if (!tile_of_block<4, 8>(blockIdx.x, (d.M + LBM - 1) / LBM, (d.N + LBN - 1) / LBN, tm, tn)) return;
+  if (!tile_of_block<4, 8>(blockIdx.x, (d.M + LBM - 1) / LBM, (d.N + LBN - 1) / LBN, tm, tn, d.xcd_balanced != 0)) return;
   const int m0 = tm * LBM, n0 = tn * LBN;
   const int z = blockIdx.z;
   const int z1 = z / d.batch2, z2 = z % d.batch2;
@@ -1928,7 +1931,7 @@ __global__ __launch_bounds__(256) void ca_gemm_skinny_kernel(const CaGemmDesc d)
   for (int mb = 0; mb < MB; ++mb) acc[mb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   const bf16x8_t zero = __builtin_bit_cast(bf16x8_t, (f32x4_t){0.f, 0.f, 0.f, 0.f});
   // The kernel is a short chain of memory round trips behind a ~4 us dependent launch (measured: 4.0 us per launch
-  // in a graph at N = K = 1024, +1 us per 24 KB a workgroup streams - the per-CU fill rate - tools/dev_skinny_time.py),
+  // in a graph at N = K = 1024, +1 us per 24 KB a workgroup streams - the per-CU fill rate - tools/archive/dev_skinny_time.py),
   // so the epilogue's operands (bias, residual, destination row) are asked for up front, beside the first K-steps.
   const int epi = d.epilogue;
   const bool wave0 = wave == 0;
@@ -2153,6 +2156,28 @@ extern "C" int ca_gemm_debug_general_epilogue(int on) {
     return CA_ERR_LAUNCH;
   }
   return CA_OK;
+}
+// CUs the compute kernels may count on (ca_gemm_set_compute_cus): 0 = all of them.  Set by the trainer of an N > 1 run,
+// where a collective's kernel holds some CUs for most of the backward: persistent launches are sized to the rest and
+// hand out every tile dynamically (CaGemmGroup.dyn_first), and the kernel-choice rule counts rounds on the rest.
+static int g_compute_cus = 0;
+extern "C" int ca_gemm_set_compute_cus(int n) {
+  g_compute_cus = n > 0 ? n : 0;
+  return CA_OK;
+}
+static unsigned x_device_cus() {
+  static const unsigned ncu = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return (unsigned)(n >= 8 ? (n / 8) * 8 : 8);
+  }();
+  return ncu;
+}
+static unsigned x_compute_cus() {
+  const unsigned ncu = x_device_cus();
+  if (g_compute_cus <= 0) return ncu;
+  const unsigned c = (unsigned)(g_compute_cus >= 8 ? (g_compute_cus / 8) * 8 : 8);
+  return c < ncu ? c : ncu;
 }
 static int g_force_kernel = 0;  // 0 auto, 1 force 128x128, 2 force 256x128 (tests / tuning)
 extern "C" int ca_gemm_force_kernel(int which) {
@@ -2516,28 +2541,6 @@ extern "C" int ca_gemm_fp8(const CaGemmDesc* desc, void* stream) {
 // Launch geometry of kernel X.  Default: persistent workgroups (one per CU) with dynamic tile pulls whenever the tile
 // grid is larger than the chip and un-batched; CA_X_PERSIST=0 restores one workgroup per tile.
 #define X_LAUNCH_LDS (CA_X_SLAB ? X_SLAB_LDS : X_LDS_BYTES + 64)
-// CUs the compute kernels may count on (ca_gemm_set_compute_cus): 0 = all of them.  Set by the trainer of an N > 1 run,
-// where a collective's kernel holds some CUs for most of the backward: persistent launches are sized to the rest and
-// hand out every tile dynamically (CaGemmGroup.dyn_first), and the kernel-choice rule counts rounds on the rest.
-static int g_compute_cus = 0;
-extern "C" int ca_gemm_set_compute_cus(int n) {
-  g_compute_cus = n > 0 ? n : 0;
-  return CA_OK;
-}
-static unsigned x_device_cus() {
-  static const unsigned ncu = [] {
-    int dev = 0, n = 256;
-    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-    return (unsigned)(n >= 8 ? (n / 8) * 8 : 8);
-  }();
-  return ncu;
-}
-static unsigned x_compute_cus() {
-  const unsigned ncu = x_device_cus();
-  if (g_compute_cus <= 0) return ncu;
-  const unsigned c = (unsigned)(g_compute_cus >= 8 ? (g_compute_cus / 8) * 8 : 8);
-  return c < ncu ? c : ncu;
-}
 static void x_launch_geometry(CaGemmGroup& g, unsigned vgrid, unsigned nbz, dim3& grid) {
   static const int persist = [] { const char* e = getenv("CA_X_PERSIST"); return e ? atoi(e) : 1; }();
   const unsigned ncu = x_compute_cus();
@@ -2621,7 +2624,12 @@ extern "C" int ca_gemm_bf16_group(const CaGemmDesc* descs, int32_t count, void* 
 
 static int ca_gemm_launch(const CaGemmDesc* desc, void* stream) {
   CA_CHECK_ARG(desc != nullptr, "ca_gemm_bf16: null descriptor");
-  const CaGemmDesc& d = *desc;
+  // (a copy: the library, not the caller, owns xcd_balanced - every XCD gets the same number of tiles whenever the
+  // host said that the chip is shared with a resident kernel, ca_gemm_set_compute_cus)
+  CaGemmDesc dcopy = *desc;
+  dcopy.xcd_balanced = g_compute_cus > 0 ? 1 : 0;
+  const CaGemmDesc& d = dcopy;
+  const bool bal = dcopy.xcd_balanced != 0;
   CA_CHECK_ARG(d.A && d.B &&
                    (d.C || ((d.epilogue == CA_EPI_GELU || d.epilogue == CA_EPI_GELU_RESIDUAL) && d.C2)),
                "ca_gemm_bf16: null operand");
@@ -2709,7 +2717,7 @@ static int ca_gemm_launch(const CaGemmDesc* desc, void* stream) {
   // (0.4 .. 3 rounds of one workgroup per CU; CA_GEMM_L_MIN, default 100 tiles: from there it also beats the 128x128
   // kernel on the d = 1024 models, XLS-R-300M step 19.95 -> 19.1 ms): the N = d projections and data gradients and q|k|v at the 2B shape.  Its
   // two-tiles-ahead LDS-DMA keeps it fed under the optimiser's HBM traffic, where the 128x128 kernel (one tile ahead)
-  // loses 25 %: XLS-R-2B step 79.2 -> 76.5 ms on one box (tools/exp_l3.sh).  CA_GEMM_PREFER_L=0 turns it off, a larger
+  // loses 25 %: XLS-R-2B step 79.2 -> 76.5 ms on one box (tools/archive/exp_l3.sh).  CA_GEMM_PREFER_L=0 turns it off, a larger
   // value widens the tile-count window (x 256).
   static const int prefer_l = [] { const char* e = getenv("CA_GEMM_PREFER_L"); return e ? atoi(e) : 3; }();
   // Kernel X (256x256): only where it fills the chip -- at least ~0.7 tiles per CU in its last round.
@@ -2734,6 +2742,27 @@ static int ca_gemm_launch(const CaGemmDesc* desc, void* stream) {
     use_l = 1;
     use_x = 0;
   }
+  // Beside a resident kernel that holds some CUs (ca_gemm_set_compute_cus(n), n below the chip's count) the rules above -
+  // tuned for exactly 256 CUs - pick single-round tilings that then run TWO rounds (240 tiles on 224 CUs).  There the
+  // choice is made by counting rounds on the CUs that are left: cost = rounds x tile work / the shape's efficiency, in
+  // units of one 128 x 128 tile's work (kernel S: two tiles per CU at a time; efficiencies from
+  // profiles/r05_gemm_shapes.txt, weight-gradient form in brackets): X 4 / 1.0, L 2 / 0.93 [0.85], S 2 / 0.8 [0.6] per
+  // pair, M 1 / 0.6.  tenant_kind: -1 = not in this regime.
+  int tenant_kind = -1;
+  if (g_force_kernel == 0 && g_compute_cus > 0 && cus < (int64_t)x_device_cus() && nb == 1 && d.a_kseg == 0 && d.b_kseg == 0 &&
+      d.K >= 512 && !d.a_colsum && d.M > 128) {
+    const int64_t ts = (int64_t)((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
+    auto rounds = [](int64_t tiles, int64_t slots) { return (double)((tiles + slots - 1) / slots); };
+    const double cx = rounds(xt, cus) * 4.0, cl = rounds(tiles_l, cus) * 2.0 / (tn ? 0.85 : 0.93),
+                 cs = rounds(ts, 2 * cus) * 2.0 / (tn ? 0.6 : 0.8), cm = rounds(ts, cus) * 1.0 / 0.6;
+    tenant_kind = 2;
+    double best = cx;
+    if (cl < best) { best = cl; tenant_kind = 1; }
+    if (cs < best) { best = cs; tenant_kind = 0; }
+    if (cm < best) { best = cm; tenant_kind = 3; }
+    use_x = tenant_kind == 2;
+    use_l = tenant_kind == 1;
+  }
   g_last_kind = use_x ? 2 : (use_l ? 1 : 0);
   if (use_x) {
     static bool xattr = false;
@@ -2752,7 +2781,7 @@ static int ca_gemm_launch(const CaGemmDesc* desc, void* stream) {
     one.count = 0;
     one.first[0] = 0;
     one.total = 0;
-    x_launch_geometry(one, tile_grid<4, 8>(xtm, xtn), (unsigned)nb, grid);
+    x_launch_geometry(one, tile_grid<4, 8>(xtm, xtn, bal), (unsigned)nb, grid);
     switch (lay + (ks ? 4 : 0)) {
       case 0: CA_LAUNCH((XK(0, 0, false)), grid, block, X_LAUNCH_LDS, s, one); break;
       case 1: CA_LAUNCH((XK(0, 1, false)), grid, block, X_LAUNCH_LDS, s, one); break;
@@ -2776,7 +2805,7 @@ static int ca_gemm_launch(const CaGemmDesc* desc, void* stream) {
       hipFuncSetAttribute((const void*)ca_gemm_kernel_l<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, L_LDS_BYTES);
       attr_done = true;
     }
-    dim3 grid(tile_grid<4, 8>((d.M + LBM - 1) / LBM, (d.N + LBN - 1) / LBN), 1, (unsigned)nb);
+    dim3 grid(tile_grid<4, 8>((d.M + LBM - 1) / LBM, (d.N + LBN - 1) / LBN, bal), 1, (unsigned)nb);
     dim3 block(512);
     switch (lay) {
       case 0: CA_LAUNCH((ca_gemm_kernel_l<0, 0>), grid, block, L_LDS_BYTES, s, d); break;
@@ -2786,13 +2815,14 @@ static int ca_gemm_launch(const CaGemmDesc* desc, void* stream) {
     }
   } else {
     const int ntm = (d.M + BM - 1) / BM, ntn = (d.N + BN - 1) / BN;
-    dim3 grid(tile_grid<8, 8>(ntm, ntn), 1, (unsigned)nb);
+    dim3 grid(tile_grid<8, 8>(ntm, ntn, bal), 1, (unsigned)nb);
     dim3 block(256);
     const size_t lds = LDS_BYTES;
     const bool ks = d.a_kseg > 0 || d.b_kseg > 0;
     // at most one tile per CU: kernel M (two waves per SIMD on the same tile; CA_GEMM_M=0 switches it off)
     static const int m_max = [] { const char* e = getenv("CA_GEMM_M"); return e ? atoi(e) : 256; }();
-    if (!ks && (g_force_kernel == 5 || (g_force_kernel == 0 && (int64_t)ntm * ntn * nb <= m_max && d.K >= 2 * BK))) {
+    if (!ks && (g_force_kernel == 5 || tenant_kind == 3 ||
+                (g_force_kernel == 0 && tenant_kind < 0 && (int64_t)ntm * ntn * nb <= m_max && d.K >= 2 * BK))) {
       static bool mattr = false;
       if (!mattr) {
         const void* fs[4] = {(const void*)ca_gemm_kernel_m<0, 0>, (const void*)ca_gemm_kernel_m<0, 1>,

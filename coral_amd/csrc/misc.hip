@@ -592,7 +592,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
 // bucket's update for the GEMM's (measured with events on both streams, XLS-R-2B: update 13.0 ms, the forward beside it
 // 31.0 instead of 20.9; capped: update 17.0 ms, forward 28.7, step 72.9 -> 70.7 ms).  What remains is the HBM queue
 // itself: the forward loses ~8.4 ms to the update's 64.8 GB whatever the update's pace (128 threads per CU: update
-// 28 ms, forward 29.5; eight requests in flight per lane instead of four: no better) - tools/dev_opt_timeline.py.
+// 28 ms, forward 29.5; eight requests in flight per lane instead of four: no better) - tools/archive/dev_opt_timeline.py.
 extern "C" int ca_adamw_step_ex(float* p, float* m, float* v, const float* g, void* p16, int64_t n,
                                 float lr, float beta1, float beta2, float eps, float weight_decay,
                                 int32_t step, float grad_scale, float max_norm,

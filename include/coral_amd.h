@@ -148,6 +148,7 @@ typedef struct CaGemmDesc {
   const float* a_ln_gamma;
   const float* a_ln_beta;
   float a_ln_eps;
+  int32_t xcd_balanced; /* internal: overwritten by the library (ca_gemm_set_compute_cus); callers leave it 0 */
 } CaGemmDesc;
 
 int ca_gemm_bf16(const CaGemmDesc* desc, void* stream);

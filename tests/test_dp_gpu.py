@@ -83,8 +83,10 @@ def test_sharded_optimizer_equals_the_replicated_trainer(tmp_path, wire):
         assert zer[r]["losses"][0] == rep[r]["losses"][0]
         # (measured up to 2.2e-4 at the third step on this tiny model)
         assert all(abs(a - b) <= 1e-3 * abs(b) for a, b in zip(zer[r]["losses"], rep[r]["losses"])), (zer[r]["losses"], rep[r]["losses"])
-    for a, b in zip(zer[0]["norms"], rep[0]["norms"]):
-        assert abs(a - b) <= 1e-6 * b  # (sums of per-slice partials in another order)
+    for i, (a, b) in enumerate(zip(zer[0]["norms"], rep[0]["norms"])):
+        # step 1: the same parameters, sums of per-slice partials in another order; later steps inherit the one-ulp flips
+        # of the bf16 copies described above (which steps flip depends on the values: 3.9e-5 seen on the bf16 wire in round 5)
+        assert abs(a - b) <= (1e-6 if i == 0 else 1e-3) * b, (i, a, b)
     if wire == "fp32":
         lr = 1e-3
         d = (zer[0]["p32"] - rep[0]["p32"]).abs()

@@ -900,3 +900,59 @@ def test_skinny_gemm_with_layernorm_prologue_is_bit_identical_to_two_launches(op
         big = torch.zeros(160, N, dtype=torch.bfloat16, device=DEV)
         with pytest.raises(Exception, match="skinny form only"):
             ops.gemm(torch.zeros(160, K, dtype=torch.bfloat16, device=DEV), W, big, M=160, N=N, K=K, lda=K, ldb=K, ldc=N, a_ln=ln)
+
+
+@pytest.mark.parametrize("M,N,K,al,bl,kind", [(3992, 7680, 1920, 0, 0, "gelu"), (3992, 1920, 1920, 0, 0, "res"),
+                                              (3992, 1920, 5760, 0, 1, "plain"), (7680, 1920, 3992, 1, 1, "wgrad"),
+                                              (2000, 5760, 1024, 0, 0, "bias")])
+def test_gemm_results_do_not_depend_on_the_compute_cu_setting(ops, M, N, K, al, bl, kind):
+    """ca_gemm_set_compute_cus (round 5: the chip shared with a resident collective): every tile of a persistent launch
+    through the counter, launches sized to n CUs, every XCD given the same number of tiles, the tile shape chosen by
+    counting rounds on n CUs - none of it may change a bit of the result (the per-tile sums of squares included, where the
+    tile shape stays the same), also with idle workgroups (ca_debug_cu_hog) holding CUs meanwhile."""
+    g = torch.Generator().manual_seed(M + N + K)
+    A = (torch.randn(M, K, generator=g) * 0.5).to(torch.bfloat16)
+    B = (torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16)
+    A = (A.t().contiguous() if al else A).to(DEV)
+    B = (B.t().contiguous() if bl else B).to(DEV)
+    kw = dict(M=M, N=N, K=K, a_layout=al, b_layout=bl, lda=(M if al else K), ldb=(N if bl else K), ldc=N)
+    bias = torch.randn(N, generator=g).to(DEV)
+    R = torch.randn(M, N, generator=g).to(torch.bfloat16).to(DEV)
+    lib = ops.lib()
+    ncu = torch.cuda.get_device_properties(0).multi_processor_count
+    side = torch.cuda.Stream()
+
+    def run():
+        if kind == "wgrad":
+            G = torch.zeros(M * N, dtype=torch.float32, device=DEV)
+            ops.gemm(A, B, G, out_f32=True, accumulate=False, **kw)
+            return (G,)
+        C1 = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+        if kind == "plain":
+            ops.gemm(A, B, C1, **kw)
+        elif kind == "bias":
+            ops.gemm(A, B, C1, bias=bias, **kw)
+        elif kind == "res":
+            ops.gemm(A, B, C1, bias=bias, R=R, ldr=N, epilogue=ops.EPI_RESIDUAL, **kw)
+        else:
+            C2 = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+            ops.gemm(A, B, C1, bias=bias, C2=C2, c2_off=0, epilogue=ops.EPI_GELU, dropout_p=0.1, dropout_seed=11, **kw)
+            return C1, C2
+        return (C1,)
+
+    try:
+        lib.ca_gemm_set_compute_cus(0)
+        want = run()
+        torch.cuda.synchronize()
+        for cus, hog in ((ncu, 0), (ncu - 32, 0), (ncu - 16, 16), (ncu, 32)):
+            lib.ca_gemm_set_compute_cus(cus)
+            if hog:
+                with torch.cuda.stream(side):
+                    ops.check(lib.ca_debug_cu_hog(hog, 256, 96 * 1024, 20.0, side.cuda_stream), "ca_debug_cu_hog")
+            got = run()
+            torch.cuda.synchronize()
+            for a, b in zip(got, want):
+                assert torch.equal(a, b), (cus, hog)
+    finally:
+        lib.ca_gemm_set_compute_cus(0)
+        torch.cuda.synchronize()
