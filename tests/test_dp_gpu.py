@@ -99,8 +99,15 @@ def test_sharded_optimizer_equals_the_replicated_trainer(tmp_path, wire):
         assert float((zer[0]["p16"] != rep[0]["p16"]).float().mean()) <= 1e-3
         assert float((zer[0]["m"] - rep[0]["m"]).abs().max()) <= 1e-2 * float(rep[0]["m"].abs().max())
     else:
+        # bf16 wire: gradient elements at the noise floor (k_proj.bias, whose true gradient is zero - softmax does not see
+        # a key bias -, and the q / k weights beside it: |g| ~ 3e-7) come off the two exchange paths with other last bits;
+        # AdamW's normalisation turns their sign into a full +-lr step, three steps in a row at worst (round 5, after the
+        # GELU evaluation changed the values: 497 of 4.8 M elements beyond lr, all of them such elements - tools/scratch
+        # diagnosis in NOTEBOOK R5).  Everything else agrees.
+        lr = 1e-3
         d = (zer[0]["p32"] - rep[0]["p32"]).abs()
-        assert float(d.max()) <= 1e-3
+        assert float(d.max()) <= 3.2 * lr, float(d.max())
+        assert float((d <= 0.1 * lr).float().mean()) >= 0.99
 
 
 def test_sharded_optimizer_on_the_whisper_engine(tmp_path):
