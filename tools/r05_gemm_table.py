@@ -2,8 +2,9 @@
    python tools/r05_gemm_table.py [workload ...] [--iters N] [--kernels 0,1,2,3,5]
 Every launch shape of a transformer layer with the epilogue it carries in the step, stand-alone (20 back-to-back
 launches, HIP events), once per kernel: 0 = the automatic choice, 1 = S (128x128, 2 workgroups / CU), 2 = L (256x128,
-3-stage ring), 3 = X (256x256, persistent), 5 = M (128x128 on 8 waves), 6 = Y (256x128 tiles, two independent
-4-wave workgroups per CU; round 5).  Output: one line per (shape, kernel) with tiles / rounds, us and TFLOP/s."""
+3-stage ring), 3 = X (256x256, persistent), 5 = M (128x128 on 8 waves), 6 = P (kernel L's tile in persistent
+workgroups, a tile's outputs stored under the next tile's main loop; round 5).  Output: one line per (shape, kernel)
+with tiles / rounds, us and TFLOP/s."""
 import argparse
 import sys
 from pathlib import Path
@@ -21,8 +22,8 @@ ap.add_argument("--only", default="", help="substring filter on the shape name")
 args = ap.parse_args()
 dev = "cuda:0"
 kernels = [int(k) for k in args.kernels.split(",")]
-KNAME = {0: "auto", 1: "S", 2: "L", 3: "X", 5: "M", 6: "Y"}
-TILE = {1: (128, 128, 512), 2: (256, 128, 256), 3: (256, 256, 256), 5: (128, 128, 256), 6: (256, 128, 512)}
+KNAME = {0: "auto", 1: "S", 2: "L", 3: "X", 5: "M", 6: "P"}
+TILE = {1: (128, 128, 512), 2: (256, 128, 256), 3: (256, 256, 256), 5: (128, 128, 256), 6: (256, 128, 256)}
 
 
 def layer_shapes(M, d, f, qkv_fused=True):
