@@ -478,26 +478,10 @@ __device__ __forceinline__ void slab_read(const float* slab, int p, int lane, f3
   b4 = *(const f32x4_t*)(row + (((c + 1) ^ r) << 2));
 }
 
-// Deferred outputs (kernel P, round 5): what a pass of the specialised walk would store - 16 bytes per lane and output -
-// stays in registers instead (`keep`: pass it -> a[it], b[it]) and leaves, one pass per K-step, from INSIDE the next
-// tile's main loop (the CU's store path, ~12.5 B/clk, is the bound of a tile's epilogue; under the main loop it is 40 %
-// busy).  The pass index is a run-time value of a rolled loop: a wave-uniform switch picks the register (see slab_park).
-struct EpiKeep {
-  u16x8_t a[8], b[8];  // passes of C and of C2 (GELU's second output)
-};
-__device__ __forceinline__ void epi_keep_put(u16x8_t (&arr)[8], int it, const u16x8_t& o) {
-#define KEEP_CASE(I) case I: asm volatile("; keep pass " #I); arr[I] = o; break;
-  switch (it) {
-    KEEP_CASE(0) KEEP_CASE(1) KEEP_CASE(2) KEEP_CASE(3) KEEP_CASE(4) KEEP_CASE(5) KEEP_CASE(6)
-    default: asm volatile("; keep pass 7"); arr[7] = o; break;
-  }
-#undef KEEP_CASE
-}
-
-template <int EPI, bool F32, bool DROP, bool SLAB = false, bool DEFER = false>
+template <int EPI, bool F32, bool DROP, bool SLAB = false>
 __device__ __forceinline__ void gemm_epilogue_fast(const CaGemmDesc& d, const float* wt, int lane, int mw, int nb, int z,
                                                    int64_t zoffC, int64_t zoffR, const float (&bias8)[8], float& ssq,
-                                                   float& amx, const f32x4_t (*acc)[4][4] = nullptr, EpiKeep* kp = nullptr) {
+                                                   float& amx, const f32x4_t (*acc)[4][4] = nullptr) {
   const int M = d.M, N = d.N;
   const float alpha = d.alpha;
   const float keep_scale = DROP ? 1.f / (1.f - d.dropout_p) : 1.f;
@@ -602,23 +586,18 @@ __device__ __forceinline__ void gemm_epilogue_fast(const CaGemmDesc& d, const fl
       u16x8_t o;
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e]);
-      if (DEFER)
-        epi_keep_put(kp->a, it, o);
-      else if (d.c_stream_out)
+      if (d.c_stream_out)
         __builtin_nontemporal_store(o, (u16x8_t*)((unsigned short*)d.C + coff));
       else
         *(u16x8_t*)((unsigned short*)d.C + coff) = o;
-      if (!DEFER && EPI == CA_EPI_DGELU && c8_on) ca_store_fp8x8((unsigned char*)d.C8 + coff, v, s8, amx);
+      if (EPI == CA_EPI_DGELU && c8_on) ca_store_fp8x8((unsigned char*)d.C8 + coff, v, s8, amx);
     }
     if (EPI == CA_EPI_GELU) {
       u16x8_t o;
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] = f2bf(v2[e]);
-      if (DEFER)
-        epi_keep_put(kp->b, it, o);
-      else
-        *(u16x8_t*)((unsigned short*)d.C2 + coff) = o;
-      if (!DEFER && c8_on) ca_store_fp8x8((unsigned char*)d.C8 + coff, v2, s8, amx);
+      *(u16x8_t*)((unsigned short*)d.C2 + coff) = o;
+      if (c8_on) ca_store_fp8x8((unsigned char*)d.C8 + coff, v2, s8, amx);
     }
     coff += cstep;
   }
@@ -627,14 +606,10 @@ __device__ __forceinline__ void gemm_epilogue_fast(const CaGemmDesc& d, const fl
 
 // PARKED: the 64 x 64 staging tile `wave` already holds the accumulators (kernel M: two waves fill one tile)
 // SLAB: `smem` is the wave's own 4-KiB slab (see slab_park); the 64 x 64 tile goes through it 16 rows at a time
-// DEFER (kernel P): an interior wave tile with bf16 output(s) and no fp8 side output leaves its passes in `keep` instead
-// of storing them and reports it through *kept (wave-uniform; 1 = C only, 2 = C and C2); any other tile is stored here.
-template <bool PARKED = false, bool SLAB = false, bool DEFER = false>
+template <bool PARKED = false, bool SLAB = false>
 __device__ __forceinline__ void gemm_epilogue(const CaGemmDesc& d, f32x4_t (&acc)[4][4], char* smem,
                                               int wave, int lane, int mw, int nw, int z, int z1,
-                                              int z2, const float (*bias_pre)[8] = nullptr, EpiKeep* keep = nullptr,
-                                              int* kept = nullptr) {
-  if (DEFER) *kept = 0;
+                                              int z2, const float (*bias_pre)[8] = nullptr) {
   // lane -> 8 consecutive columns of one row; 8 rows per pass, 8 passes; 16-byte bf16 stores
   const int M = d.M, N = d.N;
   const int64_t zoffC = z1 * d.sC1 + z2 * d.sC2;
@@ -688,20 +663,7 @@ __device__ __forceinline__ void gemm_epilogue(const CaGemmDesc& d, f32x4_t (&acc
   const bool interior = g_ca_epi_general == 0 && mw + 64 <= M && nw + 64 <= N && vec_ok && (N & 7) == 0 && d.C != nullptr && drop32_ok &&
                         (d.out_f32 || !d.accumulate) && (!has_gelu || (epi == CA_EPI_GELU && d.C2 != nullptr && !d.out_f32)) &&
                         !(d.out_f32 && epi != CA_EPI_NONE) && !(drop_on && epi == CA_EPI_NONE);
-  if (DEFER && interior && !d.out_f32 && !c8_on) {
-#define EPI_KEEP(E, D) gemm_epilogue_fast<E, false, D, SLAB, true>(d, wt, lane, mw, nb, z, zoffC, zoffR, bias8, ssq, amx, &acc, keep)
-    if (epi == CA_EPI_NONE) {
-      EPI_KEEP(CA_EPI_NONE, false);
-    } else if (epi == CA_EPI_GELU) {
-      if (drop_on) EPI_KEEP(CA_EPI_GELU, true); else EPI_KEEP(CA_EPI_GELU, false);
-    } else if (epi == CA_EPI_RESIDUAL) {
-      if (drop_on) EPI_KEEP(CA_EPI_RESIDUAL, true); else EPI_KEEP(CA_EPI_RESIDUAL, false);
-    } else {
-      if (drop_on) EPI_KEEP(CA_EPI_DGELU, true); else EPI_KEEP(CA_EPI_DGELU, false);
-    }
-#undef EPI_KEEP
-    *kept = epi == CA_EPI_GELU ? 2 : 1;
-  } else if (interior) {
+  if (interior) {
 #define EPI_FAST(E, F, D) gemm_epilogue_fast<E, F, D, SLAB>(d, wt, lane, mw, nb, z, zoffC, zoffR, bias8, ssq, amx, &acc)
     if (d.out_f32) {
       EPI_FAST(CA_EPI_NONE, true, false);
@@ -1202,7 +1164,6 @@ struct CaGemmGroup {
 // counter slots for persistent launches: launches that may be in flight together (two streams) use different slots
 #define X_CNT_SLOTS 64
 __device__ unsigned g_x_cnt[X_CNT_SLOTS][8];
-__device__ unsigned g_p_cnt[X_CNT_SLOTS][8];  // the same for kernel P's launches
 #ifdef X_STAMPS
 __device__ long long g_x_stamps[512 * 8 * 8];
 extern "C" int ca_gemm_x_stamps(long long* host, int n) {
@@ -1914,328 +1875,6 @@ __global__ __launch_bounds__(512) void ca_gemm_kernel_l(const CaGemmDesc d) {
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   gemm_epilogue(d, acc, smem, wave, lane, m0 + wm * 64, n0 + wn * 64, z, z1, z2, &lbias);
-}
-
-// ---- kernel P: kernel L's tile and main loop, persistent, with the outputs of a tile leaving under the NEXT tile ----
-// Round 5.  The epilogue of a tile is bound by the CU's store path (~12.5 B/clk per CU: 5 k cycles for the 64 KB of a
-// 256 x 128 bf16 tile, 10 k with GELU's second output - against 22 k cycles of main loop at K = 1024), and nothing
-// else of the CU works meanwhile.  Here an interior wave tile's epilogue only COMPUTES: its eight passes of 16 bytes per
-// lane (and output) stay in registers (EpiKeep: 32 / 64 VGPRs - kernel L's 64 x 64 wave tile leaves the room, kernel X's
-// 128 x 64 does not) and are stored one pass per K-step from inside the next tile's main loop, where the vector-memory
-// path is 40 % busy; what is left at the end of the launch is flushed.  Workgroups are persistent (one per CU, per-XCD
-// tile counters as in kernel X).  The main loop's counted vmcnt waits stay correct with the stores in between: stores
-// issued after a tile's LDS-DMA pieces only make a wait for "all but the youngest 6" cover more.
-// Ragged wave tiles, fp32 outputs and the fp8 side output take the classic immediate epilogue.
-struct CaGemmPersist {
-  CaGemmDesc d;
-  int vgrid;      // tiles' virtual grid (tile_grid<4, 8> of the 256 x 128 tiling)
-  unsigned* cnt;  // 8 per-XCD counters, or null (one tile per workgroup)
-  int dyn_first;  // every tile through the counter (see CaGemmGroup)
-};
-#define P_LDS_BYTES (L_LDS_BYTES + 64)
-template <int AL, int BL>
-__global__ __launch_bounds__(512) void ca_gemm_kernel_p(const CaGemmPersist pp) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const CaGemmDesc& d = pp.d;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;  // 4 x 2 waves, 64x64 each
-  const int vgrid = pp.vgrid;
-  const int xcd = (int)blockIdx.x & 7;
-  const int npx = ((int)gridDim.x - xcd + 7) >> 3;  // workgroups of this XCD in the launch
-  const int nvx = (vgrid - xcd + 7) >> 3;           // virtual blocks of this XCD
-  volatile unsigned* nextw = (volatile unsigned*)(smem + L_LDS_BYTES);  // two words, alternating per iteration
-  int vb = (int)blockIdx.x;
-  int dbase = npx, dcount = nvx > npx ? nvx - npx : 0;
-  if (pp.cnt != nullptr && pp.dyn_first) {
-    dbase = 0;
-    dcount = nvx;
-    if (tid == 0) {
-      const unsigned i = __hip_atomic_fetch_add(&pp.cnt[xcd], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (i == (unsigned)(dcount + npx - 1)) __hip_atomic_store(&pp.cnt[xcd], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      nextw[1] = i;
-    }
-    __syncthreads();
-    const unsigned i = (unsigned)__builtin_amdgcn_readfirstlane((int)nextw[1]);
-    vb = i < (unsigned)dcount ? xcd + 8 * (int)i : vgrid;
-  }
-  const int z = 0, z1 = 0, z2 = 0;  // (un-batched problems only)
-  const __bf16* A = (const __bf16*)d.A;
-  const __bf16* B = (const __bf16*)d.B;
-  const int K = d.K;
-  const int nk = (K + BK - 1) / BK;
-  // the previous tile's outputs: kept passes, how many outputs (0 = nothing kept), the next pass to store (8 = none left),
-  // this lane's element offset of pass 0 and the offset between passes
-  EpiKeep keep;
-  int kept = 0, pend = 8;
-  int64_t kcoff = 0;
-  const int64_t kcstep = 8 * d.ldc;
-  auto drip = [&](int k) {
-    const int64_t off = kcoff + (int64_t)k * kcstep;
-#define DRIP_CASE(I)                                                                  \
-  case I:                                                                             \
-    asm volatile("; drip pass " #I);                                                  \
-    if (d.c_stream_out)                                                               \
-      __builtin_nontemporal_store(keep.a[I], (u16x8_t*)((unsigned short*)d.C + off)); \
-    else                                                                              \
-      *(u16x8_t*)((unsigned short*)d.C + off) = keep.a[I];                            \
-    if (kept == 2) *(u16x8_t*)((unsigned short*)d.C2 + off) = keep.b[I];              \
-    break;
-    switch (k) {
-      DRIP_CASE(0) DRIP_CASE(1) DRIP_CASE(2) DRIP_CASE(3) DRIP_CASE(4) DRIP_CASE(5) DRIP_CASE(6)
-      default:
-        asm volatile("; drip pass 7");
-        if (d.c_stream_out)
-          __builtin_nontemporal_store(keep.a[7], (u16x8_t*)((unsigned short*)d.C + off));
-        else
-          *(u16x8_t*)((unsigned short*)d.C + off) = keep.a[7];
-        if (kept == 2) *(u16x8_t*)((unsigned short*)d.C2 + off) = keep.b[7];
-        break;
-    }
-#undef DRIP_CASE
-  };
-  for (int iter = 0; vb < vgrid; ++iter) {
-    int vb_next = vgrid;
-    if (pp.cnt != nullptr && tid == 0) {
-      const unsigned i = __hip_atomic_fetch_add(&pp.cnt[xcd], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (i == (unsigned)(dcount + npx - 1)) __hip_atomic_store(&pp.cnt[xcd], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      nextw[iter & 1] = i;
-    }
-    int tm = 0, tn = 0;
-    const bool live = tile_of_block_g<4, 8>(vb, vgrid, (d.M + LBM - 1) / LBM, (d.N + LBN - 1) / LBN, tm, tn, d.xcd_balanced != 0);
-    if (live) {
-    const int m0 = tm * LBM, n0 = tn * LBN;
-    KMajorStream<4> la_k;
-    KMajorStream<2> lb_k;
-    MNMajorStream<4, 32> la_f;
-    MNMajorStream<2, 16> lb_f;
-    if (AL == CA_KMAJOR)
-      la_k.init(A, d.lda, m0, d.M, wave, lane);
-    else
-      la_f.init(A, d.lda, m0, d.M, wave, lane);
-    if (BL == CA_KMAJOR)
-      lb_k.init(B, d.ldb, n0, d.N, wave, lane);
-    else
-      lb_f.init(B, d.ldb, n0, d.N, wave, lane);
-
-    f32x4_t acc[4][4];
-  #pragma unroll
-    for (int i = 0; i < 4; ++i)
-  #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    float lbias[8];  // the lane's bias values, requested a whole main loop ahead of the epilogue
-    epi_load_bias(d, lane, n0 + wn * 64, z1, z2, lbias);
-
-    // LDS: A0 | A1 | A2 (32 KiB each) | B0 | B1 | B2 (16 KiB each)
-    int bst = 0;  // stage of this wave's next burst (every wave issues its share of every tile, in order)
-    auto burst = [&](int kt) {  // this wave's share of tile kt: 4 A pieces + 2 B pieces
-      if (kt >= nk) return;
-      char* na = smem + bst * LA_BYTES;
-      char* nb = smem + L_NST * LA_BYTES + bst * LB_BYTES;
-      bst = bst == L_NST - 1 ? 0 : bst + 1;
-      const bool full = (kt + 1) * BK <= K;  // wave-uniform
-      if (full) {
-  #pragma unroll
-        for (int part = 0; part < 4; ++part) {
-          if (AL == CA_KMAJOR)
-            la_k.issue_one(na, wave, part);
-          else
-            la_f.issue_one(na, wave, part);
-          if (part < 2) {
-            if (BL == CA_KMAJOR)
-              lb_k.issue_one(nb, wave, part);
-            else
-              lb_f.issue_one(nb, wave, part);
-          }
-        }
-      } else {
-  #pragma unroll
-        for (int part = 0; part < 4; ++part) {
-          if (AL == CA_KMAJOR)
-            la_k.issue_one_tail(na, wave, K - kt * BK, part);
-          else
-            la_f.issue_one_tail(na, wave, lane, K - kt * BK, part);
-          if (part < 2) {
-            if (BL == CA_KMAJOR)
-              lb_k.issue_one_tail(nb, wave, K - kt * BK, part);
-            else
-              lb_f.issue_one_tail(nb, wave, lane, K - kt * BK, part);
-          }
-        }
-      }
-      if (AL == CA_KMAJOR) la_k.advance(); else la_f.advance();
-      if (BL == CA_KMAJOR) lb_k.advance(); else lb_f.advance();
-    };
-    auto zero_tail = [&](int kt) {
-      if (kt != nk - 1 || nk * BK == K) return;
-      char* na = smem + (kt % L_NST) * LA_BYTES;
-      char* nb = smem + L_NST * LA_BYTES + (kt % L_NST) * LB_BYTES;
-      const int krem = K - kt * BK;
-      if (AL == CA_KMAJOR) la_k.zero_fix(na, wave, lane, krem); else la_f.zero_fix(na, wave, lane, krem);
-      if (BL == CA_KMAJOR) lb_k.zero_fix(nb, wave, lane, krem); else lb_f.zero_fix(nb, wave, lane, krem);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    };
-    // per-lane fragment base addresses (stage 0; K-major: one per k-half, fragment = immediate offset;
-    // MN-major: one per fragment, k-half = immediate offset)
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
-    uint32_t abase[4], bbase[4];
-    if (AL == CA_KMAJOR) {
-      const int r = wm * 64 + (lane & 15);
-  #pragma unroll
-      for (int sh = 0; sh < 2; ++sh) abase[sh] = lds0 + r * 128 + (((4 * sh + (lane >> 4)) ^ ((r >> 1) & 7)) * 16);
-    } else {
-      const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
-      const int swz = q | ((g & 1) << 2);
-  #pragma unroll
-      for (int f = 0; f < 4; ++f) {
-        const int c = ((((wm * 64 + f * 16) >> 3) + (pp >> 1)) ^ (swz << 1));
-        abase[f] = lds0 + (8 * g + q) * 512 + c * 16 + (pp & 1) * 8;
-      }
-    }
-    if (BL == CA_KMAJOR) {
-      const int r = wn * 64 + (lane & 15);
-  #pragma unroll
-      for (int sh = 0; sh < 2; ++sh)
-        bbase[sh] = lds0 + L_NST * LA_BYTES + r * 128 + (((4 * sh + (lane >> 4)) ^ ((r >> 1) & 7)) * 16);
-    } else {
-      const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
-      const int swz = q | ((g & 1) << 2);
-  #pragma unroll
-      for (int f = 0; f < 4; ++f) {
-        const int c = ((((wn * 64 + f * 16) >> 3) + (pp >> 1)) ^ (swz << 1));
-        bbase[f] = lds0 + L_NST * LA_BYTES + (8 * g + q) * 256 + c * 16 + (pp & 1) * 8;
-      }
-    }
-    // (DS immediate offsets end at 64 KiB: the third A stage gets base registers of its own)
-    uint32_t abase2[4];
-  #pragma unroll
-    for (int f = 0; f < 4; ++f) abase2[f] = abase[f] + 2 * LA_BYTES;
-    bf16x8_t A0[4], A1[4], B0[4], B1[4];
-  #define L_RD_A(ST, SH, F, dst)                                                                      \
-    do {                                                                                              \
-      if (AL == CA_KMAJOR)                                                                            \
-        dst = lds_read_b128<((ST) % 2) * LA_BYTES + (F) * 2048>((ST) == 2 ? abase2[SH] : abase[SH]);  \
-      else                                                                                            \
-        dst = lds_read_tr<((ST) % 2) * LA_BYTES + (SH) * 16384, 2048>((ST) == 2 ? abase2[F] : abase[F]); \
-    } while (0)
-  #define L_RD_B(ST, SH, F, dst)                                                  \
-    do {                                                                          \
-      if (BL == CA_KMAJOR)                                                        \
-        dst = lds_read_b128<(ST) * LB_BYTES + (F) * 2048>(bbase[SH]);             \
-      else                                                                        \
-        dst = lds_read_tr<(ST) * LB_BYTES + (SH) * 8192, 1024>(bbase[F]);         \
-    } while (0)
-  #define L_SB __builtin_amdgcn_sched_barrier(0)
-  #define L_MM2(AF, BF, I, J)                                                                             \
-    do {                                                                                                  \
-      acc[I][J] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[J], AF[I], acc[I][J], 0, 0, 0);              \
-      acc[I][(J) + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[(J) + 1], AF[I], acc[I][(J) + 1], 0, 0, 0); \
-      L_SB;                                                                                               \
-    } while (0)
-    auto kstep = [&](auto st_c, int kt) {
-      constexpr int ST = decltype(st_c)::value;
-      constexpr int NS = (ST + 1) % L_NST;  // stage of tile kt + 1
-      if (wave >= 4) burst(kt + 2);
-      // block 0: k-half 0 of tile kt; reads k-half 1 (same stage)
-      lds_wait(B0);
-      lds_wait(A0);
-      L_SB;
-      __builtin_amdgcn_s_setprio(1);
-      L_MM2(A0, B0, 0, 0); L_RD_B(ST, 1, 0, B1[0]); L_SB;
-      L_MM2(A0, B0, 0, 2); L_RD_B(ST, 1, 1, B1[1]); L_SB;
-      L_MM2(A0, B0, 1, 0); L_RD_B(ST, 1, 2, B1[2]); L_SB;
-      L_MM2(A0, B0, 1, 2); L_RD_B(ST, 1, 3, B1[3]); L_SB;
-      L_MM2(A0, B0, 2, 0); L_RD_A(ST, 1, 0, A1[0]); L_SB;
-      L_MM2(A0, B0, 2, 2); L_RD_A(ST, 1, 1, A1[1]); L_SB;
-      L_MM2(A0, B0, 3, 0); L_RD_A(ST, 1, 2, A1[2]); L_SB;
-      L_MM2(A0, B0, 3, 2); L_RD_A(ST, 1, 3, A1[3]); L_SB;
-      __builtin_amdgcn_s_setprio(0);
-      lds_wait(B1);
-      lds_wait(A1);  // the last fragment reads of tile kt have returned
-      // tile kt+1 has landed (this wave's share; the barrier covers the others), tile kt+2 may still be in flight
-      if (kt + 2 < nk)
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      else
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      zero_tail(kt + 1);
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      if (wave < 4) burst(kt + 3);  // into stage ST: every wave has finished reading tile kt
-      if (pend < 8) {  // one pass of the PREVIOUS tile's outputs leaves per K-step (wave-uniform)
-        drip(pend);
-        ++pend;
-      }
-      L_SB;
-      // block 1: k-half 1 of tile kt; reads k-half 0 of tile kt+1 (harmless stale data after the last tile)
-      __builtin_amdgcn_s_setprio(1);
-      L_MM2(A1, B1, 0, 0); L_RD_B(NS, 0, 0, B0[0]); L_SB;
-      L_MM2(A1, B1, 0, 2); L_RD_B(NS, 0, 1, B0[1]); L_SB;
-      L_MM2(A1, B1, 1, 0); L_RD_B(NS, 0, 2, B0[2]); L_SB;
-      L_MM2(A1, B1, 1, 2); L_RD_B(NS, 0, 3, B0[3]); L_SB;
-      L_MM2(A1, B1, 2, 0); L_RD_A(NS, 0, 0, A0[0]); L_SB;
-      L_MM2(A1, B1, 2, 2); L_RD_A(NS, 0, 1, A0[1]); L_SB;
-      L_MM2(A1, B1, 3, 0); L_RD_A(NS, 0, 2, A0[2]); L_SB;
-      L_MM2(A1, B1, 3, 2); L_RD_A(NS, 0, 3, A0[3]); L_SB;
-      __builtin_amdgcn_s_setprio(0);
-    };
-    burst(0);
-    burst(1);
-    if (nk > 1)
-      asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-    else
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    zero_tail(0);
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    L_RD_B(0, 0, 0, B0[0]); L_RD_B(0, 0, 1, B0[1]); L_RD_B(0, 0, 2, B0[2]); L_RD_B(0, 0, 3, B0[3]);
-    L_RD_A(0, 0, 0, A0[0]); L_RD_A(0, 0, 1, A0[1]); L_RD_A(0, 0, 2, A0[2]); L_RD_A(0, 0, 3, A0[3]);
-    if (wave < 4) burst(2);
-    for (int kt = 0; kt < nk; kt += 3) {
-      kstep(std::integral_constant<int, 0>{}, kt);
-      if (kt + 1 < nk) kstep(std::integral_constant<int, 1>{}, kt + 1);
-      if (kt + 2 < nk) kstep(std::integral_constant<int, 2>{}, kt + 2);
-    }
-  #undef L_RD_A
-  #undef L_RD_B
-  #undef L_MM2
-  #undef L_SB
-
-    unsigned nxt = 0;
-    if (pp.cnt != nullptr) nxt = (unsigned)__builtin_amdgcn_readfirstlane((int)nextw[iter & 1]);  // (K-step barriers after the write)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();  // every wave has read the last K-step: the staging area is free
-    asm volatile("" ::: "memory");
-    if (pp.cnt != nullptr) vb_next = nxt < (unsigned)dcount ? xcd + 8 * (dbase + (int)nxt) : vgrid;
-    while (pend < 8) {  // (a main loop of fewer than 8 K-steps: the rest of the previous tile's passes)
-      drip(pend);
-      ++pend;
-    }
-    {
-      const int mw = m0 + wm * 64, nw = n0 + wn * 64;
-      gemm_epilogue<false, false, true>(d, acc, smem, wave, lane, mw, nw, z, z1, z2, &lbias, &keep, &kept);
-      if (kept) {
-        pend = 0;
-        kcoff = (int64_t)(mw + (lane >> 3)) * d.ldc + nw + 8 * (lane & 7);
-      }
-    }
-    if (pp.cnt != nullptr) {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __syncthreads();  // the staging reads are over before the next tile's first K-steps land in the same LDS
-    }
-    }  // live
-    else if (pp.cnt != nullptr) {
-      __syncthreads();
-      const unsigned i = (unsigned)__builtin_amdgcn_readfirstlane((int)nextw[iter & 1]);
-      vb_next = i < (unsigned)dcount ? xcd + 8 * (dbase + (int)i) : vgrid;
-    }
-    if (pp.cnt == nullptr) break;
-    vb = vb_next;
-  }  // persistent tile loop
-  while (pend < 8) {  // the last tile's outputs
-    drip(pend);
-    ++pend;
-  }
 }
 
 // ---- skinny-M kernel: M <= 32 rows (one decoded token per clip) -------------------------------------
@@ -3123,43 +2762,6 @@ static int ca_gemm_launch(const CaGemmDesc* desc, void* stream) {
     if (cm < best) { best = cm; tenant_kind = 3; }
     use_x = tenant_kind == 2;
     use_l = tenant_kind == 1;
-  }
-  // Kernel P (kernel L's tile, persistent, outputs stored under the next tile's main loop): ca_gemm_force_kernel(6), and
-  // automatically where the rule below says so (use_p)
-  int use_p = (g_force_kernel == 6 && nb == 1 && d.a_kseg == 0 && d.b_kseg == 0 && !d.a_colsum) ? 1 : 0;
-  if (use_p) {
-    static bool pattr = false;
-    if (!pattr) {
-      const void* fs[4] = {(const void*)ca_gemm_kernel_p<0, 0>, (const void*)ca_gemm_kernel_p<0, 1>, (const void*)ca_gemm_kernel_p<1, 0>,
-                           (const void*)ca_gemm_kernel_p<1, 1>};
-      for (int i = 0; i < 4; ++i) hipFuncSetAttribute(fs[i], hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS_BYTES);
-      pattr = true;
-    }
-    CaGemmPersist pp;
-    pp.d = d;
-    pp.vgrid = (int)tile_grid<4, 8>((d.M + LBM - 1) / LBM, (d.N + LBN - 1) / LBN, bal);
-    pp.cnt = nullptr;
-    pp.dyn_first = g_compute_cus > 0 ? 1 : 0;
-    unsigned gx = (unsigned)pp.vgrid;
-    const unsigned pcu = x_compute_cus();
-    static unsigned pseq = 0;
-    if ((unsigned)pp.vgrid > pcu) {
-      unsigned* base = nullptr;
-      if (hipGetSymbolAddress((void**)&base, HIP_SYMBOL(g_p_cnt)) == hipSuccess && base) {
-        pp.cnt = base + (size_t)(pseq++ % X_CNT_SLOTS) * 8;
-        gx = pcu;
-      }
-    }
-    const dim3 grid(gx), block(512);
-    g_last_kind = 1;
-    switch (lay) {
-      case 0: CA_LAUNCH((ca_gemm_kernel_p<0, 0>), grid, block, P_LDS_BYTES, s, pp); break;
-      case 1: CA_LAUNCH((ca_gemm_kernel_p<0, 1>), grid, block, P_LDS_BYTES, s, pp); break;
-      case 2: CA_LAUNCH((ca_gemm_kernel_p<1, 0>), grid, block, P_LDS_BYTES, s, pp); break;
-      default: CA_LAUNCH((ca_gemm_kernel_p<1, 1>), grid, block, P_LDS_BYTES, s, pp); break;
-    }
-    CA_CHECK_LAUNCH("ca_gemm_bf16");
-    return CA_OK;
   }
   g_last_kind = use_x ? 2 : (use_l ? 1 : 0);
   if (use_x) {

@@ -202,9 +202,8 @@ int ca_prof_end(double* ms, int64_t* count, double* flops);
  * tests/ and tools/ do, to run every tile shape through the same parity cases. ---------------------------------------
  * ca_gemm_force_kernel: 0 = automatic kernel choice, 1 = force the 128x128 kernel, 2 = force the 256x128 pipelined
  * kernel, 3 = force the 256x256 kernel, 5 = force the 128x128 tile on 8 waves (kernel M: what the automatic choice runs
- * when the grid has at most one 128x128 tile per CU), 6 = force kernel P (the 256x128 tile in persistent workgroups, a
- * tile's outputs stored under the next tile's main loop; round 5).  (4 was the one-wave-per-SIMD experiment of round 3,
- * NOTEBOOK.md 4.1: measured, not adopted, removed.)
+ * when the grid has at most one 128x128 tile per CU).  (4 was the one-wave-per-SIMD experiment of round 3 and 6 the
+ * deferred-store kernel P of round 5 - NOTEBOOK.md 4.1 / R5.1: measured, not adopted, removed.)
  * ca_gemm_debug_general_epilogue: on != 0 sends every wave tile through the general epilogue walk (interior tiles
  * normally take a specialised, predicate-free form that must give the same bits). */
 int ca_gemm_force_kernel(int which);

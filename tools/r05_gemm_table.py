@@ -2,9 +2,9 @@
    python tools/r05_gemm_table.py [workload ...] [--iters N] [--kernels 0,1,2,3,5]
 Every launch shape of a transformer layer with the epilogue it carries in the step, stand-alone (20 back-to-back
 launches, HIP events), once per kernel: 0 = the automatic choice, 1 = S (128x128, 2 workgroups / CU), 2 = L (256x128,
-3-stage ring), 3 = X (256x256, persistent), 5 = M (128x128 on 8 waves), 6 = P (kernel L's tile in persistent
-workgroups, a tile's outputs stored under the next tile's main loop; round 5).  Output: one line per (shape, kernel)
-with tiles / rounds, us and TFLOP/s."""
+3-stage ring), 3 = X (256x256, persistent), 5 = M (128x128 on 8 waves).  (6 was kernel P - kernel L's tile in persistent
+workgroups with a tile's outputs stored under the next tile's main loop: profiles/r05_gemm_kernel_p.txt, removed.)
+Output: one line per (shape, kernel) with tiles / rounds, us and TFLOP/s."""
 import argparse
 import sys
 from pathlib import Path
