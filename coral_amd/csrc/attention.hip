@@ -840,19 +840,6 @@ __device__ __forceinline__ bf16x8_t gload16_async(const void* p) {
   asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
   return v;
 }
-// the same two with the non-temporal hint: K|V caches of a large decode batch are read once per token and are far larger
-// than the Infinity Cache by the time the next token comes round (64 clips x 24 layers x 6 MB = 9.4 GB)
-__device__ __forceinline__ bf16x8_t gload16_async_nt(const void* p) {
-  bf16x8_t v;
-  asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(v) : "v"(p) : "memory");
-  return v;
-}
-__device__ __forceinline__ void glds16_async_nt(const void* g, char* lds_wave_base) {
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt"
-               :
-               : "v"(g), "s"((uint32_t)(uintptr_t)(lptr_t)lds_wave_base)
-               : "memory", "m0");
-}
 __device__ __forceinline__ void glds16_async(const void* g, char* lds_wave_base) {
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
                :
@@ -869,7 +856,7 @@ __device__ __forceinline__ void glds16_async(const void* g, char* lds_wave_base)
 // at most about two per CU; 2 (64 KiB: two workgroups per CU) for larger batches (round 5: an evaluation batch of 64
 // clips x 16 heads is 1024 workgroups - with one per CU they ran in four rounds, each paying its LayerNorm + query
 // projection prologue in front of its K|V stream; with two per CU one workgroup's prologue runs under the other's stream).
-template <int HDPV, bool QP = false, int DT = 3, bool NT = false>
+template <int HDPV, bool QP = false, int DT = 3>
 __global__ __launch_bounds__(256) void attn_fwd_smallq_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NKS = HDPV / 32, NNB = HDPV / 16;
@@ -1023,8 +1010,7 @@ __global__ __launch_bounds__(256) void attn_fwd_smallq_kernel(const AttnArgs a) 
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) {
         const int dim = 32 * ks + 8 * g;
-        kf[S][blk][ks] = NT ? gload16_async_nt(K + (int64_t)key * a.ldk + (dim < hd ? dim : 0))
-                            : gload16_async(K + (int64_t)key * a.ldk + (dim < hd ? dim : 0));
+        kf[S][blk][ks] = gload16_async(K + (int64_t)key * a.ldk + (dim < hd ? dim : 0));
       }
     }
     constexpr int PC = HDPV / 8, RPI = 64 / PC;
@@ -1037,10 +1023,7 @@ __global__ __launch_bounds__(256) void attn_fwd_smallq_kernel(const AttnArgs a) 
       const int row = kt * 64 + kr;
       const void* src = (row < a.Tk && dim < hd) ? (const void*)(V + (int64_t)row * a.ldv + dim)
                                                  : (const void*)g_attn_zero_page;
-      if (NT)
-        glds16_async_nt(src, img + i * 1024);
-      else
-        glds16_async(src, img + i * 1024);
+      glds16_async(src, img + i * 1024);
     }
   };
   auto step = [&](auto slot_c, int j) {
@@ -2108,15 +2091,12 @@ extern "C" int ca_decode_attn_qproj(const CaAttnDesc* desc, const void* x, int64
   if (!attr) {
     hipFuncSetAttribute((const void*)attn_fwd_smallq_kernel<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     hipFuncSetAttribute((const void*)attn_fwd_smallq_kernel<64, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
-    hipFuncSetAttribute((const void*)attn_fwd_smallq_kernel<64, true, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
     attr = true;
   }
   unsigned sgrid;
   if (int rc = smallq_split(*desc, a, sgrid)) return rc;
-  static const bool nt = [] { const char* e = getenv("CA_SMALLQ_NT"); return e ? atoi(e) != 0 : true; }();
-  if (sgrid >= smallq_two_per_cu() && nt)
-    hipLaunchKernelGGL((attn_fwd_smallq_kernel<64, true, 2, true>), dim3(sgrid), dim3(256), LDS2, (hipStream_t)stream, a);
-  else if (sgrid >= smallq_two_per_cu())
+  // (non-temporal loads of the K|V stream measured slower here: 8 491 -> 8 307 audio-s/s at 128 clips, round 5)
+  if (sgrid >= smallq_two_per_cu())
     hipLaunchKernelGGL((attn_fwd_smallq_kernel<64, true, 2>), dim3(sgrid), dim3(256), LDS2, (hipStream_t)stream, a);
   else
     hipLaunchKernelGGL((attn_fwd_smallq_kernel<64, true>), dim3(sgrid), dim3(256), LDS, (hipStream_t)stream, a);

@@ -13,7 +13,9 @@ for r in csv.DictReader(open(sys.argv[1])):
     d = rows.setdefault(int(r["Dispatch_Id"]), {"k": r["Kernel_Name"].split("(")[0].replace("void ", "")})
     d[r["Counter_Name"]] = d.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
 disp = [rows[k] for k in sorted(rows)]
-shapes = [l for l in open(sys.argv[2]) if l[:1] not in "#\n" and " us" not in l[:8] and "/" in l and not l.startswith("launch")]
+import re
+
+shapes = [l for l in open(sys.argv[2]) if re.search(r"\s(NT|NN|TN|TT)\s+\d", l) and not l.startswith(("launch", "W20", "E20", "I20"))]
 per = 6
 print(f"# {len(disp)} GEMM dispatches, {len(shapes)} shapes")
 for i, line in enumerate(shapes):
