@@ -1159,7 +1159,6 @@ struct CaGemmGroup {
   // first block would then cost one whole tile time at the end of the launch.  dyn_first: every block, the first
   // included, comes from the counter; a workgroup that finds it exhausted exits at once (ca_gemm_set_compute_cus).
   int dyn_first;
-  int stagger_ticks;  // experiment (CA_X_STAGGER_US): every second workgroup of an XCD starts this many 100-MHz ticks late
 };
 // counter slots for persistent launches: launches that may be in flight together (two streams) use different slots
 #define X_CNT_SLOTS 64
@@ -1171,7 +1170,7 @@ extern "C" int ca_gemm_x_stamps(long long* host, int n) {
 }
 #endif
 template <int AL, int BL, bool KS>
-__global__ __launch_bounds__(512) void ca_gemm_kernel_x(const CaGemmGroup grp) {
+__device__ __forceinline__ void gemm_x_body(const CaGemmGroup& grp) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -1206,11 +1205,6 @@ __global__ __launch_bounds__(512) void ca_gemm_kernel_x(const CaGemmGroup grp) {
   MNMajorLoader<4, 32, KS> la_m, lb_m;
   bool pre = false;
   int pre_tm = 0, pre_tn = 0;
-  if (grp.stagger_ticks > 0 && (((int)blockIdx.x >> 3) & 1)) {
-    // (experiment: would the launch gain if the CUs' epilogues - 128-256 KB of stores each - did not coincide?)
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)grp.stagger_ticks) __builtin_amdgcn_s_sleep(8);
-  }
   int vb = (int)blockIdx.x;
   int dbase = npx, dcount = ndyn;  // dynamic blocks of this XCD: local indices dbase .. dbase + dcount - 1
   if (grp.cnt != nullptr && grp.dyn_first) {
@@ -1644,6 +1638,22 @@ __global__ __launch_bounds__(512) void ca_gemm_kernel_x(const CaGemmGroup grp) {
   if (grp.cnt == nullptr) break;
   vb = vb_next;
   }  // persistent tile loop
+}
+
+template <int AL, int BL, bool KS>
+__global__ __launch_bounds__(512) void ca_gemm_kernel_x(const CaGemmGroup grp) {
+  gemm_x_body<AL, BL, KS>(grp);
+}
+// The NT form (every forward GEMM of the training step) is held to 224 registers per lane: the background AdamW of the
+// overlapped optimiser (misc.hip adamw_kernel, 60 -> 64 registers, one workgroup per CU) then fits beside the two waves
+// per SIMD of a persistent workgroup (2 x 224 + 64 = 512).  At 225 the allocation granule of 8 makes it 2 x 232: the two
+// kernels stop sharing CUs, alternate instead, and the XLS-R-2B step went from 72 to 91 ms (NOTEBOOK.md R5.6).
+// (amdgpu_num_vgpr counts one half of gfx950's unified VGPR|AGPR file: 112 = 224 registers; tests/test_build.py checks
+// the code object.)
+template <>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(112)))
+void ca_gemm_kernel_x<CA_KMAJOR, CA_KMAJOR, false>(const CaGemmGroup grp) {
+  gemm_x_body<CA_KMAJOR, CA_KMAJOR, false>(grp);
 }
 
 // ---- kernel L: 256x128 tile, 8 waves (4x2, 64x64 each), 3 LDS stages, one workgroup per CU ---------------------
@@ -2548,8 +2558,6 @@ static void x_launch_geometry(CaGemmGroup& g, unsigned vgrid, unsigned nbz, dim3
   g.vgrid = (int)vgrid;
   g.cnt = nullptr;
   g.dyn_first = g_compute_cus > 0 ? 1 : 0;
-  static const int stagger = [] { const char* e = getenv("CA_X_STAGGER_US"); return e ? (int)(atof(e) * 100.0) : 0; }();
-  g.stagger_ticks = stagger;
   grid = dim3(vgrid, 1, nbz);
   if (persist && nbz == 1 && vgrid > ncu) {
     unsigned* base = nullptr;
