@@ -99,6 +99,14 @@ class CaAttnDesc(C.Structure):
                    ("split_ws", C.c_void_p), ("split_ws_bytes", C.c_int64)])
 
 
+class CaFp8RefreshTask(C.Structure):
+    """Mirror of `CaFp8RefreshTask` in include/coral_amd.h."""
+
+    _fields_ = ([(n, C.c_void_p) for n in ("x_bf16", "q_fp8", "q_fp8_t", "scale", "amax_next")]
+                + [("rows", C.c_int32), ("cols", C.c_int32)])
+
+
+FP8_GROUP_MAX = 8  # CA_FP8_GROUP_MAX
 KMAJOR, MNMAJOR = 0, 1
 EPI_NONE, EPI_GELU, EPI_RESIDUAL, EPI_DGELU, EPI_GELU_RESIDUAL = 0, 1, 2, 3, 4
 
@@ -117,6 +125,7 @@ SIGNATURES = {
     "ca_fp8_amax_rotate": (C.c_int, [_vp, _vp, _vp, _i32, _f32, _vp]),
     "ca_dropout_rows_fp8": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _u64, _vp]),
     "ca_quantize_fp8_transposed": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp]),
+    "ca_fp8_refresh_group": (C.c_int, [_vp, _i32, _vp]),
     "ca_gemm_force_kernel": (C.c_int, [C.c_int]),
     "ca_gemm_debug_general_epilogue": (C.c_int, [C.c_int]),
     "ca_debug_cu_hog": (C.c_int, [_i32, _i32, _i32, C.c_double, _vp]),
@@ -204,6 +213,7 @@ SIGNATURES = {
         [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i64, _i32, _vp],
     ),
     "ca_argmax_masked": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i64, _vp]),
+    "ca_argmax_advance": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _i32, _vp]),
     "ca_embed_tokens": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
     "ca_embed_tokens_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
     "ca_comm_unique_id": (C.c_int, [_vp]),

@@ -2677,12 +2677,18 @@ static int ca_gemm_launch(const CaGemmDesc* desc, void* stream) {
     g_last_kind = 0;
     CA_CHECK_ARG(d.c_split_n == 0 || (d.C_hi && (d.c_split_n % 16) == 0 && d.c_split_n < d.N && d.epilogue == CA_EPI_NONE),
                  "ca_gemm_bf16: c_split_n needs C_hi, a multiple of 16 below N and no epilogue");
-    const unsigned gy = d.M <= 32 ? 1u : (unsigned)((d.M + 31) / 32);  // row blocks of 32 (blockIdx.y)
+    unsigned gy = d.M <= 32 ? 1u : (unsigned)((d.M + 31) / 32);  // row blocks of 32 (blockIdx.y)
+    // 33 .. 128 rows against a narrow weight (N = d_model: 64 column blocks): 32-row blocks leave CUs without a
+    // workgroup (128 of 256 at 64 clips) while each workgroup streams 64 KB of rows per 1024 k beside its 32 KB of
+    // weights; 16-row blocks double the workgroups at 2/3 of the bytes each (same K split per output: same bits)
+    static const int mb1 = [] { const char* e = getenv("CA_SKINNY_MB1"); return e ? atoi(e) : 1; }();
+    const bool rows16 = mb1 && d.M > 32 && (unsigned)((d.N + 15) / 16) * gy < x_device_cus();
+    if (rows16) gy = (unsigned)((d.M + 15) / 16);
     const dim3 grid((unsigned)((d.N + 15) / 16), gy);
     if (d.a_ln_gamma) {
       CA_CHECK_ARG(d.a_ln_beta && d.K <= 2048 && ((uintptr_t)d.a_ln_gamma % 16) == 0 && ((uintptr_t)d.a_ln_beta % 16) == 0,
                    "ca_gemm_bf16: a_ln_gamma needs a_ln_beta, K <= 2048 and 16-byte aligned vectors");
-      const int mb = d.M <= 16 ? 1 : 2;  // (33 .. 128 rows: 32-row blocks over blockIdx.y)
+      const int mb = (d.M <= 16 || rows16) ? 1 : 2;  // (33 .. 128 rows: 32- or 16-row blocks over blockIdx.y)
       const int nch = (d.K + 511) / 512 <= 2 ? 2 : (d.K + 511) / 512;
       const size_t lds = (size_t)4 * mb * 256 * sizeof(float) + (size_t)16 * mb * (d.K + SKINNY_LN_PAD) * 2;
 #define SKINNY_LN(MBV, NCHV)                                                                                         \
@@ -2702,7 +2708,7 @@ static int ca_gemm_launch(const CaGemmDesc* desc, void* stream) {
       else if (nch == 3) SKINNY_LN(2, 3);
       else SKINNY_LN(2, 4);
 #undef SKINNY_LN
-    } else if (d.M <= 16) {
+    } else if (d.M <= 16 || rows16) {
       CA_LAUNCH((ca_gemm_skinny_kernel<1, 0>), grid, dim3(256), 4 * 256 * sizeof(float), s, d);
     } else {
       CA_LAUNCH((ca_gemm_skinny_kernel<2, 0>), grid, dim3(256), 8 * 256 * sizeof(float), s, d);

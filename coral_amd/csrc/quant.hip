@@ -116,6 +116,112 @@ extern "C" int ca_quantize_fp8_delayed(const void* x_bf16, int64_t n, void* q_fp
   return CA_OK;
 }
 
+// ---- one launch per layer: straight + transposed e4m3 copies of up to eight weight matrices -------------------------
+// The per-step refresh of a whisper-large-turbo encoder layer was seven launches (four ca_quantize_fp8_delayed, three
+// ca_quantize_fp8_transposed: 224 launches and 1.6 ms per step, each matrix read twice).  ca_fp8_refresh_group walks the
+// 64 x 64 tiles of all of a layer's matrices in ONE launch: a tile is read once, quantised with the matrix's delayed
+// scale, stored straight (16 bytes per thread) and - where asked - transposed through LDS; the matrix's amax
+// accumulates as in fp8_cast_delayed_kernel.  Same arithmetic per element as the two kernels above: the copies are
+// bit-identical, the amax words hold the same maximum.
+struct Fp8GroupArgs {
+  CaFp8RefreshTask t[CA_FP8_GROUP_MAX];
+  int first[CA_FP8_GROUP_MAX + 1];  // first tile of task i; first[count] = the grid
+  int count;
+};
+__global__ __launch_bounds__(256) void fp8_refresh_group_kernel(const Fp8GroupArgs a) {
+  __shared__ unsigned char tile[64][64 + 8];  // tile[c][r]
+  __shared__ float red[4];
+  int ti = 0;
+#pragma unroll
+  for (int i = 1; i < CA_FP8_GROUP_MAX; ++i)
+    if (i < a.count && (int)blockIdx.x >= a.first[i]) ti = i;
+  const CaFp8RefreshTask t = a.t[ti];
+  const int rows = t.rows, cols = t.cols;
+  const int tcols = (cols + 63) / 64;
+  const int lt = (int)blockIdx.x - a.first[ti];
+  const int r0 = (lt / tcols) * 64, c0 = (lt % tcols) * 64;
+  const unsigned short* x = (const unsigned short*)t.x_bf16;
+  unsigned char* q = (unsigned char*)t.q_fp8;
+  unsigned char* qt = (unsigned char*)t.q_fp8_t;
+  const float scale = t.scale[0];
+  float m = 0.f;
+  {  // thread -> (row of the tile, 16 consecutive columns)
+    const int r = threadIdx.x >> 2, cq = (threadIdx.x & 3) * 16;
+    if (r0 + r < rows) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int c = cq + 8 * h;
+        if (c0 + c < cols) {  // cols % 8 == 0: a chunk is all-or-nothing
+          const u16x8_t u = *(const u16x8_t*)(x + (int64_t)(r0 + r) * cols + c0 + c);
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float f = bf2f(u[e]);
+            m = fmaxf(m, fabsf(f));
+            v[e] = fminf(fmaxf(f * scale, -FP8_MAX), FP8_MAX);
+          }
+          unsigned int w0 = 0, w1 = 0;
+          w0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], w0, false);
+          w0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], w0, true);
+          w1 = __builtin_amdgcn_cvt_pk_fp8_f32(v[4], v[5], w1, false);
+          w1 = __builtin_amdgcn_cvt_pk_fp8_f32(v[6], v[7], w1, true);
+          *(uint2*)(q + (int64_t)(r0 + r) * cols + c0 + c) = make_uint2(w0, w1);
+          if (qt) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              tile[c + e][r] = (unsigned char)((w0 >> (8 * e)) & 0xffu);
+              tile[c + 4 + e][r] = (unsigned char)((w1 >> (8 * e)) & 0xffu);
+            }
+          }
+        }
+      }
+    }
+  }
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0 && t.amax_next)
+    atomicMax(t.amax_next + (lt & (CA_FP8_AMAX_SLOTS - 1)),
+              __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
+  if (qt) {  // thread -> (column of x = row of q_t, 16 consecutive rows of x)
+    const int c = threadIdx.x >> 2, rq = (threadIdx.x & 3) * 16;
+    if (c0 + c < cols) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int r = rq + 8 * h;
+        if (r0 + r + 8 <= rows) {
+          *(uint2*)(qt + (int64_t)(c0 + c) * rows + r0 + r) = *(const uint2*)&tile[c][r];
+        } else {
+          for (int e = 0; e < 8; ++e)
+            if (r0 + r + e < rows) qt[(int64_t)(c0 + c) * rows + r0 + r + e] = tile[c][r + e];
+        }
+      }
+    }
+  }
+}
+extern "C" int ca_fp8_refresh_group(const CaFp8RefreshTask* tasks, int32_t count, void* stream) {
+  CA_CHECK_ARG(tasks && count > 0 && count <= CA_FP8_GROUP_MAX, "ca_fp8_refresh_group: 1 .. CA_FP8_GROUP_MAX tasks");
+  Fp8GroupArgs a;
+  int64_t total = 0;
+  for (int i = 0; i < count; ++i) {
+    const CaFp8RefreshTask& t = tasks[i];
+    CA_CHECK_ARG(t.x_bf16 && t.q_fp8 && t.scale && t.rows > 0 && t.cols > 0 && (t.cols % 8) == 0 &&
+                     ((uintptr_t)t.x_bf16 % 16) == 0 && ((uintptr_t)t.q_fp8 % 8) == 0,
+                 "ca_fp8_refresh_group: cols must be a multiple of 8, x 16-byte and q 8-byte aligned");
+    CA_CHECK_ARG(!t.q_fp8_t || ((t.rows % 8) == 0 && ((uintptr_t)t.q_fp8_t % 8) == 0),
+                 "ca_fp8_refresh_group: a transposed copy needs rows % 8 == 0 and an 8-byte aligned destination");
+    a.t[i] = t;
+    a.first[i] = (int)total;
+    total += (int64_t)((t.rows + 63) / 64) * ((t.cols + 63) / 64);
+    CA_CHECK_ARG(total < (1ll << 31), "ca_fp8_refresh_group: too many tiles");
+  }
+  for (int i = count; i <= CA_FP8_GROUP_MAX; ++i) a.first[i] = (int)total;
+  a.count = count;
+  hipLaunchKernelGGL(fp8_refresh_group_kernel, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, a);
+  CA_CHECK_LAUNCH("ca_fp8_refresh_group");
+  return CA_OK;
+}
+
 // amax of tensor i = max over its CA_FP8_AMAX_SLOTS words; scale[i] = 448 / (margin * amax), inv_scale[i] = its reciprocal (the dequantisation factor ca_gemm_fp8 takes),
 // amax_next[i] = 0 - for every tensor whose amax was measured since the last rotation (a zero word keeps the old scale).
 __global__ void fp8_rotate_kernel(unsigned int* __restrict__ amax_next, float* __restrict__ scale,

@@ -208,10 +208,21 @@ extern "C" int ca_cross_entropy_fwd_bwd(const float* logits, const int32_t* labe
 // ---- masked argmax (greedy generation) -------------------------------------------------------
 // one 1024-thread workgroup per row (greedy decoding has B rows of ~52 k logits: a wave per row would walk
 // 800 dependent loads); ties resolve to the lowest index like torch.argmax.
+// adv (ca_argmax_advance): the bookkeeping of a greedy step in the same launch - the row's last thread also records the
+// token and moves the row's cursors (eight tiny dependent launches per decoded token otherwise, ~4 us each in a graph)
+struct ArgmaxAdvance {
+  uint8_t* done;    // [rows] finished flags (a finished row records pad)
+  int64_t* ids;     // [rows, ld_ids] generated ids; the token goes to column pos[row] + 1
+  int64_t ld_ids;
+  int32_t* tok;     // [rows] next input token
+  int32_t* pos;     // [rows] position of the token just fed (+1 here)
+  int32_t* klen;    // [rows] cached keys (+1 here)
+  int32_t pad, eos;
+};
 __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ lg,
                                                       const uint8_t* __restrict__ suppress,
                                                       int32_t* __restrict__ out, int64_t rows,
-                                                      int V, int64_t ldv) {
+                                                      int V, int64_t ldv, const ArgmaxAdvance adv) {
   __shared__ float sb[16];
   __shared__ int si[16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -263,15 +274,37 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ 
         best = sb[w];
         bi = si[w];
       }
-    out[row] = bi == 0x7fffffff ? 0 : bi;
+    bi = bi == 0x7fffffff ? 0 : bi;
+    out[row] = bi;
+    if (adv.ids) {
+      const int32_t p = adv.pos[row];
+      const int32_t step = adv.done[row] ? adv.pad : bi;
+      adv.ids[row * adv.ld_ids + p + 1] = step;
+      if (step == adv.eos) adv.done[row] = 1;
+      adv.tok[row] = step;
+      adv.pos[row] = p + 1;
+      adv.klen[row] += 1;
+    }
   }
 }
 
 extern "C" int ca_argmax_masked(const float* logits, const uint8_t* suppress, int32_t* out,
                                 int64_t rows, int32_t V, int64_t ldv, void* stream) {
   CA_CHECK_ARG(logits && out && rows > 0 && V > 0 && ldv >= V, "ca_argmax_masked: bad argument");
+  ArgmaxAdvance none = {};
   hipLaunchKernelGGL(argmax_kernel, dim3((unsigned)rows), dim3(1024), 0, (hipStream_t)stream, logits,
-                     suppress, out, rows, V, ldv);
+                     suppress, out, rows, V, ldv, none);
   CA_CHECK_LAUNCH("ca_argmax_masked");
+  return CA_OK;
+}
+extern "C" int ca_argmax_advance(const float* logits, const uint8_t* suppress, int32_t* out, int64_t rows, int32_t V,
+                                 int64_t ldv, uint8_t* done, int64_t* ids, int64_t ld_ids, int32_t* tok, int32_t* pos,
+                                 int32_t* klen, int32_t pad_id, int32_t eos_id, void* stream) {
+  CA_CHECK_ARG(logits && out && rows > 0 && V > 0 && ldv >= V && done && ids && tok && pos && klen && ld_ids > 0,
+               "ca_argmax_advance: bad argument");
+  ArgmaxAdvance adv = {done, ids, ld_ids, tok, pos, klen, pad_id, eos_id};
+  hipLaunchKernelGGL(argmax_kernel, dim3((unsigned)rows), dim3(1024), 0, (hipStream_t)stream, logits,
+                     suppress, out, rows, V, ldv, adv);
+  CA_CHECK_LAUNCH("ca_argmax_advance");
   return CA_OK;
 }

@@ -160,6 +160,19 @@ def quantize_fp8_transposed(x, rows, cols, qt, scale, x_off=0, qt_off=0):
           "ca_quantize_fp8_transposed")
 
 
+def fp8_refresh_group(tasks):
+    """One launch for a layer's e4m3 weight copies.  tasks: (x, x_off, rows, cols, q, q_off, qt or None, qt_off, scale,
+    amax_next or None) with offsets in elements; straight copy as quantize_fp8_delayed, transposed copy as
+    quantize_fp8_transposed."""
+    for i in range(0, len(tasks), _lib.FP8_GROUP_MAX):
+        part = tasks[i:i + _lib.FP8_GROUP_MAX]
+        arr = (_lib.CaFp8RefreshTask * len(part))()
+        for t, (x, x_off, rows, cols, q, q_off, qt, qt_off, scale, amax) in zip(arr, part):
+            t.x_bf16, t.q_fp8, t.q_fp8_t = _p(x, x_off), _p(q, q_off), _p(qt, qt_off)
+            t.scale, t.amax_next, t.rows, t.cols = _p(scale), _p(amax), rows, cols
+        check(lib().ca_fp8_refresh_group(arr, len(part), _stream()), "ca_fp8_refresh_group")
+
+
 def quantize_fp8(x, q, inv_scale, amax_ws, n=None):
     """bf16 tensor -> e4m3 bytes (uint8 tensor q) + inv_scale (1 float on the device)."""
     check(lib().ca_quantize_fp8(_p(x), x.numel() if n is None else n, _p(q), _p(inv_scale), _p(amax_ws), _stream()),
@@ -618,6 +631,14 @@ def cross_entropy_fwd_bwd(logits, labels, loss_sum, count, grad, rows, V, ldv, i
 def argmax_masked(logits, suppress, out, rows, V, ldv):
     check(lib().ca_argmax_masked(_p(logits), _p(suppress), _p(out), rows, V, ldv, _stream()),
           "ca_argmax_masked")
+
+
+def argmax_advance(logits, suppress, out, rows, V, ldv, done, ids, tok, pos, klen, pad_id, eos_id):
+    """argmax_masked + the greedy step's bookkeeping (record the token, finished rows take pad, move the cursors)."""
+    if done.dtype != torch.bool or ids.dtype != torch.int64 or ids.dim() != 2 or ids.stride(1) != 1:
+        raise CoralAmdError("argmax_advance: done must be bool, ids a row-major int64 matrix")
+    check(lib().ca_argmax_advance(_p(logits), _p(suppress), _p(out), rows, V, ldv, done.data_ptr(), _p(ids), ids.stride(0),
+                                  _p(tok), _p(pos), _p(klen), int(pad_id), int(eos_id), _stream()), "ca_argmax_advance")
 
 
 def embed_tokens(table, pos, ids, pos_ids, y, rows, Cn):

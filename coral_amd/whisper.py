@@ -521,7 +521,7 @@ class WhisperEngine:
             out=torch.full((B, Lmax), pad_id, dtype=torch.int64, device=dev),
             logits=torch.zeros(B, _r8(s.vocab_size), dtype=torch.float32, device=dev),
             kvnew=torch.zeros(B * 2 * s.d_model, dtype=torch.bfloat16, device=dev),
-            rows=torch.arange(B, device=dev), pad=torch.full((B,), pad_id, dtype=torch.int32, device=dev),
+            rows=torch.arange(B, device=dev), pad=torch.full((B,), pad_id, dtype=torch.int32, device=dev), pad_id=pad_id,
             eos=eos_id, cross=cross_kv)
         return st
 
@@ -535,7 +535,13 @@ class WhisperEngine:
         w = self._decoder_ws(B, 1)
         import os
 
-        fused = os.environ.get("CA_DECODE_FUSED", "1") != "0" and hd <= 64 and d <= 2048
+        # LayerNorm + query projection inside the cross-attention launch: every (clip, head) workgroup streams its head's
+        # 64 x d slice of Wq in its prologue (128 KB at d = 1024, a third of the K|V it then streams) - worth it while the
+        # launch is short of workgroups (32 clips x 16 heads = 2 per CU: 3.05 against 3.14 ms per token), not above (64
+        # clips: 4.17 against 4.02, 128: 7.34 against 6.96; round 5).  CA_DECODE_FUSED = 0 / 1 forces either.
+        fz = os.environ.get("CA_DECODE_FUSED")
+        ncu = torch.cuda.get_device_properties(self.device).multi_processor_count
+        fused = (fz != "0" if fz is not None else B * H <= 2 * ncu) and hd <= 64 and d <= 2048
         ops.embed_tokens(p16[o("model.decoder.embed_tokens.weight"):], p16[o("model.decoder.embed_positions.weight"):],
                          g["tok"], g["pos"], w["h"][0], B, d)
         h0, h1 = w["h"][0], w["h"][1]
@@ -571,10 +577,13 @@ class WhisperEngine:
                                       scale=hd ** -0.5, ldk=2 * d, ldv=2 * d, ldo=d, skb=Te * 2 * d, svb=Te * 2 * d,
                                       sob=d, k_off=0, v_off=d, split_ws=w["split"])
             else:
-                ops.layernorm_fwd(h1, st.view(p + "encoder_attn_layer_norm.weight"), st.view(p + "encoder_attn_layer_norm.bias"),
-                                  w["x"], None, B, d, s.layer_norm_eps)
-                ops.gemm(w["x"], p16, w["q"], M=B, N=d, K=d, lda=d, ldb=d, ldc=d, b_off=o(p + "encoder_attn.q_proj.weight"),
-                         bias=p32, bias_off=o(p + "encoder_attn.q_proj.bias"))
+                if not ln_in:
+                    ops.layernorm_fwd(h1, st.view(p + "encoder_attn_layer_norm.weight"), st.view(p + "encoder_attn_layer_norm.bias"),
+                                      w["x"], None, B, d, s.layer_norm_eps)
+                ops.gemm(h1 if ln_in else w["x"], p16, w["q"], M=B, N=d, K=d, lda=d, ldb=d, ldc=d,
+                         b_off=o(p + "encoder_attn.q_proj.weight"), bias=p32, bias_off=o(p + "encoder_attn.q_proj.bias"),
+                         a_ln=(st.view(p + "encoder_attn_layer_norm.weight"), st.view(p + "encoder_attn_layer_norm.bias"),
+                               s.layer_norm_eps) if ln_in else None)
                 ops.attn_fwd(w["q"], g["cross"][l], g["cross"][l], w["ctx"], self._lse(B * H * 32), B=B, H=H, Tq=1, Tk=Te,
                              hd=hd, Tqp=32, scale=hd ** -0.5, ldq=d, ldk=2 * d, ldv=2 * d, ldo=d, sqb=d, skb=Te * 2 * d,
                              svb=Te * 2 * d, sob=d, k_off=0, v_off=d, split_ws=w["split"])
@@ -586,14 +595,10 @@ class WhisperEngine:
                           w["hf"], None, B, d, s.layer_norm_eps)
         V, Vp = s.vocab_size, _r8(s.vocab_size)
         ops.gemm(w["hf"], p16, g["logits"], M=B, N=V, K=d, lda=d, ldb=d, ldc=Vp, b_off=o("model.decoder.embed_tokens.weight"))
-        ops.argmax_masked(g["logits"], suppress, g["nxt"], B, V, Vp)
-        step = torch.where(g["done"], g["pad"], g["nxt"])
-        g["out"][g["rows"], g["cur"].expand(B)] = step.long()
-        g["done"] |= step == g["eos"]
-        g["tok"].copy_(step)
-        g["pos"] += 1
-        g["klen"] += 1
-        g["cur"] += 1
+        # argmax + the step's bookkeeping in one launch: out[b, pos + 1] = the token (pad for finished rows), done |= eos,
+        # tok = the token, pos += 1, klen += 1
+        ops.argmax_advance(g["logits"], suppress, g["nxt"], B, V, Vp, g["done"], g["out"], g["tok"], g["pos"], g["klen"],
+                           g["pad_id"], g["eos"])
 
     # ---- model-level API -------------------------------------------------------------------------
     def forward(self, input_features, labels=None, decoder_input_ids=None):

@@ -132,22 +132,24 @@ class WhisperTrainEngine(WhisperEngine):
         if f8 is None:
             return
         st = self.store
+        d, f = self.s.d_model, self.s.encoder_ffn_dim
+        S = ops.FP8_AMAX_SLOTS
+        shapes = ((3 * d, d), (d, d), (f, d), (d, f))  # [rows, cols] of q|k|v, out_proj, fc1, fc2
         for l in (range(self.s.encoder_layers) if layer is None else (layer,)):
+            # one launch per layer (ca_fp8_refresh_group): every matrix read once; straight copies with this step's
+            # amax for the next scale, transposed copies (same scale) for the fp8 data gradients
+            tasks = []
+            base = l * (2 * f * d + d * d)
+            t_off = {3: base, 1: base + f * d, 2: base + f * d + d * d}  # fc2^T [f, d] | out_proj^T [d, d] | fc1^T [d, f]
             for k, (name, n) in enumerate(self._fp8_weights(l)):
                 if (k == 3 and not f8["ffn2"]) or (k == 1 and not f8["out8"]):
                     continue
                 off, i = st.off(name), 4 * l + k
-                ops.quantize_fp8_delayed(st.p16[off:off + n], f8["p8"][off:off + n], f8["scale"][i:i + 1],
-                                         f8["amax"][i * ops.FP8_AMAX_SLOTS:], n=n)
-                if f8["dgrad"] and k in (1, 2, 3):  # the transposed copy, same scale
-                    d, f = self.s.d_model, self.s.encoder_ffn_dim
-                    base = l * (2 * f * d + d * d)
-                    if k == 3:    # fc2 [d, f] -> [f, d]
-                        ops.quantize_fp8_transposed(st.p16, d, f, f8["p8t"], f8["scale"][i:i + 1], x_off=off, qt_off=base)
-                    elif k == 1:  # out_proj [d, d]
-                        ops.quantize_fp8_transposed(st.p16, d, d, f8["p8t"], f8["scale"][i:i + 1], x_off=off, qt_off=base + f * d)
-                    elif f8["dgrad_fc1"]:  # fc1 [f, d] -> [d, f]
-                        ops.quantize_fp8_transposed(st.p16, f, d, f8["p8t"], f8["scale"][i:i + 1], x_off=off, qt_off=base + f * d + d * d)
+                tr = f8["dgrad"] and (k in (1, 3) or (k == 2 and f8["dgrad_fc1"]))
+                rows, cols = shapes[k]
+                tasks.append((st.p16, off, rows, cols, f8["p8"], off, f8["p8t"] if tr else None, t_off.get(k, 0),
+                              f8["scale"][i:i + 1], f8["amax"][i * S:]))
+            ops.fp8_refresh_group(tasks)
 
     def refresh_bucket(self, name: str):
         """Trainer hook: bucket `name` has just been updated (on the trainer's optimiser stream).  The first bucket of a

@@ -183,6 +183,20 @@ int ca_dropout_rows_fp8(const void* x, void* y, void* q_fp8, float* row_scale, i
                         uint64_t seed, void* stream);
 int ca_quantize_fp8_transposed(const void* x_bf16, int32_t rows, int32_t cols, void* q_fp8_t, const float* scale,
                                void* stream);
+/* The per-step refresh of a layer's e4m3 weight copies in ONE launch: for each task, q_fp8 [rows, cols] =
+ * e4m3(clamp(x * scale[0])) exactly as ca_quantize_fp8_delayed (amax of x accumulated into amax_next, may be NULL) and,
+ * when q_fp8_t is not NULL, the transposed copy [cols, rows] exactly as ca_quantize_fp8_transposed.  cols % 8 == 0;
+ * a transposed copy also needs rows % 8 == 0. */
+#define CA_FP8_GROUP_MAX 8
+typedef struct CaFp8RefreshTask {
+  const void* x_bf16;
+  void* q_fp8;
+  void* q_fp8_t;       /* or NULL */
+  const float* scale;  /* device scalar */
+  uint32_t* amax_next; /* CA_FP8_AMAX_SLOTS words, or NULL */
+  int32_t rows, cols;
+} CaFp8RefreshTask;
+int ca_fp8_refresh_group(const CaFp8RefreshTask* tasks, int32_t count, void* stream);
 /* Up to eight independent plain GEMMs of the same operand form (same a_layout / b_layout, un-batched, no epilogue,
  * no bias) in one launch of the 256x256 kernel: for problems that under-fill the chip one by one, e.g. the four
  * weight gradients of an encoder layer or the six token-side ones of a Whisper decoder layer (each replaces a
@@ -536,6 +550,13 @@ int ca_cross_entropy_fwd_bwd(const float* logits, const int32_t* labels, float* 
  * out[r] = argmax_v (logits[r,v] if !suppress[v]); suppress uint8 [V] or NULL. */
 int ca_argmax_masked(const float* logits, const uint8_t* suppress, int32_t* out,
                      int64_t rows, int32_t V, int64_t ldv, void* stream);
+/* The same argmax and, in the same launch, the bookkeeping of a greedy step
+ * ($TF/generation/utils.py `_sample`: finished rows take pad, `unfinished_sequences` falls on eos): with t = done[r] ?
+ * pad_id : out[r]:  ids[r, pos[r] + 1] = t;  done[r] |= t == eos_id;  tok[r] = t;  pos[r] += 1;  klen[r] += 1.  All state
+ * lives in device memory, so the step replays as part of a graph. */
+int ca_argmax_advance(const float* logits, const uint8_t* suppress, int32_t* out, int64_t rows, int32_t V, int64_t ldv,
+                      uint8_t* done, int64_t* ids, int64_t ld_ids, int32_t* tok, int32_t* pos, int32_t* klen,
+                      int32_t pad_id, int32_t eos_id, void* stream);
 /* embedding gather: y[r,:] = table[ids[r],:] + pos[pos_ids[r],:]  (bf16 tables)
  * $TF/models/whisper/modeling_whisper.py:204-212,676. */
 int ca_embed_tokens(const void* table, const void* pos, const int32_t* ids,

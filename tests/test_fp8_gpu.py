@@ -395,6 +395,42 @@ def test_row_quantising_dropout_and_transposed_weight_copy(ops, rows, C, p):
         assert torch.equal(qt.cpu(), want_t)
 
 
+def test_group_refresh_equals_the_single_matrix_kernels(ops):
+    """ca_fp8_refresh_group (one launch for a layer's weight copies) against ca_quantize_fp8_delayed and
+    ca_quantize_fp8_transposed per matrix: the same e4m3 bytes, the same amax after the rotation - on ragged tile edges,
+    with and without a transposed copy, more tasks than one launch takes."""
+    shapes = [(1280, 1280, True), (200, 72, True), (333, 1280, False), (64, 64, True), (8, 8, True), (3840, 1280, False),
+              (72, 200, True), (1000, 64, True), (5120, 1280, True), (16, 4096, True)]
+    S = ops.FP8_AMAX_SLOTS
+    n = len(shapes)
+    xs = [(rnd(r, c, seed=20 + i, scale=0.5 + i).to(torch.bfloat16)).to(DEV) for i, (r, c, _) in enumerate(shapes)]
+    scale = torch.tensor([448.0 / (3.0 * (0.5 + i)) for i in range(n)], device=DEV)  # (some values saturate)
+    amax_a = torch.zeros(n * S, dtype=torch.int32, device=DEV)
+    amax_b = torch.zeros(n * S, dtype=torch.int32, device=DEV)
+    qa = [torch.zeros(r, c, dtype=torch.uint8, device=DEV) for r, c, _ in shapes]
+    qb = [torch.zeros(r, c, dtype=torch.uint8, device=DEV) for r, c, _ in shapes]
+    ta = [torch.zeros(c, r, dtype=torch.uint8, device=DEV) if t else None for r, c, t in shapes]
+    tb = [torch.zeros(c, r, dtype=torch.uint8, device=DEV) if t else None for r, c, t in shapes]
+    tasks = []
+    for i, (r, c, t) in enumerate(shapes):
+        ops.quantize_fp8_delayed(xs[i], qa[i], scale[i:i + 1], amax_a[i * S:])
+        if t:
+            ops.quantize_fp8_transposed(xs[i], r, c, ta[i], scale[i:i + 1])
+        tasks.append((xs[i], 0, r, c, qb[i], 0, tb[i], 0, scale[i:i + 1], amax_b[i * S:]))
+    ops.fp8_refresh_group(tasks)
+    torch.cuda.synchronize()
+    for i, (r, c, t) in enumerate(shapes):
+        assert torch.equal(qa[i], qb[i]), (i, r, c)
+        if t:
+            assert torch.equal(ta[i], tb[i]), (i, r, c)
+        want = (xs[i].float() * scale[i]).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).view(torch.uint8)
+        assert torch.equal(qb[i], want)
+    ma = amax_a.view(n, S).amax(dim=1)
+    mb = amax_b.view(n, S).amax(dim=1)  # (non-negative floats order like their bit patterns)
+    assert torch.equal(ma, mb)
+    assert torch.equal(mb.view(torch.float32).cpu(), torch.stack([x.float().abs().amax() for x in xs]).cpu())
+
+
 def test_gemm_fp8_random_shapes(ops):
     rng = torch.Generator().manual_seed(99)
     for _ in range(8):
