@@ -2678,11 +2678,16 @@ static int ca_gemm_launch(const CaGemmDesc* desc, void* stream) {
     CA_CHECK_ARG(d.c_split_n == 0 || (d.C_hi && (d.c_split_n % 16) == 0 && d.c_split_n < d.N && d.epilogue == CA_EPI_NONE),
                  "ca_gemm_bf16: c_split_n needs C_hi, a multiple of 16 below N and no epilogue");
     unsigned gy = d.M <= 32 ? 1u : (unsigned)((d.M + 31) / 32);  // row blocks of 32 (blockIdx.y)
-    // 33 .. 128 rows against a narrow weight (N = d_model: 64 column blocks): 32-row blocks leave CUs without a
-    // workgroup (128 of 256 at 64 clips) while each workgroup streams 64 KB of rows per 1024 k beside its 32 KB of
-    // weights; 16-row blocks double the workgroups at 2/3 of the bytes each (same K split per output: same bits)
-    static const int mb1 = [] { const char* e = getenv("CA_SKINNY_MB1"); return e ? atoi(e) : 1; }();
-    const bool rows16 = mb1 && d.M > 32 && (unsigned)((d.N + 15) / 16) * gy < x_device_cus();
+    // 17 .. 128 rows: 16-row workgroups over blockIdx.y wherever that leaves the launch at most four workgroups per CU
+    // (every projection of a decoder layer; not the vocabulary).  The kernel's pace is set by the requests its waves keep
+    // in flight, not by bytes: at 32 clips the 32-row form (one workgroup per column block, two row blocks against the
+    // same weight fragment - round 3) gave N = 1024 launches 64 workgroups; 16-row workgroups re-read the weights from
+    // L2 but double the waves: 3.06 -> 2.66 ms per token at 32 clips, 4.50 -> 3.90 at 64, 6.96 -> 6.60 at 128 (round 5;
+    // 64-row workgroups, the opposite direction, measured 4.40 at 64).  Same K split per output element: same bits.
+    // CA_SKINNY_MB1=0 restores 32-row workgroups.
+    static const int mb1 = [] { const char* e = getenv("CA_SKINNY_MB1"); return e ? atoi(e) : 4; }();
+    static const int mb1_rows = [] { const char* e = getenv("CA_SKINNY_MB1_ROWS"); return e ? atoi(e) : 16; }();
+    const bool rows16 = mb1 && d.M > mb1_rows && d.M > 16 && (unsigned)((d.N + 15) / 16) * gy <= (unsigned)mb1 * x_device_cus();
     if (rows16) gy = (unsigned)((d.M + 15) / 16);
     const dim3 grid((unsigned)((d.N + 15) / 16), gy);
     if (d.a_ln_gamma) {
