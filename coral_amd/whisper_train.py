@@ -81,12 +81,16 @@ class WhisperTrainEngine(WhisperEngine):
         (ca_fp8_amax_rotate).  Backward (CA_FP8_DGRAD=0 off): the data gradients of fc2 and out_proj - the two whose
         incoming gradient passes through an elementwise pass anyway (hidden-state dropout) - run on the fp8 instruction
         too: that pass also leaves dY as e4m3 with row scales (ca_dropout_rows_fp8), the weights have transposed e4m3
-        copies (ca_quantize_fp8_transposed).  Everything else of the backward is bf16: weight gradients from the saved
-        bf16 activations, the other data gradients from bf16 weights (straight-through)."""
+        copies (one launch per layer with the straight copies: ca_fp8_refresh_group).  fc1's data gradient is ALSO fp8 by
+        default (CA_FP8_DGRAD_FC1=0 off): its incoming gradient dU leaves fc2's GELU' epilogue as e4m3 under ONE delayed
+        per-tensor scale (margin 4, saturating clamp) - the numerically most fragile piece of the path, covered by the
+        whole-gradient cosine test at full size (tests/test_fulldepth_gpu.py).  Everything else of the backward is bf16:
+        weight gradients from the saved bf16 activations, the q|k|v data gradient from bf16 weights."""
         import os
 
         # the fp8 kernels leave no registers for a co-resident optimiser wave (253 of 256 per lane, two waves per SIMD):
         # the per-bucket AdamW + re-quantisation chain runs at full width there (trainer.py: ca_adamw_step_ex)
+        # (holding ca_gemm_fp8_kernel_x to 224 registers spills inside its loop: 70.6 -> 100 ms per step, round 5)
         self.background_optimizer = not on
         if not on:
             self._fp8_train = None
