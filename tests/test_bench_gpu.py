@@ -49,6 +49,20 @@ def test_bench_spawns_its_ranks_and_reports_them(zero):
     assert ("p16_vs_master" in spread[-1]["replica_spreads"]) == (zero != 0)
 
 
+def test_the_headline_line_survives_a_secondary_run_that_does_not_finish():
+    """N > 1 default: the zero_stage 2 run follows the headline in the same process group.  If it does not finish
+    (CA_BENCH_ZERO2_TIMEOUT; here: at once) rank 0 still prints the ONE line, with the headline and an error field."""
+    env = dict(os.environ, CA_BENCH_SHARE_GPU="1", CA_BENCH_ZERO2_TIMEOUT="0.001")
+    env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--backend", "gloo", "--model", "wav2vec2-small",
+           "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=str(ROOT))
+    main = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{") and "metric" in l]
+    assert len(main) == 1, r.stdout[-1500:] + r.stderr[-1500:]
+    assert main[0]["value"] > 0 and main[0]["ranks"] == 2
+    assert "error" in main[0]["config"]["also_zero2"]
+
+
 def test_two_ranks_at_the_full_xlsr_2b_shape_with_the_sharded_optimizer():
     """BASELINE configs[2]'s model (wav2vec2-large = XLS-R-2B, 8 x 10 s per rank) on two ranks with the N > 1 default
     (reduce-scatter of the 48 layers' 44 M-element matrix parts, AdamW on 1/2, bf16 all-gather): the real bucket
