@@ -206,6 +206,10 @@ SIGNATURES = {
         C.c_int,
         [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i32, _f32, _f32, _vp, _i32, _vp],
     ),
+    "ca_adamw_step_g16": (
+        C.c_int,
+        [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i32, _f32, _f32, _vp, _i32, _vp],
+    ),
     "ca_logmel_workspace_bytes": (_i64, [_i32]),
     "ca_logmel": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i64, _i32, _vp]),
     "ca_cross_entropy_fwd_bwd": (

@@ -590,6 +590,10 @@ __device__ __forceinline__ void gemm_epilogue_fast(const CaGemmDesc& d, const fl
         __builtin_nontemporal_store(o, (u16x8_t*)((unsigned short*)d.C + coff));
       else
         *(u16x8_t*)((unsigned short*)d.C + coff) = o;
+      if (EPI == CA_EPI_NONE && d.c_sumsq != nullptr) {  // (wave-uniform) weight gradients kept in bf16: the norm of what is stored
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ssq = fmaf(bf2f(o[e]), bf2f(o[e]), ssq);
+      }
       if (EPI == CA_EPI_DGELU && c8_on) ca_store_fp8x8((unsigned char*)d.C8 + coff, v, s8, amx);
     }
     if (EPI == CA_EPI_GELU) {
@@ -780,10 +784,18 @@ __device__ __forceinline__ void gemm_epilogue(const CaGemmDesc& d, f32x4_t (&acc
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e]);
         *(u16x8_t*)C = o;
+        if (d.c_sumsq != nullptr) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ssq = fmaf(bf2f(o[e]), bf2f(o[e]), ssq);
+        }
       } else {
 #pragma unroll
         for (int e = 0; e < 8; ++e)
-          if (e < nvalid) C[e] = f2bf(d.accumulate ? bf2f(C[e]) + v[e] : v[e]);
+          if (e < nvalid) {
+            const unsigned short t = f2bf(d.accumulate ? bf2f(C[e]) + v[e] : v[e]);
+            C[e] = t;
+            ssq = fmaf(bf2f(t), bf2f(t), ssq);
+          }
       }
     }
     if (has_gelu && d.C2) {
@@ -2582,7 +2594,7 @@ extern "C" int ca_gemm_bf16_group(const CaGemmDesc* descs, int32_t count, void* 
                  "ca_gemm_bf16_group: alignment");
     CA_CHECK_ARG(p->a_layout == descs->a_layout && p->b_layout == descs->b_layout,
                  "ca_gemm_bf16_group: the problems differ in operand form");
-    CA_CHECK_ARG(p->c_sumsq == nullptr || p->out_f32, "ca_gemm_bf16_group: c_sumsq needs an fp32 output");
+    CA_CHECK_ARG(p->c_sumsq == nullptr || p->epilogue == CA_EPI_NONE, "ca_gemm_bf16_group: c_sumsq needs a plain epilogue");
     g.d[i] = *p;
     g.first[i] = total;
     total += ((p->M + XBM - 1) / XBM) * ((p->N + XBN - 1) / XBN);
@@ -2660,8 +2672,8 @@ static int ca_gemm_launch(const CaGemmDesc* desc, void* stream) {
     CA_CHECK_ARG(d.a_layout == CA_MNMAJOR && d.b_layout == CA_MNMAJOR && d.batch1 == 1 && d.batch2 == 1 && d.a_kseg == 0,
                  "ca_gemm_bf16: a_colsum needs the un-batched weight-gradient form");
   if (d.c_sumsq)
-    CA_CHECK_ARG(d.out_f32 && d.batch1 == 1 && d.batch2 == 1 && d.c_row_index == nullptr && d.c_split_n == 0,
-                 "ca_gemm_bf16: c_sumsq needs an un-batched fp32 output");
+    CA_CHECK_ARG(d.epilogue == CA_EPI_NONE && d.batch1 == 1 && d.batch2 == 1 && d.c_row_index == nullptr && d.c_split_n == 0,
+                 "ca_gemm_bf16: c_sumsq needs an un-batched output with the plain epilogue");
 
   hipStream_t s = (hipStream_t)stream;
   const int lay = (d.a_layout ? 2 : 0) + (d.b_layout ? 1 : 0);

@@ -519,10 +519,12 @@ extern "C" int ca_sum_f32(const float* x, int64_t n, float* out, int32_t accumul
 }
 
 // torch.optim.AdamW (decoupled decay) with the clip coefficient of clip_grad_norm_ folded in.
-template <bool NT>
+// G16: the gradient is a bf16 tensor (ca_adamw_step_g16: weight-matrix gradients kept as the reference's autocast
+// produces them) - 2 instead of 4 of the update's 30 bytes per parameter.
+template <bool NT, bool G16 = false>
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ m,
                                                     float* __restrict__ v,
-                                                    const float* __restrict__ g,
+                                                    const void* __restrict__ gv,
                                                     unsigned short* __restrict__ p16, int64_t n,
                                                     float lr, float b1, float b2, float eps,
                                                     float wd, float bc1, float bc2_sqrt,
@@ -537,13 +539,22 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
   const float step_size = lr / bc1;
   const float decay = 1.f - lr * wd;
   // 16 bytes per lane and array (f32x4; 8 bytes of bf16): the flat buffers and every bucket offset are 32-byte aligned
-  const bool vec = allow_vec && ((((uintptr_t)p | (uintptr_t)m | (uintptr_t)v | (uintptr_t)g) & 15) == 0) && (!p16 || ((uintptr_t)p16 & 7) == 0);
+  const float* g = (const float*)gv;
+  const unsigned short* g16 = (const unsigned short*)gv;
+  const bool vec = allow_vec && ((((uintptr_t)p | (uintptr_t)m | (uintptr_t)v | (G16 ? 0 : (uintptr_t)gv)) & 15) == 0) &&
+                   (!G16 || ((uintptr_t)gv & 7) == 0) && (!p16 || ((uintptr_t)p16 & 7) == 0);
   const int64_t n4 = vec ? (n >> 2) : 0;
   // The 28 bytes per parameter of fp32 state are touched once per step: non-temporal loads and stores keep them from
   // displacing the operand panels of the forward GEMMs this kernel runs beside (trainer.py) from the L2s / Infinity
   // Cache.  The bf16 compute copy is stored with the default policy: the next forward reads it within a millisecond.
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-    const f32x4_t g4 = NT ? __builtin_nontemporal_load((const f32x4_t*)g + i) : ((const f32x4_t*)g)[i];
+    f32x4_t g4;
+    if constexpr (G16) {
+      const u16x4_t h = NT ? __builtin_nontemporal_load((const u16x4_t*)g16 + i) : ((const u16x4_t*)g16)[i];
+      g4 = (f32x4_t){bf2f(h[0]), bf2f(h[1]), bf2f(h[2]), bf2f(h[3])};
+    } else {
+      g4 = NT ? __builtin_nontemporal_load((const f32x4_t*)g + i) : ((const f32x4_t*)g)[i];
+    }
     f32x4_t p4 = NT ? __builtin_nontemporal_load((const f32x4_t*)p + i) : ((const f32x4_t*)p)[i];
     f32x4_t m4 = NT ? __builtin_nontemporal_load((const f32x4_t*)m + i) : ((const f32x4_t*)m)[i];
     f32x4_t v4 = NT ? __builtin_nontemporal_load((const f32x4_t*)v + i) : ((const f32x4_t*)v)[i];
@@ -573,7 +584,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
     if (p16) ((u16x4_t*)p16)[i] = h4;
   }
   for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const float gi = g[i] * coef;
+    const float gi = (G16 ? bf2f(g16[i]) : g[i]) * coef;
     float pi = p[i] * decay;
     const float mi = b1 * m[i] + (1.f - b1) * gi;
     const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
@@ -593,10 +604,9 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
 // 31.0 instead of 20.9; capped: update 17.0 ms, forward 28.7, step 72.9 -> 70.7 ms).  What remains is the HBM queue
 // itself: the forward loses ~8.4 ms to the update's 64.8 GB whatever the update's pace (128 threads per CU: update
 // 28 ms, forward 29.5; eight requests in flight per lane instead of four: no better) - tools/archive/dev_opt_timeline.py.
-extern "C" int ca_adamw_step_ex(float* p, float* m, float* v, const float* g, void* p16, int64_t n,
-                                float lr, float beta1, float beta2, float eps, float weight_decay,
-                                int32_t step, float grad_scale, float max_norm,
-                                const float* gnorm_sq, int32_t max_blocks, void* stream) {
+static int adamw_launch(float* p, float* m, float* v, const void* g, bool g16, void* p16, int64_t n, float lr, float beta1,
+                        float beta2, float eps, float weight_decay, int32_t step, float grad_scale, float max_norm,
+                        const float* gnorm_sq, int32_t max_blocks, void* stream) {
   CA_CHECK_ARG(p && m && v && g && n > 0 && step >= 1 && max_blocks >= 0, "ca_adamw_step: bad argument");
   const float bc1 = 1.f - powf(beta1, (float)step);
   const float bc2 = 1.f - powf(beta2, (float)step);
@@ -607,16 +617,31 @@ extern "C" int ca_adamw_step_ex(float* p, float* m, float* v, const float* g, vo
   const int cap = cap_env > 0 ? cap_env : max_blocks;
   int grid = ew_grid(n, vec ? 4 : 1);
   if (cap > 0 && grid > cap) grid = cap;
-  if (nt)
-    hipLaunchKernelGGL(adamw_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, m, v, g,
-                       (unsigned short*)p16, n, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2), grad_scale,
-                       max_norm, gnorm_sq, vec);
-  else
-    hipLaunchKernelGGL(adamw_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, m, v, g,
-                       (unsigned short*)p16, n, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2), grad_scale,
-                       max_norm, gnorm_sq, vec);
+#define ADAMW(NTV, G16V)                                                                                              \
+  hipLaunchKernelGGL((adamw_kernel<NTV, G16V>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p, m, v, g,            \
+                     (unsigned short*)p16, n, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2), grad_scale,       \
+                     max_norm, gnorm_sq, vec)
+  if (nt && g16) ADAMW(true, true);
+  else if (nt) ADAMW(true, false);
+  else if (g16) ADAMW(false, true);
+  else ADAMW(false, false);
+#undef ADAMW
   CA_CHECK_LAUNCH("ca_adamw_step");
   return CA_OK;
+}
+extern "C" int ca_adamw_step_ex(float* p, float* m, float* v, const float* g, void* p16, int64_t n,
+                                float lr, float beta1, float beta2, float eps, float weight_decay,
+                                int32_t step, float grad_scale, float max_norm,
+                                const float* gnorm_sq, int32_t max_blocks, void* stream) {
+  return adamw_launch(p, m, v, g, false, p16, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, max_norm, gnorm_sq,
+                      max_blocks, stream);
+}
+extern "C" int ca_adamw_step_g16(float* p, float* m, float* v, const void* g_bf16, void* p16, int64_t n,
+                                 float lr, float beta1, float beta2, float eps, float weight_decay,
+                                 int32_t step, float grad_scale, float max_norm,
+                                 const float* gnorm_sq, int32_t max_blocks, void* stream) {
+  return adamw_launch(p, m, v, g_bf16, true, p16, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, max_norm,
+                      gnorm_sq, max_blocks, stream);
 }
 extern "C" int ca_adamw_step(float* p, float* m, float* v, const float* g, void* p16, int64_t n,
                              float lr, float beta1, float beta2, float eps, float weight_decay,

@@ -202,7 +202,7 @@ def sumsq_slots(M, N):
 
 
 def wgrad_gemm(dY, X, G, *, M, N, K, lda, ldb, c_off, accumulate, a_off=0, b_off=0, bias_off=None, part=None,
-               cs=None, sq=None):
+               cs=None, sq=None, Gb=None):
     """Weight gradient G[c_off : c_off + M*N] (+)= dY^T X  (dY [K, M] and X [K, N] token-major bf16, G fp32
     row-major [M, N]).  Bias gradient (dY.sum(0)): either `bias_off` (+ `part` workspace) for a separate column-sum
     pass into G[bias_off:], or `cs = (ws, off, ld)` to take partial column sums from the 256x256 kernel's A stream
@@ -211,26 +211,39 @@ def wgrad_gemm(dY, X, G, *, M, N, K, lda, ldb, c_off, accumulate, a_off=0, b_off
     along K: the slices run as one batched GEMM into an fp32 workspace and a deterministic second pass adds them
     up (no atomics: the result does not depend on scheduling).
     sq = (slots, off): the squared norm of the result as sumsq_slots(M, N) partials at slots[off:] (from the GEMM's
-    epilogue; on the split-K path the whole sum lands in slots[off] and the matrix's other slots keep their zeros)."""
+    epilogue; on the split-K path the whole sum lands in slots[off] and the matrix's other slots keep their zeros).
+    G may be a bf16 buffer (weight-matrix gradients kept as the reference's autocast produces them; never accumulated
+    into): the bias gradient then goes to the fp32 buffer `Gb`."""
     splits = 1 if cs is not None else _wgrad_splits(M, N, K)
+    g16 = G.dtype == torch.bfloat16
+    if g16 and accumulate:
+        raise CoralAmdError("wgrad_gemm: a bf16 gradient buffer is written, never accumulated into")
     if bias_off is not None:
-        colsum(dY, lda, K, M, G, part, x_off=a_off, out_off=bias_off)
+        colsum(dY, lda, K, M, Gb if g16 else G, part, x_off=a_off, out_off=bias_off)
     if splits == 1:
         kw = dict(a_colsum=cs[0], a_colsum_off=cs[1], a_colsum_ld=cs[2]) if cs is not None else {}
         if sq is not None:
             kw.update(c_sumsq=sq[0], c_sumsq_off=sq[1])
         gemm(dY, X, G, M=M, N=N, K=K, a_layout=MNMAJOR, lda=lda, b_layout=MNMAJOR, ldb=ldb, ldc=N, c_off=c_off,
-             a_off=a_off, b_off=b_off, out_f32=True, accumulate=accumulate, stream_out=STREAM_WGRAD, **kw)
+             a_off=a_off, b_off=b_off, out_f32=not g16, accumulate=accumulate, stream_out=STREAM_WGRAD, **kw)
         return
     ws = _SPLITK_WS.get(G.device)
-    if ws is None or ws.numel() < splits * M * N:
-        ws = torch.empty(splits * M * N, dtype=torch.float32, device=G.device)
+    need = max(splits * M * N, M * N + 4096)  # (+ 4096: the norm pass's partials when the result is kept in bf16)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.float32, device=G.device)
         _SPLITK_WS[G.device] = ws
     Kc = K // splits
     gemm(dY, X, ws, M=M, N=N, K=Kc, a_layout=MNMAJOR, lda=lda, b_layout=MNMAJOR, ldb=ldb, ldc=N, a_off=a_off,
          b_off=b_off, out_f32=True, batch2=splits, sA=(0, Kc * lda), sB=(0, Kc * ldb), sC=(0, M * N))
-    reduce_rows(ws, splits, M * N, M * N, G[c_off:], accumulate=accumulate)
-    if sq is not None:
+    if g16:  # (tiny shapes only: add the slices in place, then round once)
+        reduce_rows(ws, splits, M * N, M * N, ws, accumulate=False)
+        cast_f32_bf16(ws, G, M * N, y_off=c_off)
+        if sq is not None:
+            cast_bf16_f32(G[c_off:], ws, M * N)  # the norm of what is stored
+            sumsq(ws, M * N, sq[0][sq[1]:], ws[M * N:])
+    else:
+        reduce_rows(ws, splits, M * N, M * N, G[c_off:], accumulate=accumulate)
+    if sq is not None and not g16:
         sumsq(G[c_off:], M * N, sq[0][sq[1]:], ws)  # (ws: free again, >= 4096 floats)
         # the matrix's other slots may still hold the per-tile partials of a step that took the direct path (K = B*T
         # changes per batch with padding=longest, and with it _wgrad_splits): the norm is the sum over ALL slots
@@ -299,7 +312,7 @@ def wgrad_plan(problems: list):
     return [problems[i] for i in solo], [[problems[i] for i in g] for g in groups], [problems[i] for i in fallback]
 
 
-def wgrad_gemm_group(problems: list, G, colsum_ws=None, colsum_ld=0) -> bool:
+def wgrad_gemm_group(problems: list, G, colsum_ws=None, colsum_ld=0, Gb=None) -> bool:
     """Weight gradients of one layer (dicts: dY, X, M, N, K, lda, ldb, c_off, accumulate, bias_off, part, cs_off).
     Under-filled problems that contract over the same tokens share one grouped launch of the 256x256 kernel when
     together they fill >= 70 % of a round of CUs and beat separate launches; well-filled ones keep their own launch.
@@ -324,8 +337,10 @@ def wgrad_gemm_group(problems: list, G, colsum_ws=None, colsum_ld=0) -> bool:
         return {k: p[k] for k in ("M", "N", "K", "lda", "ldb", "c_off", "accumulate", "sq") if p.get(k) is not None or k != "sq"}
 
     dirty = _CS_DIRTY.setdefault(colsum_ws.data_ptr(), set()) if fused else None
+    g16 = G.dtype == torch.bfloat16  # (bf16 matrix gradients: bias gradients go to the fp32 buffer Gb)
+    Gbias = Gb if g16 else G
     for p in solo:
-        wgrad_gemm(p["dY"], p["X"], G, **base(p), **bias_kw(p))
+        wgrad_gemm(p["dY"], p["X"], G, **base(p), **bias_kw(p), Gb=Gbias)
         if fused:
             dirty.add((p["cs_off"], p["M"]))
     for p in fallback:
@@ -335,19 +350,19 @@ def wgrad_gemm_group(problems: list, G, colsum_ws=None, colsum_ld=0) -> bool:
                 clear_ranges(colsum_ws, tuple((r * colsum_ld + p["cs_off"], p["M"]) for r in range(1, COLSUM_PARTS)))
                 dirty.discard(key)
             colsum(p["dY"], p["lda"], p["K"], p["M"], colsum_ws, p["part"], accumulate=False, out_off=p["cs_off"])
-            wgrad_gemm(p["dY"], p["X"], G, **base(p))
+            wgrad_gemm(p["dY"], p["X"], G, **base(p), Gb=Gbias)
         else:
-            wgrad_gemm(p["dY"], p["X"], G, **base(p), **bias_kw(p))
+            wgrad_gemm(p["dY"], p["X"], G, **base(p), **bias_kw(p), Gb=Gbias)
     for chunk in groups:
         arr = (CaGemmDesc * len(chunk))()
         for i, p in enumerate(chunk):
             if not fused and p.get("bias_off") is not None:
-                colsum(p["dY"], p["lda"], p["K"], p["M"], G, p["part"], out_off=p["bias_off"])
+                colsum(p["dY"], p["lda"], p["K"], p["M"], Gbias, p["part"], out_off=p["bias_off"])
             kw = dict(a_colsum=colsum_ws, a_colsum_off=p["cs_off"], a_colsum_ld=colsum_ld) if fused else {}
             if p.get("sq") is not None:
                 kw.update(c_sumsq=p["sq"][0], c_sumsq_off=p["sq"][1])
             arr[i] = _gemm_desc(p["dY"], p["X"], G, M=p["M"], N=p["N"], K=p["K"], a_layout=MNMAJOR, lda=p["lda"],
-                                b_layout=MNMAJOR, ldb=p["ldb"], ldc=p["N"], c_off=p["c_off"], out_f32=True,
+                                b_layout=MNMAJOR, ldb=p["ldb"], ldc=p["N"], c_off=p["c_off"], out_f32=not g16,
                                 accumulate=p["accumulate"], stream_out=STREAM_WGRAD, **kw)
         check(lib().ca_gemm_bf16_group(arr, len(chunk), _stream()), "ca_gemm_bf16_group")
         if fused:
@@ -608,8 +623,9 @@ def adamw_step(p, m, v, g, p16, n, lr, beta1, beta2, eps, weight_decay, step, gr
                max_norm=0.0, gnorm_sq=None, max_blocks=0):
     """AdamW with the clip coefficient folded in; max_blocks > 0 caps the grid (ca_adamw_step_ex: the CU count makes
     it a background kernel that runs under the next forward's GEMMs)."""
-    check(lib().ca_adamw_step_ex(_p(p), _p(m), _p(v), _p(g), _p(p16), n, lr, beta1, beta2, eps,
-                                 weight_decay, step, grad_scale, max_norm, _p(gnorm_sq), int(max_blocks), _stream()),
+    fn = lib().ca_adamw_step_g16 if g.dtype == torch.bfloat16 else lib().ca_adamw_step_ex  # (bf16 weight-matrix gradients)
+    check(fn(_p(p), _p(m), _p(v), _p(g), _p(p16), n, lr, beta1, beta2, eps,
+             weight_decay, step, grad_scale, max_norm, _p(gnorm_sq), int(max_blocks), _stream()),
           "ca_adamw_step")
 
 

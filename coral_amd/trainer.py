@@ -495,6 +495,14 @@ class DataParallelTrainer:
         total = None
         n = len(micro_batches)
         rank = int(os.environ.get("RANK", "0")) % 64
+        # One micro-batch per optimiser step on one GPU: the layers' weight-matrix gradients stay bf16 - the dtype the
+        # reference's autocast computes them in ($TF/trainer.py training_step under torch.autocast: a Linear's weight
+        # gradient is the bf16 output of a bf16 matmul, cast to fp32 only when it is accumulated into .grad) - from the
+        # weight-gradient GEMM's epilogue to AdamW.  With accumulation or several ranks the fp32 buffer is what is
+        # accumulated into / reduced, as in the reference.  CA_WGRAD_BF16=0: fp32 always.
+        if hasattr(eng, "shard_ranges") and hasattr(eng.store, "g16"):
+            eng.wgrad_bf16 = (n == 1 and not self.dist and not self.zero and not eng.freeze_base
+                              and os.environ.get("CA_WGRAD_BF16", "1") != "0" and self._norm_plan() is not None)
         for i, mb in enumerate(micro_batches):
             # fresh activation-dropout masks per micro-batch and rank (HF draws new masks in every forward); the
             # backward of micro-batch i runs before the next forward and regenerates the masks from the same seed
@@ -650,15 +658,27 @@ class DataParallelTrainer:
         else:
             ops.sumsq(st.g32[lo:hi], n, self.gnorm_sq, self.partial)
 
-        def adam(a, b, so):
+        def adam(a, b, so, g=None):
             if b > a:
-                ops.adamw_step(st.p32[a:b], self.m[so:so + b - a], self.v[so:so + b - a], st.g32[a:b], st.p16[a:b], b - a,
+                g = st.g32 if g is None else g
+                ops.adamw_step(st.p32[a:b], self.m[so:so + b - a], self.v[so:so + b - a], g[a:b], st.p16[a:b], b - a,
                                lr, self.betas[0], self.betas[1], self.eps, self.wd, self.opt_step,
                                grad_scale=1.0 / self.world, max_norm=self.max_grad_norm, gnorm_sq=self.gnorm_sq,
                                max_blocks=self.bg_blocks if getattr(self.engine, "background_optimizer", True) else 0)
 
+        # this step's weight-matrix gradients are in the bf16 buffer (train_step): [matrix start, bucket end) per layer
+        g16_ranges = eng.shard_ranges() if getattr(eng, "matrix_grads_bf16", False) else {}
+
         def update(a, b, name=None):
             if not self.zero:
+                if g16_ranges and name is None:  # (whole-range call: bucket by bucket, the matrices from the bf16 buffer)
+                    for bname, (ba, bb) in st.buckets.items():
+                        update(max(a, ba), min(b, bb), bname)
+                    return None
+                if name in g16_ranges:
+                    mlo = g16_ranges[name][0]
+                    adam(a, min(b, mlo), a)
+                    return adam(max(a, mlo), b, max(a, mlo), st.g16)
                 return adam(a, b, a)
             rep_off, sl_off = self._state_off[name]
             if sl_off is None:

@@ -117,6 +117,16 @@ class ParamStore:
         self.p32 = torch.zeros(off, dtype=torch.float32, device=device)
         self.g32 = torch.zeros(off, dtype=torch.float32, device=device)
         self.p16 = torch.zeros(off, dtype=torch.bfloat16, device=device)
+        self._g16 = None
+
+    @property
+    def g16(self) -> torch.Tensor:
+        """bf16 gradient buffer with the same offsets (allocated on first use): the weight-matrix gradients of a step that
+        does not accumulate stay bf16 - what the reference's autocast produces - from the weight-gradient GEMMs to AdamW
+        (engine.wgrad_bf16, trainer.py)."""
+        if self._g16 is None:
+            self._g16 = torch.zeros(self.numel, dtype=torch.bfloat16, device=self.device)
+        return self._g16
 
     def off(self, name: str) -> int:
         return self.index[name][0]
@@ -681,6 +691,11 @@ class Wav2Vec2CTCEngine:
         part = w["partial"]
         acc = True  # small tensors, front and head always accumulate (zero_grad clears them)
         lacc = not overwrite_matrices  # layer weight matrices: accumulate or overwrite
+        # ... and, when they are overwritten (one micro-batch per optimiser step) and the trainer asked for it, kept in
+        # bf16: the reference's autocast computes a Linear's weight gradient as a bf16 matmul output and only casts it to
+        # fp32 when it lands in .grad.  Halves the store of the step's dominant kernel and the optimiser's gradient read.
+        self.matrix_grads_bf16 = bool(overwrite_matrices and getattr(self, "wgrad_bf16", False))
+        gm = st.g16 if self.matrix_grads_bf16 else g32
 
         # head: dlogits (fp32) -> bf16 for the MFMA path
         dl = w["dlogits"]
@@ -743,7 +758,10 @@ class Wav2Vec2CTCEngine:
             if not keep[l]:
                 if overwrite_matrices:  # dropped layer: its matrices get no gradient this step
                     lo = o(f"wav2vec2.encoder.layers.{l}.attention.q_proj.weight")
-                    ops.clear_f32(g32, st.buckets[f"layer{l}"][1] - lo, off=lo)
+                    if self.matrix_grads_bf16:
+                        gm[lo:st.buckets[f"layer{l}"][1]].zero_()
+                    else:
+                        ops.clear_f32(g32, st.buckets[f"layer{l}"][1] - lo, off=lo)
                     if plan is not None:
                         a0 = plan["slot_off"][(l, "qkv")]
                         a1 = plan["slot_off"][(l + 1, "qkv")] if l + 1 < L else plan["nslots"]
@@ -796,7 +814,7 @@ class Wav2Vec2CTCEngine:
             bias_fused = [False]
 
             def wgrads(wg=wg, pl=pl, bias_fused=bias_fused):
-                bias_fused[0] = ops.wgrad_gemm_group(wg, g32, colsum_ws=w["bias_ws"], colsum_ld=nb)
+                bias_fused[0] = ops.wgrad_gemm_group(wg, gm, colsum_ws=w["bias_ws"], colsum_ld=nb, Gb=g32)
 
             on_side(mark(), wgrads)
             dx1 = other

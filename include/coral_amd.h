@@ -120,7 +120,8 @@ typedef struct CaGemmDesc {
   const float* a_scale;
   const float* b_scale;
   const float* a_row_scale; /* fp8 form only: [M] per-row factors of A (ca_layernorm_fwd_fp8), NULL = none */
-  /* Optional, fp32 output (out_f32 = 1), un-batched: the sum of squares of the values stored to C (after `accumulate`),
+  /* Optional, plain epilogue, un-batched, fp32 or bf16 output: the sum of squares of the values stored to C (after
+   * `accumulate`; of the ROUNDED values when C is bf16),
    * one partial per 64 x 64 output block at c_sumsq[(m / 64) * ceil(N / 64) + n / 64] (plain stores, every block of the
    * output written once per launch: no atomics, the same bits on every run).  The squared norm of a weight gradient
    * then costs no second pass over it: Trainer's clip_grad_norm_ ($TF/trainer.py:1778-1796) adds the partials of all
@@ -527,6 +528,13 @@ int ca_adamw_step_ex(float* p, float* m, float* v, const float* g, void* p16, in
                      float lr, float beta1, float beta2, float eps, float weight_decay,
                      int32_t step, float grad_scale, float max_norm, const float* gnorm_sq,
                      int32_t max_blocks, void* stream);
+/* The same update reading the gradient as a bf16 tensor: under the reference's bf16 autocast the weight gradient of a
+ * Linear IS bf16 (the matmul's output dtype; cast to fp32 only when it lands in .grad), so a single-micro-batch step can
+ * keep the weight-matrix gradients in bf16 from the weight-gradient GEMM's epilogue to here (coral_amd/trainer.py). */
+int ca_adamw_step_g16(float* p, float* m, float* v, const void* g_bf16, void* p16, int64_t n,
+                      float lr, float beta1, float beta2, float eps, float weight_decay,
+                      int32_t step, float grad_scale, float max_norm, const float* gnorm_sq,
+                      int32_t max_blocks, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Whisper log-mel front end.  $TF/models/whisper/feature_extraction_whisper.py:135-168

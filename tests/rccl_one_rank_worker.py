@@ -24,6 +24,9 @@ def run(forced, wire, steps, zero=0, clip=1e9):
     from coral_amd.trainer import DataParallelTrainer
 
     os.environ["CA_DP_FORCE"] = "1" if forced else "0"
+    # (the plain trainer would keep a single micro-batch's weight-matrix gradients in bf16; the exchange path reduces
+    # fp32 gradients - the comparison is about the exchange, so both run on the fp32 buffer)
+    os.environ["CA_WGRAD_BF16"] = "0"
     eng, shard = dp_worker.build_case()
     tr = DataParallelTrainer(eng, learning_rate=1e-3, warmup_steps=0, max_steps=100, max_grad_norm=clip,
                              compress_grads=(wire == "bf16"), zero_stage=zero)

@@ -115,6 +115,49 @@ def test_gradient_norm_from_the_weight_gradient_epilogues_matches_a_pass_over_th
     assert n1 == n2 and torch.equal(p1, p2)  # the overlapped optimiser changes nothing
 
 
+def test_single_micro_batch_steps_keep_the_matrix_gradients_in_bf16(monkeypatch):
+    """One micro-batch per optimiser step on one GPU: the layers' weight-matrix gradients go from the weight-gradient
+    GEMMs to AdamW as bf16 (what the reference's autocast computes), everything else through the fp32 buffer.  Against the
+    fp32 route (CA_WGRAD_BF16=0): the first step's loss is the same number, its gradient norm agrees to bf16 rounding of
+    the matrices, the runs stay together; a dropped layer's matrices are cleared in the buffer that is read."""
+    from coral_amd.trainer import DataParallelTrainer
+    from coral_amd.wav2vec2 import Wav2Vec2CTCEngine, Wav2Vec2Shape
+    from oracle import wav2vec2_ref as ref
+
+    kw = dict(hidden_size=128, num_hidden_layers=3, num_attention_heads=4, intermediate_size=256)
+    g = torch.Generator().manual_seed(0)
+    waves = [(0.1 * torch.randn(n, generator=g)).numpy() for n in (8000, 6400, 7000, 8000)]
+    iv, am = ref.zero_mean_unit_var_norm(waves)
+    labels = torch.randint(0, 42, (4, 6), generator=g)
+    out = {}
+    for mode, overlap in (("0", True), ("1", True), ("1", False)):
+        monkeypatch.setenv("CA_WGRAD_BF16", mode)
+        eng = Wav2Vec2CTCEngine(Wav2Vec2Shape(**kw), "cuda:0")
+        eng.load_state_dict(ref.synth_params(ref.W2V2Config(**kw)))
+        tr = DataParallelTrainer(eng, learning_rate=1e-3, warmup_steps=1, max_steps=100, max_grad_norm=0.05, overlap_optimizer=overlap)
+        losses, norms = [], []
+        for step in range(4):
+            keep = [True, step != 2, True]  # step 2 drops layer 1
+            losses.append(float(tr.train_step([dict(input_values=torch.from_numpy(iv), attention_mask=torch.from_numpy(am),
+                                                    labels=labels, layer_keep=keep)])))
+            norms.append(tr.grad_norm())
+            assert eng.matrix_grads_bf16 == (mode == "1")
+            if step == 2 and mode == "1":
+                tr.finish()
+                torch.cuda.synchronize()
+                lo, hi = eng.shard_ranges()["layer1"]
+                assert float(eng.store.g16[lo:hi].float().abs().sum()) == 0.0
+        tr.finish()
+        torch.cuda.synchronize()
+        out[(mode, overlap)] = (losses, norms, eng.store.p32.clone())
+    (l0, n0, p0), (l1, n1, p1), (l2, n2, p2) = out[("0", True)], out[("1", True)], out[("1", False)]
+    assert l1 == l2 and n1 == n2 and torch.equal(p1, p2)  # the overlapped optimiser changes nothing
+    assert l0[0] == l1[0] and abs(n0[0] - n1[0]) <= 2e-3 * n0[0], (l0, l1, n0, n1)
+    assert all(a > 0.05 for a in n0), n0  # the clip is active
+    assert np.allclose(l0, l1, rtol=2e-3) and np.allclose(n0, n1, rtol=2e-2), (l0, l1, n0, n1)
+    assert float((p0 - p1).abs().max()) <= 4.5e-3  # (4 steps of lr 1e-3: a sign flip of a noise-level element costs 2 lr per step)
+
+
 def test_early_gradient_norm_pass_matches_the_single_pass(monkeypatch):
     """N = 1: the squared gradient norm taken in two pieces (tail of the flat buffer on the side stream during the
     backward, head behind it) gives the same clip factor as one pass: same parameters after the steps up to fp32

@@ -435,6 +435,16 @@ def test_optimizer_kernels(ops):
     for o in outs[1:]:
         assert all(torch.equal(a, b) for a, b in zip(o, outs[0]))
     assert not torch.equal(outs[0][0], pd)
+    # a bf16 gradient (ca_adamw_step_g16: weight-matrix gradients kept as the reference's autocast produces them) gives
+    # the bits of the fp32 kernel on the same, rounded values - full grid, capped grid, odd length (scalar tail)
+    g16 = gd.to(torch.bfloat16)
+    gr = g16.float()
+    for length, blocks in ((pad, 0), (pad, 37), (pad - 3, 0)):
+        a = [t.clone() for t in (pd, m, v, p16)]
+        b = [t.clone() for t in (pd, m, v, p16)]
+        ops.adamw_step(a[0], a[1], a[2], gr, a[3], length, 1e-3, 0.9, 0.98, 1e-8, 0.01, 4, 1.0, 1.0, nsq, max_blocks=blocks)
+        ops.adamw_step(b[0], b[1], b[2], g16, b[3], length, 1e-3, 0.9, 0.98, 1e-8, 0.01, 4, 1.0, 1.0, nsq, max_blocks=blocks)
+        assert all(torch.equal(x, y) for x, y in zip(a, b)) and not torch.equal(a[0], pd)
 
 
 def test_misc_reorders(ops):
@@ -757,6 +767,35 @@ def test_gemm_sum_of_squares_partials(ops, M, N, K, force, accumulate):
     sq[:M, :N] = got.double() ** 2
     blocks = sq.view(nbm, 64, nbn, 64).sum(dim=(1, 3)).reshape(-1)
     assert torch.all(slots[nbm * nbn:] == -1.0)  # nothing written past the last block
+    rel = (slots[:nbm * nbn].double() - blocks).abs() / blocks.clamp_min(1e-30)
+    assert float(rel.max()) <= 1e-5, float(rel.max())
+
+
+@pytest.mark.parametrize("M,N,K,force", [(7680, 1920, 512, 0), (296, 200, 256, 0), (520, 392, 192, 1), (520, 392, 192, 2),
+                                         (1000, 1496, 320, 3), (520, 392, 192, 5)])
+def test_gemm_sum_of_squares_partials_of_a_bf16_output(ops, M, N, K, force):
+    """c_sumsq with a bf16 output (weight-matrix gradients kept in bf16): the partials are the sums of squares of the
+    ROUNDED values that were stored; the stored values are the fp32 launch's, rounded."""
+    g = torch.Generator().manual_seed(M + N + K + 1)
+    dY = bf(torch.randn(K, M, generator=g)).to(DEV)
+    X = bf(torch.randn(K, N, generator=g)).to(DEV)
+    G32 = torch.zeros(M * N, device=DEV)
+    G16 = torch.zeros(M * N, dtype=torch.bfloat16, device=DEV)
+    nbm, nbn = (M + 63) // 64, (N + 63) // 64
+    slots = torch.full((nbm * nbn + 8,), -1.0, device=DEV)
+    ops.lib().ca_gemm_force_kernel(force)
+    try:
+        ops.gemm(dY, X, G32, M=M, N=N, K=K, a_layout=1, lda=M, b_layout=1, ldb=N, ldc=N, out_f32=True)
+        ops.gemm(dY, X, G16, M=M, N=N, K=K, a_layout=1, lda=M, b_layout=1, ldb=N, ldc=N, out_f32=False, stream_out=True,
+                 c_sumsq=slots, c_sumsq_off=0)
+    finally:
+        ops.lib().ca_gemm_force_kernel(0)
+    torch.cuda.synchronize()
+    assert torch.equal(G16, G32.to(torch.bfloat16))
+    sq = torch.zeros(nbm * 64, nbn * 64, dtype=torch.float64, device=DEV)
+    sq[:M, :N] = G16.view(M, N).double() ** 2
+    blocks = sq.view(nbm, 64, nbn, 64).sum(dim=(1, 3)).reshape(-1)
+    assert torch.all(slots[nbm * nbn:] == -1.0)
     rel = (slots[:nbm * nbn].double() - blocks).abs() / blocks.clamp_min(1e-30)
     assert float(rel.max()) <= 1e-5, float(rel.max())
 
