@@ -500,7 +500,7 @@ class DataParallelTrainer:
         # gradient is the bf16 output of a bf16 matmul, cast to fp32 only when it is accumulated into .grad) - from the
         # weight-gradient GEMM's epilogue to AdamW.  With accumulation or several ranks the fp32 buffer is what is
         # accumulated into / reduced, as in the reference.  CA_WGRAD_BF16=0: fp32 always.
-        if hasattr(eng, "shard_ranges") and hasattr(eng.store, "g16"):
+        if hasattr(eng, "bf16_grad_ranges") and hasattr(eng.store, "g16"):
             eng.wgrad_bf16 = (n == 1 and not self.dist and not self.zero and not eng.freeze_base
                               and os.environ.get("CA_WGRAD_BF16", "1") != "0" and self._norm_plan() is not None)
         for i, mb in enumerate(micro_batches):
@@ -666,8 +666,8 @@ class DataParallelTrainer:
                                grad_scale=1.0 / self.world, max_norm=self.max_grad_norm, gnorm_sq=self.gnorm_sq,
                                max_blocks=self.bg_blocks if getattr(self.engine, "background_optimizer", True) else 0)
 
-        # this step's weight-matrix gradients are in the bf16 buffer (train_step): [matrix start, bucket end) per layer
-        g16_ranges = eng.shard_ranges() if getattr(eng, "matrix_grads_bf16", False) else {}
+        # this step's weight-matrix gradients are in the bf16 buffer (train_step): [lo, hi) inside a layer's bucket
+        g16_ranges = eng.bf16_grad_ranges() if (getattr(eng, "matrix_grads_bf16", False) and getattr(eng, "wgrad_bf16", False)) else {}
 
         def update(a, b, name=None):
             if not self.zero:
@@ -676,9 +676,10 @@ class DataParallelTrainer:
                         update(max(a, ba), min(b, bb), bname)
                     return None
                 if name in g16_ranges:
-                    mlo = g16_ranges[name][0]
+                    mlo, mhi = g16_ranges[name]
                     adam(a, min(b, mlo), a)
-                    return adam(max(a, mlo), b, max(a, mlo), st.g16)
+                    adam(max(a, mlo), min(b, mhi), max(a, mlo), st.g16)
+                    return adam(max(a, mhi), b, max(a, mhi))
                 return adam(a, b, a)
             rep_off, sl_off = self._state_off[name]
             if sl_off is None:

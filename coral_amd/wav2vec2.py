@@ -348,6 +348,11 @@ class Wav2Vec2CTCEngine:
         return {f"layer{l}": (st.off(f"wav2vec2.encoder.layers.{l}.attention.q_proj.weight"), st.buckets[f"layer{l}"][1])
                 for l in range(self.s.num_hidden_layers)}
 
+    def bf16_grad_ranges(self) -> dict:
+        """{layer bucket: (lo, hi)}: the weight matrices whose gradients a single-micro-batch step may keep in bf16
+        (trainer.py, ParamStore.g16): every layer's, = shard_ranges()."""
+        return self.shard_ranges()
+
     def zero_grad(self, matrices: bool = True):
         """Clear gradients.  matrices=False clears everything except the transformer layers' weight
         matrices (>99 % of the bytes): the next backward(overwrite_matrices=True) writes those

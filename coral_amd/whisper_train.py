@@ -209,6 +209,11 @@ class WhisperTrainEngine(WhisperEngine):
             out[f"dec{l}"] = (st.off(f"model.decoder.layers.{l}.self_attn.q_proj.weight"), st.buckets[f"dec{l}"][1])
         return out
 
+    def bf16_grad_ranges(self) -> dict:
+        """{bucket: (lo, hi)}: the weight matrices whose gradients a single-micro-batch step may keep in bf16
+        (trainer.py, ParamStore.g16) - the encoder layers' (the ones with per-tile norm partials, norm_plan)."""
+        return {f"enc{l}": self._enc_matrix_range(l) for l in range(self.s.encoder_layers)}
+
     def _enc_matrices(self, l: int):
         d, f = self.s.d_model, self.s.encoder_ffn_dim
         p = f"model.encoder.layers.{l}."
@@ -553,13 +558,17 @@ class WhisperTrainEngine(WhisperEngine):
         cur = ring[0]
         plan = self.norm_plan()
         eacc = not overwrite_matrices  # encoder weight matrices: accumulate, or overwrite in a step's first micro-batch
+        # ... and then, when the trainer asked for it, kept in bf16 - the dtype the reference's autocast computes them in
+        # (wav2vec2.py backward; NOTEBOOK R5.10)
+        self.matrix_grads_bf16 = bool(overwrite_matrices and getattr(self, "wgrad_bf16", False) and plan is not None)
+        gm = st.g16 if self.matrix_grads_bf16 else g32
         for l in reversed(range(s.encoder_layers)):
             sqd = ({k: (plan["slots"], plan["slot_off"][(l, k)]) for k in ("qkv", "o", "fc1", "fc2")}
                    if plan is not None else None)
             if not sv["ek"][l]:
                 if overwrite_matrices:  # dropped layer: its (uncleared) matrices get no gradient this step
                     lo, hi = self._enc_matrix_range(l)
-                    g32[lo:hi].zero_()
+                    gm[lo:hi].zero_()
                 done(f"enc{l}")
                 continue
             sa, ff = self.enc_blocks[l]
@@ -575,7 +584,7 @@ class WhisperTrainEngine(WhisperEngine):
             nb = 5 * d + s.encoder_ffn_dim
 
             def wgrads(wg=wg, bw=bw, l=l, second=second):
-                if ops.wgrad_gemm_group(wg, g32, colsum_ws=bw, colsum_ld=nb):
+                if ops.wgrad_gemm_group(wg, gm, colsum_ws=bw, colsum_ld=nb, Gb=g32):
                     second.append((bw, ops.COLSUM_PARTS, nb, nb,
                                    g32[o(f"model.encoder.layers.{l}.self_attn.q_proj.bias"):], True))
                 ops.reduce_rows_multi(second)  # both norms' d gamma | d beta and the bias vector: one launch

@@ -184,6 +184,40 @@ def test_whisper_trainer_reduces_loss():
             assert float(eng.store.view(n).abs().sum()) == 0.0
 
 
+def test_whisper_single_micro_batch_steps_keep_the_encoder_matrix_gradients_in_bf16(monkeypatch):
+    """One micro-batch per optimiser step: the encoder layers' weight-matrix gradients go to AdamW as bf16 (the dtype
+    the reference's autocast computes them in; tests/test_finetune_gpu.py has the wav2vec2 form).  Against the fp32 route
+    (CA_WGRAD_BF16=0): same first loss, first norm within bf16 rounding of those matrices, the runs stay together."""
+    from coral_amd.trainer import DataParallelTrainer
+    from coral_amd.whisper import WhisperShape
+    from coral_amd.whisper_train import WhisperTrainEngine
+    from oracle import whisper_ref as w
+
+    kw, c = _tiny()
+    g = torch.Generator().manual_seed(5)
+    batch = dict(input_features=torch.randn(2, 80, 3000, generator=g) * 0.5, labels=torch.randint(0, 150, (2, 10), generator=g))
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("CA_WGRAD_BF16", mode)
+        eng = WhisperTrainEngine(WhisperShape(**kw), DEV)
+        eng.load_state_dict(w.synth_params(c))
+        tr = DataParallelTrainer(eng, learning_rate=1e-3, warmup_steps=1, max_steps=30, max_grad_norm=0.05)
+        losses, norms = [], []
+        for _ in range(4):
+            losses.append(float(tr.train_step([batch])))
+            norms.append(tr.grad_norm())
+            assert eng.matrix_grads_bf16 == (mode == "1")
+        tr.finish()
+        torch.cuda.synchronize()
+        out[mode] = (losses, norms, eng.store.p32.clone())
+    (l0, n0, p0), (l1, n1, p1) = out["0"], out["1"]
+    # (the cross-entropy sum is an atomic accumulation: the same parameters give the loss to ~1e-7, not to the bit)
+    assert abs(l0[0] - l1[0]) <= 1e-6 * l0[0] and abs(n0[0] - n1[0]) <= 2e-3 * n0[0], (l0, l1, n0, n1)
+    assert all(a > 0.05 for a in n0), n0  # the clip is active
+    assert np.allclose(l0, l1, rtol=2e-3) and np.allclose(n0, n1, rtol=2e-2), (l0, l1, n0, n1)
+    assert float((p0 - p1).abs().max()) <= 4.5e-3
+
+
 def test_whisper_gradient_norm_without_a_pass_over_the_encoder_matrices(monkeypatch):
     """The trainer's clip norm for the Whisper engine: encoder weight matrices are overwritten by the first
     micro-batch (not cleared, not read back) and contribute through the weight-gradient GEMMs' per-tile sums of squares;
