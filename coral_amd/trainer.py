@@ -500,7 +500,7 @@ class DataParallelTrainer:
         # gradient is the bf16 output of a bf16 matmul, cast to fp32 only when it is accumulated into .grad) - from the
         # weight-gradient GEMM's epilogue to AdamW.  With accumulation or several ranks the fp32 buffer is what is
         # accumulated into / reduced, as in the reference.  CA_WGRAD_BF16=0: fp32 always.
-        if hasattr(eng, "bf16_grad_ranges") and hasattr(eng.store, "g16"):
+        if hasattr(eng, "bf16_grad_ranges") and hasattr(type(eng.store), "g16"):  # (the class: the property allocates on first read)
             eng.wgrad_bf16 = (n == 1 and not self.dist and not self.zero and not eng.freeze_base
                               and os.environ.get("CA_WGRAD_BF16", "1") != "0" and self._norm_plan() is not None)
         for i, mb in enumerate(micro_batches):
