@@ -467,6 +467,7 @@ def run_w2v2(model_key, args, world, rank, device, roofline: bool):
     trainer.finish()
     torch.cuda.synchronize()
     res["bg_blocks"] = int(getattr(trainer, "bg_blocks", 0) or 0)
+    res["matrix_grads"] = "bf16" if getattr(eng, "matrix_grads_bf16", False) else "fp32"
     if world == 1:
         trainer.close()  # (the C-ABI communicator of a --one-rank-exchange run goes back with it)
         res["trainer"] = None  # (N = 1: nothing to check afterwards; the moments' memory goes back before the next workload)
@@ -596,7 +597,11 @@ def main():
                        # what the runtime was told: kernel arguments in device memory; AdamW's grid cap
                        # under the next forward (workgroups; 0 = full grid)
                        "runtime": {"HIP_FORCE_DEV_KERNARG": os.environ.get("HIP_FORCE_DEV_KERNARG"),
-                                   "optimizer_background_blocks": res.get("bg_blocks")},
+                                   "optimizer_background_blocks": res.get("bg_blocks"),
+                                   # single-micro-batch steps on one GPU keep the layers' weight-matrix gradients in the
+                                   # dtype the reference's bf16 autocast computes them in (fp32 master, fp32 moments and
+                                   # every other gradient unchanged; CA_WGRAD_BF16=0 = fp32 buffer: + 0.9 ms per step)
+                                   "layer_matrix_gradients": res.get("matrix_grads")},
                        "loss": round(loss_val, 3),
                        **({"fwd_bwd": dict(res["fwd_bwd"], frac_of_peak=round(
                            res["step_tflop"] / (res["fwd_bwd"]["ms_per_step"] * 1e-3) / MFMA_BF16_DENSE_PEAK_TFLOPS, 4))}
