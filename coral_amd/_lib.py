@@ -87,6 +87,34 @@ class CaReduceDesc(C.Structure):
                 ("n", C.c_int32), ("accumulate", C.c_int32)]
 
 
+class CaDecodeLayer(C.Structure):
+    """Mirror of `CaDecodeLayer` in include/coral_amd.h (one record per decoder layer, in DEVICE memory)."""
+
+    FIELDS = ("ln1_g", "ln1_b", "wqkv", "bqkv", "wo", "bo", "ln2_g", "ln2_b", "wq2", "bq2", "wo2", "bo2", "ln3_g", "ln3_b",
+              "w1", "b1", "w2", "b2", "self_kv", "cross_kv")
+    _fields_ = [(n, C.c_void_p) for n in FIELDS]
+
+
+class CaDecodeDesc(C.Structure):
+    """Mirror of `CaDecodeDesc` in include/coral_amd.h."""
+
+    _fields_ = ([("layers", C.c_void_p)]
+                + [(n, C.c_int32) for n in ("n_layers", "B", "d", "f", "H", "Te", "max_len", "V")]
+                + [(n, C.c_void_p) for n in ("embed", "embed_pos", "lnf_g", "lnf_b")]
+                + [("eps", C.c_float), ("logits", C.c_void_p), ("ld_logits", C.c_int64), ("suppress", C.c_void_p),
+                   ("out", C.c_void_p), ("done", C.c_void_p), ("ids", C.c_void_p), ("ld_ids", C.c_int64),
+                   ("tok", C.c_void_p), ("pos", C.c_void_p), ("klen", C.c_void_p), ("pad_id", C.c_int32),
+                   ("eos_id", C.c_int32), ("ws", C.c_void_p), ("ws_bytes", C.c_int64), ("status", C.c_void_p)])
+
+
+DECODE_MAX_B = 16
+
+
+def decode_ws_bytes(B, d, f, H, n_layers):
+    """CA_DECODE_WS_BYTES of include/coral_amd.h."""
+    return (4096 + n_layers * 16 * H * 4 + 16 * (7 * d + f) * 2 + 16 * H * 4 * 16 * 66 * 4 + 256 * 16 * 8 + 4096)
+
+
 class CaAttnDesc(C.Structure):
     """Mirror of `CaAttnDesc` in include/coral_amd.h."""
 
@@ -217,6 +245,8 @@ SIGNATURES = {
         [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i64, _i32, _vp],
     ),
     "ca_argmax_masked": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i64, _vp]),
+    "ca_whisper_decode_token": (C.c_int, [C.POINTER(CaDecodeDesc), _vp]),
+    "ca_whisper_decode_token_supported": (C.c_int, [_i32, _i32, _i32, _i32, _i32]),
     "ca_argmax_advance": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _i32, _vp]),
     "ca_embed_tokens": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
     "ca_embed_tokens_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),

@@ -1,0 +1,1067 @@
+// Greedy decoding: one persistent launch per token for a whole Whisper decoder (include/coral_amd.h,
+// ca_whisper_decode_token).  gfx950 only.
+//
+// Why one launch: a decoded token at 8 .. 16 clips is a chain of ~170 dependent launches, and a dependent launch on this
+// chip costs ~4.7 us from dispatch to completion before it moves a byte (profiles/r06_token16_base_by_grid.txt: the
+// embedding gather, 8 workgroups, takes 4.7 us) - 0.8 ms of the 2.0 ms a token took, in which HBM idles.  An all-to-all
+// seam INSIDE a launch costs ~3.2 us (tools/r06/seam_bench.hip), and everything that does not depend on the token's
+// activations - the weights - can be in LDS before the seam that needs it.
+//
+// Structure.  G = one 256-thread workgroup per CU, all resident (~156 KB of LDS each).  A layer is eight phases:
+//   A  LayerNorm + q|k|v projection (K|V rows into the self-attention cache)      all-to-all in
+//   B  self-attention over the cache, one (clip, head) per workgroup
+//   C  out-projection + residual                                                  all-to-all in
+//   D  LayerNorm + cross-attention query projection                               all-to-all in
+//   E  attention over the cached encoder K|V, (clip, head, key split) per workgroup: the token's HBM stream
+//   F  out-projection + residual                                                  all-to-all in
+//   G  LayerNorm + fc1 + GELU                                                     all-to-all in
+//   H  fc2 + residual                                                             all-to-all in
+// then LayerNorm + the tied output projection (16 vocabulary rows per tile, tiles dealt round-robin) and the greedy pick.
+// Projection phases give every workgroup N / G output columns (groups of four: 4 at N = 1024) against the WHOLE K: a
+// wave owns a quarter of K, as in ca_gemm_skinny_kernel, so per output element the MFMA chain and the (p0 + p1) + (p2 + p3)
+// combine are that kernel's - the same bits.  The residual stream's columns of a workgroup stay in registers.
+//
+// Seams.  Every workgroup owns one progress word (flags[w] = phases it has completed).  A phase's outputs are stored
+// write-through (sc1) by wave 0, which then drains (s_waitcnt vmcnt(0)) and stores the word (sc1); a consumer's wave 0
+// polls ALL words with one 16-byte sc1 load per lane, then the workgroup's barrier, then every load of handed-off bytes is
+// an sc1 load to registers (MI355X_MICROARCH.md, visibility: the form "one lane of each storing workgroup / sc1 poll of
+// every shard / barrier / sc1 loads").  The one exception is phase B, whose V tiles arrive by LDS-DMA: an agent-scope
+// acquire in front of it.  Every spin is bounded: on a timeout the workgroup sets status[0] and leaves, the others follow.
+// Buffers are written once per layer and read in the next phase, so re-use one layer later is ordered by the seams.
+//
+// Weights.  A wave's quarter of K of its workgroup's columns of every matrix goes through a private LDS ring (22 pieces of
+// 1 KiB) by LDS-DMA, issued as far ahead as the ring holds (about one layer): piece = 4 columns x 128 k, 256 contiguous
+// bytes per column, chunk positions XOR-ed so that the MFMA fragment reads (ds_read_b128) hit 16 distinct bank slots.
+#include "common.h"
+#include <type_traits>
+
+typedef __attribute__((address_space(3))) void* dk_lptr_t;
+typedef __attribute__((ext_vector_type(8))) short dk_s16x8_t;
+typedef __attribute__((ext_vector_type(4))) unsigned dk_u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned dk_u32x2;
+
+__device__ __attribute__((aligned(16))) uint32_t g_dec_zero_page[4];
+
+#define DK_NEG_BIG (-1.0e30f)
+#define DK_LOG2E 1.44269504088896340736f
+#define DK_RP 22             // pieces (1 KiB) of a wave's weight ring
+#define DK_SCRATCH (64 * 1024)  // LayerNorm image | V rings + merge buffers
+#define DK_PART (4 * 1024)
+#define DK_LDS (DK_PART + DK_SCRATCH + 4 * DK_RP * 1024)
+#define DK_XPAD 32           // bf16 elements between rows of the LayerNorm image beyond K (ca_gemm_skinny_kernel's pad)
+#define DK_SPLIT_ROW 66      // floats of a partial: m, l, 64 output columns
+#define DK_MAXTILES 16       // vocabulary tiles per workgroup (V <= 16 * 16 * G)
+#define DK_SPIN_LIMIT (1u << 21)
+
+struct DecArgs {
+  const CaDecodeLayer* layers;
+  int n_layers, B, d, f, H, Te, Lmax, V, ns;
+  const unsigned short *embed, *pos_tab;
+  const float *lnf_g, *lnf_b;
+  float eps, scale;
+  float* logits;
+  int64_t ld_logits;
+  const uint8_t* suppress;
+  int32_t* out;
+  uint8_t* done;
+  int64_t* ids;
+  int64_t ld_ids;
+  int32_t *tok, *pos, *klen;
+  int32_t pad, eos;
+  // workspace
+  unsigned* flags;
+  unsigned* split_cnt;  // [n_layers][B * H]
+  unsigned short *q, *ctx, *h1, *q2, *ctx2, *h2, *h, *gbuf;
+  float* slab;          // [B * H * ns][DK_SPLIT_ROW]
+  float* amax_val;      // [G][16]
+  int* amax_idx;
+  unsigned* status;
+};
+
+// ---- memory helpers ------------------------------------------------------------------------------------------------
+// Loads whose result an asm statement defines: the compiler knows nothing of the latency, so a use must be ordered behind
+// the wait by a data dependence (dk_tie after dk_vm0; cdna_hip_programming.md 5.7).
+__device__ __forceinline__ void dk_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void dk_tie(u16x8_t& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void dk_tie(bf16x8_t& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void dk_tie(dk_u32x4& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void dk_tie(f32x4_t& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ u16x8_t dk_ld16_sc1(const void* p) {
+  u16x8_t v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+__device__ __forceinline__ bf16x8_t dk_ld16(const void* p) {
+  bf16x8_t v;
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+__device__ __forceinline__ dk_u32x4 dk_ld16u_sc1(const void* p) {
+  dk_u32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+__device__ __forceinline__ void dk_st8_sc1(void* p, dk_u32x2 v) {
+  asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void dk_st4_sc1(void* p, unsigned v) {
+  asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void dk_st2_sc1(void* p, unsigned v) {
+  asm volatile("global_store_short %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+// LDS-DMA: 16 bytes per lane from `g` to lds_wave_base + 16 * lane
+__device__ __forceinline__ void dk_glds16(const void* g, uint32_t lds_wave_base) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+               :
+               : "v"(g), "s"(__builtin_amdgcn_readfirstlane(lds_wave_base))
+               : "memory", "m0");
+}
+__device__ __forceinline__ uint32_t dk_lds_addr(const void* p) { return (uint32_t)(uintptr_t)(dk_lptr_t)p; }
+__device__ __forceinline__ bf16x8_t dk_zero8() { return __builtin_bit_cast(bf16x8_t, (f32x4_t){0.f, 0.f, 0.f, 0.f}); }
+
+// ---- seams -----------------------------------------------------------------------------------------------------------
+// wave 0: wait until every workgroup's progress word is >= target.  Returns false on a timeout (wave-uniform).
+__device__ __forceinline__ bool dk_poll(const DecArgs& a, unsigned target, int G, int lane) {
+  for (unsigned spins = 0;; ++spins) {
+    dk_u32x4 f = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+    if (lane * 4 < G) f = dk_ld16u_sc1(a.flags + lane * 4);
+    dk_vm0();
+    dk_tie(f);
+    bool ok = true;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ok &= (lane * 4 + e >= G) || f[e] >= target;
+    if (__all(ok)) return true;
+    if (spins > DK_SPIN_LIMIT) return false;
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+// All waves: the seam in front of phase `ph` (1-based; waits for every workgroup to have completed ph - 1).  Returns
+// false when the launch is being abandoned.  `lds_ok`: one LDS word.
+__device__ __forceinline__ bool dk_seam(const DecArgs& a, unsigned ph, int G, volatile int* lds_ok, int wave, int lane) {
+  if (wave == 0) {
+    const bool ok = dk_poll(a, ph - 1, G, lane);
+    if (lane == 0) {
+      *lds_ok = ok ? 1 : 0;
+      if (!ok) atomicMax(a.status, ph + 1);
+    }
+  }
+  __syncthreads();
+  const bool ok = *lds_ok != 0;
+  return ok;
+}
+// wave 0 (the only wave that stores handed-off bytes): drain, then publish that this workgroup has completed phase ph
+__device__ __forceinline__ void dk_publish(const DecArgs& a, unsigned ph, int w, int wave, int lane) {
+  if (wave == 0) {
+    dk_vm0();
+    if (lane == 0) dk_st4_sc1(a.flags + w, ph);
+  }
+}
+
+// ---- columns of a workgroup ----------------------------------------------------------------------------------------------
+__device__ __forceinline__ void dk_cols(int N, int w, int G, int& c0, int& nc) {
+  const int ng = N >> 2, base = ng / G, rem = ng - base * G;
+  const int mine = base + (w < rem ? 1 : 0);
+  const int g0 = w * base + (w < rem ? w : rem);
+  c0 = 4 * g0;
+  nc = 4 * mine;
+}
+
+// ---- the weight ring ---------------------------------------------------------------------------------------------------
+struct DkEnt {
+  const unsigned short* W;  // row c0 of the matrix
+  int nc, K;                // this workgroup's columns, the matrix's K
+};
+struct DkRing {
+  int start, used, next_e, cur_e;
+};
+__device__ __forceinline__ int dk_per(int K) { return (((K + 31) >> 5) + 3) >> 2; }  // k-steps of a wave's K quarter
+__device__ __forceinline__ int dk_pieces(const DkEnt& e) {
+  if (e.nc <= 0) return 0;
+  return ((e.nc + 3) >> 2) * ((dk_per(e.K) + 3) >> 2);
+}
+__device__ __forceinline__ DkEnt dk_entry(const DecArgs& a, int e, int w, int G) {
+  DkEnt r;
+  const int L6 = 6 * a.n_layers;
+  if (e < L6) {
+    const int l = e / 6, p = e - 6 * l;
+    const CaDecodeLayer& ly = a.layers[l];
+    const void* W;
+    int N, K = a.d;
+    switch (p) {
+      case 0: W = ly.wqkv; N = 3 * a.d; break;
+      case 1: W = ly.wo; N = a.d; break;
+      case 2: W = ly.wq2; N = a.d; break;
+      case 3: W = ly.wo2; N = a.d; break;
+      case 4: W = ly.w1; N = a.f; break;
+      default: W = ly.w2; N = a.d; K = a.f; break;
+    }
+    int c0;
+    dk_cols(N, w, G, c0, r.nc);
+    r.K = K;
+    r.W = (const unsigned short*)W + (int64_t)c0 * K;
+  } else {
+    const int tile = w + G * (e - L6);
+    const int c0 = 16 * tile;
+    r.nc = a.V - c0 < 16 ? a.V - c0 : 16;
+    r.K = a.d;
+    r.W = a.embed + (int64_t)c0 * a.d;
+  }
+  return r;
+}
+// piece pc of an entry = column group pc / nquads, k-step quad pc % nquads: lane i brings chunk (i & 15) ^ (4 (i >> 4)) of
+// column i >> 4 (16-byte chunks of the quad's 128 k) to position i
+__device__ __forceinline__ void dk_issue_entry(const DkEnt& e, int pcs, int slot0, uint32_t ring_lds, int wave, int lane) {
+  const int per = dk_per(e.K), nquads = (per + 3) >> 2;
+  const int ksteps = (e.K + 31) >> 5;
+  const int ks0 = wave * per;
+  const int c = lane >> 4, jj = (lane & 15) ^ (4 * c);
+  int cg = 0, S = 0;
+  for (int pc = 0; pc < pcs; ++pc) {
+    const int col = 4 * cg + c;
+    const int ks = 4 * S + (jj >> 2);  // k-step within the wave's quarter
+    const int k = (ks0 + ks) * 32 + 8 * (jj & 3);
+    const bool ok = col < e.nc && ks < per && ks0 + ks < ksteps && k < e.K;
+    const void* src = ok ? (const void*)(e.W + (int64_t)col * e.K + k) : (const void*)g_dec_zero_page;
+    int slot = slot0 + pc;
+    slot = slot >= DK_RP ? slot - DK_RP : slot;
+    dk_glds16(src, ring_lds + (uint32_t)slot * 1024u);
+    if (++S == nquads) {
+      S = 0;
+      ++cg;
+    }
+  }
+}
+__device__ __forceinline__ void dk_ring_advance(const DecArgs& a, DkRing& rg, int n_entries, int w, int G, uint32_t ring_lds,
+                                                int wave, int lane) {
+  while (rg.next_e < n_entries) {
+    const DkEnt e = dk_entry(a, rg.next_e, w, G);
+    const int pcs = dk_pieces(e);
+    if (rg.used + pcs > DK_RP) break;
+    int slot0 = rg.start + rg.used;
+    slot0 = slot0 >= DK_RP ? slot0 - DK_RP : slot0;
+    if (pcs > 0) dk_issue_entry(e, pcs, slot0, ring_lds, wave, lane);
+    rg.used += pcs;
+    ++rg.next_e;
+  }
+}
+__device__ __forceinline__ void dk_ring_pop(DkRing& rg, int pcs) {
+  rg.start += pcs;
+  rg.start = rg.start >= DK_RP ? rg.start - DK_RP : rg.start;
+  rg.used -= pcs;
+  ++rg.cur_e;
+}
+// MFMA A fragment (weights) of 16-column tile t16, k-step s of the wave's quarter, from the ring entry at rg.start
+__device__ __forceinline__ bf16x8_t dk_wfrag(const char* ring, int start, int groups, int nquads, int t16, int s, int lane) {
+  const int r = lane & 15, g = lane >> 4;
+  int cg = 4 * t16 + (r >> 2);
+  cg = cg < groups ? cg : 0;  // (rows beyond the workgroup's columns: a copy, dropped by the epilogue)
+  const int c = r & 3;
+  int slot = start + cg * nquads + (s >> 2);
+  slot = slot >= DK_RP ? slot - DK_RP : slot;
+  const int pos = 16 * c + ((4 * (s & 3) + g) ^ (4 * c));
+  return *(const bf16x8_t*)(ring + slot * 1024 + pos * 16);
+}
+
+// ---- LayerNorm of the B rows into the LDS image (the arithmetic of ca_gemm_skinny_kernel's prologue = ln_fwd_kernel) ---------
+// EMB: the rows are token + position embeddings formed here (embed_kernel's arithmetic) instead of loaded
+template <int NC, bool EMB>
+__device__ __forceinline__ void dk_ln_rows(const DecArgs& a, const unsigned short* x, const float* gamma, const float* beta,
+                                           unsigned short* xs, int wave, int lane) {
+  const int C = a.d, nchunk = C >> 3, xpitch = C + DK_XPAD;
+  u16x8_t raw[4][NC], rawp[EMB ? 4 : 1][EMB ? NC : 1];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = wave + 4 * i;
+    int64_t t_off = 0, p_off = 0;
+    if (EMB && row < a.B) {
+      t_off = (int64_t)a.tok[row] * C;
+      p_off = (int64_t)a.pos[row] * C;
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int ch = lane + c * 64;
+      const bool ok = row < a.B && ch < nchunk;
+      if (EMB) {
+        raw[i][c] = ok ? *(const u16x8_t*)(a.embed + t_off + ch * 8) : (u16x8_t){0, 0, 0, 0, 0, 0, 0, 0};
+        rawp[i][c] = ok ? *(const u16x8_t*)(a.pos_tab + p_off + ch * 8) : (u16x8_t){0, 0, 0, 0, 0, 0, 0, 0};
+      } else {
+        raw[i][c] = ok ? dk_ld16_sc1(x + (int64_t)row * C + ch * 8) : (u16x8_t){0, 0, 0, 0, 0, 0, 0, 0};
+      }
+    }
+  }
+  f32x4_t gq[NC][2], bq[NC][2];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int ch = lane + c * 64;
+    if (ch < nchunk) {
+      gq[c][0] = *(const f32x4_t*)(gamma + ch * 8);
+      gq[c][1] = *(const f32x4_t*)(gamma + ch * 8 + 4);
+      bq[c][0] = *(const f32x4_t*)(beta + ch * 8);
+      bq[c][1] = *(const f32x4_t*)(beta + ch * 8 + 4);
+    }
+  }
+  if (!EMB) {
+    dk_vm0();
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int c = 0; c < NC; ++c) dk_tie(raw[i][c]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) raw[i][c][e] = f2bf(bf2f(raw[i][c][e]) + bf2f(rawp[i][c][e]));
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int lrow = wave + 4 * i;
+    if (lrow >= a.B) break;  // (wave-uniform)
+    float sx = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      if (lane + c * 64 < nchunk) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sx += bf2f(raw[i][c][e]);
+      }
+    }
+    const float mean = wave_sum(sx) / (float)C;
+    float s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      if (lane + c * 64 < nchunk) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float dlt = bf2f(raw[i][c][e]) - mean;
+          s2 += dlt * dlt;
+        }
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(s2) / (float)C + a.eps);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int ch = lane + c * 64;
+      if (ch < nchunk) {
+        u16x8_t o8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          o8[e] = f2bf(ln_apply(bf2f(raw[i][c][e]), mean, rstd, e < 4 ? gq[c][0][e] : gq[c][1][e - 4],
+                                e < 4 ? bq[c][0][e] : bq[c][1][e - 4]));
+        *(u16x8_t*)(xs + (int64_t)lrow * xpitch + ch * 8) = o8;
+      }
+    }
+  }
+}
+
+// ---- a projection phase -------------------------------------------------------------------------------------------------
+// out[m, c0 + j] = epilogue(sum_k A[m, k] W[c0 + j, k]) for this workgroup's columns.  A: the LayerNorm image in LDS (LN)
+// or bf16 rows in global memory (handed-off bytes: sc1 loads).  PMAX: unroll bound of the wave's k-steps.  The epilogue
+// functor is called by wave 0's lanes with a valid row m for every group of four columns j0 .. j0 + 3 they hold:
+// epi(m, j0, v[4]) with v = (p0 + p1) + (p2 + p3), the combine of ca_gemm_skinny_kernel.
+template <int PMAX, bool LN, class Epi>
+__device__ __forceinline__ void dk_project(const DecArgs& a, DkRing& rg, const DkEnt& ent, const unsigned short* Ag, int64_t lda,
+                                           const unsigned short* xs, const char* ring, float* part, int wave, int lane, Epi epi) {
+  const int r = lane & 15, g = lane >> 4;
+  const int K = ent.K, per = dk_per(K), ksteps = (K + 31) >> 5, nquads = (per + 3) >> 2;
+  const int ks0 = wave * per, ks1 = ks0 + per < ksteps ? ks0 + per : ksteps;
+  const int groups = (ent.nc + 3) >> 2, pcs = dk_pieces(ent);
+  const int xpitch = K + DK_XPAD;
+  if (ent.nc <= 0) {  // (no columns of this matrix: nothing in the ring either)
+    dk_ring_pop(rg, 0);
+    return;
+  }
+  bf16x8_t af[PMAX];
+  if (!LN) {
+    const unsigned short* ap = Ag + (int64_t)(r < a.B ? r : a.B - 1) * lda + 8 * g;
+#pragma unroll
+    for (int s = 0; s < PMAX; ++s) {
+      const int k = (ks0 + s) * 32 + 8 * g;
+      const bool ok = s < per && ks0 + s < ks1 && k < K && r < a.B;
+      af[s] = ok ? __builtin_bit_cast(bf16x8_t, dk_ld16_sc1(ap + (int64_t)(ks0 + s) * 32)) : dk_zero8();
+    }
+  }
+  dk_vm0();  // the activation rows - and every ring piece issued before them - have landed
+  if (!LN) {
+#pragma unroll
+    for (int s = 0; s < PMAX; ++s) dk_tie(af[s]);
+  } else {
+#pragma unroll
+    for (int s = 0; s < PMAX; ++s) {
+      const int k = (ks0 + s) * 32 + 8 * g;
+      const bool ok = s < per && ks0 + s < ks1 && k < K && r < a.B;
+      af[s] = ok ? *(const bf16x8_t*)(xs + (int64_t)r * xpitch + k) : dk_zero8();
+    }
+  }
+  const int ntile = (ent.nc + 15) >> 4;
+  for (int t16 = 0; t16 < ntile; ++t16) {
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < PMAX; ++s) {
+      if (s < per) {
+        const bool ok = ks0 + s < ks1 && (ks0 + s) * 32 + 8 * g < K;
+        bf16x8_t wf = dk_wfrag(ring, rg.start, groups, nquads, t16, s, lane);
+        if (!ok) wf = dk_zero8();
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[s], acc, 0, 0, 0);
+      }
+    }
+    if (t16) __syncthreads();  // (wave 0 has read the previous tile's partials)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) part[wave * 256 + r * 16 + 4 * g + e] = acc[e];
+    __syncthreads();
+    const int j0 = 16 * t16 + 4 * g;
+    if (wave == 0 && r < a.B && j0 < ent.nc) {
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int i = r * 16 + 4 * g + e;
+        v[e] = (part[i] + part[256 + i]) + (part[512 + i] + part[768 + i]);
+      }
+      epi(r, j0, v);
+    }
+  }
+  dk_ring_pop(rg, pcs);
+}
+// four bf16 of consecutive columns: one 8-byte write-through store
+__device__ __forceinline__ void dk_store4(unsigned short* dst, const unsigned (&hv)[4]) {
+  dk_u32x2 pk = {hv[0] | (hv[1] << 16), hv[2] | (hv[3] << 16)};
+  dk_st8_sc1(dst, pk);
+}
+
+// ---- single-query attention over a K|V cache: the arithmetic of attn_fwd_smallq_kernel<64, false, D> -------------------------
+__device__ __forceinline__ int dk_mnswz8(int kr) { return (((kr >> 1) & 1) << 1) | (((kr >> 3) & 1) << 2); }
+__device__ __forceinline__ int dk_rowperm(int bb, int r) { return 8 * (r >> 2) + 4 * bb + (r & 3); }
+__device__ __forceinline__ bf16x8_t dk_pack8(const float (&v)[8]) {
+  dk_s16x8_t o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (short)f2bf(v[e]);
+  return __builtin_bit_cast(bf16x8_t, o);
+}
+__device__ __forceinline__ bf16x8_t dk_tr_pair(const char* a0, const char* a1) {
+  s16x4_t lo, hi;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(dk_lds_addr(a0)));
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(dk_lds_addr(a1)));
+  dk_s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+__device__ __forceinline__ bf16x8_t dk_vfrag(const char* img, int s, int nb, int lane) {  // timg_frag_async<64>
+  const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+  const int kr = 32 * s + 8 * g + q;
+  const int c = ((2 * nb) + (p >> 1)) ^ dk_mnswz8(kr);
+  const char* a0 = img + kr * 128 + c * 16 + (p & 1) * 8;
+  return dk_tr_pair(a0, a0 + 4 * 128);
+}
+// One (clip, head[, key split]) item.  Q: the query row (64 bf16, handed-off bytes); K, V: the head's columns of row 0 of
+// the clip's cache (row strides ldk = ldv = 2d); Tk: rows of the cache (clamp bound), kl: valid keys; vw / nvw: this
+// wave's place among the 4 * ns waves that share the keys.  smem: DK_SCRATCH.  Wave 0 ends with the merged (M, L, o) of
+// the four waves; ns == 1: it stores the output row O (64 bf16, sc1); ns > 1: its partial into `slab`.
+__device__ __forceinline__ void dk_attend(const unsigned short* Q, const unsigned short* K, const unsigned short* V, int64_t ldkv,
+                                          int Tk, int kl, int ns, int sp, float c2, char* smem, unsigned short* O, float* slab,
+                                          int wave, int lane) {
+  constexpr int D = 2, IMG = 64 * 64 * 2, NKS = 2, NNB = 4;
+  const int g = lane >> 4, r = lane & 15;
+  const int vw = sp * 4 + wave, nvw = 4 * ns;
+  char* Vring = smem + wave * D * IMG;
+  bf16x8_t qf[NKS];
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) qf[ks] = __builtin_bit_cast(bf16x8_t, dk_ld16_sc1(Q + 32 * ks + 8 * g));
+  const int ntile = (kl + 63) / 64;
+  const int nw = ntile > vw ? (ntile - vw + nvw - 1) / nvw : 0;
+  float m = DK_NEG_BIG, l = 0.f;
+  f32x4_t o[NNB];
+#pragma unroll
+  for (int nb = 0; nb < NNB; ++nb) o[nb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  dk_vm0();
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) dk_tie(qf[ks]);
+  bf16x8_t kf[D][4][NKS];
+  auto issue = [&](auto slot_c, int j) {
+    constexpr int S = decltype(slot_c)::value;
+    const int kt = vw + nvw * j;
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk) {
+      int key = kt * 64 + 32 * (blk >> 1) + dk_rowperm(blk & 1, r);
+      key = key < Tk ? key : Tk - 1;
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) kf[S][blk][ks] = dk_ld16(K + (int64_t)key * ldkv + 32 * ks + 8 * g);
+    }
+    const uint32_t img = dk_lds_addr(Vring + S * IMG);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int kr = i * 8 + lane / 8;
+      const int c = (lane % 8) ^ dk_mnswz8(kr);
+      const int row = kt * 64 + kr;
+      const void* src = row < Tk ? (const void*)(V + (int64_t)row * ldkv + c * 8) : (const void*)g_dec_zero_page;
+      dk_glds16(src, img + i * 1024);
+    }
+  };
+  auto step = [&](auto slot_c, int j) {
+    constexpr int S = decltype(slot_c)::value;
+    const int kt = vw + nvw * j;
+    const int rem = nw - 1 - j;
+    if (rem >= 1)
+      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const char* Vimg = Vring + S * IMG;
+    bf16x8_t vf[2][NNB];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int nb = 0; nb < NNB; ++nb) vf[s][nb] = dk_vfrag(Vimg, s, nb, lane);
+    f32x4_t sc[4];
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk) {
+      f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        dk_tie(kf[S][blk][ks]);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[S][blk][ks], qf[ks], acc, 0, 0, 0);
+      }
+      sc[blk] = acc;
+    }
+    auto rest = [&](auto full_c) __attribute__((always_inline)) {
+      constexpr bool FULL = decltype(full_c)::value;
+      if constexpr (!FULL) {
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int key = kt * 64 + 32 * (blk >> 1) + 8 * g + 4 * (blk & 1) + e;
+            sc[blk][e] = key < kl ? sc[blk][e] : DK_NEG_BIG;
+          }
+      }
+      float tmax = fmaxf(fmaxf(sc[0][0], sc[0][1]), fmaxf(sc[0][2], sc[0][3]));
+#pragma unroll
+      for (int blk = 1; blk < 4; ++blk)
+        tmax = fmaxf(tmax, fmaxf(fmaxf(sc[blk][0], sc[blk][1]), fmaxf(sc[blk][2], sc[blk][3])));
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+      const float m_new = fmaxf(m, tmax * c2);
+      const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+      float p[16];
+      float sum = 0.f;
+#pragma unroll
+      for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float pv = __builtin_amdgcn_exp2f(fmaf(sc[blk][e], c2, -m_new));
+          if constexpr (!FULL) pv = sc[blk][e] > 0.5f * DK_NEG_BIG ? pv : 0.f;
+          p[4 * blk + e] = pv;
+          sum += pv;
+        }
+      l = fmaf(l, alpha, sum);
+      float ar[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ar[e] = __shfl(alpha, 4 * g + e, 64);
+#pragma unroll
+      for (int nb = 0; nb < NNB; ++nb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[nb][e] *= ar[e];
+      m = m_new;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        float ps[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ps[e] = p[8 * s + e];
+        const bf16x8_t pf = dk_pack8(ps);
+#pragma unroll
+        for (int nb = 0; nb < NNB; ++nb) {
+          dk_tie(vf[s][nb]);
+          o[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, vf[s][nb], o[nb], 0, 0, 0);
+        }
+      }
+    };
+    if (kt * 64 + 64 <= kl)
+      rest(std::true_type{});
+    else
+      rest(std::false_type{});
+    if (j + D < nw) issue(slot_c, j + D);
+  };
+  if (nw > 0) issue(std::integral_constant<int, 0>{}, 0);
+  if (nw > 1) issue(std::integral_constant<int, 1>{}, 1);
+  for (int j = 0; j < nw; j += D) {
+    step(std::integral_constant<int, 0>{}, j);
+    if (j + 1 < nw) step(std::integral_constant<int, 1>{}, j + 1);
+  }
+  l += __shfl_xor(l, 16, 64);
+  l += __shfl_xor(l, 32, 64);
+  __syncthreads();
+  float* cm = (float*)smem;  // [4][16]
+  float* cl = cm + 64;       // [4][16]
+  float* co = cl + 64;       // [4][16][64]
+  if (g == 0) {
+    cm[wave * 16 + r] = m;
+    cl[wave * 16 + r] = l;
+  }
+#pragma unroll
+  for (int nb = 0; nb < NNB; ++nb)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) co[(wave * 16 + 4 * g + e) * 64 + 16 * nb + r] = o[nb][e];
+  __syncthreads();
+  if (wave == 0 && g == 0) {  // query 0 only: lane r takes the output columns 4 r .. 4 r + 3 (one 8-byte store)
+    const int q = 0;
+    float M = cm[q];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) M = fmaxf(M, cm[w * 16 + q]);
+    float L = 0.f, wgt[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      wgt[w] = __builtin_amdgcn_exp2f(cm[w * 16 + q] - M);
+      L = fmaf(cl[w * 16 + q], wgt[w], L);
+    }
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      v[k] = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) v[k] = fmaf(co[(w * 16 + q) * 64 + 4 * r + k], wgt[w], v[k]);
+    }
+    if (ns > 1) {
+      if (r == 0) {
+        dk_st4_sc1(slab, __builtin_bit_cast(unsigned, M));
+        dk_st4_sc1(slab + 1, __builtin_bit_cast(unsigned, L));
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) dk_st4_sc1(slab + 2 + 4 * r + k, __builtin_bit_cast(unsigned, v[k]));
+    } else {
+      const float inv = L > 0.f ? 1.0f / L : 0.f;
+      unsigned hv[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) hv[k] = f2bf(v[k] * inv);
+      dk_store4(O + 4 * r, hv);
+    }
+  }
+  __syncthreads();  // (the merge buffers are the next item's V rings)
+}
+// wave 0 of the workgroup that drew the last ticket of (clip, head): merge the ns partials in slab order (the arithmetic
+// of attn_fwd_smallq_kernel's split merge) and store the output row
+__device__ __forceinline__ void dk_merge_split(const float* base, int ns, unsigned short* O, int lane) {
+  float Mt[CA_ATTN_SPLIT_MAX], Lt[CA_ATTN_SPLIT_MAX], ot[CA_ATTN_SPLIT_MAX];
+  unsigned um[CA_ATTN_SPLIT_MAX], ul[CA_ATTN_SPLIT_MAX], uo[CA_ATTN_SPLIT_MAX];
+#pragma unroll
+  for (int t = 0; t < CA_ATTN_SPLIT_MAX; ++t) {
+    const float* row = base + (t < ns ? t : 0) * DK_SPLIT_ROW;
+    asm volatile("global_load_dword %0, %1, off sc1" : "=v"(um[t]) : "v"(row) : "memory");
+    asm volatile("global_load_dword %0, %1, off sc1" : "=v"(ul[t]) : "v"(row + 1) : "memory");
+    asm volatile("global_load_dword %0, %1, off sc1" : "=v"(uo[t]) : "v"(row + 2 + lane) : "memory");
+  }
+  dk_vm0();
+#pragma unroll
+  for (int t = 0; t < CA_ATTN_SPLIT_MAX; ++t) {
+    asm volatile("" : "+v"(um[t]), "+v"(ul[t]), "+v"(uo[t]));
+    Mt[t] = __builtin_bit_cast(float, um[t]);
+    Lt[t] = __builtin_bit_cast(float, ul[t]);
+    ot[t] = __builtin_bit_cast(float, uo[t]);
+  }
+  float M = DK_NEG_BIG;
+#pragma unroll
+  for (int t = 0; t < CA_ATTN_SPLIT_MAX; ++t) M = fmaxf(M, t < ns ? Mt[t] : DK_NEG_BIG);
+  float L = 0.f, v = 0.f;
+#pragma unroll
+  for (int t = 0; t < CA_ATTN_SPLIT_MAX; ++t) {
+    const float wt = t < ns ? __builtin_amdgcn_exp2f(Mt[t] - M) : 0.f;
+    L = fmaf(Lt[t], wt, L);
+    v = fmaf(ot[t], wt, v);
+  }
+  const float inv = L > 0.f ? 1.0f / L : 0.f;
+  const float out = v * inv;
+  unsigned hv[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) hv[k] = f2bf(__shfl(out, 4 * (lane & 15) + k, 64));
+  if (lane < 16) dk_store4(O + 4 * lane, hv);
+}
+
+// ---- the kernel ---------------------------------------------------------------------------------------------------------------
+template <int NC>
+__global__ __launch_bounds__(256) void whisper_decode_token_kernel(const DecArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char dk_smem[];
+  constexpr int PD = 4 * NC, PF = 16 * NC;  // k-steps of a wave's quarter of K = d / K = f, at most
+  float* part = (float*)dk_smem;
+  volatile int* lds_ok = (volatile int*)(dk_smem + DK_PART - 16);
+  char* scratch = dk_smem + DK_PART;
+  unsigned short* xs = (unsigned short*)scratch;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const char* ring = dk_smem + DK_PART + DK_SCRATCH + wave * DK_RP * 1024;
+  const uint32_t ring_lds = dk_lds_addr(ring);
+  const int G = gridDim.x, w = blockIdx.x;
+  const int r = lane & 15, g = lane >> 4;
+  const int d = a.d, B = a.B, H = a.H;
+  const int ntiles = (a.V + 15) >> 4;
+  const int my_tiles = ntiles > w ? (ntiles - w + G - 1) / G : 0;
+  const int n_entries = 6 * a.n_layers + (ntiles + G - 1) / G;
+  DkRing rg = {0, 0, 0, 0};
+  dk_ring_advance(a, rg, n_entries, w, G, ring_lds, wave, lane);
+  unsigned ph = 0;  // phases completed by this workgroup
+  int dc0, dnc;
+  dk_cols(d, w, G, dc0, dnc);  // this workgroup's columns of every N = d projection (at most 16)
+  // wave 0: the residual stream at (row r, column dc0 + 4 g + e), as stored (bf16).  Layer 0: the embedding rows
+  // (embed_kernel's arithmetic)
+  float res[4] = {0.f, 0.f, 0.f, 0.f};
+  if (wave == 0 && r < B && 4 * g < dnc) {
+    const int64_t t_off = (int64_t)a.tok[r] * d, p_off = (int64_t)a.pos[r] * d;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int n = dc0 + 4 * g + e;
+      res[e] = bf2f(f2bf(bf2f(a.embed[t_off + n]) + bf2f(a.pos_tab[p_off + n])));
+    }
+  }
+#define DK_SEAM()                                          \
+  do {                                                     \
+    if (!dk_seam(a, ph + 1, G, lds_ok, wave, lane)) return; \
+  } while (0)
+#define DK_DONE()                                                   \
+  do {                                                              \
+    ++ph;                                                           \
+    dk_publish(a, ph, w, wave, lane);                               \
+    dk_ring_advance(a, rg, n_entries, w, G, ring_lds, wave, lane);  \
+  } while (0)
+  // out-projection / fc2 epilogue: + bias + residual, rounded to bf16 as the launch sequence stores it, kept as the next
+  // residual
+  auto res_epi = [&](const float* bias, unsigned short* dst) {
+    return [&res, bias, dst, dc0, d](int m, int j0, const float(&v)[4]) {
+      unsigned hv[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float t = v[e] * 1.0f + (bias ? bias[dc0 + j0 + e] : 0.f);
+        t += res[e];
+        hv[e] = f2bf(t);
+        res[e] = bf2f((unsigned short)hv[e]);
+      }
+      dk_store4(dst + (int64_t)m * d + dc0 + j0, hv);
+    };
+  };
+
+  for (int l = 0; l < a.n_layers; ++l) {
+    const CaDecodeLayer& ly = a.layers[l];
+    unsigned short* ckv = (unsigned short*)ly.self_kv;
+    // ---- A: LayerNorm + q|k|v -------------------------------------------------------------------------------------------
+    {
+      const DkEnt ent = dk_entry(a, rg.cur_e, w, G);
+      int c0, nc;
+      dk_cols(3 * d, w, G, c0, nc);
+      if (l > 0) {
+        DK_SEAM();
+        if (nc > 0) dk_ln_rows<NC, false>(a, a.h, ly.ln1_g, ly.ln1_b, xs, wave, lane);
+      } else {
+        __syncthreads();
+        if (nc > 0) dk_ln_rows<NC, true>(a, nullptr, ly.ln1_g, ly.ln1_b, xs, wave, lane);
+      }
+      __syncthreads();
+      const float* bias = ly.bqkv;
+      dk_project<PD, true>(a, rg, ent, nullptr, 0, xs, ring, part, wave, lane, [&](int m, int j0, const float(&v)[4]) {
+        const int n = c0 + j0;  // (a group of four never straddles d: both are multiples of 4)
+        unsigned hv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hv[e] = f2bf(v[e] * 1.0f + (bias ? bias[n + e] : 0.f));
+        unsigned short* dst = n < d ? a.q + (int64_t)m * d + n : ckv + ((int64_t)m * a.Lmax + a.pos[m]) * 2 * d + (n - d);
+        dk_store4(dst, hv);
+      });
+      DK_DONE();
+    }
+    // ---- B: self-attention over the cache ----------------------------------------------------------------------------------
+    {
+      if (w < B * H) {
+        DK_SEAM();
+        // the V tiles (this token's row among them) come by LDS-DMA, not by sc1 register loads: acquire
+        if (threadIdx.x == 0) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          dk_vm0();
+        }
+        __syncthreads();
+        for (int it = w; it < B * H; it += G) {
+          const int b = it / H, h = it - b * H;
+          int kl = a.klen[b];
+          kl = kl < a.Lmax ? kl : a.Lmax;
+          const unsigned short* Kp = ckv + (int64_t)b * a.Lmax * 2 * d + h * 64;
+          dk_attend(a.q + (int64_t)b * d + h * 64, Kp, Kp + d, 2 * d, a.Lmax, kl, 1, 0, a.scale * DK_LOG2E, scratch,
+                    a.ctx + (int64_t)b * d + h * 64, nullptr, wave, lane);
+        }
+      }
+      DK_DONE();
+    }
+    // ---- C: out-projection + residual ----------------------------------------------------------------------------------------
+    {
+      const DkEnt ent = dk_entry(a, rg.cur_e, w, G);
+      if (ent.nc > 0) DK_SEAM();
+      dk_project<PD, false>(a, rg, ent, a.ctx, d, nullptr, ring, part, wave, lane, res_epi(ly.bo, a.h1));
+      DK_DONE();
+    }
+    // ---- D: LayerNorm + cross-attention query ----------------------------------------------------------------------------------
+    {
+      const DkEnt ent = dk_entry(a, rg.cur_e, w, G);
+      if (ent.nc > 0) {
+        DK_SEAM();
+        dk_ln_rows<NC, false>(a, a.h1, ly.ln2_g, ly.ln2_b, xs, wave, lane);
+        __syncthreads();
+      }
+      const float* bias = ly.bq2;
+      dk_project<PD, true>(a, rg, ent, nullptr, 0, xs, ring, part, wave, lane, [&](int m, int j0, const float(&v)[4]) {
+        const int n = dc0 + j0;
+        unsigned hv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hv[e] = f2bf(v[e] * 1.0f + (bias ? bias[n + e] : 0.f));
+        dk_store4(a.q2 + (int64_t)m * d + n, hv);
+      });
+      DK_DONE();
+    }
+    // ---- E: attention over the encoder K|V -------------------------------------------------------------------------------------
+    {
+      const int ns = a.ns, nit = B * H * ns;
+      if (w < nit) {
+        DK_SEAM();
+        const unsigned short* xkv = (const unsigned short*)ly.cross_kv;
+        for (int it = w; it < nit; it += G) {
+          const int bh = it / ns, sp = it - bh * ns;
+          const int b = bh / H, h = bh - b * H;
+          const unsigned short* Kp = xkv + (int64_t)b * a.Te * 2 * d + h * 64;
+          unsigned short* O = a.ctx2 + (int64_t)b * d + h * 64;
+          dk_attend(a.q2 + (int64_t)b * d + h * 64, Kp, Kp + d, 2 * d, a.Te, a.Te, ns, sp, a.scale * DK_LOG2E, scratch, O,
+                    a.slab + (int64_t)it * DK_SPLIT_ROW, wave, lane);
+          if (ns > 1 && wave == 0) {
+            dk_vm0();  // this workgroup's partial is out
+            unsigned ticket = 0;
+            if (lane == 0)
+              ticket = __hip_atomic_fetch_add(a.split_cnt + (int64_t)l * 16 * H + bh, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ticket = __builtin_amdgcn_readfirstlane(ticket);
+            if (ticket == (unsigned)(ns - 1)) dk_merge_split(a.slab + (int64_t)bh * ns * DK_SPLIT_ROW, ns, O, lane);
+          }
+        }
+      }
+      DK_DONE();
+    }
+    // ---- F: out-projection + residual ----------------------------------------------------------------------------------------
+    {
+      const DkEnt ent = dk_entry(a, rg.cur_e, w, G);
+      if (ent.nc > 0) DK_SEAM();
+      dk_project<PD, false>(a, rg, ent, a.ctx2, d, nullptr, ring, part, wave, lane, res_epi(ly.bo2, a.h2));
+      DK_DONE();
+    }
+    // ---- G: LayerNorm + fc1 + GELU ----------------------------------------------------------------------------------------------
+    {
+      const DkEnt ent = dk_entry(a, rg.cur_e, w, G);
+      int c0, nc;
+      dk_cols(a.f, w, G, c0, nc);
+      if (nc > 0) {
+        DK_SEAM();
+        dk_ln_rows<NC, false>(a, a.h2, ly.ln3_g, ly.ln3_b, xs, wave, lane);
+        __syncthreads();
+      }
+      const float* bias = ly.b1;
+      dk_project<PD, true>(a, rg, ent, nullptr, 0, xs, ring, part, wave, lane, [&](int m, int j0, const float(&v)[4]) {
+        const int n = c0 + j0;
+        unsigned hv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hv[e] = f2bf(gelu_erf(v[e] * 1.0f + (bias ? bias[n + e] : 0.f)));
+        dk_store4(a.gbuf + (int64_t)m * a.f + n, hv);
+      });
+      DK_DONE();
+    }
+    // ---- H: fc2 + residual: the next layer's input ---------------------------------------------------------------------------------
+    {
+      const DkEnt ent = dk_entry(a, rg.cur_e, w, G);
+      if (ent.nc > 0) DK_SEAM();
+      dk_project<PF, false>(a, rg, ent, a.gbuf, a.f, nullptr, ring, part, wave, lane, res_epi(ly.b2, a.h));
+      DK_DONE();
+    }
+  }
+  // ---- LayerNorm + the tied output projection: 16 vocabulary rows per tile, tiles w, w + G, ... ----------------------------------
+  float best = -__builtin_inff();
+  int bi = 0x7fffffff;
+  if (my_tiles > 0) {
+    DK_SEAM();
+    dk_ln_rows<NC, false>(a, a.h, a.lnf_g, a.lnf_b, xs, wave, lane);
+    __syncthreads();
+    for (int t = 0; t < my_tiles; ++t) {
+      const DkEnt ent = dk_entry(a, rg.cur_e, w, G);
+      const int n0 = 16 * (w + G * t);
+      dk_project<PD, true>(a, rg, ent, nullptr, 0, xs, ring, part, wave, lane, [&](int m, int j0, const float(&v)[4]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int n = n0 + j0 + e;
+          if (n < a.V) {
+            const float x = v[e] * 1.0f + 0.f;
+            a.logits[(int64_t)m * a.ld_logits + n] = x;
+            if (!(a.suppress && a.suppress[n]) && x > best) {  // (a lane's candidates come in increasing index order)
+              best = x;
+              bi = n;
+            }
+          }
+        }
+      });
+      __syncthreads();  // (wave 0 has read the partials before the next tile's are written)
+      dk_ring_advance(a, rg, n_entries, w, G, ring_lds, wave, lane);
+    }
+  }
+  // this workgroup's best per row: lanes (r, g) hold row r
+  if (wave == 0) {
+#pragma unroll
+    for (int o = 16; o <= 32; o <<= 1) {
+      const float ob = __shfl_xor(best, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ob > best || (ob == best && oi < bi)) {
+        best = ob;
+        bi = oi;
+      }
+    }
+    if (g == 0) {
+      dk_st4_sc1(a.amax_val + w * 16 + r, __builtin_bit_cast(unsigned, best));
+      dk_st4_sc1(a.amax_idx + w * 16 + r, (unsigned)bi);
+    }
+  }
+  DK_DONE();
+  // ---- the greedy pick of row w and the step's bookkeeping (ca_argmax_advance's) -------------------------------------------------
+  if (w < B) {
+    DK_SEAM();
+    if (wave == 0) {
+      float vb = -__builtin_inff();
+      int vi = 0x7fffffff;
+      unsigned uv[4], ui[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int src = lane * 4 + k;
+        uv[k] = 0xff800000u;  // -inf
+        ui[k] = 0x7fffffffu;
+        if (src < G) {
+          asm volatile("global_load_dword %0, %1, off sc1" : "=v"(uv[k]) : "v"(a.amax_val + src * 16 + w) : "memory");
+          asm volatile("global_load_dword %0, %1, off sc1" : "=v"(ui[k]) : "v"(a.amax_idx + src * 16 + w) : "memory");
+        }
+      }
+      dk_vm0();
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        asm volatile("" : "+v"(uv[k]), "+v"(ui[k]));
+        const float ob = __builtin_bit_cast(float, uv[k]);
+        const int oi = (int)ui[k];
+        if (ob > vb || (ob == vb && oi < vi)) {
+          vb = ob;
+          vi = oi;
+        }
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(vb, o, 64);
+        const int oi = __shfl_xor(vi, o, 64);
+        if (ob > vb || (ob == vb && oi < vi)) {
+          vb = ob;
+          vi = oi;
+        }
+      }
+      if (lane == 0) {
+        vi = vi == 0x7fffffff ? 0 : vi;
+        a.out[w] = vi;
+        const int32_t p = a.pos[w];
+        const int32_t step = a.done[w] ? a.pad : vi;
+        a.ids[(int64_t)w * a.ld_ids + p + 1] = step;
+        if (step == a.eos) a.done[w] = 1;
+        a.tok[w] = step;
+        a.pos[w] = p + 1;
+        a.klen[w] += 1;
+      }
+    }
+  }
+#undef DK_SEAM
+#undef DK_DONE
+}
+
+// ---- C ABI --------------------------------------------------------------------------------------------------------------------
+static int dk_device_cus() {
+  static const int ncu = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n;
+  }();
+  return ncu;
+}
+extern "C" int ca_whisper_decode_token_supported(int32_t B, int32_t d, int32_t f, int32_t H, int32_t V) {
+  const int G = dk_device_cus();
+  if (G < 16 || G > 256) return 0;
+  if (B < 1 || B > CA_DECODE_MAX_B) return 0;
+  if (d < 64 || d > 1536 || (d % 64) != 0 || H * 64 != d) return 0;
+  if (f < 64 || (f % 32) != 0 || f > 4 * 1536 || f > 2048 * ((d + 511) / 512)) return 0;
+  if (d / 4 > 16 * G) return 0;                         // at most 16 columns of an N = d projection per workgroup
+  if (((int64_t)V + 15) / 16 > (int64_t)DK_MAXTILES * 16 * G) return 0;
+  // the widest ring entry must fit the ring: fc1 (f / 4 groups over G workgroups, K = d) and fc2 (d / 4 groups, K = f)
+  auto pieces = [&](int N, int K) {
+    const int ng = N / 4, mine = (ng + G - 1) / G;
+    const int per = (((K + 31) / 32) + 3) / 4;
+    return mine * ((per + 3) / 4);
+  };
+  if (pieces(3 * d, d) > DK_RP || pieces(f, d) > DK_RP || pieces(d, f) > DK_RP || 4 * ((((d + 31) / 32 + 3) / 4 + 3) / 4) > DK_RP)
+    return 0;
+  return 1;
+}
+
+extern "C" int ca_whisper_decode_token(const CaDecodeDesc* desc, void* stream) {
+  CA_CHECK_ARG(desc && desc->layers && desc->embed && desc->embed_pos && desc->lnf_g && desc->lnf_b && desc->logits &&
+                   desc->out && desc->done && desc->ids && desc->tok && desc->pos && desc->klen && desc->ws && desc->status,
+               "ca_whisper_decode_token: null pointer");
+  const CaDecodeDesc& c = *desc;
+  CA_CHECK_ARG(c.n_layers > 0 && ca_whisper_decode_token_supported(c.B, c.d, c.f, c.H, c.V),
+               "ca_whisper_decode_token: shape not supported (B <= %d, head_dim 64, d_model <= 1536, <= 256 CUs)", CA_DECODE_MAX_B);
+  CA_CHECK_ARG(c.Te > 0 && c.max_len > 0 && c.ld_logits >= c.V && c.ld_ids >= c.max_len, "ca_whisper_decode_token: bad sizes");
+  CA_CHECK_ARG(c.ws_bytes >= CA_DECODE_WS_BYTES(c.B, c.d, c.f, c.H, c.n_layers) && ((uintptr_t)c.ws % 16) == 0,
+               "ca_whisper_decode_token: ws needs CA_DECODE_WS_BYTES bytes, 16-byte aligned");
+  const int G = dk_device_cus();
+  DecArgs a;
+  a.layers = c.layers; a.n_layers = c.n_layers; a.B = c.B; a.d = c.d; a.f = c.f; a.H = c.H; a.Te = c.Te; a.Lmax = c.max_len;
+  a.V = c.V;
+  // key split of the cross-attention: ca_attn_fwd's rule (smallq_split), so the merge order - and the bits - are its
+  int ns = 1;
+  if (c.Te >= 1024) {
+    ns = G / (c.B * c.H);
+    static const int cap = [] { const char* e = getenv("CA_ATTN_SPLIT"); return e ? atoi(e) : CA_ATTN_SPLIT_MAX; }();
+    ns = ns > CA_ATTN_SPLIT_MAX ? CA_ATTN_SPLIT_MAX : ns;
+    ns = ns > cap ? cap : ns;
+    ns = ns < 2 ? 1 : ns;
+  }
+  a.ns = ns;
+  a.embed = (const unsigned short*)c.embed; a.pos_tab = (const unsigned short*)c.embed_pos;
+  a.lnf_g = c.lnf_g; a.lnf_b = c.lnf_b; a.eps = c.eps; a.scale = 0.125f;  // head_dim 64
+  a.logits = c.logits; a.ld_logits = c.ld_logits; a.suppress = c.suppress; a.out = c.out; a.done = c.done; a.ids = c.ids;
+  a.ld_ids = c.ld_ids; a.tok = c.tok; a.pos = c.pos; a.klen = c.klen; a.pad = c.pad_id; a.eos = c.eos_id;
+  char* p = (char*)c.ws;
+  a.flags = (unsigned*)p;
+  a.split_cnt = (unsigned*)(p + 4096);
+  const size_t zero_bytes = 4096 + (size_t)c.n_layers * 16 * c.H * 4;
+  p += zero_bytes;
+  const size_t row = (size_t)16 * c.d * 2;
+  a.q = (unsigned short*)p; p += row;
+  a.ctx = (unsigned short*)p; p += row;
+  a.h1 = (unsigned short*)p; p += row;
+  a.q2 = (unsigned short*)p; p += row;
+  a.ctx2 = (unsigned short*)p; p += row;
+  a.h2 = (unsigned short*)p; p += row;
+  a.h = (unsigned short*)p; p += row;
+  a.gbuf = (unsigned short*)p; p += (size_t)16 * c.f * 2;
+  a.slab = (float*)p; p += (size_t)16 * c.H * CA_ATTN_SPLIT_MAX * DK_SPLIT_ROW * 4;
+  a.amax_val = (float*)p; p += 256 * 16 * 4;
+  a.amax_idx = (int*)p; p += 256 * 16 * 4;
+  a.status = c.status;
+  CA_CHECK_ARG((size_t)(p - (char*)c.ws) <= (size_t)c.ws_bytes, "ca_whisper_decode_token: workspace layout exceeds ws_bytes");
+  hipStream_t s = (hipStream_t)stream;
+  static bool attr = false;
+  if (!attr) {
+    hipFuncSetAttribute((const void*)whisper_decode_token_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, DK_LDS);
+    hipFuncSetAttribute((const void*)whisper_decode_token_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, DK_LDS);
+    hipFuncSetAttribute((const void*)whisper_decode_token_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, DK_LDS);
+    attr = true;
+  }
+  // every polled word starts at zero (a memset node when the step is captured in a graph)
+  if (hipMemsetAsync(c.ws, 0, zero_bytes, s) != hipSuccess || hipMemsetAsync(c.status, 0, 16, s) != hipSuccess) {
+    ca_set_error("ca_whisper_decode_token: hipMemsetAsync failed");
+    return CA_ERR_LAUNCH;
+  }
+  const int nc = (c.d + 511) / 512;
+  if (nc == 1)
+    hipLaunchKernelGGL(whisper_decode_token_kernel<1>, dim3(G), dim3(256), DK_LDS, s, a);
+  else if (nc == 2)
+    hipLaunchKernelGGL(whisper_decode_token_kernel<2>, dim3(G), dim3(256), DK_LDS, s, a);
+  else
+    hipLaunchKernelGGL(whisper_decode_token_kernel<3>, dim3(G), dim3(256), DK_LDS, s, a);
+  CA_CHECK_LAUNCH("ca_whisper_decode_token");
+  return CA_OK;
+}

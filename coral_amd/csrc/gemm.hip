@@ -1921,10 +1921,18 @@ __global__ __launch_bounds__(512) void ca_gemm_kernel_l(const CaGemmDesc d) {
 // rows.  A workgroup then streams 64 KB of A per 1024 k beside its 32 KB of weights, as at 32 rows (four row blocks in one
 // workgroup measured 17.7 us per launch at 64 rows against 8 at 32: the A rows, re-read by every workgroup, were 4/5 of
 // its bytes); the weight fragment is read by the 2 - 4 workgroups of a column block, once from HBM and then from L2.
-template <int MB, int NCH = 0, int U = 8>
+// Round 6: NT = output columns per workgroup (16, 8 or 4: MFMA rows NT .. 15 repeat rows 0 .. NT-1 and are dropped), U =
+// k-steps a wave asks for at once.  What a launch of this kernel costs is the bytes its BUSIEST CU takes in (~10 B/clk
+// per CU from HBM, the weights; ~3x that from L2, the activation rows every workgroup reads): at N = 1024 sixteen-column
+// workgroups put the whole weight matrix through 64 CUs (fc2 of a decoded token at 16 clips: 128 KB of weights + 128 KB
+// of activations per CU, in four dependent rounds of eight k-steps: 13 us); four-column workgroups on 256 CUs with the
+// wave's whole K quarter in flight take 32 KB of weights each.  Per output element the same K split and the same MFMA
+// chain: the same bits whatever NT and U.
+template <int MB, int NCH = 0, int U = 8, int NT = 16>
 __global__ __launch_bounds__(256) void ca_gemm_skinny_kernel(const CaGemmDesc d) {
   constexpr bool LN = NCH > 0;
   static_assert(!LN || U == 8, "the LayerNorm prologue keeps eight weight fragments in flight");
+  static_assert(NT == 16 || NT == 8 || NT == 4, "4, 8 or 16 columns per workgroup");
   const int mrow0 = (int)blockIdx.y * 16 * MB;  // first row of this workgroup's row block
   constexpr int NC = LN ? NCH : 1;
   extern __shared__ __attribute__((aligned(16))) char sk_smem[];
@@ -1933,11 +1941,12 @@ __global__ __launch_bounds__(256) void ca_gemm_skinny_kernel(const CaGemmDesc d)
   const int xpitch = d.K + SKINNY_LN_PAD;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int n0 = blockIdx.x * 16;
+  const int n0 = blockIdx.x * NT;
   const int r = lane & 15, g = lane >> 4;
   const __bf16* A = (const __bf16*)d.A;
   const __bf16* W = (const __bf16*)d.B;
-  const int nrow = n0 + r < d.N ? n0 + r : d.N - 1;
+  const int rr = r & (NT - 1);  // (MFMA rows beyond NT: copies, same addresses - one request)
+  const int nrow = n0 + rr < d.N ? n0 + rr : d.N - 1;
   const __bf16* wp = W + (int64_t)nrow * d.ldb + 8 * g;
   const __bf16* ap[MB];
 #pragma unroll
@@ -1973,7 +1982,7 @@ __global__ __launch_bounds__(256) void ca_gemm_skinny_kernel(const CaGemmDesc d)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int n = n0 + 4 * g + e;
-        if (n < d.N) {
+        if (n < d.N && 4 * g + e < NT) {
           if (mb == 0 && d.bias) e_bias[e] = d.bias[n];
           if (epi == CA_EPI_GELU_RESIDUAL || epi == CA_EPI_RESIDUAL)
             e_res[mb][e] = bf2f(((const unsigned short*)d.R)[(int64_t)m * d.ldr + n]);
@@ -2095,7 +2104,7 @@ __global__ __launch_bounds__(256) void ca_gemm_skinny_kernel(const CaGemmDesc d)
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int n = n0 + 4 * g + e;
-      if (n >= d.N) continue;
+      if (n >= d.N || 4 * g + e >= NT) continue;
       const int i = mb * 256 + r * 16 + 4 * g + e;
       float v = (part[0][i] + part[1][i]) + (part[2][i] + part[3][i]);
       v = v * d.alpha + e_bias[e];
@@ -2701,32 +2710,65 @@ static int ca_gemm_launch(const CaGemmDesc* desc, void* stream) {
     static const int mb1_rows = [] { const char* e = getenv("CA_SKINNY_MB1_ROWS"); return e ? atoi(e) : 16; }();
     const bool rows16 = mb1 && d.M > mb1_rows && d.M > 16 && (unsigned)((d.N + 15) / 16) * gy <= (unsigned)mb1 * x_device_cus();
     if (rows16) gy = (unsigned)((d.M + 15) / 16);
-    const dim3 grid((unsigned)((d.N + 15) / 16), gy);
+    // columns per workgroup (round 6): the widest of 16 / 8 / 4 that still gives the launch 3/4 of a workgroup per CU
+    // (16-row workgroups only; CA_SKINNY_NT=16 restores sixteen everywhere)
+    static const int nt_force = [] { const char* e = getenv("CA_SKINNY_NT"); return e ? atoi(e) : 0; }();
+    int nt = 16;
+    if (d.M <= 16 || rows16) {
+      const unsigned want = 3u * x_device_cus() / 4u;
+      if ((unsigned)((d.N + 15) / 16) * gy < want) nt = (unsigned)((d.N + 7) / 8) * gy >= want ? 8 : 4;
+      if (nt_force == 4 || nt_force == 8 || nt_force == 16) nt = nt_force;
+    }
+    const dim3 grid((unsigned)((d.N + nt - 1) / nt), gy);
     if (d.a_ln_gamma) {
       CA_CHECK_ARG(d.a_ln_beta && d.K <= 2048 && ((uintptr_t)d.a_ln_gamma % 16) == 0 && ((uintptr_t)d.a_ln_beta % 16) == 0,
                    "ca_gemm_bf16: a_ln_gamma needs a_ln_beta, K <= 2048 and 16-byte aligned vectors");
       const int mb = (d.M <= 16 || rows16) ? 1 : 2;  // (33 .. 128 rows: 32- or 16-row blocks over blockIdx.y)
       const int nch = (d.K + 511) / 512 <= 2 ? 2 : (d.K + 511) / 512;
       const size_t lds = (size_t)4 * mb * 256 * sizeof(float) + (size_t)16 * mb * (d.K + SKINNY_LN_PAD) * 2;
-#define SKINNY_LN(MBV, NCHV)                                                                                         \
+#define SKINNY_LN(MBV, NCHV, NTV)                                                                                    \
   do {                                                                                                               \
     static bool attr_ln = false;                                                                                     \
     if (!attr_ln) {                                                                                                  \
-      hipFuncSetAttribute((const void*)ca_gemm_skinny_kernel<MBV, NCHV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                          160 * 1024);                                                                               \
+      hipFuncSetAttribute((const void*)ca_gemm_skinny_kernel<MBV, NCHV, 8, NTV>,                                     \
+                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                   \
       attr_ln = true;                                                                                                \
     }                                                                                                                \
-    CA_LAUNCH((ca_gemm_skinny_kernel<MBV, NCHV>), grid, dim3(256), lds, s, d);                                       \
+    CA_LAUNCH((ca_gemm_skinny_kernel<MBV, NCHV, 8, NTV>), grid, dim3(256), lds, s, d);                               \
   } while (0)
-      if (mb == 1 && nch == 2) SKINNY_LN(1, 2);
-      else if (mb == 1 && nch == 3) SKINNY_LN(1, 3);
-      else if (mb == 1) SKINNY_LN(1, 4);
-      else if (nch == 2) SKINNY_LN(2, 2);
-      else if (nch == 3) SKINNY_LN(2, 3);
-      else SKINNY_LN(2, 4);
+#define SKINNY_LN1(NCHV)                   \
+  do {                                     \
+    if (nt == 16) SKINNY_LN(1, NCHV, 16);  \
+    else if (nt == 8) SKINNY_LN(1, NCHV, 8); \
+    else SKINNY_LN(1, NCHV, 4);            \
+  } while (0)
+      if (mb == 1 && nch == 2) SKINNY_LN1(2);
+      else if (mb == 1 && nch == 3) SKINNY_LN1(3);
+      else if (mb == 1) SKINNY_LN1(4);
+      else if (nch == 2) SKINNY_LN(2, 2, 16);
+      else if (nch == 3) SKINNY_LN(2, 3, 16);
+      else SKINNY_LN(2, 4, 16);
+#undef SKINNY_LN1
 #undef SKINNY_LN
     } else if (d.M <= 16 || rows16) {
-      CA_LAUNCH((ca_gemm_skinny_kernel<1, 0>), grid, dim3(256), 4 * 256 * sizeof(float), s, d);
+      // k-steps in flight per wave: its whole K quarter up to 32 (K = 4096: one round of loads instead of four;
+      // CA_SKINNY_U=8 restores eight)
+      static const int u_force = [] { const char* e = getenv("CA_SKINNY_U"); return e ? atoi(e) : 0; }();
+      const int per = ((d.K + 31) / 32 + 3) / 4;
+      int u = per <= 8 ? 8 : (per <= 16 ? 16 : 32);
+      if (u_force == 8 || u_force == 16 || u_force == 32) u = u_force;
+#define SKINNY_P(UV, NTV) CA_LAUNCH((ca_gemm_skinny_kernel<1, 0, UV, NTV>), grid, dim3(256), 4 * 256 * sizeof(float), s, d)
+#define SKINNY_PU(UV)            \
+  do {                           \
+    if (nt == 16) SKINNY_P(UV, 16); \
+    else if (nt == 8) SKINNY_P(UV, 8); \
+    else SKINNY_P(UV, 4);        \
+  } while (0)
+      if (u == 8) SKINNY_PU(8);
+      else if (u == 16) SKINNY_PU(16);
+      else SKINNY_PU(32);
+#undef SKINNY_PU
+#undef SKINNY_P
     } else {
       CA_LAUNCH((ca_gemm_skinny_kernel<2, 0>), grid, dim3(256), 8 * 256 * sizeof(float), s, d);
     }

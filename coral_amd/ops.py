@@ -243,10 +243,12 @@ def wgrad_gemm(dY, X, G, *, M, N, K, lda, ldb, c_off, accumulate, a_off=0, b_off
             sumsq(ws, M * N, sq[0][sq[1]:], ws[M * N:])
     else:
         reduce_rows(ws, splits, M * N, M * N, G[c_off:], accumulate=accumulate)
-    if sq is not None and not g16:
-        sumsq(G[c_off:], M * N, sq[0][sq[1]:], ws)  # (ws: free again, >= 4096 floats)
-        # the matrix's other slots may still hold the per-tile partials of a step that took the direct path (K = B*T
-        # changes per batch with padding=longest, and with it _wgrad_splits): the norm is the sum over ALL slots
+        if sq is not None:
+            sumsq(G[c_off:], M * N, sq[0][sq[1]:], ws)  # (ws: free again, >= 4096 floats)
+    if sq is not None:
+        # (both gradient dtypes) the matrix's other slots may still hold the per-tile partials of a step that took the
+        # direct path (K = B*T changes per batch with padding=longest, and with it _wgrad_splits): the norm is the sum
+        # over ALL slots
         ns = sumsq_slots(M, N)
         if ns > 1:
             clear_f32(sq[0], ns - 1, off=sq[1] + 1)
@@ -655,6 +657,17 @@ def argmax_advance(logits, suppress, out, rows, V, ldv, done, ids, tok, pos, kle
         raise CoralAmdError("argmax_advance: done must be bool, ids a row-major int64 matrix")
     check(lib().ca_argmax_advance(_p(logits), _p(suppress), _p(out), rows, V, ldv, done.data_ptr(), _p(ids), ids.stride(0),
                                   _p(tok), _p(pos), _p(klen), int(pad_id), int(eos_id), _stream()), "ca_argmax_advance")
+
+
+def whisper_decode_token_supported(B, d, f, H, V) -> bool:
+    """True when ca_whisper_decode_token (one persistent launch per decoded token) takes this shape on this device."""
+    return bool(lib().ca_whisper_decode_token_supported(B, d, f, H, V))
+
+
+def whisper_decode_token(desc):
+    """One decoded token for every clip of the batch in one launch (`desc`: a filled _lib.CaDecodeDesc whose tensors the
+    caller keeps alive)."""
+    check(lib().ca_whisper_decode_token(C.byref(desc), _stream()), "ca_whisper_decode_token")
 
 
 def embed_tokens(table, pos, ids, pos_ids, y, rows, Cn):

@@ -349,6 +349,7 @@ class GradSync:
         if self.capi is not None:
             self.capi.close(abort=abort)
             self.capi = None
+            self.comm_stream = None  # (it wrapped the communicator's HIP stream, gone with it)
 
     def scale_(self):
         """DDP-mean semantics for host-side consumers: g /= world."""
@@ -431,6 +432,7 @@ class DataParallelTrainer:
             # ca_gemm_set_compute_cus; measured beside an emulated ring kernel: tools/r05_hog_gemm.py)
             ncu = torch.cuda.get_device_properties(st.device).multi_processor_count
             ops.lib().ca_gemm_set_compute_cus(int(os.environ.get("CA_COMPUTE_CUS", ncu)))
+            self._set_compute_cus = True  # (process-global library state: close() puts the default back)
         self.overlap = overlap and self.dist
         # AdamW moments.  Replicated: the parameters' own offsets.  Sharded: a compact buffer holding, bucket by bucket,
         # the replicated part [lo, mlo) and this rank's slice of the sharded part - 1/N of the state.
@@ -535,6 +537,10 @@ class DataParallelTrainer:
             self.sync.start_all()
         self.sync.finish()
         self.optimizer_step()
+        if hasattr(eng, "wgrad_bf16"):
+            # the choice belongs to THIS step: a later direct engine.backward(overwrite_matrices=True) (the autograd
+            # route, tests reading store.g32) must find fp32 matrix gradients, not stale ones beside a bf16 buffer
+            eng.wgrad_bf16 = False
         return total
 
     def _norm_plan(self):
@@ -620,6 +626,9 @@ class DataParallelTrainer:
             torch.cuda.synchronize()
         self._ag_comm = None
         self.sync.close()
+        if getattr(self, "_set_compute_cus", False):
+            ops.lib().ca_gemm_set_compute_cus(0)  # later single-GPU trainers of this process launch as a fresh process would
+            self._set_compute_cus = False
 
     def optimizer_step(self):
         eng, st = self.engine, self.engine.store

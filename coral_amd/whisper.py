@@ -26,7 +26,7 @@ from dataclasses import dataclass
 import numpy as np
 import torch
 
-from . import ops
+from . import _lib, ops
 from .ops import EPI_GELU, EPI_GELU_RESIDUAL, EPI_NONE, EPI_RESIDUAL, KMAJOR, MNMAJOR
 from .wav2vec2 import ParamStore, _r8
 
@@ -525,8 +525,67 @@ class WhisperEngine:
             eos=eos_id, cross=cross_kv)
         return st
 
+    def _persistent_state(self, cache: dict, g: dict, suppress: torch.Tensor):
+        """Descriptor + device tables of ca_whisper_decode_token for this decode state, or None where the launch
+        sequence stays (shape / device outside the kernel's limits, CA_DECODE_PERSISTENT=0)."""
+        if "persist" in g:
+            return g["persist"]
+        s, st = self.s, self.store
+        B, Lmax = cache["B"], cache["max_len"]
+        d, f, H, V = s.d_model, s.decoder_ffn_dim, s.decoder_attention_heads, s.vocab_size
+        g["persist"] = None
+        if os.environ.get("CA_DECODE_PERSISTENT", "1") == "0" or d != 64 * H:
+            return None
+        if not ops.whisper_decode_token_supported(B, d, f, H, V):
+            return None
+        p16, p32, o = st.p16.data_ptr(), st.p32.data_ptr(), st.off
+        w16 = lambda n: p16 + 2 * o(n)  # noqa: E731
+        w32 = lambda n: p32 + 4 * o(n)  # noqa: E731
+        rows = []
+        for l in range(s.decoder_layers):
+            p = f"model.decoder.layers.{l}."
+            rows.append([
+                w32(p + "self_attn_layer_norm.weight"), w32(p + "self_attn_layer_norm.bias"),
+                w16(p + "self_attn.q_proj.weight"), w32(p + "self_attn.q_proj.bias"),
+                w16(p + "self_attn.out_proj.weight"), w32(p + "self_attn.out_proj.bias"),
+                w32(p + "encoder_attn_layer_norm.weight"), w32(p + "encoder_attn_layer_norm.bias"),
+                w16(p + "encoder_attn.q_proj.weight"), w32(p + "encoder_attn.q_proj.bias"),
+                w16(p + "encoder_attn.out_proj.weight"), w32(p + "encoder_attn.out_proj.bias"),
+                w32(p + "final_layer_norm.weight"), w32(p + "final_layer_norm.bias"),
+                w16(p + "fc1.weight"), w32(p + "fc1.bias"), w16(p + "fc2.weight"), w32(p + "fc2.bias"),
+                cache["kv"][l].data_ptr(), g["cross"][l].data_ptr()])
+        assert len(rows[0]) == len(_lib.CaDecodeLayer.FIELDS)
+        table = torch.tensor(rows, dtype=torch.int64).to(self.device)
+        nbytes = _lib.decode_ws_bytes(B, d, f, H, s.decoder_layers)
+        ws = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
+        status = torch.zeros(4, dtype=torch.int32, device=self.device)
+        dsc = _lib.CaDecodeDesc()
+        dsc.layers, dsc.n_layers, dsc.B, dsc.d, dsc.f, dsc.H = table.data_ptr(), s.decoder_layers, B, d, f, H
+        dsc.Te, dsc.max_len, dsc.V = s.max_source_positions, Lmax, V
+        dsc.embed, dsc.embed_pos = w16("model.decoder.embed_tokens.weight"), w16("model.decoder.embed_positions.weight")
+        dsc.lnf_g, dsc.lnf_b = w32("model.decoder.layer_norm.weight"), w32("model.decoder.layer_norm.bias")
+        dsc.eps = s.layer_norm_eps
+        dsc.logits, dsc.ld_logits = g["logits"].data_ptr(), g["logits"].stride(0)
+        dsc.suppress = suppress.data_ptr()
+        dsc.out, dsc.done, dsc.ids, dsc.ld_ids = g["nxt"].data_ptr(), g["done"].data_ptr(), g["out"].data_ptr(), g["out"].stride(0)
+        dsc.tok, dsc.pos, dsc.klen = g["tok"].data_ptr(), g["pos"].data_ptr(), g["klen"].data_ptr()
+        dsc.pad_id, dsc.eos_id = g["pad_id"], g["eos"]
+        dsc.ws, dsc.ws_bytes, dsc.status = ws.data_ptr(), nbytes, status.data_ptr()
+        g["persist"] = dict(desc=dsc, table=table, ws=ws, status=status, suppress=suppress)
+        return g["persist"]
+
     def _token_step(self, cache: dict, g: dict, suppress: torch.Tensor):
-        """Decode the token in g["tok"] at position g["pos"], pick the next one (masked argmax), record it."""
+        """Decode the token in g["tok"] at position g["pos"], pick the next one (masked argmax), record it.
+        Up to 16 clips: ONE persistent launch (ca_whisper_decode_token, csrc/decode.hip; bit-identical to the launch
+        sequence below, which larger batches keep)."""
+        ps = self._persistent_state(cache, g, suppress)
+        if ps is not None:
+            ops.whisper_decode_token(ps["desc"])
+            return
+        self._token_step_launches(cache, g, suppress)
+
+    def _token_step_launches(self, cache: dict, g: dict, suppress: torch.Tensor):
+        """The same step as a sequence of ~7 launches per layer."""
         s, st = self.s, self.store
         p32, p16, o = st.p32, st.p16, st.off
         B, Lmax = cache["B"], cache["max_len"]
@@ -694,6 +753,12 @@ class WhisperEngine:
             graph.replay()
             n_done += 1
         out = g["out"][:, :n_done]
+        if g.get("persist") is not None:
+            code = int(g["persist"]["status"][0])  # (synchronises)
+            if code != 0:
+                raise ops.CoralAmdError(f"ca_whisper_decode_token gave up at the seam in front of phase {code - 1}: the launch "
+                                        "needs every CU of the device (nothing else may run beside it); "
+                                        "CA_DECODE_PERSISTENT=0 keeps the launch sequence")
         # trim like the eager loop: stop at the first column where every row had already finished
         fin = (out == s.eos_token_id).cumsum(1) > 0
         allfin = fin.all(0)

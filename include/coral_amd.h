@@ -574,6 +574,79 @@ int ca_embed_tokens_bwd(const void* dy, const int32_t* ids, const int32_t* pos_i
                         float* dpos, int64_t rows, int32_t C, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * Greedy decoding: ONE launch per token for a whole Whisper decoder (round 6).
+ *
+ * Replaces, for a batch of at most 16 clips, the ~170 dependent launches of a decoded token - per layer
+ * `WhisperDecoderLayer.forward` ($TF/models/whisper/modeling_whisper.py:451-518: self_attn_layer_norm, q|k|v, cached
+ * self-attention, out_proj + residual, encoder_attn_layer_norm, q_proj, attention over the cached encoder K|V, out_proj
+ * + residual, final_layer_norm, fc1 + GELU, fc2 + residual), then `layer_norm`, the tied `proj_out` and the greedy pick
+ * of `generate` ($TF/generation/utils.py `_sample`; call sites R/src/coral/evaluate.py:56-60, R/config/evaluation.yaml:20) -
+ * by a persistent kernel of one 256-thread workgroup per CU.  The phases of a layer are separated by all-to-all seams
+ * inside the launch (every workgroup publishes a progress word with a write-through store behind its drained
+ * write-through payload stores; one wave per workgroup polls all of them with one 16-byte load per lane; every spin is
+ * bounded); each workgroup's slices of the weight matrices arrive in LDS ahead of the seam that needs them (a ring per
+ * wave, LDS-DMA), and the activations every workgroup needs are a few tens of KB from L2.  A dependent launch costs
+ * ~4.7 us on this chip before it moves a byte, a seam ~3.2 us (tools/r06/seam_bench.hip).
+ *
+ * Per output element the arithmetic is that of the launch sequence it replaces (ca_gemm_bf16's weight-streaming form
+ * with the LayerNorm prologue, ca_attn_fwd's single-query form with the same key split, ca_argmax_advance): logits and
+ * token ids are bit-identical to it.
+ *
+ * All pointers are DEVICE pointers.  `layers`: n_layers records in device memory.  Weights bf16 row-major [N, K] with
+ * row stride K; biases / LayerNorm vectors fp32 (16-byte aligned); a NULL bias reads as zeros.  State as for
+ * ca_argmax_advance.  `ws`: CA_DECODE_WS_BYTES(B, d, f, H, n_layers) bytes of workspace (16-byte aligned, any contents);
+ * `status`: 4 words the launch zeroes and the kernel sets on failure (word 0: 0 = ok, else 1 + the phase whose seam timed
+ * out; the host reads it after synchronising - a launch that gave up has written no token).
+ * Limits: B <= 16, head_dim 64, d_model a multiple of 64 up to 1536, at most 256 CUs, and every CU of the device free
+ * (the workgroups must all be resident: nothing else may run beside the launch).
+ * ---------------------------------------------------------------------------------- */
+typedef struct CaDecodeLayer {
+  const float *ln1_g, *ln1_b;
+  const void* wqkv;   /* [3d, d]: q | k | v rows */
+  const float* bqkv;  /* [3d] (zeros in the k part) */
+  const void* wo;
+  const float* bo;
+  const float *ln2_g, *ln2_b;
+  const void* wq2;
+  const float* bq2;
+  const void* wo2;
+  const float* bo2;
+  const float *ln3_g, *ln3_b;
+  const void* w1;     /* [f, d] */
+  const float* b1;
+  const void* w2;     /* [d, f] */
+  const float* b2;
+  void* self_kv;        /* bf16 [B, max_len, 2d]: K | V of the tokens decoded so far; this token's row is written */
+  const void* cross_kv; /* bf16 [B, Te, 2d]: K | V projections of the encoder states */
+} CaDecodeLayer;
+typedef struct CaDecodeDesc {
+  const CaDecodeLayer* layers; /* device array */
+  int32_t n_layers, B, d, f, H, Te, max_len, V;
+  const void *embed, *embed_pos; /* bf16 [V, d] (also the output projection), [max positions, d] */
+  const float *lnf_g, *lnf_b;
+  float eps;
+  float* logits;      /* fp32 [B, ld_logits]: written for every row */
+  int64_t ld_logits;
+  const uint8_t* suppress; /* [V] or NULL */
+  int32_t* out;       /* [B] the tokens picked */
+  uint8_t* done;
+  int64_t* ids;
+  int64_t ld_ids;
+  int32_t *tok, *pos, *klen;
+  int32_t pad_id, eos_id;
+  void* ws;
+  int64_t ws_bytes;
+  uint32_t* status;
+} CaDecodeDesc;
+#define CA_DECODE_MAX_B 16
+#define CA_DECODE_WS_BYTES(B, d, f, H, n_layers)                                                              \
+  (4096 + (int64_t)(n_layers) * 16 * (H) * 4 + (int64_t)16 * (7 * (int64_t)(d) + (f)) * 2 +                     \
+   (int64_t)16 * (H) * CA_ATTN_SPLIT_MAX * 16 * 66 * 4 + 256 * 16 * 8 + 4096)
+int ca_whisper_decode_token(const CaDecodeDesc* desc, void* stream);
+/* 1 when ca_whisper_decode_token takes this shape on the current device, else 0 (the caller keeps the launch sequence) */
+int ca_whisper_decode_token_supported(int32_t B, int32_t d, int32_t f, int32_t H, int32_t V);
+
+/* ------------------------------------------------------------------------------------
  * Data-parallel exchange: bucket collectives over RCCL (xGMI), one context per rank.  Replaces what the reference gets
  * from accelerate's DDP wrapper / DeepSpeed ZeRO-2 under `Trainer` (accelerate/accelerator.py:1892 prepare_model ->
  * DistributedDataParallel, :2053 backward; launch lines R/makefile:79-84): a SUM all-reduce per gradient bucket
