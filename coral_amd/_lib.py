@@ -247,6 +247,7 @@ SIGNATURES = {
     "ca_argmax_masked": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i64, _vp]),
     "ca_whisper_decode_token": (C.c_int, [C.POINTER(CaDecodeDesc), _vp]),
     "ca_whisper_decode_token_supported": (C.c_int, [_i32, _i32, _i32, _i32, _i32]),
+    "ca_debug_decode_stamps": (C.c_int, [_vp, _i32]),
     "ca_argmax_advance": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _i32, _vp]),
     "ca_embed_tokens": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
     "ca_embed_tokens_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),

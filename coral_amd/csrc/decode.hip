@@ -29,7 +29,7 @@
 // acquire in front of it.  Every spin is bounded: on a timeout the workgroup sets status[0] and leaves, the others follow.
 // Buffers are written once per layer and read in the next phase, so re-use one layer later is ordered by the seams.
 //
-// Weights.  A wave's quarter of K of its workgroup's columns of every matrix goes through a private LDS ring (22 pieces of
+// Weights.  A wave's quarter of K of its workgroup's columns of every matrix goes through a private LDS ring (21 pieces of
 // 1 KiB) by LDS-DMA, issued as far ahead as the ring holds (about one layer): piece = 4 columns x 128 k, 256 contiguous
 // bytes per column, chunk positions XOR-ed so that the MFMA fragment reads (ds_read_b128) hit 16 distinct bank slots.
 #include "common.h"
@@ -44,15 +44,21 @@ __device__ __attribute__((aligned(16))) uint32_t g_dec_zero_page[4];
 
 #define DK_NEG_BIG (-1.0e30f)
 #define DK_LOG2E 1.44269504088896340736f
-#define DK_RP 22             // pieces (1 KiB) of a wave's weight ring
+#define DK_RP 21             // pieces (1 KiB) of a wave's weight ring
 #define DK_SCRATCH (64 * 1024)  // LayerNorm image | V rings + merge buffers
-#define DK_PART (4 * 1024)
+#define DK_PART (12 * 1024)   // partial tiles (4 KiB) | seam word (1 KiB) | the layer records (7 KiB: 44 layers)
+#define DK_MAXLAYERS 44
 #define DK_LDS (DK_PART + DK_SCRATCH + 4 * DK_RP * 1024)
 #define DK_XPAD 32           // bf16 elements between rows of the LayerNorm image beyond K (ca_gemm_skinny_kernel's pad)
 #define DK_SPLIT_ROW 66      // floats of a partial: m, l, 64 output columns
 #define DK_MAXTILES 16       // vocabulary tiles per workgroup (V <= 16 * 16 * G)
 #define DK_SPIN_LIMIT (1u << 21)
 
+// CaDecodeLayer as 20 64-bit words (the kernel keeps the records in LDS: a pointer is one ds_read away, not a scalar load
+// from device memory in front of every phase)
+enum { LY_LN1G, LY_LN1B, LY_WQKV, LY_BQKV, LY_WO, LY_BO, LY_LN2G, LY_LN2B, LY_WQ2, LY_BQ2, LY_WO2, LY_BO2, LY_LN3G, LY_LN3B,
+       LY_W1, LY_B1, LY_W2, LY_B2, LY_SELFKV, LY_CROSSKV, LY_WORDS };
+static_assert(sizeof(CaDecodeLayer) == LY_WORDS * 8, "CaDecodeLayer is 20 pointers");
 struct DecArgs {
   const CaDecodeLayer* layers;
   int n_layers, B, d, f, H, Te, Lmax, V, ns;
@@ -76,6 +82,9 @@ struct DecArgs {
   float* amax_val;      // [G][16]
   int* amax_idx;
   unsigned* status;
+  unsigned long long* stamps;  // debug (ca_debug_decode_stamps): [G][stamp_nph][2] realtime ticks, or NULL
+  int stamp_nph;
+  int pre_issue;  // phase E: the first K|V tiles are asked for before the seam
 };
 
 // ---- memory helpers ------------------------------------------------------------------------------------------------
@@ -120,6 +129,27 @@ __device__ __forceinline__ void dk_glds16(const void* g, uint32_t lds_wave_base)
 __device__ __forceinline__ uint32_t dk_lds_addr(const void* p) { return (uint32_t)(uintptr_t)(dk_lptr_t)p; }
 __device__ __forceinline__ bf16x8_t dk_zero8() { return __builtin_bit_cast(bf16x8_t, (f32x4_t){0.f, 0.f, 0.f, 0.f}); }
 
+// wait until at most n vector-memory operations of this wave are outstanding.  Loads complete in order, so "at most n"
+// means every load older than the n youngest operations has landed (stores in flight only make the wait stricter).
+__device__ __forceinline__ void dk_wait_vm(int n) {
+  switch (n) {
+#define DK_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+    DK_W(1) DK_W(2) DK_W(3) DK_W(4) DK_W(5) DK_W(6) DK_W(7) DK_W(8) DK_W(9) DK_W(10) DK_W(11) DK_W(12) DK_W(13) DK_W(14)
+    DK_W(15) DK_W(16) DK_W(17) DK_W(18) DK_W(19) DK_W(20) DK_W(21) DK_W(22) DK_W(23) DK_W(24)
+#undef DK_W
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+}
+
+// debug stamps (ca_debug_decode_stamps): thread 0 of a workgroup appends the shader clock at fixed points of the program
+struct DkDbg {
+  unsigned long long* p;
+  int n, i;
+};
+__device__ __forceinline__ void dk_t(DkDbg& dbg) {
+  if (dbg.p && threadIdx.x == 0 && dbg.i < dbg.n) dbg.p[dbg.i++] = __builtin_readcyclecounter();
+}
+
 // ---- seams -----------------------------------------------------------------------------------------------------------
 // wave 0: wait until every workgroup's progress word is >= target.  Returns false on a timeout (wave-uniform).
 __device__ __forceinline__ bool dk_poll(const DecArgs& a, unsigned target, int G, int lane) {
@@ -138,13 +168,19 @@ __device__ __forceinline__ bool dk_poll(const DecArgs& a, unsigned target, int G
 }
 // All waves: the seam in front of phase `ph` (1-based; waits for every workgroup to have completed ph - 1).  Returns
 // false when the launch is being abandoned.  `lds_ok`: one LDS word.
-__device__ __forceinline__ bool dk_seam(const DecArgs& a, unsigned ph, int G, volatile int* lds_ok, int wave, int lane) {
+__device__ __forceinline__ bool dk_seam(const DecArgs& a, unsigned ph, int G, volatile int* lds_ok, int wave, int lane,
+                                        int keep_in_flight) {
   if (wave == 0) {
     const bool ok = dk_poll(a, ph - 1, G, lane);
     if (lane == 0) {
       *lds_ok = ok ? 1 : 0;
       if (!ok) atomicMax(a.status, ph + 1);
     }
+  }
+  else {
+    // this wave's LDS-DMA pieces - its own and its share of wave 0's - have landed, but for the batch issued last where
+    // the coming phase's entry is older than that batch (keep_in_flight = the batch's instructions, else 0)
+    dk_wait_vm(keep_in_flight);
   }
   __syncthreads();
   const bool ok = *lds_ok != 0;
@@ -170,54 +206,93 @@ __device__ __forceinline__ void dk_cols(int N, int w, int G, int& c0, int& nc) {
 // ---- the weight ring ---------------------------------------------------------------------------------------------------
 struct DkEnt {
   const unsigned short* W;  // row c0 of the matrix
-  int nc, K;                // this workgroup's columns, the matrix's K
+  int nc, K, pcs;           // this workgroup's columns, the matrix's K, pieces of a wave's quarter
 };
 struct DkRing {
   int start, used, next_e, cur_e;
+  int batch_first, batch_issued;  // the latest dk_ring_advance: its first entry, the LDS-DMA instructions THIS wave issued
+};
+// the six projections of a layer as this workgroup sees them (layer-independent: built once, kept in LDS): first column,
+// columns, K, pieces, field of the weight pointer in the layer record; entry 6: K and quads of a vocabulary tile
+struct DkKind {
+  int c0, nc, K, pcs, fld, nquads, pad0, pad1;
 };
 __device__ __forceinline__ int dk_per(int K) { return (((K + 31) >> 5) + 3) >> 2; }  // k-steps of a wave's K quarter
-__device__ __forceinline__ int dk_pieces(const DkEnt& e) {
-  if (e.nc <= 0) return 0;
-  return ((e.nc + 3) >> 2) * ((dk_per(e.K) + 3) >> 2);
+template <class T>
+__device__ __forceinline__ T dk_lyp(const unsigned long long* ltab, int l, int field) {
+  return (T)(uintptr_t)ltab[l * LY_WORDS + field];
 }
-__device__ __forceinline__ DkEnt dk_entry(const DecArgs& a, int e, int w, int G) {
+__device__ __forceinline__ void dk_build_kinds(const DecArgs& a, DkKind* kt, int w, int G) {
+  const int t = threadIdx.x;
+  if (t < 7) {
+    DkKind k;
+    int N = a.d;
+    k.K = a.d;
+    switch (t) {
+      case 0: k.fld = LY_WQKV; N = 3 * a.d; break;
+      case 1: k.fld = LY_WO; break;
+      case 2: k.fld = LY_WQ2; break;
+      case 3: k.fld = LY_WO2; break;
+      case 4: k.fld = LY_W1; N = a.f; break;
+      case 5: k.fld = LY_W2; k.K = a.f; break;
+      default: k.fld = 0; N = 0; break;
+    }
+    k.c0 = 0;
+    k.nc = 0;
+    if (t < 6) dk_cols(N, w, G, k.c0, k.nc);
+    k.nquads = (dk_per(k.K) + 3) >> 2;
+    k.pcs = k.nc > 0 ? ((k.nc + 3) >> 2) * k.nquads : 0;
+    k.pad0 = k.pad1 = 0;
+    kt[t] = k;
+  }
+}
+// pieces of entry e (cheap: what wave 0, which issues nothing, needs)
+__device__ __forceinline__ int dk_entry_pcs(const DecArgs& a, const DkKind* kt, int e, int w, int G) {
+  const int L6 = 6 * a.n_layers;
+  if (e < L6) return kt[e % 6].pcs;
+  const int c0 = 16 * (w + G * (e - L6));
+  const int nc = a.V - c0 < 16 ? a.V - c0 : 16;
+  return nc > 0 ? ((nc + 3) >> 2) * kt[6].nquads : 0;
+}
+__device__ __forceinline__ DkEnt dk_entry(const DecArgs& a, const unsigned long long* ltab, const DkKind* kt, int e, int w, int G) {
   DkEnt r;
   const int L6 = 6 * a.n_layers;
   if (e < L6) {
     const int l = e / 6, p = e - 6 * l;
-    const CaDecodeLayer& ly = a.layers[l];
-    const void* W;
-    int N, K = a.d;
-    switch (p) {
-      case 0: W = ly.wqkv; N = 3 * a.d; break;
-      case 1: W = ly.wo; N = a.d; break;
-      case 2: W = ly.wq2; N = a.d; break;
-      case 3: W = ly.wo2; N = a.d; break;
-      case 4: W = ly.w1; N = a.f; break;
-      default: W = ly.w2; N = a.d; K = a.f; break;
-    }
-    int c0;
-    dk_cols(N, w, G, c0, r.nc);
-    r.K = K;
-    r.W = (const unsigned short*)W + (int64_t)c0 * K;
+    const DkKind k = kt[p];
+    r.nc = k.nc;
+    r.K = k.K;
+    r.pcs = k.pcs;
+    r.W = dk_lyp<const unsigned short*>(ltab, l, k.fld) + (int64_t)k.c0 * k.K;
   } else {
-    const int tile = w + G * (e - L6);
-    const int c0 = 16 * tile;
+    const int c0 = 16 * (w + G * (e - L6));
     r.nc = a.V - c0 < 16 ? a.V - c0 : 16;
     r.K = a.d;
+    r.pcs = r.nc > 0 ? ((r.nc + 3) >> 2) * kt[6].nquads : 0;
     r.W = a.embed + (int64_t)c0 * a.d;
   }
   return r;
 }
 // piece pc of an entry = column group pc / nquads, k-step quad pc % nquads: lane i brings chunk (i & 15) ^ (4 (i >> 4)) of
 // column i >> 4 (16-byte chunks of the quad's 128 k) to position i
-__device__ __forceinline__ void dk_issue_entry(const DkEnt& e, int pcs, int slot0, uint32_t ring_lds, int wave, int lane) {
+// Waves 1 .. 3 issue the LDS-DMA: their own pieces and, dealt round-robin, wave 0's - wave 0 polls the seams, and a load
+// of its own behind freshly issued pieces would wait for them to land (vmcnt counts in order: a 64 KB refill in front of the
+// poll measured +3 .. 4 us on the seam).  The issuing waves wait for their pieces in front of the seam's barrier, where they
+// idle anyway - for all but the batch issued last, which no phase needs yet; behind that barrier the pieces of the next
+// phase are in LDS for all four waves.
+__device__ __forceinline__ int dk_issue_pieces(const DkEnt& e, int slot0, uint32_t ring0_lds, int target, int first, int stride,
+                                               int lane) {
   const int per = dk_per(e.K), nquads = (per + 3) >> 2;
   const int ksteps = (e.K + 31) >> 5;
-  const int ks0 = wave * per;
+  const int ks0 = target * per;
+  const uint32_t ring_lds = ring0_lds + (uint32_t)target * (DK_RP * 1024u);
   const int c = lane >> 4, jj = (lane & 15) ^ (4 * c);
-  int cg = 0, S = 0;
-  for (int pc = 0; pc < pcs; ++pc) {
+  int cg = 0, S = first, n = 0;
+  while (S >= nquads) {
+    S -= nquads;
+    ++cg;
+  }
+  for (int pc = first; pc < e.pcs; pc += stride) {
     const int col = 4 * cg + c;
     const int ks = 4 * S + (jj >> 2);  // k-step within the wave's quarter
     const int k = (ks0 + ks) * 32 + 8 * (jj & 3);
@@ -226,21 +301,29 @@ __device__ __forceinline__ void dk_issue_entry(const DkEnt& e, int pcs, int slot
     int slot = slot0 + pc;
     slot = slot >= DK_RP ? slot - DK_RP : slot;
     dk_glds16(src, ring_lds + (uint32_t)slot * 1024u);
-    if (++S == nquads) {
-      S = 0;
+    ++n;
+    S += stride;
+    while (S >= nquads) {
+      S -= nquads;
       ++cg;
     }
   }
+  return n;
 }
-__device__ __forceinline__ void dk_ring_advance(const DecArgs& a, DkRing& rg, int n_entries, int w, int G, uint32_t ring_lds,
-                                                int wave, int lane) {
+__device__ __forceinline__ void dk_ring_advance(const DecArgs& a, const unsigned long long* ltab, const DkKind* kt, DkRing& rg,
+                                                int n_entries, int w, int G, uint32_t ring_lds, int wave, int lane) {
+  rg.batch_first = rg.next_e;
+  rg.batch_issued = 0;
   while (rg.next_e < n_entries) {
-    const DkEnt e = dk_entry(a, rg.next_e, w, G);
-    const int pcs = dk_pieces(e);
+    const int pcs = dk_entry_pcs(a, kt, rg.next_e, w, G);
     if (rg.used + pcs > DK_RP) break;
-    int slot0 = rg.start + rg.used;
-    slot0 = slot0 >= DK_RP ? slot0 - DK_RP : slot0;
-    if (pcs > 0) dk_issue_entry(e, pcs, slot0, ring_lds, wave, lane);
+    if (pcs > 0 && wave != 0) {
+      int slot0 = rg.start + rg.used;
+      slot0 = slot0 >= DK_RP ? slot0 - DK_RP : slot0;
+      const DkEnt e = dk_entry(a, ltab, kt, rg.next_e, w, G);
+      rg.batch_issued += dk_issue_pieces(e, slot0, ring_lds, wave, 0, 1, lane);
+      rg.batch_issued += dk_issue_pieces(e, slot0, ring_lds, 0, wave - 1, 3, lane);
+    }
     rg.used += pcs;
     ++rg.next_e;
   }
@@ -251,23 +334,99 @@ __device__ __forceinline__ void dk_ring_pop(DkRing& rg, int pcs) {
   rg.used -= pcs;
   ++rg.cur_e;
 }
-// MFMA A fragment (weights) of 16-column tile t16, k-step s of the wave's quarter, from the ring entry at rg.start
-__device__ __forceinline__ bf16x8_t dk_wfrag(const char* ring, int start, int groups, int nquads, int t16, int s, int lane) {
+// MFMA A fragment (weights) of 16-column tile t16, k-step s of the wave's quarter, from the ring entry at `start`: the lane's
+// column group and its four chunk offsets (one per k-step of a quad) are fixed per tile
+struct DkWf {
+  int slot0;   // ring slot of the lane's column group, quad 0
+  int off[4];  // byte offset inside a piece for k-step s & 3
+};
+__device__ __forceinline__ DkWf dk_wfrag_setup(int start, int groups, int nquads, int t16, int lane) {
   const int r = lane & 15, g = lane >> 4;
   int cg = 4 * t16 + (r >> 2);
   cg = cg < groups ? cg : 0;  // (rows beyond the workgroup's columns: a copy, dropped by the epilogue)
   const int c = r & 3;
-  int slot = start + cg * nquads + (s >> 2);
+  DkWf f;
+  f.slot0 = start + cg * nquads;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) f.off[q] = (16 * c + ((4 * q + g) ^ (4 * c))) * 16;
+  return f;
+}
+__device__ __forceinline__ bf16x8_t dk_wfrag(const char* ring, const DkWf& f, int s) {
+  int slot = f.slot0 + (s >> 2);
   slot = slot >= DK_RP ? slot - DK_RP : slot;
-  const int pos = 16 * c + ((4 * (s & 3) + g) ^ (4 * c));
-  return *(const bf16x8_t*)(ring + slot * 1024 + pos * 16);
+  return *(const bf16x8_t*)(ring + slot * 1024 + f.off[s & 3]);
 }
 
+// wave_sum's butterfly (v += v[lane ^ o] for o = 32, 16, 8, 4, 2, 1 - the same pairs, so the same bits) on four values at
+// once with one trip through the LDS crossbar instead of six: ds_bpermute for ^32, v_permlane16_swap for ^16 (of x = y = v
+// it leaves the two partners of every lane in x and y: x + y is the step's result, the operand order being immaterial), DPP
+// for the rest (^8 = row_ror:8, ^4 = half-row mirror of the quad's mirror, ^2 and ^1 quad permutes).  Six ds_bpermute_b32 and their
+// waits per reduction made the LayerNorm of 16 rows 3.7 us of every projection phase that starts with one.
+template <int CTRL>
+__device__ __forceinline__ float dk_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float dk_bfly_sum(float v) {
+#ifdef DK_SHFL_BFLY
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+#endif
+  // (^32: ds_bpermute.  v_permlane32_swap_b32 on this chip left zeros in the low half of its second operand,
+  // tools/r06/bfly_test.hip; and hipcc 7.2 models only the first result of the permlane*_swap builtins, hence inline asm)
+  v += __shfl_xor(v, 32, 64);
+  {
+    unsigned x = __builtin_bit_cast(unsigned, v), y = x;
+    // (s_nop: the VALU -> permlane and permlane -> VALU wait states the assembler does not insert for inline asm)
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
+    v = __builtin_bit_cast(float, x) + __builtin_bit_cast(float, y);
+  }
+  v += dk_dpp<0x128>(v);                 // row_ror:8
+  v += dk_dpp<0x141>(dk_dpp<0x1B>(v));   // quad_perm [3,2,1,0], then row_half_mirror: lane ^ 3 ^ 7 = lane ^ 4
+  v += dk_dpp<0x4E>(v);                  // quad_perm [2,3,0,1]
+  v += dk_dpp<0xB1>(v);                  // quad_perm [1,0,3,2]
+  return v;
+}
+// The LayerNorm arithmetic of ln_fwd_kernel / ca_gemm_skinny_kernel's prologue AS THOSE KERNELS ARE COMPILED: the squared
+// deviations are rounded products added one by one (their loops are packed into v_pk_mul_f32 + v_add_f32: no fused
+// multiply-add), the affine part is one fused multiply-add on the rounded (x - mean) * rstd.  Written out here - contraction
+// off, the one fusion explicit - because the compiler's choice depends on the shape of the code around the expression
+// (four rows side by side compiled to other fusions: different bits in 2 rows of 16, tools/r06/persist_check.py).
+__device__ __forceinline__ float dk_sq_acc(float s2, float x, float mean) {
+#pragma clang fp contract(off)
+  const float dlt = x - mean;
+  const float p = dlt * dlt;
+  return s2 + p;
+}
+__device__ __forceinline__ float dk_ln_apply(float x, float mean, float rstd, float gm, float bt) {
+#pragma clang fp contract(off)
+  const float t = (x - mean) * rstd;
+  return __builtin_fmaf(t, gm, bt);
+}
 // ---- LayerNorm of the B rows into the LDS image (the arithmetic of ca_gemm_skinny_kernel's prologue = ln_fwd_kernel) ---------
 // EMB: the rows are token + position embeddings formed here (embed_kernel's arithmetic) instead of loaded
+// gamma / beta of a LayerNorm into registers: asked for BEFORE the seam in front of the phase (parameters, not handed-off
+// bytes), so their trip to HBM runs while the seam resolves
+template <int NC>
+__device__ __forceinline__ void dk_ln_params(const float* gamma, const float* beta, int C, int lane, f32x4_t (&gq)[NC][2],
+                                             f32x4_t (&bq)[NC][2]) {
+  const int nchunk = C >> 3;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int ch = lane + c * 64;
+    if (ch < nchunk) {
+      gq[c][0] = *(const f32x4_t*)(gamma + ch * 8);
+      gq[c][1] = *(const f32x4_t*)(gamma + ch * 8 + 4);
+      bq[c][0] = *(const f32x4_t*)(beta + ch * 8);
+      bq[c][1] = *(const f32x4_t*)(beta + ch * 8 + 4);
+    } else {
+      gq[c][0] = gq[c][1] = bq[c][0] = bq[c][1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    }
+  }
+}
 template <int NC, bool EMB>
-__device__ __forceinline__ void dk_ln_rows(const DecArgs& a, const unsigned short* x, const float* gamma, const float* beta,
-                                           unsigned short* xs, int wave, int lane) {
+__device__ __forceinline__ void dk_ln_rows(const DecArgs& a, const unsigned short* x, const f32x4_t (&gq)[NC][2],
+                                           const f32x4_t (&bq)[NC][2], unsigned short* xs, int wave, int lane, DkDbg& dbg) {
   const int C = a.d, nchunk = C >> 3, xpitch = C + DK_XPAD;
   u16x8_t raw[4][NC], rawp[EMB ? 4 : 1][EMB ? NC : 1];
 #pragma unroll
@@ -290,17 +449,6 @@ __device__ __forceinline__ void dk_ln_rows(const DecArgs& a, const unsigned shor
       }
     }
   }
-  f32x4_t gq[NC][2], bq[NC][2];
-#pragma unroll
-  for (int c = 0; c < NC; ++c) {
-    const int ch = lane + c * 64;
-    if (ch < nchunk) {
-      gq[c][0] = *(const f32x4_t*)(gamma + ch * 8);
-      gq[c][1] = *(const f32x4_t*)(gamma + ch * 8 + 4);
-      bq[c][0] = *(const f32x4_t*)(beta + ch * 8);
-      bq[c][1] = *(const f32x4_t*)(beta + ch * 8 + 4);
-    }
-  }
   if (!EMB) {
     dk_vm0();
 #pragma unroll
@@ -315,44 +463,58 @@ __device__ __forceinline__ void dk_ln_rows(const DecArgs& a, const unsigned shor
 #pragma unroll
         for (int e = 0; e < 8; ++e) raw[i][c][e] = f2bf(bf2f(raw[i][c][e]) + bf2f(rawp[i][c][e]));
   }
+  dk_t(dbg);  // LN: rows landed
+  // the four rows of a wave side by side (independent reduction chains overlap their latencies); per row the arithmetic
+  // and its order are ln_fwd_kernel's (dk_sq_acc / dk_ln_apply: with the fusions written out).  Rows beyond B are zeros
+  // and are not stored.
+  float sx[4], mean[4], s2[4], rstd[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int lrow = wave + 4 * i;
-    if (lrow >= a.B) break;  // (wave-uniform)
-    float sx = 0.f;
+    sx[i] = 0.f;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       if (lane + c * 64 < nchunk) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) sx += bf2f(raw[i][c][e]);
-      }
-    }
-    const float mean = wave_sum(sx) / (float)C;
-    float s2 = 0.f;
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      if (lane + c * 64 < nchunk) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float dlt = bf2f(raw[i][c][e]) - mean;
-          s2 += dlt * dlt;
-        }
-      }
-    }
-    const float rstd = rsqrtf(wave_sum(s2) / (float)C + a.eps);
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      const int ch = lane + c * 64;
-      if (ch < nchunk) {
-        u16x8_t o8;
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-          o8[e] = f2bf(ln_apply(bf2f(raw[i][c][e]), mean, rstd, e < 4 ? gq[c][0][e] : gq[c][1][e - 4],
-                                e < 4 ? bq[c][0][e] : bq[c][1][e - 4]));
-        *(u16x8_t*)(xs + (int64_t)lrow * xpitch + ch * 8) = o8;
+        for (int e = 0; e < 8; ++e) sx[i] += bf2f(raw[i][c][e]);
       }
     }
   }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) sx[i] = dk_bfly_sum(sx[i]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    mean[i] = sx[i] / (float)C;
+    s2[i] = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      if (lane + c * 64 < nchunk) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s2[i] = dk_sq_acc(s2[i], bf2f(raw[i][c][e]), mean[i]);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) s2[i] = dk_bfly_sum(s2[i]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int lrow = wave + 4 * i;
+    rstd[i] = rsqrtf(s2[i] / (float)C + a.eps);
+    if (lrow < a.B) {
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const int ch = lane + c * 64;
+        if (ch < nchunk) {
+          u16x8_t o8;
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            o8[e] = f2bf(dk_ln_apply(bf2f(raw[i][c][e]), mean[i], rstd[i], e < 4 ? gq[c][0][e] : gq[c][1][e - 4],
+                                     e < 4 ? bq[c][0][e] : bq[c][1][e - 4]));
+          *(u16x8_t*)(xs + (int64_t)lrow * xpitch + ch * 8) = o8;
+        }
+      }
+    }
+  }
+  dk_t(dbg);  // LN: image written
 }
 
 // ---- a projection phase -------------------------------------------------------------------------------------------------
@@ -362,11 +524,12 @@ __device__ __forceinline__ void dk_ln_rows(const DecArgs& a, const unsigned shor
 // epi(m, j0, v[4]) with v = (p0 + p1) + (p2 + p3), the combine of ca_gemm_skinny_kernel.
 template <int PMAX, bool LN, class Epi>
 __device__ __forceinline__ void dk_project(const DecArgs& a, DkRing& rg, const DkEnt& ent, const unsigned short* Ag, int64_t lda,
-                                           const unsigned short* xs, const char* ring, float* part, int wave, int lane, Epi epi) {
+                                           const unsigned short* xs, const char* ring, float* part, const f32x4_t (&bias4)[2],
+                                           int younger, int wave, int lane, DkDbg& dbg, Epi epi) {
   const int r = lane & 15, g = lane >> 4;
   const int K = ent.K, per = dk_per(K), ksteps = (K + 31) >> 5, nquads = (per + 3) >> 2;
   const int ks0 = wave * per, ks1 = ks0 + per < ksteps ? ks0 + per : ksteps;
-  const int groups = (ent.nc + 3) >> 2, pcs = dk_pieces(ent);
+  const int groups = (ent.nc + 3) >> 2, pcs = ent.pcs;
   const int xpitch = K + DK_XPAD;
   if (ent.nc <= 0) {  // (no columns of this matrix: nothing in the ring either)
     dk_ring_pop(rg, 0);
@@ -381,12 +544,17 @@ __device__ __forceinline__ void dk_project(const DecArgs& a, DkRing& rg, const D
       const bool ok = s < per && ks0 + s < ks1 && k < K && r < a.B;
       af[s] = ok ? __builtin_bit_cast(bf16x8_t, dk_ld16_sc1(ap + (int64_t)(ks0 + s) * 32)) : dk_zero8();
     }
-  }
-  dk_vm0();  // the activation rows - and every ring piece issued before them - have landed
-  if (!LN) {
+    dk_vm0();  // the activation rows - and every ring piece issued before them - have landed
 #pragma unroll
     for (int s = 0; s < PMAX; ++s) dk_tie(af[s]);
   } else {
+    // the ring pieces of this entry: everything but the `younger` pieces issued behind them (the LayerNorm's loads,
+    // waited for by the caller, were issued behind the entries that were in flight then)
+#ifdef DK_VM0_ALWAYS
+    dk_vm0();
+#else
+    if (younger >= 0) dk_wait_vm(younger);
+#endif
 #pragma unroll
     for (int s = 0; s < PMAX; ++s) {
       const int k = (ks0 + s) * 32 + 8 * g;
@@ -394,14 +562,16 @@ __device__ __forceinline__ void dk_project(const DecArgs& a, DkRing& rg, const D
       af[s] = ok ? *(const bf16x8_t*)(xs + (int64_t)r * xpitch + k) : dk_zero8();
     }
   }
+  dk_t(dbg);  // project: operands ready
   const int ntile = (ent.nc + 15) >> 4;
   for (int t16 = 0; t16 < ntile; ++t16) {
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    const DkWf wfs = dk_wfrag_setup(rg.start, groups, nquads, t16, lane);
 #pragma unroll
     for (int s = 0; s < PMAX; ++s) {
       if (s < per) {
         const bool ok = ks0 + s < ks1 && (ks0 + s) * 32 + 8 * g < K;
-        bf16x8_t wf = dk_wfrag(ring, rg.start, groups, nquads, t16, s, lane);
+        bf16x8_t wf = dk_wfrag(ring, wfs, s);
         if (!ok) wf = dk_zero8();
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[s], acc, 0, 0, 0);
       }
@@ -410,6 +580,7 @@ __device__ __forceinline__ void dk_project(const DecArgs& a, DkRing& rg, const D
 #pragma unroll
     for (int e = 0; e < 4; ++e) part[wave * 256 + r * 16 + 4 * g + e] = acc[e];
     __syncthreads();
+    dk_t(dbg);  // project: partials of all waves in LDS
     const int j0 = 16 * t16 + 4 * g;
     if (wave == 0 && r < a.B && j0 < ent.nc) {
       float v[4];
@@ -417,11 +588,22 @@ __device__ __forceinline__ void dk_project(const DecArgs& a, DkRing& rg, const D
       for (int e = 0; e < 4; ++e) {
         const int i = r * 16 + 4 * g + e;
         v[e] = (part[i] + part[256 + i]) + (part[512 + i] + part[768 + i]);
+        v[e] = v[e] * 1.0f + (t16 ? bias4[1][e] : bias4[0][e]);
       }
       epi(r, j0, v);
     }
   }
   dk_ring_pop(rg, pcs);
+}
+// the epilogue's bias of wave 0's lanes (this workgroup's first column at bias_c0; at most two 16-column tiles), asked for
+// before the seam in front of the phase
+__device__ __forceinline__ void dk_bias4(const float* bias_c0, int nc, int wave, int lane, f32x4_t (&bias4)[2]) {
+  const int g = lane >> 4;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    bias4[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    if (wave == 0 && bias_c0 && 16 * t + 4 * g < nc) bias4[t] = *(const f32x4_t*)(bias_c0 + 16 * t + 4 * g);
+  }
 }
 // four bf16 of consecutive columns: one 8-byte write-through store
 __device__ __forceinline__ void dk_store4(unsigned short* dst, const unsigned (&hv)[4]) {
@@ -456,25 +638,23 @@ __device__ __forceinline__ bf16x8_t dk_vfrag(const char* img, int s, int nb, int
 // the clip's cache (row strides ldk = ldv = 2d); Tk: rows of the cache (clamp bound), kl: valid keys; vw / nvw: this
 // wave's place among the 4 * ns waves that share the keys.  smem: DK_SCRATCH.  Wave 0 ends with the merged (M, L, o) of
 // the four waves; ns == 1: it stores the output row O (64 bf16, sc1); ns > 1: its partial into `slab`.
-__device__ __forceinline__ void dk_attend(const unsigned short* Q, const unsigned short* K, const unsigned short* V, int64_t ldkv,
+// `hook`: called once the first tiles are in flight and before the query row is read - the seam in front of the phase where
+// K and V do not depend on it (the encoder K|V: 128 KB per CU under way while the seam resolves); false = give up.
+template <class Hook>
+__device__ __forceinline__ bool dk_attend(const unsigned short* Q, const unsigned short* K, const unsigned short* V, int64_t ldkv,
                                           int Tk, int kl, int ns, int sp, float c2, char* smem, unsigned short* O, float* slab,
-                                          int wave, int lane) {
+                                          int wave, int lane, bool pre, Hook hook) {
   constexpr int D = 2, IMG = 64 * 64 * 2, NKS = 2, NNB = 4;
   const int g = lane >> 4, r = lane & 15;
   const int vw = sp * 4 + wave, nvw = 4 * ns;
   char* Vring = smem + wave * D * IMG;
   bf16x8_t qf[NKS];
-#pragma unroll
-  for (int ks = 0; ks < NKS; ++ks) qf[ks] = __builtin_bit_cast(bf16x8_t, dk_ld16_sc1(Q + 32 * ks + 8 * g));
   const int ntile = (kl + 63) / 64;
   const int nw = ntile > vw ? (ntile - vw + nvw - 1) / nvw : 0;
   float m = DK_NEG_BIG, l = 0.f;
   f32x4_t o[NNB];
 #pragma unroll
   for (int nb = 0; nb < NNB; ++nb) o[nb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  dk_vm0();
-#pragma unroll
-  for (int ks = 0; ks < NKS; ++ks) dk_tie(qf[ks]);
   bf16x8_t kf[D][4][NKS];
   auto issue = [&](auto slot_c, int j) {
     constexpr int S = decltype(slot_c)::value;
@@ -580,8 +760,31 @@ __device__ __forceinline__ void dk_attend(const unsigned short* Q, const unsigne
       rest(std::false_type{});
     if (j + D < nw) issue(slot_c, j + D);
   };
+#ifdef DK_V1_ORDER
+  if (!hook()) return false;
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) qf[ks] = __builtin_bit_cast(bf16x8_t, dk_ld16_sc1(Q + 32 * ks + 8 * g));
+  dk_vm0();
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) dk_tie(qf[ks]);
   if (nw > 0) issue(std::integral_constant<int, 0>{}, 0);
   if (nw > 1) issue(std::integral_constant<int, 1>{}, 1);
+#else
+  if (pre) {
+    if (nw > 0) issue(std::integral_constant<int, 0>{}, 0);
+    if (nw > 1) issue(std::integral_constant<int, 1>{}, 1);
+    if (!hook()) return false;
+  } else {
+    if (!hook()) return false;
+    if (nw > 0) issue(std::integral_constant<int, 0>{}, 0);
+    if (nw > 1) issue(std::integral_constant<int, 1>{}, 1);
+  }
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) qf[ks] = __builtin_bit_cast(bf16x8_t, dk_ld16_sc1(Q + 32 * ks + 8 * g));
+  dk_vm0();  // (the query; the first tiles, older, with it)
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) dk_tie(qf[ks]);
+#endif
   for (int j = 0; j < nw; j += D) {
     step(std::integral_constant<int, 0>{}, j);
     if (j + 1 < nw) step(std::integral_constant<int, 1>{}, j + 1);
@@ -635,6 +838,7 @@ __device__ __forceinline__ void dk_attend(const unsigned short* Q, const unsigne
     }
   }
   __syncthreads();  // (the merge buffers are the next item's V rings)
+  return true;
 }
 // wave 0 of the workgroup that drew the last ticket of (clip, head): merge the ns partials in slab order (the arithmetic
 // of attn_fwd_smallq_kernel's split merge) and store the output row
@@ -680,86 +884,107 @@ __global__ __launch_bounds__(256) void whisper_decode_token_kernel(const DecArgs
   extern __shared__ __attribute__((aligned(16))) char dk_smem[];
   constexpr int PD = 4 * NC, PF = 16 * NC;  // k-steps of a wave's quarter of K = d / K = f, at most
   float* part = (float*)dk_smem;
-  volatile int* lds_ok = (volatile int*)(dk_smem + DK_PART - 16);
+  volatile int* lds_ok = (volatile int*)(dk_smem + 4096);
+  unsigned long long* ltab = (unsigned long long*)(dk_smem + 5120);
   char* scratch = dk_smem + DK_PART;
   unsigned short* xs = (unsigned short*)scratch;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const char* ring = dk_smem + DK_PART + DK_SCRATCH + wave * DK_RP * 1024;
-  const uint32_t ring_lds = dk_lds_addr(ring);
+  const uint32_t ring_lds = dk_lds_addr(dk_smem + DK_PART + DK_SCRATCH);  // (wave 0's ring: dk_issue_pieces adds the wave)
   const int G = gridDim.x, w = blockIdx.x;
   const int r = lane & 15, g = lane >> 4;
   const int d = a.d, B = a.B, H = a.H;
   const int ntiles = (a.V + 15) >> 4;
   const int my_tiles = ntiles > w ? (ntiles - w + G - 1) / G : 0;
   const int n_entries = 6 * a.n_layers + (ntiles + G - 1) / G;
-  DkRing rg = {0, 0, 0, 0};
-  dk_ring_advance(a, rg, n_entries, w, G, ring_lds, wave, lane);
+  DkKind* kt = (DkKind*)(dk_smem + 4096 + 64);  // (7 x 32 bytes behind the seam word)
+  for (int i = threadIdx.x; i < a.n_layers * LY_WORDS; i += 256) ltab[i] = ((const unsigned long long*)a.layers)[i];
+  dk_build_kinds(a, kt, w, G);
+  __syncthreads();
+  DkRing rg = {0, 0, 0, 0, 0, 0};
+  dk_ring_advance(a, ltab, kt, rg, n_entries, w, G, ring_lds, wave, lane);
   unsigned ph = 0;  // phases completed by this workgroup
   int dc0, dnc;
   dk_cols(d, w, G, dc0, dnc);  // this workgroup's columns of every N = d projection (at most 16)
   // wave 0: the residual stream at (row r, column dc0 + 4 g + e), as stored (bf16).  Layer 0: the embedding rows
   // (embed_kernel's arithmetic)
   float res[4] = {0.f, 0.f, 0.f, 0.f};
+  const int mypos = r < B ? a.pos[r] : 0;  // the cache row this token's K|V go to (clip r)
   if (wave == 0 && r < B && 4 * g < dnc) {
-    const int64_t t_off = (int64_t)a.tok[r] * d, p_off = (int64_t)a.pos[r] * d;
+    const int64_t t_off = (int64_t)a.tok[r] * d, p_off = (int64_t)mypos * d;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int n = dc0 + 4 * g + e;
       res[e] = bf2f(f2bf(bf2f(a.embed[t_off + n]) + bf2f(a.pos_tab[p_off + n])));
     }
   }
+  int my_kl = 0;  // keys of the first self-attention item of this workgroup
+  if (w < B * H) {
+    my_kl = a.klen[w / H];
+    my_kl = my_kl < a.Lmax ? my_kl : a.Lmax;
+  }
+  DkDbg dbg = {a.stamps ? a.stamps + (int64_t)w * a.stamp_nph : nullptr, a.stamp_nph, 0};
+#define DK_STAMP(which) dk_t(dbg)
 #define DK_SEAM()                                          \
   do {                                                     \
-    if (!dk_seam(a, ph + 1, G, lds_ok, wave, lane)) return; \
+    if (!dk_seam(a, ph + 1, G, lds_ok, wave, lane, rg.cur_e < rg.batch_first ? rg.batch_issued : 0)) return; \
+    DK_STAMP(0);                                           \
   } while (0)
-#define DK_DONE()                                                   \
-  do {                                                              \
-    ++ph;                                                           \
-    dk_publish(a, ph, w, wave, lane);                               \
-    dk_ring_advance(a, rg, n_entries, w, G, ring_lds, wave, lane);  \
+#define DK_DONE()                                                         \
+  do {                                                                    \
+    DK_STAMP(1);                                                          \
+    ++ph;                                                                 \
+    dk_publish(a, ph, w, wave, lane);                                     \
+    dk_t(dbg);                                                            \
+    dk_ring_advance(a, ltab, kt, rg, n_entries, w, G, ring_lds, wave, lane);  \
+    dk_t(dbg);                                                            \
   } while (0)
-  // out-projection / fc2 epilogue: + bias + residual, rounded to bf16 as the launch sequence stores it, kept as the next
-  // residual
-  auto res_epi = [&](const float* bias, unsigned short* dst) {
-    return [&res, bias, dst, dc0, d](int m, int j0, const float(&v)[4]) {
+  // out-projection / fc2 epilogue: (+ bias, by the projection) + residual, rounded to bf16 as the launch sequence stores it,
+  // kept as the next residual
+  auto res_epi = [&](unsigned short* dst) {
+    return [&res, dst, dc0, d](int m, int j0, const float(&v)[4]) {
       unsigned hv[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        float t = v[e] * 1.0f + (bias ? bias[dc0 + j0 + e] : 0.f);
-        t += res[e];
-        hv[e] = f2bf(t);
+        hv[e] = f2bf(v[e] + res[e]);
         res[e] = bf2f((unsigned short)hv[e]);
       }
       dk_store4(dst + (int64_t)m * d + dc0 + j0, hv);
     };
   };
+  auto no_hook = [] { return true; };
 
   for (int l = 0; l < a.n_layers; ++l) {
-    const CaDecodeLayer& ly = a.layers[l];
-    unsigned short* ckv = (unsigned short*)ly.self_kv;
+    unsigned short* ckv = dk_lyp<unsigned short*>(ltab, l, LY_SELFKV);
     // ---- A: LayerNorm + q|k|v -------------------------------------------------------------------------------------------
     {
-      const DkEnt ent = dk_entry(a, rg.cur_e, w, G);
+      const DkEnt ent = dk_entry(a, ltab, kt, rg.cur_e, w, G);
       int c0, nc;
       dk_cols(3 * d, w, G, c0, nc);
+      f32x4_t gq[NC][2], bq[NC][2], bias4[2];
+      dk_ln_params<NC>(dk_lyp<const float*>(ltab, l, LY_LN1G), dk_lyp<const float*>(ltab, l, LY_LN1B), d, lane, gq, bq);
+      const float* bias = dk_lyp<const float*>(ltab, l, LY_BQKV);
+      dk_bias4(bias ? bias + c0 : nullptr, nc, wave, lane, bias4);
       if (l > 0) {
         DK_SEAM();
-        if (nc > 0) dk_ln_rows<NC, false>(a, a.h, ly.ln1_g, ly.ln1_b, xs, wave, lane);
+        if (nc > 0) dk_ln_rows<NC, false>(a, a.h, gq, bq, xs, wave, lane, dbg);
       } else {
+        if (wave != 0) dk_vm0();  // (the first ring pieces: see dk_issue_entry)
         __syncthreads();
-        if (nc > 0) dk_ln_rows<NC, true>(a, nullptr, ly.ln1_g, ly.ln1_b, xs, wave, lane);
+        if (nc > 0) dk_ln_rows<NC, true>(a, nullptr, gq, bq, xs, wave, lane, dbg);
       }
       __syncthreads();
-      const float* bias = ly.bqkv;
-      dk_project<PD, true>(a, rg, ent, nullptr, 0, xs, ring, part, wave, lane, [&](int m, int j0, const float(&v)[4]) {
-        const int n = c0 + j0;  // (a group of four never straddles d: both are multiples of 4)
-        unsigned hv[4];
+      dk_project<PD, true>(a, rg, ent, nullptr, 0, xs, ring, part, bias4, -1, wave, lane, dbg,
+                           [&](int m, int j0, const float(&v)[4]) {
+                             const int n = c0 + j0;  // (a group of four never straddles d: both are multiples of 4)
+                             unsigned hv[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) hv[e] = f2bf(v[e] * 1.0f + (bias ? bias[n + e] : 0.f));
-        unsigned short* dst = n < d ? a.q + (int64_t)m * d + n : ckv + ((int64_t)m * a.Lmax + a.pos[m]) * 2 * d + (n - d);
-        dk_store4(dst, hv);
-      });
+                             for (int e = 0; e < 4; ++e) hv[e] = f2bf(v[e]);
+                             unsigned short* dst = n < d ? a.q + (int64_t)m * d + n
+                                                         : ckv + ((int64_t)m * a.Lmax + mypos) * 2 * d + (n - d);
+                             dk_store4(dst, hv);
+                           });
       DK_DONE();
     }
     // ---- B: self-attention over the cache ----------------------------------------------------------------------------------
@@ -774,53 +999,72 @@ __global__ __launch_bounds__(256) void whisper_decode_token_kernel(const DecArgs
         __syncthreads();
         for (int it = w; it < B * H; it += G) {
           const int b = it / H, h = it - b * H;
-          int kl = a.klen[b];
-          kl = kl < a.Lmax ? kl : a.Lmax;
+          int kl = my_kl;
+          if (it != w) {
+            kl = a.klen[b];
+            kl = kl < a.Lmax ? kl : a.Lmax;
+          }
           const unsigned short* Kp = ckv + (int64_t)b * a.Lmax * 2 * d + h * 64;
           dk_attend(a.q + (int64_t)b * d + h * 64, Kp, Kp + d, 2 * d, a.Lmax, kl, 1, 0, a.scale * DK_LOG2E, scratch,
-                    a.ctx + (int64_t)b * d + h * 64, nullptr, wave, lane);
+                    a.ctx + (int64_t)b * d + h * 64, nullptr, wave, lane, false, no_hook);
         }
       }
       DK_DONE();
     }
     // ---- C: out-projection + residual ----------------------------------------------------------------------------------------
     {
-      const DkEnt ent = dk_entry(a, rg.cur_e, w, G);
+      const DkEnt ent = dk_entry(a, ltab, kt, rg.cur_e, w, G);
+      const float* bias = dk_lyp<const float*>(ltab, l, LY_BO);
+      f32x4_t bias4[2];
+      dk_bias4(bias ? bias + dc0 : nullptr, ent.nc, wave, lane, bias4);
       if (ent.nc > 0) DK_SEAM();
-      dk_project<PD, false>(a, rg, ent, a.ctx, d, nullptr, ring, part, wave, lane, res_epi(ly.bo, a.h1));
+      dk_project<PD, false>(a, rg, ent, a.ctx, d, nullptr, ring, part, bias4, -1, wave, lane, dbg, res_epi(a.h1));
       DK_DONE();
     }
     // ---- D: LayerNorm + cross-attention query ----------------------------------------------------------------------------------
     {
-      const DkEnt ent = dk_entry(a, rg.cur_e, w, G);
+      const DkEnt ent = dk_entry(a, ltab, kt, rg.cur_e, w, G);
+      f32x4_t gq[NC][2], bq[NC][2], bias4[2];
+      dk_ln_params<NC>(dk_lyp<const float*>(ltab, l, LY_LN2G), dk_lyp<const float*>(ltab, l, LY_LN2B), d, lane, gq, bq);
+      const float* bias = dk_lyp<const float*>(ltab, l, LY_BQ2);
+      dk_bias4(bias ? bias + dc0 : nullptr, ent.nc, wave, lane, bias4);
       if (ent.nc > 0) {
         DK_SEAM();
-        dk_ln_rows<NC, false>(a, a.h1, ly.ln2_g, ly.ln2_b, xs, wave, lane);
+        dk_ln_rows<NC, false>(a, a.h1, gq, bq, xs, wave, lane, dbg);
         __syncthreads();
       }
-      const float* bias = ly.bq2;
-      dk_project<PD, true>(a, rg, ent, nullptr, 0, xs, ring, part, wave, lane, [&](int m, int j0, const float(&v)[4]) {
-        const int n = dc0 + j0;
-        unsigned hv[4];
+      dk_project<PD, true>(a, rg, ent, nullptr, 0, xs, ring, part, bias4, -1, wave, lane, dbg,
+                           [&](int m, int j0, const float(&v)[4]) {
+                             unsigned hv[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) hv[e] = f2bf(v[e] * 1.0f + (bias ? bias[n + e] : 0.f));
-        dk_store4(a.q2 + (int64_t)m * d + n, hv);
-      });
+                             for (int e = 0; e < 4; ++e) hv[e] = f2bf(v[e]);
+                             dk_store4(a.q2 + (int64_t)m * d + dc0 + j0, hv);
+                           });
       DK_DONE();
     }
     // ---- E: attention over the encoder K|V -------------------------------------------------------------------------------------
     {
       const int ns = a.ns, nit = B * H * ns;
       if (w < nit) {
-        DK_SEAM();
-        const unsigned short* xkv = (const unsigned short*)ly.cross_kv;
+        const unsigned short* xkv = dk_lyp<const unsigned short*>(ltab, l, LY_CROSSKV);
         for (int it = w; it < nit; it += G) {
           const int bh = it / ns, sp = it - bh * ns;
           const int b = bh / H, h = bh - b * H;
           const unsigned short* Kp = xkv + (int64_t)b * a.Te * 2 * d + h * 64;
           unsigned short* O = a.ctx2 + (int64_t)b * d + h * 64;
-          dk_attend(a.q2 + (int64_t)b * d + h * 64, Kp, Kp + d, 2 * d, a.Te, a.Te, ns, sp, a.scale * DK_LOG2E, scratch, O,
-                    a.slab + (int64_t)it * DK_SPLIT_ROW, wave, lane);
+          bool ok;
+          // (the first item's first tiles are asked for BEFORE the seam: K and V do not depend on this token)
+          if (it == w)
+            ok = dk_attend(a.q2 + (int64_t)b * d + h * 64, Kp, Kp + d, 2 * d, a.Te, a.Te, ns, sp, a.scale * DK_LOG2E, scratch, O,
+                           a.slab + (int64_t)it * DK_SPLIT_ROW, wave, lane, a.pre_issue != 0, [&] {
+                             const bool pass = dk_seam(a, ph + 1, G, lds_ok, wave, lane, 0);
+                             if (pass) DK_STAMP(0);
+                             return pass;
+                           });
+          else
+            ok = dk_attend(a.q2 + (int64_t)b * d + h * 64, Kp, Kp + d, 2 * d, a.Te, a.Te, ns, sp, a.scale * DK_LOG2E, scratch, O,
+                           a.slab + (int64_t)it * DK_SPLIT_ROW, wave, lane, false, no_hook);
+          if (!ok) return;
           if (ns > 1 && wave == 0) {
             dk_vm0();  // this workgroup's partial is out
             unsigned ticket = 0;
@@ -835,36 +1079,45 @@ __global__ __launch_bounds__(256) void whisper_decode_token_kernel(const DecArgs
     }
     // ---- F: out-projection + residual ----------------------------------------------------------------------------------------
     {
-      const DkEnt ent = dk_entry(a, rg.cur_e, w, G);
+      const DkEnt ent = dk_entry(a, ltab, kt, rg.cur_e, w, G);
+      const float* bias = dk_lyp<const float*>(ltab, l, LY_BO2);
+      f32x4_t bias4[2];
+      dk_bias4(bias ? bias + dc0 : nullptr, ent.nc, wave, lane, bias4);
       if (ent.nc > 0) DK_SEAM();
-      dk_project<PD, false>(a, rg, ent, a.ctx2, d, nullptr, ring, part, wave, lane, res_epi(ly.bo2, a.h2));
+      dk_project<PD, false>(a, rg, ent, a.ctx2, d, nullptr, ring, part, bias4, -1, wave, lane, dbg, res_epi(a.h2));
       DK_DONE();
     }
     // ---- G: LayerNorm + fc1 + GELU ----------------------------------------------------------------------------------------------
     {
-      const DkEnt ent = dk_entry(a, rg.cur_e, w, G);
+      const DkEnt ent = dk_entry(a, ltab, kt, rg.cur_e, w, G);
       int c0, nc;
       dk_cols(a.f, w, G, c0, nc);
+      f32x4_t gq[NC][2], bq[NC][2], bias4[2];
+      dk_ln_params<NC>(dk_lyp<const float*>(ltab, l, LY_LN3G), dk_lyp<const float*>(ltab, l, LY_LN3B), d, lane, gq, bq);
+      const float* bias = dk_lyp<const float*>(ltab, l, LY_B1);
+      dk_bias4(bias ? bias + c0 : nullptr, nc, wave, lane, bias4);
       if (nc > 0) {
         DK_SEAM();
-        dk_ln_rows<NC, false>(a, a.h2, ly.ln3_g, ly.ln3_b, xs, wave, lane);
+        dk_ln_rows<NC, false>(a, a.h2, gq, bq, xs, wave, lane, dbg);
         __syncthreads();
       }
-      const float* bias = ly.b1;
-      dk_project<PD, true>(a, rg, ent, nullptr, 0, xs, ring, part, wave, lane, [&](int m, int j0, const float(&v)[4]) {
-        const int n = c0 + j0;
-        unsigned hv[4];
+      dk_project<PD, true>(a, rg, ent, nullptr, 0, xs, ring, part, bias4, -1, wave, lane, dbg,
+                           [&](int m, int j0, const float(&v)[4]) {
+                             unsigned hv[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) hv[e] = f2bf(gelu_erf(v[e] * 1.0f + (bias ? bias[n + e] : 0.f)));
-        dk_store4(a.gbuf + (int64_t)m * a.f + n, hv);
-      });
+                             for (int e = 0; e < 4; ++e) hv[e] = f2bf(gelu_erf(v[e]));
+                             dk_store4(a.gbuf + (int64_t)m * a.f + c0 + j0, hv);
+                           });
       DK_DONE();
     }
     // ---- H: fc2 + residual: the next layer's input ---------------------------------------------------------------------------------
     {
-      const DkEnt ent = dk_entry(a, rg.cur_e, w, G);
+      const DkEnt ent = dk_entry(a, ltab, kt, rg.cur_e, w, G);
+      const float* bias = dk_lyp<const float*>(ltab, l, LY_B2);
+      f32x4_t bias4[2];
+      dk_bias4(bias ? bias + dc0 : nullptr, ent.nc, wave, lane, bias4);
       if (ent.nc > 0) DK_SEAM();
-      dk_project<PF, false>(a, rg, ent, a.gbuf, a.f, nullptr, ring, part, wave, lane, res_epi(ly.b2, a.h));
+      dk_project<PF, false>(a, rg, ent, a.gbuf, a.f, nullptr, ring, part, bias4, -1, wave, lane, dbg, res_epi(a.h));
       DK_DONE();
     }
   }
@@ -872,28 +1125,35 @@ __global__ __launch_bounds__(256) void whisper_decode_token_kernel(const DecArgs
   float best = -__builtin_inff();
   int bi = 0x7fffffff;
   if (my_tiles > 0) {
+    f32x4_t gq[NC][2], bq[NC][2];
+    const f32x4_t nobias[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    dk_ln_params<NC>(a.lnf_g, a.lnf_b, d, lane, gq, bq);
     DK_SEAM();
-    dk_ln_rows<NC, false>(a, a.h, a.lnf_g, a.lnf_b, xs, wave, lane);
-    __syncthreads();
+    dk_ln_rows<NC, false>(a, a.h, gq, bq, xs, wave, lane, dbg);
     for (int t = 0; t < my_tiles; ++t) {
-      const DkEnt ent = dk_entry(a, rg.cur_e, w, G);
+      const DkEnt ent = dk_entry(a, ltab, kt, rg.cur_e, w, G);
       const int n0 = 16 * (w + G * t);
-      dk_project<PD, true>(a, rg, ent, nullptr, 0, xs, ring, part, wave, lane, [&](int m, int j0, const float(&v)[4]) {
+      // this tile's pieces have landed (the issuing waves wait; the next tiles' pieces, issued behind them, stay in
+      // flight); the barrier also says that wave 0 has read the previous tile's partials and the image is written
+      if (wave != 0) dk_wait_vm(t == 0 ? 0 : rg.used - ent.pcs);
+      __syncthreads();
+      dk_project<PD, true>(a, rg, ent, nullptr, 0, xs, ring, part, nobias, -1, wave, lane, dbg,
+                           [&](int m, int j0, const float(&v)[4]) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int n = n0 + j0 + e;
-          if (n < a.V) {
-            const float x = v[e] * 1.0f + 0.f;
-            a.logits[(int64_t)m * a.ld_logits + n] = x;
-            if (!(a.suppress && a.suppress[n]) && x > best) {  // (a lane's candidates come in increasing index order)
-              best = x;
-              bi = n;
-            }
-          }
-        }
-      });
-      __syncthreads();  // (wave 0 has read the partials before the next tile's are written)
-      dk_ring_advance(a, rg, n_entries, w, G, ring_lds, wave, lane);
+                             for (int e = 0; e < 4; ++e) {
+                               const int n = n0 + j0 + e;
+                               if (n < a.V) {
+                                 const float x = v[e];
+                                 a.logits[(int64_t)m * a.ld_logits + n] = x;
+                                 // (a lane's candidates come in increasing index order)
+                                 if (!(a.suppress && a.suppress[n]) && x > best) {
+                                   best = x;
+                                   bi = n;
+                                 }
+                               }
+                             }
+                           });
+      dk_ring_advance(a, ltab, kt, rg, n_entries, w, G, ring_lds, wave, lane);
     }
   }
   // this workgroup's best per row: lanes (r, g) hold row r
@@ -965,6 +1225,7 @@ __global__ __launch_bounds__(256) void whisper_decode_token_kernel(const DecArgs
   }
 #undef DK_SEAM
 #undef DK_DONE
+#undef DK_STAMP
 }
 
 // ---- C ABI --------------------------------------------------------------------------------------------------------------------
@@ -975,6 +1236,15 @@ static int dk_device_cus() {
     return n;
   }();
   return ncu;
+}
+static unsigned long long* g_dk_stamps = nullptr;
+static int g_dk_stamp_nph = 0;
+// debug: launches from now on leave per-workgroup phase stamps (shader clock) in `device_buf` ([CUs][nph][2] 64-bit words:
+// seam passed / phase done); NULL switches them off
+extern "C" int ca_debug_decode_stamps(void* device_buf, int32_t nph) {
+  g_dk_stamps = (unsigned long long*)device_buf;
+  g_dk_stamp_nph = device_buf ? nph : 0;
+  return CA_OK;
 }
 extern "C" int ca_whisper_decode_token_supported(int32_t B, int32_t d, int32_t f, int32_t H, int32_t V) {
   const int G = dk_device_cus();
@@ -1000,7 +1270,7 @@ extern "C" int ca_whisper_decode_token(const CaDecodeDesc* desc, void* stream) {
                    desc->out && desc->done && desc->ids && desc->tok && desc->pos && desc->klen && desc->ws && desc->status,
                "ca_whisper_decode_token: null pointer");
   const CaDecodeDesc& c = *desc;
-  CA_CHECK_ARG(c.n_layers > 0 && ca_whisper_decode_token_supported(c.B, c.d, c.f, c.H, c.V),
+  CA_CHECK_ARG(c.n_layers > 0 && c.n_layers <= DK_MAXLAYERS && ca_whisper_decode_token_supported(c.B, c.d, c.f, c.H, c.V),
                "ca_whisper_decode_token: shape not supported (B <= %d, head_dim 64, d_model <= 1536, <= 256 CUs)", CA_DECODE_MAX_B);
   CA_CHECK_ARG(c.Te > 0 && c.max_len > 0 && c.ld_logits >= c.V && c.ld_ids >= c.max_len, "ca_whisper_decode_token: bad sizes");
   CA_CHECK_ARG(c.ws_bytes >= CA_DECODE_WS_BYTES(c.B, c.d, c.f, c.H, c.n_layers) && ((uintptr_t)c.ws % 16) == 0,
@@ -1041,6 +1311,10 @@ extern "C" int ca_whisper_decode_token(const CaDecodeDesc* desc, void* stream) {
   a.amax_val = (float*)p; p += 256 * 16 * 4;
   a.amax_idx = (int*)p; p += 256 * 16 * 4;
   a.status = c.status;
+  a.stamps = g_dk_stamps;
+  a.stamp_nph = g_dk_stamp_nph;
+  static const int pre = [] { const char* e = getenv("CA_DECODE_PREISSUE"); return e ? atoi(e) : 1; }();
+  a.pre_issue = pre;
   CA_CHECK_ARG((size_t)(p - (char*)c.ws) <= (size_t)c.ws_bytes, "ca_whisper_decode_token: workspace layout exceeds ws_bytes");
   hipStream_t s = (hipStream_t)stream;
   static bool attr = false;

@@ -645,6 +645,9 @@ typedef struct CaDecodeDesc {
 int ca_whisper_decode_token(const CaDecodeDesc* desc, void* stream);
 /* 1 when ca_whisper_decode_token takes this shape on the current device, else 0 (the caller keeps the launch sequence) */
 int ca_whisper_decode_token_supported(int32_t B, int32_t d, int32_t f, int32_t H, int32_t V);
+/* debug / measurement: launches of ca_whisper_decode_token from now on leave per-workgroup phase stamps (shader clock) in
+ * device_buf, [CUs][nph][2] 64-bit words (seam passed, phase done); NULL switches them off (tools/r06/persist_stamps.py) */
+int ca_debug_decode_stamps(void* device_buf, int32_t nph);
 
 /* ------------------------------------------------------------------------------------
  * Data-parallel exchange: bucket collectives over RCCL (xGMI), one context per rank.  Replaces what the reference gets

@@ -58,6 +58,17 @@ for B in batches:
         print(f"{model} B={B} token {t}: status {st} logits {'same' if same_logits else f'DIFFER ({nd} values, max {md:.3e})'} "
               f"tokens {'same' if same_tok else 'DIFFER'} bookkeeping {'same' if same_book else 'DIFFER'} "
               f"cache {'same' if same_cache else 'DIFFER'}", flush=True)
+        if not ok:
+            rows = (la != lb).any(1).nonzero().flatten().tolist()
+            print("   rows that differ:", rows, "tok(launches)", ga["tok"].tolist(), "tok(persistent)", gb["tok"].tolist(),
+                  "done", ga["done"].tolist(), "pos", ga["pos"].tolist()[:4])
+            for li, (x, y) in enumerate(zip(ca["kv"], cb["kv"])):
+                if not torch.equal(x, y):
+                    dd = (x.view(B, Lmax, -1) != y.view(B, Lmax, -1))
+                    print("   first cache layer that differs:", li, "clips", dd.any(2).any(1).nonzero().flatten().tolist(),
+                          "positions", dd.any(2).any(0).nonzero().flatten().tolist(), "cols(min,max)",
+                          int(dd.any(0).any(0).nonzero().min()), int(dd.any(0).any(0).nonzero().max()))
+                    break
         if st[0] != 0:
             break
     del eng, kv, ca, cb, ga, gb, ps
