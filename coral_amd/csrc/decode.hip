@@ -215,7 +215,8 @@ struct DkRing {
 // the six projections of a layer as this workgroup sees them (layer-independent: built once, kept in LDS): first column,
 // columns, K, pieces, field of the weight pointer in the layer record; entry 6: K and quads of a vocabulary tile
 struct DkKind {
-  int c0, nc, K, pcs, fld, nquads, pad0, pad1;
+  int c0, nc, K, pcs, fld, nquads;
+  int ln_fld, bias_fld;  // fields of the LayerNorm gamma (beta = + 1; -1: no LayerNorm) and of the bias in the layer record
 };
 __device__ __forceinline__ int dk_per(int K) { return (((K + 31) >> 5) + 3) >> 2; }  // k-steps of a wave's K quarter
 template <class T>
@@ -228,21 +229,22 @@ __device__ __forceinline__ void dk_build_kinds(const DecArgs& a, DkKind* kt, int
     DkKind k;
     int N = a.d;
     k.K = a.d;
+    k.ln_fld = -1;
+    k.bias_fld = 0;
     switch (t) {
-      case 0: k.fld = LY_WQKV; N = 3 * a.d; break;
-      case 1: k.fld = LY_WO; break;
-      case 2: k.fld = LY_WQ2; break;
-      case 3: k.fld = LY_WO2; break;
-      case 4: k.fld = LY_W1; N = a.f; break;
-      case 5: k.fld = LY_W2; k.K = a.f; break;
-      default: k.fld = 0; N = 0; break;
+      case 0: k.fld = LY_WQKV; N = 3 * a.d; k.ln_fld = LY_LN1G; k.bias_fld = LY_BQKV; break;
+      case 1: k.fld = LY_WO; k.bias_fld = LY_BO; break;
+      case 2: k.fld = LY_WQ2; k.ln_fld = LY_LN2G; k.bias_fld = LY_BQ2; break;
+      case 3: k.fld = LY_WO2; k.bias_fld = LY_BO2; break;
+      case 4: k.fld = LY_W1; N = a.f; k.ln_fld = LY_LN3G; k.bias_fld = LY_B1; break;
+      case 5: k.fld = LY_W2; k.K = a.f; k.bias_fld = LY_B2; break;
+      default: k.fld = 0; N = 0; break;  // a vocabulary tile: K, quads
     }
     k.c0 = 0;
     k.nc = 0;
     if (t < 6) dk_cols(N, w, G, k.c0, k.nc);
     k.nquads = (dk_per(k.K) + 3) >> 2;
     k.pcs = k.nc > 0 ? ((k.nc + 3) >> 2) * k.nquads : 0;
-    k.pad0 = k.pad1 = 0;
     kt[t] = k;
   }
 }
@@ -406,15 +408,15 @@ __device__ __forceinline__ float dk_ln_apply(float x, float mean, float rstd, fl
 // ---- LayerNorm of the B rows into the LDS image (the arithmetic of ca_gemm_skinny_kernel's prologue = ln_fwd_kernel) ---------
 // EMB: the rows are token + position embeddings formed here (embed_kernel's arithmetic) instead of loaded
 // gamma / beta of a LayerNorm into registers: asked for BEFORE the seam in front of the phase (parameters, not handed-off
-// bytes), so their trip to HBM runs while the seam resolves
-template <int NC>
+// bytes), so their trip to HBM runs while the seam resolves.  NCX: d is a multiple of 512 (every lane has NC whole chunks).
+template <int NC, bool NCX>
 __device__ __forceinline__ void dk_ln_params(const float* gamma, const float* beta, int C, int lane, f32x4_t (&gq)[NC][2],
                                              f32x4_t (&bq)[NC][2]) {
   const int nchunk = C >> 3;
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
     const int ch = lane + c * 64;
-    if (ch < nchunk) {
+    if (NCX || c < NC - 1 || ch < nchunk) {
       gq[c][0] = *(const f32x4_t*)(gamma + ch * 8);
       gq[c][1] = *(const f32x4_t*)(gamma + ch * 8 + 4);
       bq[c][0] = *(const f32x4_t*)(beta + ch * 8);
@@ -424,32 +426,26 @@ __device__ __forceinline__ void dk_ln_params(const float* gamma, const float* be
     }
   }
 }
-template <int NC, bool EMB>
-__device__ __forceinline__ void dk_ln_rows(const DecArgs& a, const unsigned short* x, const f32x4_t (&gq)[NC][2],
-                                           const f32x4_t (&bq)[NC][2], unsigned short* xs, int wave, int lane, DkDbg& dbg) {
+// LayerNorm of the 16 rows into the LDS image (the arithmetic of ca_gemm_skinny_kernel's prologue = ln_fwd_kernel): a wave
+// takes rows wave, wave + 4, ...; rows beyond B are formed from zeros and not stored.  emb: the rows are token + position
+// embeddings formed here (embed_kernel's arithmetic) instead of loaded.
+template <int NC, bool NCX>
+__device__ __forceinline__ void dk_ln_rows(const DecArgs& a, const unsigned short* x, bool emb, const f32x4_t (&gq)[NC][2],
+                                           const f32x4_t (&bq)[NC][2], unsigned short* xs, int wave, int lane) {
   const int C = a.d, nchunk = C >> 3, xpitch = C + DK_XPAD;
-  u16x8_t raw[4][NC], rawp[EMB ? 4 : 1][EMB ? NC : 1];
+  const u16x8_t z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  u16x8_t raw[4][NC];
+  if (!emb) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = wave + 4 * i;
-    int64_t t_off = 0, p_off = 0;
-    if (EMB && row < a.B) {
-      t_off = (int64_t)a.tok[row] * C;
-      p_off = (int64_t)a.pos[row] * C;
-    }
+    for (int i = 0; i < 4; ++i) {
+      const int row = wave + 4 * i;
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      const int ch = lane + c * 64;
-      const bool ok = row < a.B && ch < nchunk;
-      if (EMB) {
-        raw[i][c] = ok ? *(const u16x8_t*)(a.embed + t_off + ch * 8) : (u16x8_t){0, 0, 0, 0, 0, 0, 0, 0};
-        rawp[i][c] = ok ? *(const u16x8_t*)(a.pos_tab + p_off + ch * 8) : (u16x8_t){0, 0, 0, 0, 0, 0, 0, 0};
-      } else {
-        raw[i][c] = ok ? dk_ld16_sc1(x + (int64_t)row * C + ch * 8) : (u16x8_t){0, 0, 0, 0, 0, 0, 0, 0};
+      for (int c = 0; c < NC; ++c) {
+        const int ch = lane + c * 64;
+        const bool ok = row < a.B && (NCX || c < NC - 1 || ch < nchunk);
+        raw[i][c] = ok ? dk_ld16_sc1(x + (int64_t)row * C + ch * 8) : z8;
       }
     }
-  }
-  if (!EMB) {
     dk_vm0();
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -457,23 +453,33 @@ __device__ __forceinline__ void dk_ln_rows(const DecArgs& a, const unsigned shor
       for (int c = 0; c < NC; ++c) dk_tie(raw[i][c]);
   } else {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i) {
+      const int row = wave + 4 * i;
+      int64_t t_off = 0, p_off = 0;
+      if (row < a.B) {
+        t_off = (int64_t)a.tok[row] * C;
+        p_off = (int64_t)a.pos[row] * C;
+      }
 #pragma unroll
-      for (int c = 0; c < NC; ++c)
+      for (int c = 0; c < NC; ++c) {
+        const int ch = lane + c * 64;
+        const bool ok = row < a.B && (NCX || c < NC - 1 || ch < nchunk);
+        const u16x8_t ta = ok ? *(const u16x8_t*)(a.embed + t_off + ch * 8) : z8;
+        const u16x8_t pa = ok ? *(const u16x8_t*)(a.pos_tab + p_off + ch * 8) : z8;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) raw[i][c][e] = f2bf(bf2f(raw[i][c][e]) + bf2f(rawp[i][c][e]));
+        for (int e = 0; e < 8; ++e) raw[i][c][e] = f2bf(bf2f(ta[e]) + bf2f(pa[e]));
+      }
+    }
   }
-  dk_t(dbg);  // LN: rows landed
   // the four rows of a wave side by side (independent reduction chains overlap their latencies); per row the arithmetic
-  // and its order are ln_fwd_kernel's (dk_sq_acc / dk_ln_apply: with the fusions written out).  Rows beyond B are zeros
-  // and are not stored.
+  // and its order are ln_fwd_kernel's (dk_sq_acc / dk_ln_apply: with the fusions written out)
   float sx[4], mean[4], s2[4], rstd[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     sx[i] = 0.f;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-      if (lane + c * 64 < nchunk) {
+      if (NCX || c < NC - 1 || lane + c * 64 < nchunk) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) sx[i] += bf2f(raw[i][c][e]);
       }
@@ -487,7 +493,7 @@ __device__ __forceinline__ void dk_ln_rows(const DecArgs& a, const unsigned shor
     s2[i] = 0.f;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-      if (lane + c * 64 < nchunk) {
+      if (NCX || c < NC - 1 || lane + c * 64 < nchunk) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) s2[i] = dk_sq_acc(s2[i], bf2f(raw[i][c][e]), mean[i]);
       }
@@ -503,7 +509,7 @@ __device__ __forceinline__ void dk_ln_rows(const DecArgs& a, const unsigned shor
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
         const int ch = lane + c * 64;
-        if (ch < nchunk) {
+        if (NCX || c < NC - 1 || ch < nchunk) {
           u16x8_t o8;
 #pragma unroll
           for (int e = 0; e < 8; ++e)
@@ -514,73 +520,66 @@ __device__ __forceinline__ void dk_ln_rows(const DecArgs& a, const unsigned shor
       }
     }
   }
-  dk_t(dbg);  // LN: image written
 }
 
-// ---- a projection phase -------------------------------------------------------------------------------------------------
-// out[m, c0 + j] = epilogue(sum_k A[m, k] W[c0 + j, k]) for this workgroup's columns.  A: the LayerNorm image in LDS (LN)
-// or bf16 rows in global memory (handed-off bytes: sc1 loads).  PMAX: unroll bound of the wave's k-steps.  The epilogue
-// functor is called by wave 0's lanes with a valid row m for every group of four columns j0 .. j0 + 3 they hold:
-// epi(m, j0, v[4]) with v = (p0 + p1) + (p2 + p3), the combine of ca_gemm_skinny_kernel.
-template <int PMAX, bool LN, class Epi>
-__device__ __forceinline__ void dk_project(const DecArgs& a, DkRing& rg, const DkEnt& ent, const unsigned short* Ag, int64_t lda,
+// ---- a projection ------------------------------------------------------------------------------------------------------
+// out[m, c0 + j] = epilogue(sum_k A[m, k] W[c0 + j, k] + bias) for this workgroup's columns of one ring entry.  A: the
+// LayerNorm image in LDS (ln) or bf16 rows in global memory (handed-off bytes: sc1 loads).  K is a multiple of 128: a wave's
+// quarter is `per` = K / 128 whole k-steps (PF = the unroll bound).  The epilogue functor is called by wave 0's lanes with a
+// valid row m for every group of four columns j0 .. j0 + 3 they hold: epi(m, j0, v[4]), v = (p0 + p1) + (p2 + p3) + bias -
+// the combine of ca_gemm_skinny_kernel.
+template <int PD, class Epi>
+__device__ __forceinline__ void dk_project(const DecArgs& a, const DkEnt& ent, int start, bool ln, const unsigned short* Ag,
                                            const unsigned short* xs, const char* ring, float* part, const f32x4_t (&bias4)[2],
-                                           int younger, int wave, int lane, DkDbg& dbg, Epi epi) {
+                                           int wave, int lane, Epi epi) {
+  constexpr int PF = 4 * PD;
   const int r = lane & 15, g = lane >> 4;
-  const int K = ent.K, per = dk_per(K), ksteps = (K + 31) >> 5, nquads = (per + 3) >> 2;
-  const int ks0 = wave * per, ks1 = ks0 + per < ksteps ? ks0 + per : ksteps;
-  const int groups = (ent.nc + 3) >> 2, pcs = ent.pcs;
-  const int xpitch = K + DK_XPAD;
-  if (ent.nc <= 0) {  // (no columns of this matrix: nothing in the ring either)
-    dk_ring_pop(rg, 0);
-    return;
-  }
-  bf16x8_t af[PMAX];
-  if (!LN) {
-    const unsigned short* ap = Ag + (int64_t)(r < a.B ? r : a.B - 1) * lda + 8 * g;
+  const int K = ent.K, nquads = K > 128 * PD ? PD : (PD + 3) >> 2;  // (K = d: PD k-steps per wave; K = f = 4 d: PF)
+  const bool wide = K > 128 * PD;
+  const int ks0 = wave * (wide ? PF : PD);
+  const int groups = (ent.nc + 3) >> 2;
+  bf16x8_t af[PF];
+  if (!ln) {
+    const unsigned short* ap = Ag + (int64_t)(r < a.B ? r : a.B - 1) * K + ks0 * 32 + 8 * g;  // (rows beyond B: a copy, dropped)
 #pragma unroll
-    for (int s = 0; s < PMAX; ++s) {
-      const int k = (ks0 + s) * 32 + 8 * g;
-      const bool ok = s < per && ks0 + s < ks1 && k < K && r < a.B;
-      af[s] = ok ? __builtin_bit_cast(bf16x8_t, dk_ld16_sc1(ap + (int64_t)(ks0 + s) * 32)) : dk_zero8();
+    for (int s = 0; s < PD; ++s) af[s] = __builtin_bit_cast(bf16x8_t, dk_ld16_sc1(ap + s * 32));
+    if (wide) {
+#pragma unroll
+      for (int s = PD; s < PF; ++s) af[s] = __builtin_bit_cast(bf16x8_t, dk_ld16_sc1(ap + s * 32));
     }
-    dk_vm0();  // the activation rows - and every ring piece issued before them - have landed
+    dk_vm0();  // the activation rows have landed
 #pragma unroll
-    for (int s = 0; s < PMAX; ++s) dk_tie(af[s]);
+    for (int s = 0; s < PF; ++s) dk_tie(af[s]);
   } else {
-    // the ring pieces of this entry: everything but the `younger` pieces issued behind them (the LayerNorm's loads,
-    // waited for by the caller, were issued behind the entries that were in flight then)
-#ifdef DK_VM0_ALWAYS
-    dk_vm0();
-#else
-    if (younger >= 0) dk_wait_vm(younger);
-#endif
+    const unsigned short* xp = xs + (int64_t)r * (K + DK_XPAD) + ks0 * 32 + 8 * g;
 #pragma unroll
-    for (int s = 0; s < PMAX; ++s) {
-      const int k = (ks0 + s) * 32 + 8 * g;
-      const bool ok = s < per && ks0 + s < ks1 && k < K && r < a.B;
-      af[s] = ok ? *(const bf16x8_t*)(xs + (int64_t)r * xpitch + k) : dk_zero8();
-    }
+    for (int s = 0; s < PD; ++s) af[s] = *(const bf16x8_t*)(xp + s * 32);
   }
-  dk_t(dbg);  // project: operands ready
   const int ntile = (ent.nc + 15) >> 4;
   for (int t16 = 0; t16 < ntile; ++t16) {
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-    const DkWf wfs = dk_wfrag_setup(rg.start, groups, nquads, t16, lane);
+    const DkWf wfs = dk_wfrag_setup(start, groups, nquads, t16, lane);
+    {
+      bf16x8_t wf[PD];  // (all fragment reads of a batch in flight before the first MFMA waits)
 #pragma unroll
-    for (int s = 0; s < PMAX; ++s) {
-      if (s < per) {
-        const bool ok = ks0 + s < ks1 && (ks0 + s) * 32 + 8 * g < K;
-        bf16x8_t wf = dk_wfrag(ring, wfs, s);
-        if (!ok) wf = dk_zero8();
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[s], acc, 0, 0, 0);
+      for (int s = 0; s < PD; ++s) wf[s] = dk_wfrag(ring, wfs, s);
+#pragma unroll
+      for (int s = 0; s < PD; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s], af[s], acc, 0, 0, 0);
+    }
+    if (wide) {
+#pragma unroll
+      for (int b = 1; b < 4; ++b) {
+        bf16x8_t wf[PD];
+#pragma unroll
+        for (int s = 0; s < PD; ++s) wf[s] = dk_wfrag(ring, wfs, b * PD + s);
+#pragma unroll
+        for (int s = 0; s < PD; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s], af[b * PD + s], acc, 0, 0, 0);
       }
     }
     if (t16) __syncthreads();  // (wave 0 has read the previous tile's partials)
 #pragma unroll
     for (int e = 0; e < 4; ++e) part[wave * 256 + r * 16 + 4 * g + e] = acc[e];
     __syncthreads();
-    dk_t(dbg);  // project: partials of all waves in LDS
     const int j0 = 16 * t16 + 4 * g;
     if (wave == 0 && r < a.B && j0 < ent.nc) {
       float v[4];
@@ -593,7 +592,6 @@ __device__ __forceinline__ void dk_project(const DecArgs& a, DkRing& rg, const D
       epi(r, j0, v);
     }
   }
-  dk_ring_pop(rg, pcs);
 }
 // the epilogue's bias of wave 0's lanes (this workgroup's first column at bias_c0; at most two 16-column tiles), asked for
 // before the seam in front of the phase
@@ -760,16 +758,6 @@ __device__ __forceinline__ bool dk_attend(const unsigned short* Q, const unsigne
       rest(std::false_type{});
     if (j + D < nw) issue(slot_c, j + D);
   };
-#ifdef DK_V1_ORDER
-  if (!hook()) return false;
-#pragma unroll
-  for (int ks = 0; ks < NKS; ++ks) qf[ks] = __builtin_bit_cast(bf16x8_t, dk_ld16_sc1(Q + 32 * ks + 8 * g));
-  dk_vm0();
-#pragma unroll
-  for (int ks = 0; ks < NKS; ++ks) dk_tie(qf[ks]);
-  if (nw > 0) issue(std::integral_constant<int, 0>{}, 0);
-  if (nw > 1) issue(std::integral_constant<int, 1>{}, 1);
-#else
   if (pre) {
     if (nw > 0) issue(std::integral_constant<int, 0>{}, 0);
     if (nw > 1) issue(std::integral_constant<int, 1>{}, 1);
@@ -784,7 +772,6 @@ __device__ __forceinline__ bool dk_attend(const unsigned short* Q, const unsigne
   dk_vm0();  // (the query; the first tiles, older, with it)
 #pragma unroll
   for (int ks = 0; ks < NKS; ++ks) dk_tie(qf[ks]);
-#endif
   for (int j = 0; j < nw; j += D) {
     step(std::integral_constant<int, 0>{}, j);
     if (j + 1 < nw) step(std::integral_constant<int, 1>{}, j + 1);
@@ -879,12 +866,17 @@ __device__ __forceinline__ void dk_merge_split(const float* base, int ns, unsign
 }
 
 // ---- the kernel ---------------------------------------------------------------------------------------------------------------
-template <int NC>
+// One loop over the 8 L + 1 steps of a token with ONE site for the projection code and ONE for the attention code: written as
+// eight specialised phases per layer the kernel was 188 KB of instructions - three times the instruction cache, and ~31 k
+// instructions per wave and layer at one wave per SIMD (1.87 ms per token at 16 clips, instruction-issue bound).
+// PD = d / 128 (k-steps of a wave's quarter of K = d; K = f = 4 d: 4 PD), NC = 64-lane rounds of 8-element chunks in a row.
+template <int PD, int NC, bool NCX>
 __global__ __launch_bounds__(256) void whisper_decode_token_kernel(const DecArgs a) {
   extern __shared__ __attribute__((aligned(16))) char dk_smem[];
-  constexpr int PD = 4 * NC, PF = 16 * NC;  // k-steps of a wave's quarter of K = d / K = f, at most
+  constexpr int PF = 4 * PD;
   float* part = (float*)dk_smem;
   volatile int* lds_ok = (volatile int*)(dk_smem + 4096);
+  DkKind* kt = (DkKind*)(dk_smem + 4096 + 64);  // (7 x 32 bytes behind the seam word)
   unsigned long long* ltab = (unsigned long long*)(dk_smem + 5120);
   char* scratch = dk_smem + DK_PART;
   unsigned short* xs = (unsigned short*)scratch;
@@ -894,19 +886,18 @@ __global__ __launch_bounds__(256) void whisper_decode_token_kernel(const DecArgs
   const uint32_t ring_lds = dk_lds_addr(dk_smem + DK_PART + DK_SCRATCH);  // (wave 0's ring: dk_issue_pieces adds the wave)
   const int G = gridDim.x, w = blockIdx.x;
   const int r = lane & 15, g = lane >> 4;
-  const int d = a.d, B = a.B, H = a.H;
+  const int d = a.d, B = a.B, H = a.H, L = a.n_layers;
   const int ntiles = (a.V + 15) >> 4;
   const int my_tiles = ntiles > w ? (ntiles - w + G - 1) / G : 0;
-  const int n_entries = 6 * a.n_layers + (ntiles + G - 1) / G;
-  DkKind* kt = (DkKind*)(dk_smem + 4096 + 64);  // (7 x 32 bytes behind the seam word)
-  for (int i = threadIdx.x; i < a.n_layers * LY_WORDS; i += 256) ltab[i] = ((const unsigned long long*)a.layers)[i];
+  const int n_entries = 6 * L + (ntiles + G - 1) / G;
+  for (int i = threadIdx.x; i < L * LY_WORDS; i += 256) ltab[i] = ((const unsigned long long*)a.layers)[i];
   dk_build_kinds(a, kt, w, G);
   __syncthreads();
   DkRing rg = {0, 0, 0, 0, 0, 0};
   dk_ring_advance(a, ltab, kt, rg, n_entries, w, G, ring_lds, wave, lane);
   unsigned ph = 0;  // phases completed by this workgroup
-  int dc0, dnc;
-  dk_cols(d, w, G, dc0, dnc);  // this workgroup's columns of every N = d projection (at most 16)
+  DkDbg dbg = {a.stamps ? a.stamps + (int64_t)w * a.stamp_nph : nullptr, a.stamp_nph, 0};
+  const int dc0 = kt[1].c0, dnc = kt[1].nc;  // this workgroup's columns of every N = d projection (at most 16)
   // wave 0: the residual stream at (row r, column dc0 + 4 g + e), as stored (bf16).  Layer 0: the embedding rows
   // (embed_kernel's arithmetic)
   float res[4] = {0.f, 0.f, 0.f, 0.f};
@@ -919,151 +910,58 @@ __global__ __launch_bounds__(256) void whisper_decode_token_kernel(const DecArgs
       res[e] = bf2f(f2bf(bf2f(a.embed[t_off + n]) + bf2f(a.pos_tab[p_off + n])));
     }
   }
-  int my_kl = 0;  // keys of the first self-attention item of this workgroup
-  if (w < B * H) {
-    my_kl = a.klen[w / H];
-    my_kl = my_kl < a.Lmax ? my_kl : a.Lmax;
-  }
-  DkDbg dbg = {a.stamps ? a.stamps + (int64_t)w * a.stamp_nph : nullptr, a.stamp_nph, 0};
-#define DK_STAMP(which) dk_t(dbg)
-#define DK_SEAM()                                          \
-  do {                                                     \
-    if (!dk_seam(a, ph + 1, G, lds_ok, wave, lane, rg.cur_e < rg.batch_first ? rg.batch_issued : 0)) return; \
-    DK_STAMP(0);                                           \
-  } while (0)
-#define DK_DONE()                                                         \
-  do {                                                                    \
-    DK_STAMP(1);                                                          \
-    ++ph;                                                                 \
-    dk_publish(a, ph, w, wave, lane);                                     \
-    dk_t(dbg);                                                            \
-    dk_ring_advance(a, ltab, kt, rg, n_entries, w, G, ring_lds, wave, lane);  \
-    dk_t(dbg);                                                            \
-  } while (0)
-  // out-projection / fc2 epilogue: (+ bias, by the projection) + residual, rounded to bf16 as the launch sequence stores it,
-  // kept as the next residual
-  auto res_epi = [&](unsigned short* dst) {
-    return [&res, dst, dc0, d](int m, int j0, const float(&v)[4]) {
-      unsigned hv[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        hv[e] = f2bf(v[e] + res[e]);
-        res[e] = bf2f((unsigned short)hv[e]);
-      }
-      dk_store4(dst + (int64_t)m * d + dc0 + j0, hv);
-    };
+  float best = -__builtin_inff();  // wave 0: the running greedy pick of (row r, this lane's vocabulary columns)
+  int bi = 0x7fffffff;
+  // the seam in front of the next phase; false = the launch is being abandoned
+  auto seam = [&](int keep) {
+    const bool ok = dk_seam(a, ph + 1, G, lds_ok, wave, lane, keep);
+    if (ok) dk_t(dbg);
+    return ok;
   };
-  auto no_hook = [] { return true; };
+  auto done = [&] {
+    dk_t(dbg);
+    ++ph;
+    dk_publish(a, ph, w, wave, lane);
+    dk_ring_advance(a, ltab, kt, rg, n_entries, w, G, ring_lds, wave, lane);
+  };
 
-  for (int l = 0; l < a.n_layers; ++l) {
-    unsigned short* ckv = dk_lyp<unsigned short*>(ltab, l, LY_SELFKV);
-    // ---- A: LayerNorm + q|k|v -------------------------------------------------------------------------------------------
-    {
-      const DkEnt ent = dk_entry(a, ltab, kt, rg.cur_e, w, G);
-      int c0, nc;
-      dk_cols(3 * d, w, G, c0, nc);
-      f32x4_t gq[NC][2], bq[NC][2], bias4[2];
-      dk_ln_params<NC>(dk_lyp<const float*>(ltab, l, LY_LN1G), dk_lyp<const float*>(ltab, l, LY_LN1B), d, lane, gq, bq);
-      const float* bias = dk_lyp<const float*>(ltab, l, LY_BQKV);
-      dk_bias4(bias ? bias + c0 : nullptr, nc, wave, lane, bias4);
-      if (l > 0) {
-        DK_SEAM();
-        if (nc > 0) dk_ln_rows<NC, false>(a, a.h, gq, bq, xs, wave, lane, dbg);
-      } else {
-        if (wave != 0) dk_vm0();  // (the first ring pieces: see dk_issue_entry)
-        __syncthreads();
-        if (nc > 0) dk_ln_rows<NC, true>(a, nullptr, gq, bq, xs, wave, lane, dbg);
-      }
-      __syncthreads();
-      dk_project<PD, true>(a, rg, ent, nullptr, 0, xs, ring, part, bias4, -1, wave, lane, dbg,
-                           [&](int m, int j0, const float(&v)[4]) {
-                             const int n = c0 + j0;  // (a group of four never straddles d: both are multiples of 4)
-                             unsigned hv[4];
-#pragma unroll
-                             for (int e = 0; e < 4; ++e) hv[e] = f2bf(v[e]);
-                             unsigned short* dst = n < d ? a.q + (int64_t)m * d + n
-                                                         : ckv + ((int64_t)m * a.Lmax + mypos) * 2 * d + (n - d);
-                             dk_store4(dst, hv);
-                           });
-      DK_DONE();
-    }
-    // ---- B: self-attention over the cache ----------------------------------------------------------------------------------
-    {
-      if (w < B * H) {
-        DK_SEAM();
-        // the V tiles (this token's row among them) come by LDS-DMA, not by sc1 register loads: acquire
-        if (threadIdx.x == 0) {
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-          dk_vm0();
-        }
-        __syncthreads();
-        for (int it = w; it < B * H; it += G) {
-          const int b = it / H, h = it - b * H;
-          int kl = my_kl;
-          if (it != w) {
-            kl = a.klen[b];
-            kl = kl < a.Lmax ? kl : a.Lmax;
-          }
-          const unsigned short* Kp = ckv + (int64_t)b * a.Lmax * 2 * d + h * 64;
-          dk_attend(a.q + (int64_t)b * d + h * 64, Kp, Kp + d, 2 * d, a.Lmax, kl, 1, 0, a.scale * DK_LOG2E, scratch,
-                    a.ctx + (int64_t)b * d + h * 64, nullptr, wave, lane, false, no_hook);
-        }
-      }
-      DK_DONE();
-    }
-    // ---- C: out-projection + residual ----------------------------------------------------------------------------------------
-    {
-      const DkEnt ent = dk_entry(a, ltab, kt, rg.cur_e, w, G);
-      const float* bias = dk_lyp<const float*>(ltab, l, LY_BO);
-      f32x4_t bias4[2];
-      dk_bias4(bias ? bias + dc0 : nullptr, ent.nc, wave, lane, bias4);
-      if (ent.nc > 0) DK_SEAM();
-      dk_project<PD, false>(a, rg, ent, a.ctx, d, nullptr, ring, part, bias4, -1, wave, lane, dbg, res_epi(a.h1));
-      DK_DONE();
-    }
-    // ---- D: LayerNorm + cross-attention query ----------------------------------------------------------------------------------
-    {
-      const DkEnt ent = dk_entry(a, ltab, kt, rg.cur_e, w, G);
-      f32x4_t gq[NC][2], bq[NC][2], bias4[2];
-      dk_ln_params<NC>(dk_lyp<const float*>(ltab, l, LY_LN2G), dk_lyp<const float*>(ltab, l, LY_LN2B), d, lane, gq, bq);
-      const float* bias = dk_lyp<const float*>(ltab, l, LY_BQ2);
-      dk_bias4(bias ? bias + dc0 : nullptr, ent.nc, wave, lane, bias4);
-      if (ent.nc > 0) {
-        DK_SEAM();
-        dk_ln_rows<NC, false>(a, a.h1, gq, bq, xs, wave, lane, dbg);
-        __syncthreads();
-      }
-      dk_project<PD, true>(a, rg, ent, nullptr, 0, xs, ring, part, bias4, -1, wave, lane, dbg,
-                           [&](int m, int j0, const float(&v)[4]) {
-                             unsigned hv[4];
-#pragma unroll
-                             for (int e = 0; e < 4; ++e) hv[e] = f2bf(v[e]);
-                             dk_store4(a.q2 + (int64_t)m * d + dc0 + j0, hv);
-                           });
-      DK_DONE();
-    }
-    // ---- E: attention over the encoder K|V -------------------------------------------------------------------------------------
-    {
-      const int ns = a.ns, nit = B * H * ns;
+  const int nsteps = 8 * L + 1;
+  for (int step = 0; step < nsteps; ++step) {
+    const int l = step >> 3, p = step & 7;
+    const bool head = step == 8 * L;
+    if (!head && (p == 1 || p == 4)) {
+      // ---- attention: B (self, over this layer's cache) or E (over the cached encoder K|V) ----------------------------------------
+      const bool cross = p == 4;
+      const int ns = cross ? a.ns : 1, nit = B * H * ns;
       if (w < nit) {
-        const unsigned short* xkv = dk_lyp<const unsigned short*>(ltab, l, LY_CROSSKV);
+        const unsigned short* kvbase = dk_lyp<const unsigned short*>(ltab, l, cross ? LY_CROSSKV : LY_SELFKV);
+        const int Tk = cross ? a.Te : a.Lmax;
+        const unsigned short* Qb = cross ? a.q2 : a.q;
+        unsigned short* Ob = cross ? a.ctx2 : a.ctx;
+        if (!cross) {
+          if (!seam(0)) return;
+          // the V tiles (this token's row among them) come by LDS-DMA, not by sc1 register loads: acquire
+          if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            dk_vm0();
+          }
+          __syncthreads();
+        }
         for (int it = w; it < nit; it += G) {
           const int bh = it / ns, sp = it - bh * ns;
           const int b = bh / H, h = bh - b * H;
-          const unsigned short* Kp = xkv + (int64_t)b * a.Te * 2 * d + h * 64;
-          unsigned short* O = a.ctx2 + (int64_t)b * d + h * 64;
-          bool ok;
-          // (the first item's first tiles are asked for BEFORE the seam: K and V do not depend on this token)
-          if (it == w)
-            ok = dk_attend(a.q2 + (int64_t)b * d + h * 64, Kp, Kp + d, 2 * d, a.Te, a.Te, ns, sp, a.scale * DK_LOG2E, scratch, O,
-                           a.slab + (int64_t)it * DK_SPLIT_ROW, wave, lane, a.pre_issue != 0, [&] {
-                             const bool pass = dk_seam(a, ph + 1, G, lds_ok, wave, lane, 0);
-                             if (pass) DK_STAMP(0);
-                             return pass;
-                           });
-          else
-            ok = dk_attend(a.q2 + (int64_t)b * d + h * 64, Kp, Kp + d, 2 * d, a.Te, a.Te, ns, sp, a.scale * DK_LOG2E, scratch, O,
-                           a.slab + (int64_t)it * DK_SPLIT_ROW, wave, lane, false, no_hook);
+          int kl = Tk;
+          if (!cross) {
+            kl = a.klen[b];
+            kl = kl < Tk ? kl : Tk;
+          }
+          const unsigned short* Kp = kvbase + (int64_t)b * Tk * 2 * d + h * 64;
+          unsigned short* O = Ob + (int64_t)b * d + h * 64;
+          const bool first_cross = cross && it == w;  // (E: the first tiles are asked for BEFORE the seam: K and V do not
+                                                     // depend on this token)
+          const bool ok = dk_attend(Qb + (int64_t)b * d + h * 64, Kp, Kp + d, 2 * d, Tk, kl, ns, sp, a.scale * DK_LOG2E, scratch, O,
+                                    a.slab + (int64_t)it * DK_SPLIT_ROW, wave, lane, first_cross && a.pre_issue != 0,
+                                    [&] { return first_cross ? seam(0) : true; });
           if (!ok) return;
           if (ns > 1 && wave == 0) {
             dk_vm0();  // this workgroup's partial is out
@@ -1075,107 +973,115 @@ __global__ __launch_bounds__(256) void whisper_decode_token_kernel(const DecArgs
           }
         }
       }
-      DK_DONE();
+      done();
+      continue;
     }
-    // ---- F: out-projection + residual ----------------------------------------------------------------------------------------
-    {
-      const DkEnt ent = dk_entry(a, ltab, kt, rg.cur_e, w, G);
-      const float* bias = dk_lyp<const float*>(ltab, l, LY_BO2);
-      f32x4_t bias4[2];
-      dk_bias4(bias ? bias + dc0 : nullptr, ent.nc, wave, lane, bias4);
-      if (ent.nc > 0) DK_SEAM();
-      dk_project<PD, false>(a, rg, ent, a.ctx2, d, nullptr, ring, part, bias4, -1, wave, lane, dbg, res_epi(a.h2));
-      DK_DONE();
+    // ---- a projection: A (LayerNorm + q|k|v), C / F (out-projection + residual), D (LayerNorm + cross query), G (LayerNorm +
+    // fc1 + GELU), H (fc2 + residual) or the tied output projection (head: LayerNorm, then this workgroup's vocabulary tiles) ----
+    const int kind = head ? 6 : (p == 0 ? 0 : p == 2 ? 1 : p == 3 ? 2 : p == 5 ? 3 : p == 6 ? 4 : 5);
+    const DkKind kk = kt[kind];
+    const bool ln = kind == 0 || kind == 2 || kind == 4 || kind == 6;
+    const int my_nc = head ? (my_tiles > 0 ? 16 : 0) : kk.nc;
+    f32x4_t gq[NC][2], bq[NC][2], bias4[2];
+    if (ln && my_nc > 0) {
+      const float* gm = head ? a.lnf_g : dk_lyp<const float*>(ltab, l, kk.ln_fld);
+      const float* bt = head ? a.lnf_b : dk_lyp<const float*>(ltab, l, kk.ln_fld + 1);
+      dk_ln_params<NC, NCX>(gm, bt, d, lane, gq, bq);
     }
-    // ---- G: LayerNorm + fc1 + GELU ----------------------------------------------------------------------------------------------
     {
-      const DkEnt ent = dk_entry(a, ltab, kt, rg.cur_e, w, G);
-      int c0, nc;
-      dk_cols(a.f, w, G, c0, nc);
-      f32x4_t gq[NC][2], bq[NC][2], bias4[2];
-      dk_ln_params<NC>(dk_lyp<const float*>(ltab, l, LY_LN3G), dk_lyp<const float*>(ltab, l, LY_LN3B), d, lane, gq, bq);
-      const float* bias = dk_lyp<const float*>(ltab, l, LY_B1);
-      dk_bias4(bias ? bias + c0 : nullptr, nc, wave, lane, bias4);
-      if (nc > 0) {
-        DK_SEAM();
-        dk_ln_rows<NC, false>(a, a.h2, gq, bq, xs, wave, lane, dbg);
+      const float* bias = head ? nullptr : dk_lyp<const float*>(ltab, l, kk.bias_fld);
+      dk_bias4(bias ? bias + kk.c0 : nullptr, my_nc, wave, lane, bias4);
+    }
+    if (my_nc > 0) {
+      if (step > 0) {
+        if (!seam(rg.cur_e < rg.batch_first ? rg.batch_issued : 0)) return;
+      } else {
+        if (wave != 0) dk_vm0();  // (the first ring pieces: see dk_issue_pieces)
         __syncthreads();
       }
-      dk_project<PD, true>(a, rg, ent, nullptr, 0, xs, ring, part, bias4, -1, wave, lane, dbg,
-                           [&](int m, int j0, const float(&v)[4]) {
-                             unsigned hv[4];
-#pragma unroll
-                             for (int e = 0; e < 4; ++e) hv[e] = f2bf(gelu_erf(v[e]));
-                             dk_store4(a.gbuf + (int64_t)m * a.f + c0 + j0, hv);
-                           });
-      DK_DONE();
+      if (ln) {
+        const unsigned short* x = kind == 2 ? a.h1 : kind == 4 ? a.h2 : a.h;
+        dk_ln_rows<NC, NCX>(a, x, step == 0, gq, bq, xs, wave, lane);
+        if (!head) __syncthreads();
+      }
+      dk_t(dbg);
     }
-    // ---- H: fc2 + residual: the next layer's input ---------------------------------------------------------------------------------
-    {
+    unsigned short* ckv = dk_lyp<unsigned short*>(ltab, head ? 0 : l, LY_SELFKV);
+    const int nent = head ? my_tiles : 1;
+    for (int t = 0; t < nent; ++t) {
       const DkEnt ent = dk_entry(a, ltab, kt, rg.cur_e, w, G);
-      const float* bias = dk_lyp<const float*>(ltab, l, LY_B2);
-      f32x4_t bias4[2];
-      dk_bias4(bias ? bias + dc0 : nullptr, ent.nc, wave, lane, bias4);
-      if (ent.nc > 0) DK_SEAM();
-      dk_project<PF, false>(a, rg, ent, a.gbuf, a.f, nullptr, ring, part, bias4, -1, wave, lane, dbg, res_epi(a.h));
-      DK_DONE();
-    }
-  }
-  // ---- LayerNorm + the tied output projection: 16 vocabulary rows per tile, tiles w, w + G, ... ----------------------------------
-  float best = -__builtin_inff();
-  int bi = 0x7fffffff;
-  if (my_tiles > 0) {
-    f32x4_t gq[NC][2], bq[NC][2];
-    const f32x4_t nobias[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    dk_ln_params<NC>(a.lnf_g, a.lnf_b, d, lane, gq, bq);
-    DK_SEAM();
-    dk_ln_rows<NC, false>(a, a.h, gq, bq, xs, wave, lane, dbg);
-    for (int t = 0; t < my_tiles; ++t) {
-      const DkEnt ent = dk_entry(a, ltab, kt, rg.cur_e, w, G);
-      const int n0 = 16 * (w + G * t);
-      // this tile's pieces have landed (the issuing waves wait; the next tiles' pieces, issued behind them, stay in
-      // flight); the barrier also says that wave 0 has read the previous tile's partials and the image is written
-      if (wave != 0) dk_wait_vm(t == 0 ? 0 : rg.used - ent.pcs);
-      __syncthreads();
-      dk_project<PD, true>(a, rg, ent, nullptr, 0, xs, ring, part, nobias, -1, wave, lane, dbg,
-                           [&](int m, int j0, const float(&v)[4]) {
+      if (head) {
+        // this tile's pieces have landed (the issuing waves wait; the next tiles' pieces, issued behind them, stay in
+        // flight); the barrier also says that wave 0 has read the previous tile's partials and that the image is written
+        if (wave != 0) dk_wait_vm(t == 0 ? 0 : rg.used - ent.pcs);
+        __syncthreads();
+      }
+      if (ent.nc > 0) {
+        const unsigned short* Ag = kind == 1 ? a.ctx : kind == 3 ? a.ctx2 : a.gbuf;
+        const int n0 = head ? 16 * (w + G * t) : kk.c0;
+        dk_project<PD>(a, ent, rg.start, ln, Ag, xs, ring, part, bias4, wave, lane, [&](int m, int j0, const float(&v)[4]) {
+          const int n = n0 + j0;
+          unsigned hv[4];
+          if (kind == 6) {  // logits (fp32) + this lane's running greedy pick (candidates come in increasing index order)
 #pragma unroll
-                             for (int e = 0; e < 4; ++e) {
-                               const int n = n0 + j0 + e;
-                               if (n < a.V) {
-                                 const float x = v[e];
-                                 a.logits[(int64_t)m * a.ld_logits + n] = x;
-                                 // (a lane's candidates come in increasing index order)
-                                 if (!(a.suppress && a.suppress[n]) && x > best) {
-                                   best = x;
-                                   bi = n;
-                                 }
-                               }
-                             }
-                           });
-      dk_ring_advance(a, ltab, kt, rg, n_entries, w, G, ring_lds, wave, lane);
-    }
-  }
-  // this workgroup's best per row: lanes (r, g) hold row r
-  if (wave == 0) {
+            for (int e = 0; e < 4; ++e) {
+              if (n + e < a.V) {
+                a.logits[(int64_t)m * a.ld_logits + n + e] = v[e];
+                if (!(a.suppress && a.suppress[n + e]) && v[e] > best) {
+                  best = v[e];
+                  bi = n + e;
+                }
+              }
+            }
+            return;
+          }
+          if (kind == 1 || kind == 3 || kind == 5) {  // + residual, rounded as the launch sequence stores it; the next residual
 #pragma unroll
-    for (int o = 16; o <= 32; o <<= 1) {
-      const float ob = __shfl_xor(best, o, 64);
-      const int oi = __shfl_xor(bi, o, 64);
-      if (ob > best || (ob == best && oi < bi)) {
-        best = ob;
-        bi = oi;
+            for (int e = 0; e < 4; ++e) {
+              hv[e] = f2bf(v[e] + res[e]);
+              res[e] = bf2f((unsigned short)hv[e]);
+            }
+            dk_store4((kind == 1 ? a.h1 : kind == 3 ? a.h2 : a.h) + (int64_t)m * d + n, hv);
+            return;
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) hv[e] = f2bf(kind == 4 ? gelu_erf(v[e]) : v[e]);
+          unsigned short* dst;
+          if (kind == 0)  // q | this token's K|V row of the cache (a group of four never straddles d: multiples of 4)
+            dst = n < d ? a.q + (int64_t)m * d + n : ckv + ((int64_t)m * a.Lmax + mypos) * 2 * d + (n - d);
+          else if (kind == 2)
+            dst = a.q2 + (int64_t)m * d + n;
+          else
+            dst = a.gbuf + (int64_t)m * a.f + n;
+          dk_store4(dst, hv);
+        });
+      }
+      dk_ring_pop(rg, ent.pcs);
+      if (head) dk_ring_advance(a, ltab, kt, rg, n_entries, w, G, ring_lds, wave, lane);
+    }
+    if (head) {
+      // this workgroup's best per row: lanes (r, g) of wave 0 hold row r
+      if (wave == 0) {
+#pragma unroll
+        for (int o = 16; o <= 32; o <<= 1) {
+          const float ob = __shfl_xor(best, o, 64);
+          const int oi = __shfl_xor(bi, o, 64);
+          if (ob > best || (ob == best && oi < bi)) {
+            best = ob;
+            bi = oi;
+          }
+        }
+        if (g == 0) {
+          dk_st4_sc1(a.amax_val + w * 16 + r, __builtin_bit_cast(unsigned, best));
+          dk_st4_sc1(a.amax_idx + w * 16 + r, (unsigned)bi);
+        }
       }
     }
-    if (g == 0) {
-      dk_st4_sc1(a.amax_val + w * 16 + r, __builtin_bit_cast(unsigned, best));
-      dk_st4_sc1(a.amax_idx + w * 16 + r, (unsigned)bi);
-    }
+    done();
   }
-  DK_DONE();
   // ---- the greedy pick of row w and the step's bookkeeping (ca_argmax_advance's) -------------------------------------------------
   if (w < B) {
-    DK_SEAM();
+    if (!seam(0)) return;
     if (wave == 0) {
       float vb = -__builtin_inff();
       int vi = 0x7fffffff;
@@ -1213,19 +1119,16 @@ __global__ __launch_bounds__(256) void whisper_decode_token_kernel(const DecArgs
       if (lane == 0) {
         vi = vi == 0x7fffffff ? 0 : vi;
         a.out[w] = vi;
-        const int32_t p = a.pos[w];
-        const int32_t step = a.done[w] ? a.pad : vi;
-        a.ids[(int64_t)w * a.ld_ids + p + 1] = step;
-        if (step == a.eos) a.done[w] = 1;
-        a.tok[w] = step;
-        a.pos[w] = p + 1;
+        const int32_t pz = a.pos[w];
+        const int32_t tk = a.done[w] ? a.pad : vi;
+        a.ids[(int64_t)w * a.ld_ids + pz + 1] = tk;
+        if (tk == a.eos) a.done[w] = 1;
+        a.tok[w] = tk;
+        a.pos[w] = pz + 1;
         a.klen[w] += 1;
       }
     }
   }
-#undef DK_SEAM
-#undef DK_DONE
-#undef DK_STAMP
 }
 
 // ---- C ABI --------------------------------------------------------------------------------------------------------------------
@@ -1250,18 +1153,18 @@ extern "C" int ca_whisper_decode_token_supported(int32_t B, int32_t d, int32_t f
   const int G = dk_device_cus();
   if (G < 16 || G > 256) return 0;
   if (B < 1 || B > CA_DECODE_MAX_B) return 0;
-  if (d < 64 || d > 1536 || (d % 64) != 0 || H * 64 != d) return 0;
-  if (f < 64 || (f % 32) != 0 || f > 4 * 1536 || f > 2048 * ((d + 511) / 512)) return 0;
-  if (d / 4 > 16 * G) return 0;                         // at most 16 columns of an N = d projection per workgroup
+  // the Whisper family: d_model 384 / 512 / 768 / 1024 / 1280 (a wave's quarter of K is whole k-steps), f = 4 d, head_dim 64
+  if (!(d == 384 || d == 512 || d == 768 || d == 1024 || d == 1280) || H * 64 != d || f != 4 * d) return 0;
+  if (d / 4 > 16 * G) return 0;  // at most 16 columns of an N = d projection per workgroup
   if (((int64_t)V + 15) / 16 > (int64_t)DK_MAXTILES * 16 * G) return 0;
-  // the widest ring entry must fit the ring: fc1 (f / 4 groups over G workgroups, K = d) and fc2 (d / 4 groups, K = f)
+  // the widest ring entry must fit the ring (and fc1's columns two MFMA tiles)
   auto pieces = [&](int N, int K) {
     const int ng = N / 4, mine = (ng + G - 1) / G;
-    const int per = (((K + 31) / 32) + 3) / 4;
+    const int per = K / 128;
     return mine * ((per + 3) / 4);
   };
-  if (pieces(3 * d, d) > DK_RP || pieces(f, d) > DK_RP || pieces(d, f) > DK_RP || 4 * ((((d + 31) / 32 + 3) / 4 + 3) / 4) > DK_RP)
-    return 0;
+  if (pieces(3 * d, d) > DK_RP || pieces(f, d) > DK_RP || pieces(d, f) > DK_RP || 4 * ((d / 128 + 3) / 4) > DK_RP) return 0;
+  if ((f / 4 + G - 1) / G * 4 > 32 || (3 * d / 4 + G - 1) / G * 4 > 32) return 0;
   return 1;
 }
 
@@ -1317,11 +1220,13 @@ extern "C" int ca_whisper_decode_token(const CaDecodeDesc* desc, void* stream) {
   a.pre_issue = pre;
   CA_CHECK_ARG((size_t)(p - (char*)c.ws) <= (size_t)c.ws_bytes, "ca_whisper_decode_token: workspace layout exceeds ws_bytes");
   hipStream_t s = (hipStream_t)stream;
+#define DK_KERNELS(X) X(3, 1, false) X(4, 1, true) X(6, 2, false) X(8, 2, true) X(10, 3, false)
   static bool attr = false;
   if (!attr) {
-    hipFuncSetAttribute((const void*)whisper_decode_token_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, DK_LDS);
-    hipFuncSetAttribute((const void*)whisper_decode_token_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, DK_LDS);
-    hipFuncSetAttribute((const void*)whisper_decode_token_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, DK_LDS);
+#define DK_ATTR(PD, NC, NCX) \
+  hipFuncSetAttribute((const void*)whisper_decode_token_kernel<PD, NC, NCX>, hipFuncAttributeMaxDynamicSharedMemorySize, DK_LDS);
+    DK_KERNELS(DK_ATTR)
+#undef DK_ATTR
     attr = true;
   }
   // every polled word starts at zero (a memset node when the step is captured in a graph)
@@ -1329,13 +1234,11 @@ extern "C" int ca_whisper_decode_token(const CaDecodeDesc* desc, void* stream) {
     ca_set_error("ca_whisper_decode_token: hipMemsetAsync failed");
     return CA_ERR_LAUNCH;
   }
-  const int nc = (c.d + 511) / 512;
-  if (nc == 1)
-    hipLaunchKernelGGL(whisper_decode_token_kernel<1>, dim3(G), dim3(256), DK_LDS, s, a);
-  else if (nc == 2)
-    hipLaunchKernelGGL(whisper_decode_token_kernel<2>, dim3(G), dim3(256), DK_LDS, s, a);
-  else
-    hipLaunchKernelGGL(whisper_decode_token_kernel<3>, dim3(G), dim3(256), DK_LDS, s, a);
+#define DK_LAUNCH(PD, NC, NCX) \
+  if (c.d == 128 * PD) hipLaunchKernelGGL((whisper_decode_token_kernel<PD, NC, NCX>), dim3(G), dim3(256), DK_LDS, s, a);
+  DK_KERNELS(DK_LAUNCH)
+#undef DK_LAUNCH
+#undef DK_KERNELS
   CA_CHECK_LAUNCH("ca_whisper_decode_token");
   return CA_OK;
 }

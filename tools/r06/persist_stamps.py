@@ -27,12 +27,12 @@ ps = eng._persistent_state(cache, g, sup)
 G = torch.cuda.get_device_properties(dev).multi_processor_count
 L = shape.decoder_layers
 # thread 0 of every workgroup appends the shader clock at fixed points (csrc/decode.hip, dk_t): per layer 50 stamps
-LAB = {"A": ["seam passed", "LN rows landed", "LN image written", "operands ready", "partials in LDS", "epilogue done", "published", "ring advanced"],
-       "B": ["seam passed", "attention done", "published", "ring advanced"],
-       "C": ["seam passed", "operands ready", "partials in LDS", "epilogue done", "published", "ring advanced"],
-       "E": ["seam passed (first tiles in flight)", "attention done", "published", "ring advanced"]}
+LAB = {"A": ["publish + ring + seam", "LayerNorm image written", "projection + epilogue done"],
+       "B": ["publish + ring + seam", "attention done"],
+       "C": ["publish + ring + seam", "(no LayerNorm)", "rows gathered, projection + epilogue done"]}
 LAB["D"] = LAB["G"] = LAB["A"]
 LAB["F"] = LAB["H"] = LAB["C"]
+LAB["E"] = ["publish + ring + first tiles + seam", "attention done"]
 ORDER = "ABCDEFGH"
 per_layer = sum(len(LAB[k]) for k in ORDER)
 nst = per_layer * L + 64
