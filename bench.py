@@ -648,9 +648,15 @@ def main():
         dec = {}
         for Bd in (8, 16, 32, 64):  # (the K|V-cached greedy step runs on the weight-streaming kernel: M = batch <= 128)
             r4 = whisper_measure("whisper-medium", args, world, rank, device, decode=True, B=Bd, steps=3, warmup=1)
+            from coral_amd import ops as _ops
+
+            one = Bd <= 16 and os.environ.get("CA_DECODE_PERSISTENT", "1") != "0" and _ops.whisper_decode_token_supported(
+                Bd, r4["shape"].d_model, r4["shape"].decoder_ffn_dim, r4["shape"].decoder_attention_heads, r4["shape"].vocab_size)
             dec[f"B{Bd}"] = {"ms_per_token": round(r4["ms_per_token"], 4), "bytes_per_token": int(r4["bytes_per_token"]),
                              "frac_of_8TBps": round(r4["hbm_frac"], 4),
-                             "audio_s_per_s_incl_logmel_encoder": round(r4["value"], 1)}
+                             "audio_s_per_s_incl_logmel_encoder": round(r4["value"], 1),
+                             "step": "one persistent launch per token (ca_whisper_decode_token)" if one
+                             else "launch sequence, ~7 launches per layer"}
             del r4
             torch.cuda.empty_cache()
         out["config"]["also_decode"] = dict(workload=f"whisper-medium greedy decode (log-mel + encoder + {args.decode_tokens} "

@@ -29,7 +29,7 @@
 // acquire in front of it.  Every spin is bounded: on a timeout the workgroup sets status[0] and leaves, the others follow.
 // Buffers are written once per layer and read in the next phase, so re-use one layer later is ordered by the seams.
 //
-// Weights.  A wave's quarter of K of its workgroup's columns of every matrix goes through a private LDS ring (21 pieces of
+// Weights.  A wave's quarter of K of its workgroup's columns of every matrix goes through a private LDS ring (20 pieces of
 // 1 KiB) by LDS-DMA, issued as far ahead as the ring holds (about one layer): piece = 4 columns x 128 k, 256 contiguous
 // bytes per column, chunk positions XOR-ed so that the MFMA fragment reads (ds_read_b128) hit 16 distinct bank slots.
 #include "common.h"
@@ -44,9 +44,9 @@ __device__ __attribute__((aligned(16))) uint32_t g_dec_zero_page[4];
 
 #define DK_NEG_BIG (-1.0e30f)
 #define DK_LOG2E 1.44269504088896340736f
-#define DK_RP 21             // pieces (1 KiB) of a wave's weight ring
+#define DK_RP 20             // pieces (1 KiB) of a wave's weight ring
 #define DK_SCRATCH (64 * 1024)  // LayerNorm image | V rings + merge buffers
-#define DK_PART (12 * 1024)   // partial tiles (4 KiB) | seam word (1 KiB) | the layer records (7 KiB: 44 layers)
+#define DK_PART (14 * 1024)   // partial tiles (4 KiB) | seam word, kinds (1 KiB) | the layer records (7 KiB: 44 layers) | biases (2 KiB)
 #define DK_MAXLAYERS 44
 #define DK_LDS (DK_PART + DK_SCRATCH + 4 * DK_RP * 1024)
 #define DK_XPAD 32           // bf16 elements between rows of the LayerNorm image beyond K (ca_gemm_skinny_kernel's pad)
@@ -83,8 +83,9 @@ struct DecArgs {
   int* amax_idx;
   unsigned* status;
   unsigned long long* stamps;  // debug (ca_debug_decode_stamps): [G][stamp_nph][2] realtime ticks, or NULL
-  int stamp_nph;
+  int stamp_nph, stamp_tid, stamp_fine;
   int pre_issue;  // phase E: the first K|V tiles are asked for before the seam
+  int ring_budget;
 };
 
 // ---- memory helpers ------------------------------------------------------------------------------------------------
@@ -144,10 +145,10 @@ __device__ __forceinline__ void dk_wait_vm(int n) {
 // debug stamps (ca_debug_decode_stamps): thread 0 of a workgroup appends the shader clock at fixed points of the program
 struct DkDbg {
   unsigned long long* p;
-  int n, i;
+  int n, i, tid;
 };
 __device__ __forceinline__ void dk_t(DkDbg& dbg) {
-  if (dbg.p && threadIdx.x == 0 && dbg.i < dbg.n) dbg.p[dbg.i++] = __builtin_readcyclecounter();
+  if (dbg.p && (int)threadIdx.x == dbg.tid && dbg.i < dbg.n) dbg.p[dbg.i++] = __builtin_readcyclecounter();
 }
 
 // ---- seams -----------------------------------------------------------------------------------------------------------
@@ -169,7 +170,7 @@ __device__ __forceinline__ bool dk_poll(const DecArgs& a, unsigned target, int G
 // All waves: the seam in front of phase `ph` (1-based; waits for every workgroup to have completed ph - 1).  Returns
 // false when the launch is being abandoned.  `lds_ok`: one LDS word.
 __device__ __forceinline__ bool dk_seam(const DecArgs& a, unsigned ph, int G, volatile int* lds_ok, int wave, int lane,
-                                        int keep_in_flight) {
+                                        int keep_in_flight, DkDbg& dbg) {
   if (wave == 0) {
     const bool ok = dk_poll(a, ph - 1, G, lane);
     if (lane == 0) {
@@ -182,6 +183,7 @@ __device__ __forceinline__ bool dk_seam(const DecArgs& a, unsigned ph, int G, vo
     // the coming phase's entry is older than that batch (keep_in_flight = the batch's instructions, else 0)
     dk_wait_vm(keep_in_flight);
   }
+  if (a.stamp_fine) dk_t(dbg);
   __syncthreads();
   const bool ok = *lds_ok != 0;
   return ok;
@@ -211,6 +213,10 @@ struct DkEnt {
 struct DkRing {
   int start, used, next_e, cur_e;
   int batch_first, batch_issued;  // the latest dk_ring_advance: its first entry, the LDS-DMA instructions THIS wave issued
+  int next_k;                     // next_e % 6 while next_e is a layer's entry
+  int iss_pc, iss_slot0;          // pieces of entry next_e already issued (0: none), its first slot
+  unsigned pcs_pack;              // pieces of the six projections, 5 bits each (the bookkeeping of wave 0 sits between its
+                                  // publish and its poll: no division, no LDS read)
 };
 // the six projections of a layer as this workgroup sees them (layer-independent: built once, kept in LDS): first column,
 // columns, K, pieces, field of the weight pointer in the layer record; entry 6: K and quads of a vocabulary tile
@@ -282,52 +288,87 @@ __device__ __forceinline__ DkEnt dk_entry(const DecArgs& a, const unsigned long 
 // poll measured +3 .. 4 us on the seam).  The issuing waves wait for their pieces in front of the seam's barrier, where they
 // idle anyway - for all but the batch issued last, which no phase needs yet; behind that barrier the pieces of the next
 // phase are in LDS for all four waves.
-__device__ __forceinline__ int dk_issue_pieces(const DkEnt& e, int slot0, uint32_t ring0_lds, int target, int first, int stride,
-                                               int lane) {
-  const int per = dk_per(e.K), nquads = (per + 3) >> 2;
-  const int ksteps = (e.K + 31) >> 5;
-  const int ks0 = target * per;
-  const uint32_t ring_lds = ring0_lds + (uint32_t)target * (DK_RP * 1024u);
+// (no piece needs zeros: columns beyond the workgroup's and k-steps beyond the quarter's are never read back as operands
+// that reach a stored output - their lanes fetch a valid neighbour instead.  EXACT: the quarter is whole quads, PD % 4 == 0.)
+// Pieces [pc0, pc1) of an entry.
+template <bool EXACT>
+__device__ __forceinline__ int dk_issue_pieces(const DkEnt& e, int slot0, int pc0, int pc1, uint32_t ring0_lds, int wave, int lane) {
+  // wave 1 .. 3: every piece of its own quarter of K, and every third piece (pc % 3 == wave - 1) of wave 0's
+  const int per = e.K >> 7, nquads = (per + 3) >> 2;
   const int c = lane >> 4, jj = (lane & 15) ^ (4 * c);
-  int cg = 0, S = first, n = 0;
+  const int kq = jj >> 2;  // k-step inside a quad
+  const int own_k = wave * per * 32;
+  const uint32_t own_lds = ring0_lds + (uint32_t)wave * (DK_RP * 1024u);
+  int cg = 0, S = pc0;
   while (S >= nquads) {
     S -= nquads;
     ++cg;
   }
-  for (int pc = first; pc < e.pcs; pc += stride) {
-    const int col = 4 * cg + c;
-    const int ks = 4 * S + (jj >> 2);  // k-step within the wave's quarter
-    const int k = (ks0 + ks) * 32 + 8 * (jj & 3);
-    const bool ok = col < e.nc && ks < per && ks0 + ks < ksteps && k < e.K;
-    const void* src = ok ? (const void*)(e.W + (int64_t)col * e.K + k) : (const void*)g_dec_zero_page;
-    int slot = slot0 + pc;
-    slot = slot >= DK_RP ? slot - DK_RP : slot;
-    dk_glds16(src, ring_lds + (uint32_t)slot * 1024u);
+  int third = (pc0 + 3 - (wave - 1)) % 3;  // 0 when pc % 3 == wave - 1
+  int slot = slot0 + pc0;
+  slot = slot >= DK_RP ? slot - DK_RP : slot;
+  int n = 0;
+  for (int pc = pc0; pc < pc1; ++pc) {
+    int col = 4 * cg + c;
+    col = col < e.nc ? col : e.nc - 1;
+    int ks = 4 * S + kq;
+    if (!EXACT) ks = ks < per ? ks : per - 1;
+    const unsigned short* src = e.W + (int64_t)col * e.K + 8 * (jj & 3) + ks * 32;
+    dk_glds16(src + own_k, own_lds + (uint32_t)slot * 1024u);
     ++n;
-    S += stride;
-    while (S >= nquads) {
-      S -= nquads;
+    if (third == 0) {
+      dk_glds16(src, ring0_lds + (uint32_t)slot * 1024u);
+      ++n;
+    }
+    third = third == 2 ? 0 : third + 1;
+    if (++S == nquads) {
+      S = 0;
       ++cg;
     }
+    slot = slot + 1 >= DK_RP ? 0 : slot + 1;
   }
   return n;
 }
+// Refill the ring: at most `budget` pieces per call (an entry may be issued over several calls: an LDS-DMA instruction costs
+// its wave ~350 clocks here, and a burst of 16 between a phase's end and the next seam's barrier was on every workgroup's
+// critical path), but never less than what completes the entry the NEXT projection consumes.
+template <bool EXACT>
 __device__ __forceinline__ void dk_ring_advance(const DecArgs& a, const unsigned long long* ltab, const DkKind* kt, DkRing& rg,
-                                                int n_entries, int w, int G, uint32_t ring_lds, int wave, int lane) {
+                                                int n_entries, int w, int G, uint32_t ring_lds, int wave, int lane, int budget) {
   rg.batch_first = rg.next_e;
   rg.batch_issued = 0;
+  const int L6 = 6 * a.n_layers;
   while (rg.next_e < n_entries) {
-    const int pcs = dk_entry_pcs(a, kt, rg.next_e, w, G);
-    if (rg.used + pcs > DK_RP) break;
-    if (pcs > 0 && wave != 0) {
-      int slot0 = rg.start + rg.used;
-      slot0 = slot0 >= DK_RP ? slot0 - DK_RP : slot0;
-      const DkEnt e = dk_entry(a, ltab, kt, rg.next_e, w, G);
-      rg.batch_issued += dk_issue_pieces(e, slot0, ring_lds, wave, 0, 1, lane);
-      rg.batch_issued += dk_issue_pieces(e, slot0, ring_lds, 0, wave - 1, 3, lane);
+    int pcs;
+    if (rg.next_e < L6) {
+      pcs = (int)((rg.pcs_pack >> (5 * rg.next_k)) & 31u);
+    } else {
+      const int c0 = 16 * (w + G * (rg.next_e - L6));
+      const int nc = a.V - c0 < 16 ? a.V - c0 : 16;
+      pcs = nc > 0 ? ((nc + 3) >> 2) * (int)(rg.pcs_pack >> 30) : 0;
     }
-    rg.used += pcs;
+    const bool urgent = rg.next_e <= rg.cur_e;
+    if (rg.iss_pc == 0) {  // a new entry: its whole space is taken now
+      if (rg.used + pcs > DK_RP) break;
+      if (budget <= 0 && !urgent) break;
+      rg.iss_slot0 = rg.start + rg.used;
+      rg.iss_slot0 = rg.iss_slot0 >= DK_RP ? rg.iss_slot0 - DK_RP : rg.iss_slot0;
+      rg.used += pcs;
+    } else if (budget <= 0 && !urgent) {
+      break;
+    }
+    int upto = urgent ? pcs : rg.iss_pc + budget;
+    upto = upto < pcs ? upto : pcs;
+    if (upto > rg.iss_pc && wave != 0) {
+      const DkEnt e = dk_entry(a, ltab, kt, rg.next_e, w, G);
+      rg.batch_issued += dk_issue_pieces<EXACT>(e, rg.iss_slot0, rg.iss_pc, upto, ring_lds, wave, lane);
+    }
+    budget -= upto - rg.iss_pc;
+    rg.iss_pc = upto;
+    if (rg.iss_pc < pcs) break;  // (budget spent inside the entry)
+    rg.iss_pc = 0;
     ++rg.next_e;
+    rg.next_k = rg.next_k == 5 ? 0 : rg.next_k + 1;
   }
 }
 __device__ __forceinline__ void dk_ring_pop(DkRing& rg, int pcs) {
@@ -407,20 +448,55 @@ __device__ __forceinline__ float dk_ln_apply(float x, float mean, float rstd, fl
 }
 // ---- LayerNorm of the B rows into the LDS image (the arithmetic of ca_gemm_skinny_kernel's prologue = ln_fwd_kernel) ---------
 // EMB: the rows are token + position embeddings formed here (embed_kernel's arithmetic) instead of loaded
+// LayerNorm vectors and biases reach their phase through LDS too (LDS-DMA by waves 1 .. 3, behind a ring batch so that the
+// seam's counted wait leaves them in flight): gamma | beta of the NEXT LayerNorm phase are asked for when the previous one
+// is two seams away and the scratch region is not an attention phase's (after B for D, after E for G, after G for the next
+// layer's A or the output projection), the six biases of the next layer (this workgroup's columns) during phase A.  As loads
+// in front of the seam they put an HBM round trip in front of wave 0's poll (vmcnt counts in order).
+#define DK_PSLOT 49152                 // in the scratch region, above the LayerNorm image: gamma (6 KiB) | beta (6 KiB)
+#define DK_BSLOT 12288                 // in the first region: 2 layers x 6 projections x 128 B (32 columns)
+__device__ __forceinline__ int dk_issue_ln(const float* gamma, const float* beta, int d, uint32_t pslot_lds, int wave, int lane) {
+  if (wave != 1 && wave != 2) return 0;
+  const float* src = wave == 1 ? gamma : beta;
+  const uint32_t dst = pslot_lds + (wave == 1 ? 0u : 6144u);
+  const int nch = d >> 2;  // 16-byte chunks
+  int n = 0;
+  for (int i = 0; i * 64 < nch; ++i) {
+    const int ch = i * 64 + lane;
+    dk_glds16(ch < nch ? (const void*)(src + ch * 4) : (const void*)g_dec_zero_page, dst + (uint32_t)i * 1024u);
+    ++n;
+  }
+  return n;
+}
+__device__ __forceinline__ int dk_issue_biases(const unsigned long long* ltab, const DkKind* kt, int l, uint32_t bslot_lds, int wave,
+                                               int lane) {
+  if (wave != 3) return 0;
+  int n = 0;
+  for (int k = 0; k < 6; ++k) {
+    const DkKind kk = kt[k];
+    const float* bias = dk_lyp<const float*>(ltab, l, kk.bias_fld);
+    if (kk.nc <= 0) continue;
+    const bool ok = bias != nullptr && lane * 4 < kk.nc;
+    if (lane < 8)  // (the inactive lanes write nothing: 128 bytes per slot)
+      dk_glds16(ok ? (const void*)(bias + kk.c0 + lane * 4) : (const void*)g_dec_zero_page,
+                bslot_lds + (uint32_t)(((l & 1) * 6 + k) * 128));
+    ++n;
+  }
+  return n;
+}
 // gamma / beta of a LayerNorm into registers: asked for BEFORE the seam in front of the phase (parameters, not handed-off
 // bytes), so their trip to HBM runs while the seam resolves.  NCX: d is a multiple of 512 (every lane has NC whole chunks).
 template <int NC, bool NCX>
-__device__ __forceinline__ void dk_ln_params(const float* gamma, const float* beta, int C, int lane, f32x4_t (&gq)[NC][2],
-                                             f32x4_t (&bq)[NC][2]) {
+__device__ __forceinline__ void dk_ln_params(const char* pslot, int C, int lane, f32x4_t (&gq)[NC][2], f32x4_t (&bq)[NC][2]) {
   const int nchunk = C >> 3;
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
     const int ch = lane + c * 64;
     if (NCX || c < NC - 1 || ch < nchunk) {
-      gq[c][0] = *(const f32x4_t*)(gamma + ch * 8);
-      gq[c][1] = *(const f32x4_t*)(gamma + ch * 8 + 4);
-      bq[c][0] = *(const f32x4_t*)(beta + ch * 8);
-      bq[c][1] = *(const f32x4_t*)(beta + ch * 8 + 4);
+      gq[c][0] = *(const f32x4_t*)(pslot + ch * 32);
+      gq[c][1] = *(const f32x4_t*)(pslot + ch * 32 + 16);
+      bq[c][0] = *(const f32x4_t*)(pslot + 6144 + ch * 32);
+      bq[c][1] = *(const f32x4_t*)(pslot + 6144 + ch * 32 + 16);
     } else {
       gq[c][0] = gq[c][1] = bq[c][0] = bq[c][1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     }
@@ -593,14 +669,13 @@ __device__ __forceinline__ void dk_project(const DecArgs& a, const DkEnt& ent, i
     }
   }
 }
-// the epilogue's bias of wave 0's lanes (this workgroup's first column at bias_c0; at most two 16-column tiles), asked for
-// before the seam in front of the phase
-__device__ __forceinline__ void dk_bias4(const float* bias_c0, int nc, int wave, int lane, f32x4_t (&bias4)[2]) {
+// the epilogue's bias of wave 0's lanes from the projection's LDS slot (at most two 16-column tiles)
+__device__ __forceinline__ void dk_bias4(const char* slot, int nc, int wave, int lane, f32x4_t (&bias4)[2]) {
   const int g = lane >> 4;
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     bias4[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    if (wave == 0 && bias_c0 && 16 * t + 4 * g < nc) bias4[t] = *(const f32x4_t*)(bias_c0 + 16 * t + 4 * g);
+    if (wave == 0 && slot && 16 * t + 4 * g < nc) bias4[t] = *(const f32x4_t*)(slot + (16 * t + 4 * g) * 4);
   }
 }
 // four bf16 of consecutive columns: one 8-byte write-through store
@@ -893,10 +968,16 @@ __global__ __launch_bounds__(256) void whisper_decode_token_kernel(const DecArgs
   for (int i = threadIdx.x; i < L * LY_WORDS; i += 256) ltab[i] = ((const unsigned long long*)a.layers)[i];
   dk_build_kinds(a, kt, w, G);
   __syncthreads();
-  DkRing rg = {0, 0, 0, 0, 0, 0};
-  dk_ring_advance(a, ltab, kt, rg, n_entries, w, G, ring_lds, wave, lane);
+  const uint32_t pslot_lds = dk_lds_addr(scratch + DK_PSLOT), bslot_lds = dk_lds_addr(dk_smem + DK_BSLOT);
+  const char* pslot = scratch + DK_PSLOT;
+  DkRing rg = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0u};
+  for (int k = 0; k < 6; ++k) rg.pcs_pack |= (unsigned)kt[k].pcs << (5 * k);
+  rg.pcs_pack |= (unsigned)kt[6].nquads << 30;  // (quads of a vocabulary tile: at most 3)
+  dk_issue_ln(dk_lyp<const float*>(ltab, 0, LY_LN1G), dk_lyp<const float*>(ltab, 0, LY_LN1B), a.d, pslot_lds, wave, lane);
+  dk_issue_biases(ltab, kt, 0, bslot_lds, wave, lane);
+  dk_ring_advance<PD % 4 == 0>(a, ltab, kt, rg, n_entries, w, G, ring_lds, wave, lane, 1 << 20);
   unsigned ph = 0;  // phases completed by this workgroup
-  DkDbg dbg = {a.stamps ? a.stamps + (int64_t)w * a.stamp_nph : nullptr, a.stamp_nph, 0};
+  DkDbg dbg = {a.stamps ? a.stamps + (int64_t)w * a.stamp_nph : nullptr, a.stamp_nph, 0, a.stamp_tid};
   const int dc0 = kt[1].c0, dnc = kt[1].nc;  // this workgroup's columns of every N = d projection (at most 16)
   // wave 0: the residual stream at (row r, column dc0 + 4 g + e), as stored (bf16).  Layer 0: the embedding rows
   // (embed_kernel's arithmetic)
@@ -914,15 +995,33 @@ __global__ __launch_bounds__(256) void whisper_decode_token_kernel(const DecArgs
   int bi = 0x7fffffff;
   // the seam in front of the next phase; false = the launch is being abandoned
   auto seam = [&](int keep) {
-    const bool ok = dk_seam(a, ph + 1, G, lds_ok, wave, lane, keep);
+    const bool ok = dk_seam(a, ph + 1, G, lds_ok, wave, lane, keep, dbg);
     if (ok) dk_t(dbg);
     return ok;
   };
-  auto done = [&] {
+  // `step` is over: publish, refill the ring, and ask for what a later phase reads from the LDS slots (behind the ring
+  // batch: the next seam's counted wait leaves both in flight)
+  auto done = [&](int step) {
     dk_t(dbg);
     ++ph;
     dk_publish(a, ph, w, wave, lane);
-    dk_ring_advance(a, ltab, kt, rg, n_entries, w, G, ring_lds, wave, lane);
+    if (a.stamp_fine) dk_t(dbg);
+    dk_ring_advance<PD % 4 == 0>(a, ltab, kt, rg, n_entries, w, G, ring_lds, wave, lane, step < 8 * L - 1 ? a.ring_budget : 1 << 20);
+    if (a.stamp_fine) dk_t(dbg);
+    const int l = step >> 3, p = step & 7;
+    if (step < 8 * L) {
+      if (p == 1)
+        rg.batch_issued += dk_issue_ln(dk_lyp<const float*>(ltab, l, LY_LN2G), dk_lyp<const float*>(ltab, l, LY_LN2B), a.d, pslot_lds, wave, lane);
+      else if (p == 4)
+        rg.batch_issued += dk_issue_ln(dk_lyp<const float*>(ltab, l, LY_LN3G), dk_lyp<const float*>(ltab, l, LY_LN3B), a.d, pslot_lds, wave, lane);
+      else if (p == 6) {
+        if (l + 1 < L)
+          rg.batch_issued += dk_issue_ln(dk_lyp<const float*>(ltab, l + 1, LY_LN1G), dk_lyp<const float*>(ltab, l + 1, LY_LN1B), a.d, pslot_lds, wave, lane);
+        else
+          rg.batch_issued += dk_issue_ln(a.lnf_g, a.lnf_b, a.d, pslot_lds, wave, lane);
+      } else if (p == 0 && l + 1 < L)
+        rg.batch_issued += dk_issue_biases(ltab, kt, l + 1, bslot_lds, wave, lane);
+    }
   };
 
   const int nsteps = 8 * L + 1;
@@ -933,6 +1032,7 @@ __global__ __launch_bounds__(256) void whisper_decode_token_kernel(const DecArgs
       // ---- attention: B (self, over this layer's cache) or E (over the cached encoder K|V) ----------------------------------------
       const bool cross = p == 4;
       const int ns = cross ? a.ns : 1, nit = B * H * ns;
+      if (w >= nit && wave != 0) dk_wait_vm(rg.cur_e < rg.batch_first ? rg.batch_issued : 0);
       if (w < nit) {
         const unsigned short* kvbase = dk_lyp<const unsigned short*>(ltab, l, cross ? LY_CROSSKV : LY_SELFKV);
         const int Tk = cross ? a.Te : a.Lmax;
@@ -973,7 +1073,7 @@ __global__ __launch_bounds__(256) void whisper_decode_token_kernel(const DecArgs
           }
         }
       }
-      done();
+      done(step);
       continue;
     }
     // ---- a projection: A (LayerNorm + q|k|v), C / F (out-projection + residual), D (LayerNorm + cross query), G (LayerNorm +
@@ -982,30 +1082,27 @@ __global__ __launch_bounds__(256) void whisper_decode_token_kernel(const DecArgs
     const DkKind kk = kt[kind];
     const bool ln = kind == 0 || kind == 2 || kind == 4 || kind == 6;
     const int my_nc = head ? (my_tiles > 0 ? 16 : 0) : kk.nc;
-    f32x4_t gq[NC][2], bq[NC][2], bias4[2];
-    if (ln && my_nc > 0) {
-      const float* gm = head ? a.lnf_g : dk_lyp<const float*>(ltab, l, kk.ln_fld);
-      const float* bt = head ? a.lnf_b : dk_lyp<const float*>(ltab, l, kk.ln_fld + 1);
-      dk_ln_params<NC, NCX>(gm, bt, d, lane, gq, bq);
-    }
-    {
-      const float* bias = head ? nullptr : dk_lyp<const float*>(ltab, l, kk.bias_fld);
-      dk_bias4(bias ? bias + kk.c0 : nullptr, my_nc, wave, lane, bias4);
-    }
+    f32x4_t bias4[2];
+    const int keep = rg.cur_e < rg.batch_first ? rg.batch_issued : 0;
     if (my_nc > 0) {
       if (step > 0) {
-        if (!seam(rg.cur_e < rg.batch_first ? rg.batch_issued : 0)) return;
+        if (!seam(keep)) return;
       } else {
-        if (wave != 0) dk_vm0();  // (the first ring pieces: see dk_issue_pieces)
+        if (wave != 0) dk_vm0();  // (the first ring pieces and LDS slots: see dk_issue_pieces)
         __syncthreads();
       }
       if (ln) {
+        f32x4_t gq[NC][2], bq[NC][2];
+        dk_ln_params<NC, NCX>(pslot, d, lane, gq, bq);
         const unsigned short* x = kind == 2 ? a.h1 : kind == 4 ? a.h2 : a.h;
         dk_ln_rows<NC, NCX>(a, x, step == 0, gq, bq, xs, wave, lane);
         if (!head) __syncthreads();
       }
       dk_t(dbg);
+    } else if (wave != 0) {
+      dk_wait_vm(keep);  // (no seam here: the issuing waves still keep the order of what has landed)
     }
+    dk_bias4(head ? nullptr : dk_smem + DK_BSLOT + ((l & 1) * 6 + kind) * 128, my_nc, wave, lane, bias4);
     unsigned short* ckv = dk_lyp<unsigned short*>(ltab, head ? 0 : l, LY_SELFKV);
     const int nent = head ? my_tiles : 1;
     for (int t = 0; t < nent; ++t) {
@@ -1057,7 +1154,7 @@ __global__ __launch_bounds__(256) void whisper_decode_token_kernel(const DecArgs
         });
       }
       dk_ring_pop(rg, ent.pcs);
-      if (head) dk_ring_advance(a, ltab, kt, rg, n_entries, w, G, ring_lds, wave, lane);
+      if (head) dk_ring_advance<PD % 4 == 0>(a, ltab, kt, rg, n_entries, w, G, ring_lds, wave, lane, 1 << 20);
     }
     if (head) {
       // this workgroup's best per row: lanes (r, g) of wave 0 hold row r
@@ -1077,7 +1174,7 @@ __global__ __launch_bounds__(256) void whisper_decode_token_kernel(const DecArgs
         }
       }
     }
-    done();
+    done(step);
   }
   // ---- the greedy pick of row w and the step's bookkeeping (ca_argmax_advance's) -------------------------------------------------
   if (w < B) {
@@ -1216,8 +1313,12 @@ extern "C" int ca_whisper_decode_token(const CaDecodeDesc* desc, void* stream) {
   a.status = c.status;
   a.stamps = g_dk_stamps;
   a.stamp_nph = g_dk_stamp_nph;
+  { const char* e = getenv("CA_DECODE_STAMP_TID"); a.stamp_tid = e ? atoi(e) : 0; }
+  { const char* e = getenv("CA_DECODE_STAMP_FINE"); a.stamp_fine = e ? atoi(e) : 0; }
   static const int pre = [] { const char* e = getenv("CA_DECODE_PREISSUE"); return e ? atoi(e) : 1; }();
   a.pre_issue = pre;
+  static const int budget = [] { const char* e = getenv("CA_DECODE_RING_BUDGET"); return e ? atoi(e) : 5; }();
+  a.ring_budget = budget > 0 ? budget : 1 << 20;
   CA_CHECK_ARG((size_t)(p - (char*)c.ws) <= (size_t)c.ws_bytes, "ca_whisper_decode_token: workspace layout exceeds ws_bytes");
   hipStream_t s = (hipStream_t)stream;
 #define DK_KERNELS(X) X(3, 1, false) X(4, 1, true) X(6, 2, false) X(8, 2, true) X(10, 3, false)

@@ -11,7 +11,8 @@ GOLDEN = ROOT / "tests" / "golden"
 
 # Hot-path parity first (SURVEY.md §8 rows a), then full-size properties and the finetune entry points, then the
 # "next" rows (f) and the opt-in fp8 path: with `-x` a failure in a later row can never hide the rows in front of it.
-_ORDER = ["test_kernels_gpu", "test_w2v2_gpu", "test_depth_gpu", "test_whisper_gpu", "test_fulldepth_gpu", "test_fullsize_gpu",
+_ORDER = ["test_kernels_gpu", "test_w2v2_gpu", "test_depth_gpu", "test_trainer_traj_gpu", "test_whisper_gpu",
+          "test_decode_persistent_gpu", "test_fulldepth_gpu", "test_fullsize_gpu",
           "test_finetune_gpu", "test_dp_gpu", "test_bench_gpu", "test_eval_gpu", "test_ckpt_gpu", "test_input_pipeline_gpu",
           "test_augment_gpu", "test_fp8_gpu"]
 

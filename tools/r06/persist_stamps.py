@@ -33,6 +33,11 @@ LAB = {"A": ["publish + ring + seam", "LayerNorm image written", "projection + e
 LAB["D"] = LAB["G"] = LAB["A"]
 LAB["F"] = LAB["H"] = LAB["C"]
 LAB["E"] = ["publish + ring + first tiles + seam", "attention done"]
+import os
+FINE = os.environ.get("CA_DECODE_STAMP_FINE", "0") != "0"
+if FINE:  # every phase: ... its own work ..., then "published", "ring advanced"; in front: "at the seam's barrier"
+    for k in list(LAB):
+        LAB[k] = ["at the seam's barrier (from the previous 'ring advanced')", "barrier passed"] + LAB[k][1:] + ["published", "ring advanced"]
 ORDER = "ABCDEFGH"
 per_layer = sum(len(LAB[k]) for k in ORDER)
 nst = per_layer * L + 64
@@ -52,7 +57,7 @@ for _ in range(10):
 e1.record()
 torch.cuda.synchronize()
 us_launch = e0.elapsed_time(e1) * 100.0
-first = per_layer - 1  # layer 0 has no seam stamp in phase A
+first = per_layer - (2 if FINE else 1)  # layer 0 has no seam stamp(s) in phase A
 last_layer_end = first + per_layer * (L - 1)
 span_ticks = float(t[:, last_layer_end - 1].max() - t[:, 0].min())
 print(f"{model} B={B}: launch {us_launch:.1f} us (events); layers span {span_ticks:.0f} ticks; status {ps['status'].tolist()}")
