@@ -57,51 +57,98 @@ def finetune(config, n_examples: int | None = None) -> dict:
                 steps_done=out.global_step, state=trainer.state, train_output=out)
 
 
-def evaluate_split_seq2seq(model, examples, collator, compute_metrics, batch_size, max_length) -> dict:
+def _dist_rank_world():
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        return torch.distributed.get_rank(), torch.distributed.get_world_size()
+    return 0, 1
+
+
+def eval_batches_of_rank(n_examples: int, batch_size: int, rank: int, world: int) -> list[tuple[int, int]]:
+    """The evaluation batches `rank` decodes: batch k = examples [k B, (k + 1) B) goes to rank k % world - the
+    round-robin of accelerate's `BatchSamplerShard` under `Trainer.evaluate` ($TF/trainer.py:2653-2777: the evaluation
+    dataloader is sharded over the ranks, every rank decodes 1 / world of the set)."""
+    batches = [(i, min(i + batch_size, n_examples)) for i in range(0, n_examples, batch_size)]
+    return batches[rank::world]
+
+
+def gather_rows_in_order(rows: list[list[int]], starts: list[int], n_examples: int, fill: int, rank: int, world: int):
+    """Every rank's id rows -> ONE [n_examples, W] int64 array in dataset order, on every rank.
+
+    rows[j] belongs to example starts[j].  The rows are padded with `fill` to the widest row of any rank and the row
+    counts to the largest of any rank with all-`fill` rows (what `pad_across_processes(pad_index=-100)` +
+    `gather_for_metrics` do, $TF/trainer.py:2754-2777; the filler rows are what R/src/coral/compute_metrics.py:63-66
+    special-cases) - here they carry the example index -1 and are dropped after the gather instead.  Ids, not logits:
+    46 x fewer bytes than the reference moves.  One all_gather of a [rows, 1 + W] matrix per evaluation set."""
+    import numpy as np
+
+    if world == 1:
+        W = max((len(r) for r in rows), default=1)
+        out = np.full((n_examples, max(W, 1)), fill, dtype=np.int64)
+        for r, i in zip(rows, starts):
+            out[i, :len(r)] = r
+        return out
+    dist = torch.distributed
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    dims = torch.tensor([len(rows), max((len(r) for r in rows), default=1)], dtype=torch.int64, device=dev)
+    dist.all_reduce(dims, op=dist.ReduceOp.MAX)
+    R, W = int(dims[0]), max(1, int(dims[1]))
+    local = np.full((R, 1 + W), fill, dtype=np.int64)
+    local[:, 0] = -1
+    for j, (r, i) in enumerate(zip(rows, starts)):
+        local[j, 0] = i
+        local[j, 1:1 + len(r)] = r
+    mine = torch.from_numpy(local).to(dev)
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine)
+    out = np.full((n_examples, W), fill, dtype=np.int64)
+    seen = np.zeros(n_examples, dtype=bool)
+    for part in parts:
+        a = part.cpu().numpy()
+        keep = a[:, 0] >= 0
+        out[a[keep, 0]] = a[keep, 1:]
+        seen[a[keep, 0]] = True
+    if not seen.all():
+        raise RuntimeError(f"sharded evaluation: {int((~seen).sum())} of {n_examples} examples were decoded by no rank")
+    return out
+
+
+def evaluate_split_seq2seq(model, examples, collator, compute_metrics, batch_size, max_length, rank=None, world=None) -> dict:
     """`predict_with_generate` evaluation (R/src/coral/whisper.py:221-222): greedy generation on the GPU,
-    CER/WER of the decoded strings on the host."""
+    CER/WER of the decoded strings on the host.  Under N > 1 ranks every rank generates for its share of the batches
+    (`eval_batches_of_rank`), the id rows are all-gathered (`gather_rows_in_order`) and every rank computes the same
+    metrics from the whole set - early stopping stays in lock-step."""
+    if rank is None or world is None:
+        rank, world = _dist_rank_world()
     model.eval()
-    preds, labels = [], []
-    for i in range(0, len(examples), batch_size):
-        batch = collator(examples[i:i + batch_size])
+    preds, labels, starts = [], [], []
+    for lo, hi in eval_batches_of_rank(len(examples), batch_size, rank, world):
+        batch = collator(examples[lo:hi])
         ids = model.generate(batch["input_features"], language="danish", task="transcribe", max_length=max_length)
         preds.extend(ids.tolist() if hasattr(ids, "tolist") else ids)
         labels.extend(batch["labels"].tolist())
-    import numpy as np
-
-    pad = model.shape.pad_token_id
-    P = np.full((len(preds), max(len(p) for p in preds)), pad, dtype=np.int64)
-    for i, p in enumerate(preds):
-        P[i, :len(p)] = p
-    Lb = np.full((len(labels), max(len(x) for x in labels)), -100, dtype=np.int64)
-    for i, x in enumerate(labels):
-        Lb[i, :len(x)] = x
+        starts.extend(range(lo, hi))
+    P = gather_rows_in_order(preds, starts, len(examples), model.shape.pad_token_id, rank, world)
+    Lb = gather_rows_in_order(labels, starts, len(examples), -100, rank, world)
     return compute_metrics(P, Lb)
 
 
-def evaluate_split(model, examples, collator, compute_metrics, batch_size) -> dict:
-    """Greedy CTC evaluation: argmax + collapse on the GPU, CER/WER on the host."""
+def evaluate_split(model, examples, collator, compute_metrics, batch_size, rank=None, world=None) -> dict:
+    """Greedy CTC evaluation: argmax + collapse on the GPU, CER/WER on the host; sharded over the ranks like
+    `evaluate_split_seq2seq`."""
+    if rank is None or world is None:
+        rank, world = _dist_rank_world()
     model.eval()
-    preds, labels = [], []
-    for i in range(0, len(examples), batch_size):
-        batch = collator(examples[i:i + batch_size])
+    preds, labels, starts = [], [], []
+    for lo, hi in eval_batches_of_rank(len(examples), batch_size, rank, world):
+        batch = collator(examples[lo:hi])
         with torch.no_grad():
             model(batch["input_values"], batch["attention_mask"])
         ids, _ = model.engine.greedy_decode()
-        width = max(1, max(len(x) for x in ids))
-        for row in ids:
-            preds.append(row + [model.shape.pad_token_id] * (width - len(row)))
+        preds.extend(list(r) for r in ids)
         labels.extend(batch["labels"].tolist())
-    import numpy as np
-
-    W = max(len(p) for p in preds)
-    P = np.full((len(preds), W), model.shape.pad_token_id, dtype=np.int64)
-    for i, p in enumerate(preds):
-        P[i, :len(p)] = p
-    Lw = max(len(x) for x in labels)
-    Lb = np.full((len(labels), Lw), -100, dtype=np.int64)
-    for i, x in enumerate(labels):
-        Lb[i, :len(x)] = x
+        starts.extend(range(lo, hi))
+    P = gather_rows_in_order(preds, starts, len(examples), model.shape.pad_token_id, rank, world)
+    Lb = gather_rows_in_order(labels, starts, len(examples), -100, rank, world)
     # ids are already collapsed: decode without grouping so genuine double letters survive
     tok = compute_metrics.keywords["processor"].tokenizer if hasattr(compute_metrics, "keywords") else None
     if tok is not None:
