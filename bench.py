@@ -435,6 +435,31 @@ def run_w2v2(model_key, args, world, rank, device, roofline: bool):
                           "unit": "audio-seconds/sec",
                           "note": "forward + backward only (BASELINE.json's wording of the metric); `value` is the whole "
                                   "step with gradient-norm clip and AdamW"}
+    if world == 1 and roofline and not args.no_fwd_bwd and os.environ.get("CA_WGRAD_BF16", "1") != "0":
+        # The N = 1 line keeps the layers' weight-matrix gradients in bf16 (one micro-batch, one rank: what the reference's
+        # autocast computes); N > 1 and accumulation use the fp32 buffer.  The same step on the fp32 route, so that an
+        # N = 1 -> N = 8 comparison can start from like for like (`config.fp32_matrix_gradients`).
+        trainer.finish()
+        torch.cuda.synchronize()
+        os.environ["CA_WGRAD_BF16"] = "0"
+        try:
+            for _ in range(2):
+                trainer.train_step(make_step_batch())
+            trainer.finish()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                trainer.train_step(make_step_batch())
+            trainer.finish()
+            torch.cuda.synchronize()
+            f32 = (time.perf_counter() - t0) / args.steps
+            res["fp32_matrix_gradients"] = {"ms_per_step": round(f32 * 1e3, 3), "value": round(float(lens.sum()) / 16000.0 / f32, 2),
+                                            "unit": "audio-seconds/sec",
+                                            "note": "the same step with CA_WGRAD_BF16=0 (the gradient route of N > 1 ranks and "
+                                                    "of accumulation)"}
+        finally:
+            del os.environ["CA_WGRAD_BF16"]
+        trainer.train_step(make_step_batch())  # (back on the default route before the profiled steps)
     if roofline:
         # Per-kernel durations are only meaningful with the kernels serialised: the timed steps above run the weight
         # gradients on their own stream beside the data-gradient chain (wav2vec2.py backward) and the HBM-bound AdamW
@@ -605,7 +630,8 @@ def main():
                        "loss": round(loss_val, 3),
                        **({"fwd_bwd": dict(res["fwd_bwd"], frac_of_peak=round(
                            res["step_tflop"] / (res["fwd_bwd"]["ms_per_step"] * 1e-3) / MFMA_BF16_DENSE_PEAK_TFLOPS, 4))}
-                          if "fwd_bwd" in res else {})},
+                          if "fwd_bwd" in res else {}),
+                       **({"fp32_matrix_gradients": res["fp32_matrix_gradients"]} if "fp32_matrix_gradients" in res else {})},
             "roofline": {"bound": "mfma", "kernel": dom["kernel"], "achieved": round(ach, 1),
                          "timing": "hipEvents around every launch of two extra steps run with all kernels on one stream "
                                    "(the timed steps overlap the optimiser and the weight gradients on side streams)",

@@ -104,7 +104,8 @@ class CaDecodeDesc(C.Structure):
                 + [("eps", C.c_float), ("logits", C.c_void_p), ("ld_logits", C.c_int64), ("suppress", C.c_void_p),
                    ("out", C.c_void_p), ("done", C.c_void_p), ("ids", C.c_void_p), ("ld_ids", C.c_int64),
                    ("tok", C.c_void_p), ("pos", C.c_void_p), ("klen", C.c_void_p), ("pad_id", C.c_int32),
-                   ("eos_id", C.c_int32), ("ws", C.c_void_p), ("ws_bytes", C.c_int64), ("status", C.c_void_p)])
+                   ("eos_id", C.c_int32), ("ws", C.c_void_p), ("ws_bytes", C.c_int64), ("status", C.c_void_p),
+                   ("cross_head_major", C.c_int32)])
 
 
 DECODE_MAX_B = 16

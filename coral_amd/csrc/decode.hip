@@ -25,8 +25,8 @@
 // write-through (sc1) by wave 0, which then drains (s_waitcnt vmcnt(0)) and stores the word (sc1); a consumer's wave 0
 // polls ALL words with one 16-byte sc1 load per lane, then the workgroup's barrier, then every load of handed-off bytes is
 // an sc1 load to registers (MI355X_MICROARCH.md, visibility: the form "one lane of each storing workgroup / sc1 poll of
-// every shard / barrier / sc1 loads").  The one exception is phase B, whose V tiles arrive by LDS-DMA: an agent-scope
-// acquire in front of it.  Every spin is bounded: on a timeout the workgroup sets status[0] and leaves, the others follow.
+// every shard / barrier / sc1 loads").  Phase B's V tiles arrive by LDS-DMA: the one row of them written in this launch is
+// fetched again by an sc1 load and written over the tile's copy in LDS (dk_attend, fresh_row).  Every spin is bounded: on a timeout the workgroup sets status[0] and leaves, the others follow.
 // Buffers are written once per layer and read in the next phase, so re-use one layer later is ordered by the seams.
 //
 // Weights.  A wave's quarter of K of its workgroup's columns of every matrix goes through a private LDS ring (20 pieces of
@@ -86,6 +86,8 @@ struct DecArgs {
   int stamp_nph, stamp_tid, stamp_fine;
   int pre_issue;  // phase E: the first K|V tiles are asked for before the seam
   int ring_budget;
+  int cross_hm;  // the encoder K|V are head-major copies
+  int b_fence;
 };
 
 // ---- memory helpers ------------------------------------------------------------------------------------------------
@@ -505,15 +507,16 @@ __device__ __forceinline__ void dk_ln_params(const char* pslot, int C, int lane,
 // LayerNorm of the 16 rows into the LDS image (the arithmetic of ca_gemm_skinny_kernel's prologue = ln_fwd_kernel): a wave
 // takes rows wave, wave + 4, ...; rows beyond B are formed from zeros and not stored.  emb: the rows are token + position
 // embeddings formed here (embed_kernel's arithmetic) instead of loaded.
-template <int NC, bool NCX>
+// NR: rows per wave (4; 2 where B <= 8: rows wave + 8 and wave + 12 do not exist)
+template <int NC, bool NCX, int NR>
 __device__ __forceinline__ void dk_ln_rows(const DecArgs& a, const unsigned short* x, bool emb, const f32x4_t (&gq)[NC][2],
                                            const f32x4_t (&bq)[NC][2], unsigned short* xs, int wave, int lane) {
   const int C = a.d, nchunk = C >> 3, xpitch = C + DK_XPAD;
   const u16x8_t z8 = {0, 0, 0, 0, 0, 0, 0, 0};
-  u16x8_t raw[4][NC];
+  u16x8_t raw[NR][NC];
   if (!emb) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NR; ++i) {
       const int row = wave + 4 * i;
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
@@ -524,12 +527,12 @@ __device__ __forceinline__ void dk_ln_rows(const DecArgs& a, const unsigned shor
     }
     dk_vm0();
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NR; ++i)
 #pragma unroll
       for (int c = 0; c < NC; ++c) dk_tie(raw[i][c]);
   } else {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NR; ++i) {
       const int row = wave + 4 * i;
       int64_t t_off = 0, p_off = 0;
       if (row < a.B) {
@@ -549,9 +552,9 @@ __device__ __forceinline__ void dk_ln_rows(const DecArgs& a, const unsigned shor
   }
   // the four rows of a wave side by side (independent reduction chains overlap their latencies); per row the arithmetic
   // and its order are ln_fwd_kernel's (dk_sq_acc / dk_ln_apply: with the fusions written out)
-  float sx[4], mean[4], s2[4], rstd[4];
+  float sx[NR], mean[NR], s2[NR], rstd[NR];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < NR; ++i) {
     sx[i] = 0.f;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
@@ -562,9 +565,9 @@ __device__ __forceinline__ void dk_ln_rows(const DecArgs& a, const unsigned shor
     }
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) sx[i] = dk_bfly_sum(sx[i]);
+  for (int i = 0; i < NR; ++i) sx[i] = dk_bfly_sum(sx[i]);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < NR; ++i) {
     mean[i] = sx[i] / (float)C;
     s2[i] = 0.f;
 #pragma unroll
@@ -576,9 +579,9 @@ __device__ __forceinline__ void dk_ln_rows(const DecArgs& a, const unsigned shor
     }
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) s2[i] = dk_bfly_sum(s2[i]);
+  for (int i = 0; i < NR; ++i) s2[i] = dk_bfly_sum(s2[i]);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < NR; ++i) {
     const int lrow = wave + 4 * i;
     rstd[i] = rsqrtf(s2[i] / (float)C + a.eps);
     if (lrow < a.B) {
@@ -711,12 +714,16 @@ __device__ __forceinline__ bf16x8_t dk_vfrag(const char* img, int s, int nb, int
 // the clip's cache (row strides ldk = ldv = 2d); Tk: rows of the cache (clamp bound), kl: valid keys; vw / nvw: this
 // wave's place among the 4 * ns waves that share the keys.  smem: DK_SCRATCH.  Wave 0 ends with the merged (M, L, o) of
 // the four waves; ns == 1: it stores the output row O (64 bf16, sc1); ns > 1: its partial into `slab`.
+// fresh_row >= 0 (the self-attention): row fresh_row of K and V was written by other workgroups in this launch - the K
+// fragments are then sc1 loads, and V's row, which arrives in its tile by LDS-DMA (not a load the write-through hand-off
+// covers), is fetched again by an sc1 register load and written over the tile's copy in LDS: every handed-off byte that
+// is used came through an sc1 load to registers, so the phase needs no acquire (1.5 us per layer).
 // `hook`: called once the first tiles are in flight and before the query row is read - the seam in front of the phase where
 // K and V do not depend on it (the encoder K|V: 128 KB per CU under way while the seam resolves); false = give up.
 template <class Hook>
 __device__ __forceinline__ bool dk_attend(const unsigned short* Q, const unsigned short* K, const unsigned short* V, int64_t ldkv,
                                           int Tk, int kl, int ns, int sp, float c2, char* smem, unsigned short* O, float* slab,
-                                          int wave, int lane, bool pre, Hook hook) {
+                                          int wave, int lane, bool pre, int fresh_row, Hook hook) {
   constexpr int D = 2, IMG = 64 * 64 * 2, NKS = 2, NNB = 4;
   const int g = lane >> 4, r = lane & 15;
   const int vw = sp * 4 + wave, nvw = 4 * ns;
@@ -729,6 +736,7 @@ __device__ __forceinline__ bool dk_attend(const unsigned short* Q, const unsigne
 #pragma unroll
   for (int nb = 0; nb < NNB; ++nb) o[nb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   bf16x8_t kf[D][4][NKS];
+  u16x8_t vfresh = {0, 0, 0, 0, 0, 0, 0, 0};  // lanes 0 .. 7: chunk `lane` of V's fresh row
   auto issue = [&](auto slot_c, int j) {
     constexpr int S = decltype(slot_c)::value;
     const int kt = vw + nvw * j;
@@ -737,7 +745,8 @@ __device__ __forceinline__ bool dk_attend(const unsigned short* Q, const unsigne
       int key = kt * 64 + 32 * (blk >> 1) + dk_rowperm(blk & 1, r);
       key = key < Tk ? key : Tk - 1;
 #pragma unroll
-      for (int ks = 0; ks < NKS; ++ks) kf[S][blk][ks] = dk_ld16(K + (int64_t)key * ldkv + 32 * ks + 8 * g);
+      for (int ks = 0; ks < NKS; ++ks)  // (sc1 in both attention phases: one code path; the self-attention needs it)
+        kf[S][blk][ks] = __builtin_bit_cast(bf16x8_t, dk_ld16_sc1(K + (int64_t)key * ldkv + 32 * ks + 8 * g));
     }
     const uint32_t img = dk_lds_addr(Vring + S * IMG);
 #pragma unroll
@@ -758,6 +767,10 @@ __device__ __forceinline__ bool dk_attend(const unsigned short* Q, const unsigne
     else
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const char* Vimg = Vring + S * IMG;
+    if (fresh_row >= 0 && kt == (fresh_row >> 6)) {  // (wave-uniform) the tile's copy of the fresh row: replaced
+      const int kr = fresh_row & 63;
+      if (lane < 8) *(u16x8_t*)(Vring + S * IMG + kr * 128 + ((lane ^ dk_mnswz8(kr)) * 16)) = vfresh;
+    }
     bf16x8_t vf[2][NNB];
 #pragma unroll
     for (int s = 0; s < 2; ++s)
@@ -844,9 +857,11 @@ __device__ __forceinline__ bool dk_attend(const unsigned short* Q, const unsigne
   }
 #pragma unroll
   for (int ks = 0; ks < NKS; ++ks) qf[ks] = __builtin_bit_cast(bf16x8_t, dk_ld16_sc1(Q + 32 * ks + 8 * g));
+  if (fresh_row >= 0 && lane < 8) vfresh = dk_ld16_sc1(V + (int64_t)fresh_row * ldkv + lane * 8);
   dk_vm0();  // (the query; the first tiles, older, with it)
 #pragma unroll
   for (int ks = 0; ks < NKS; ++ks) dk_tie(qf[ks]);
+  dk_tie(vfresh);
   for (int j = 0; j < nw; j += D) {
     step(std::integral_constant<int, 0>{}, j);
     if (j + 1 < nw) step(std::integral_constant<int, 1>{}, j + 1);
@@ -1040,12 +1055,13 @@ __global__ __launch_bounds__(256) void whisper_decode_token_kernel(const DecArgs
         unsigned short* Ob = cross ? a.ctx2 : a.ctx;
         if (!cross) {
           if (!seam(0)) return;
-          // the V tiles (this token's row among them) come by LDS-DMA, not by sc1 register loads: acquire
-          if (threadIdx.x == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            dk_vm0();
+          if (a.b_fence) {  // (CA_DECODE_B_FENCE=1: an agent acquire in front of the phase, as well)
+            if (threadIdx.x == 0) {
+              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+              dk_vm0();
+            }
+            __syncthreads();
           }
-          __syncthreads();
         }
         for (int it = w; it < nit; it += G) {
           const int bh = it / ns, sp = it - bh * ns;
@@ -1055,13 +1071,18 @@ __global__ __launch_bounds__(256) void whisper_decode_token_kernel(const DecArgs
             kl = a.klen[b];
             kl = kl < Tk ? kl : Tk;
           }
-          const unsigned short* Kp = kvbase + (int64_t)b * Tk * 2 * d + h * 64;
+          // K | V of (clip, head): columns h * 64 .. of the [Tk, 2 d] rows (K, then V at + d) - or, the encoder K|V in
+          // the head-major copy (CaDecodeDesc.cross_head_major: [B][2][H][Te][64]), two contiguous 188 KB strips
+          const bool hm = cross && a.cross_hm;
+          const unsigned short* Kp = hm ? kvbase + ((int64_t)(b * 2) * H + h) * Tk * 64 : kvbase + (int64_t)b * Tk * 2 * d + h * 64;
+          const unsigned short* Vp = hm ? Kp + (int64_t)H * Tk * 64 : Kp + d;
+          const int ldkv = hm ? 64 : 2 * d;
           unsigned short* O = Ob + (int64_t)b * d + h * 64;
           const bool first_cross = cross && it == w;  // (E: the first tiles are asked for BEFORE the seam: K and V do not
                                                      // depend on this token)
-          const bool ok = dk_attend(Qb + (int64_t)b * d + h * 64, Kp, Kp + d, 2 * d, Tk, kl, ns, sp, a.scale * DK_LOG2E, scratch, O,
+          const bool ok = dk_attend(Qb + (int64_t)b * d + h * 64, Kp, Vp, ldkv, Tk, kl, ns, sp, a.scale * DK_LOG2E, scratch, O,
                                     a.slab + (int64_t)it * DK_SPLIT_ROW, wave, lane, first_cross && a.pre_issue != 0,
-                                    [&] { return first_cross ? seam(0) : true; });
+                                    cross ? -1 : kl - 1, [&] { return first_cross ? seam(0) : true; });
           if (!ok) return;
           if (ns > 1 && wave == 0) {
             dk_vm0();  // this workgroup's partial is out
@@ -1095,7 +1116,10 @@ __global__ __launch_bounds__(256) void whisper_decode_token_kernel(const DecArgs
         f32x4_t gq[NC][2], bq[NC][2];
         dk_ln_params<NC, NCX>(pslot, d, lane, gq, bq);
         const unsigned short* x = kind == 2 ? a.h1 : kind == 4 ? a.h2 : a.h;
-        dk_ln_rows<NC, NCX>(a, x, step == 0, gq, bq, xs, wave, lane);
+        if (B > 8)
+          dk_ln_rows<NC, NCX, 4>(a, x, step == 0, gq, bq, xs, wave, lane);
+        else
+          dk_ln_rows<NC, NCX, 2>(a, x, step == 0, gq, bq, xs, wave, lane);
         if (!head) __syncthreads();
       }
       dk_t(dbg);
@@ -1319,6 +1343,8 @@ extern "C" int ca_whisper_decode_token(const CaDecodeDesc* desc, void* stream) {
   a.pre_issue = pre;
   static const int budget = [] { const char* e = getenv("CA_DECODE_RING_BUDGET"); return e ? atoi(e) : 5; }();
   a.ring_budget = budget > 0 ? budget : 1 << 20;
+  a.cross_hm = c.cross_head_major;
+  { const char* e = getenv("CA_DECODE_B_FENCE"); a.b_fence = e ? atoi(e) : 0; }
   CA_CHECK_ARG((size_t)(p - (char*)c.ws) <= (size_t)c.ws_bytes, "ca_whisper_decode_token: workspace layout exceeds ws_bytes");
   hipStream_t s = (hipStream_t)stream;
 #define DK_KERNELS(X) X(3, 1, false) X(4, 1, true) X(6, 2, false) X(8, 2, true) X(10, 3, false)

@@ -637,6 +637,9 @@ typedef struct CaDecodeDesc {
   void* ws;
   int64_t ws_bytes;
   uint32_t* status;
+  /* 1: CaDecodeLayer.cross_kv is the head-major copy [B][2 (K, V)][H][Te][64] of the encoder K|V (a (clip, head)'s keys
+   * and values are two contiguous strips: the cross-attention streams them without 4 KB strides); 0: [B, Te, 2d] */
+  int32_t cross_head_major;
 } CaDecodeDesc;
 #define CA_DECODE_MAX_B 16
 #define CA_DECODE_WS_BYTES(B, d, f, H, n_layers)                                                              \
