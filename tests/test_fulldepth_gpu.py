@@ -170,7 +170,20 @@ def test_xlsr2b_bench_batch_ctc_loss_against_the_oracle():
     nll = out["nll"].float().cpu()
     loss = float(out.loss)
     logits = out.logits.float().cpu()
-    del eng
+    # A/B (round 6, the review's question): the SAME last hidden state (bf16, as the engine holds it) through a final
+    # LayerNorm + lm_head in fp32 with the fp32 master weights ($TF/models/wav2vec2/modeling_wav2vec2.py:791,1700,1717) -
+    # does that remove the per-utterance CTC error?  (plain torch on the GPU: a measurement, not a product path)
+    Bq, Tq, Vq = out.logits.shape
+    hL = eng._saved["w"]["h"][cfg.num_hidden_layers].float().view(Bq, Tq, -1)
+    ln32 = torch.nn.functional.layer_norm(hL, (hL.shape[-1],), P["wav2vec2.encoder.layer_norm.weight"].to(DEV).float(),
+                                          P["wav2vec2.encoder.layer_norm.bias"].to(DEV).float(), cfg.layer_norm_eps)
+    lg32 = ln32 @ P["lm_head.weight"].to(DEV).float().t() + P["lm_head.bias"].to(DEV).float()
+    flen = eng._saved["flen"].long().cpu()
+    lab_c = batch["labels"].long().cpu()
+    tl = (lab_c >= 0).sum(-1)
+    nll_head32 = torch.nn.functional.ctc_loss(lg32.log_softmax(-1).transpose(0, 1).cpu(), lab_c.clamp(min=0), flen, tl,
+                                              blank=cfg.pad_token_id, reduction="none", zero_infinity=False)
+    del eng, hL, ln32, lg32
     torch.cuda.empty_cache()
     t1 = time.time()
     iv, am, lab = batch["input_values"].float().cpu(), batch["attention_mask"].long().cpu(), batch["labels"].long().cpu()
@@ -189,9 +202,52 @@ def test_xlsr2b_bench_batch_ctc_loss_against_the_oracle():
     print(f"\nXLS-R-2B on the bench batch (8 x 10 s): batch CTC loss {loss:.3f} vs {float(nll_ref.sum()):.3f} (rel {rel:.2e}); "
           "per utterance " + ", ".join(f"{x:.2e}" for x in per) + f"; logits max-abs err {err:.4f}, cosine "
           f"{_cos(logits, logits_ref):.6f}; oracle forward {t_ref:.0f} s")
+    per32 = [abs(float(a) - float(b)) / float(b) for a, b in zip(nll_head32, nll_ref)]
+    rel32 = abs(float(nll_head32.sum()) - float(nll_ref.sum())) / float(nll_ref.sum())
+    print("  the same hidden state through an fp32 final LayerNorm + lm_head: per utterance " + ", ".join(f"{x:.2e}" for x in per32) +
+          f"; batch {rel32:.2e}")
     assert rel <= 1e-3, rel
     assert max(per) <= 4e-3, per
     assert err <= 8e-2 and _cos(logits, logits_ref) >= 0.999
+
+
+@pytest.mark.parametrize("model", ["wav2vec2-medium", "wav2vec2-small"])
+def test_eight_utterance_batch_ctc_loss_against_the_oracle_at_the_other_model_keys(model):
+    """The north star's 1e-3 on the BATCH CTC loss at CoRal's other two model keys - XLS-R-1B (48 layers, d 1280) and
+    XLS-R-300M (24 layers, d 1024) - on the same kind of batch as configs[1]'s (8 x 10 s, `bench.synth_batch`): the bound is
+    a property of eight utterances averaging their per-utterance offsets, not of the 2B shape (round 5's four-utterance
+    XLS-R-1B batch sits at 1.3e-3).  Forward only, fp32 oracle on the host cores."""
+    import sys
+    from pathlib import Path
+
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+    import bench
+    from coral_amd.wav2vec2 import CORAL_W2V2_SHAPES, Wav2Vec2CTCEngine, Wav2Vec2Shape
+    from oracle import wav2vec2_ref as ref
+
+    cfg = ref.W2V2Config(**ref.CORAL_SHAPES[model])
+    P = ref.synth_params(cfg)
+    batch, lens = bench.synth_batch(8, 10.0, 0, DEV)
+    eng = Wav2Vec2CTCEngine(Wav2Vec2Shape(**CORAL_W2V2_SHAPES[model]), DEV)
+    eng.load_state_dict(P)
+    out = eng(batch["input_values"], batch["attention_mask"], batch["labels"])
+    torch.cuda.synchronize()
+    nll, loss = out["nll"].float().cpu(), float(out.loss)
+    del eng
+    torch.cuda.empty_cache()
+    iv, am, lab = batch["input_values"].float().cpu(), batch["attention_mask"].long().cpu(), batch["labels"].long().cpu()
+    t1 = time.time()
+    nll_ref = []
+    with torch.no_grad():
+        for b0 in range(0, 8, 2):
+            nll_ref.append(ref.forward_loss(iv[b0:b0 + 2], am[b0:b0 + 2], lab[b0:b0 + 2], P, cfg)[2])
+    nll_ref = torch.cat(nll_ref)
+    per = [abs(float(a) - float(b)) / float(b) for a, b in zip(nll, nll_ref)]
+    rel = abs(loss - float(nll_ref.sum())) / float(nll_ref.sum())
+    print(f"\n{model} on 8 x 10 s: batch CTC loss {loss:.3f} vs {float(nll_ref.sum()):.3f} (rel {rel:.2e}); per utterance "
+          + ", ".join(f"{x:.2e}" for x in per) + f"; oracle forward {time.time() - t1:.0f} s")
+    assert rel <= 1e-3, rel
+    assert max(per) <= 5e-3, per
 
 
 def test_xlsr1b_batch_of_four_ctc_loss_against_the_oracle():
