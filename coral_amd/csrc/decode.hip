@@ -625,10 +625,14 @@ __device__ __forceinline__ void dk_project(const DecArgs& a, const DkEnt& ent, i
     if (wide) {
 #pragma unroll
       for (int s = PD; s < PF; ++s) af[s] = __builtin_bit_cast(bf16x8_t, dk_ld16_sc1(ap + s * 32));
+      // (K = f: the MFMAs of a quarter of the k-steps start when ITS rows have landed - loads complete in order, whatever
+      // this wave issued before them is older - while the later quarters are still on their way)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PD <= 63 ? 3 * PD : 63) : "memory");
+    } else {
+      dk_vm0();  // the activation rows have landed
     }
-    dk_vm0();  // the activation rows have landed
 #pragma unroll
-    for (int s = 0; s < PF; ++s) dk_tie(af[s]);
+    for (int s = 0; s < PD; ++s) dk_tie(af[s]);
   } else {
     const unsigned short* xp = xs + (int64_t)r * (K + DK_XPAD) + ks0 * 32 + 8 * g;
 #pragma unroll
@@ -651,6 +655,13 @@ __device__ __forceinline__ void dk_project(const DecArgs& a, const DkEnt& ent, i
         bf16x8_t wf[PD];
 #pragma unroll
         for (int s = 0; s < PD; ++s) wf[s] = dk_wfrag(ring, wfs, b * PD + s);
+        if (!ln && t16 == 0) {
+          if (b == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PD <= 63 ? 2 * PD : 63) : "memory");
+          if (b == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PD) : "memory");
+          if (b == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+          for (int s = 0; s < PD; ++s) dk_tie(af[b * PD + s]);
+        }
 #pragma unroll
         for (int s = 0; s < PD; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s], af[b * PD + s], acc, 0, 0, 0);
       }
