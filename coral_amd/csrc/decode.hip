@@ -1368,7 +1368,7 @@ extern "C" int ca_whisper_decode_token(const CaDecodeDesc* desc, void* stream) {
     attr = true;
   }
   // every polled word starts at zero (a memset node when the step is captured in a graph)
-  if (hipMemsetAsync(c.ws, 0, zero_bytes, s) != hipSuccess || hipMemsetAsync(c.status, 0, 16, s) != hipSuccess) {
+  if (hipMemsetAsync(c.ws, 0, zero_bytes, s) != hipSuccess) {
     ca_set_error("ca_whisper_decode_token: hipMemsetAsync failed");
     return CA_ERR_LAUNCH;
   }
