@@ -1969,6 +1969,18 @@ static unsigned smallq_two_per_cu() {
   }();
   return thr;
 }
+// How many workgroups share one (clip, head)'s keys: CUs / (clips x heads), at most CA_ATTN_SPLIT_MAX (8 clips x 16 heads on
+// 256 CUs: 2; 1 clip: 4; 16 x 16: 1).  ONE rule for ca_attn_fwd, ca_decode_attn_qproj and ca_whisper_decode_token
+// (decode.hip): the merge order, and so the bits, are the same.  (Round 6, measured and dropped: splitting also where clips
+// x heads exceeds the CUs so that the rounds come out even - whisper-large at 16 clips, 320 items -> 1280 quarter-items -
+// took the persistent token from 3.04 to 3.17 ms and the launch sequence from 4.5 to 6.3: every part pays the prologue,
+// the barriers and the merge.)
+int ca_attn_key_split(int bh, int ncu, int cap) {
+  int ns = ncu / bh;
+  ns = ns > CA_ATTN_SPLIT_MAX ? CA_ATTN_SPLIT_MAX : ns;
+  ns = ns > cap ? cap : ns;
+  return ns < 2 ? 1 : ns;
+}
 static int smallq_split(const CaAttnDesc& d, AttnArgs& a, unsigned& grid) {
   const int bh = d.B * d.H;
   grid = (unsigned)bh;
@@ -1980,9 +1992,7 @@ static int smallq_split(const CaAttnDesc& d, AttnArgs& a, unsigned& grid) {
     return n > 0 ? n : 256;
   }();
   static const int cap = [] { const char* e = getenv("CA_ATTN_SPLIT"); return e ? atoi(e) : CA_ATTN_SPLIT_MAX; }();
-  int ns = ncu / bh;
-  ns = ns > CA_ATTN_SPLIT_MAX ? CA_ATTN_SPLIT_MAX : ns;
-  ns = ns > cap ? cap : ns;
+  const int ns = ca_attn_key_split(bh, ncu, cap);
   if (ns < 2) return CA_OK;
   CA_CHECK_ARG(d.split_ws_bytes >= CA_ATTN_SPLIT_WS_BYTES(d.B, d.H) && ((uintptr_t)d.split_ws % 16) == 0,
                "attention: split_ws needs CA_ATTN_SPLIT_WS_BYTES(B, H) bytes, 16-byte aligned");

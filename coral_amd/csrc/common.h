@@ -176,3 +176,6 @@ __device__ __forceinline__ unsigned int ca_dropout_keep4_lo(unsigned int s_eff, 
 // out[i] (+)= sum_p partial[p*stride + i]  (defined in norm.hip)
 void ca_reduce_partials_launch(const float* partial, int nparts, int64_t stride, int n, float* out,
                                int accumulate, hipStream_t s);
+
+// key split of the single-query attention forms (defined in attention.hip; shared with decode.hip)
+int ca_attn_key_split(int bh, int ncu, int cap);

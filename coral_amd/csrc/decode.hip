@@ -1317,11 +1317,8 @@ extern "C" int ca_whisper_decode_token(const CaDecodeDesc* desc, void* stream) {
   // key split of the cross-attention: ca_attn_fwd's rule (smallq_split), so the merge order - and the bits - are its
   int ns = 1;
   if (c.Te >= 1024) {
-    ns = G / (c.B * c.H);
     static const int cap = [] { const char* e = getenv("CA_ATTN_SPLIT"); return e ? atoi(e) : CA_ATTN_SPLIT_MAX; }();
-    ns = ns > CA_ATTN_SPLIT_MAX ? CA_ATTN_SPLIT_MAX : ns;
-    ns = ns > cap ? cap : ns;
-    ns = ns < 2 ? 1 : ns;
+    ns = ca_attn_key_split(c.B * c.H, G, cap);
   }
   a.ns = ns;
   a.embed = (const unsigned short*)c.embed; a.pos_tab = (const unsigned short*)c.embed_pos;
