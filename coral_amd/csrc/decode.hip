@@ -550,8 +550,16 @@ __device__ __forceinline__ void dk_ln_rows(const DecArgs& a, const unsigned shor
       }
     }
   }
-  // the four rows of a wave side by side (independent reduction chains overlap their latencies); per row the arithmetic
-  // and its order are ln_fwd_kernel's (dk_sq_acc / dk_ln_apply: with the fusions written out)
+  // the rows of a wave side by side (independent reduction chains overlap their latencies); per row the arithmetic and its
+  // order are ln_fwd_kernel's (dk_sq_acc / dk_ln_apply: with the fusions written out).  The rows as fp32 once, for the
+  // three passes.
+  float xf[NR][NC][8];
+#pragma unroll
+  for (int i = 0; i < NR; ++i)
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) xf[i][c][e] = bf2f(raw[i][c][e]);
   float sx[NR], mean[NR], s2[NR], rstd[NR];
 #pragma unroll
   for (int i = 0; i < NR; ++i) {
@@ -560,7 +568,7 @@ __device__ __forceinline__ void dk_ln_rows(const DecArgs& a, const unsigned shor
     for (int c = 0; c < NC; ++c) {
       if (NCX || c < NC - 1 || lane + c * 64 < nchunk) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) sx[i] += bf2f(raw[i][c][e]);
+        for (int e = 0; e < 8; ++e) sx[i] += xf[i][c][e];
       }
     }
   }
@@ -574,7 +582,7 @@ __device__ __forceinline__ void dk_ln_rows(const DecArgs& a, const unsigned shor
     for (int c = 0; c < NC; ++c) {
       if (NCX || c < NC - 1 || lane + c * 64 < nchunk) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) s2[i] = dk_sq_acc(s2[i], bf2f(raw[i][c][e]), mean[i]);
+        for (int e = 0; e < 8; ++e) s2[i] = dk_sq_acc(s2[i], xf[i][c][e], mean[i]);
       }
     }
   }
@@ -592,7 +600,7 @@ __device__ __forceinline__ void dk_ln_rows(const DecArgs& a, const unsigned shor
           u16x8_t o8;
 #pragma unroll
           for (int e = 0; e < 8; ++e)
-            o8[e] = f2bf(dk_ln_apply(bf2f(raw[i][c][e]), mean[i], rstd[i], e < 4 ? gq[c][0][e] : gq[c][1][e - 4],
+            o8[e] = f2bf(dk_ln_apply(xf[i][c][e], mean[i], rstd[i], e < 4 ? gq[c][0][e] : gq[c][1][e - 4],
                                      e < 4 ? bq[c][0][e] : bq[c][1][e - 4]));
           *(u16x8_t*)(xs + (int64_t)lrow * xpitch + ch * 8) = o8;
         }
