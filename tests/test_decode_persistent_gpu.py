@@ -91,3 +91,41 @@ def test_the_persistent_step_is_what_generate_runs_up_to_16_clips_and_larger_bat
     eng, shape, waves = _engine("whisper-xxsmall", 17)
     eng.generate(eng.log_mel(waves), PREFIX, 12)
     assert not calls
+
+
+def test_a_launch_that_cannot_have_every_cu_comes_back_and_says_so():
+    """16 idle workgroups holding 96 KiB of LDS each (ca_debug_cu_hog on a side stream, a chain of 2-s holds) sit on 16 CUs
+    while the persistent launch starts: its spins are bounded, so it comes back - either having given up (status word set,
+    NO token written, nothing advanced) or, if the CUs came free in a gap of the chain, having decoded normally.  With the
+    chip free again the same state decodes."""
+    import time
+
+    from coral_amd import ops
+
+    B = 8
+    eng, shape, waves = _engine("whisper-xxsmall", B)
+    kv = eng.cross_kv(eng.encode(eng.log_mel(waves)))
+    sup = torch.zeros(shape.vocab_size, dtype=torch.uint8, device=DEV)
+    cache, g = _state(eng, shape, kv, B, 4 + 40, sup)
+    ps = eng._persistent_state(cache, g, sup)
+    ops.whisper_decode_token(ps["desc"])
+    torch.cuda.synchronize()
+    assert ps["status"].tolist() == [0, 0, 0, 0] and g["pos"].tolist() == [5] * B
+    side = torch.cuda.Stream()
+    for _ in range(3):
+        ops.check(ops.lib().ca_debug_cu_hog(16, 256, 96 * 1024, 2000.0, side.cuda_stream), "ca_debug_cu_hog")
+    time.sleep(0.2)
+    t0 = time.time()
+    ops.whisper_decode_token(ps["desc"])
+    torch.cuda.current_stream().synchronize()
+    dt = time.time() - t0
+    code, pos = int(ps["status"][0]), g["pos"].tolist()
+    print(f"\n16 CUs held: the launch came back after {dt:.2f} s with status {code}, pos {pos[:2]}")
+    assert dt < 30.0
+    assert (code != 0 and pos == [5] * B) or (code == 0 and pos == [6] * B)
+    side.synchronize()
+    gave_up = code != 0
+    ps["status"].zero_()
+    ops.whisper_decode_token(ps["desc"])
+    torch.cuda.synchronize()
+    assert ps["status"].tolist() == [0, 0, 0, 0] and g["pos"].tolist() == [6 if gave_up else 7] * B
