@@ -717,9 +717,19 @@ def main():
         # The headline (BASELINE's all-reduce configuration) is measured: the secondary run must not be able to lose it.
         # An exception in it becomes an `error` field; if it hangs (a rank-local failure inside a collective), rank 0
         # prints the line it has after CA_BENCH_ZERO2_TIMEOUT seconds (default 300) and leaves.
+        emit_lock = threading.Lock()  # the headline line goes out ONCE: from the watchdog or from the main thread
+        emitted = [False]
+
         def _emit_without_zero2():
-            out["config"]["also_zero2"] = {"error": "the zero_stage 2 run did not finish in time; headline unaffected"}
-            print(json.dumps(out), flush=True)
+            with emit_lock:
+                if emitted[0]:
+                    return
+                emitted[0] = True
+                out["config"]["also_zero2"] = {"error": "the zero_stage 2 run did not finish in time; headline unaffected"}
+                print(json.dumps(out), flush=True)
+            # The peers are blocked inside a collective: nothing orderly is left to do in this process.  Exit code 0 - the
+            # measured headline is valid and the line says what did not finish (`also_zero2.error`); the launcher tears
+            # the other ranks down when rank 0 leaves.
             os._exit(0)
 
         watchdog = None
@@ -755,7 +765,14 @@ def main():
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out), flush=True)
+        lock = locals().get("emit_lock")
+        if lock is None:
+            print(json.dumps(out), flush=True)
+        else:
+            with lock:
+                if not emitted[0]:
+                    emitted[0] = True
+                    print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

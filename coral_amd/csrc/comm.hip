@@ -158,10 +158,15 @@ extern "C" int ca_comm_destroy(CaComm* c) {
 // kernel would spin for ever; ncclCommAbort ends it).  The rendezvous fallback of the host side uses it.
 extern "C" int ca_comm_abort(CaComm* c) {
   if (!c) return CA_OK;
-  if (g_rccl.CommAbort)
-    g_rccl.CommAbort(c->comm);
-  else if (g_rccl.CommDestroy)
-    g_rccl.CommDestroy(c->comm);
+  if (!g_rccl.CommAbort) {
+    // Without ncclCommAbort nothing can end a collective kernel whose peers never joined: destroying the communicator
+    // or synchronising its stream would block for ever - the very case this call exists for.  The context (communicator,
+    // stream, event) is leaked instead, and the caller is told.
+    ca_set_error("ca_comm_abort: librccl has no ncclCommAbort; the context is left behind (not destroyed, not waited for)");
+    fprintf(stderr, "coral_amd: ca_comm_abort: librccl has no ncclCommAbort; leaking the communicator context\n");
+    return CA_ERR_UNSUPPORTED;
+  }
+  g_rccl.CommAbort(c->comm);
   hipStreamSynchronize(c->stream);  // (the aborted kernels have left the stream)
   hipEventDestroy(c->ev);
   hipStreamDestroy(c->stream);

@@ -90,10 +90,10 @@ class CommContext:
             (self.lib.ca_comm_abort if abort else self.lib.ca_comm_destroy)(ctx)
 
     def __del__(self):
-        try:
-            self.close()
-        except Exception:  # noqa: BLE001  (interpreter shutdown: the library may be gone)
-            pass
+        # Not `close()`: ca_comm_destroy waits for the context's stream, and a garbage-collected context (or one collected
+        # at interpreter shutdown) may still have a collective in flight whose peers are gone - that wait would never end.
+        # An owner that is done with a context calls close(); a context that is merely dropped is left to the process's end.
+        self.ctx = None
 
     @staticmethod
     def _dt(t):
