@@ -625,28 +625,29 @@ __device__ __forceinline__ void dk_project(const DecArgs& a, const DkEnt& ent, i
   const bool wide = K > 128 * PD;
   const int ks0 = wave * (wide ? PF : PD);
   const int groups = (ent.nc + 3) >> 2;
-  bf16x8_t af[PF];
+  // the activation fragments of the wave's K quarter, PD k-steps at a time (K = f: four batches, the next one's loads
+  // in flight under the current one's MFMAs - loads complete in order, so vmcnt(PD) says the older batch has landed;
+  // 2 x PD fragments of registers instead of 4 x PD)
+  bf16x8_t af[2][PD];
+  const unsigned short* ap = Ag + (int64_t)(r < a.B ? r : a.B - 1) * K + ks0 * 32 + 8 * g;  // (rows beyond B: a copy, dropped)
+  const unsigned short* xp = xs + (int64_t)r * (K + DK_XPAD) + ks0 * 32 + 8 * g;
   if (!ln) {
-    const unsigned short* ap = Ag + (int64_t)(r < a.B ? r : a.B - 1) * K + ks0 * 32 + 8 * g;  // (rows beyond B: a copy, dropped)
 #pragma unroll
-    for (int s = 0; s < PD; ++s) af[s] = __builtin_bit_cast(bf16x8_t, dk_ld16_sc1(ap + s * 32));
+    for (int s = 0; s < PD; ++s) af[0][s] = __builtin_bit_cast(bf16x8_t, dk_ld16_sc1(ap + s * 32));
     if (wide) {
 #pragma unroll
-      for (int s = PD; s < PF; ++s) af[s] = __builtin_bit_cast(bf16x8_t, dk_ld16_sc1(ap + s * 32));
-      // (K = f: the MFMAs of a quarter of the k-steps start when ITS rows have landed - loads complete in order, whatever
-      // this wave issued before them is older - while the later quarters are still on their way)
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PD <= 63 ? 3 * PD : 63) : "memory");
+      for (int s = 0; s < PD; ++s) af[1][s] = __builtin_bit_cast(bf16x8_t, dk_ld16_sc1(ap + (PD + s) * 32));
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PD) : "memory");
     } else {
       dk_vm0();  // the activation rows have landed
     }
 #pragma unroll
-    for (int s = 0; s < PD; ++s) dk_tie(af[s]);
+    for (int s = 0; s < PD; ++s) dk_tie(af[0][s]);
   } else {
-    const unsigned short* xp = xs + (int64_t)r * (K + DK_XPAD) + ks0 * 32 + 8 * g;
 #pragma unroll
-    for (int s = 0; s < PD; ++s) af[s] = *(const bf16x8_t*)(xp + s * 32);
+    for (int s = 0; s < PD; ++s) af[0][s] = *(const bf16x8_t*)(xp + s * 32);
   }
-  const int ntile = (ent.nc + 15) >> 4;
+  const int ntile = (ent.nc + 15) >> 4;  // (two tiles only where N / CUs > 16: fc1 of whisper-large; K = d there)
   for (int t16 = 0; t16 < ntile; ++t16) {
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
     const DkWf wfs = dk_wfrag_setup(start, groups, nquads, t16, lane);
@@ -655,23 +656,26 @@ __device__ __forceinline__ void dk_project(const DecArgs& a, const DkEnt& ent, i
 #pragma unroll
       for (int s = 0; s < PD; ++s) wf[s] = dk_wfrag(ring, wfs, s);
 #pragma unroll
-      for (int s = 0; s < PD; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s], af[s], acc, 0, 0, 0);
+      for (int s = 0; s < PD; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s], af[0][s], acc, 0, 0, 0);
     }
-    if (wide) {
+    if (wide) {  // (non-LayerNorm, one tile: fc2)
 #pragma unroll
       for (int b = 1; b < 4; ++b) {
         bf16x8_t wf[PD];
 #pragma unroll
         for (int s = 0; s < PD; ++s) wf[s] = dk_wfrag(ring, wfs, b * PD + s);
-        if (!ln && t16 == 0) {
-          if (b == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PD <= 63 ? 2 * PD : 63) : "memory");
-          if (b == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PD) : "memory");
-          if (b == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // batch b sits in af[b & 1]; batch b + 1 goes where batch b - 1 was
+        if (b < 3) {
 #pragma unroll
-          for (int s = 0; s < PD; ++s) dk_tie(af[b * PD + s]);
+          for (int s = 0; s < PD; ++s) af[(b + 1) & 1][s] = __builtin_bit_cast(bf16x8_t, dk_ld16_sc1(ap + ((b + 1) * PD + s) * 32));
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PD) : "memory");
+        } else {
+          dk_vm0();
         }
 #pragma unroll
-        for (int s = 0; s < PD; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s], af[b * PD + s], acc, 0, 0, 0);
+        for (int s = 0; s < PD; ++s) dk_tie(af[b & 1][s]);
+#pragma unroll
+        for (int s = 0; s < PD; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s], af[b & 1][s], acc, 0, 0, 0);
       }
     }
     if (t16) __syncthreads();  // (wave 0 has read the previous tile's partials)
