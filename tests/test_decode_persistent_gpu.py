@@ -129,3 +129,31 @@ def test_a_launch_that_cannot_have_every_cu_comes_back_and_says_so():
     ops.whisper_decode_token(ps["desc"])
     torch.cuda.synchronize()
     assert ps["status"].tolist() == [0, 0, 0, 0] and g["pos"].tolist() == [6 if gave_up else 7] * B
+
+
+def test_finished_rows_take_pad_in_both_paths():
+    """The bookkeeping of finished rows (ca_argmax_advance: a finished row records pad, eos sets `done`): with everything
+    but eos suppressed every row finishes at the first step; the following steps must record pad, keep `done`, and leave
+    the two paths' state identical."""
+    from coral_amd import ops
+
+    B = 5
+    eng, shape, waves = _engine("whisper-xxsmall", B)
+    kv = eng.cross_kv(eng.encode(eng.log_mel(waves)))
+    V = shape.vocab_size
+    sup = torch.ones(V, dtype=torch.uint8, device=DEV)
+    sup[shape.eos_token_id] = 0
+    free = torch.zeros(V, dtype=torch.uint8, device=DEV)
+    ca, ga = _state(eng, shape, kv, B, 4 + 12, free)
+    cb, gb = _state(eng, shape, kv, B, 4 + 12, free)
+    ps = eng._persistent_state(cb, gb, sup)
+    for t in range(4):
+        eng._token_step_launches(ca, ga, sup)
+        ops.whisper_decode_token(ps["desc"])
+        torch.cuda.synchronize()
+        assert ps["status"].tolist() == [0, 0, 0, 0]
+        for k in ("nxt", "tok", "pos", "klen", "done", "out"):
+            assert torch.equal(ga[k], gb[k]), f"{k} differs at token {t}"
+    assert bool(gb["done"].all())
+    out = gb["out"][:, 5:9].tolist()
+    assert all(row[0] == shape.eos_token_id and row[1:] == [shape.pad_token_id] * 3 for row in out), out
