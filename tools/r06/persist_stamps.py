@@ -1,6 +1,7 @@
 """Round 6: where a persistent decode launch spends its time - per phase, the time from the previous phase's end to the
 seam being passed (wait) and from there to the phase's end (work), median / max over workgroups, summed per phase kind.
 usage: python tools/r06/persist_stamps.py [model] [batch]"""
+import os
 import sys
 from pathlib import Path
 
@@ -49,6 +50,9 @@ ops.whisper_decode_token(ps["desc"])
 torch.cuda.synchronize()
 ops.lib().ca_debug_decode_stamps(None, 0)
 t = buf.view(G, nst).cpu().double()
+if os.environ.get("STAMP_WG"):  # one workgroup's view (small batches: workgroups without an item skip phases, their stamp
+    t = t[int(os.environ["STAMP_WG"]):int(os.environ["STAMP_WG"]) + 1]  # sequences do not line up with the others')
+    G = 1
 # calibrate ticks -> us with the event-timed launch
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
