@@ -317,6 +317,7 @@ struct AttnArgs {
   // small-query kernel only: the keys of one (clip, head) dealt to nsplit workgroups (CaAttnDesc.split_ws): partial
   // (max, normaliser, unnormalised output) slabs + one arrival counter per (clip, head); nsplit <= 1 = off
   int nsplit;
+  CaKeySplit split;         // (nsplit > 1: how the grid's workgroups map to (clip, head) and part)
   float* split_slab;        // [B * H][nsplit][16][SPLIT_ROW]
   unsigned int* split_cnt;  // [B * H], zero between launches
   // greedy decoding with the query projection inside the kernel (attn_fwd_smallq_kernel<.., true>, ca_decode_attn_qproj):
@@ -871,8 +872,8 @@ __global__ __launch_bounds__(256) void attn_fwd_smallq_kernel(const AttnArgs a) 
   // 256 CUs) half the chip would idle while each workgroup streams its 384 KB of cross-attention K|V at what ONE CU takes
   // in.  The tiles are dealt to 4 x nsplit "waves"; each workgroup leaves its (m, l, O) partial in a slab and the last
   // one to arrive (one counter per clip and head; release / acquire at agent scope around it) merges them in slab order.
-  const int ns = a.nsplit > 1 ? a.nsplit : 1;
-  const int bh = blockIdx.x / ns, sp = blockIdx.x - bh * ns;
+  int ns = 1, bh = blockIdx.x, sp = 0, part0 = blockIdx.x;
+  if (a.nsplit > 1) ca_key_split_item(a.split, blockIdx.x, bh, sp, ns, part0);
   const int h = bh % a.H, b = bh / a.H;
   const int vw = sp * 4 + wave, nvw = 4 * ns;  // this wave's place among the waves that share the keys
   const int hd = a.hd;
@@ -1149,7 +1150,7 @@ __global__ __launch_bounds__(256) void attn_fwd_smallq_kernel(const AttnArgs a) 
   unsigned short* O = a.O + b * a.sob + h * hd;
   if (ns > 1) {
     // this workgroup's partial: per query (m, l) and the unnormalised output row
-    float* slab = a.split_slab + ((int64_t)bh * ns + sp) * (16 * SPLIT_ROW);
+    float* slab = a.split_slab + ((int64_t)part0 + sp) * (16 * SPLIT_ROW);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int q = 4 * g + e;
@@ -1187,7 +1188,7 @@ __global__ __launch_bounds__(256) void attn_fwd_smallq_kernel(const AttnArgs a) 
     if (ticket != (unsigned)(ns - 1)) return;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const float* base = a.split_slab + (int64_t)bh * ns * (16 * SPLIT_ROW);
+    const float* base = a.split_slab + (int64_t)part0 * (16 * SPLIT_ROW);
     // lane = output column; every slab value of a query is asked for before the first is used (one round trip per
     // query - a decoded token has one query per clip - instead of one per slab and value)
     for (int q = 0; q < a.Tq; ++q) {
@@ -1971,15 +1972,33 @@ static unsigned smallq_two_per_cu() {
 }
 // How many workgroups share one (clip, head)'s keys: CUs / (clips x heads), at most CA_ATTN_SPLIT_MAX (8 clips x 16 heads on
 // 256 CUs: 2; 1 clip: 4; 16 x 16: 1).  ONE rule for ca_attn_fwd, ca_decode_attn_qproj and ca_whisper_decode_token
-// (decode.hip): the merge order, and so the bits, are the same.  (Round 6, measured and dropped: splitting also where clips
-// x heads exceeds the CUs so that the rounds come out even - whisper-large at 16 clips, 320 items -> 1280 quarter-items -
-// took the persistent token from 3.04 to 3.17 ms and the launch sequence from 4.5 to 6.3: every part pays the prologue,
-// the barriers and the merge.)
-int ca_attn_key_split(int bh, int ncu, int cap) {
-  int ns = ncu / bh;
-  ns = ns > CA_ATTN_SPLIT_MAX ? CA_ATTN_SPLIT_MAX : ns;
-  ns = ns > cap ? cap : ns;
-  return ns < 2 ? 1 : ns;
+// (decode.hip): the merge order, and so the bits, are the same.  (Round 6, measured and dropped: splitting EVERY item where
+// clips x heads exceeds the CUs so that the rounds come out even - whisper-large at 16 clips, 320 items -> 1280
+// quarter-items - took the persistent token from 3.04 to 3.17 ms and the launch sequence from 4.5 to 6.3: every part pays
+// the prologue, the barriers and the merge.)
+// More items than CUs, fewer than two rounds of them (whisper-large at 16 clips: 320 on 256): the items of the second,
+// partly filled round - and only they - are split so that their parts fill it: 64 items x 4 parts, a quarter of the keys
+// each, beside 256 whole items.  Same box, per token: persistent launch 2.97 -> 2.74 ms, launch sequence 4.48 -> 4.02
+// (NOTEBOOK R6.5); CA_ATTN_SPLIT_TAIL=0 keeps whole items.
+CaKeySplit ca_attn_key_split(int bh, int ncu, int cap) {
+  cap = cap > CA_ATTN_SPLIT_MAX ? CA_ATTN_SPLIT_MAX : cap;
+  CaKeySplit s;
+  s.ns = 1; s.tail_start = bh; s.ns_tail = 1;
+  static const int tail_on = [] { const char* e = getenv("CA_ATTN_SPLIT_TAIL"); return e ? atoi(e) : 1; }();
+  if (bh <= ncu) {
+    int ns = ncu / bh;
+    ns = ns > cap ? cap : ns;
+    s.ns = ns < 2 ? 1 : ns;
+  } else if (bh < 2 * ncu && tail_on) {
+    const int t = bh - ncu;
+    int nt = ncu / t;
+    nt = nt > cap ? cap : nt;
+    if (nt >= 2) {
+      s.tail_start = ncu;
+      s.ns_tail = nt;
+    }
+  }
+  return s;
 }
 static int smallq_split(const CaAttnDesc& d, AttnArgs& a, unsigned& grid) {
   const int bh = d.B * d.H;
@@ -1992,14 +2011,15 @@ static int smallq_split(const CaAttnDesc& d, AttnArgs& a, unsigned& grid) {
     return n > 0 ? n : 256;
   }();
   static const int cap = [] { const char* e = getenv("CA_ATTN_SPLIT"); return e ? atoi(e) : CA_ATTN_SPLIT_MAX; }();
-  const int ns = ca_attn_key_split(bh, ncu, cap);
-  if (ns < 2) return CA_OK;
+  const CaKeySplit sp = ca_attn_key_split(bh, ncu, cap);
+  if (sp.ns < 2 && sp.ns_tail < 2) return CA_OK;
   CA_CHECK_ARG(d.split_ws_bytes >= CA_ATTN_SPLIT_WS_BYTES(d.B, d.H) && ((uintptr_t)d.split_ws % 16) == 0,
                "attention: split_ws needs CA_ATTN_SPLIT_WS_BYTES(B, H) bytes, 16-byte aligned");
-  a.nsplit = ns;
+  a.nsplit = sp.ns > sp.ns_tail ? sp.ns : sp.ns_tail;
+  a.split = sp;
   a.split_cnt = (unsigned int*)d.split_ws;
   a.split_slab = (float*)((char*)d.split_ws + ((size_t)bh * 4 + 255) / 256 * 256);
-  grid = (unsigned)(bh * ns);
+  grid = (unsigned)ca_key_split_parts(sp, bh);
   return CA_OK;
 }
 

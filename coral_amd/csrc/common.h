@@ -177,5 +177,28 @@ __device__ __forceinline__ unsigned int ca_dropout_keep4_lo(unsigned int s_eff, 
 void ca_reduce_partials_launch(const float* partial, int nparts, int64_t stride, int n, float* out,
                                int accumulate, hipStream_t s);
 
-// key split of the single-query attention forms (defined in attention.hip; shared with decode.hip)
-int ca_attn_key_split(int bh, int ncu, int cap);
+// Key split of the single-query attention forms (rule in attention.hip; shared with decode.hip): the keys of (clip, head)
+// item i go to `ns` workgroups for i < tail_start and to `ns_tail` for the others.  Parts of an item are consecutive
+// sub-items; sub-items are numbered items-first.
+struct CaKeySplit {
+  int ns, tail_start, ns_tail;
+};
+CaKeySplit ca_attn_key_split(int bh, int ncu, int cap);
+__host__ __device__ __forceinline__ int ca_key_split_parts(const CaKeySplit& s, int bh) {
+  return s.tail_start * s.ns + (bh - s.tail_start) * s.ns_tail;
+}
+// sub-item `it` -> its item, its place among the item's n parts, the item's first sub-item
+__device__ __forceinline__ void ca_key_split_item(const CaKeySplit& s, int it, int& bh, int& sp, int& n, int& part0) {
+  const int head = s.tail_start * s.ns;
+  if (it < head) {
+    n = s.ns;
+    bh = it / n;
+    part0 = bh * n;
+  } else {
+    n = s.ns_tail;
+    const int t = (it - head) / n;
+    bh = s.tail_start + t;
+    part0 = head + t * n;
+  }
+  sp = it - part0;
+}

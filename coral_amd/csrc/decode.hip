@@ -61,7 +61,8 @@ enum { LY_LN1G, LY_LN1B, LY_WQKV, LY_BQKV, LY_WO, LY_BO, LY_LN2G, LY_LN2B, LY_WQ
 static_assert(sizeof(CaDecodeLayer) == LY_WORDS * 8, "CaDecodeLayer is 20 pointers");
 struct DecArgs {
   const CaDecodeLayer* layers;
-  int n_layers, B, d, f, H, Te, Lmax, V, ns;
+  int n_layers, B, d, f, H, Te, Lmax, V;
+  CaKeySplit split;  // of the cross-attention's (clip, head) items
   const unsigned short *embed, *pos_tab;
   const float *lnf_g, *lnf_b;
   float eps, scale;
@@ -1069,7 +1070,7 @@ __global__ __launch_bounds__(256) void whisper_decode_token_kernel(const DecArgs
     if (!head && (p == 1 || p == 4)) {
       // ---- attention: B (self, over this layer's cache) or E (over the cached encoder K|V) ----------------------------------------
       const bool cross = p == 4;
-      const int ns = cross ? a.ns : 1, nit = B * H * ns;
+      const int nit = cross ? ca_key_split_parts(a.split, B * H) : B * H;
       if (w >= nit && wave != 0) dk_wait_vm(rg.cur_e < rg.batch_first ? rg.batch_issued : 0);
       if (w < nit) {
         const unsigned short* kvbase = dk_lyp<const unsigned short*>(ltab, l, cross ? LY_CROSSKV : LY_SELFKV);
@@ -1087,7 +1088,8 @@ __global__ __launch_bounds__(256) void whisper_decode_token_kernel(const DecArgs
           }
         }
         for (int it = w; it < nit; it += G) {
-          const int bh = it / ns, sp = it - bh * ns;
+          int bh = it, sp = 0, ns = 1, part0 = it;
+          if (cross) ca_key_split_item(a.split, it, bh, sp, ns, part0);
           const int b = bh / H, h = bh - b * H;
           int kl = Tk;
           if (!cross) {
@@ -1113,7 +1115,7 @@ __global__ __launch_bounds__(256) void whisper_decode_token_kernel(const DecArgs
             if (lane == 0)
               ticket = __hip_atomic_fetch_add(a.split_cnt + (int64_t)l * 16 * H + bh, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             ticket = __builtin_amdgcn_readfirstlane(ticket);
-            if (ticket == (unsigned)(ns - 1)) dk_merge_split(a.slab + (int64_t)bh * ns * DK_SPLIT_ROW, ns, O, lane);
+            if (ticket == (unsigned)(ns - 1)) dk_merge_split(a.slab + (int64_t)part0 * DK_SPLIT_ROW, ns, O, lane);
           }
         }
       }
@@ -1327,12 +1329,11 @@ extern "C" int ca_whisper_decode_token(const CaDecodeDesc* desc, void* stream) {
   a.layers = c.layers; a.n_layers = c.n_layers; a.B = c.B; a.d = c.d; a.f = c.f; a.H = c.H; a.Te = c.Te; a.Lmax = c.max_len;
   a.V = c.V;
   // key split of the cross-attention: ca_attn_fwd's rule (smallq_split), so the merge order - and the bits - are its
-  int ns = 1;
+  a.split.ns = 1; a.split.tail_start = c.B * c.H; a.split.ns_tail = 1;
   if (c.Te >= 1024) {
     static const int cap = [] { const char* e = getenv("CA_ATTN_SPLIT"); return e ? atoi(e) : CA_ATTN_SPLIT_MAX; }();
-    ns = ca_attn_key_split(c.B * c.H, G, cap);
+    a.split = ca_attn_key_split(c.B * c.H, G, cap);
   }
-  a.ns = ns;
   a.embed = (const unsigned short*)c.embed; a.pos_tab = (const unsigned short*)c.embed_pos;
   a.lnf_g = c.lnf_g; a.lnf_b = c.lnf_b; a.eps = c.eps; a.scale = 0.125f;  // head_dim 64
   a.logits = c.logits; a.ld_logits = c.ld_logits; a.suppress = c.suppress; a.out = c.out; a.done = c.done; a.ids = c.ids;

@@ -392,6 +392,87 @@ def test_whisper_medium_full_depth_one_clip_against_the_oracle():
     _whisper_full_depth_one_clip("whisper-medium", [50258, 50285, 50359, 50363], seed=21)
 
 
+def test_whisper_medium_sixteen_clips_decoded_to_max_length_against_the_oracle():
+    """The reference's evaluation call at its own batch size (R/config/evaluation.yaml:20 `batch_size: 16`,
+    R/src/coral/evaluate.py:56-60 -> $TF/models/whisper/generation_whisper.py:383) run to `max_length` 225: 16 different
+    30 s clips through log-mel + encoder + the persistent one-launch-per-token decoder (csrc/decode.hip), the 221 picks
+    of a row checked against the fp32 oracle's teacher-forced logits of the engine's OWN sequence (tests/greedy_check.py,
+    policy 1 + 2: every pick within `accept` of the oracle's maximum; equal to the oracle's argmax wherever its top-2
+    margin exceeds `forced` - so by induction the oracle's own greedy sequence can only leave the engine's at a
+    near-tie; the oracle's greedy loop itself is O(T^2) decoder passes and is not run at this length).  The oracle costs
+    12 s per row on the GPU box's host cores: rows 0, 3, .. 15 by default, all 16 with CORAL_TEST_ALL_ROWS=1 (recorded
+    run, NOTEBOOK R6.4: 3 536 picks, 13 beside the oracle's argmax, none at a margin above 0.031; logit error 0.054)."""
+    import contextlib
+    import io
+    import os
+
+    from coral_amd import ops
+    from coral_amd.whisper import CORAL_WHISPER_SHAPES, WhisperEngine, WhisperShape
+    from oracle import whisper_ref as w
+
+    t0 = time.time()
+    kw = dict(CORAL_WHISPER_SHAPES["whisper-medium"])
+    c = w.WhisperConfig(**kw)
+    P = w.synth_params(c)
+    g = torch.Generator().manual_seed(77)
+    B, max_length, prefix = 16, 225, [50258, 50285, 50359, 50363]
+    feats = torch.from_numpy(np.stack([
+        w.log_mel(w.pad_or_trim((0.05 + 0.01 * b) * torch.randn(16_000 * (5 + b), generator=g).numpy()), c.num_mel_bins)
+        for b in range(B)]))
+    eng = WhisperEngine(WhisperShape(**kw), DEV)
+    eng.load_state_dict(P)
+    assert ops.whisper_decode_token_supported(B, c.d_model, c.decoder_ffn_dim, c.decoder_attention_heads, c.vocab_size)
+    bs = [220, c.eos_token_id]
+    ids = eng.generate(feats, prefix, max_length, suppress_tokens=None, begin_suppress_tokens=bs)
+    torch.cuda.synchronize()
+    t1 = time.time()
+    assert len(ids) == B and all(len(r) == max_length or c.eos_token_id in r for r in ids)
+    n_full = sum(len(r) == max_length and c.eos_token_id not in r[:-1] for r in ids)
+    worst = dict(regret=0.0, margin_at_mismatch=0.0, mismatches=0, picks=0, e_log=0.0)
+    # rows that ended early carry pad after eos: the policy is checked up to and including the eos pick
+    cut = [r[:r.index(c.eos_token_id) + 1] if c.eos_token_id in r else r for r in ids]
+    with torch.no_grad():
+        enc_eng = eng.encode(feats).clone()
+        checked = list(range(B)) if os.environ.get("CORAL_TEST_ALL_ROWS") == "1" else list(range(0, B, 3))
+        lg_ref = {}
+        for b in checked:
+            lg = w.decoder(torch.tensor([cut[b][:-1]]), w.encoder(feats[b:b + 1], P, c), P, c)[0].clone()
+            lg[len(prefix) - 1, bs] = float("-inf")
+            lg_ref[b] = lg
+            # the engine's teacher-forced logits of the same sequence: the measured logit error sets the tie margins
+            # (as in _whisper_full_depth_one_clip)
+            mine = eng.decode(torch.tensor([cut[b][:-1]]), enc_eng[b:b + 1])[0].float().cpu()
+            mine[len(prefix) - 1, bs] = float("-inf")
+            keep = torch.isfinite(lg)
+            worst["e_log"] = max(worst["e_log"], float((mine[keep] - lg[keep]).abs().max()))
+        t2 = time.time()
+
+        def rows(i, seq):
+            lg = lg_ref[checked[i]]
+            for t in range(len(prefix), len(seq)):
+                top2 = lg[t - 1].topk(2)
+                worst["picks"] += 1
+                worst["regret"] = max(worst["regret"], float(top2.values[0] - lg[t - 1, seq[t]]))
+                if int(top2.indices[0]) != seq[t]:
+                    worst["mismatches"] += 1
+                    worst["margin_at_mismatch"] = max(worst["margin_at_mismatch"], float(top2.values[0] - top2.values[1]))
+            return lg
+
+        e_log = worst["e_log"]
+        assert e_log <= 8e-2, e_log
+        mine = [cut[b] for b in checked]
+        with contextlib.redirect_stdout(io.StringIO()):  # (no second sequence to report a divergence from)
+            check_greedy_rows(rows, mine, mine, len(prefix), accept=max(3e-2, 1.5 * e_log), forced=max(6e-2, 3 * e_log),
+                              label="whisper-medium x16")
+    print(f"\nwhisper-medium, 16 x 30 s to max_length {max_length}: {n_full} rows ran to max_length; rows {checked} against the "
+          f"oracle: teacher-forced logits max-abs err {e_log:.4f}; {worst['picks']} picks, "
+          f"{worst['mismatches']} differ from the oracle's argmax (largest fp32 top-2 margin there {worst['margin_at_mismatch']:.4f}), "
+          f"largest distance of a pick below the oracle's maximum {worst['regret']:.4f}; engine {t1 - t0:.1f} s incl. set-up, "
+          f"oracle {t2 - t1:.1f} s")
+    del eng
+    torch.cuda.empty_cache()
+
+
 def test_whisper_large_the_reference_default_model_full_depth_against_the_oracle():
     """`model=whisper-large` is the reference's DEFAULT (R/config/asr_finetuning.yaml:1-11; R/config/model/whisper-large.yaml:
     openai/whisper-large-v3): 32 + 32 layers, d 1280, 20 heads, 128 mel bins, vocabulary 51 866 - the one CoRal key whose
