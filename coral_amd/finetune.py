@@ -71,17 +71,20 @@ def eval_batches_of_rank(n_examples: int, batch_size: int, rank: int, world: int
     return batches[rank::world]
 
 
-def gather_rows_in_order(rows: list[list[int]], starts: list[int], n_examples: int, fill: int, rank: int, world: int):
+def gather_rows_in_order(rows: list[list[int]], starts: list[int], n_examples: int, fill: int, rank: int, world: int,
+                         collective: bool | None = None):
     """Every rank's id rows -> ONE [n_examples, W] int64 array in dataset order, on every rank.
 
     rows[j] belongs to example starts[j].  The rows are padded with `fill` to the widest row of any rank and the row
     counts to the largest of any rank with all-`fill` rows (what `pad_across_processes(pad_index=-100)` +
     `gather_for_metrics` do, $TF/trainer.py:2754-2777; the filler rows are what R/src/coral/compute_metrics.py:63-66
     special-cases) - here they carry the example index -1 and are dropped after the gather instead.  Ids, not logits:
-    46 x fewer bytes than the reference moves.  One all_gather of a [rows, 1 + W] matrix per evaluation set."""
+    46 x fewer bytes than the reference moves.  One all_gather of a [rows, 1 + W] matrix per evaluation set.
+    `collective=True` takes the collective route over a one-rank group too (tests/rccl_one_rank_worker.py: RCCL with
+    device tensors on a 1-GPU box)."""
     import numpy as np
 
-    if world == 1:
+    if world == 1 and not collective:
         W = max((len(r) for r in rows), default=1)
         out = np.full((n_examples, max(W, 1)), fill, dtype=np.int64)
         for r, i in zip(rows, starts):

@@ -66,6 +66,13 @@ def main():
     os.environ["CA_COMM_CAPI"] = "0"
     res["fp32_torch"] = run(True, "fp32", steps)
     os.environ.pop("CA_COMM_CAPI")
+    # sharded evaluation's id gather (coral_amd/finetune.py) over the same group: device tensors through RCCL's
+    # all_reduce(MAX) + all_gather; one rank holds every row, so the collective route must equal the direct one
+    from coral_amd.finetune import gather_rows_in_order
+
+    rows, starts = [[5, 6, 7], [], [9], [1, 2, 3, 4, 5, 6]], [2, 0, 3, 1]
+    res["gather_direct"] = torch.from_numpy(gather_rows_in_order(rows, starts, 4, -100, 0, 1))
+    res["gather_rccl"] = torch.from_numpy(gather_rows_in_order(rows, starts, 4, -100, 0, 1, collective=True))
     torch.save(res, out)
     torch.distributed.destroy_process_group()
 

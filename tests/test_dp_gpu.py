@@ -146,6 +146,9 @@ def test_rccl_one_rank_group_reproduces_the_plain_trainer(tmp_path):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     res = torch.load(out)
     plain, f32, b16 = res["plain"], res["fp32"], res["bf16"]
+    # the evaluation's id gather through RCCL (device tensors) = the direct one-rank result
+    assert torch.equal(res["gather_direct"], res["gather_rccl"]) and res["gather_rccl"].shape == (4, 6)
+    assert res["gather_rccl"][1].tolist() == [1, 2, 3, 4, 5, 6] and res["gather_rccl"][0].tolist() == [-100] * 6
     # Without the clip (see the worker: the comparison must not hang on the last bit of the gradient norm) the identity
     # exchange changes nothing, bit for bit: fp32 wire through the C ABI's ca_* collectives (the default on RCCL) and
     # through torch.distributed's, and the sharded optimiser over the same one-rank group (RCCL's in-place

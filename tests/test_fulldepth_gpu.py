@@ -10,7 +10,8 @@ themselves (tests/test_fullsize_gpu.py keeps the batch-of-8 property checks).
   configs[1]  wav2vec2-large (XLS-R-2B): logits / CTC loss / greedy ids / gradient norms + cosines
               ($TF/models/wav2vec2/modeling_wav2vec2.py:1667-1728)
   configs[3]  whisper-medium: encoder states, 8 teacher-forced logits rows, 16 greedy tokens under the tie margin
-              ($TF/models/whisper/modeling_whisper.py:994-1099, generation_whisper.py:383)
+              ($TF/models/whisper/modeling_whisper.py:994-1099, generation_whisper.py:383); 16 clips (the reference's
+              evaluation batch) decoded to max_length 225, every pick against the oracle's teacher-forced logits
   default     whisper-large (R/config/asr_finetuning.yaml:1-11: the reference's default model key), 32 + 32 layers: the
               same three comparisons on one clip, and its training step at the reference's batch of 64 (R/makefile:109-137)
   configs[4]  whisper-large-turbo, 32 + 4 layers, 2 clips: bf16 engine loss vs the oracle, and the fp8-forward step
