@@ -159,6 +159,7 @@ SIGNATURES = {
     "ca_gemm_debug_general_epilogue": (C.c_int, [C.c_int]),
     "ca_debug_cu_hog": (C.c_int, [_i32, _i32, _i32, C.c_double, _vp]),
     "ca_gemm_set_compute_cus": (C.c_int, [C.c_int]),
+    "ca_background_update_fits": (C.c_int, [C.POINTER(C.c_int32)]),
     "ca_prof_begin": (C.c_int, []),
     "ca_prof_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "ca_attn_fwd": (C.c_int, [C.POINTER(CaAttnDesc), _vp]),

@@ -202,3 +202,6 @@ __device__ __forceinline__ void ca_key_split_item(const CaKeySplit& s, int it, i
   }
   sp = it - part0;
 }
+
+// host stub of the AdamW kernel the trainer runs in the background (defined in misc.hip; for hipFuncGetAttributes)
+const void* ca_adamw_background_kernel();

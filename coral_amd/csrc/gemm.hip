@@ -2196,6 +2196,22 @@ extern "C" int ca_gemm_set_compute_cus(int n) {
   g_compute_cus = n > 0 ? n : 0;
   return CA_OK;
 }
+// see include/coral_amd.h: the forward kernel that holds the most registers is kernel X's K-major form
+extern "C" int ca_background_update_fits(int32_t* regs) {
+  hipFuncAttributes ax, aw;
+  const hipError_t e1 = hipFuncGetAttributes(&ax, (const void*)ca_gemm_kernel_x<0, 0, false>);
+  const hipError_t e2 = hipFuncGetAttributes(&aw, ca_adamw_background_kernel());
+  if (e1 != hipSuccess || e2 != hipSuccess) {
+    ca_set_error("ca_background_update_fits: hipFuncGetAttributes: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+    return CA_ERR_LAUNCH;
+  }
+  if (regs) {
+    regs[0] = ax.numRegs;
+    regs[1] = aw.numRegs;
+  }
+  const int gx = (ax.numRegs + 7) / 8 * 8, gw = (aw.numRegs + 7) / 8 * 8;
+  return 2 * gx + gw <= 512 ? 1 : 0;
+}
 static unsigned x_device_cus() {
   static const unsigned ncu = [] {
     int dev = 0, n = 256;

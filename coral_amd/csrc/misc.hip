@@ -629,6 +629,7 @@ static int adamw_launch(float* p, float* m, float* v, const void* g, bool g16, v
   CA_CHECK_LAUNCH("ca_adamw_step");
   return CA_OK;
 }
+const void* ca_adamw_background_kernel() { return (const void*)adamw_kernel<true, true>; }
 extern "C" int ca_adamw_step_ex(float* p, float* m, float* v, const float* g, void* p16, int64_t n,
                                 float lr, float beta1, float beta2, float eps, float weight_decay,
                                 int32_t step, float grad_scale, float max_norm,

@@ -42,6 +42,16 @@ def lib():
 _SIDE_STREAMS: dict = {}
 
 
+def background_update_fits():
+    """-> (fits, registers of the forward GEMM kernel, registers of the update kernel): can the capped-grid AdamW run
+    under the next step's forward GEMMs (ca_background_update_fits, include/coral_amd.h)?"""
+    regs = (C.c_int32 * 2)()
+    rc = lib().ca_background_update_fits(regs)
+    if rc < 0:
+        check(rc, "ca_background_update_fits")
+    return bool(rc), int(regs[0]), int(regs[1])
+
+
 def side_stream(device, role: str, priority: int = 0):
     """The process's side stream for `role` ("wgrad", "optimizer", "exchange", "gather", "copy") on `device`: created once
     and shared by every engine / trainer of the process.  torch hands out pool streams round-robin and HIP folds them

@@ -474,6 +474,17 @@ class DataParallelTrainer:
         if self.overlap_optimizer:
             bg = os.environ.get("CA_OPT_BG_BLOCKS")
             self.bg_blocks = int(bg) if bg is not None else torch.cuda.get_device_properties(st.device).multi_processor_count
+            if bg is None:
+                # ... which holds only while the loaded kernels' register counts say so (a compiler that gives the forward
+                # kernel 8 registers more turns the capped update into a 19 ms stall, tests/test_build.py): asked of the
+                # code object itself; otherwise the full-grid update, which alternates with the GEMMs
+                fits, rx, ru = ops.background_update_fits()
+                if not fits:
+                    import warnings
+
+                    warnings.warn(f"coral_amd: the forward GEMM kernel holds {rx} registers per lane and the update "
+                                  f"kernel {ru}: the update cannot run beside it; using the full-grid update")
+                    self.bg_blocks = 0
         # per-bucket squared gradient norms, computed on the side stream as the buckets complete
         self.bucket_index = {name: i for i, name in enumerate(st.buckets)}
         self.bucket_sq = torch.zeros(len(st.buckets), dtype=torch.float32, device=st.device)

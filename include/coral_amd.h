@@ -535,6 +535,13 @@ int ca_adamw_step_g16(float* p, float* m, float* v, const void* g_bf16, void* p1
                       float lr, float beta1, float beta2, float eps, float weight_decay,
                       int32_t step, float grad_scale, float max_norm, const float* gnorm_sq,
                       int32_t max_blocks, void* stream);
+/* Does a wave of the update kernel fit into the registers the forward GEMMs' workgroups (two waves per SIMD) leave free?
+ * The capped-grid update (max_blocks = the CU count) only runs UNDER the next step's forward while it does
+ * (2 x registers of the forward kernel + the update's <= 512 per SIMD, in allocation granules of 8); one register too
+ * many in the forward kernel and the capped update starves instead (+ 19 ms per XLS-R-2B step, round 5) - the trainer
+ * asks at start-up and falls back to the full-grid update.  regs (optional, 2 words): registers per lane of the forward
+ * GEMM kernel and of the update kernel as the loaded code object reports them.  Returns 1 / 0, negative on an error. */
+int ca_background_update_fits(int32_t* regs);
 
 /* ------------------------------------------------------------------------------------
  * Whisper log-mel front end.  $TF/models/whisper/feature_extraction_whisper.py:135-168

@@ -58,3 +58,17 @@ def test_background_adamw_fits_beside_the_forward_gemm_kernel():
     adamw = [v for k, v in regs.items() if "adamw_kernel" in k]
     assert len(x_nt) == 1 and len(adamw) == 4, (x_nt, adamw)  # (non-temporal or not) x (fp32 or bf16 gradient)
     assert 2 * alloc(x_nt[0]) + alloc(max(adamw)) <= 512, (x_nt, adamw)
+
+
+@pytest.mark.gpu
+def test_the_loaded_code_object_reports_the_same_budget():
+    """ca_background_update_fits (what the trainer asks at start-up, falling back to the full-grid update if the answer
+    is no) reads the registers of the LOADED kernels: the same numbers as the code objects' notes above."""
+    from coral_amd import ops
+
+    fits, rx, ru = ops.background_update_fits()
+    regs = kernel_vgprs(LIB)
+    x_nt = [v for k, v in regs.items() if "ca_gemm_kernel_xILi0ELi0ELb0E" in k][0]
+    upd = [v for k, v in regs.items() if "adamw_kernelILb1ELb1E" in k][0]
+    print(f"\nforward GEMM kernel {rx} registers (notes {x_nt}), background update {ru} (notes {upd}), fits: {fits}")
+    assert (rx, ru) == (x_nt, upd) and fits
