@@ -534,7 +534,7 @@ class WhisperEngine:
         B, Lmax = cache["B"], cache["max_len"]
         d, f, H, V = s.d_model, s.decoder_ffn_dim, s.decoder_attention_heads, s.vocab_size
         g["persist"] = None
-        if os.environ.get("CA_DECODE_PERSISTENT", "1") == "0" or d != 64 * H:
+        if os.environ.get("CA_DECODE_PERSISTENT", "1") == "0" or d != 64 * H or getattr(self, "_persistent_off", False):
             return None
         if not ops.whisper_decode_token_supported(B, d, f, H, V):
             return None
@@ -772,9 +772,18 @@ class WhisperEngine:
         if g.get("persist") is not None:
             code = int(g["persist"]["status"][0])  # (synchronises)
             if code != 0:
-                raise ops.CoralAmdError(f"ca_whisper_decode_token gave up at the seam in front of phase {code - 1}: the launch "
-                                        "needs every CU of the device (nothing else may run beside it); "
-                                        "CA_DECODE_PERSISTENT=0 keeps the launch sequence")
+                msg = (f"ca_whisper_decode_token gave up at the seam in front of phase {code - 1}: the launch needs every "
+                       "CU of the device (nothing else may run beside it)")
+                if os.environ.get("CA_DECODE_STRICT") == "1":
+                    raise ops.CoralAmdError(msg + "; CA_DECODE_PERSISTENT=0 keeps the launch sequence")
+                # a launch that gave up has written no token: the ids above are not a generation.  This engine keeps
+                # the launch sequence from here on (same bits) and decodes the batch again.
+                import warnings
+
+                warnings.warn("coral_amd: " + msg + "; decoding this batch again as a launch sequence and keeping that "
+                              "path for this engine (CA_DECODE_STRICT=1 raises instead)")
+                self._persistent_off = True
+                return self._generate_graph(kv, prefix, max_length, sup, sup_begin)
         # trim like the eager loop: stop at the first column where every row had already finished
         fin = (out == s.eos_token_id).cumsum(1) > 0
         allfin = fin.all(0)

@@ -157,3 +157,37 @@ def test_finished_rows_take_pad_in_both_paths():
     assert bool(gb["done"].all())
     out = gb["out"][:, 5:9].tolist()
     assert all(row[0] == shape.eos_token_id and row[1:] == [shape.pad_token_id] * 3 for row in out), out
+
+
+def test_generate_decodes_again_as_a_launch_sequence_when_a_persistent_launch_gave_up(monkeypatch):
+    """`generate` reads the status word at the end: a launch that gave up (every CU was not free) has written no token,
+    so the batch is decoded again through the launch sequence - the same bits - with a warning, and the engine keeps
+    that path; CA_DECODE_STRICT=1 raises instead.  The give-up is injected: the status word of a fresh decode state is
+    raised before its first launch (the word is sticky)."""
+    from coral_amd import ops
+
+    eng, shape, waves = _engine("whisper-xxsmall", 8)
+    feats = eng.log_mel(waves)
+    monkeypatch.setenv("CA_DECODE_PERSISTENT", "0")
+    ref = eng.generate(feats, PREFIX, 40)
+    monkeypatch.setenv("CA_DECODE_PERSISTENT", "1")
+    real = eng._persistent_state
+
+    def spoiled(cache, g, suppress):
+        fresh = "persist" not in g
+        ps = real(cache, g, suppress)
+        if fresh and ps is not None:
+            ps["status"][0] = 5
+        return ps
+
+    monkeypatch.setattr(eng, "_persistent_state", spoiled)
+    monkeypatch.setenv("CA_DECODE_STRICT", "1")
+    with pytest.raises(ops.CoralAmdError):
+        eng.generate(feats, PREFIX, 40)
+    monkeypatch.delenv("CA_DECODE_STRICT")
+    with pytest.warns(UserWarning, match="gave up"):
+        got = eng.generate(feats, PREFIX, 40)
+    assert got == ref and eng._persistent_off
+    calls = []
+    monkeypatch.setattr(ops, "whisper_decode_token", lambda d: calls.append(1))
+    assert eng.generate(feats, PREFIX, 40) == ref and not calls  # the engine stays on the launch sequence
