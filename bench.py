@@ -685,6 +685,15 @@ def main():
                              else "launch sequence, ~7 launches per layer"}
             del r4
             torch.cuda.empty_cache()
+        # the reference's DEFAULT model key at its evaluation batch (whisper-large = large-v3, R/config/evaluation.yaml:20):
+        # 16 clips x 20 heads = 320 (clip, head) items on 256 CUs - the second round's items are key-split (attention.hip)
+        r4 = whisper_measure("whisper-large", args, world, rank, device, decode=True, B=16, steps=3, warmup=1)
+        dec["large_B16"] = {"workload": "whisper-large (32 + 32 layers, d 1280, 20 heads), 16 clips",
+                            "ms_per_token": round(r4["ms_per_token"], 4), "bytes_per_token": int(r4["bytes_per_token"]),
+                            "frac_of_8TBps": round(r4["hbm_frac"], 4),
+                            "audio_s_per_s_incl_logmel_encoder": round(r4["value"], 1)}
+        del r4
+        torch.cuda.empty_cache()
         out["config"]["also_decode"] = dict(workload=f"whisper-medium greedy decode (log-mel + encoder + {args.decode_tokens} "
                                                      "K|V-cached, graph-replayed decoder steps), 30 s clips; per-token time = "
                                                      "difference of two generation lengths; bytes = bf16 decoder weights + "
