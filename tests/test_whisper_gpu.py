@@ -387,12 +387,15 @@ def test_decode_attention_with_the_query_projection_inside_is_bit_identical(d, H
 
 
 @pytest.mark.parametrize("d,H,Tk,B,Tq", [(1024, 16, 1500, 8, 1), (1024, 16, 1500, 2, 1), (1280, 20, 1500, 3, 1), (512, 8, 1100, 5, 7),
-                                         (1024, 16, 1500, 16, 1)])
+                                         (1024, 16, 1500, 16, 1), (1280, 20, 1500, 16, 1), (1024, 16, 1500, 24, 1),
+                                         (1024, 16, 1500, 32, 1)])
 def test_decode_attention_with_the_keys_dealt_to_several_workgroups(d, H, Tk, B, Tq):
     """CaAttnDesc.split_ws: the keys of one (clip, head) dealt to 2-4 workgroups whose partials the last one to finish
     merges - against fp32 torch and against the one-workgroup launch (same values up to the merge order), the fused
     q-projection form bit-identical to the unfused one under the same split, the counters back at zero after every
-    launch (the same workspace serves 30 launches in a row), and no split where B x H already fills the chip."""
+    launch (the same workspace serves 30 launches in a row), and no split where B x H already fills the chip.  Between
+    one and two rounds of items (320 = 16 clips x 20 heads, 384 = 24 x 16) only the second round's items are split, 4 or
+    2 ways (CaKeySplit.tail_start); from two rounds on (512) nothing is."""
     from coral_amd import ops
 
     hd = d // H
@@ -403,7 +406,7 @@ def test_decode_attention_with_the_keys_dealt_to_several_workgroups(d, H, Tk, B,
     bias = 0.1 * torch.randn(d, device=DEV, generator=g)
     kv = torch.randn(B, Tk, 2 * d, device=DEV, generator=g).to(torch.bfloat16)
     q = torch.randn(B, Tq, d, device=DEV, generator=g).to(torch.bfloat16)
-    klen = torch.tensor([Tk, max(1, Tk - 37), 1, Tk // 2, Tk, 64, 65, Tk] * 2, dtype=torch.int32, device=DEV)[:B]
+    klen = torch.tensor([Tk, max(1, Tk - 37), 1, Tk // 2, Tk, 64, 65, Tk] * 4, dtype=torch.int32, device=DEV)[:B]
     ws = ops.attn_split_workspace(B, H, DEV)
     akw = dict(B=B, H=H, Tk=Tk, hd=hd, scale=hd ** -0.5, ldk=2 * d, ldv=2 * d, ldo=d, skb=Tk * 2 * d, svb=Tk * 2 * d, k_off=0, v_off=d)
     nb = (B * H * 4 + 255) // 256 * 256 // 4  # the counters' words
@@ -424,8 +427,12 @@ def test_decode_attention_with_the_keys_dealt_to_several_workgroups(d, H, Tk, B,
         assert (many.float() - ref).abs().max() < 2e-2
         assert (many.float() - one.float()).abs().max() <= 4e-3  # (bf16 outputs of the same fp32 sums in another order)
         assert (lse2 - lse1).abs().max() < 1e-4
-        if B * H * 2 > 256:  # nothing to deal: the very same launch
+        ncu = torch.cuda.get_device_properties(0).multi_processor_count
+        if B * H == ncu or B * H >= 2 * ncu:  # nothing to deal: the very same launch
             assert torch.equal(many, one)
+        elif B * H > ncu:  # the whole items of the first round are the same launch's, the split ones differ in the last bits
+            assert torch.equal(many.view(B * H, -1)[:ncu], one.view(B * H, -1)[:ncu]) if Tq == 1 else True
+            assert not torch.equal(many, one)
         if Tq == 1:
             xn, qp = torch.empty_like(x), torch.empty_like(x)
             want, got = torch.zeros(B, d, dtype=torch.bfloat16, device=DEV), torch.ones(B, d, dtype=torch.bfloat16, device=DEV)
