@@ -418,8 +418,10 @@ typedef struct CaAttnDesc {
    * workspace of CA_ATTN_SPLIT_WS_BYTES(B, H) bytes, zero-filled ONCE by the caller (the kernels leave its counters at
    * zero), lets the keys of one (clip, head) be dealt to up to CA_ATTN_SPLIT_MAX workgroups when B x H workgroups would
    * leave half of the CUs idle and Tk >= 1024 (the 1500 cross-attention keys of $TF/models/whisper/modeling_whisper.py:
-   * 312-335 at the evaluation batch sizes of R/config/evaluation.yaml); partial results are merged in a fixed order by
-   * the workgroup that finishes last.  One launch at a time per workspace.  NULL = one workgroup per (clip, head). */
+   * 312-335 at the evaluation batch sizes of R/config/evaluation.yaml) - or, with more than one round of (clip, head)
+   * items and fewer than two (whisper-large at 16 clips: 320 on 256 CUs), the items of the second round only, so that
+   * their parts fill it; partial results are merged in a fixed order by the workgroup that finishes last.  One launch at
+   * a time per workspace.  NULL = one workgroup per (clip, head). */
   void* split_ws;
   int64_t split_ws_bytes;
 } CaAttnDesc;
