@@ -113,7 +113,7 @@ DECODE_MAX_B = 16
 
 def decode_ws_bytes(B, d, f, H, n_layers):
     """CA_DECODE_WS_BYTES of include/coral_amd.h."""
-    return (4096 + n_layers * 16 * H * 4 + 16 * (7 * d + f) * 2 + 16 * H * 4 * 16 * 66 * 4 + 256 * 16 * 8 + 4096)
+    return (8192 + n_layers * 16 * H * 4 + 16 * (7 * d + f) * 2 + 16 * H * 4 * 16 * 66 * 4 + 256 * 16 * 8 + 4096)
 
 
 class CaAttnDesc(C.Structure):

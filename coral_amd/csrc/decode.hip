@@ -21,7 +21,8 @@
 // wave owns a quarter of K, as in ca_gemm_skinny_kernel, so per output element the MFMA chain and the (p0 + p1) + (p2 + p3)
 // combine are that kernel's - the same bits.  The residual stream's columns of a workgroup stay in registers.
 //
-// Seams.  Every workgroup owns one progress word (flags[w] = phases it has completed).  A phase's outputs are stored
+// Seams.  Every workgroup owns one progress word (flags[w] = phases it has completed; kept in 8 replicas, each polled by
+// an eighth of the workgroups, all stored by one wave instruction of the owner).  A phase's outputs are stored
 // write-through (sc1) by wave 0, which then drains (s_waitcnt vmcnt(0)) and stores the word (sc1); a consumer's wave 0
 // polls ALL words with one 16-byte sc1 load per lane, then the workgroup's barrier, then every load of handed-off bytes is
 // an sc1 load to registers (MI355X_MICROARCH.md, visibility: the form "one lane of each storing workgroup / sc1 poll of
@@ -53,6 +54,8 @@ __device__ __attribute__((aligned(16))) uint32_t g_dec_zero_page[4];
 #define DK_SPLIT_ROW 66      // floats of a partial: m, l, 64 output columns
 #define DK_MAXTILES 16       // vocabulary tiles per workgroup (V <= 16 * 16 * G)
 #define DK_SPIN_LIMIT (1u << 21)
+#define DK_FLAG_STRIDE 256   // words between replicas of the progress words (one replica = 1 KiB: 256 workgroups)
+#define DK_FLAG_REPS_MAX 8
 
 // CaDecodeLayer as 20 64-bit words (the kernel keeps the records in LDS: a pointer is one ds_read away, not a scalar load
 // from device memory in front of every phase)
@@ -76,7 +79,9 @@ struct DecArgs {
   int32_t *tok, *pos, *klen;
   int32_t pad, eos;
   // workspace
-  unsigned* flags;
+  unsigned* flags;          // [flag_reps][DK_FLAG_STRIDE] progress words
+  int flag_reps;            // 1, 2, 4 or 8: workgroup w polls replica w & (flag_reps - 1)
+  int poll_sleep;
   unsigned* split_cnt;  // [n_layers][B * H]
   unsigned short *q, *ctx, *h1, *q2, *ctx2, *h2, *h, *gbuf;
   float* slab;          // [B * H * ns][DK_SPLIT_ROW]
@@ -157,9 +162,10 @@ __device__ __forceinline__ void dk_t(DkDbg& dbg) {
 // ---- seams -----------------------------------------------------------------------------------------------------------
 // wave 0: wait until every workgroup's progress word is >= target.  Returns false on a timeout (wave-uniform).
 __device__ __forceinline__ bool dk_poll(const DecArgs& a, unsigned target, int G, int lane) {
+  const unsigned* myflags = a.flags + ((int)blockIdx.x & (a.flag_reps - 1)) * DK_FLAG_STRIDE;
   for (unsigned spins = 0;; ++spins) {
     dk_u32x4 f = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
-    if (lane * 4 < G) f = dk_ld16u_sc1(a.flags + lane * 4);
+    if (lane * 4 < G) f = dk_ld16u_sc1(myflags + lane * 4);
     dk_vm0();
     dk_tie(f);
     bool ok = true;
@@ -167,7 +173,13 @@ __device__ __forceinline__ bool dk_poll(const DecArgs& a, unsigned target, int G
     for (int e = 0; e < 4; ++e) ok &= (lane * 4 + e >= G) || f[e] >= target;
     if (__all(ok)) return true;
     if (spins > DK_SPIN_LIMIT) return false;
-    __builtin_amdgcn_s_sleep(1);
+    switch (a.poll_sleep) {  // (64 clocks per unit; CA_DECODE_POLL_SLEEP)
+      case 0: break;
+      case 1: __builtin_amdgcn_s_sleep(1); break;
+      case 2: __builtin_amdgcn_s_sleep(2); break;
+      case 4: __builtin_amdgcn_s_sleep(4); break;
+      default: __builtin_amdgcn_s_sleep(8); break;
+    }
   }
 }
 // All waves: the seam in front of phase `ph` (1-based; waits for every workgroup to have completed ph - 1).  Returns
@@ -195,7 +207,7 @@ __device__ __forceinline__ bool dk_seam(const DecArgs& a, unsigned ph, int G, vo
 __device__ __forceinline__ void dk_publish(const DecArgs& a, unsigned ph, int w, int wave, int lane) {
   if (wave == 0) {
     dk_vm0();
-    if (lane == 0) dk_st4_sc1(a.flags + w, ph);
+    if (lane < a.flag_reps) dk_st4_sc1(a.flags + lane * DK_FLAG_STRIDE + w, ph);  // ONE wave instruction: every replica's word
   }
 }
 
@@ -1340,8 +1352,20 @@ extern "C" int ca_whisper_decode_token(const CaDecodeDesc* desc, void* stream) {
   a.ld_ids = c.ld_ids; a.tok = c.tok; a.pos = c.pos; a.klen = c.klen; a.pad = c.pad_id; a.eos = c.eos_id;
   char* p = (char*)c.ws;
   a.flags = (unsigned*)p;
-  a.split_cnt = (unsigned*)(p + 4096);
-  const size_t zero_bytes = 4096 + (size_t)c.n_layers * 16 * c.H * 4;
+  // The progress words in R replicas, each polled by 1 / R of the workgroups (tools/r06/seam_bench.hip: a bare seam 3.25 us
+  // with one copy that all 256 workgroups poll, 2.44 at R = 4, 2.55 at R = 8; with a 16 KB gather behind it 5.15 -> 3.49 at
+  // R = 8): a publishing workgroup stores all R words with one wave instruction.  CA_DECODE_FLAG_REPLICAS (1 .. 8).
+  static const int reps = [] {
+    const char* e = getenv("CA_DECODE_FLAG_REPLICAS");
+    const int r = e ? atoi(e) : 8;
+    return r >= 8 ? 8 : (r >= 4 ? 4 : (r >= 2 ? 2 : 1));
+  }();
+  a.flag_reps = reps;
+  static const int psleep = [] { const char* e = getenv("CA_DECODE_POLL_SLEEP"); return e ? atoi(e) : 1; }();
+  a.poll_sleep = psleep;
+  constexpr size_t FLAG_BYTES = (size_t)DK_FLAG_REPS_MAX * DK_FLAG_STRIDE * 4;  // 8 KiB
+  a.split_cnt = (unsigned*)(p + FLAG_BYTES);
+  const size_t zero_bytes = FLAG_BYTES + (size_t)c.n_layers * 16 * c.H * 4;
   p += zero_bytes;
   const size_t row = (size_t)16 * c.d * 2;
   a.q = (unsigned short*)p; p += row;

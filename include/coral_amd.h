@@ -652,7 +652,7 @@ typedef struct CaDecodeDesc {
 } CaDecodeDesc;
 #define CA_DECODE_MAX_B 16
 #define CA_DECODE_WS_BYTES(B, d, f, H, n_layers)                                                              \
-  (4096 + (int64_t)(n_layers) * 16 * (H) * 4 + (int64_t)16 * (7 * (int64_t)(d) + (f)) * 2 +                     \
+  (8192 + (int64_t)(n_layers) * 16 * (H) * 4 + (int64_t)16 * (7 * (int64_t)(d) + (f)) * 2 +                     \
    (int64_t)16 * (H) * CA_ATTN_SPLIT_MAX * 16 * 66 * 4 + 256 * 16 * 8 + 4096)
 int ca_whisper_decode_token(const CaDecodeDesc* desc, void* stream);
 /* 1 when ca_whisper_decode_token takes this shape on the current device, else 0 (the caller keeps the launch sequence) */
