@@ -1361,7 +1361,7 @@ extern "C" int ca_whisper_decode_token(const CaDecodeDesc* desc, void* stream) {
     return r >= 8 ? 8 : (r >= 4 ? 4 : (r >= 2 ? 2 : 1));
   }();
   a.flag_reps = reps;
-  static const int psleep = [] { const char* e = getenv("CA_DECODE_POLL_SLEEP"); return e ? atoi(e) : 1; }();
+  static const int psleep = [] { const char* e = getenv("CA_DECODE_POLL_SLEEP"); return e ? atoi(e) : 2; }();
   a.poll_sleep = psleep;
   constexpr size_t FLAG_BYTES = (size_t)DK_FLAG_REPS_MAX * DK_FLAG_STRIDE * 4;  // 8 KiB
   a.split_cnt = (unsigned*)(p + FLAG_BYTES);
