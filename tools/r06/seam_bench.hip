@@ -43,21 +43,26 @@ __device__ __forceinline__ void vm0_tie(u32x4& v) { asm volatile("s_waitcnt vmcn
 
 // mode 0: flags + payload gather; 1: flags only; 2: acquire fence instead of sc1 loads (plain loads)
 // POLL: 0 = one sc1 register load at a time; N > 0: N LDS-DMA sc1 polls in flight, landing in N LDS slots (round 6, late)
+// MODE 3 (late in round 6): every seam's payload at an address not touched before in this launch (FRESH regions, the launch
+// runs FRESH - 1 seams), gathered with PLAIN loads and no fence: a line that no workgroup of the XCD has touched since the
+// launch's own acquire cannot be stale in its L2, and after the first miss the XCD's other 31 workgroups hit in L2.
+#define FRESH 64
 template <int MODE, int POLL = 0>
 __global__ __launch_bounds__(256) void seam_kernel(unsigned* flags, unsigned* pay0, unsigned* pay1, int pay_words, int nseam,
-                                                   unsigned* err, unsigned* tmo, long long* cyc, unsigned* dbg, int R = 1, int RP = 1) {
+                                                   unsigned* err, unsigned* tmo, long long* cyc, unsigned* dbg, int R = 1, int RP = 1, unsigned salt = 0) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int G = gridDim.x, w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   unsigned bad = 0;
   const long long t0 = wall_clock64();
   for (int s = 1; s <= nseam; ++s) {
     unsigned* pay = (s & 1) ? pay1 : pay0;
+    if (MODE == 3) pay = pay0 + (size_t)(s % FRESH) * ((size_t)G * pay_words);  // an address is written once per FRESH seams
     // publish my slice: pay_words words, value = s * 0x10001 + w * 977 + i; RP replicas of the payload (each G * pay_words
     // words), a consumer gathers from replica w % RP: RP x fewer readers per line
     const size_t rstride = (size_t)G * pay_words;
     for (int i = tid * 4; i < pay_words; i += 1024) {
       u32x4 v;
-      for (int e = 0; e < 4; ++e) v[e] = (unsigned)s * 0x10001u + (unsigned)w * 977u + (unsigned)(i + e);
+      for (int e = 0; e < 4; ++e) v[e] = (unsigned)s * 0x10001u + (unsigned)w * 977u + (unsigned)(i + e) + salt * 0x9E3779B1u;
       for (int rp = 0; rp < RP; ++rp) st16_sc1(pay + rp * rstride + (size_t)w * pay_words + i, v);
     }
     vm0();
@@ -109,7 +114,7 @@ __global__ __launch_bounds__(256) void seam_kernel(unsigned* flags, unsigned* pa
         for (int u = 0; u < 8; ++u) {
           const int i = i0 + u * 1024;
           if (i < total) {
-            if (MODE == 2) v[u] = *(const u32x4*)(pay + i); else v[u] = ld16_sc1(pay + i);
+            if (MODE == 2 || MODE == 3) v[u] = *(const u32x4*)(pay + i); else v[u] = ld16_sc1(pay + i);
           }
         }
         vm0();
@@ -120,7 +125,7 @@ __global__ __launch_bounds__(256) void seam_kernel(unsigned* flags, unsigned* pa
           const int i = i0 + u * 1024;
           if (i < total) {
             const int pw = i / pay_words, pi = i - pw * pay_words;
-            for (int e = 0; e < 4; ++e) { const unsigned ex = (unsigned)s * 0x10001u + (unsigned)pw * 977u + (unsigned)(pi + e); if (v[u][e] != ex) { if (!bad && atomicAdd(dbg, 1u) < 8) { unsigned* d = dbg + 8 + 8 * (atomicAdd(dbg + 1, 1u) & 7); d[0] = s; d[1] = w; d[2] = i + e; d[3] = v[u][e]; d[4] = ex; d[5] = tid; } ++bad; } }
+            for (int e = 0; e < 4; ++e) { const unsigned ex = (unsigned)s * 0x10001u + (unsigned)pw * 977u + (unsigned)(pi + e) + salt * 0x9E3779B1u; if (v[u][e] != ex) { if (!bad && atomicAdd(dbg, 1u) < 8) { unsigned* d = dbg + 8 + 8 * (atomicAdd(dbg + 1, 1u) & 7); d[0] = s; d[1] = w; d[2] = i + e; d[3] = v[u][e]; d[4] = ex; d[5] = tid; } ++bad; } }
           }
         }
       }
@@ -143,7 +148,7 @@ int main(int argc, char** argv) {
   long long* cyc; unsigned* dbg;
   const int maxpay = 1024;  // words per workgroup
   CHECK(hipMalloc(&flags, 32 * 4096));
-  CHECK(hipMalloc(&pay0, (size_t)G * maxpay * 4 * 8));
+  CHECK(hipMalloc(&pay0, (size_t)G * maxpay * 4 * 64));
   CHECK(hipMalloc(&pay1, (size_t)G * maxpay * 4 * 8));
   CHECK(hipMalloc(&err, 4)); CHECK(hipMalloc(&tmo, 4)); CHECK(hipMalloc(&cyc, G * 8)); CHECK(hipMalloc(&dbg, 4096));
   const int nseam = 2000;
@@ -178,6 +183,20 @@ int main(int argc, char** argv) {
                  pw * 4, ms * 1000.f / nseam, herr, htmo);
         }
       }
+  CHECK(hipFuncSetAttribute((const void*)seam_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+  for (int pw : {16, 32, 128, 512})
+    for (int rep = 0; rep < 6; ++rep) {  // the same addresses again in every launch, with other values (seed = launch)
+      CHECK(hipMemset(flags, 0, 32 * 4096)); CHECK(hipMemset(err, 0, 4)); CHECK(hipMemset(tmo, 0, 4)); CHECK(hipMemset(dbg, 0, 4096));
+      hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+      CHECK(hipEventRecord(e0));
+      const int ns3 = FRESH - 1;
+      seam_kernel<3><<<G, 256, 96 * 1024>>>(flags, pay0, pay1, pw, ns3, err, tmo, cyc, dbg, 8, 1, (unsigned)(rep + 1 + 16 * pw));
+      CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+      float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+      unsigned herr, htmo; CHECK(hipMemcpy(&herr, err, 4, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(&htmo, tmo, 4, hipMemcpyDeviceToHost));
+      printf("fresh addresses + plain loads (8 flag replicas): pay/WG %5d B  gather %4d KB : %.3f us per seam   stale words %u  timeouts %u\n",
+             pw * 4, G * pw * 4 / 1024, ms * 1000.f / ns3, herr, htmo);
+    }
   for (int RP : {1, 2, 4, 8})
     for (int pw : {32, 128}) {
       for (int rep = 0; rep < 2; ++rep) {
