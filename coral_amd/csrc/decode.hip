@@ -1013,6 +1013,24 @@ __global__ __launch_bounds__(256) void whisper_decode_token_kernel(const DecArgs
   const int G = gridDim.x, w = blockIdx.x;
   const int r = lane & 15, g = lane >> 4;
   const int d = a.d, B = a.B, H = a.H, L = a.n_layers;
+  {
+    // Every clip had finished before this launch (`done` is only written at the very end of a launch, behind all seams:
+    // every workgroup reads the same values here): nothing to decode - the step's bookkeeping alone (a finished row records
+    // pad and moves on, ca_argmax_advance; `out`, the logits and the cache keep what they have).  What lets the host keep a
+    // chunk of launches queued AHEAD of its all-finished check (WhisperEngine._generate_graph) at no cost.
+    bool all = true;
+    for (int b = 0; b < B; ++b) all &= a.done[b] != 0;
+    if (all) {
+      if (w < B && threadIdx.x == 0) {
+        const int32_t pz = a.pos[w];
+        if (pz + 1 < a.ld_ids) a.ids[(int64_t)w * a.ld_ids + pz + 1] = a.pad;
+        a.tok[w] = a.pad;
+        a.pos[w] = pz + 1;
+        a.klen[w] += 1;
+      }
+      return;
+    }
+  }
   const int ntiles = (a.V + 15) >> 4;
   const int my_tiles = ntiles > w ? (ntiles - w + G - 1) / G : 0;
   const int n_entries = 6 * L + (ntiles + G - 1) / G;

@@ -606,6 +606,8 @@ int ca_embed_tokens_bwd(const void* dy, const int32_t* ids, const int32_t* pos_i
  * ca_argmax_advance.  `ws`: CA_DECODE_WS_BYTES(B, d, f, H, n_layers) bytes of workspace (16-byte aligned, any contents);
  * `status`: 4 words the CALLER zeroes once; a launch only ever raises word 0 (0 = ok, else 1 + the phase whose seam timed
  * out - sticky over a series of launches; the host reads it after synchronising: a launch that gave up has written no token).
+ * A launch that finds every clip finished (`done`) records pad for each, advances the positions and returns at once - a
+ * host may queue launches ahead of its own all-finished check.
  * Limits: B <= 16, head_dim 64, d_model a multiple of 64 up to 1536, at most 256 CUs, and every CU of the device free
  * (the workgroups must all be resident: nothing else may run beside the launch).
  * ---------------------------------------------------------------------------------- */

@@ -152,7 +152,9 @@ def test_finished_rows_take_pad_in_both_paths():
         ops.whisper_decode_token(ps["desc"])
         torch.cuda.synchronize()
         assert ps["status"].tolist() == [0, 0, 0, 0]
-        for k in ("nxt", "tok", "pos", "klen", "done", "out"):
+        # (from the second step on every clip had finished BEFORE the launch: the persistent launch then does the step's
+        # bookkeeping and nothing else - the raw argmax `nxt` of logits nobody computed is not part of it)
+        for k in ("nxt", "tok", "pos", "klen", "done", "out")[(1 if t else 0):]:
             assert torch.equal(ga[k], gb[k]), f"{k} differs at token {t}"
     assert bool(gb["done"].all())
     out = gb["out"][:, 5:9].tolist()
