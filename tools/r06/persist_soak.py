@@ -33,10 +33,19 @@ for B in batches:
             n = 16_000 * (3 + (r + b) % 27)
             w[b, :n] = (0.02 + 0.02 * torch.rand(1, generator=g).item()) * torch.randn(n, generator=g)
         feats = eng.log_mel(w)
+        sup = None
+        if os.environ.get("EOS_MODE") == "1":
+            # everything suppressed but 24 tokens and eos: clips finish at different, random steps - the finished-row
+            # bookkeeping, the host's late all-finished check and the trimming get exercised
+            allowed = set(torch.randint(0, 50000, (24,), generator=g).tolist()) | {shape.eos_token_id}
+            sup = [t for t in range(shape.vocab_size) if t not in allowed]
         os.environ["CA_DECODE_PERSISTENT"] = "0"
-        ref = eng.generate(feats, prefix, max_length)
+        ref = eng.generate(feats, prefix, max_length, suppress_tokens=sup)
         os.environ["CA_DECODE_PERSISTENT"] = "1"
-        got = eng.generate(feats, prefix, max_length)
+        got = eng.generate(feats, prefix, max_length, suppress_tokens=sup)
+        if os.environ.get("EOS_MODE") == "1" and r < 3:
+            print(f"  round {r}: lengths {sorted(len(x) for x in got)[:4]} .. {max(len(x) for x in got)}, "
+                  f"finished rows {sum(shape.eos_token_id in x for x in got)} of {B}", flush=True)
         gens += 1
         launches += max(len(x) for x in got) - len(prefix) - 1
         if got != ref:
