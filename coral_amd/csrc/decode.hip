@@ -109,6 +109,11 @@ __device__ __forceinline__ u16x8_t dk_ld16_sc1(const void* p) {
   asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
   return v;
 }
+__device__ __forceinline__ u16x8_t dk_ld16_nt(const void* p) {
+  u16x8_t v;
+  asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
 __device__ __forceinline__ bf16x8_t dk_ld16(const void* p) {
   bf16x8_t v;
   asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
@@ -135,6 +140,20 @@ __device__ __forceinline__ void dk_glds16(const void* g, uint32_t lds_wave_base)
                : "v"(g), "s"(__builtin_amdgcn_readfirstlane(lds_wave_base))
                : "memory", "m0");
 }
+// the same with the non-temporal policy: bytes ONE workgroup reads once per token (its weight columns, its K|V strip)
+__device__ __forceinline__ void dk_glds16_nt(const void* g, uint32_t lds_wave_base) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt"
+               :
+               : "v"(g), "s"(__builtin_amdgcn_readfirstlane(lds_wave_base))
+               : "memory", "m0");
+}
+// Which streams carry it (bit 0: weight ring, bit 1: V tiles, bit 2: K fragments of the cross-attention).  Measured per token
+// at 16 | 8 clips (same box, tools/r06/token_step_time.py): none 1 486 | 1 242 us, ring only 1 489 | 1 233, V tiles 1 469 | 1 223,
+// V tiles + cross K 1 464 | 1 226, all three 1 465 | 1 230: the K|V strips (98 MB per layer at 16 clips) no longer displace
+// what the L2s and the Infinity Cache hold for the phases around them; the ring's pieces gain nothing.
+#ifndef DK_NT
+#define DK_NT 6
+#endif
 __device__ __forceinline__ uint32_t dk_lds_addr(const void* p) { return (uint32_t)(uintptr_t)(dk_lptr_t)p; }
 __device__ __forceinline__ bf16x8_t dk_zero8() { return __builtin_bit_cast(bf16x8_t, (f32x4_t){0.f, 0.f, 0.f, 0.f}); }
 
@@ -329,10 +348,10 @@ __device__ __forceinline__ int dk_issue_pieces(const DkEnt& e, int slot0, int pc
     int ks = 4 * S + kq;
     if (!EXACT) ks = ks < per ? ks : per - 1;
     const unsigned short* src = e.W + (int64_t)col * e.K + 8 * (jj & 3) + ks * 32;
-    dk_glds16(src + own_k, own_lds + (uint32_t)slot * 1024u);
+    if (DK_NT & 1) dk_glds16_nt(src + own_k, own_lds + (uint32_t)slot * 1024u); else dk_glds16(src + own_k, own_lds + (uint32_t)slot * 1024u);
     ++n;
     if (third == 0) {
-      dk_glds16(src, ring0_lds + (uint32_t)slot * 1024u);
+      if (DK_NT & 1) dk_glds16_nt(src, ring0_lds + (uint32_t)slot * 1024u); else dk_glds16(src, ring0_lds + (uint32_t)slot * 1024u);
       ++n;
     }
     third = third == 2 ? 0 : third + 1;
@@ -782,7 +801,10 @@ __device__ __forceinline__ bool dk_attend(const unsigned short* Q, const unsigne
       key = key < Tk ? key : Tk - 1;
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks)  // (sc1 in both attention phases: one code path; the self-attention needs it)
-        kf[S][blk][ks] = __builtin_bit_cast(bf16x8_t, dk_ld16_sc1(K + (int64_t)key * ldkv + 32 * ks + 8 * g));
+        if ((DK_NT & 4) && fresh_row < 0)
+          kf[S][blk][ks] = __builtin_bit_cast(bf16x8_t, dk_ld16_nt(K + (int64_t)key * ldkv + 32 * ks + 8 * g));
+        else
+          kf[S][blk][ks] = __builtin_bit_cast(bf16x8_t, dk_ld16_sc1(K + (int64_t)key * ldkv + 32 * ks + 8 * g));
     }
     const uint32_t img = dk_lds_addr(Vring + S * IMG);
 #pragma unroll
@@ -791,7 +813,7 @@ __device__ __forceinline__ bool dk_attend(const unsigned short* Q, const unsigne
       const int c = (lane % 8) ^ dk_mnswz8(kr);
       const int row = kt * 64 + kr;
       const void* src = row < Tk ? (const void*)(V + (int64_t)row * ldkv + c * 8) : (const void*)g_dec_zero_page;
-      dk_glds16(src, img + i * 1024);
+      if (DK_NT & 2) dk_glds16_nt(src, img + i * 1024); else dk_glds16(src, img + i * 1024);
     }
   };
   auto step = [&](auto slot_c, int j) {
